@@ -1,0 +1,132 @@
+"""Pins the CPU oracle (oracle/) against fixtures produced by the REAL reference (tools/gen_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ccd_amd.synthetic import make_batch
+from oracle import ccd_oracle as O
+from oracle import ccl_np
+
+pytestmark = pytest.mark.filterwarnings("ignore")
+
+
+def _stat(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().sum().item(), t.pow(2).sum().sqrt().item()])
+
+
+def _check_stats(names, stats, table, rtol, atol=1e-7, what=""):
+    for n, row in zip(names, stats):
+        got = _stat(table[str(n)])
+        # [sum, abs-sum, l2]: the plain sum may cancel to ~0, so its error is judged against the abs-sum
+        np.testing.assert_allclose(got[1:], row[1:], rtol=rtol, atol=atol, err_msg=f"{what}:{n}")
+        assert abs(got[0] - row[0]) <= rtol * row[1] + atol, f"{what}:{n} sum {got[0]} vs {row[0]}"
+
+
+def test_schedules(golden_dir):
+    g = np.load(os.path.join(golden_dir, "sched.npz"))
+    np.testing.assert_array_equal(O.cosine_iter_schedule(0.0005 * 8 / 256.0, 1e-6, 50, warmup_iters=10), g["lr"])
+    np.testing.assert_array_equal(O.cosine_iter_schedule(0.04, 0.4, 50), g["wd"])
+    np.testing.assert_array_equal(O.cosine_iter_schedule(0.9995, 1, 50), g["mom"])
+    np.testing.assert_array_equal(O.cosine_iter_schedule(1e-3, 1e-5, 17), g["lr_nowarm"])
+    np.testing.assert_array_equal(O.teacher_temp_schedule(0.04, 0.04, 0, 40), g["teacher_temp_0_40"])
+    np.testing.assert_array_equal(O.teacher_temp_schedule(0.02, 0.07, 5, 12), g["teacher_temp_5_12"])
+
+
+def test_ccl_cases(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ccl_cases.npz"))
+    for name, mask, want, tie in zip(g["names"], g["masks"], g["idmaps"], g["has_tie"]):
+        got = ccl_np.label_idmap(mask)
+        if not tie:
+            np.testing.assert_array_equal(got, want, err_msg=str(name))
+        else:  # order inside a mean-column tie is unspecified in the reference (unstable argsort)
+            assert (got == 255).sum() == (want == 255).sum()
+            pairs = set(zip(got[got != 255].tolist(), want[want != 255].tolist()))
+            assert len(pairs) == len(set(p[0] for p in pairs)), f"{name}: not a relabelling"
+
+
+def test_state_keys_and_init(golden_dir):
+    keys = json.load(open(os.path.join(golden_dir, "state_keys.json")))
+    for arch, cfg in O.ARCH.items():
+        spec = O.Spec(out_dim=1024, seg_in=cfg["embed_dim"], norm_last_layer=False, **cfg)
+        s, t = O.build_pair(spec, seed=0)
+        assert [[k, list(v.shape), str(v.dtype)] for k, v in s.P.items()] == keys[arch]["student"]
+        assert [[k, list(v.shape), str(v.dtype)] for k, v in t.P.items()] == keys[arch]["teacher"]
+        assert s.trainable == keys[arch]["student_trainable"]
+
+
+def _tiny_spec():
+    return O.Spec(embed_dim=192, depth=3, heads=3, taps=(1, 2, 3), out_dim=512, head_hidden=256,
+                  head_bottleneck=64, norm_last_layer=False, seg_in=192)
+
+
+def test_tiny_step(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiny_step.npz"))
+    student, teacher = O.build_pair(_tiny_spec(), seed=3)
+    _check_stats(g["init_names"], g["init_stats"], student.P, rtol=0, atol=0, what="init")
+    batch = make_batch(2, seed=11)
+    np.testing.assert_array_equal(batch[1].numpy().astype(np.uint8), g["masks"])
+    np.testing.assert_array_equal(batch[2].numpy(), g["metrics"])
+    epoch, lr, wd, mom, clip, freeze = g["hyper"]
+    rec = O.train_iteration(student, teacher, torch.zeros(1, 512), O.AdamWState(), batch, int(epoch), lr, wd, mom,
+                            clip=clip, freeze_last_layer=int(freeze))
+    s, t = rec["s_out"], rec["t_out"]
+    np.testing.assert_array_equal(s["idmap"], g["zero_idmap"])
+    np.testing.assert_array_equal(s["index"].numpy(), g["new_index"])
+    np.testing.assert_array_equal(rec["masks_image"].numpy().astype(np.uint8), g["masks_image"])
+    np.testing.assert_allclose(s["mask"].detach().numpy(), g["seg_logits"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(s["instances_view"].detach().numpy(), g["student_logits"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(t["instances_view"].detach().numpy(), g["teacher_logits"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(t["feature"].detach().numpy()[:, ::4], g["teacher_feature"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose([rec["loss"], rec["mask_loss"], rec["dino_loss"]], g["losses"], rtol=1e-6)
+    np.testing.assert_allclose(rec["center"].numpy(), g["center_after"], rtol=1e-5, atol=1e-8)
+    assert sorted(rec["grads_raw"]) == sorted(map(str, g["grad_names"]))
+    _check_stats(g["grad_names"], g["grad_stats"], rec["grads_raw"], rtol=2e-4, atol=1e-9, what="grad")
+    for k in g.files:
+        if k.startswith("grad/"):
+            np.testing.assert_allclose(rec["grads_raw"][k[5:]].numpy(), g[k], rtol=1e-3, atol=1e-7, err_msg=k)
+    _check_stats(g["post_names"], g["post_stats"], student.P, rtol=1e-4, atol=1e-7, what="post")
+    _check_stats(g["teacher_post_names"], g["teacher_post_stats"], teacher.P, rtol=1e-4, atol=1e-7, what="ema")
+
+
+def test_small_step(golden_dir):
+    """CCD_pretrain_ViT_small hyper-parameters, B=8, two iterations (BASELINE config #1)."""
+    g = np.load(os.path.join(golden_dir, "small_step.npz"))
+    spec = O.Spec(norm_last_layer=False, **O.ARCH["vit_small"])
+    student, teacher = O.build_pair(spec, seed=0)
+    _check_stats(g["init_names"], g["init_stats"], student.P, rtol=0, atol=0, what="init")
+    center, opt = torch.zeros(1, spec.out_dim), O.AdamWState()
+    for step in range(2):
+        p = f"s{step}/"
+        epoch, lr, wd, mom, clip, freeze, seed = g[p + "hyper"]
+        batch = make_batch(8, seed=int(seed))
+        np.testing.assert_array_equal(batch[1].numpy().astype(np.uint8), g[p + "masks"])
+        np.testing.assert_allclose(_stat(batch[0]), g[p + "image_stat"], rtol=1e-12)
+        rec = O.train_iteration(student, teacher, center, opt, batch, int(epoch), lr, wd, mom, clip=clip,
+                                freeze_last_layer=int(freeze))
+        center = rec["center"]
+        s, t = rec["s_out"], rec["t_out"]
+        np.testing.assert_array_equal(s["idmap"], g[p + "zero_idmap"])
+        np.testing.assert_array_equal(s["index"].numpy(), g[p + "new_index"])
+        np.testing.assert_array_equal(rec["masks_image"].numpy().astype(np.uint8), g[p + "masks_image"])
+        np.testing.assert_allclose([rec["loss"], rec["mask_loss"], rec["dino_loss"]], g[p + "losses"], rtol=2e-6)
+        r, c = g[p + "rows"], g[p + "cols"]
+        np.testing.assert_allclose(s["instances_view"].detach()[r][:, c].numpy(), g[p + "student_logits_sample"],
+                                   rtol=1e-3, atol=2e-6)
+        np.testing.assert_allclose(t["instances_view"].detach()[r][:, c].numpy(), g[p + "teacher_logits_sample"],
+                                   rtol=1e-3, atol=2e-6)
+        np.testing.assert_allclose(center[0, c].numpy(), g[p + "center_sample"], rtol=1e-4, atol=1e-8)
+        _check_stats(g[p + "grad_names"], g[p + "grad_stats"], rec["grads_raw"], rtol=1e-3, atol=2e-7, what="grad")
+        _check_stats(g[p + "grad_names"], g[p + "grad_clipped_stats"], rec["grads_clipped"], rtol=1e-3, atol=2e-7,
+                     what="clipped")
+        _check_stats(g[p + "post_names"], g[p + "post_stats"], student.P, rtol=1e-4, atol=1e-6, what="post")
+        _check_stats(g[p + "teacher_post_names"], g[p + "teacher_post_stats"], teacher.P, rtol=1e-5, atol=1e-6,
+                     what="ema")
+    # predicted-mask branch: CCL + warp + row selection on the reference's own thresholded prediction
+    ids = O.label_batch(g["pred/mask"])
+    src = torch.from_numpy(ccl_np.idmap_to_planes(ids))
+    clusters = torch.cat([src, O.warp_planes(src, torch.from_numpy(g["pred/metrics"]))])
+    np.testing.assert_array_equal(ccl_np.planes_to_idmap(clusters.numpy()), g["pred/zero_idmap"])

@@ -1,0 +1,372 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (/root/reference, read-only) on CPU.
+
+Runs only in the build container (the reference never travels to the GPU box).  The reference is imported
+with the stub third-party modules of tools/oracle_stubs/ and its pretraining iteration (train.py:221-272)
+is re-enacted by this harness; nothing from the reference is copied - only its numerical outputs for our
+seeded synthetic inputs (ccd_amd/synthetic.py) are recorded.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [--only ccl|tiny|small|sched]
+
+Fixtures (all small):
+  sched.npz        cosine_iter_scheduler / teacher-temp schedule arrays           (modules/utils.py:200-210)
+  ccl_cases.npz    adversarial masks -> label_cluster outputs as uint8 id maps     (utils/DBSCAN.py:61-103)
+  tiny_step.npz    3-block E=192 model, B=2: full tensors of every stage + grads
+  small_step.npz   CCD_pretrain_ViT_small hyper-parameters, B=8, 2 iterations: losses, index maps,
+                   sampled logits, per-parameter grad norms / post-step checksums
+"""
+import argparse
+import os
+import sys
+from functools import partial
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(HERE, "oracle_stubs"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, REPO)
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ccd_amd.synthetic import make_batch  # our generator, not reference code
+
+GOLD = os.path.join(REPO, "tests", "golden")
+
+
+def planes_to_idmap(planes):
+    """[..., 26, H, W] 0/1 planes (disjoint) -> uint8 id map, 255 = background."""
+    planes = np.asarray(planes)
+    assert planes.shape[-3] == 26
+    cnt = (planes > 0).sum(axis=-3)
+    assert cnt.max() <= 1, "planes overlap: id-map encoding would be lossy"
+    ids = np.argmax(planes > 0, axis=-3).astype(np.uint8)
+    ids[cnt == 0] = 255
+    return ids
+
+
+def stat(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().sum().item(), t.pow(2).sum().sqrt().item()])
+
+
+def state_stats(named):
+    names, rows = [], []
+    for n, t in named:
+        names.append(n)
+        rows.append(stat(t))
+    return np.array(names), np.stack(rows)
+
+
+def ensure_pg():
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+
+
+# --------------------------------------------------------------------------------------------------
+def gen_sched():
+    from Dino.modules import utils as rutils
+    from Dino.loss.Dino_loss import DINOLoss
+    out = {}
+    out["lr"] = rutils.cosine_iter_scheduler(0.0005 * 8 / 256.0, 1e-6, 50, warmup_iters=10)
+    out["wd"] = rutils.cosine_iter_scheduler(0.04, 0.4, 50)
+    out["mom"] = rutils.cosine_iter_scheduler(0.9995, 1, 50)
+    out["lr_nowarm"] = rutils.cosine_iter_scheduler(1e-3, 1e-5, 17)
+    out["teacher_temp_0_40"] = DINOLoss(16, 2, 0.04, 0.04, 0, 40).teacher_temp_schedule
+    out["teacher_temp_5_12"] = DINOLoss(16, 2, 0.02, 0.07, 5, 12).teacher_temp_schedule
+    np.savez_compressed(os.path.join(GOLD, "sched.npz"), **out)
+    print("sched.npz written")
+
+
+# --------------------------------------------------------------------------------------------------
+def ccl_cases():
+    H, W = 32, 128
+    rs = np.random.RandomState(7)
+    cases = {}
+    cases["empty"] = np.zeros((H, W), np.float32)
+    m = np.zeros((H, W), np.float32); m[:] = 1
+    cases["full"] = m
+    # areas 29 / 30 / 31 side by side
+    m = np.zeros((H, W), np.float32)
+    m[2:7, 2:8] = 1; m[6, 7] = 0            # 30-1 = 29
+    m[2:7, 20:26] = 1                        # 30
+    m[2:7, 40:46] = 1; m[7, 40] = 1          # 31
+    cases["area_29_30_31"] = m
+    # diagonal touching squares merge under 8-connectivity
+    m = np.zeros((H, W), np.float32)
+    m[4:10, 10:16] = 1; m[10:16, 16:22] = 1
+    m[4:10, 60:66] = 1; m[11:17, 66:72] = 1  # gap of one row: stays separate
+    cases["diagonal"] = m
+    # 40 one-pixel stripes, 32 tall -> more than 26 qualifying components
+    m = np.zeros((H, W), np.float32)
+    for k in range(40):
+        m[:, 3 * k] = 1
+    cases["stripes40"] = m
+    # stripes whose raster-first-pixel order differs from left-to-right order (cap keeps first 26 labels)
+    m = np.zeros((H, W), np.float32)
+    for k in range(32):
+        top = (k * 7) % 2
+        m[top:32, 4 * k] = 1
+    cases["stripes32_stagger"] = m
+    # thin stroke invisible to the centre-2x2 down-sample, plus a normal char
+    m = np.zeros((H, W), np.float32)
+    m[0:32, 4] = 1      # column 4: x%4==0 -> never in centre columns (1,2)
+    m[8:24, 40:50] = 1
+    cases["thin_stroke"] = m
+    # U shape / nested ring
+    m = np.zeros((H, W), np.float32)
+    m[4:28, 10:40] = 1; m[8:24, 14:36] = 0; m[12:20, 20:30] = 1
+    cases["ring_nested"] = m
+    # spiral-ish snake to stress label propagation
+    m = np.zeros((H, W), np.float32)
+    for r in range(0, 32, 4):
+        m[r, 2:126] = 1
+        if (r // 4) % 2 == 0:
+            m[r:r + 4, 125] = 1
+        else:
+            m[r:r + 4, 2] = 1
+    cases["snake"] = m
+    # random blobs at several densities
+    for i, p in enumerate([0.3, 0.45, 0.55, 0.7]):
+        cases[f"random_p{int(p * 100)}"] = (rs.uniform(size=(H, W)) < p).astype(np.float32)
+    # checkerboard: all diagonal-connected -> one component
+    yy, xx = np.mgrid[0:H, 0:W]
+    cases["checker"] = ((yy + xx) % 2 == 0).astype(np.float32)
+    # blocky random (characters-like)
+    m = np.zeros((H, W), np.float32)
+    for _ in range(30):
+        y0, x0 = rs.randint(0, 26), rs.randint(0, 120)
+        m[y0:y0 + rs.randint(3, 9), x0:x0 + rs.randint(3, 9)] = 1
+    cases["blocks30"] = m
+    return cases
+
+
+def gen_ccl():
+    from Dino.utils.DBSCAN import label_cluster
+    lab = label_cluster()
+    cases = ccl_cases()
+    # mean-x ties make the reference's argsort order host dependent: record a flag
+    names, masks, idmaps, has_tie = [], [], [], []
+    from scipy import ndimage
+    for name, m in cases.items():
+        planes = lab(m)
+        names.append(name); masks.append(m.astype(np.uint8)); idmaps.append(planes_to_idmap(planes))
+        cl = ndimage.label(m != 0, structure=np.ones((3, 3)))[0]
+        locs = []
+        for c in range(1, cl.max() + 1):
+            sub = cl == c
+            if sub.sum() >= 30:
+                locs.append(np.where(sub)[1].mean())
+                if len(locs) >= 26:
+                    break
+        has_tie.append(len(set(locs)) != len(locs))
+    np.savez_compressed(os.path.join(GOLD, "ccl_cases.npz"), names=np.array(names), masks=np.stack(masks),
+                        idmaps=np.stack(idmaps), has_tie=np.array(has_tie))
+    print("ccl_cases.npz written:", dict(zip(names, has_tie)))
+
+
+# --------------------------------------------------------------------------------------------------
+def build_reference_pair(arch_kwargs, head_kwargs, seg_channel, seed, drop_path_rate, tiny):
+    """Mirrors the construction ORDER of train.py:63-114 (student vit, teacher vit, SegHead, DINOHeads)."""
+    from Dino.modules import vision_transformer as vits
+    from Dino.modules.segmentor import SegHead
+    from Dino.model.dino_vision import ABIDINOModel
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    if tiny:
+        mk = lambda **kw: vits.VisionTransformer(img_size=[32, 128], qkv_bias=True,
+                                                 norm_layer=partial(nn.LayerNorm, eps=1e-6), **arch_kwargs, **kw)
+    else:
+        mk = lambda **kw: vits.__dict__[arch_kwargs["arch"]](patch_size=4, **kw)
+    student_b = mk(drop_path_rate=drop_path_rate)
+    teacher_b = mk()
+    embed_dim = student_b.embed_dim
+    student = ABIDINOModel(student_b, SegHead(in_channels=seg_channel, mla_channels=128, mlahead_channels=64,
+                                              num_classes=2),
+                           vits.DINOHead(embed_dim, norm_last_layer=False, **head_kwargs))
+    teacher = ABIDINOModel(teacher_b, None, vits.DINOHead(embed_dim, **head_kwargs))
+    teacher.backbone.load_state_dict(student.backbone.state_dict())
+    teacher.head.load_state_dict(student.head.state_dict())
+    for p in teacher.parameters():
+        p.requires_grad = False
+    return student, teacher
+
+
+def reference_iteration(student, teacher, dino_loss, optimizer, batch, epoch, lr, wd, mom, clip, freeze_last_layer,
+                        record):
+    """train.py:221-272 re-enacted on CPU tensors."""
+    from Dino.modules import utils as rutils
+    images, masks, metrics = batch
+    for i, g in enumerate(optimizer.param_groups):
+        g["lr"] = lr
+        if i == 0:
+            g["weight_decay"] = wd
+    s_out = student(images, metrics, masks, epoch, clusters=None)
+    t_out = teacher(images, metrics, None, None, clusters=s_out["zero"], index=s_out["index"])
+    grid = F.affine_grid(metrics[:, :2, :], size=(masks.shape[0], 1, masks.shape[1], masks.shape[2]))
+    masks_image = (F.grid_sample(masks.unsqueeze(1), grid) > 0.1).float().squeeze()
+    s_out["gt"] = [masks, masks_image]
+    center_before = dino_loss.center.clone()
+    loss = dino_loss(s_out, t_out, epoch)
+    optimizer.zero_grad()
+    loss.backward()
+    record["loss"] = loss.item()
+    record["mask_loss"] = dino_loss.last_losses["mask_loss"].item()
+    record["dino_loss"] = dino_loss.last_losses["Dino_loss"].item()
+    record["s_out"], record["t_out"] = s_out, t_out
+    record["masks_image"] = masks_image
+    record["center_before"] = center_before
+    record["grads_raw"] = {n: p.grad.detach().clone() for n, p in student.named_parameters() if p.grad is not None}
+    rutils.clip_gradients(student, clip)
+    record["grads_clipped"] = {n: p.grad.detach().clone() for n, p in student.named_parameters()
+                               if p.grad is not None}
+    rutils.cancel_gradients_last_layer(epoch, student, freeze_last_layer)
+    optimizer.step()
+    with torch.no_grad():
+        for pq, pk in zip(student.backbone.parameters(), teacher.backbone.parameters()):
+            pk.data.mul_(mom).add_((1 - mom) * pq.detach().data)
+        for pq, pk in zip(student.head.parameters(), teacher.head.parameters()):
+            pk.data.mul_(mom).add_((1 - mom) * pq.detach().data)
+    return record
+
+
+def gen_tiny():
+    ensure_pg()
+    from Dino.modules import utils as rutils
+    from Dino.loss.Dino_loss import DINOLoss
+    B, K = 2, 512
+    arch = dict(patch_size=4, embed_dim=192, depth=3, num_heads=3, out_indices=[1, 2, 3])
+    head = dict(out_dim=K, hidden_dim=256, bottleneck_dim=64)
+    student, teacher = build_reference_pair(arch, head, 192, seed=3, drop_path_rate=0.0, tiny=True)
+    out = {}
+    out["init_names"], out["init_stats"] = state_stats(student.state_dict().items())
+    dino_loss = DINOLoss(K, 2, 0.04, 0.04, 0, 40)
+    optimizer = torch.optim.AdamW(rutils.get_params_groups(student))
+    batch = make_batch(B, seed=11)
+    rec = reference_iteration(student, teacher, dino_loss, optimizer, batch, epoch=1, lr=2e-4, wd=0.05, mom=0.99,
+                              clip=3.0, freeze_last_layer=1, record={})
+    # stage tensors (full, the model is small)
+    images, masks, metrics = batch
+    s_out, t_out = rec["s_out"], rec["t_out"]
+    out["masks"] = masks.numpy().astype(np.uint8)
+    out["metrics"] = metrics.numpy()
+    out["zero_idmap"] = planes_to_idmap(s_out["zero"].numpy())
+    out["new_index"] = s_out["index"].numpy()
+    out["masks_image"] = rec["masks_image"].numpy().astype(np.uint8)
+    out["seg_logits"] = s_out["mask"].detach().numpy()
+    out["student_logits"] = s_out["instances_view"].detach().numpy()
+    out["teacher_logits"] = t_out["instances_view"].detach().numpy()
+    out["teacher_feature"] = t_out["feature"].detach().numpy()[:, ::4]  # every 4th channel, [2B,48,8,32]
+    out["losses"] = np.array([rec["loss"], rec["mask_loss"], rec["dino_loss"]])
+    out["center_after"] = dino_loss.center.numpy()
+    gn, gs = state_stats(rec["grads_raw"].items())
+    out["grad_names"], out["grad_stats"] = gn, gs
+    # a few full gradients for layout checks
+    for key in ["backbone.pos_embed", "backbone.patch_embed.proj.weight", "backbone.blocks.1.attn.qkv.weight",
+                "backbone.blocks.2.mlp.fc2.bias", "backbone.norm_seg.1.weight", "segmentation.cls.weight",
+                "segmentation.mlahead.head3.3.weight", "segmentation.unpool1.1.weight", "head.mlp.4.weight",
+                "head.last_layer.weight_g"]:
+        out["grad/" + key] = rec["grads_raw"][key].numpy()
+    out["post_names"], out["post_stats"] = state_stats(student.state_dict().items())
+    out["teacher_post_names"], out["teacher_post_stats"] = state_stats(teacher.state_dict().items())
+    out["hyper"] = np.array([1, 2e-4, 0.05, 0.99, 3.0, 1])  # epoch lr wd mom clip freeze
+    np.savez_compressed(os.path.join(GOLD, "tiny_step.npz"), **out)
+    print("tiny_step.npz written; losses", out["losses"], "M", int(out["new_index"].sum()))
+
+
+def gen_small():
+    ensure_pg()
+    from Dino.modules import utils as rutils
+    from Dino.loss.Dino_loss import DINOLoss
+    B, K = 8, 65536
+    student, teacher = build_reference_pair(dict(arch="vit_small"), dict(out_dim=K), 384, seed=0,
+                                            drop_path_rate=0.0, tiny=False)
+    out = {}
+    out["init_names"], out["init_stats"] = state_stats(student.state_dict().items())
+    dino_loss = DINOLoss(K, 2, 0.04, 0.04, 0, 40)
+    optimizer = torch.optim.AdamW(rutils.get_params_groups(student))
+    lr_s = rutils.cosine_iter_scheduler(0.0005 * B / 256.0, 1e-6, 50, warmup_iters=10)
+    wd_s = rutils.cosine_iter_scheduler(0.04, 0.4, 50)
+    mom_s = rutils.cosine_iter_scheduler(0.9995, 1, 50)
+    rows = np.array([0, 5, 17, 40, 47, 63, 80, 95])
+    cols = np.arange(0, K, 1024)
+    for step, (it, epoch, seed) in enumerate([(5, 0, 0), (6, 1, 1)]):
+        batch = make_batch(B, seed=seed)
+        rec = reference_iteration(student, teacher, dino_loss, optimizer, batch, epoch=epoch, lr=lr_s[it],
+                                  wd=wd_s[it], mom=mom_s[it], clip=3.0, freeze_last_layer=1, record={})
+        p = f"s{step}/"
+        s_out, t_out = rec["s_out"], rec["t_out"]
+        out[p + "hyper"] = np.array([epoch, lr_s[it], wd_s[it], mom_s[it], 3.0, 1, seed])
+        out[p + "masks"] = batch[1].numpy().astype(np.uint8)
+        out[p + "metrics"] = batch[2].numpy()
+        out[p + "image_stat"] = stat(batch[0])
+        out[p + "zero_idmap"] = planes_to_idmap(s_out["zero"].numpy())
+        out[p + "new_index"] = s_out["index"].numpy()
+        out[p + "masks_image"] = rec["masks_image"].numpy().astype(np.uint8)
+        out[p + "losses"] = np.array([rec["loss"], rec["mask_loss"], rec["dino_loss"]])
+        sl, tl = s_out["instances_view"].detach(), t_out["instances_view"].detach()
+        r = rows[rows < sl.shape[0]]
+        out[p + "rows"], out[p + "cols"] = r, cols
+        out[p + "student_logits_sample"] = sl[r][:, cols].numpy()
+        out[p + "teacher_logits_sample"] = tl[r][:, cols].numpy()
+        out[p + "student_logits_stat"] = stat(sl)
+        out[p + "teacher_logits_stat"] = stat(tl)
+        out[p + "seg_logits_stat"] = stat(s_out["mask"])
+        out[p + "seg_logits_sample"] = s_out["mask"].detach()[:, :, ::8, ::16].numpy()
+        out[p + "teacher_feature_stat"] = stat(t_out["feature"])
+        out[p + "center_stat"] = stat(dino_loss.center)
+        out[p + "center_sample"] = dino_loss.center[0, cols].numpy()
+        out[p + "grad_names"], out[p + "grad_stats"] = state_stats(rec["grads_raw"].items())
+        _, out[p + "grad_clipped_stats"] = state_stats(rec["grads_clipped"].items())
+        out[p + "post_names"], out[p + "post_stats"] = state_stats(student.state_dict().items())
+        out[p + "teacher_post_names"], out[p + "teacher_post_stats"] = state_stats(teacher.state_dict().items())
+        print(f"step {step}: losses {out[p + 'losses']}  M={int(s_out['index'].sum())}")
+    # predicted-mask branch (epoch >= 30, dino_vision.py:64-70): record the thresholded prediction + its maps
+    batch = make_batch(B, seed=2)
+    with torch.no_grad():
+        s_out = student(batch[0], batch[2], batch[1], 30, clusters=None)
+        pred = (F.softmax(s_out["mask"], dim=1)[:, 1] > 0.5).int()[:B]
+    out["pred/mask"] = pred.numpy().astype(np.uint8)
+    out["pred/metrics"] = batch[2].numpy()
+    out["pred/zero_idmap"] = planes_to_idmap(s_out["zero"].numpy())
+    out["pred/new_index"] = s_out["index"].numpy()
+    np.savez_compressed(os.path.join(GOLD, "small_step.npz"), **out)
+    print("small_step.npz written")
+
+
+def gen_keys():
+    """State-dict key names + shapes of student/teacher for the three shipped archs."""
+    import json
+    table = {}
+    for arch in ["vit_tiny", "vit_small", "vit_base"]:
+        from Dino.modules import vision_transformer as vits
+        e = {"vit_tiny": 192, "vit_small": 384, "vit_base": 512}[arch]
+        student, teacher = build_reference_pair(dict(arch=arch), dict(out_dim=1024), e, seed=0, drop_path_rate=0.1,
+                                                tiny=False)
+        table[arch] = {
+            "student": [[k, list(v.shape), str(v.dtype)] for k, v in student.state_dict().items()],
+            "teacher": [[k, list(v.shape), str(v.dtype)] for k, v in teacher.state_dict().items()],
+            "student_trainable": [n for n, p in student.named_parameters() if p.requires_grad],
+        }
+    with open(os.path.join(GOLD, "state_keys.json"), "w") as f:
+        json.dump(table, f)
+    print("state_keys.json written", {k: len(v["student"]) for k, v in table.items()})
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    os.chdir("/root/reference")  # Config() and friends use relative paths; we never write here
+    torch.set_num_threads(8)
+    todo = [a.only] if a.only else ["sched", "ccl", "tiny", "small", "keys"]
+    for t in todo:
+        {"sched": gen_sched, "ccl": gen_ccl, "tiny": gen_tiny, "small": gen_small, "keys": gen_keys}[t]()
