@@ -1,0 +1,71 @@
+"""ctypes binding of libccd_hip.so (the C ABI of include/ccd_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
+The library is built in-tree by `__graft_entry__.build()` / `ccd_amd/csrc/build.sh` as ccd_amd/libccd_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libccd_hip.so")
+
+_handle = None            # ctypes.CDLL once loaded
+_stream_override = None   # tests of the ABI may pin the stream argument
+
+P = C.c_void_p
+I = C.c_int
+L = C.c_long
+F = C.c_float
+
+# name -> argtypes (restype is always int unless listed in _RESTYPES); mirrors include/ccd_hip.h
+SIGNATURES = {
+    "ccd_abi_version": [],
+    "ccd_build_info": [],
+    "ccd_gemm_nt": [P, L, P, L, I, I, I, I, P, L, P, L, P, P, L, P, I, P, L, F, I, P],
+    "ccd_gemm_tn": [P, L, P, L, I, I, I, I, P, L, F, I, P],
+    "ccd_ln_fwd": [P, P, P, P, P, P, I, I, F, P],
+    "ccd_ln_bwd": [P, P, P, P, P, P, I, P, P, I, I, P],
+    "ccd_attention_fwd": [P, P, P, I, I, F, P],
+    "ccd_attention_bwd": [P, P, P, P, P, P, I, I, F, P],
+}
+_RESTYPES = {"ccd_build_info": C.c_char_p}
+
+
+def bind(lib: C.CDLL) -> C.CDLL:
+    """Attach argtypes/restypes; raises AttributeError if the library lacks a declared symbol."""
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, I)
+    return lib
+
+
+def get() -> C.CDLL:
+    global _handle
+    if _handle is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                f"ccd_amd: HIP library not found at {LIB_PATH}. Build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). ccd_amd has no CPU fallback.")
+        _handle = bind(C.CDLL(LIB_PATH))
+    return _handle
+
+
+def stream() -> int:
+    if _stream_override is not None:
+        return _stream_override
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(code: int, what: str):
+    if code != 0:
+        kind = {-1: "invalid argument", -2: "unsupported shape"}.get(code, f"hipError {code}")
+        raise RuntimeError(f"ccd_amd: {what} failed: {kind}")
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()

@@ -1,0 +1,221 @@
+// attention_bwd.h - backward of the T=256, d=64 attention of attention_fwd.h, as two kernels per layer:
+//   attention_bwd_dq_kernel   one WG (8 waves x 32 queries) per (view, head): D = rowsum(dO*O), dQ
+//   attention_bwd_dkv_kernel  one WG (8 waves x 32 keys)    per (view, head): dK, dV
+// P is recomputed from the saved LSE (never stored).  Both kernels use the transposed-product trick of the
+// forward: the probability / dS tile that comes out of one MFMA is directly the B operand of the next one,
+// and the LDS-resident A operands (K^T, Q^T, dO^T images) carry the matching key/query permutation.
+//   dP = dO V^T ; dS = P * (dP - D) * scale ; dQ = dS K ; dK = dS^T Q ; dV = P^T dO
+#pragma once
+
+namespace ccd {
+
+constexpr int ATTB_THREADS = 512;
+constexpr int ATTB_IMG = ATT_T * ATT_D * 2;                    // 32 KiB per operand image
+constexpr int ATTB_DQ_SMEM = 3 * ATTB_IMG;                     // K, V, K^T
+constexpr int ATTB_DKV_SMEM = 4 * ATTB_IMG + 2 * ATT_T * 4;    // Q, dO, Q^T, dO^T, lse, D
+
+__device__ __forceinline__ void attb_stage_rows(const bf16_t* __restrict__ src, long row_stride, char* img) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = t + ATTB_THREADS * i, row = id >> 3, slot = id & 7;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + (long)row * row_stride + slot * 8);
+        *reinterpret_cast<u32x4*>(img + row * 128 + ((slot ^ ((row >> 1) & 7)) * 16)) = v;
+    }
+}
+__device__ __forceinline__ void attb_stage_transposed(const bf16_t* __restrict__ src, long row_stride, char* img) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int kb = 16 * (w & 3) + (lane & 15);
+    const int db = (lane >> 4) + 4 * (w >> 2);
+    u32x4 r[4];
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq)
+        r[kq] = *reinterpret_cast<const u32x4*>(src + (long)(4 * kb + kq) * row_stride + db * 8);
+    const int chunk = 4 * (kb >> 2) + att_chunk_pos(kb & 3);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int d = 8 * db + j;
+        const unsigned w0 = r[0][j >> 1], w1 = r[1][j >> 1], w2 = r[2][j >> 1], w3 = r[3][j >> 1];
+        unsigned e0, e1, e2, e3;
+        if (j & 1) { e0 = w0 >> 16; e1 = w1 >> 16; e2 = w2 >> 16; e3 = w3 >> 16; }
+        else { e0 = w0 & 0xffffu; e1 = w1 & 0xffffu; e2 = w2 & 0xffffu; e3 = w3 & 0xffffu; }
+        u32x2 o;
+        o.x = e0 | (e1 << 16);
+        o.y = e2 | (e3 << 16);
+        const int slot = (chunk >> 1) ^ (d & 15);
+        *reinterpret_cast<u32x2*>(img + d * 512 + slot * 16 + (chunk & 1) * 8) = o;
+    }
+}
+__device__ __forceinline__ bf16x8 attb_row_frag(const char* img, int row, int kk, int hf) {
+    return *reinterpret_cast<const bf16x8*>(img + row * 128 + (((2 * kk + hf) ^ ((row >> 1) & 7)) * 16));
+}
+__device__ __forceinline__ bf16x8 attb_tr_frag(const char* img, int d, int ks, int hf) {
+    return *reinterpret_cast<const bf16x8*>(img + d * 512 + (((2 * ks + hf) ^ (d & 15)) * 16));
+}
+__device__ __forceinline__ void attb_store_t(bf16_t* row_ptr, const f32x16 (&acc)[2], int hf) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x2 pk;
+            pk.x = pack_bf2(acc[dt][4 * g + 0], acc[dt][4 * g + 1]);
+            pk.y = pack_bf2(acc[dt][4 * g + 2], acc[dt][4 * g + 3]);
+            *reinterpret_cast<u32x2*>(row_ptr + 32 * dt + 8 * g + 4 * hf) = pk;
+        }
+}
+
+__global__ __launch_bounds__(512) void attention_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
+                                                               const bf16_t* __restrict__ o,
+                                                               const bf16_t* __restrict__ d_o,
+                                                               const float* __restrict__ lse,
+                                                               float* __restrict__ delta, bf16_t* __restrict__ dqkv,
+                                                               int heads, float scale) {
+    char* smem = dynamic_smem();
+    char* k_img = smem;
+    char* v_img = smem + ATTB_IMG;
+    char* kt_img = smem + 2 * ATTB_IMG;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hf = lane >> 5, lq = lane & 31;
+    const int view = blockIdx.x / heads, head = blockIdx.x % heads;
+    const int E = heads * ATT_D;
+    const long rs3 = 3L * E;
+    const bf16_t* q_base = qkv + (long)view * ATT_T * rs3 + head * ATT_D;
+    attb_stage_rows(q_base + E, rs3, k_img);
+    attb_stage_rows(q_base + 2 * E, rs3, v_img);
+    attb_stage_transposed(q_base + E, rs3, kt_img);
+
+    const int q = 32 * w + lq;
+    const long orow = ((long)view * ATT_T + q) * E + head * ATT_D;
+    bf16x8 qf[4], dof[4];
+    float dsum = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        qf[kk] = *reinterpret_cast<const bf16x8*>(q_base + (long)q * rs3 + 16 * kk + 8 * hf);
+        const u32x4 dw = *reinterpret_cast<const u32x4*>(d_o + orow + 16 * kk + 8 * hf);
+        const u32x4 ow = *reinterpret_cast<const u32x4*>(o + orow + 16 * kk + 8 * hf);
+        dof[kk] = __builtin_bit_cast(bf16x8, dw);
+        float a[8], b[8];
+        unpack8(dw, a);
+        unpack8(ow, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsum += a[e] * b[e];
+    }
+    dsum += shfl_xor(dsum, 32);
+    const long stat = ((long)view * heads + head) * ATT_T + q;
+    const float my_lse = lse[stat];
+    if (hf == 0) delta[stat] = dsum;
+    __syncthreads();
+
+    f32x16 dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+#pragma unroll 1
+    for (int kt = 0; kt < 8; ++kt) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        const int row = 32 * kt + lq;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            s = mfma_32x32x16_bf16(attb_row_frag(k_img, row, kk, hf), qf[kk], s);
+            dp = mfma_32x32x16_bf16(attb_row_frag(v_img, row, kk, hf), dof[kk], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = fast_exp(s[r] * scale - my_lse);
+            s[r] = p * (dp[r] - dsum) * scale;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 dsf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dsf[e] = (short)f2bf(s[8 * s2 + e]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                dq[dt] = mfma_32x32x16_bf16(attb_tr_frag(kt_img, 32 * dt + lq, 2 * kt + s2, hf), dsf, dq[dt]);
+        }
+    }
+    attb_store_t(dqkv + ((long)view * ATT_T + q) * rs3 + head * ATT_D, dq, hf);
+}
+
+__global__ __launch_bounds__(512) void attention_bwd_dkv_kernel(const bf16_t* __restrict__ qkv,
+                                                                const bf16_t* __restrict__ d_o,
+                                                                const float* __restrict__ lse,
+                                                                const float* __restrict__ delta,
+                                                                bf16_t* __restrict__ dqkv, int heads, float scale) {
+    char* smem = dynamic_smem();
+    char* q_img = smem;
+    char* do_img = smem + ATTB_IMG;
+    char* qt_img = smem + 2 * ATTB_IMG;
+    char* dot_img = smem + 3 * ATTB_IMG;
+    float* lse_s = reinterpret_cast<float*>(smem + 4 * ATTB_IMG);
+    float* del_s = lse_s + ATT_T;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hf = lane >> 5, lq = lane & 31;
+    const int view = blockIdx.x / heads, head = blockIdx.x % heads;
+    const int E = heads * ATT_D;
+    const long rs3 = 3L * E;
+    const bf16_t* q_base = qkv + (long)view * ATT_T * rs3 + head * ATT_D;
+    const bf16_t* do_base = d_o + (long)view * ATT_T * E + head * ATT_D;
+    attb_stage_rows(q_base, rs3, q_img);
+    attb_stage_rows(do_base, E, do_img);
+    attb_stage_transposed(q_base, rs3, qt_img);
+    attb_stage_transposed(do_base, E, dot_img);
+    if (threadIdx.x < ATT_T) {
+        const long stat = ((long)view * heads + head) * ATT_T + threadIdx.x;
+        lse_s[threadIdx.x] = lse[stat];
+        del_s[threadIdx.x] = delta[stat];
+    }
+    const int key = 32 * w + lq;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        kf[kk] = *reinterpret_cast<const bf16x8*>(q_base + E + (long)key * rs3 + 16 * kk + 8 * hf);
+        vf[kk] = *reinterpret_cast<const bf16x8*>(q_base + 2 * E + (long)key * rs3 + 16 * kk + 8 * hf);
+    }
+    __syncthreads();
+
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+#pragma unroll 1
+    for (int qt = 0; qt < 8; ++qt) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        const int row = 32 * qt + lq;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            s = mfma_32x32x16_bf16(attb_row_frag(q_img, row, kk, hf), kf[kk], s);      // S[q][key]
+            dp = mfma_32x32x16_bf16(attb_row_frag(do_img, row, kk, hf), vf[kk], dp);   // dP[q][key]
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            const float p = fast_exp(s[r] * scale - lse_s[qq]);
+            s[r] = p;
+            dp[r] = p * (dp[r] - del_s[qq]) * scale;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 pf, dsf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pf[e] = (short)f2bf(s[8 * s2 + e]);
+                dsf[e] = (short)f2bf(dp[8 * s2 + e]);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dv[dt] = mfma_32x32x16_bf16(attb_tr_frag(dot_img, 32 * dt + lq, 2 * qt + s2, hf), pf, dv[dt]);
+                dk[dt] = mfma_32x32x16_bf16(attb_tr_frag(qt_img, 32 * dt + lq, 2 * qt + s2, hf), dsf, dk[dt]);
+            }
+        }
+    }
+    bf16_t* drow = dqkv + ((long)view * ATT_T + key) * rs3 + head * ATT_D;
+    attb_store_t(drow + E, dk, hf);
+    attb_store_t(drow + 2 * E, dv, hf);
+}
+
+}  // namespace ccd

@@ -1,0 +1,155 @@
+// attention_fwd.h - softmax(Q K^T / sqrt(d)) V for T = 256 tokens, head_dim = 64 (vision_transformer.py:85-89),
+// one workgroup (4 waves) per (view, head); the whole K and V of the head live in LDS (64 KiB), so 2 WGs/CU.
+//
+// Everything is computed TRANSPOSED so that the softmax row of a query sits inside one lane:
+//   S^T[key][q] = K . Q^T     (A = K rows from LDS, B = Q rows straight from HBM into registers)
+//   a lane (q = lane & 31) then owns 128 of the 256 scores of its query, the partner lane ^ 32 the other 128:
+//   the row max / row sum are in-register reductions plus ONE cross-lane exchange;
+//   O^T[d][q]   = V^T . P^T   (A = V^T from LDS, B = P^T = the exponentiated accumulators, converted in place)
+// The MFMA k-slot <-> key assignment of P^T is whatever the S^T accumulator layout gives
+// (lanes < 32: keys {0-3, 8-11} of each 16-key group, lanes >= 32: keys {4-7, 12-15}); V^T is written to LDS
+// with the same permutation, so no cross-lane data movement is needed between the two products.
+// The [256,256] attention matrix is never materialised (it is only consumed by get_last_selfattention,
+// vision_transformer.py:92/253-261, which is off the pretraining path).
+// Saves LSE[view, head, q] = max*scale + log(sum) for the backward pass.
+#pragma once
+
+namespace ccd {
+
+constexpr int ATT_T = 256, ATT_D = 64;
+constexpr int ATT_SMEM_BYTES = 2 * ATT_T * ATT_D * 2;   // K image + V^T image = 64 KiB
+
+// position of a 4-key chunk inside the permuted 16-key group: chunks {0,1,2,3} -> {0,2,1,3}
+__device__ __forceinline__ int att_chunk_pos(int chunk) { return ((chunk & 1) << 1) | ((chunk >> 1) & 1); }
+
+// K image: [256 keys][64 d], 128-B rows, 16-B slot XOR ((row >> 1) & 7)      (same image as the GEMM tiles)
+__device__ __forceinline__ void att_stage_rows(const bf16_t* __restrict__ src, long row_stride, char* img) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int id = t + 256 * i, row = id >> 3, slot = id & 7;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + (long)row * row_stride + slot * 8);
+        *reinterpret_cast<u32x4*>(img + row * 128 + ((slot ^ ((row >> 1) & 7)) * 16)) = v;
+    }
+}
+// transposed image: [64 d][256 keys] with keys permuted inside 16-groups, 512-B rows, slot XOR (d & 15)
+__device__ __forceinline__ void att_stage_transposed(const bf16_t* __restrict__ src, long row_stride, char* img) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int kb = 16 * w + (lane & 15);                  // 4-key block, keys 4*kb .. 4*kb+3
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int db = (lane >> 4) + 4 * i;               // 8-wide d block
+        u32x4 r[4];
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq)
+            r[kq] = *reinterpret_cast<const u32x4*>(src + (long)(4 * kb + kq) * row_stride + db * 8);
+        const int chunk = 4 * (kb >> 2) + att_chunk_pos(kb & 3);   // 8-byte chunk index inside the 512-B row
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = 8 * db + j;
+            const unsigned w0 = r[0][j >> 1], w1 = r[1][j >> 1], w2 = r[2][j >> 1], w3 = r[3][j >> 1];
+            unsigned e0, e1, e2, e3;
+            if (j & 1) { e0 = w0 >> 16; e1 = w1 >> 16; e2 = w2 >> 16; e3 = w3 >> 16; }
+            else { e0 = w0 & 0xffffu; e1 = w1 & 0xffffu; e2 = w2 & 0xffffu; e3 = w3 & 0xffffu; }
+            u32x2 o;
+            o.x = e0 | (e1 << 16);
+            o.y = e2 | (e3 << 16);
+            const int slot = (chunk >> 1) ^ (d & 15);
+            *reinterpret_cast<u32x2*>(img + d * 512 + slot * 16 + (chunk & 1) * 8) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                            float* __restrict__ lse, int heads, float scale) {
+    char* smem = dynamic_smem();
+    char* k_img = smem;
+    char* vt_img = smem + ATT_T * ATT_D * 2;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hf = lane >> 5, lq = lane & 31;
+    const int view = blockIdx.x / heads, head = blockIdx.x % heads;
+    const int E = heads * ATT_D;
+    const long row_stride = 3L * E;
+    const bf16_t* q_base = qkv + (long)view * ATT_T * row_stride + head * ATT_D;
+    const bf16_t* k_base = q_base + E;
+    const bf16_t* v_base = q_base + 2 * E;
+
+    att_stage_rows(k_base, row_stride, k_img);
+    att_stage_transposed(v_base, row_stride, vt_img);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = 64 * w + 32 * qt + lq;
+        bf16x8 qf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            qf[kk] = *reinterpret_cast<const bf16x8*>(q_base + (long)q * row_stride + 16 * kk + 8 * hf);
+
+        f32x16 s[8];
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+            const int row = 32 * kt + lq;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int slot = (2 * kk + hf) ^ ((row >> 1) & 7);
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_img + row * 128 + slot * 16);
+                s[kt] = mfma_32x32x16_bf16(kf, qf[kk], s[kt]);
+            }
+        }
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+        mx = fmaxf(mx, shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = fast_exp((s[kt][r] - mx) * scale);
+                s[kt][r] = p;
+                sum += p;
+            }
+        sum += shfl_xor(sum, 32);
+
+        f32x16 o[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = (short)f2bf(s[kt][8 * s2 + e]);
+                const int ks = 2 * kt + s2;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int d = 32 * dt + lq;
+                    const int slot = (2 * ks + hf) ^ (d & 15);
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vt_img + d * 512 + slot * 16);
+                    o[dt] = mfma_32x32x16_bf16(vf, pf, o[dt]);
+                }
+            }
+        }
+        const float inv = 1.0f / sum;
+        bf16_t* orow = out + ((long)view * ATT_T + q) * E + head * ATT_D;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 pk;
+                pk.x = pack_bf2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+                pk.y = pack_bf2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+                *reinterpret_cast<u32x2*>(orow + 32 * dt + 8 * g + 4 * hf) = pk;
+            }
+        if (hf == 0) lse[((long)view * heads + head) * ATT_T + q] = mx * scale + logf(sum);
+    }
+}
+
+}  // namespace ccd

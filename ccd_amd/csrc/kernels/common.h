@@ -1,0 +1,60 @@
+// common.h - small device helpers shared by every kernel header (no #includes: see prelude_hip.h).
+#pragma once
+
+namespace ccd {
+typedef unsigned short bf16_t;                                    // raw bfloat16 storage
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;       // one 16-byte global/LDS transaction per lane
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+
+__device__ __forceinline__ unsigned f2bits(float f) { unsigned u; __builtin_memcpy(&u, &f, 4); return u; }
+__device__ __forceinline__ float bits2f(unsigned u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+__device__ __forceinline__ float bf2f(bf16_t h) { return bits2f((unsigned)h << 16); }
+// round-to-nearest-even, NaN preserved (same rule as torch's float -> bfloat16)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = f2bits(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ float bf_lo(unsigned w) { return bits2f(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return bits2f(w & 0xffff0000u); }
+
+__device__ __forceinline__ void unpack8(const u32x4& w, float* v) {
+    v[0] = bf_lo(w.x); v[1] = bf_hi(w.x); v[2] = bf_lo(w.y); v[3] = bf_hi(w.y);
+    v[4] = bf_lo(w.z); v[5] = bf_hi(w.z); v[6] = bf_lo(w.w); v[7] = bf_hi(w.w);
+}
+__device__ __forceinline__ u32x4 pack8(const float* v) {
+    u32x4 w;
+    w.x = pack_bf2(v[0], v[1]); w.y = pack_bf2(v[2], v[3]); w.z = pack_bf2(v[4], v[5]); w.w = pack_bf2(v[6], v[7]);
+    return w;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m));
+    return v;
+}
+
+// exact (erf) GELU as nn.GELU() computes it, and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// XCD-aware bijective remap of a linear workgroup id: consecutive work items land on the same XCD
+// (hardware dispatches block b to XCD b % 8; guide T1, bijective variant for nwg % 8 != 0)
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+    const unsigned xcd = bid & 7u, q = nwg >> 3, r = nwg & 7u;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+}  // namespace ccd

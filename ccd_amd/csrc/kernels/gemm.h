@@ -1,0 +1,259 @@
+// gemm.h - bf16 MFMA GEMM family for gfx950 (fp32 accumulate), 128x128 output tile, BK = 64, 4 waves (2x2).
+//
+//   NT :  C[M,N] (+)= A[M,K] . B[N,K]^T        A, B row-major with the contraction index contiguous
+//         (every nn.Linear forward, and every dX = dY . W via the pre-transposed bf16 copy of W)
+//   TN :  C[P,Q] (+)= sum_m A[m,P]^T . B[m,Q]   both operands have the contraction index as the ROW index
+//         (every dW = dY^T . X), split over blockIdx.z along m with fp32 atomics
+//
+// LDS tile image (both operands, both modes): [128 rows][64 k] bf16 = 128 B per row, 16-byte slots
+// XOR-swizzled by ((row >> 1) & 7): conflict-free for the ds_read_b128 fragment reads (16 distinct rows
+// per lane group) and for the staging writes of both loaders (see the loaders).  Two stages (64 KiB), the
+// fp32 epilogue staging tile [128][132] aliases them, so 2 workgroups fit a CU's 160 KiB.
+// MFMA: v_mfma_f32_32x32x16_bf16, each wave owns a 64x64 quadrant = 2x2 accumulators of 16 VGPRs.
+#pragma once
+
+namespace ccd {
+
+enum GemmEpilogue {
+    EPI_BF16 = 0,       // C(bf16) = acc + bias
+    EPI_GELU = 1,       // C(bf16) = u = acc + bias ; C2(bf16) = gelu(u)
+    EPI_RESID = 2,      // C(f32)  = resid + (acc + bias) * rowscale[row / rows_per_sample]
+    EPI_F32 = 3,        // C(f32)  = acc + bias
+    EPI_ATOMIC = 4,     // C(f32) += acc                       (split-K partial sums)
+    EPI_DGELU = 5,      // C(bf16) = acc * gelu'(aux)          (aux = saved pre-activation u, bf16)
+    EPI_BF16_ADDF32 = 6 // C(bf16) = acc + bias ; C2(f32) += acc (unused hook kept for head experiments)
+};
+
+struct GemmParams {
+    const bf16_t* A;
+    const bf16_t* B;
+    long lda, ldb;          // row strides in elements
+    int M, N, K;            // NT: C is MxN, contraction K (multiple of 64).  TN: C is PxQ = MxN, contraction length K
+    void* C;
+    long ldc;
+    void* C2;
+    long ldc2;
+    const float* bias;      // [N] or null
+    const float* resid;     // EPI_RESID
+    long ldr;
+    const float* rowscale;  // EPI_RESID: per-sample scale (DropPath), or null
+    int rows_per_sample;
+    const bf16_t* aux;      // EPI_DGELU
+    long ldaux;
+    int k_per_split;        // TN: contraction rows handled by one blockIdx.z slice (multiple of 64)
+    int m_fastest;          // tile order: 0 = column tiles fastest, 1 = row tiles fastest
+    float alpha;            // scales acc before the epilogue
+};
+
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 64;
+constexpr int GEMM_STAGE_BYTES = GEMM_BM * GEMM_BK * 2;          // one operand, one stage: 16 KiB
+constexpr int GEMM_CS_LD = 132;                                   // fp32 staging row stride (floats)
+constexpr int GEMM_SMEM_BYTES = GEMM_BM * GEMM_CS_LD * 4;         // 67,584 B  (>= 4 stages * 16 KiB)
+
+__device__ __forceinline__ int gemm_swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
+
+// ---- NT loader: thread t fetches 4 x 16 B per operand; 8 consecutive threads cover one 128-B tile row
+__device__ __forceinline__ void gemm_load_nt(const bf16_t* __restrict__ src, long ld, int row0, int nrows, int k0,
+                                              u32x4 (&r)[4]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = t + 256 * i, row = id >> 3, slot = id & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row0 + row < nrows) v = *reinterpret_cast<const u32x4*>(src + (long)(row0 + row) * ld + k0 + slot * 8);
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void gemm_store_nt(char* tile, const u32x4 (&r)[4]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = t + 256 * i, row = id >> 3, slot = id & 7;
+        *reinterpret_cast<u32x4*>(tile + row * 128 + gemm_swz(row, slot) * 16) = r[i];
+    }
+}
+// ---- TN loader: the tile is 64 contraction rows x 128 columns in memory; a thread fetches a 4(m) x 8(col)
+// block (4 x 16 B, each 16-lane group reads 16 different m rows of the same 8 columns... 4 groups of a wave sit
+// on adjacent column blocks so a wave instruction touches 16 rows x 64 contiguous bytes), transposes it in
+// registers and writes 8 x 8 B: instruction j stores column 8*nb+j, m-chunk mb -> the 16 lanes of a write
+// group share the LDS row and cover its 16 distinct 8-byte chunks (conflict-free).
+__device__ __forceinline__ void gemm_load_tn(const bf16_t* __restrict__ src, long ld, int col0, int ncols, int m0,
+                                              int m_end, u32x4 (&r)[4]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int mb = lane & 15, nb = w * 4 + (lane >> 4);
+    const int col = col0 + 8 * nb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 4 * mb + i;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (m < m_end && col < ncols) v = *reinterpret_cast<const u32x4*>(src + (long)m * ld + col);
+        r[i] = v;
+    }
+}
+__device__ __forceinline__ void gemm_store_tn(char* tile, const u32x4 (&r)[4]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int mb = lane & 15, nb = w * 4 + (lane >> 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = 8 * nb + j;                         // tile row = output row/column index
+        unsigned e0, e1, e2, e3;                            // element j of the four m rows
+        const unsigned w0 = r[0][j >> 1], w1 = r[1][j >> 1], w2 = r[2][j >> 1], w3 = r[3][j >> 1];
+        if (j & 1) { e0 = w0 >> 16; e1 = w1 >> 16; e2 = w2 >> 16; e3 = w3 >> 16; }
+        else { e0 = w0 & 0xffffu; e1 = w1 & 0xffffu; e2 = w2 & 0xffffu; e3 = w3 & 0xffffu; }
+        u32x2 o;
+        o.x = e0 | (e1 << 16);
+        o.y = e2 | (e3 << 16);
+        *reinterpret_cast<u32x2*>(tile + row * 128 + gemm_swz(row, mb >> 1) * 16 + (mb & 1) * 8) = o;
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_row8(const GemmParams& p, int gm, int gn, float* v) {
+    if (EPI != EPI_ATOMIC && EPI != EPI_DGELU && p.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += p.bias[gn + e];
+    }
+    if (EPI == EPI_BF16) {
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = pack8(v);
+    } else if (EPI == EPI_GELU) {
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = pack8(v);
+        float g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = gelu_f(v[e]);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + (long)gm * p.ldc2 + gn) = pack8(g);
+    } else if (EPI == EPI_RESID) {
+        const float s = p.rowscale ? p.rowscale[gm / p.rows_per_sample] : 1.0f;
+        const f32x4v* rp = reinterpret_cast<const f32x4v*>(p.resid + (long)gm * p.ldr + gn);
+        f32x4v r0 = rp[0], r1 = rp[1];
+        f32x4v o0 = {r0.x + v[0] * s, r0.y + v[1] * s, r0.z + v[2] * s, r0.w + v[3] * s};
+        f32x4v o1 = {r1.x + v[4] * s, r1.y + v[5] * s, r1.z + v[6] * s, r1.w + v[7] * s};
+        f32x4v* op = reinterpret_cast<f32x4v*>(reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn);
+        op[0] = o0;
+        op[1] = o1;
+    } else if (EPI == EPI_F32) {
+        f32x4v* op = reinterpret_cast<f32x4v*>(reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn);
+        f32x4v o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        op[0] = o0;
+        op[1] = o1;
+    } else if (EPI == EPI_ATOMIC) {
+        float* op = reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(op + e, v[e]);
+    } else if (EPI == EPI_DGELU) {
+        const u32x4 uw = *reinterpret_cast<const u32x4*>(p.aux + (long)gm * p.ldaux + gn);
+        float u[8];
+        unpack8(uw, u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= dgelu_f(u[e]);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = pack8(v);
+    }
+}
+
+template <bool TN, int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+    char* smem = dynamic_smem();
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+
+    const int tiles_m = (p.M + GEMM_BM - 1) / GEMM_BM, tiles_n = (p.N + GEMM_BN - 1) / GEMM_BN;
+    const unsigned tile = xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n));
+    int tm, tn;
+    if (p.m_fastest) { tm = tile % tiles_m; tn = tile / tiles_m; }
+    else { tn = tile % tiles_n; tm = tile / tiles_n; }
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+
+    int k_begin = 0, k_end = p.K;
+    if (TN) {
+        k_begin = blockIdx.z * p.k_per_split;
+        k_end = k_begin + p.k_per_split < p.K ? k_begin + p.k_per_split : p.K;
+    }
+    const int nk = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    u32x4 ra[4], rb[4];
+    auto load = [&](int kt) {
+        const int k0 = k_begin + kt * GEMM_BK;
+        if (TN) {
+            gemm_load_tn(p.A, p.lda, m0, p.M, k0, k_end, ra);
+            gemm_load_tn(p.B, p.ldb, n0, p.N, k0, k_end, rb);
+        } else {
+            gemm_load_nt(p.A, p.lda, m0, p.M, k0, ra);
+            gemm_load_nt(p.B, p.ldb, n0, p.N, k0, rb);
+        }
+    };
+    auto store = [&](int stage) {
+        char* as = smem + stage * 2 * GEMM_STAGE_BYTES;
+        char* bs = as + GEMM_STAGE_BYTES;
+        if (TN) { gemm_store_tn(as, ra); gemm_store_tn(bs, rb); }
+        else { gemm_store_nt(as, ra); gemm_store_nt(bs, rb); }
+    };
+
+    if (nk > 0) {
+        load(0);
+        store(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        if (kt + 1 < nk) load(kt + 1);                      // global loads in flight under the MFMAs
+        const char* as = smem + stage * 2 * GEMM_STAGE_BYTES;
+        const char* bs = as + GEMM_STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int slot = 2 * kk + (lane >> 5);
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = 64 * wm + 32 * i + (lane & 31);
+                a[i] = *reinterpret_cast<const bf16x8*>(as + row * 128 + gemm_swz(row, slot) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = 64 * wn + 32 * j + (lane & 31);
+                b[j] = *reinterpret_cast<const bf16x8*>(bs + row * 128 + gemm_swz(row, slot) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16_bf16(a[i], b[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) store(stage ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> fp32 LDS tile -> row-contiguous 8-wide global accesses
+    float* cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = 64 * wn + 32 * j + (lane & 31);
+                cs[row * GEMM_CS_LD + col] = acc[i][j][r] * p.alpha;
+            }
+    __syncthreads();
+#pragma unroll 1
+    for (int pass = 0; pass < 8; ++pass) {
+        const int row = pass * 16 + (t >> 4), col = (t & 15) * 8;
+        const int gm = m0 + row, gn = n0 + col;
+        if (gm < p.M && gn < p.N) {
+            float v[8];
+            const f32x4v c0 = *reinterpret_cast<const f32x4v*>(cs + row * GEMM_CS_LD + col);
+            const f32x4v c1 = *reinterpret_cast<const f32x4v*>(cs + row * GEMM_CS_LD + col + 4);
+            v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
+            v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+            gemm_epilogue_row8<EPI>(p, gm, gn, v);
+        }
+    }
+}
+
+}  // namespace ccd

@@ -1,0 +1,71 @@
+// prelude_hip.h - device-side vocabulary of the ccd kernels on gfx950 (CDNA4, wave64).
+// Kernel headers under kernels/ include nothing themselves; they are written against the few names
+// defined here (ccd:: MFMA wrappers, wave shuffles, dynamic LDS accessor) plus plain HIP builtins.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ccd {
+typedef __attribute__((ext_vector_type(8))) short bf16x8;    // 8 raw bf16 = one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;   // 32x32 accumulator fragment
+typedef __attribute__((ext_vector_type(4))) float f32x4;     // 16x16 accumulator fragment
+typedef __attribute__((ext_vector_type(8))) __bf16 hw_bf16x8;
+
+extern __shared__ __attribute__((aligned(16))) char dyn_smem_base[];
+__device__ __forceinline__ char* dynamic_smem() { return dyn_smem_base; }
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+template <typename T>
+__device__ __forceinline__ T shfl(T v, int src_lane) { return __shfl(v, src_lane, 64); }
+template <typename T>
+__device__ __forceinline__ T shfl_xor(T v, int mask) { return __shfl_xor(v, mask, 64); }
+template <typename T>
+__device__ __forceinline__ T shfl_down(T v, int d) { return __shfl_down(v, d, 64); }
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
+
+// D = A*B + C on one wave64.  A[i=l&31][k=8*(l>>5)+e], B[k][j=l&31]; D col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5)
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hw_bf16x8, a), __builtin_bit_cast(hw_bf16x8, b),
+                                                   c, 0, 0, 0);
+}
+// A[i=l&15][k=8*(l>>4)+e], B[k][j=l&15]; D col=l&15, row=4*(l>>4)+r
+__device__ __forceinline__ f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hw_bf16x8, a), __builtin_bit_cast(hw_bf16x8, b),
+                                                   c, 0, 0, 0);
+}
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __frcp_rn(x); }
+__device__ __forceinline__ float fast_rsqrt(float x) { return rsqrtf(x); }
+}  // namespace ccd
+
+template <typename F>
+static inline const void* ccd_fn_ptr(F* f) { return reinterpret_cast<const void*>(f); }
+// dynamic LDS above 64 KiB has to be opted into once per kernel (gfx950 allows up to 160 KiB per workgroup)
+#define CCD_LAUNCH(kernel, grid, block, smem, stream, ...)                                                      \
+    do {                                                                                                        \
+        if ((smem) > 65536) {                                                                                   \
+            static bool ccd_once_ = false;                                                                      \
+            if (!ccd_once_) {                                                                                   \
+                (void)hipFuncSetAttribute(ccd_fn_ptr(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                          (int)(smem));                                                         \
+                ccd_once_ = true;                                                                               \
+            }                                                                                                   \
+        }                                                                                                       \
+        hipLaunchKernelGGL(kernel, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__);                \
+    } while (0)
+static inline int ccd_rt_memset_async(void* p, int v, size_t n, void* stream) {
+    return (int)hipMemsetAsync(p, v, n, (hipStream_t)stream);
+}
+static inline int ccd_rt_last_error() { return (int)hipGetLastError(); }
+static inline int ccd_rt_num_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}

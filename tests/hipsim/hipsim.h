@@ -1,0 +1,238 @@
+// hipsim.h - TEST INFRASTRUCTURE ONLY.
+//
+// A small host-side SIMT executor so that the *same* kernel sources and C-ABI launchers that ship in
+// ccd_amd/csrc can be executed on a CPU at tiny problem sizes (this build container has no GPU and GPU
+// time is scarce).  It provides the handful of names ccd_amd/csrc/prelude_hip.h provides on the device:
+// __global__/__shared__/threadIdx/.../__syncthreads, wave64 shuffles, atomics and an emulation of the
+// MFMA instructions with the documented gfx950 operand/accumulator layouts (MI355X guide section 3).
+// Every lane is a ucontext fiber; a workgroup is run by one OS thread, workgroups run in parallel.
+// It is NOT a compatibility layer of the product: ccd_amd never loads anything built from this file.
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static thread_local
+#define __launch_bounds__(...)
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+typedef void* hipStream_t;
+
+namespace sim {
+constexpr int WAVE = 64;
+struct Block;
+struct Lane {
+    dim3 tid;
+    int linear = 0;
+    int wave = 0;
+    int lane = 0;
+    ucontext_t ctx;
+    bool done = false;
+    int wait_kind = 0;       // 0 runnable, 1 waiting wave barrier, 2 waiting block barrier
+    unsigned wait_gen = 0;
+    Block* blk = nullptr;
+    void* stack = nullptr;
+};
+struct WaveState {
+    int alive = 0, arrived = 0;
+    unsigned gen = 0;
+    alignas(16) unsigned char xchg[WAVE][64];   // per-lane exchange slot (up to 64 bytes)
+};
+struct Block {
+    dim3 bid, bdim, gdim;
+    std::vector<Lane> lanes;
+    std::vector<WaveState> waves;
+    int alive = 0, arrived = 0;
+    unsigned gen = 0;
+    ucontext_t sched;
+    char* dyn_smem = nullptr;
+    const std::function<void()>* body = nullptr;
+};
+extern thread_local Lane* cur;
+extern thread_local Block* curblk;
+
+inline void yield_to_scheduler() { swapcontext(&cur->ctx, &cur->blk->sched); }
+
+inline void wave_sync() {
+    Lane* l = cur;
+    WaveState& w = l->blk->waves[l->wave];
+    if (++w.arrived >= w.alive) {
+        w.arrived = 0;
+        ++w.gen;
+        return;
+    }
+    l->wait_kind = 1;
+    l->wait_gen = w.gen;
+    yield_to_scheduler();
+}
+inline void block_sync() {
+    Lane* l = cur;
+    Block* b = l->blk;
+    if (++b->arrived >= b->alive) {
+        b->arrived = 0;
+        ++b->gen;
+        return;
+    }
+    l->wait_kind = 2;
+    l->wait_gen = b->gen;
+    yield_to_scheduler();
+}
+void launch(dim3 grid, dim3 block, size_t dyn_smem, const std::function<void()>& body);
+}  // namespace sim
+
+#define threadIdx (sim::cur->tid)
+#define blockIdx (sim::curblk->bid)
+#define blockDim (sim::curblk->bdim)
+#define gridDim (sim::curblk->gdim)
+inline void __syncthreads() { sim::block_sync(); }
+
+// ------------------------------------------------------------------------------------------- atomics
+template <typename T>
+inline T sim_atomic_rmw(T* p, T v, T (*op)(T, T)) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "");
+    using U = typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type;
+    U* up = reinterpret_cast<U*>(p);
+    U old = __atomic_load_n(up, __ATOMIC_RELAXED);
+    for (;;) {
+        T o;
+        std::memcpy(&o, &old, sizeof(T));
+        T n = op(o, v);
+        U nu;
+        std::memcpy(&nu, &n, sizeof(T));
+        if (__atomic_compare_exchange_n(up, &old, nu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return o;
+    }
+}
+inline float atomicAdd(float* p, float v) { return sim_atomic_rmw<float>(p, v, [](float a, float b) { return a + b; }); }
+inline int atomicAdd(int* p, int v) { return sim_atomic_rmw<int>(p, v, [](int a, int b) { return a + b; }); }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { return sim_atomic_rmw<unsigned>(p, v, [](unsigned a, unsigned b) { return a + b; }); }
+inline int atomicMin(int* p, int v) { return sim_atomic_rmw<int>(p, v, [](int a, int b) { return a < b ? a : b; }); }
+inline int atomicMax(int* p, int v) { return sim_atomic_rmw<int>(p, v, [](int a, int b) { return a > b ? a : b; }); }
+inline unsigned atomicMin(unsigned* p, unsigned v) { return sim_atomic_rmw<unsigned>(p, v, [](unsigned a, unsigned b) { return a < b ? a : b; }); }
+
+// --------------------------------------------------------------------------- the ccd:: device prelude
+namespace ccd {
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+inline char* dynamic_smem() { return sim::curblk->dyn_smem; }
+inline int lane_id() { return sim::cur->lane; }
+inline int wave_id() { return sim::cur->wave; }
+
+template <typename T>
+inline T shfl(T v, int src_lane) {
+    static_assert(sizeof(T) <= 64, "");
+    sim::WaveState& w = sim::curblk->waves[sim::cur->wave];
+    std::memcpy(w.xchg[sim::cur->lane], &v, sizeof(T));
+    sim::wave_sync();
+    T r;
+    std::memcpy(&r, w.xchg[src_lane & 63], sizeof(T));
+    sim::wave_sync();
+    return r;
+}
+template <typename T>
+inline T shfl_xor(T v, int mask) { return shfl(v, sim::cur->lane ^ mask); }
+template <typename T>
+inline T shfl_down(T v, int d) { int s = sim::cur->lane + d; return shfl(v, s > 63 ? sim::cur->lane : s); }
+inline unsigned long long ballot(bool p) {
+    unsigned long long bit = p ? 1ull : 0ull;
+    unsigned long long all = 0;
+    // gather through shuffles (slow but simple)
+    sim::WaveState& w = sim::curblk->waves[sim::cur->wave];
+    std::memcpy(w.xchg[sim::cur->lane], &bit, 8);
+    sim::wave_sync();
+    for (int i = 0; i < 64; ++i) {
+        unsigned long long b;
+        std::memcpy(&b, w.xchg[i], 8);
+        // lanes that already exited keep their last slot content; treat missing lanes as 0
+        all |= (b & 1ull) << i;
+    }
+    sim::wave_sync();
+    return all;
+}
+inline float bf16_bits_to_f32(unsigned short h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
+
+// v_mfma_f32_32x32x16_bf16: A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31],
+// D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
+inline f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    struct AB { short a[8]; short b[8]; };
+    sim::WaveState& w = sim::curblk->waves[sim::cur->wave];
+    AB me;
+    for (int e = 0; e < 8; ++e) { me.a[e] = a[e]; me.b[e] = b[e]; }
+    std::memcpy(w.xchg[sim::cur->lane], &me, sizeof(me));
+    sim::wave_sync();
+    int l = sim::cur->lane;
+    int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            AB la, lb;
+            std::memcpy(&la, w.xchg[row + 32 * (k >> 3)], sizeof(AB));
+            std::memcpy(&lb, w.xchg[col + 32 * (k >> 3)], sizeof(AB));
+            acc += bf16_bits_to_f32((unsigned short)la.a[k & 7]) * bf16_bits_to_f32((unsigned short)lb.b[k & 7]);
+        }
+        c[r] = acc;
+    }
+    sim::wave_sync();
+    return c;
+}
+// v_mfma_f32_16x16x32_bf16: A[i=l&15][k=8*(l>>4)+e], B[k=8*(l>>4)+e][j=l&15], D: col=l&15, row=4*(l>>4)+r
+inline f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    struct AB { short a[8]; short b[8]; };
+    sim::WaveState& w = sim::curblk->waves[sim::cur->wave];
+    AB me;
+    for (int e = 0; e < 8; ++e) { me.a[e] = a[e]; me.b[e] = b[e]; }
+    std::memcpy(w.xchg[sim::cur->lane], &me, sizeof(me));
+    sim::wave_sync();
+    int l = sim::cur->lane;
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) {
+            AB la, lb;
+            std::memcpy(&la, w.xchg[row + 16 * (k >> 3)], sizeof(AB));
+            std::memcpy(&lb, w.xchg[col + 16 * (k >> 3)], sizeof(AB));
+            acc += bf16_bits_to_f32((unsigned short)la.a[k & 7]) * bf16_bits_to_f32((unsigned short)lb.b[k & 7]);
+        }
+        c[r] = acc;
+    }
+    sim::wave_sync();
+    return c;
+}
+inline float fast_exp(float x) { return std::exp(x); }
+inline float fast_rcp(float x) { return 1.0f / x; }
+inline float fast_rsqrt(float x) { return 1.0f / std::sqrt(x); }
+}  // namespace ccd
+
+// <cmath> already declares ::erff, ::expf, ::fabsf, ::fmaxf, ::fminf, ::logf, ::sqrtf in the global namespace
+inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
+inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+
+// launch + runtime shims used by abi_impl.h
+#define CCD_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    sim::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
+inline int ccd_rt_memset_async(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return 0; }
+inline int ccd_rt_last_error() { return 0; }
+inline int ccd_rt_num_cus() { return 8; }
