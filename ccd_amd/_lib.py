@@ -25,12 +25,41 @@ F = C.c_float
 SIGNATURES = {
     "ccd_abi_version": [],
     "ccd_build_info": [],
-    "ccd_gemm_nt": [P, L, P, L, I, I, I, I, P, L, P, L, P, P, L, P, I, P, L, F, I, P],
-    "ccd_gemm_tn": [P, L, P, L, I, I, I, I, P, L, F, I, P],
+    "ccd_gemm_nt": [P, L, P, L, I, I, I, I, P, L, P, L, P, P, L, P, I, P, L, F, I, P, I, P],
+    "ccd_gemm_tn": [P, L, P, L, I, I, I, I, P, L, F, I, P, I, P],
     "ccd_ln_fwd": [P, P, P, P, P, P, I, I, F, P],
     "ccd_ln_bwd": [P, P, P, P, P, P, I, P, P, I, I, P],
     "ccd_attention_fwd": [P, P, P, I, I, F, P],
     "ccd_attention_bwd": [P, P, P, P, P, P, I, I, F, P],
+    "ccd_patch_embed_fwd": [P, P, P, P, P, I, I, P],
+    "ccd_patch_embed_bwd": [P, P, P, P, P, I, I, P],
+    "ccd_small_matmul_f32": [P, P, P, I, I, I, I, I, P],
+    "ccd_colsum_bf16": [P, L, I, I, P, I, P, P],
+    "ccd_mirror_bf16": [P, I, I, P],
+    "ccd_cast_bf16": [P, P, L, P],
+    "ccd_ccl_label": [P, P, I, P],
+    "ccd_mask_to_idmap": [P, P, I, P],
+    "ccd_seg_to_mask": [P, P, I, P],
+    "ccd_warp_idmap": [P, P, I, P, I, P],
+    "ccd_region_stats": [P, P, P, P, I, P],
+    "ccd_select_scan": [P, I, P, P, P, P, P],
+    "ccd_region_pool_fwd": [P, P, P, P, P, P, P, I, I, P],
+    "ccd_region_pool_bwd": [P, P, P, P, P, P, P, I, I, P],
+    "ccd_idmap_to_planes": [P, P, I, P],
+    "ccd_planes_to_idmap": [P, P, I, P],
+    "ccd_l2norm_fwd": [P, P, P, I, P, I, I, P],
+    "ccd_l2norm_bwd": [P, P, P, P, I, P, I, I, P],
+    "ccd_weightnorm_fwd": [P, P, P, P, P, I, I, P],
+    "ccd_weightnorm_bwd": [P, P, P, P, P, P, I, I, P],
+    "ccd_dino_loss_fwd": [P, P, P, I, P, I, F, F, P, P, P],
+    "ccd_dino_loss_bwd": [P, P, P, I, P, I, F, F, P, F, P, P],
+    "ccd_colsum_f32": [P, I, P, I, I, P, P],
+    "ccd_center_ema": [P, P, I, P, I, F, P],
+    "ccd_seg_loss": [P, P, P, I, F, P, P, P],
+    "ccd_seg_sumsq": [P, P, P, P, I, P, P],
+    "ccd_adamw": [P, P, P, P, P, P, P, P, I, P, P, F, F, F, F, P],
+    "ccd_clip_scale": [P, P, P, P, I, P, F, P],
+    "ccd_ema": [P, P, P, L, F, F, P],
 }
 _RESTYPES = {"ccd_build_info": C.c_char_p}
 

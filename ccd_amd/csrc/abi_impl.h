@@ -9,6 +9,11 @@
 #include "kernels/layernorm.h"
 #include "kernels/attention_fwd.h"
 #include "kernels/attention_bwd.h"
+#include "kernels/charmap.h"
+#include "kernels/embed.h"
+#include "kernels/head.h"
+#include "kernels/loss.h"
+#include "kernels/optim.h"
 
 #define CCD_CHECK(cond, code) \
     do {                      \
@@ -42,7 +47,7 @@ const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi1"; }
 int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, int epilogue, void* C,
                 long ldc, void* C2, long ldc2, const float* bias, const float* resid, long ldr,
                 const float* rowscale, int rows_per_sample, const ccd_bf16* aux, long ldaux, float alpha,
-                int m_fastest, void* stream) {
+                int m_fastest, const int* d_rows, int rows_mul, void* stream) {
     CCD_CHECK(A && B && C, CCD_EINVAL);
     CCD_CHECK(CCD_ALIGNED16(A) && CCD_ALIGNED16(B) && CCD_ALIGNED16(C), CCD_EINVAL);
     if (M == 0 || N == 0) return CCD_OK;
@@ -55,12 +60,12 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
     p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K;
     p.C = C; p.ldc = ldc; p.C2 = C2; p.ldc2 = ldc2; p.bias = bias; p.resid = resid; p.ldr = ldr;
     p.rowscale = rowscale; p.rows_per_sample = rows_per_sample; p.aux = aux; p.ldaux = ldaux;
-    p.k_per_split = K; p.m_fastest = m_fastest; p.alpha = alpha;
+    p.k_per_split = K; p.m_fastest = m_fastest; p.alpha = alpha; p.d_rows = d_rows; p.rows_mul = rows_mul;
     return ccd_launch_gemm<false>(p, epilogue, 1, stream);
 }
 
 int ccd_gemm_tn(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P, int Q, int Mc, int epilogue, float* C,
-                long ldc, float alpha, int splits, void* stream) {
+                long ldc, float alpha, int splits, const int* d_rows, int rows_mul, void* stream) {
     CCD_CHECK(A && B && C, CCD_EINVAL);
     CCD_CHECK(CCD_ALIGNED16(A) && CCD_ALIGNED16(B) && CCD_ALIGNED16(C), CCD_EINVAL);
     if (P == 0 || Q == 0 || Mc == 0) return CCD_OK;
@@ -79,7 +84,7 @@ int ccd_gemm_tn(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P,
     p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.M = P; p.N = Q; p.K = Mc;
     p.C = C; p.ldc = ldc; p.C2 = nullptr; p.ldc2 = 0; p.bias = nullptr; p.resid = nullptr; p.ldr = 0;
     p.rowscale = nullptr; p.rows_per_sample = 1; p.aux = nullptr; p.ldaux = 0;
-    p.k_per_split = per; p.m_fastest = 0; p.alpha = alpha;
+    p.k_per_split = per; p.m_fastest = 0; p.alpha = alpha; p.d_rows = d_rows; p.rows_mul = rows_mul;
     return ccd_launch_gemm<true>(p, epilogue, splits, stream);
 }
 
@@ -132,6 +137,251 @@ int ccd_attention_bwd(const ccd_bf16* qkv, const ccd_bf16* out, const ccd_bf16* 
                lse, delta_ws, d_qkv, heads, scale);
     CCD_LAUNCH(ccd::attention_bwd_dkv_kernel, dim3(views * heads), dim3(512), ccd::ATTB_DKV_SMEM, stream, qkv, d_out, lse,
                delta_ws, d_qkv, heads, scale);
+    return ccd_rt_last_error();
+}
+
+// ------------------------------------------------------------------------------- patch embed & helpers
+int ccd_patch_embed_fwd(const float* img, const float* w, const float* bias, const float* pos, float* out, int views,
+                        int E, void* stream) {
+    CCD_CHECK(img && w && bias && pos && out, CCD_EINVAL);
+    if (views == 0) return CCD_OK;
+    CCD_CHECK(views > 0 && E > 0, CCD_EINVAL);
+    CCD_LAUNCH(ccd::patch_embed_fwd_kernel, dim3(views * ccd::PE_GH), dim3(128), 0, stream, img, w, bias, pos, out, E);
+    return ccd_rt_last_error();
+}
+int ccd_patch_embed_bwd(const float* img, const float* g, float* d_w, float* d_bias, float* d_pos, int views, int E,
+                        void* stream) {
+    CCD_CHECK(img && g && d_w && d_bias && d_pos, CCD_EINVAL);
+    if (views == 0) return CCD_OK;
+    CCD_CHECK(views > 0 && E > 0, CCD_EINVAL);
+    int vpb = (views * ccd::PE_GH + 4 * ccd_rt_num_cus() - 1) / (4 * ccd_rt_num_cus());
+    if (vpb < 1) vpb = 1;
+    const int groups = (views + vpb - 1) / vpb;
+    CCD_LAUNCH(ccd::patch_embed_bwd_kernel, dim3(groups * ccd::PE_GH), dim3(128), 0, stream, img, g, d_w, d_bias, d_pos,
+               views, vpb, E);
+    return ccd_rt_last_error();
+}
+int ccd_small_matmul_f32(const float* A, const float* B, float* C, int M, int N, int K, int trans_a, int accumulate,
+                         void* stream) {
+    CCD_CHECK(A && B && C && M > 0 && N > 0 && K > 0, CCD_EINVAL);
+    CCD_LAUNCH(ccd::small_matmul_f32_kernel, dim3((N + 127) / 128, M), dim3(128), 0, stream, A, B, C, M, N, K, trans_a,
+               accumulate);
+    return ccd_rt_last_error();
+}
+int ccd_colsum_bf16(const ccd_bf16* x, long ld, int rows, int N, const int* d_rows, int rows_mul, float* out,
+                    void* stream) {
+    CCD_CHECK(x && out, CCD_EINVAL);
+    if (rows == 0 || N == 0) return CCD_OK;
+    CCD_CHECK(rows > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0 && CCD_ALIGNED16(x), CCD_ESHAPE);
+    const int col_blocks = (N + 255) / 256;
+    int row_blocks = (4 * ccd_rt_num_cus() + col_blocks - 1) / col_blocks;
+    int rpb = (rows + row_blocks - 1) / row_blocks;
+    rpb = ((rpb + 7) / 8) * 8;
+    row_blocks = (rows + rpb - 1) / rpb;
+    CCD_LAUNCH(ccd::colsum_bf16_kernel, dim3(col_blocks, row_blocks), dim3(256), 0, stream, x, ld, rows, N, d_rows,
+               rows_mul, out, rpb);
+    return ccd_rt_last_error();
+}
+int ccd_mirror_bf16(const ccd_mirror_desc* d_descs, int ndesc, int total_tiles, void* stream) {
+    CCD_CHECK(d_descs && ndesc > 0 && total_tiles > 0, CCD_EINVAL);
+    static_assert(sizeof(ccd_mirror_desc) == sizeof(ccd::MirrorDesc) + 4 || sizeof(ccd_mirror_desc) == sizeof(ccd::MirrorDesc),
+                  "descriptor layout");
+    CCD_LAUNCH(ccd::mirror_bf16_kernel, dim3(total_tiles), dim3(256), 0, stream,
+               reinterpret_cast<const ccd::MirrorDesc*>(d_descs), ndesc);
+    return ccd_rt_last_error();
+}
+int ccd_cast_bf16(const float* src, ccd_bf16* dst, long n, void* stream) {
+    CCD_CHECK(src && dst && n >= 0, CCD_EINVAL);
+    if (n == 0) return CCD_OK;
+    CCD_LAUNCH(ccd::cast_bf16_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, src, dst, n);
+    return ccd_rt_last_error();
+}
+
+// ------------------------------------------------------------------------------- character-region path
+int ccd_ccl_label(const float* mask, uint8_t* idmap, int images, void* stream) {
+    CCD_CHECK(mask && idmap && images >= 0, CCD_EINVAL);
+    if (images == 0) return CCD_OK;
+    CCD_LAUNCH(ccd::ccl_label_kernel, dim3(images), dim3(256), 0, stream, mask, idmap, images);
+    return ccd_rt_last_error();
+}
+int ccd_mask_to_idmap(const float* mask, uint8_t* idmap, int images, void* stream) {
+    CCD_CHECK(mask && idmap && images >= 0, CCD_EINVAL);
+    if (images == 0) return CCD_OK;
+    const long n = (long)images * ccd::CM_PIX;
+    CCD_LAUNCH(ccd::mask_to_idmap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mask, idmap, n);
+    return ccd_rt_last_error();
+}
+int ccd_seg_to_mask(const float* seg_logits, float* mask, int images, void* stream) {
+    CCD_CHECK(seg_logits && mask && images >= 0, CCD_EINVAL);
+    if (images == 0) return CCD_OK;
+    const long n = (long)images * ccd::CM_PIX;
+    CCD_LAUNCH(ccd::seg_to_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, seg_logits, mask, images);
+    return ccd_rt_last_error();
+}
+int ccd_warp_idmap(const uint8_t* src, const float* theta, int theta_stride, uint8_t* dst, int images, void* stream) {
+    CCD_CHECK(src && theta && dst && images >= 0 && theta_stride >= 6, CCD_EINVAL);
+    if (images == 0) return CCD_OK;
+    CCD_LAUNCH(ccd::warp_idmap_kernel, dim3(ccd::CM_PIX / 256, images), dim3(256), 0, stream, src, theta, theta_stride,
+               dst, images);
+    return ccd_rt_last_error();
+}
+int ccd_region_stats(const uint8_t* idmap, uint8_t* tok_plane, float* tok_coef, uint8_t* present, int views,
+                     void* stream) {
+    CCD_CHECK(idmap && tok_plane && tok_coef && present && views >= 0, CCD_EINVAL);
+    if (views == 0) return CCD_OK;
+    CCD_LAUNCH(ccd::region_stats_kernel, dim3(views), dim3(256), 0, stream, idmap, tok_plane, tok_coef, present, views);
+    return ccd_rt_last_error();
+}
+int ccd_select_scan(const uint8_t* present, int batch, int* nsel, int* offset, int* total, uint8_t* new_index,
+                    void* stream) {
+    CCD_CHECK(present && nsel && offset && total && new_index && batch > 0, CCD_EINVAL);
+    CCD_LAUNCH(ccd::select_scan_kernel, dim3(1), dim3(256), 0, stream, present, batch, nsel, offset, total, new_index);
+    return ccd_rt_last_error();
+}
+int ccd_region_pool_fwd(const ccd_bf16* feat, const uint8_t* tok_plane, const float* tok_coef, const int* nsel,
+                        const int* offset, const int* total, ccd_bf16* rows, int batch, int E, void* stream) {
+    CCD_CHECK(feat && tok_plane && tok_coef && nsel && offset && total && rows && batch > 0 && E > 0, CCD_EINVAL);
+    const size_t smem = (size_t)ccd::CM_PLANES * E * 4;
+    CCD_CHECK(smem <= 120 * 1024, CCD_ESHAPE);
+    CCD_LAUNCH(ccd::region_pool_fwd_kernel, dim3(2 * batch), dim3(256), smem, stream, feat, tok_plane, tok_coef, nsel,
+               offset, total, rows, batch, E);
+    return ccd_rt_last_error();
+}
+int ccd_region_pool_bwd(const ccd_bf16* d_rows, const uint8_t* tok_plane, const float* tok_coef, const int* nsel,
+                        const int* offset, const int* total, ccd_bf16* d_feat, int batch, int E, void* stream) {
+    CCD_CHECK(d_rows && tok_plane && tok_coef && nsel && offset && total && d_feat && batch > 0 && E > 0, CCD_EINVAL);
+    CCD_CHECK(E % 8 == 0, CCD_ESHAPE);
+    CCD_LAUNCH(ccd::region_pool_bwd_kernel, dim3(2 * batch), dim3(256), 0, stream, d_rows, tok_plane, tok_coef, nsel,
+               offset, total, d_feat, batch, E);
+    return ccd_rt_last_error();
+}
+int ccd_idmap_to_planes(const uint8_t* idmap, float* planes, int images, void* stream) {
+    CCD_CHECK(idmap && planes && images >= 0, CCD_EINVAL);
+    if (images == 0) return CCD_OK;
+    const long n = (long)images * ccd::CM_PLANES * ccd::CM_PIX;
+    CCD_LAUNCH(ccd::idmap_to_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, idmap, planes,
+               (long)images);
+    return ccd_rt_last_error();
+}
+int ccd_planes_to_idmap(const float* planes, uint8_t* idmap, int images, void* stream) {
+    CCD_CHECK(idmap && planes && images >= 0, CCD_EINVAL);
+    if (images == 0) return CCD_OK;
+    const long n = (long)images * ccd::CM_PIX;
+    CCD_LAUNCH(ccd::planes_to_idmap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, planes, idmap,
+               (long)images);
+    return ccd_rt_last_error();
+}
+
+// ------------------------------------------------------------------------------- DINO head pieces
+int ccd_l2norm_fwd(const ccd_bf16* x, ccd_bf16* y, float* inv, int max_rows, const int* d_rows, int rows_mul, int D,
+                   void* stream) {
+    CCD_CHECK(x && y && inv && max_rows >= 0, CCD_EINVAL);
+    if (max_rows == 0) return CCD_OK;
+    CCD_CHECK(D > 0 && D <= 64 * ccd::HD_MAX_PER_LANE, CCD_ESHAPE);
+    CCD_LAUNCH(ccd::l2norm_fwd_kernel, dim3((max_rows + 3) / 4), dim3(256), 0, stream, x, y, inv, max_rows, d_rows,
+               rows_mul, D);
+    return ccd_rt_last_error();
+}
+int ccd_l2norm_bwd(const ccd_bf16* x, const float* inv, const ccd_bf16* dy, ccd_bf16* dx, int max_rows,
+                   const int* d_rows, int rows_mul, int D, void* stream) {
+    CCD_CHECK(x && inv && dy && dx && max_rows >= 0, CCD_EINVAL);
+    if (max_rows == 0) return CCD_OK;
+    CCD_CHECK(D > 0 && D <= 64 * ccd::HD_MAX_PER_LANE, CCD_ESHAPE);
+    CCD_LAUNCH(ccd::l2norm_bwd_kernel, dim3((max_rows + 3) / 4), dim3(256), 0, stream, x, inv, dy, dx, max_rows, d_rows,
+               rows_mul, D);
+    return ccd_rt_last_error();
+}
+int ccd_weightnorm_fwd(const float* v, const float* g, ccd_bf16* w, ccd_bf16* w_t, float* inv, int K, int D,
+                       void* stream) {
+    CCD_CHECK(v && g && w && inv && K > 0 && D > 0, CCD_EINVAL);
+    const size_t smem = (size_t)32 * (D + 1) * 4;
+    CCD_CHECK(smem <= 64 * 1024, CCD_ESHAPE);
+    CCD_LAUNCH(ccd::weightnorm_fwd_kernel, dim3((K + 31) / 32), dim3(256), smem, stream, v, g, w, w_t, inv, K, D);
+    return ccd_rt_last_error();
+}
+int ccd_weightnorm_bwd(const float* v, const float* g, const float* inv, const float* dw, float* dv, float* dg, int K,
+                       int D, void* stream) {
+    CCD_CHECK(v && g && inv && dw && dv && K > 0 && D > 0, CCD_EINVAL);
+    CCD_LAUNCH(ccd::weightnorm_bwd_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, v, g, inv, dw, dv, dg, K, D);
+    return ccd_rt_last_error();
+}
+
+// ------------------------------------------------------------------------------- losses
+int ccd_dino_loss_fwd(const float* s_logits, const float* t_logits, const float* center, int K, const int* d_m,
+                      int max_rows, float student_temp, float teacher_temp, float* stats, float* loss_out,
+                      void* stream) {
+    CCD_CHECK(s_logits && t_logits && center && d_m && stats && loss_out, CCD_EINVAL);
+    CCD_CHECK(K > 0 && K % 4 == 0 && max_rows > 0 && student_temp > 0 && teacher_temp > 0, CCD_ESHAPE);
+    CCD_LAUNCH(ccd::dino_loss_fwd_kernel, dim3(max_rows), dim3(256), 0, stream, s_logits, t_logits, center, K, d_m,
+               max_rows, 1.0f / student_temp, 1.0f / teacher_temp, stats, loss_out);
+    return ccd_rt_last_error();
+}
+int ccd_dino_loss_bwd(const float* s_logits, const float* t_logits, const float* center, int K, const int* d_m,
+                      int max_rows, float student_temp, float teacher_temp, const float* stats, float grad_scale,
+                      ccd_bf16* d_logits, void* stream) {
+    CCD_CHECK(s_logits && t_logits && center && d_m && stats && d_logits, CCD_EINVAL);
+    CCD_CHECK(K > 0 && K % 4 == 0 && max_rows > 0 && student_temp > 0 && teacher_temp > 0, CCD_ESHAPE);
+    CCD_LAUNCH(ccd::dino_loss_bwd_kernel, dim3(max_rows), dim3(256), 0, stream, s_logits, t_logits, center, K, d_m,
+               max_rows, 1.0f / student_temp, 1.0f / teacher_temp, stats, grad_scale, d_logits);
+    return ccd_rt_last_error();
+}
+int ccd_colsum_f32(const float* x, int K, const int* d_rows, int rows_mul, int max_rows, float* out, void* stream) {
+    CCD_CHECK(x && out && K > 0 && K % 4 == 0 && max_rows > 0, CCD_EINVAL);
+    const int col_blocks = (K / 4 + 255) / 256;
+    int row_blocks = (8 * ccd_rt_num_cus() + col_blocks - 1) / col_blocks;
+    if (row_blocks > max_rows) row_blocks = max_rows;
+    const int rpb = (max_rows + row_blocks - 1) / row_blocks;
+    row_blocks = (max_rows + rpb - 1) / rpb;
+    CCD_LAUNCH(ccd::colsum_f32_kernel, dim3(col_blocks, row_blocks), dim3(256), 0, stream, x, K, d_rows, rows_mul,
+               max_rows, rpb, out);
+    return ccd_rt_last_error();
+}
+int ccd_center_ema(float* center, const float* batch_sum, int K, const int* d_m, int world, float momentum,
+                   void* stream) {
+    CCD_CHECK(center && batch_sum && d_m && K > 0 && world > 0, CCD_EINVAL);
+    CCD_LAUNCH(ccd::center_ema_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, center, batch_sum, K, d_m, world,
+               momentum);
+    return ccd_rt_last_error();
+}
+int ccd_seg_loss(const float* logits, const float* mask_a, const uint8_t* idmap_b, int half, float grad_scale,
+                 float* loss_out, float* d_logits, void* stream) {
+    CCD_CHECK(logits && mask_a && idmap_b && loss_out && half > 0, CCD_EINVAL);
+    const long npix = 2L * half * ccd::CM_PIX;
+    CCD_LAUNCH(ccd::seg_loss_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, logits, mask_a, idmap_b,
+               half, grad_scale, loss_out, d_logits);
+    return ccd_rt_last_error();
+}
+
+// ------------------------------------------------------------------------------- optimiser
+int ccd_seg_sumsq(const float* grad, const int* chunk_seg, const long* chunk_begin, const int* chunk_len, int nchunks,
+                  float* norm2, void* stream) {
+    CCD_CHECK(grad && chunk_seg && chunk_begin && chunk_len && norm2 && nchunks > 0, CCD_EINVAL);
+    CCD_LAUNCH(ccd::seg_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, grad, chunk_seg, chunk_begin, chunk_len, norm2);
+    return ccd_rt_last_error();
+}
+int ccd_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, ccd_bf16* mirror,
+              const int* chunk_seg, const long* chunk_begin, const int* chunk_len, int nchunks,
+              const ccd_seg_hyper* hyper, const float* norm2, float clip, float beta1, float beta2, float eps,
+              void* stream) {
+    CCD_CHECK(param && grad && exp_avg && exp_avg_sq && chunk_seg && chunk_begin && chunk_len && hyper && norm2, CCD_EINVAL);
+    CCD_CHECK(nchunks > 0, CCD_EINVAL);
+    static_assert(sizeof(ccd_seg_hyper) == sizeof(ccd::SegHyper), "hyper layout");
+    CCD_LAUNCH(ccd::adamw_kernel, dim3(nchunks), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, mirror, chunk_seg,
+               chunk_begin, chunk_len, reinterpret_cast<const ccd::SegHyper*>(hyper), norm2, clip, beta1, beta2, eps);
+    return ccd_rt_last_error();
+}
+int ccd_clip_scale(float* grad, const int* chunk_seg, const long* chunk_begin, const int* chunk_len, int nchunks,
+                   const float* norm2, float clip, void* stream) {
+    CCD_CHECK(grad && chunk_seg && chunk_begin && chunk_len && norm2 && nchunks > 0 && clip > 0, CCD_EINVAL);
+    CCD_LAUNCH(ccd::clip_scale_kernel, dim3(nchunks), dim3(256), 0, stream, grad, chunk_seg, chunk_begin, chunk_len, norm2,
+               clip);
+    return ccd_rt_last_error();
+}
+int ccd_ema(float* teacher, const float* student, ccd_bf16* mirror, long n, float m, float one_minus_m, void* stream) {
+    CCD_CHECK(teacher && student && n >= 0, CCD_EINVAL);
+    if (n == 0) return CCD_OK;
+    CCD_LAUNCH(ccd::ema_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, teacher, student, mirror, n, m,
+               one_minus_m);
     return ccd_rt_last_error();
 }
 

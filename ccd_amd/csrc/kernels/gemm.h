@@ -43,6 +43,8 @@ struct GemmParams {
     int k_per_split;        // TN: contraction rows handled by one blockIdx.z slice (multiple of 64)
     int m_fastest;          // tile order: 0 = column tiles fastest, 1 = row tiles fastest
     float alpha;            // scales acc before the epilogue
+    const int* d_rows;      // optional device-side row count: NT rows M / TN contraction length K become
+    int rows_mul;           //   min(static value, d_rows[0] * rows_mul); the grid is sized for the static value
 };
 
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 64;
@@ -151,16 +153,23 @@ __device__ __forceinline__ void gemm_epilogue_row8(const GemmParams& p, int gm, 
 
 template <bool TN, int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+    const int m_static = p.M;                               // the launch grid was sized for the static shape
+    if (p.d_rows) {
+        const int dyn = p.d_rows[0] * p.rows_mul;
+        if (TN) p.K = dyn < p.K ? dyn : p.K;
+        else p.M = dyn < p.M ? dyn : p.M;
+    }
     char* smem = dynamic_smem();
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wm = w >> 1, wn = w & 1;
 
-    const int tiles_m = (p.M + GEMM_BM - 1) / GEMM_BM, tiles_n = (p.N + GEMM_BN - 1) / GEMM_BN;
+    const int tiles_m = (m_static + GEMM_BM - 1) / GEMM_BM, tiles_n = (p.N + GEMM_BN - 1) / GEMM_BN;
     const unsigned tile = xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n));
     int tm, tn;
     if (p.m_fastest) { tm = tile % tiles_m; tn = tile / tiles_m; }
     else { tn = tile % tiles_n; tm = tile / tiles_n; }
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    if (m0 >= p.M) return;                                  // only possible with a device-side row count
 
     int k_begin = 0, k_end = p.K;
     if (TN) {

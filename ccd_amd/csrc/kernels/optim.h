@@ -1,0 +1,106 @@
+// optim.h - the parameter update of train.py:244-272 as three multi-tensor kernels over the flat parameter arena:
+//   seg_sumsq_kernel   per-tensor squared gradient norms            (clip_gradients, modules/utils.py:132-141)
+//   adamw_kernel       per-TENSOR clip (coef = clip/(norm+1e-6) if < 1) fused with torch.optim.AdamW's update
+//                      (train.py:133, defaults betas (0.9,0.999), eps 1e-8) and the bf16 mirror refresh
+//   ema_kernel         teacher = m*teacher + (1-m)*student          (train.py:264-272) + teacher bf16 mirror
+// A "segment" is one parameter tensor; the arena is cut into chunks of <= 1024 elements that never straddle a
+// segment (tables built on the host once).  HBM-bound: AdamW touches 4+4+4 B read, 4+4+4+2 B written per element.
+#pragma once
+
+namespace ccd {
+
+constexpr int OPT_CHUNK = 1024;
+
+struct SegHyper {        // per segment, refreshed by the host every iteration
+    float lr_wd;         // lr * weight_decay (0 for biases / 1-D tensors, modules/utils.py:643-654)
+    float step_size;     // lr / (1 - beta1^t)
+    float inv_sqrt_bc2;  // 1 / sqrt(1 - beta2^t)
+    float active;        // 0: tensor has no gradient this iteration (unused param, or cancelled last layer)
+};
+
+__global__ __launch_bounds__(256) void seg_sumsq_kernel(const float* __restrict__ grad, const int* __restrict__ chunk_seg,
+                                                        const long* __restrict__ chunk_begin,
+                                                        const int* __restrict__ chunk_len, float* __restrict__ norm2) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const long base = chunk_begin[c];
+    const int len = chunk_len[c];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < len; i += 256) { const float g = grad[base + i]; s += g * g; }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(norm2 + chunk_seg[c], red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                    float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
+                                                    bf16_t* __restrict__ mirror, const int* __restrict__ chunk_seg,
+                                                    const long* __restrict__ chunk_begin,
+                                                    const int* __restrict__ chunk_len,
+                                                    const SegHyper* __restrict__ hyper,
+                                                    const float* __restrict__ norm2, float clip, float beta1,
+                                                    float beta2, float eps) {
+    const int c = blockIdx.x;
+    const int seg = chunk_seg[c];
+    const SegHyper h = hyper[seg];
+    if (h.active == 0.0f) return;
+    float coef = 1.0f;
+    if (clip > 0.f) {
+        const float cc = clip / (sqrtf(norm2[seg]) + 1e-6f);
+        if (cc < 1.0f) coef = cc;
+    }
+    const long base = chunk_begin[c];
+    const int len = chunk_len[c];
+    for (int i = threadIdx.x; i < len; i += 256) {
+        const long k = base + i;
+        const float g = grad[k] * coef;
+        float p = param[k];
+        p *= 1.0f - h.lr_wd;
+        const float m = exp_avg[k] * beta1 + (1.0f - beta1) * g;
+        const float v = exp_avg_sq[k] * beta2 + (1.0f - beta2) * g * g;
+        const float denom = sqrtf(v) * h.inv_sqrt_bc2 + eps;
+        p -= h.step_size * (m / denom);
+        param[k] = p;
+        exp_avg[k] = m;
+        exp_avg_sq[k] = v;
+        if (mirror) mirror[k] = f2bf(p);
+    }
+}
+
+// in-place per-tensor clip only (when an external optimizer is used): grad *= min(1, clip/(norm+1e-6))
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ grad, const int* __restrict__ chunk_seg,
+                                                         const long* __restrict__ chunk_begin,
+                                                         const int* __restrict__ chunk_len,
+                                                         const float* __restrict__ norm2, float clip) {
+    const int c = blockIdx.x;
+    const float cc = clip / (sqrtf(norm2[chunk_seg[c]]) + 1e-6f);
+    if (!(cc < 1.0f)) return;
+    const long base = chunk_begin[c];
+    for (int i = threadIdx.x; i < chunk_len[c]; i += 256) grad[base + i] *= cc;
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ teacher, const float* __restrict__ student,
+                                                  bf16_t* __restrict__ mirror, long n, float m, float om) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        f32x4v t = *reinterpret_cast<f32x4v*>(teacher + i);
+        const f32x4v s = *reinterpret_cast<const f32x4v*>(student + i);
+        t.x = t.x * m + om * s.x; t.y = t.y * m + om * s.y; t.z = t.z * m + om * s.z; t.w = t.w * m + om * s.w;
+        *reinterpret_cast<f32x4v*>(teacher + i) = t;
+        if (mirror) {
+            u32x2 o;
+            o.x = pack_bf2(t.x, t.y);
+            o.y = pack_bf2(t.z, t.w);
+            *reinterpret_cast<u32x2*>(mirror + i) = o;
+        }
+    } else {
+        for (long k = i; k < n; ++k) {
+            const float t = teacher[k] * m + om * student[k];
+            teacher[k] = t;
+            if (mirror) mirror[k] = f2bf(t);
+        }
+    }
+}
+
+}  // namespace ccd

@@ -20,7 +20,7 @@ def _chk(t, dtype, name):
 
 
 def gemm_nt(a, b, *, epilogue=EPI_BF16, out=None, out2=None, bias=None, resid=None, rowscale=None,
-            rows_per_sample=1, aux=None, alpha=1.0, m_fastest=None):
+            rows_per_sample=1, aux=None, alpha=1.0, m_fastest=None, d_rows=None, rows_mul=1):
     """out[M,N] = a[M,K] @ b[N,K]^T with a fused epilogue (see include/ccd_hip.h)."""
     _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(bias, F32, "bias"); _chk(resid, F32, "resid")
     _chk(rowscale, F32, "rowscale"); _chk(aux, BF16, "aux")
@@ -40,11 +40,11 @@ def gemm_nt(a, b, *, epilogue=EPI_BF16, out=None, out2=None, bias=None, resid=No
                                out.stride(0), _lib.ptr(out2), 0 if out2 is None else out2.stride(0), _lib.ptr(bias),
                                _lib.ptr(resid), 0 if resid is None else resid.stride(0), _lib.ptr(rowscale),
                                rows_per_sample, _lib.ptr(aux), 0 if aux is None else aux.stride(0), float(alpha),
-                               int(m_fastest), _lib.stream()), "gemm_nt")
+                               int(m_fastest), _lib.ptr(d_rows), int(rows_mul), _lib.stream()), "gemm_nt")
     return (out, out2) if epilogue == EPI_GELU else out
 
 
-def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, splits=0):
+def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, splits=0, d_rows=None, rows_mul=1):
     """out[P,Q] (+)= a[Mc,P]^T @ b[Mc,Q]  (fp32 out; accumulate=True adds with fp32 atomics, split over Mc)."""
     _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(out, F32, "out")
     Mc, Pd = a.shape
@@ -53,7 +53,8 @@ def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, splits=0):
     lib = _lib.get()
     _lib.check(lib.ccd_gemm_tn(_lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0), Pd, Q, Mc,
                                EPI_ATOMIC if accumulate else EPI_F32, _lib.ptr(out), out.stride(0), float(alpha),
-                               int(splits) if accumulate else 1, _lib.stream()), "gemm_tn")
+                               int(splits) if accumulate else 1, _lib.ptr(d_rows), int(rows_mul), _lib.stream()),
+               "gemm_tn")
     return out
 
 
@@ -101,3 +102,197 @@ def attention_bwd(qkv, out, d_out, lse, heads, scale):
                                             _lib.ptr(delta), _lib.ptr(d_qkv), views, heads, float(scale),
                                             _lib.stream()), "attention_bwd")
     return d_qkv
+
+
+U8, I32 = torch.uint8, torch.int32
+
+
+def _call(name, *args):
+    _lib.check(getattr(_lib.get(), name)(*args, _lib.stream()), name)
+
+
+# ------------------------------------------------------------------------------------------ patch embed & helpers
+def patch_embed_fwd(img, w, bias, pos, out=None):
+    views, E = img.shape[0], w.shape[0]
+    assert img.dtype == F32 and img.is_contiguous() and tuple(img.shape[1:]) == (3, 32, 128)
+    if out is None:
+        out = torch.empty((views * 256, E), dtype=F32, device=img.device)
+    _call("ccd_patch_embed_fwd", _lib.ptr(img), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(pos), _lib.ptr(out), views, E)
+    return out
+
+
+def patch_embed_bwd(img, g, d_w, d_bias, d_pos):
+    views, E = img.shape[0], g.shape[-1]
+    _call("ccd_patch_embed_bwd", _lib.ptr(img), _lib.ptr(g), _lib.ptr(d_w), _lib.ptr(d_bias), _lib.ptr(d_pos), views, E)
+
+
+def small_matmul(a, b, out, trans_a=False, accumulate=False):
+    """out[M,N] (+)= op(a) @ b, fp32."""
+    K, N = b.shape
+    M = a.shape[1] if trans_a else a.shape[0]
+    _call("ccd_small_matmul_f32", _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), M, N, K, int(trans_a), int(accumulate))
+    return out
+
+
+def colsum_bf16(x, out, d_rows=None, rows_mul=1):
+    rows, N = x.shape
+    _call("ccd_colsum_bf16", _lib.ptr(x), x.stride(0), rows, N, _lib.ptr(d_rows), int(rows_mul), _lib.ptr(out))
+    return out
+
+
+def cast_bf16(src, dst):
+    _call("ccd_cast_bf16", _lib.ptr(src), _lib.ptr(dst), src.numel())
+    return dst
+
+
+def mirror_bf16(descs_dev, ndesc, total_tiles):
+    _call("ccd_mirror_bf16", _lib.ptr(descs_dev), ndesc, total_tiles)
+
+
+# ------------------------------------------------------------------------------------------ character-region path
+def ccl_label(mask):
+    """mask [B,32,128] fp32 (nonzero = text) -> uint8 id map [B,32,128] (255 = background)."""
+    assert mask.dtype == F32 and mask.is_contiguous() and tuple(mask.shape[1:]) == (32, 128)
+    out = torch.empty(mask.shape, dtype=U8, device=mask.device)
+    _call("ccd_ccl_label", _lib.ptr(mask), _lib.ptr(out), mask.shape[0])
+    return out
+
+
+def mask_to_idmap(mask):
+    out = torch.empty(mask.shape, dtype=U8, device=mask.device)
+    _call("ccd_mask_to_idmap", _lib.ptr(mask), _lib.ptr(out), mask.shape[0])
+    return out
+
+
+def seg_to_mask(seg_logits, images):
+    out = torch.empty((images, 32, 128), dtype=F32, device=seg_logits.device)
+    _call("ccd_seg_to_mask", _lib.ptr(seg_logits), _lib.ptr(out), images)
+    return out
+
+
+def warp_idmap(src, theta):
+    """src uint8 [B,32,128], theta fp32 [B,3,3] (or [B,2,3]) -> warped id map (view 2)."""
+    assert src.dtype == U8 and src.is_contiguous() and theta.dtype == F32 and theta.is_contiguous()
+    out = torch.empty_like(src)
+    _call("ccd_warp_idmap", _lib.ptr(src), _lib.ptr(theta), theta.stride(0), _lib.ptr(out), src.shape[0])
+    return out
+
+
+def region_stats(idmap):
+    views = idmap.shape[0]
+    dev = idmap.device
+    tok_plane = torch.empty((views, 256), dtype=U8, device=dev)
+    tok_coef = torch.empty((views, 256), dtype=F32, device=dev)
+    present = torch.empty((views, 26), dtype=U8, device=dev)
+    _call("ccd_region_stats", _lib.ptr(idmap), _lib.ptr(tok_plane), _lib.ptr(tok_coef), _lib.ptr(present), views)
+    return tok_plane, tok_coef, present
+
+
+def select_scan(present, batch):
+    dev = present.device
+    nsel = torch.empty(batch, dtype=I32, device=dev)
+    offset = torch.empty(batch, dtype=I32, device=dev)
+    total = torch.empty(1, dtype=I32, device=dev)
+    new_index = torch.empty((batch, 26), dtype=U8, device=dev)
+    _call("ccd_select_scan", _lib.ptr(present), batch, _lib.ptr(nsel), _lib.ptr(offset), _lib.ptr(total),
+          _lib.ptr(new_index))
+    return nsel, offset, total, new_index
+
+
+def region_pool_fwd(feat, tok_plane, tok_coef, nsel, offset, total, rows, batch):
+    E = feat.shape[-1]
+    _call("ccd_region_pool_fwd", _lib.ptr(feat), _lib.ptr(tok_plane), _lib.ptr(tok_coef), _lib.ptr(nsel),
+          _lib.ptr(offset), _lib.ptr(total), _lib.ptr(rows), batch, E)
+    return rows
+
+
+def region_pool_bwd(d_rows, tok_plane, tok_coef, nsel, offset, total, d_feat, batch):
+    E = d_feat.shape[-1]
+    _call("ccd_region_pool_bwd", _lib.ptr(d_rows), _lib.ptr(tok_plane), _lib.ptr(tok_coef), _lib.ptr(nsel),
+          _lib.ptr(offset), _lib.ptr(total), _lib.ptr(d_feat), batch, E)
+    return d_feat
+
+
+def idmap_to_planes(idmap):
+    out = torch.empty((idmap.shape[0], 26, 32, 128), dtype=F32, device=idmap.device)
+    _call("ccd_idmap_to_planes", _lib.ptr(idmap), _lib.ptr(out), idmap.shape[0])
+    return out
+
+
+def planes_to_idmap(planes):
+    planes = planes.contiguous().float()
+    out = torch.empty((planes.shape[0], 32, 128), dtype=U8, device=planes.device)
+    _call("ccd_planes_to_idmap", _lib.ptr(planes), _lib.ptr(out), planes.shape[0])
+    return out
+
+
+# ------------------------------------------------------------------------------------------ DINO head pieces
+def l2norm_fwd(x, y, inv, d_rows=None, rows_mul=1):
+    _call("ccd_l2norm_fwd", _lib.ptr(x), _lib.ptr(y), _lib.ptr(inv), x.shape[0], _lib.ptr(d_rows), rows_mul, x.shape[1])
+
+
+def l2norm_bwd(x, inv, dy, dx, d_rows=None, rows_mul=1):
+    _call("ccd_l2norm_bwd", _lib.ptr(x), _lib.ptr(inv), _lib.ptr(dy), _lib.ptr(dx), x.shape[0], _lib.ptr(d_rows),
+          rows_mul, x.shape[1])
+
+
+def weightnorm_fwd(v, g, w, w_t, inv):
+    K, D = v.shape
+    _call("ccd_weightnorm_fwd", _lib.ptr(v), _lib.ptr(g), _lib.ptr(w), _lib.ptr(w_t), _lib.ptr(inv), K, D)
+
+
+def weightnorm_bwd(v, g, inv, dw, dv, dg):
+    K, D = v.shape
+    _call("ccd_weightnorm_bwd", _lib.ptr(v), _lib.ptr(g), _lib.ptr(inv), _lib.ptr(dw), _lib.ptr(dv), _lib.ptr(dg), K, D)
+
+
+# ------------------------------------------------------------------------------------------ losses
+def dino_loss_fwd(s_logits, t_logits, center, d_m, student_temp, teacher_temp, stats, loss_out):
+    max_rows, K = s_logits.shape
+    _call("ccd_dino_loss_fwd", _lib.ptr(s_logits), _lib.ptr(t_logits), _lib.ptr(center), K, _lib.ptr(d_m), max_rows,
+          float(student_temp), float(teacher_temp), _lib.ptr(stats), _lib.ptr(loss_out))
+
+
+def dino_loss_bwd(s_logits, t_logits, center, d_m, student_temp, teacher_temp, stats, grad_scale, d_logits):
+    max_rows, K = s_logits.shape
+    _call("ccd_dino_loss_bwd", _lib.ptr(s_logits), _lib.ptr(t_logits), _lib.ptr(center), K, _lib.ptr(d_m), max_rows,
+          float(student_temp), float(teacher_temp), _lib.ptr(stats), float(grad_scale), _lib.ptr(d_logits))
+
+
+def colsum_f32(x, out, d_rows=None, rows_mul=1):
+    max_rows, K = x.shape
+    _call("ccd_colsum_f32", _lib.ptr(x), K, _lib.ptr(d_rows), rows_mul, max_rows, _lib.ptr(out))
+
+
+def center_ema(center, batch_sum, d_m, world, momentum):
+    _call("ccd_center_ema", _lib.ptr(center), _lib.ptr(batch_sum), center.numel(), _lib.ptr(d_m), int(world),
+          float(momentum))
+
+
+def seg_loss(logits, mask_a, idmap_b, grad_scale, loss_out, d_logits=None):
+    half = mask_a.shape[0]
+    assert logits.shape[0] == 2 * half and logits.is_contiguous()
+    _call("ccd_seg_loss", _lib.ptr(logits), _lib.ptr(mask_a), _lib.ptr(idmap_b), half, float(grad_scale),
+          _lib.ptr(loss_out), _lib.ptr(d_logits))
+
+
+# ------------------------------------------------------------------------------------------ optimiser
+def seg_sumsq(grad, chunk_seg, chunk_begin, chunk_len, norm2):
+    _call("ccd_seg_sumsq", _lib.ptr(grad), _lib.ptr(chunk_seg), _lib.ptr(chunk_begin), _lib.ptr(chunk_len),
+          chunk_seg.numel(), _lib.ptr(norm2))
+
+
+def adamw(param, grad, exp_avg, exp_avg_sq, mirror, chunk_seg, chunk_begin, chunk_len, hyper, norm2, clip,
+          beta1=0.9, beta2=0.999, eps=1e-8):
+    _call("ccd_adamw", _lib.ptr(param), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), _lib.ptr(mirror),
+          _lib.ptr(chunk_seg), _lib.ptr(chunk_begin), _lib.ptr(chunk_len), chunk_seg.numel(), _lib.ptr(hyper),
+          _lib.ptr(norm2), float(clip), float(beta1), float(beta2), float(eps))
+
+
+def clip_scale(grad, chunk_seg, chunk_begin, chunk_len, norm2, clip):
+    _call("ccd_clip_scale", _lib.ptr(grad), _lib.ptr(chunk_seg), _lib.ptr(chunk_begin), _lib.ptr(chunk_len),
+          chunk_seg.numel(), _lib.ptr(norm2), float(clip))
+
+
+def ema(teacher, student, mirror, m):
+    _call("ccd_ema", _lib.ptr(teacher), _lib.ptr(student), _lib.ptr(mirror), teacher.numel(), float(m), float(1.0 - m))

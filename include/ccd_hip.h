@@ -45,11 +45,13 @@ const char* ccd_build_info(void);
 int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, int epilogue,
                 void* C, long ldc, void* C2, long ldc2, const float* bias, const float* resid, long ldr,
                 const float* rowscale, int rows_per_sample, const ccd_bf16* aux, long ldaux, float alpha,
-                int m_fastest, void* stream);
+                int m_fastest, const int* d_rows, int rows_mul, void* stream);
 /* C[P,Q] (+)= sum_m A[m,P] * B[m,Q]   (weight gradients dW = dY^T X of every Linear; autograd of the above)
  * P % 8 == 0, Q % 8 == 0; epilogue CCD_EPI_ATOMIC accumulates into fp32 C (split over m), CCD_EPI_F32 stores. */
 int ccd_gemm_tn(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P, int Q, int Mc, int epilogue,
-                float* C, long ldc, float alpha, int splits, void* stream);
+                float* C, long ldc, float alpha, int splits, const int* d_rows, int rows_mul, void* stream);
+/* d_rows (optional, both GEMMs): device int; the effective row count (NT: M, TN: Mc) is
+ * min(static value, d_rows[0] * rows_mul) so data-dependent row counts never reach the host. */
 
 /* ---------------------------------------------------------------- LayerNorm (eps 1e-6), vit.py:99,103,156,162-166 */
 int ccd_ln_fwd(const float* x, const float* gamma, const float* beta, ccd_bf16* y, float* mean, float* rstd,
@@ -64,6 +66,90 @@ int ccd_attention_fwd(const ccd_bf16* qkv, ccd_bf16* out, float* lse, int views,
                       void* stream);
 int ccd_attention_bwd(const ccd_bf16* qkv, const ccd_bf16* out, const ccd_bf16* d_out, const float* lse,
                       float* delta_ws, ccd_bf16* d_qkv, int views, int heads, float scale, void* stream);
+
+/* ---------------------------------------------------------------- patch embedding, vit.py:128-131,225-236
+ * img [views,3,32,128] fp32 NCHW; w [E,3,4,4]; pos [256,E] = the bicubically resampled pos_embed; out fp32 [views*256,E] */
+int ccd_patch_embed_fwd(const float* img, const float* w, const float* bias, const float* pos, float* out, int views,
+                        int E, void* stream);
+/* g = d(out); d_w, d_bias, d_pos are ACCUMULATED (fp32 atomics) */
+int ccd_patch_embed_bwd(const float* img, const float* g, float* d_w, float* d_bias, float* d_pos, int views, int E,
+                        void* stream);
+/* C[M,N] (+)= op(A) . B, fp32, tiny problems (bicubic pos-embed resampling = fixed 256x256 linear map, vit.py:182-201) */
+int ccd_small_matmul_f32(const float* A, const float* B, float* C, int M, int N, int K, int trans_a, int accumulate,
+                         void* stream);
+/* out[n] += sum_rows x[row,n] (bias gradients) */
+int ccd_colsum_bf16(const ccd_bf16* x, long ld, int rows, int N, const int* d_rows, int rows_mul, float* out,
+                    void* stream);
+/* bf16 mirrors (and transposed mirrors) of a batch of fp32 matrices */
+typedef struct ccd_mirror_desc {
+    const float* src;
+    ccd_bf16* dst;    /* [rows, cols] or NULL */
+    ccd_bf16* dst_t;  /* [cols, rows] or NULL */
+    int rows, cols;
+    int tile_begin;   /* first 32x32 tile of this matrix in the launch (prefix sum) */
+    int pad_;
+} ccd_mirror_desc;
+int ccd_mirror_bf16(const ccd_mirror_desc* d_descs, int ndesc, int total_tiles, void* stream);
+int ccd_cast_bf16(const float* src, ccd_bf16* dst, long n, void* stream);
+
+/* ---------------------------------------------------------------- character-region path (id maps: uint8, 255 = none)
+ * label_cluster.forward, Dino/utils/DBSCAN.py:65-103: mask [images,32,128] (nonzero = text) -> idmap            */
+int ccd_ccl_label(const float* mask, uint8_t* idmap, int images, void* stream);
+int ccd_mask_to_idmap(const float* mask, uint8_t* idmap, int images, void* stream);
+/* softmax(seg)[:,1] > 0.5 of the first `images` images (dino_vision.py:65-66); seg [>=images,2,32,128] fp32 */
+int ccd_seg_to_mask(const float* seg_logits, float* mask, int images, void* stream);
+/* affine_grid(theta[:, :2]) + grid_sample(bilinear) > 0.1, dino_vision.py:72-77 / train.py:234-236; theta row stride in floats */
+int ccd_warp_idmap(const uint8_t* src, const float* theta, int theta_stride, uint8_t* dst, int images, void* stream);
+/* ABIDINOModel.attention, dino_vision.py:38-49, in sparse form: per token its plane and normalised weight */
+int ccd_region_stats(const uint8_t* idmap, uint8_t* tok_plane, float* tok_coef, uint8_t* present, int views,
+                     void* stream);
+/* dino_vision.py:82-85: nsel[b], offset[b], total[0] = M, new_index [batch,26] */
+int ccd_select_scan(const uint8_t* present, int batch, int* nsel, int* offset, int* total, uint8_t* new_index,
+                    void* stream);
+/* rows [2M,E] bf16 = gathered pooled character vectors of both views (dino_vision.py:44-47,87); views = 2*batch */
+int ccd_region_pool_fwd(const ccd_bf16* feat, const uint8_t* tok_plane, const float* tok_coef, const int* nsel,
+                        const int* offset, const int* total, ccd_bf16* rows, int batch, int E, void* stream);
+int ccd_region_pool_bwd(const ccd_bf16* d_rows, const uint8_t* tok_plane, const float* tok_coef, const int* nsel,
+                        const int* offset, const int* total, ccd_bf16* d_feat, int batch, int E, void* stream);
+int ccd_idmap_to_planes(const uint8_t* idmap, float* planes, int images, void* stream);
+int ccd_planes_to_idmap(const float* planes, uint8_t* idmap, int images, void* stream);
+
+/* ---------------------------------------------------------------- DINOHead pieces, vit.py:313,326 */
+int ccd_l2norm_fwd(const ccd_bf16* x, ccd_bf16* y, float* inv, int max_rows, const int* d_rows, int rows_mul, int D,
+                   void* stream);
+int ccd_l2norm_bwd(const ccd_bf16* x, const float* inv, const ccd_bf16* dy, ccd_bf16* dx, int max_rows,
+                   const int* d_rows, int rows_mul, int D, void* stream);
+int ccd_weightnorm_fwd(const float* v, const float* g, ccd_bf16* w, ccd_bf16* w_t, float* inv, int K, int D,
+                       void* stream);
+int ccd_weightnorm_bwd(const float* v, const float* g, const float* inv, const float* dw, float* dv, float* dg, int K,
+                       int D, void* stream);
+
+/* ---------------------------------------------------------------- DINOLoss, Dino/loss/Dino_loss.py:59-143
+ * student/teacher logits fp32 [>=2M, K]; d_m = device M; stats [max_rows,4]; loss_out accumulates the scalar */
+int ccd_dino_loss_fwd(const float* s_logits, const float* t_logits, const float* center, int K, const int* d_m,
+                      int max_rows, float student_temp, float teacher_temp, float* stats, float* loss_out,
+                      void* stream);
+int ccd_dino_loss_bwd(const float* s_logits, const float* t_logits, const float* center, int K, const int* d_m,
+                      int max_rows, float student_temp, float teacher_temp, const float* stats, float grad_scale,
+                      ccd_bf16* d_logits, void* stream);
+int ccd_colsum_f32(const float* x, int K, const int* d_rows, int rows_mul, int max_rows, float* out, void* stream);
+int ccd_center_ema(float* center, const float* batch_sum, int K, const int* d_m, int world, float momentum,
+                   void* stream);
+/* softmax -> cross_entropy (double softmax) of the seg logits [2*half,2,32,128]; d_logits may be NULL */
+int ccd_seg_loss(const float* logits, const float* mask_a, const uint8_t* idmap_b, int half, float grad_scale,
+                 float* loss_out, float* d_logits, void* stream);
+
+/* ---------------------------------------------------------------- optimiser, train.py:244-272 */
+typedef struct ccd_seg_hyper { float lr_wd, step_size, inv_sqrt_bc2, active; } ccd_seg_hyper;
+int ccd_seg_sumsq(const float* grad, const int* chunk_seg, const long* chunk_begin, const int* chunk_len, int nchunks,
+                  float* norm2, void* stream);
+int ccd_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, ccd_bf16* mirror,
+              const int* chunk_seg, const long* chunk_begin, const int* chunk_len, int nchunks,
+              const ccd_seg_hyper* hyper, const float* norm2, float clip, float beta1, float beta2, float eps,
+              void* stream);
+int ccd_clip_scale(float* grad, const int* chunk_seg, const long* chunk_begin, const int* chunk_len, int nchunks,
+                   const float* norm2, float clip, void* stream);
+int ccd_ema(float* teacher, const float* student, ccd_bf16* mirror, long n, float m, float one_minus_m, void* stream);
 
 #ifdef __cplusplus
 }

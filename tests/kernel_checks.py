@@ -118,3 +118,262 @@ def check_attention(dev, views, heads, seed=3, spike=False):
     for i, nm in enumerate("qkv"):
         close(d_qkv[..., i * E:(i + 1) * E], want[..., i * E:(i + 1) * E], 4e-2, 4e-2 * want.abs().max().item(),
               f"attn/d{nm}")
+
+
+# =========================================================================================== round-2 kernels
+import os
+import struct
+
+import numpy as np
+
+from oracle import ccd_oracle as O
+from oracle import ccl_np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def check_ccl(dev):
+    g = np.load(os.path.join(GOLD, "ccl_cases.npz"))
+    masks = torch.from_numpy(g["masks"].astype(np.float32)).to(dev)
+    got = ops.ccl_label(masks).cpu().numpy()
+    for name, out, want, tie in zip(g["names"], got, g["idmaps"], g["has_tie"]):
+        if not tie:
+            np.testing.assert_array_equal(out, want, err_msg=str(name))
+        else:
+            np.testing.assert_array_equal(out, ccl_np.label_idmap(g["masks"][list(g["names"]).index(name)]))
+    rs = np.random.RandomState(5)
+    rnd_masks = (rs.uniform(size=(24, 32, 128)) < rs.uniform(0.2, 0.75, size=(24, 1, 1))).astype(np.float32)
+    got = ops.ccl_label(torch.from_numpy(rnd_masks).to(dev)).cpu().numpy()
+    for m, o in zip(rnd_masks, got):
+        np.testing.assert_array_equal(o, ccl_np.label_idmap(m))
+
+
+def check_warp(dev):
+    g = np.load(os.path.join(GOLD, "small_step.npz"))
+    for p in ("s0/", "s1/"):
+        ids = g[p + "zero_idmap"]
+        B = ids.shape[0] // 2
+        theta = torch.from_numpy(g[p + "metrics"]).to(dev)
+        got = ops.warp_idmap(torch.from_numpy(ids[:B].copy()).to(dev), theta).cpu().numpy()
+        np.testing.assert_array_equal(got, ids[B:], err_msg=p + "clusters")
+        m = torch.from_numpy(g[p + "masks"].astype(np.float32)).to(dev)
+        mi = ops.warp_idmap(ops.mask_to_idmap(m), theta).cpu().numpy()
+        np.testing.assert_array_equal((mi != 255).astype(np.uint8), g[p + "masks_image"], err_msg=p + "gt")
+    ids = g["pred/zero_idmap"]
+    B = ids.shape[0] // 2
+    mask = torch.from_numpy(g["pred/mask"].astype(np.float32)).to(dev)
+    src = ops.ccl_label(mask)
+    np.testing.assert_array_equal(src.cpu().numpy(), ids[:B])
+    got = ops.warp_idmap(src, torch.from_numpy(g["pred/metrics"]).to(dev)).cpu().numpy()
+    np.testing.assert_array_equal(got, ids[B:])
+
+
+def check_region(dev, E=128, seed=7):
+    g = np.load(os.path.join(GOLD, "small_step.npz"))
+    ids = np.concatenate([g["s0/zero_idmap"], g["pred/zero_idmap"]])          # two different kinds of maps
+    ids = np.concatenate([ids[:8], ids[16:24], ids[8:16], ids[24:32]])         # [view1 x16, view2 x16]
+    B = ids.shape[0] // 2
+    gen = torch.Generator().manual_seed(seed)
+    feat = rnd((2 * B, 256, E), gen).to(BF)
+    planes = torch.from_numpy(ccl_np.idmap_to_planes(ids))
+    region_f = feat.float().reshape(2 * B, 8, 32, E).permute(0, 3, 1, 2).requires_grad_(True)
+    vecs, index = O.region_pool(region_f, planes)
+    rows_ref, new_index_ref = O.select_rows(vecs, index)
+    idm = torch.from_numpy(ids).to(dev)
+    tok_plane, tok_coef, present = ops.region_stats(idm)
+    np.testing.assert_array_equal(present.cpu().numpy().astype(bool), index.numpy())
+    nsel, offset, total, new_index = ops.select_scan(present, B)
+    np.testing.assert_array_equal(new_index.cpu().numpy().astype(bool), new_index_ref.numpy())
+    M = int(total.cpu().item())
+    assert 2 * M == rows_ref.shape[0]
+    rows = torch.zeros((2 * 26 * B, E), dtype=BF).to(dev)
+    ops.region_pool_fwd(feat.to(dev), tok_plane, tok_coef, nsel, offset, total, rows, B)
+    close(rows[:2 * M], rows_ref, 1e-2, 1e-2, "pool/rows")
+    d_rows = torch.zeros((2 * 26 * B, E), dtype=BF)
+    d_rows[:2 * M] = rnd((2 * M, E), gen).to(BF)
+    rows_ref.backward(d_rows[:2 * M].float())
+    d_feat = torch.empty((2 * B, 256, E), dtype=BF).to(dev)
+    ops.region_pool_bwd(d_rows.to(dev), tok_plane, tok_coef, nsel, offset, total, d_feat, B)
+    want = region_f.grad.permute(0, 2, 3, 1).reshape(2 * B, 256, E)
+    close(d_feat, want, 1e-2, 1e-3, "pool/d_feat")
+    # dense-plane round trip
+    np.testing.assert_array_equal(ops.idmap_to_planes(idm).cpu().numpy(), planes.numpy())
+    np.testing.assert_array_equal(ops.planes_to_idmap(planes.to(dev)).cpu().numpy(), ids)
+
+
+def check_patch_embed(dev, views=3, E=192, seed=8):
+    gen = torch.Generator().manual_seed(seed)
+    img = rnd((views, 3, 32, 128), gen)
+    w = rnd((E, 3, 4, 4), gen, 0.1).requires_grad_(True)
+    b = rnd((E,), gen, 0.1).requires_grad_(True)
+    pos = rnd((256, E), gen, 0.1).requires_grad_(True)
+    ref = F.conv2d(img, w, b, stride=4).flatten(2).transpose(1, 2) + pos
+    out = ops.patch_embed_fwd(img.to(dev), w.detach().to(dev), b.detach().to(dev), pos.detach().to(dev))
+    close(out.reshape(views, 256, E), ref, 1e-4, 1e-4, "pe/out")
+    gr = rnd((views, 256, E), gen)
+    ref.backward(gr)
+    dw, db, dp = torch.zeros(E, 48).to(dev), torch.zeros(E).to(dev), torch.zeros(256, E).to(dev)
+    ops.patch_embed_bwd(img.to(dev), gr.reshape(-1, E).to(dev), dw, db, dp)
+    close(dw.reshape(E, 3, 4, 4), w.grad, 1e-3, 1e-3, "pe/dw")
+    close(db, b.grad, 1e-3, 1e-3, "pe/db")
+    close(dp, pos.grad, 1e-3, 1e-4, "pe/dpos")
+
+
+def check_small_ops(dev, seed=9):
+    gen = torch.Generator().manual_seed(seed)
+    a, b = rnd((37, 50), gen), rnd((50, 70), gen)
+    out = torch.ones(37, 70).to(dev)
+    close(ops.small_matmul(a.to(dev), b.to(dev), out, accumulate=True), a @ b + 1, 1e-4, 1e-4, "smm/acc")
+    at = rnd((50, 37), gen)
+    close(ops.small_matmul(at.to(dev), b.to(dev), torch.empty(37, 70).to(dev), trans_a=True), at.t() @ b, 1e-4, 1e-4,
+          "smm/trans")
+    x = rnd((333, 136), gen).to(BF)
+    out = torch.full((136,), 2.0).to(dev)
+    close(ops.colsum_bf16(x.to(dev), out), x.float().sum(0) + 2, 1e-3, 1e-2, "colsum")
+    d_rows = torch.tensor([50], dtype=torch.int32).to(dev)
+    out = torch.zeros(136).to(dev)
+    close(ops.colsum_bf16(x.to(dev), out, d_rows=d_rows, rows_mul=2), x[:100].float().sum(0), 1e-3, 1e-2, "colsum/dyn")
+    src = rnd((5000,), gen)
+    close(ops.cast_bf16(src.to(dev), torch.empty(5000, dtype=BF).to(dev)), src.to(BF), 0, 0, "cast")
+    # mirror (bf16 copy + transposed copy) of two matrices in one launch
+    m1, m2 = rnd((70, 45), gen), rnd((33, 130), gen)
+    s1, s2 = m1.to(dev), m2.to(dev)
+    d1, t1 = torch.empty(70, 45, dtype=BF).to(dev), torch.empty(45, 70, dtype=BF).to(dev)
+    t2 = torch.empty(130, 33, dtype=BF).to(dev)
+    tiles1 = 3 * 2
+    tiles2 = 2 * 5
+    blob = struct.pack("PPPiiii", s1.data_ptr(), d1.data_ptr(), t1.data_ptr(), 70, 45, 0, 0)
+    blob += struct.pack("PPPiiii", s2.data_ptr(), 0, t2.data_ptr(), 33, 130, tiles1, 0)
+    descs = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    ops.mirror_bf16(descs, 2, tiles1 + tiles2)
+    close(d1, m1.to(BF), 0, 0, "mirror/d1"); close(t1, m1.t().to(BF), 0, 0, "mirror/t1")
+    close(t2, m2.t().to(BF), 0, 0, "mirror/t2")
+
+
+def check_head_pieces(dev, rows=37, D=64, K=200, seed=10):
+    gen = torch.Generator().manual_seed(seed)
+    x = rnd((rows, D), gen).to(BF)
+    xr = x.float().requires_grad_(True)
+    yr = F.normalize(xr, dim=-1, p=2)
+    y, inv = torch.empty(rows, D, dtype=BF).to(dev), torch.empty(rows).to(dev)
+    d_rows = torch.tensor([rows - 5], dtype=torch.int32).to(dev)
+    ops.l2norm_fwd(x.to(dev), y, inv, d_rows=d_rows)
+    close(y[:rows - 5], yr[:rows - 5], 1e-2, 1e-2, "l2/y")
+    dy = rnd((rows, D), gen).to(BF)
+    yr.backward(dy.float())
+    dx = torch.zeros(rows, D, dtype=BF).to(dev)
+    ops.l2norm_bwd(x.to(dev), inv, dy.to(dev), dx, d_rows=d_rows)
+    close(dx[:rows - 5], xr.grad[:rows - 5], 2e-2, 1e-2, "l2/dx")
+    v = rnd((K, D), gen).requires_grad_(True)
+    gg = (1 + 0.1 * rnd((K, 1), gen)).requires_grad_(True)
+    wr = v * (gg / v.norm(dim=1, keepdim=True))
+    w, wt, winv = torch.empty(K, D, dtype=BF).to(dev), torch.empty(D, K, dtype=BF).to(dev), torch.empty(K).to(dev)
+    ops.weightnorm_fwd(v.detach().to(dev), gg.detach().to(dev), w, wt, winv)
+    close(w, wr, 1e-2, 1e-3, "wn/w"); close(wt, wr.t(), 1e-2, 1e-3, "wn/wt")
+    dw = rnd((K, D), gen)
+    wr.backward(dw)
+    dv, dg = torch.empty(K, D).to(dev), torch.empty(K, 1).to(dev)
+    ops.weightnorm_bwd(v.detach().to(dev), gg.detach().to(dev), winv, dw.to(dev), dv, dg)
+    close(dv, v.grad, 1e-3, 1e-4, "wn/dv"); close(dg, gg.grad, 1e-3, 1e-4, "wn/dg")
+
+
+def check_dino_loss(dev, M=11, K=4096, seed=11, temp=0.04):
+    gen = torch.Generator().manual_seed(seed)
+    max_rows = 2 * M + 6
+    s = torch.zeros(max_rows, K); t = torch.zeros(max_rows, K)
+    s[:2 * M] = rnd((2 * M, K), gen, 0.5); t[:2 * M] = rnd((2 * M, K), gen, 0.5)
+    s[3, 77] = 9.0; t[5, 1234] = 6.0                                # force online-softmax rescales late in the row
+    center = rnd((1, K), gen, 0.1)
+    sr = s[:2 * M].clone().requires_grad_(True)
+    ref = O.dino_ce(sr, t[:2 * M], center, temp)
+    ref.backward()
+    d_m = torch.tensor([M], dtype=torch.int32).to(dev)
+    stats = torch.zeros(max_rows, 4).to(dev)
+    loss = torch.zeros(1).to(dev)
+    S, T_, C_ = s.to(dev), t.to(dev), center.to(dev)
+    ops.dino_loss_fwd(S, T_, C_, d_m, 0.1, temp, stats, loss)
+    close(loss, ref.reshape(1), 1e-5, 1e-5, "dino/loss")
+    dl = torch.zeros(max_rows, K, dtype=BF).to(dev)
+    ops.dino_loss_bwd(S, T_, C_, d_m, 0.1, temp, stats, 1.0, dl)
+    close(dl[:2 * M], sr.grad, 2e-2, 1e-6, "dino/dlogits")
+    bsum = torch.zeros(K).to(dev)
+    ops.colsum_f32(T_, bsum, d_rows=d_m, rows_mul=2)
+    close(bsum, t[:2 * M].sum(0), 1e-4, 1e-4, "dino/colsum")
+    cen = center.clone().reshape(-1).to(dev)
+    ops.center_ema(cen, bsum, d_m, 1, 0.9)
+    close(cen, O.center_update(center, t[:2 * M]).reshape(-1), 1e-5, 1e-6, "dino/center")
+
+
+def check_seg_loss(dev, half=2, seed=12):
+    gen = torch.Generator().manual_seed(seed)
+    logits = rnd((2 * half, 2, 32, 128), gen, 2.0)
+    ma = (torch.rand((half, 32, 128), generator=gen) > 0.5).float()
+    mb = (torch.rand((half, 32, 128), generator=gen) > 0.5)
+    lr = logits.clone().requires_grad_(True)
+    ref = O.seg_loss(lr, torch.cat([ma, mb.float()]))
+    ref.backward()
+    idb = torch.where(mb, torch.tensor(0, dtype=torch.uint8), torch.tensor(255, dtype=torch.uint8))
+    loss, dlog = torch.zeros(1).to(dev), torch.empty_like(logits).to(dev)
+    ops.seg_loss(logits.to(dev), ma.to(dev), idb.to(dev), 1.0, loss, dlog)
+    close(loss, ref.reshape(1), 1e-5, 1e-6, "seg/loss")
+    close(dlog, lr.grad, 1e-3, 1e-9, "seg/dlogits")
+
+
+def check_optimizer(dev, seed=13):
+    gen = torch.Generator().manual_seed(seed)
+    sizes = [5, 1024, 1500, 64, 3000]
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + 63) // 64 * 64
+    param = rnd((total,), gen); grad = rnd((total,), gen) * torch.tensor(3.0)
+    grad[offs[2]:offs[2] + sizes[2]] *= 0.001          # a tensor whose norm stays under the clip
+    chunk_seg, chunk_begin, chunk_len = [], [], []
+    for s_, (o, n) in enumerate(zip(offs, sizes)):
+        for c in range(0, n, 1024):
+            chunk_seg.append(s_); chunk_begin.append(o + c); chunk_len.append(min(1024, n - c))
+    cs = torch.tensor(chunk_seg, dtype=torch.int32).to(dev)
+    cb = torch.tensor(chunk_begin, dtype=torch.int64).to(dev)
+    cl = torch.tensor(chunk_len, dtype=torch.int32).to(dev)
+    norm2 = torch.zeros(len(sizes)).to(dev)
+    G = grad.to(dev)
+    ops.seg_sumsq(G, cs, cb, cl, norm2)
+    want = torch.stack([grad[o:o + n].pow(2).sum() for o, n in zip(offs, sizes)])
+    close(norm2, want, 1e-4, 1e-6, "opt/norm2")
+    lr, wd, clip, step = 3e-3, 0.1, 3.0, 4
+    active = [1, 1, 1, 0, 1]
+    decay = [1, 0, 1, 1, 1]
+    hyper = torch.tensor([[lr * wd * d, lr / (1 - 0.9 ** step), 1 / np.sqrt(1 - 0.999 ** step), a]
+                          for d, a in zip(decay, active)], dtype=torch.float32).to(dev)
+    m0, v0 = rnd((total,), gen) * 0.1, rnd((total,), gen).abs() * 0.1
+    Pd, Md, Vd = param.clone().to(dev), m0.clone().to(dev), v0.clone().to(dev)
+    mirror = torch.zeros(total, dtype=BF).to(dev)
+    ops.adamw(Pd, G, Md, Vd, mirror, cs, cb, cl, hyper, norm2, clip)
+    # reference: the oracle's per-tensor clip + AdamW formulas
+    for s_, (o, n) in enumerate(zip(offs, sizes)):
+        sl = slice(o, o + n)
+        if not active[s_]:
+            close(Pd[sl], param[sl], 0, 0, "opt/inactive")
+            continue
+        gsl = grad[sl].clone()
+        O.clip_per_tensor({"g": gsl}, clip)
+        p = param[sl].clone()
+        p.mul_(1 - lr * (wd if decay[s_] else 0.0))
+        m = m0[sl] * 0.9 + 0.1 * gsl
+        v = v0[sl] * 0.999 + 0.001 * gsl * gsl
+        p.addcdiv_(m, (v.sqrt() / np.sqrt(1 - 0.999 ** step)).add_(1e-8), value=-lr / (1 - 0.9 ** step))
+        close(Pd[sl], p, 1e-5, 1e-6, f"opt/param{s_}")
+        close(Md[sl], m, 1e-5, 1e-7, f"opt/m{s_}")
+        close(Vd[sl], v, 1e-5, 1e-7, f"opt/v{s_}")
+        close(mirror[sl], p.to(BF), 1e-2, 1e-6, f"opt/mirror{s_}")
+    G2 = grad.clone().to(dev)
+    ops.clip_scale(G2, cs, cb, cl, norm2, clip)
+    for s_, (o, n) in enumerate(zip(offs, sizes)):
+        gsl = grad[o:o + n].clone()
+        O.clip_per_tensor({"g": gsl}, clip)
+        close(G2[o:o + n], gsl, 1e-5, 1e-7, f"opt/clip{s_}")
+    teacher = rnd((total + 3,), gen); student = rnd((total + 3,), gen)
+    Td, tm = teacher.clone().to(dev), torch.zeros(total + 3, dtype=BF).to(dev)
+    ops.ema(Td, student.to(dev), tm, 0.9995)
+    close(Td, teacher * 0.9995 + (1 - 0.9995) * student, 1e-6, 1e-7, "opt/ema")
+    close(tm, Td.to(BF), 0, 0, "opt/ema-mirror")

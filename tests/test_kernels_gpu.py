@@ -36,3 +36,58 @@ def test_layernorm(hip, rows, E):
 @pytest.mark.parametrize("views,heads,spike", [(1, 2, False), (16, 6, False), (3, 8, True)])
 def test_attention(hip, views, heads, spike):
     kc.check_attention(hip.device, views, heads, spike=spike)
+
+
+def test_gemm_dynamic_rows(hip):
+    from ccd_amd import ops
+    g = torch.Generator().manual_seed(0)
+    a = kc.rnd((3000, 256), g).to(kc.BF); b = kc.rnd((520, 256), g).to(kc.BF)
+    d_rows = torch.tensor([750], dtype=torch.int32, device=hip.device)
+    out = torch.full((3000, 520), 7.0, device=hip.device)
+    ops.gemm_nt(a.to(hip.device), b.to(hip.device), epilogue=ops.EPI_F32, out=out, d_rows=d_rows, rows_mul=2)
+    kc.close(out[:1500], a[:1500].float() @ b.float().t(), 1e-4, 1e-3, "dyn/nt")
+    assert (out[1500:] == 7.0).all()
+    c = kc.rnd((3000, 136), g).to(kc.BF)
+    acc = torch.zeros(256, 136, device=hip.device)
+    ops.gemm_tn(a.to(hip.device), c.to(hip.device), acc, d_rows=d_rows, rows_mul=2)
+    kc.close(acc, a[:1500].float().t() @ c[:1500].float(), 1e-4, 5e-2, "dyn/tn")
+
+
+def test_ccl(hip):
+    kc.check_ccl(hip.device)
+
+
+def test_warp(hip):
+    kc.check_warp(hip.device)
+
+
+@pytest.mark.parametrize("E", [128, 384])
+def test_region(hip, E):
+    kc.check_region(hip.device, E=E)
+
+
+@pytest.mark.parametrize("views,E", [(3, 192), (32, 384)])
+def test_patch_embed(hip, views, E):
+    kc.check_patch_embed(hip.device, views=views, E=E)
+
+
+def test_small_ops(hip):
+    kc.check_small_ops(hip.device)
+
+
+@pytest.mark.parametrize("rows,D,K", [(37, 64, 200), (500, 256, 4096)])
+def test_head_pieces(hip, rows, D, K):
+    kc.check_head_pieces(hip.device, rows=rows, D=D, K=K)
+
+
+@pytest.mark.parametrize("M,K", [(11, 4096), (48, 65536)])
+def test_dino_loss(hip, M, K):
+    kc.check_dino_loss(hip.device, M=M, K=K)
+
+
+def test_seg_loss(hip):
+    kc.check_seg_loss(hip.device, half=4)
+
+
+def test_optimizer(hip):
+    kc.check_optimizer(hip.device)

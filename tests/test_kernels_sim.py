@@ -28,3 +28,55 @@ def test_layernorm_sim(sim):
 
 def test_attention_sim(sim):
     kc.check_attention(sim.device, views=1, heads=2)
+
+
+def test_gemm_dynamic_rows_sim(sim):
+    import torch
+    from ccd_amd import ops
+    g = torch.Generator().manual_seed(0)
+    a = kc.rnd((300, 64), g).to(kc.BF); b = kc.rnd((72, 64), g).to(kc.BF)
+    d_rows = torch.tensor([75], dtype=torch.int32)
+    out = torch.full((300, 72), 7.0)
+    ops.gemm_nt(a, b, epilogue=ops.EPI_F32, out=out, d_rows=d_rows, rows_mul=2)
+    kc.close(out[:150], a[:150].float() @ b.float().t(), 1e-4, 1e-4, "dyn/nt")
+    assert (out[150:] == 7.0).all()
+    c = kc.rnd((300, 40), g).to(kc.BF)
+    acc = torch.zeros(64, 40)
+    ops.gemm_tn(a, c, acc, d_rows=d_rows, rows_mul=2, splits=2)
+    kc.close(acc, a[:150].float().t() @ c[:150].float(), 1e-4, 1e-2, "dyn/tn")
+
+
+def test_ccl_sim(sim):
+    kc.check_ccl(sim.device)
+
+
+def test_warp_sim(sim):
+    kc.check_warp(sim.device)
+
+
+def test_region_sim(sim):
+    kc.check_region(sim.device)
+
+
+def test_patch_embed_sim(sim):
+    kc.check_patch_embed(sim.device)
+
+
+def test_small_ops_sim(sim):
+    kc.check_small_ops(sim.device)
+
+
+def test_head_pieces_sim(sim):
+    kc.check_head_pieces(sim.device)
+
+
+def test_dino_loss_sim(sim):
+    kc.check_dino_loss(sim.device)
+
+
+def test_seg_loss_sim(sim):
+    kc.check_seg_loss(sim.device)
+
+
+def test_optimizer_sim(sim):
+    kc.check_optimizer(sim.device)
