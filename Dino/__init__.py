@@ -1,0 +1,24 @@
+"""`Dino.*` import paths of the reference (TongkunGuan/CCD) mapped onto the MI355X-native implementation in
+`ccd_amd`, so `from Dino.modules import vision_transformer as vits`, `from Dino.model.dino_vision import
+ABIDINOModel`, `from Dino.loss.Dino_loss import DINOLoss`, `from Dino.utils.utils import Config` keep working.
+Only the pretraining path exists here."""
+import importlib
+import sys
+
+_ALIASES = {
+    "Dino.modules": "ccd_amd.modules",
+    "Dino.modules.vision_transformer": "ccd_amd.modules.vision_transformer",
+    "Dino.modules.segmentor": "ccd_amd.modules.segmentor",
+    "Dino.modules.utils": "ccd_amd.modules.utils",
+    "Dino.model": "ccd_amd.model",
+    "Dino.model.dino_vision": "ccd_amd.model.dino_vision",
+    "Dino.loss": "ccd_amd.loss",
+    "Dino.loss.Dino_loss": "ccd_amd.loss.Dino_loss",
+    "Dino.utils": "ccd_amd.utils",
+    "Dino.utils.utils": "ccd_amd.utils.utils",
+}
+for _alias, _target in _ALIASES.items():
+    _mod = importlib.import_module(_target)
+    sys.modules[_alias] = _mod
+    _parent, _, _leaf = _alias.rpartition(".")
+    setattr(sys.modules[_parent], _leaf, _mod)

@@ -37,6 +37,7 @@ SIGNATURES = {
     "ccd_colsum_bf16": [P, L, I, I, P, I, P, P],
     "ccd_mirror_bf16": [P, I, I, P],
     "ccd_cast_bf16": [P, P, L, P],
+    "ccd_scale_cast_rows": [P, P, P, I, L, I, P],
     "ccd_ccl_label": [P, P, I, P],
     "ccd_mask_to_idmap": [P, P, I, P],
     "ccd_seg_to_mask": [P, P, I, P],
@@ -52,7 +53,7 @@ SIGNATURES = {
     "ccd_weightnorm_fwd": [P, P, P, P, P, I, I, P],
     "ccd_weightnorm_bwd": [P, P, P, P, P, P, I, I, P],
     "ccd_dino_loss_fwd": [P, P, P, I, P, I, F, F, P, P, P],
-    "ccd_dino_loss_bwd": [P, P, P, I, P, I, F, F, P, F, P, P],
+    "ccd_dino_loss_bwd": [P, P, P, I, P, I, F, F, P, F, P, P, P],
     "ccd_colsum_f32": [P, I, P, I, I, P, P],
     "ccd_center_ema": [P, P, I, P, I, F, P],
     "ccd_seg_loss": [P, P, P, I, F, P, P, P],

@@ -190,6 +190,15 @@ int ccd_mirror_bf16(const ccd_mirror_desc* d_descs, int ndesc, int total_tiles, 
                reinterpret_cast<const ccd::MirrorDesc*>(d_descs), ndesc);
     return ccd_rt_last_error();
 }
+int ccd_scale_cast_rows(const float* src, ccd_bf16* dst, const float* rowscale, int rows_per_sample, long rows, int E,
+                        void* stream) {
+    CCD_CHECK(src && dst && rows >= 0 && E > 0 && E % 4 == 0 && rows_per_sample > 0, CCD_EINVAL);
+    if (rows == 0) return CCD_OK;
+    const long n = rows * (E / 4);
+    CCD_LAUNCH(ccd::scale_cast_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, dst, rowscale,
+               rows_per_sample, rows, E);
+    return ccd_rt_last_error();
+}
 int ccd_cast_bf16(const float* src, ccd_bf16* dst, long n, void* stream) {
     CCD_CHECK(src && dst && n >= 0, CCD_EINVAL);
     if (n == 0) return CCD_OK;
@@ -318,11 +327,11 @@ int ccd_dino_loss_fwd(const float* s_logits, const float* t_logits, const float*
 }
 int ccd_dino_loss_bwd(const float* s_logits, const float* t_logits, const float* center, int K, const int* d_m,
                       int max_rows, float student_temp, float teacher_temp, const float* stats, float grad_scale,
-                      ccd_bf16* d_logits, void* stream) {
+                      const float* d_grad_scale, ccd_bf16* d_logits, void* stream) {
     CCD_CHECK(s_logits && t_logits && center && d_m && stats && d_logits, CCD_EINVAL);
     CCD_CHECK(K > 0 && K % 4 == 0 && max_rows > 0 && student_temp > 0 && teacher_temp > 0, CCD_ESHAPE);
     CCD_LAUNCH(ccd::dino_loss_bwd_kernel, dim3(max_rows), dim3(256), 0, stream, s_logits, t_logits, center, K, d_m,
-               max_rows, 1.0f / student_temp, 1.0f / teacher_temp, stats, grad_scale, d_logits);
+               max_rows, 1.0f / student_temp, 1.0f / teacher_temp, stats, grad_scale, d_grad_scale, d_logits);
     return ccd_rt_last_error();
 }
 int ccd_colsum_f32(const float* x, int K, const int* d_rows, int rows_mul, int max_rows, float* out, void* stream) {

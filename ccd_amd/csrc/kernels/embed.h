@@ -170,6 +170,24 @@ __global__ __launch_bounds__(256) void mirror_bf16_kernel(const MirrorDesc* __re
     }
 }
 
+// dst(bf16)[r, :] = src(f32)[r, :] * rowscale[r / rows_per_sample]: the residual-gradient stream entering a branch
+// (the DropPath scale of that branch, vision_transformer.py:27-35, applied on the way back)
+__global__ __launch_bounds__(256) void scale_cast_rows_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                              const float* __restrict__ rowscale, int rows_per_sample,
+                                                              long rows, int E) {
+    const int e4 = E >> 2;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * e4) return;
+    const long r = i / e4;
+    const int c = (int)(i % e4) * 4;
+    const float s = rowscale ? rowscale[r / rows_per_sample] : 1.0f;
+    const f32x4v v = *reinterpret_cast<const f32x4v*>(src + r * E + c);
+    u32x2 o;
+    o.x = pack_bf2(v.x * s, v.y * s);
+    o.y = pack_bf2(v.z * s, v.w * s);
+    *reinterpret_cast<u32x2*>(dst + r * E + c) = o;
+}
+
 // plain fp32 -> bf16 cast of a flat range (used to mirror whole parameter arenas)
 __global__ void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;

@@ -105,14 +105,15 @@ __global__ __launch_bounds__(256) void dino_loss_bwd_kernel(const float* __restr
                                                             const float* __restrict__ center, int K,
                                                             const int* __restrict__ d_m, int max_rows, float inv_ts,
                                                             float inv_tt, const float* __restrict__ stats,
-                                                            float grad_scale, bf16_t* __restrict__ d_logits) {
+                                                            float grad_scale, const float* __restrict__ d_grad_scale,
+                                                            bf16_t* __restrict__ d_logits) {
     const int M = d_m[0];
     const int i = blockIdx.x;
     if (i >= 2 * M || i >= max_rows) return;
     const int j = i < M ? i + M : i - M;
     const float ms = stats[(long)i * 4 + 0], inv_ls = 1.0f / stats[(long)i * 4 + 1];
     const float mt = stats[(long)i * 4 + 2], inv_lt = 1.0f / stats[(long)i * 4 + 3];
-    const float gs = grad_scale * inv_ts / (float)(2 * M);
+    const float gs = grad_scale * (d_grad_scale ? d_grad_scale[0] : 1.0f) * inv_ts / (float)(2 * M);
     const float* s = s_logits + (long)i * K;
     const float* tr = t_logits + (long)j * K;
     bf16_t* d = d_logits + (long)i * K;

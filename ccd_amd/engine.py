@@ -1,0 +1,341 @@
+"""Forward/backward drivers of the HIP kernels (autograd.Function wrappers).
+
+Granularity: one Function per sub-network (backbone, region pooling, DINO head, the two losses), each with a
+hand-written backward that launches HIP kernels and writes parameter gradients STRAIGHT into the arena's gradient
+buffer (ccd_amd.arena) - autograd only carries activation gradients between the Functions.  Mixed precision:
+fp32 residual stream / parameters / statistics, bf16 GEMM and attention operands, fp32 accumulation.
+
+Reference call sites: Dino/modules/vision_transformer.py:107-113, 225-251 (backbone); Dino/model/dino_vision.py:38-49,
+80-88 (region pooling + row selection); vision_transformer.py:324-328 (head); Dino/loss/Dino_loss.py:59-143.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class VitSpec:
+    def __init__(self, embed_dim, depth, heads, taps, patch=4, eps=1e-6, drop_path_rate=0.0):
+        self.E, self.depth, self.heads, self.taps, self.patch, self.eps = embed_dim, depth, heads, tuple(taps), patch, eps
+        self.dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]   # vision_transformer.py:150
+
+
+# ------------------------------------------------------------------------------------------------ pos-embed resampling
+def bicubic_resample_matrix(n_src_side=16, out_h=8, out_w=32):
+    """The linear map of interpolate_pos_encoding (vision_transformer.py:182-201) as a dense [out_h*out_w, n*n]
+    fp32 matrix: F.interpolate(mode='bicubic', align_corners=False) with the PASSED scale factors
+    ((out+0.1)/n) driving the coordinate transform, cubic coefficient A = -0.75, border-clamped taps.
+    Restated from ATen's upsample_bicubic2d (area_pixel_compute_source_index(scale, dst, False, cubic=True),
+    get_cubic_upsample_coefficients)."""
+    import numpy as np
+
+    def coeffs(t):
+        a = np.float32(-0.75)
+        t = np.float32(t)
+        c1 = lambda x: ((a + np.float32(2)) * x - (a + np.float32(3))) * x * x + np.float32(1)
+        c2 = lambda x: ((a * x - np.float32(5) * a) * x + np.float32(8) * a) * x - np.float32(4) * a
+        return [c2(t + np.float32(1)), c1(t), c1(np.float32(1) - t), c2(np.float32(2) - t)]
+
+    def axis(n_in, n_out):
+        sf = (n_out + 0.1) / math.sqrt(n_in * n_in)            # the scale_factor the reference passes
+        scale = np.float32(1.0 / sf)                           # compute_scales_value: 1 / scale_factor
+        taps = []
+        for o in range(n_out):
+            src = scale * (np.float32(o) + np.float32(0.5)) - np.float32(0.5)
+            fl = np.floor(src)
+            w = coeffs(src - fl)
+            idx = [min(max(int(fl) - 1 + k, 0), n_in - 1) for k in range(4)]
+            taps.append((idx, w))
+        return taps
+
+    import numpy as np
+    ty, tx = axis(n_src_side, out_h), axis(n_src_side, out_w)
+    m = np.zeros((out_h * out_w, n_src_side * n_src_side), dtype=np.float32)
+    for oy in range(out_h):
+        for ox in range(out_w):
+            for iy, wy in zip(*ty[oy]):
+                for ix, wx in zip(*tx[ox]):
+                    m[oy * out_w + ox, iy * n_src_side + ix] += np.float32(wy) * np.float32(wx)
+    return torch.from_numpy(m)
+
+
+# ------------------------------------------------------------------------------------------------------ backbone
+class _BlockCtx:
+    __slots__ = ("x_in", "y1", "mean1", "rstd1", "qkv", "att", "lse", "x_mid", "y2", "mean2", "rstd2", "u", "gact",
+                 "ds1", "ds2")
+
+
+def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training):
+    """img [N,3,32,128] fp32 -> (tokens bf16 [N*256,E], [tap bf16 [N*256,E]] * len(taps), ctx or None)."""
+    E, N = spec.E, img.shape[0]
+    R = N * 256
+    dev = img.device
+    pos = ops.small_matmul(resample, arena.w(pre + "pos_embed").view(-1, E), torch.empty((256, E), dtype=F32, device=dev))
+    x = ops.patch_embed_fwd(img, arena.w(pre + "patch_embed.proj.weight"), arena.w(pre + "patch_embed.proj.bias"), pos)
+    ctxs, taps, tap_ctx = [], [], []
+    scale = (E // spec.heads) ** -0.5
+    for i in range(spec.depth):
+        b = f"{pre}blocks.{i}."
+        c = _BlockCtx()
+        c.ds1 = c.ds2 = None
+        if training and spec.dpr[i] > 0.0:       # DropPath: per-sample keep mask / keep_prob (vision_transformer.py:27-35)
+            keep = 1.0 - spec.dpr[i]
+            r = torch.rand((2, N), device=dev)
+            m = torch.floor(r + keep) / keep
+            c.ds1, c.ds2 = m[0].contiguous(), m[1].contiguous()
+        c.x_in = x
+        c.y1, c.mean1, c.rstd1 = ops.ln_fwd(x, arena.w(b + "norm1.weight"), arena.w(b + "norm1.bias"), spec.eps)
+        c.qkv = ops.gemm_nt(c.y1, arena.wb(b + "attn.qkv.weight"), bias=arena.w(b + "attn.qkv.bias"))
+        c.att, c.lse = ops.attention_fwd(c.qkv.view(N, 256, 3 * E), spec.heads, scale)
+        c.x_mid = ops.gemm_nt(c.att.view(R, E), arena.wb(b + "attn.proj.weight"), epilogue=ops.EPI_RESID,
+                              bias=arena.w(b + "attn.proj.bias"), resid=x, rowscale=c.ds1, rows_per_sample=256)
+        c.y2, c.mean2, c.rstd2 = ops.ln_fwd(c.x_mid, arena.w(b + "norm2.weight"), arena.w(b + "norm2.bias"), spec.eps)
+        c.u, c.gact = ops.gemm_nt(c.y2, arena.wb(b + "mlp.fc1.weight"), epilogue=ops.EPI_GELU,
+                                  bias=arena.w(b + "mlp.fc1.bias"))
+        x = ops.gemm_nt(c.gact, arena.wb(b + "mlp.fc2.weight"), epilogue=ops.EPI_RESID,
+                        bias=arena.w(b + "mlp.fc2.bias"), resid=c.x_mid, rowscale=c.ds2, rows_per_sample=256)
+        if not save:
+            c.y1 = c.qkv = c.att = c.y2 = c.u = c.gact = None
+        ctxs.append(c if save else None)
+        if i + 1 in spec.taps:
+            j = len(taps)
+            t, mu, rs = ops.ln_fwd(x, arena.w(f"{pre}norm_seg.{j}.weight"), arena.w(f"{pre}norm_seg.{j}.bias"), spec.eps)
+            taps.append(t)
+            tap_ctx.append((i, x, mu, rs))
+    tokens, mu, rs = ops.ln_fwd(x, arena.w(pre + "norm.weight"), arena.w(pre + "norm.bias"), spec.eps)
+    ctx = (ctxs, tap_ctx, (x, mu, rs), img) if save else None
+    return tokens, taps, ctx
+
+
+def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample, on_block_done=None):
+    """Consumes bf16 gradients of the final-norm tokens and the taps; fills the arena gradient slots of `pre`*."""
+    ctxs, tap_ctx, (x_last, mu, rs), img = ctx
+    E, N = spec.E, img.shape[0]
+    R = N * 256
+    dev = img.device
+    g = torch.empty((R, E), dtype=F32, device=dev)
+    if d_tokens is not None:
+        ops.ln_bwd(d_tokens.reshape(R, E), x_last, mu, rs, arena.w(pre + "norm.weight"), g, arena.g(pre + "norm.weight"),
+                   arena.g(pre + "norm.bias"), accumulate=False)
+    else:
+        g.zero_()
+    tap_at = {i: (j, x, m, r) for j, (i, x, m, r) in enumerate(tap_ctx)}
+    scale = (E // spec.heads) ** -0.5
+    gb = torch.empty((R, E), dtype=BF16, device=dev)
+    for i in reversed(range(spec.depth)):
+        if i in tap_at and d_taps[tap_at[i][0]] is not None:
+            j, xt, m, r = tap_at[i]
+            ops.ln_bwd(d_taps[j].reshape(R, E), xt, m, r, arena.w(f"{pre}norm_seg.{j}.weight"), g,
+                       arena.g(f"{pre}norm_seg.{j}.weight"), arena.g(f"{pre}norm_seg.{j}.bias"), accumulate=True)
+        b = f"{pre}blocks.{i}."
+        c = ctxs[i]
+        # ---- MLP branch: x_out = x_mid + ds2 * fc2(gelu(fc1(LN2(x_mid))))
+        ops.scale_cast_rows(g, gb, c.ds2, 256)
+        ops.gemm_tn(gb, c.gact, arena.g(b + "mlp.fc2.weight"))
+        ops.colsum_bf16(gb, arena.g(b + "mlp.fc2.bias"))
+        du = ops.gemm_nt(gb, arena.wbt(b + "mlp.fc2.weight"), epilogue=ops.EPI_DGELU, aux=c.u)
+        ops.gemm_tn(du, c.y2, arena.g(b + "mlp.fc1.weight"))
+        ops.colsum_bf16(du, arena.g(b + "mlp.fc1.bias"))
+        dy2 = ops.gemm_nt(du, arena.wbt(b + "mlp.fc1.weight"))
+        del du
+        ops.ln_bwd(dy2, c.x_mid, c.mean2, c.rstd2, arena.w(b + "norm2.weight"), g, arena.g(b + "norm2.weight"),
+                   arena.g(b + "norm2.bias"), accumulate=True)
+        # ---- attention branch: x_mid = x_in + ds1 * proj(attn(qkv(LN1(x_in))))
+        ops.scale_cast_rows(g, gb, c.ds1, 256)
+        ops.gemm_tn(gb, c.att.view(R, E), arena.g(b + "attn.proj.weight"))
+        ops.colsum_bf16(gb, arena.g(b + "attn.proj.bias"))
+        d_att = ops.gemm_nt(gb, arena.wbt(b + "attn.proj.weight"))
+        d_qkv = ops.attention_bwd(c.qkv.view(N, 256, 3 * E), c.att, d_att.view(N, 256, E), c.lse, spec.heads, scale)
+        d_qkv = d_qkv.view(R, 3 * E)
+        ops.gemm_tn(d_qkv, c.y1, arena.g(b + "attn.qkv.weight"))
+        ops.colsum_bf16(d_qkv, arena.g(b + "attn.qkv.bias"))
+        dy1 = ops.gemm_nt(d_qkv, arena.wbt(b + "attn.qkv.weight"))
+        ops.ln_bwd(dy1, c.x_in, c.mean1, c.rstd1, arena.w(b + "norm1.weight"), g, arena.g(b + "norm1.weight"),
+                   arena.g(b + "norm1.bias"), accumulate=True)
+        ctxs[i] = None
+        if on_block_done is not None:
+            on_block_done(b)
+    d_pos_rs = torch.zeros((256, E), dtype=F32, device=dev)
+    ops.patch_embed_bwd(img, g, arena.g(pre + "patch_embed.proj.weight").view(E, -1),
+                        arena.g(pre + "patch_embed.proj.bias"), d_pos_rs)
+    ops.small_matmul(resample, d_pos_rs, arena.g(pre + "pos_embed").view(-1, E), trans_a=True, accumulate=True)
+    if on_block_done is not None:
+        on_block_done(pre + "patch_embed.")
+
+
+class BackboneFn(torch.autograd.Function):
+    """tokens, tap0, tap1, tap2 = BackboneFn.apply(anchor, img, module)   (anchor: any tensor that requires grad)."""
+
+    @staticmethod
+    def forward(ctx, anchor, img, module):
+        save = ctx.needs_input_grad[0]      # False under no_grad / frozen teacher
+        tokens, taps, saved = backbone_forward(module.arena, module.arena_prefix, module.spec, img, module.resample,
+                                               save, module.training)
+        ctx.module, ctx.saved = module, saved
+        N, E = img.shape[0], module.spec.E
+        outs = [tokens.view(N, 256, E)] + [t.view(N, 256, E) for t in taps]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, d_tokens, *d_taps):
+        m = ctx.module
+        cast = lambda t: None if t is None else t.contiguous().to(BF16)
+        backbone_backward(m.arena, m.arena_prefix, m.spec, ctx.saved, cast(d_tokens), [cast(t) for t in d_taps],
+                          m.resample, m.grad_ready_hook)
+        ctx.saved = None
+        return None, None, None
+
+
+# ---------------------------------------------------------------------------------------------- region pooling
+class Selection:
+    """Device-resident result of the character-region bookkeeping for one batch (both views)."""
+
+    def __init__(self, idmap, batch):
+        self.idmap, self.batch = idmap, batch                      # uint8 [2B,32,128]
+        self.tok_plane, self.tok_coef, self.present = ops.region_stats(idmap)
+        self.nsel, self.offset, self.total, self.new_index = ops.select_scan(self.present, batch)
+        self.max_rows = 2 * 26 * batch
+        self._m = None
+
+    @property
+    def M(self):                                                   # host sync; only for API-compat accessors / logging
+        if self._m is None:
+            self._m = int(self.total.item())
+        return self._m
+
+    def dense(self):
+        """The reference's `clusters` tensor [2B,26,32,128] fp32 (dino_vision.py:78)."""
+        return ops.idmap_to_planes(self.idmap)
+
+
+class RegionPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tokens, sel: Selection):
+        E = tokens.shape[-1]
+        rows = torch.zeros((sel.max_rows, E), dtype=BF16, device=tokens.device)
+        ops.region_pool_fwd(tokens.contiguous(), sel.tok_plane, sel.tok_coef, sel.nsel, sel.offset, sel.total, rows,
+                            sel.batch)
+        ctx.sel, ctx.shape = sel, tokens.shape
+        return rows
+
+    @staticmethod
+    def backward(ctx, d_rows):
+        sel = ctx.sel
+        d_feat = torch.empty(ctx.shape, dtype=BF16, device=d_rows.device)
+        ops.region_pool_bwd(d_rows.contiguous().to(BF16), sel.tok_plane, sel.tok_coef, sel.nsel, sel.offset, sel.total,
+                            d_feat, sel.batch)
+        return d_feat, None
+
+
+# ------------------------------------------------------------------------------------------------------- DINO head
+def head_forward(arena, pre, rows, d_total, save, rows_mul=2):
+    """rows bf16 [max_rows, E] -> logits fp32 [max_rows, K] (only the first rows_mul*d_total[0] rows are computed)."""
+    dev = rows.device
+    dyn = dict(d_rows=d_total, rows_mul=rows_mul)
+    u0, a0 = ops.gemm_nt(rows, arena.wb(pre + "mlp.0.weight"), epilogue=ops.EPI_GELU, bias=arena.w(pre + "mlp.0.bias"), **dyn)
+    u1, a1 = ops.gemm_nt(a0, arena.wb(pre + "mlp.2.weight"), epilogue=ops.EPI_GELU, bias=arena.w(pre + "mlp.2.bias"), **dyn)
+    z = ops.gemm_nt(a1, arena.wb(pre + "mlp.4.weight"), bias=arena.w(pre + "mlp.4.bias"), **dyn)
+    zn = torch.empty_like(z)
+    inv = torch.empty(z.shape[0], dtype=F32, device=dev)
+    ops.l2norm_fwd(z, zn, inv, d_rows=d_total, rows_mul=rows_mul)
+    v, gw = arena.w(pre + "last_layer.weight_v"), arena.w(pre + "last_layer.weight_g")
+    K, D = v.shape
+    w = torch.empty((K, D), dtype=BF16, device=dev)
+    w_t = torch.empty((D, K), dtype=BF16, device=dev) if save else None
+    winv = torch.empty(K, dtype=F32, device=dev)
+    ops.weightnorm_fwd(v, gw, w, w_t, winv)
+    logits = torch.empty((rows.shape[0], K), dtype=F32, device=dev)
+    ops.gemm_nt(zn, w, epilogue=ops.EPI_F32, out=logits, m_fastest=1, **dyn)
+    saved = (rows, u0, a0, u1, a1, z, zn, inv, w_t, winv) if save else None
+    return logits, saved
+
+
+def head_backward(arena, pre, saved, d_logits, d_total, last_layer_trainable_g, rows_mul=2):
+    rows, u0, a0, u1, a1, z, zn, inv, w_t, winv = saved
+    dev = rows.device
+    dyn = dict(d_rows=d_total, rows_mul=rows_mul)
+    v, gw = arena.w(pre + "last_layer.weight_v"), arena.w(pre + "last_layer.weight_g")
+    K, D = v.shape
+    dw = torch.empty((K, D), dtype=F32, device=dev)
+    ops.gemm_tn(d_logits, zn, dw, accumulate=False, **dyn)                       # dW_eff = d_logits^T . zn
+    ops.weightnorm_bwd(v, gw, winv, dw, arena.g(pre + "last_layer.weight_v"),
+                       arena.g(pre + "last_layer.weight_g") if last_layer_trainable_g else None)
+    dzn = ops.gemm_nt(d_logits, w_t, m_fastest=0, **dyn)                          # [rows, D]
+    dz = torch.zeros_like(z)
+    ops.l2norm_bwd(z, inv, dzn, dz, **dyn)
+    ops.gemm_tn(dz, a1, arena.g(pre + "mlp.4.weight"), **dyn)
+    ops.colsum_bf16(dz, arena.g(pre + "mlp.4.bias"), **dyn)
+    du1 = ops.gemm_nt(dz, arena.wbt(pre + "mlp.4.weight"), epilogue=ops.EPI_DGELU, aux=u1, **dyn)
+    ops.gemm_tn(du1, a0, arena.g(pre + "mlp.2.weight"), **dyn)
+    ops.colsum_bf16(du1, arena.g(pre + "mlp.2.bias"), **dyn)
+    du0 = ops.gemm_nt(du1, arena.wbt(pre + "mlp.2.weight"), epilogue=ops.EPI_DGELU, aux=u0, **dyn)
+    ops.gemm_tn(du0, rows, arena.g(pre + "mlp.0.weight"), **dyn)
+    ops.colsum_bf16(du0, arena.g(pre + "mlp.0.bias"), **dyn)
+    d_rows_t = torch.zeros_like(rows)
+    ops.gemm_nt(du0, arena.wbt(pre + "mlp.0.weight"), out=d_rows_t, **dyn)
+    return d_rows_t
+
+
+class HeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows, module, d_total, rows_mul=2):
+        save = ctx.needs_input_grad[0]
+        logits, saved = head_forward(module.arena, module.arena_prefix, rows, d_total, save, rows_mul)
+        ctx.module, ctx.saved, ctx.d_total, ctx.rows_mul = module, saved, d_total, rows_mul
+        return logits
+
+    @staticmethod
+    def backward(ctx, d_logits):
+        m = ctx.module
+        d_rows = head_backward(m.arena, m.arena_prefix, ctx.saved, d_logits.contiguous().to(BF16), ctx.d_total,
+                               m.weight_g_trainable, ctx.rows_mul)
+        ctx.saved = None
+        if m.grad_ready_hook is not None:
+            m.grad_ready_hook(m.arena_prefix)
+        return d_rows, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------- losses
+class DinoLossFn(torch.autograd.Function):
+    """loss (1-element fp32 tensor) of the two cross-view CE terms; d(student logits) in bf16."""
+
+    @staticmethod
+    def forward(ctx, s_logits, t_logits, center, d_total, student_temp, teacher_temp):
+        dev = s_logits.device
+        stats = torch.empty((s_logits.shape[0], 4), dtype=F32, device=dev)
+        loss = torch.zeros(1, dtype=F32, device=dev)
+        center = center.clone()     # DINOLoss.update_center rewrites the buffer in place right after this forward
+        ops.dino_loss_fwd(s_logits, t_logits, center, d_total, student_temp, teacher_temp, stats, loss)
+        ctx.save_for_backward(s_logits, t_logits, center, stats)
+        ctx.d_total, ctx.temps = d_total, (student_temp, teacher_temp)
+        return loss
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        s_logits, t_logits, center, stats = ctx.saved_tensors
+        d_logits = torch.zeros(s_logits.shape, dtype=BF16, device=s_logits.device)
+        ops.dino_loss_bwd(s_logits, t_logits, center, ctx.d_total, ctx.temps[0], ctx.temps[1], stats, 1.0, d_logits,
+                          d_grad_scale=d_loss.contiguous().float())      # upstream gradient stays a device scalar
+        return d_logits, None, None, None, None, None
+
+
+class SegLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, seg_logits, mask_a, idmap_b):
+        dev = seg_logits.device
+        loss = torch.zeros(1, dtype=F32, device=dev)
+        d_logits = torch.empty(seg_logits.shape, dtype=F32, device=dev) if ctx.needs_input_grad[0] else None   # NCHW-contiguous
+        ops.seg_loss(seg_logits.contiguous(), mask_a, idmap_b, 1.0, loss, d_logits)
+        ctx.d_logits = d_logits
+        return loss
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        d = ctx.d_logits
+        ctx.d_logits = None
+        return d * d_loss, None, None          # 8 MB elementwise at B=256: not worth a kernel argument

@@ -145,6 +145,12 @@ def cast_bf16(src, dst):
     return dst
 
 
+def scale_cast_rows(src, dst, rowscale=None, rows_per_sample=1):
+    rows, E = src.shape
+    _call("ccd_scale_cast_rows", _lib.ptr(src), _lib.ptr(dst), _lib.ptr(rowscale), int(rows_per_sample), rows, E)
+    return dst
+
+
 def mirror_bf16(descs_dev, ndesc, total_tiles):
     _call("ccd_mirror_bf16", _lib.ptr(descs_dev), ndesc, total_tiles)
 
@@ -253,10 +259,12 @@ def dino_loss_fwd(s_logits, t_logits, center, d_m, student_temp, teacher_temp, s
           float(student_temp), float(teacher_temp), _lib.ptr(stats), _lib.ptr(loss_out))
 
 
-def dino_loss_bwd(s_logits, t_logits, center, d_m, student_temp, teacher_temp, stats, grad_scale, d_logits):
+def dino_loss_bwd(s_logits, t_logits, center, d_m, student_temp, teacher_temp, stats, grad_scale, d_logits,
+                  d_grad_scale=None):
     max_rows, K = s_logits.shape
     _call("ccd_dino_loss_bwd", _lib.ptr(s_logits), _lib.ptr(t_logits), _lib.ptr(center), K, _lib.ptr(d_m), max_rows,
-          float(student_temp), float(teacher_temp), _lib.ptr(stats), float(grad_scale), _lib.ptr(d_logits))
+          float(student_temp), float(teacher_temp), _lib.ptr(stats), float(grad_scale), _lib.ptr(d_grad_scale),
+          _lib.ptr(d_logits))
 
 
 def colsum_f32(x, out, d_rows=None, rows_mul=1):

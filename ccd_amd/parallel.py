@@ -1,0 +1,102 @@
+"""Data parallelism for the arena-backed student: one process per GPU, gradients all-reduced (mean) over RCCL/xGMI
+in contiguous arena buckets that are launched WHILE the backward pass is still running (replaces
+DistributedDataParallel(student, find_unused_parameters=True), train.py:106, collective C2 of SURVEY.md 2.3).
+
+The HIP backward writes gradients straight into the arena, so "gradient ready" is signalled by the engine
+(module.grad_ready_hook(prefix)) instead of autograd hooks: the DINO head finishes first (its 16.8 M-element last
+layer is the largest bucket), then the transformer blocks in reverse order, then patch-embed; everything else
+(segmentation head, norm layers touched last) goes in finish().  Works on any backend: 'nccl' (= RCCL) on GPUs,
+'gloo' in the CPU tests.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class GradReducer:
+    def __init__(self, arena, process_group=None, bucket_elems=8 * 1024 * 1024):
+        self.arena, self.pg, self.bucket_elems = arena, process_group, bucket_elems
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._pending, self._works, self._done = [], [], []
+        self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+
+    def _launch(self, lo, hi):
+        if self.world == 1 or hi <= lo:
+            return
+        buf = self.arena.grad[lo:hi]
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self._works.append((dist.all_reduce(buf, op=op, group=self.pg, async_op=True), lo, hi))
+
+    def mark_ready(self, prefix):
+        """All gradients of parameters named `prefix`* are final: reduce the range (merged into buckets)."""
+        lo, hi = self.arena.range_of(prefix)
+        self._done.append((lo, hi))
+        self._pending.append((lo, hi))
+        size = sum(h - l for l, h in self._pending)
+        if size >= self.bucket_elems:
+            self._flush()
+
+    def _flush(self):
+        # merge adjacent ranges so one collective covers as much contiguous memory as possible
+        for lo, hi in _merge(self._pending):
+            self._launch(lo, hi)
+        self._pending = []
+
+    def finish(self):
+        """Reduce whatever has not been announced yet, then wait for every collective."""
+        self._flush()
+        covered = _merge(self._done)
+        pos = 0
+        for lo, hi in covered + [(self.arena.total, self.arena.total)]:
+            if lo > pos:
+                self._launch(pos, lo)
+            pos = max(pos, hi)
+        for work, lo, hi in self._works:
+            work.wait()
+            if not self._avg and self.world > 1:
+                self.arena.grad[lo:hi].div_(self.world)
+        self._works, self._done = [], []
+
+
+def _merge(ranges):
+    out = []
+    for lo, hi in sorted(ranges):
+        if out and lo <= out[-1][1]:
+            out[-1] = (out[-1][0], max(out[-1][1], hi))
+        else:
+            out.append((lo, hi))
+    return out
+
+
+class DataParallel(nn.Module):
+    """Drop-in for DistributedDataParallel around an arena-backed ccd_amd model: `.module`, `module.`-prefixed
+    state-dict keys (the finetune script expects them, train_finetune.py:193-200), rank-0 parameter broadcast at
+    construction, overlapped gradient averaging."""
+
+    def __init__(self, module, device_ids=None, find_unused_parameters=False, process_group=None,
+                 bucket_elems=8 * 1024 * 1024):
+        super().__init__()
+        self.module = module
+        self.reducer = None
+        if dist.is_available() and dist.is_initialized():
+            arena = module.ensure_arena()
+            dist.broadcast(arena.flat, src=0, group=process_group)
+            for b in module.buffers():
+                if b.is_floating_point() or b.dtype in (torch.int64, torch.int32):
+                    dist.broadcast(b, src=0, group=process_group)
+            arena.refresh_mirrors()
+            if any(p.requires_grad for p in module.parameters()) and dist.get_world_size(process_group) > 1:
+                self.reducer = GradReducer(arena, process_group, bucket_elems)
+                hook = self.reducer.mark_ready
+                for m in module.modules():
+                    if hasattr(m, "grad_ready_hook"):
+                        m.grad_ready_hook = hook
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def finish_gradient_sync(self):
+        if self.reducer is not None:
+            self.reducer.finish()

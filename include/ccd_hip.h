@@ -91,6 +91,9 @@ typedef struct ccd_mirror_desc {
 } ccd_mirror_desc;
 int ccd_mirror_bf16(const ccd_mirror_desc* d_descs, int ndesc, int total_tiles, void* stream);
 int ccd_cast_bf16(const float* src, ccd_bf16* dst, long n, void* stream);
+/* dst(bf16)[r,:] = src(f32)[r,:] * rowscale[r / rows_per_sample] (rowscale may be NULL): residual gradient -> branch */
+int ccd_scale_cast_rows(const float* src, ccd_bf16* dst, const float* rowscale, int rows_per_sample, long rows, int E,
+                        void* stream);
 
 /* ---------------------------------------------------------------- character-region path (id maps: uint8, 255 = none)
  * label_cluster.forward, Dino/utils/DBSCAN.py:65-103: mask [images,32,128] (nonzero = text) -> idmap            */
@@ -131,7 +134,8 @@ int ccd_dino_loss_fwd(const float* s_logits, const float* t_logits, const float*
                       void* stream);
 int ccd_dino_loss_bwd(const float* s_logits, const float* t_logits, const float* center, int K, const int* d_m,
                       int max_rows, float student_temp, float teacher_temp, const float* stats, float grad_scale,
-                      ccd_bf16* d_logits, void* stream);
+                      const float* d_grad_scale /* optional device scalar, multiplied in */, ccd_bf16* d_logits,
+                      void* stream);
 int ccd_colsum_f32(const float* x, int K, const int* d_rows, int rows_mul, int max_rows, float* out, void* stream);
 int ccd_center_ema(float* center, const float* batch_sum, int K, const int* d_m, int world, float momentum,
                    void* stream);

@@ -1,0 +1,104 @@
+"""End-to-end checks of the product stack (modules + engine + optimizer) against golden fixtures produced by the
+real reference; run under the CPU SIMT executor (tiny model) and on the GPU."""
+import os
+
+import numpy as np
+import torch
+
+from ccd_amd import pretrain
+from ccd_amd.loss.Dino_loss import DINOLoss
+from ccd_amd.synthetic import make_batch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# Every image contributes ONE all-zero pooled row per view (`grid <= length` keeps length+1 rows, dino_vision.py:82-85).
+# While the head biases are still 0 such a row reaches F.normalize as an exact zero vector, whose backward multiplies by
+# 1/eps = 1e12; the reference's incoming gradient there is fp32 rounding residue of (1/K - 1/K), so its head-bias
+# gradients at that point are amplified noise (L2 ~ 1e2..1e4, then clipped to 3).  Ours are exactly 0 for those rows.
+# Those three tensors are therefore excluded from gradient / post-step parity (documented in DESIGN.md).
+NOISE_DOMINATED = ("head.mlp.0.bias", "head.mlp.2.bias", "head.mlp.4.bias")
+
+
+def stat(t):
+    t = t.detach().double().cpu()
+    return np.array([t.sum().item(), t.abs().sum().item(), t.pow(2).sum().sqrt().item()])
+
+
+def tiny_networks(device):
+    torch.manual_seed(3)
+    np.random.seed(3)
+    return pretrain.build_networks(arch=None, out_dim=512, drop_path_rate=0.0, norm_last_layer=False, seg_channel=192,
+                                   backbone_kwargs=dict(embed_dim=192, depth=3, num_heads=3, out_indices=[1, 2, 3]),
+                                   head_kwargs=dict(hidden_dim=256, bottleneck_dim=64), device=device)
+
+
+def check_tiny_step(device, logit_tol=3e-2, loss_tol=2e-3, grad_rtol=6e-2):
+    g = np.load(os.path.join(GOLD, "tiny_step.npz"))
+    student, teacher = tiny_networks(device)
+    # 1. same seed -> bit-identical initial weights as the reference (construction order / RNG stream)
+    sd = student.state_dict()
+    for n, row in zip(g["init_names"], g["init_stats"]):
+        np.testing.assert_allclose(stat(sd[str(n)]), row, rtol=0, atol=0, err_msg=f"init:{n}")
+    dino_loss = DINOLoss(512, 2, 0.04, 0.04, 0, 40).to(device)
+    opt = pretrain.make_optimizer(student, clip_grad=float(g["hyper"][4]))
+    images, masks, metrics = make_batch(2, seed=11, device=device)
+    epoch, lr, wd, mom, clip, freeze = g["hyper"]
+    # forward pieces first (so individual stages can be compared), then the full iteration on fresh grads
+    bn_state = {k: v.clone() for k, v in student.state_dict().items() if "running_" in k or "num_batches" in k}
+    s_out = student(images, metrics, masks, int(epoch))
+    sel = s_out.raw("selection")
+    np.testing.assert_array_equal(sel.idmap.cpu().numpy(), g["zero_idmap"])                # bit-exact index map
+    np.testing.assert_array_equal(s_out["index"].cpu().numpy(), g["new_index"])
+    M = sel.M
+    assert 2 * M == g["student_logits"].shape[0]
+    err = (s_out["mask"].detach().float().cpu().numpy() - g["seg_logits"])
+    assert np.abs(err).max() < 5e-2 * max(1.0, np.abs(g["seg_logits"]).max()), f"seg logits off by {np.abs(err).max()}"
+    got = s_out["instances_view"].detach().float().cpu().numpy()
+    assert np.abs(got - g["student_logits"]).max() < logit_tol, np.abs(got - g["student_logits"]).max()
+    with torch.no_grad():
+        t_out = teacher(images, metrics, None, None, clusters=s_out["zero"])
+    got_t = t_out["instances_view"].float().cpu().numpy()
+    assert np.abs(got_t - g["teacher_logits"]).max() < logit_tol
+    feat = t_out["feature"].float().cpu().numpy()[:, ::4]
+    assert np.abs(feat - g["teacher_feature"]).max() < 6e-2, np.abs(feat - g["teacher_feature"]).max()
+    del s_out, t_out
+    student.load_state_dict(bn_state, strict=False)     # the stage-by-stage forward above must not count as a BN step
+    loss = pretrain.training_iteration(student, teacher, dino_loss, opt, images, masks, metrics, int(epoch), lr, wd, mom,
+                                       freeze_last_layer=int(freeze))
+    losses = np.array([loss.item(), dino_loss.last_losses["mask_loss"].item(), dino_loss.last_losses["Dino_loss"].item()])
+    np.testing.assert_allclose(losses, g["losses"], atol=loss_tol, rtol=0)
+    np.testing.assert_allclose(dino_loss.center.cpu().numpy(), g["center_after"], rtol=0, atol=2e-3)
+    # gradients (pre-clip) against the reference's autograd: L2 norms of every tensor + a few full tensors
+    arena = student.arena
+    worst = 0.0
+    for n, row in zip(g["grad_names"], g["grad_stats"]):
+        got_l2 = arena.g(str(n)).double().pow(2).sum().sqrt().item()
+        if str(n) in NOISE_DOMINATED:
+            continue
+        if row[2] > 1e-6:
+            worst = max(worst, abs(got_l2 - row[2]) / row[2])
+            assert abs(got_l2 - row[2]) <= grad_rtol * row[2] + 1e-7, f"grad norm {n}: {got_l2} vs {row[2]}"
+    for k in g.files:
+        if k.startswith("grad/"):
+            want = g[k]
+            got_g = arena.g(k[5:]).float().cpu().numpy().reshape(want.shape)
+            denom = np.abs(want).max() + 1e-12
+            assert np.abs(got_g - want).max() / denom < 0.15, f"{k}: rel err {np.abs(got_g - want).max() / denom}"
+    # post-step weights and teacher EMA
+    sd = student.state_dict()
+    for n, row in zip(g["post_names"], g["post_stats"]):
+        got_s = stat(sd[str(n)])
+        if "num_batches_tracked" in str(n) or str(n) in NOISE_DOMINATED:
+            continue
+        # Adam's first steps move EVERY element by ~lr, also where the true gradient is exactly 0 and only rounding
+        # noise decides the sign (e.g. the key bias of qkv, to which softmax is invariant): bound by the step size
+        slack = 2.0 * float(lr) * np.sqrt(sd[str(n)].numel())
+        assert abs(got_s[2] - row[2]) <= 2e-3 * row[2] + slack + 1e-6, f"post {n}: {got_s} vs {row}"
+    tsd = teacher.state_dict()
+    for n, row in zip(g["teacher_post_names"], g["teacher_post_stats"]):
+        if str(n) in NOISE_DOMINATED:
+            continue
+        got_s = stat(tsd[str(n)])
+        slack = 2.0 * float(lr) * (1 - float(mom)) * np.sqrt(tsd[str(n)].numel())
+        assert abs(got_s[2] - row[2]) <= 1e-4 * row[2] + slack + 1e-6, f"ema {n}: {got_s} vs {row}"
+    return worst

@@ -1,0 +1,17 @@
+"""The whole product stack (modules, engine, arena, fused optimizer) on the reference's tiny-model fixture, with the
+HIP kernels executed by the CPU SIMT executor."""
+import pytest
+import torch
+
+from backends import Backend
+import model_checks as mc
+
+
+@pytest.fixture(scope="module")
+def sim():
+    with Backend("sim") as b:
+        yield b
+
+
+def test_tiny_training_iteration_sim(sim):
+    mc.check_tiny_step(sim.device)
