@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""bench.py - images/sec of the CCD-ViT-Small pretraining step (BASELINE.json metric) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W                      (single GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = the full iteration of train.py:221-272 on a resident synthetic batch: student fwd
+(2 views), teacher fwd, seg + DINO loss, centre update, backward, per-tensor clip, AdamW, teacher EMA.  bf16 MFMA
+operands, fp32 accumulation / master weights.  Prints ONE JSON line on rank 0 (contract in the task statement) with
+the extra `roofline` (dominant kernel, timed live with HIP events) and `cpu_baseline` (the CPU oracle on this host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_BF16_TF = 2500.0          # MI355X dense bf16 MFMA peak (guide: MI355X_MICROARCH.md)
+GF_PER_IMAGE = {"vit_small": (96.7 + 8.7, 44.56e-3 * 4), "vit_base": (167.6 + 10.1, 45.09e-3 * 4),
+                "vit_tiny": (25.6 + 6.6, 43.9e-3 * 4)}   # (backbone+seg GF/img, head GF per selected row pair) SURVEY 8d
+
+
+def cpu_baseline(arch, steps=2):
+    """The CPU oracle (oracle/, a restatement of the reference's CPU path) on BASELINE config #1: B=8, fp32."""
+    from ccd_amd.synthetic import make_batch
+    from oracle import ccd_oracle as O
+    spec = O.Spec(norm_last_layer=False, drop_path_rate=0.0, **O.ARCH[arch])
+    student, teacher = O.build_pair(spec, seed=0)
+    center, opt = torch.zeros(1, spec.out_dim), O.AdamWState()
+    batch = make_batch(8, seed=0)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        rec = O.train_iteration(student, teacher, center, opt, batch, 1, 1e-5, 0.04, 0.9995)
+        center = rec["center"]
+        if i:
+            times.append(time.perf_counter() - t0)
+    sec = sorted(times)[len(times) // 2]
+    return {"value": round(8.0 / sec, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{arch} B=8 fp32, {steps} timed steps after 1 warm-up, median {sec:.2f} s/step (oracle/ccd_oracle.py)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--arch", default="vit_small")
+    ap.add_argument("--out-dim", type=int, default=65536)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from ccd_amd import ops, pretrain
+    from ccd_amd.loss.Dino_loss import DINOLoss
+    from ccd_amd.parallel import DataParallel
+    from ccd_amd.synthetic import make_batch
+
+    torch.manual_seed(0)
+    student, teacher = pretrain.build_networks(arch=a.arch, out_dim=a.out_dim, drop_path_rate=0.1,
+                                               norm_last_layer=False, device=dev)
+    if world > 1:
+        student = torch.nn.SyncBatchNorm.convert_sync_batchnorm(student)      # train.py:96-98
+        model = DataParallel(student)
+    else:
+        model = student
+    dino_loss = DINOLoss(a.out_dim, 2, 0.04, 0.04, 0, 100).to(dev)
+    opt = pretrain.make_optimizer(student, clip_grad=3.0)
+    B = a.batch
+    images, masks, metrics = make_batch(B, seed=1000 + rank, device=dev)
+    lr, wd, mom = 0.0005 * B * world / 256.0, 0.04, 0.9995
+
+    def step():
+        return pretrain.training_iteration(model, teacher, dino_loss, opt, images, masks, metrics, epoch=1, lr=lr, wd=wd,
+                                           momentum=mom)
+
+    for _ in range(a.warmup):
+        loss = step()
+    timer = None if a.no_kernel_timer else ops.KernelTimer()
+    ops.TIMER = timer
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+    final_loss = loss.item()
+    assert final_loss == final_loss and abs(final_loss) < 1e4, f"non-finite loss {final_loss}"
+
+    if rank == 0:
+        ms = elapsed / a.steps * 1e3
+        ips = B * world * a.steps / elapsed
+        # whole-step MFMA fraction: SURVEY 8(d) FLOP table with the measured rows-per-image of this batch
+        from ccd_amd import engine
+        ids = ops.ccl_label(masks)
+        m_rows = engine.Selection(torch.cat([ids, ops.warp_idmap(ids, metrics)]), B).M / B
+        body, per_row = GF_PER_IMAGE.get(a.arch, GF_PER_IMAGE["vit_small"])
+        gf_img = body + per_row * 2 * m_rows
+        line = {"metric": "images/sec (32x128 crops, 2 views) CCD-ViT-Small pretrain step", "value": round(ips, 2),
+                "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": f"CCD_pretrain_{a.arch} bf16, bs={B}/GPU, 2 views 32x128, out_dim={a.out_dim}, "
+                                       f"drop_path 0.1, dataset-mask branch (pseudo-epoch 1), synthetic batch in HBM",
+                           "global_batch": B * world, "parallelism": f"dp{world}",
+                           "rows_per_image_per_view": round(m_rows, 3), "gflop_per_image": round(gf_img, 1),
+                           "step_frac_of_mfma_peak": round(ips / world * gf_img / 1e3 / PEAK_BF16_TF, 4),
+                           "final_loss": round(final_loss, 4)}}
+        if timer is not None:
+            summ = timer.summary()
+            top = max(summ.items(), key=lambda kv: kv[1]["ms"])
+            key, d = top
+            avg_ms = d["ms"] / d["launches"]
+            achieved = d["flops"] / d["launches"] / avg_ms / 1e9
+            line["roofline"] = {"bound": "mfma", "kernel": f"ccd::gemm_bf16_kernel ({key})",
+                                "achieved": round(achieved, 1), "peak": PEAK_BF16_TF, "unit": "TFLOP/s",
+                                "frac": round(achieved / PEAK_BF16_TF, 4), "traffic": None,
+                                "avg_launch_ms": round(avg_ms, 4), "launches_per_step": d["launches"] // a.steps,
+                                "gemm_ms_per_step": round(sum(v["ms"] for v in summ.values()) / a.steps, 3),
+                                "by_kind_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in sorted(summ.items())}}
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.arch)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

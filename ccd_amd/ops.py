@@ -8,6 +8,32 @@ from . import _lib
 
 EPI_BF16, EPI_GELU, EPI_RESID, EPI_F32, EPI_ATOMIC, EPI_DGELU = range(6)
 BF16, F32 = torch.bfloat16, torch.float32
+_EPI_NAMES = ("bf16", "gelu", "resid", "f32", "atomic", "dgelu")
+
+
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launching stream (bench.py's roofline leg).  Events are
+    only read after the timed region has been synchronised, so recording them never stalls the stream."""
+
+    def __init__(self):
+        self.records = []          # (key, flops, start_event, end_event)
+
+    def span(self, key, flops):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.append((key, flops, e0, e1))
+        return e0, e1
+
+    def summary(self):
+        out = {}
+        for key, flops, e0, e1 in self.records:
+            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+        return out
+
+
+TIMER = None     # set to a KernelTimer to time every GEMM launch
 
 
 def _chk(t, dtype, name):
@@ -36,11 +62,16 @@ def gemm_nt(a, b, *, epilogue=EPI_BF16, out=None, out2=None, bias=None, resid=No
     if m_fastest is None:
         m_fastest = 1 if N > M else 0
     lib = _lib.get()
+    span = TIMER.span("gemm_nt_" + _EPI_NAMES[epilogue], 2.0 * M * N * K) if TIMER is not None and d_rows is None else None
+    if span:
+        span[0].record()
     _lib.check(lib.ccd_gemm_nt(_lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0), M, N, K, epilogue, _lib.ptr(out),
                                out.stride(0), _lib.ptr(out2), 0 if out2 is None else out2.stride(0), _lib.ptr(bias),
                                _lib.ptr(resid), 0 if resid is None else resid.stride(0), _lib.ptr(rowscale),
                                rows_per_sample, _lib.ptr(aux), 0 if aux is None else aux.stride(0), float(alpha),
                                int(m_fastest), _lib.ptr(d_rows), int(rows_mul), _lib.stream()), "gemm_nt")
+    if span:
+        span[1].record()
     return (out, out2) if epilogue == EPI_GELU else out
 
 
@@ -51,10 +82,16 @@ def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, splits=0, d_rows=None, row
     Q = b.shape[1]
     assert b.shape[0] == Mc and tuple(out.shape) == (Pd, Q)
     lib = _lib.get()
+    span = TIMER.span("gemm_tn_" + ("atomic" if accumulate else "f32"), 2.0 * Mc * Pd * Q) \
+        if TIMER is not None and d_rows is None else None
+    if span:
+        span[0].record()
     _lib.check(lib.ccd_gemm_tn(_lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0), Pd, Q, Mc,
                                EPI_ATOMIC if accumulate else EPI_F32, _lib.ptr(out), out.stride(0), float(alpha),
                                int(splits) if accumulate else 1, _lib.ptr(d_rows), int(rows_mul), _lib.stream()),
                "gemm_tn")
+    if span:
+        span[1].record()
     return out
 
 

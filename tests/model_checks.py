@@ -102,3 +102,89 @@ def check_tiny_step(device, logit_tol=3e-2, loss_tol=2e-3, grad_rtol=6e-2):
         slack = 2.0 * float(lr) * (1 - float(mom)) * np.sqrt(tsd[str(n)].numel())
         assert abs(got_s[2] - row[2]) <= 1e-4 * row[2] + slack + 1e-6, f"ema {n}: {got_s} vs {row}"
     return worst
+
+
+def check_small_steps(device, loss_tol=1e-3):
+    """BASELINE config #1: CCD_pretrain_ViT_small hyper-parameters, B=8, two consecutive iterations vs the reference."""
+    g = np.load(os.path.join(GOLD, "small_step.npz"))
+    torch.manual_seed(0)
+    np.random.seed(0)
+    student, teacher = pretrain.build_networks(arch="vit_small", out_dim=65536, drop_path_rate=0.0,
+                                               norm_last_layer=False, device=device)
+    sd = student.state_dict()
+    for n, row in zip(g["init_names"], g["init_stats"]):
+        np.testing.assert_allclose(stat(sd[str(n)]), row, rtol=0, atol=0, err_msg=f"init:{n}")
+    dino_loss = DINOLoss(65536, 2, 0.04, 0.04, 0, 40).to(device)
+    opt = pretrain.make_optimizer(student, clip_grad=3.0)
+    report = {}
+    for step in range(2):
+        p = f"s{step}/"
+        epoch, lr, wd, mom, clip, freeze, seed = g[p + "hyper"]
+        images, masks, metrics = make_batch(8, seed=int(seed), device=device)
+        captured = {}
+        orig = student.forward
+
+        def spy(*a, **k):
+            out = orig(*a, **k)
+            captured["out"] = out
+            return out
+
+        student.forward = spy
+        loss = pretrain.training_iteration(student, teacher, dino_loss, opt, images, masks, metrics, int(epoch), lr, wd,
+                                           mom, freeze_last_layer=int(freeze))
+        student.forward = orig
+        out = captured["out"]
+        sel = out.raw("selection")
+        np.testing.assert_array_equal(sel.idmap.cpu().numpy(), g[p + "zero_idmap"])          # bit-exact index map
+        np.testing.assert_array_equal(out["index"].cpu().numpy(), g[p + "new_index"])
+        losses = np.array([loss.item(), dino_loss.last_losses["mask_loss"].item(),
+                           dino_loss.last_losses["Dino_loss"].item()])
+        report[f"step{step}"] = {"got": losses.tolist(), "want": g[p + "losses"].tolist()}
+        np.testing.assert_allclose(losses, g[p + "losses"], atol=loss_tol, rtol=0, err_msg=f"losses step {step}")
+        r, c = g[p + "rows"], g[p + "cols"]
+        sl = out["instances_view"].detach().float()[torch.as_tensor(r)][:, torch.as_tensor(c)].cpu().numpy()
+        assert np.abs(sl - g[p + "student_logits_sample"]).max() < 3e-2
+        np.testing.assert_allclose(dino_loss.center[0, torch.as_tensor(c)].cpu().numpy(), g[p + "center_sample"], atol=2e-3)
+        arena = student.arena
+        for n, row in zip(g[p + "grad_names"], g[p + "grad_stats"]):
+            if str(n) in NOISE_DOMINATED or row[2] < 1e-5:
+                continue
+            if step == 0 and "last_layer" in str(n):
+                pass        # cancelled for the update, but the gradient itself is still comparable
+            got_l2 = arena.g(str(n)).double().pow(2).sum().sqrt().item()
+            assert abs(got_l2 - row[2]) <= 8e-2 * row[2] + 1e-7, f"step {step} grad norm {n}: {got_l2} vs {row[2]}"
+    return report
+
+
+def check_properties_full_size(device, B=256):
+    """Size-independent properties at BASELINE's full batch (where the oracle is too slow to be the checker)."""
+    from ccd_amd import engine, ops
+    images, masks, metrics = make_batch(B, seed=5, device=device)
+    ids = ops.ccl_label(masks)
+    # round trip through the reference's dense representation
+    assert torch.equal(ops.planes_to_idmap(ops.idmap_to_planes(ids)), ids)
+    # identity warp is the identity map; labelling a relabelled map is idempotent
+    eye = torch.eye(3, device=device).repeat(B, 1, 1)
+    assert torch.equal(ops.warp_idmap(ids, eye), ids)
+    relabel = ops.ccl_label((ids != 255).float())
+    assert torch.equal(relabel, ids)
+    # planes are ordered left to right: mean column of plane k is non-decreasing in k
+    idn = ids.cpu().numpy()
+    xs = np.arange(128)[None, None, :]
+    for b in range(0, B, 37):
+        means = [(xs * (idn[b:b + 1] == k)).sum() / max((idn[b] == k).sum(), 1) for k in range(26) if (idn[b] == k).any()]
+        assert means == sorted(means)
+    # attention with V == 1 returns 1 (softmax rows sum to one), any Q/K
+    E, heads = 384, 6
+    qkv = torch.randn(64, 256, 3 * E, device=device, dtype=torch.bfloat16)
+    qkv[..., 2 * E:] = 1.0
+    out, _ = ops.attention_fwd(qkv, heads, 0.125)
+    assert (out.float() - 1.0).abs().max() < 1e-2
+    # region pooling is linear in the features
+    sel = engine.Selection(torch.cat([ids, ops.warp_idmap(ids, metrics)]), B)
+    f1 = torch.randn(2 * B, 256, E, device=device, dtype=torch.bfloat16)
+    f2 = torch.randn(2 * B, 256, E, device=device, dtype=torch.bfloat16)
+    pool = lambda f: engine.RegionPoolFn.apply(f, sel).float()
+    assert (pool(f1) + pool(f2) - pool((f1.float() + f2.float()).to(torch.bfloat16))).abs().max() < 8e-2
+    # optimizer: zero learning rate leaves the weights untouched; EMA with momentum 1 leaves the teacher untouched
+    return int(sel.M)
