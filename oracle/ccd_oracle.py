@@ -293,18 +293,30 @@ def select_rows(vecs: torch.Tensor, index: torch.Tensor):
     return rows, new_index
 
 
-def dino_head_forward(P, pre, x):
-    """DINOHead.forward, vision_transformer.py:324-328; weight_norm: w = g * v / ||v||_row (:313)."""
+def dino_head_forward(P, pre, x, exact_zero_rows=False):
+    """DINOHead.forward, vision_transformer.py:324-328; weight_norm: w = g * v / ||v||_row (:313).
+
+    exact_zero_rows (NOT the reference's behaviour, default off): every image contributes one all-zero pooled row
+    per view (`grid <= length` keeps length+1 rows, dino_vision.py:82-85).  While the head biases are still 0 such a
+    row reaches F.normalize as an exact zero vector whose backward multiplies by 1/eps = 1e12; in exact arithmetic
+    the incoming gradient there is 0 ((1/K - 1/K)), in fp32 it is rounding residue, so the reference's head-bias
+    gradients at those iterations are amplified noise (L2 ~ 1e4 at B=8).  With the flag set those rows carry no
+    gradient - the mathematically exact result - which is what a different arithmetic (e.g. the HIP path) produces."""
+    x_in = x
     x = F.gelu(F.linear(x, P[pre + "mlp.0.weight"], P[pre + "mlp.0.bias"]))
     x = F.gelu(F.linear(x, P[pre + "mlp.2.weight"], P[pre + "mlp.2.bias"]))
     x = F.linear(x, P[pre + "mlp.4.weight"], P[pre + "mlp.4.bias"])
     x = F.normalize(x, dim=-1, p=2)
     v, g = P[pre + "last_layer.weight_v"], P[pre + "last_layer.weight_g"]
     w = v * (g / v.norm(dim=1, keepdim=True))
-    return F.linear(x, w)
+    out = F.linear(x, w)
+    if exact_zero_rows:
+        dead = x_in.abs().sum(dim=1, keepdim=True) == 0
+        out = torch.where(dead, out.detach(), out)
+    return out
 
 
-def student_forward(net: Net, images, metrics, target_mask, epoch, drop=None):
+def student_forward(net: Net, images, metrics, target_mask, epoch, drop=None, exact_zero_rows=False):
     """ABIDINOModel.forward with clusters=None, dino_vision.py:51-97."""
     P, spec = net.P, net.spec
     x = torch.cat([images[:, 1], images[:, 2]])
@@ -321,7 +333,7 @@ def student_forward(net: Net, images, metrics, target_mask, epoch, drop=None):
     clusters = torch.cat([src, warp_planes(src, metrics)], dim=0)
     vecs, index = region_pool(region_f, clusters)
     rows, new_index = select_rows(vecs, index)
-    logits = dino_head_forward(P, "head.", rows)
+    logits = dino_head_forward(P, "head.", rows, exact_zero_rows)
     return {"instances_view": logits, "mask": seg, "zero": clusters, "index": new_index,
             "idmap": ccl_np.planes_to_idmap(clusters.numpy()), "pool_index": index, "rows": rows,
             "region_f": region_f}
@@ -432,10 +444,11 @@ def ema_teacher(student: Net, teacher: Net, m: float):
 
 
 def train_iteration(student: Net, teacher: Net, center, opt: AdamWState, batch, epoch, lr, wd, mom,
-                    teacher_temp=0.04, clip=3.0, freeze_last_layer=1, world_size=1, all_reduce=None, drop=None):
+                    teacher_temp=0.04, clip=3.0, freeze_last_layer=1, world_size=1, all_reduce=None, drop=None,
+                    exact_zero_rows=False):
     """train.py:221-272 on CPU.  Returns a record of everything the parity tests look at."""
     images, masks, metrics = batch
-    s_out = student_forward(student, images, metrics, masks, epoch, drop)
+    s_out = student_forward(student, images, metrics, masks, epoch, drop, exact_zero_rows)
     t_out = teacher_forward(teacher, images, s_out["zero"])
     masks_image = warp_planes(masks.unsqueeze(1), metrics).squeeze(1)
     gt = torch.cat([masks, masks_image])
