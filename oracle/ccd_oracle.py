@@ -300,18 +300,19 @@ def dino_head_forward(P, pre, x, exact_zero_rows=False):
     per view (`grid <= length` keeps length+1 rows, dino_vision.py:82-85).  While the head biases are still 0 such a
     row reaches F.normalize as an exact zero vector whose backward multiplies by 1/eps = 1e12; in exact arithmetic
     the incoming gradient there is 0 ((1/K - 1/K)), in fp32 it is rounding residue, so the reference's head-bias
-    gradients at those iterations are amplified noise (L2 ~ 1e4 at B=8).  With the flag set those rows carry no
-    gradient - the mathematically exact result - which is what a different arithmetic (e.g. the HIP path) produces."""
-    x_in = x
+    gradients at those iterations are amplified noise (L2 ~ 1e4 at B=8).  With the flag set, rows whose pre-normalise
+    vector is EXACTLY zero carry no gradient - the mathematically exact result, and what a different arithmetic
+    (e.g. the HIP path) produces.  Once the biases have moved (after the first update) no row is exactly zero any more
+    and the flag changes nothing."""
     x = F.gelu(F.linear(x, P[pre + "mlp.0.weight"], P[pre + "mlp.0.bias"]))
     x = F.gelu(F.linear(x, P[pre + "mlp.2.weight"], P[pre + "mlp.2.bias"]))
     x = F.linear(x, P[pre + "mlp.4.weight"], P[pre + "mlp.4.bias"])
+    dead = x.detach().abs().sum(dim=1, keepdim=True) == 0      # rows that reach F.normalize as exact zeros
     x = F.normalize(x, dim=-1, p=2)
     v, g = P[pre + "last_layer.weight_v"], P[pre + "last_layer.weight_g"]
     w = v * (g / v.norm(dim=1, keepdim=True))
     out = F.linear(x, w)
     if exact_zero_rows:
-        dead = x_in.abs().sum(dim=1, keepdim=True) == 0
         out = torch.where(dead, out.detach(), out)
     return out
 
