@@ -1,0 +1,111 @@
+"""Host-side logic of the product package (no GPU, no kernels): config surface, schedules, parameter naming / init
+parity with the reference, the bicubic positional resampling matrix, optimizer checkpoint layout, C-ABI symbols."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    from ccd_amd import _lib
+    header = open(os.path.join(ROOT, "include", "ccd_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(?:int|const char\*)\s+(ccd_\w+)\s*\(", header)))
+    assert len(declared) >= 35, declared
+    assert os.path.isfile(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(_lib.LIB_PATH)            # loads without a GPU; no compute call is made here
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(_lib.SIGNATURES) == declared, "ccd_amd/_lib.py signature table out of sync with include/ccd_hip.h"
+    _lib.bind(lib)
+    assert lib.ccd_abi_version() == 1
+
+
+def test_product_has_no_cpu_fallback():
+    """Without the HIP library / a GPU the ops raise instead of computing something on the host."""
+    from ccd_amd import _lib
+    from ccd_amd.modules import vision_transformer as vits
+    assert _lib._stream_override is None
+    m = vits.VisionTransformer(patch_size=4, embed_dim=64, depth=1, num_heads=1, qkv_bias=True, out_indices=[1, 1, 1])
+    with pytest.raises(RuntimeError, match="GPU"):
+        m(torch.zeros(1, 3, 32, 128))
+    for f in os.listdir(os.path.join(ROOT, "ccd_amd")):
+        if f.endswith(".py"):
+            assert "oracle" not in open(os.path.join(ROOT, "ccd_amd", f)).read().replace("the CPU oracle", ""), f
+
+
+def test_schedules_match_reference(golden_dir):
+    from ccd_amd.loss.Dino_loss import DINOLoss
+    from ccd_amd.modules import utils
+    g = np.load(os.path.join(golden_dir, "sched.npz"))
+    np.testing.assert_array_equal(utils.cosine_iter_scheduler(0.0005 * 8 / 256.0, 1e-6, 50, warmup_iters=10), g["lr"])
+    np.testing.assert_array_equal(utils.cosine_iter_scheduler(0.04, 0.4, 50), g["wd"])
+    np.testing.assert_array_equal(utils.cosine_iter_scheduler(0.9995, 1, 50), g["mom"])
+    np.testing.assert_array_equal(DINOLoss(16, 2, 0.02, 0.07, 5, 12).teacher_temp_schedule, g["teacher_temp_5_12"])
+
+
+def test_state_dict_names_shapes_and_trainable_sets(golden_dir):
+    from ccd_amd.model.dino_vision import ABIDINOModel
+    from ccd_amd.modules import utils, vision_transformer as vits
+    from ccd_amd.modules.segmentor import SegHead
+    keys = json.load(open(os.path.join(golden_dir, "state_keys.json")))
+    for arch, e in (("vit_tiny", 192), ("vit_small", 384), ("vit_base", 512)):
+        torch.manual_seed(0)
+        sb = vits.__dict__[arch](patch_size=4, drop_path_rate=0.1)
+        tb = vits.__dict__[arch](patch_size=4)
+        student = ABIDINOModel(sb, SegHead(in_channels=e, mla_channels=128, mlahead_channels=64, num_classes=2),
+                               vits.DINOHead(e, 1024, norm_last_layer=False))
+        teacher = ABIDINOModel(tb, None, vits.DINOHead(e, 1024))
+        assert [[k, list(v.shape), str(v.dtype)] for k, v in student.state_dict().items()] == keys[arch]["student"]
+        assert [[k, list(v.shape), str(v.dtype)] for k, v in teacher.state_dict().items()] == keys[arch]["teacher"]
+        assert [n for n, p in student.named_parameters() if p.requires_grad] == keys[arch]["student_trainable"]
+        groups = utils.get_params_groups(student)
+        assert groups[1]["weight_decay"] == 0.0 and all(p.dim() == 1 for p in groups[1]["params"])
+        assert utils.has_batchnorms(student) and not utils.has_batchnorms(teacher)
+        unused = student.unused_parameter_names()
+        assert len(unused) == 19 and "backbone.cls_token" in unused          # SURVEY: 19 tensors never get a gradient
+
+
+def test_bicubic_resample_matrix_is_aten_bicubic():
+    """The fixed 256x256 map used for pos-embed resampling == F.interpolate(bicubic, scale_factor=(8.1/16, 32.1/16))."""
+    from ccd_amd.engine import bicubic_resample_matrix
+    m = bicubic_resample_matrix(16, 8, 32)
+    g = torch.Generator().manual_seed(0)
+    pos = torch.randn(1, 256, 24, generator=g)
+    want = F.interpolate(pos.reshape(1, 16, 16, 24).permute(0, 3, 1, 2), scale_factor=(8.1 / 16, 32.1 / 16),
+                         mode="bicubic").permute(0, 2, 3, 1).reshape(256, 24)
+    np.testing.assert_allclose((m @ pos[0]).numpy(), want.numpy(), rtol=0, atol=2e-6)
+    assert abs(float(m.sum(1).mean()) - 1.0) < 1e-5        # rows are interpolation weights
+
+
+def test_config_surface():
+    from ccd_amd.utils.utils import Config
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        for name, arch, seg, nl in (("small", "vit_small", 384, False), ("Tiny", "vit_tiny", 192, False),
+                                    ("Base", "vit_base", 512, True)):
+            c = Config(f"Dino/configs/CCD_pretrain_ViT_{name}.yaml")
+            assert (c.arch, c.model_seg_channel, c.norm_last_layer) == (arch, seg, nl)
+            assert (c.patch_size, c.out_dim, c.crops_number, c.clip_grad, c.optimizer) == (4, 65536, 2, 3.0, "adamw")
+            assert (c.dataset_image_height, c.dataset_image_width, c.training_epochs, c.imgnet_based) == (32, 128, 3, 1000000)
+            assert c.not_a_key is None and isinstance(c.dataset_train, dict)
+            assert c.global_workdir == os.path.join("workdir", c.global_name)
+    finally:
+        os.chdir(cwd)
+
+
+def test_dino_import_paths_alias_the_product():
+    import Dino  # noqa: F401
+    from Dino.loss.Dino_loss import DINOLoss
+    from Dino.model.dino_vision import ABIDINOModel
+    from Dino.modules import vision_transformer as vits
+    import ccd_amd.modules.vision_transformer as native
+    assert vits is native and ABIDINOModel.__module__.startswith("ccd_amd") and DINOLoss.__module__.startswith("ccd_amd")

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Steady-state per-kernel summary of a `rocprofv3 --kernel-trace --output-format csv` run of bench.py.
+
+The whole-process `--stats` table is dominated by one-off work (MIOpen's solver search for the segmentation-head
+convolutions launches naive reference kernels during the warm-up steps), so this script cuts the trace at the
+student patch-embedding launches and aggregates the LAST `--steps` training iterations only.
+
+    python tools/prof_summary.py gpurun_out/prof_r1b/bench_kernel_trace.csv --steps 2 > profiles/<name>.md
+"""
+import argparse
+import collections
+import csv
+import re
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name)
+    name = name.replace("void ", "")
+    return name[:110]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("trace")
+    ap.add_argument("--steps", type=int, default=2)
+    a = ap.parse_args()
+    rows = []
+    with open(a.trace) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["VGPR_Count"]),
+                         int(r["Accum_VGPR_Count"]), int(r["LDS_Block_Size"])))
+    rows.sort()
+    marks = [i for i, r in enumerate(rows) if "patch_embed_fwd_kernel" in r[2]]
+    assert len(marks) >= 2 * a.steps, "trace too short"
+    begin = marks[-2 * a.steps]                      # two launches per iteration: student, then teacher
+    sel = rows[begin:]
+    wall_ms = (sel[-1][1] - sel[0][0]) / 1e6
+    agg = collections.OrderedDict()
+    for s, e, n, v, av, lds in sel:
+        d = agg.setdefault(short(n), {"calls": 0, "ns": 0, "vgpr": v, "agpr": av, "lds": lds, "min": 1 << 62, "max": 0})
+        d["calls"] += 1
+        d["ns"] += e - s
+        d["min"], d["max"] = min(d["min"], e - s), max(d["max"], e - s)
+    busy_ms = sum(d["ns"] for d in agg.values()) / 1e6
+    print(f"# steady-state kernel summary: last {a.steps} iteration(s) of `{a.trace}`\n")
+    print(f"wall {wall_ms / a.steps:.3f} ms/iteration, kernel-busy {busy_ms / a.steps:.3f} ms/iteration "
+          f"({100 * busy_ms / wall_ms:.1f} % of wall)\n")
+    print("| kernel | calls/iter | total ms/iter | % busy | avg us | min us | max us | VGPR+AGPR | LDS B |")
+    print("|---|---|---|---|---|---|---|---|---|")
+    for k, d in sorted(agg.items(), key=lambda kv: -kv[1]["ns"]):
+        print(f"| `{k}` | {d['calls'] / a.steps:.1f} | {d['ns'] / 1e6 / a.steps:.3f} | {100 * d['ns'] / 1e6 / busy_ms:.1f} | "
+              f"{d['ns'] / d['calls'] / 1e3:.1f} | {d['min'] / 1e3:.1f} | {d['max'] / 1e3:.1f} | {d['vgpr']}+{d['agpr']} | {d['lds']} |")
+
+
+if __name__ == "__main__":
+    main()
