@@ -24,7 +24,7 @@
 template <bool TN>
 static int ccd_launch_gemm(const ccd::GemmParams& p, int epilogue, int splits, void* stream) {
     const int tiles = ((p.M + ccd::GEMM_BM - 1) / ccd::GEMM_BM) * ((p.N + ccd::GEMM_BN - 1) / ccd::GEMM_BN);
-    const dim3 grid(tiles, 1, splits), block(256);
+    const dim3 grid(tiles * splits), block(256);
     const size_t smem = ccd::GEMM_SMEM_BYTES;
     switch (epilogue) {
         case CCD_EPI_BF16: CCD_LAUNCH((ccd::gemm_bf16_kernel<TN, ccd::EPI_BF16>), grid, block, smem, stream, p); break;

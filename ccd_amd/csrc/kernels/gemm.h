@@ -164,7 +164,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const int wm = w >> 1, wn = w & 1;
 
     const int tiles_m = (m_static + GEMM_BM - 1) / GEMM_BM, tiles_n = (p.N + GEMM_BN - 1) / GEMM_BN;
-    const unsigned tile = xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n));
+    // 1-D grid of tiles x splits.  After the XCD remap consecutive ids share an XCD (= an L2): for NT these are the
+    // column tiles of one A row-panel, for TN all output tiles of ONE contraction slice, which stream the same
+    // dY / X rows at the same time - the re-reads are then L2 hits instead of HBM traffic.
+    const unsigned ntile = (unsigned)(tiles_m * tiles_n);
+    const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned tile = lin % ntile, split = lin / ntile;
     int tm, tn;
     if (p.m_fastest) { tm = tile % tiles_m; tn = tile / tiles_m; }
     else { tn = tile % tiles_n; tm = tile / tiles_n; }
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 
     int k_begin = 0, k_end = p.K;
     if (TN) {
-        k_begin = blockIdx.z * p.k_per_split;
+        k_begin = split * p.k_per_split;
         k_end = k_begin + p.k_per_split < p.K ? k_begin + p.k_per_split : p.K;
     }
     const int nk = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
