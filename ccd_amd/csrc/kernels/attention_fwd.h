@@ -60,7 +60,7 @@ __device__ __forceinline__ void att_stage_transposed(const bf16_t* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, int heads, float scale) {
     char* smem = dynamic_smem();
     char* k_img = smem;
