@@ -52,59 +52,92 @@ constexpr int GEMM_STAGE_BYTES = GEMM_BM * GEMM_BK * 2;          // one operand,
 constexpr int GEMM_CS_LD = 132;                                   // fp32 staging row stride (floats)
 constexpr int GEMM_SMEM_BYTES = GEMM_BM * GEMM_CS_LD * 4;         // 67,584 B  (>= 4 stages * 16 KiB)
 
-__device__ __forceinline__ int gemm_swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
+// 16-byte slot swizzle of the LDS image.  Brute-force checked (all lane groups of ds_read_b128 / ds_write_b128 /
+// ds_write_b64): fragment reads and NT staging writes conflict-free, TN staging writes 2-way.
+__device__ __forceinline__ int gemm_swz(int row, int slot) { return slot ^ (((row >> 1) ^ (row >> 4)) & 7); }
 
-// ---- NT loader: thread t fetches 4 x 16 B per operand; 8 consecutive threads cover one 128-B tile row
-__device__ __forceinline__ void gemm_load_nt(const bf16_t* __restrict__ src, long ld, int row0, int nrows, int k0,
-                                              u32x4 (&r)[4]) {
-    const int t = threadIdx.x;
+// ---- NT staging: thread t moves 4 x 16 B per operand; 8 consecutive lanes cover one 128-B tile row (coalesced),
+// chunk i of thread t is tile row (t >> 3) + 32 i, slot t & 7.  Row validity is loop-invariant.
+struct NtCursor {
+    const bf16_t* ptr[4];
+    bool ok[4];
+    __device__ __forceinline__ void init(const bf16_t* base, long ld, int row0, int nrows, int k_begin) {
+        const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int id = t + 256 * i, row = id >> 3, slot = id & 7;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (row0 + row < nrows) v = *reinterpret_cast<const u32x4*>(src + (long)(row0 + row) * ld + k0 + slot * 8);
-        r[i] = v;
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + (t >> 3) + 32 * i;
+            ok[i] = row < nrows;
+            ptr[i] = base + (long)(ok[i] ? row : 0) * ld + k_begin + (t & 7) * 8;
+        }
     }
-}
+    __device__ __forceinline__ void load(u32x4 (&r)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok[i]) v = *reinterpret_cast<const u32x4*>(ptr[i]);
+            r[i] = v;
+            ptr[i] += GEMM_BK;
+        }
+    }
+};
 __device__ __forceinline__ void gemm_store_nt(char* tile, const u32x4 (&r)[4]) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int id = t + 256 * i, row = id >> 3, slot = id & 7;
+        const int row = (t >> 3) + 32 * i, slot = t & 7;
         *reinterpret_cast<u32x4*>(tile + row * 128 + gemm_swz(row, slot) * 16) = r[i];
     }
 }
-// ---- TN loader: the tile is 64 contraction rows x 128 columns in memory; a thread fetches a 4(m) x 8(col)
-// block (4 x 16 B, each 16-lane group reads 16 different m rows of the same 8 columns... 4 groups of a wave sit
-// on adjacent column blocks so a wave instruction touches 16 rows x 64 contiguous bytes), transposes it in
-// registers and writes 8 x 8 B: instruction j stores column 8*nb+j, m-chunk mb -> the 16 lanes of a write
-// group share the LDS row and cover its 16 distinct 8-byte chunks (conflict-free).
-__device__ __forceinline__ void gemm_load_tn(const bf16_t* __restrict__ src, long ld, int col0, int ncols, int m0,
-                                              int m_end, u32x4 (&r)[4]) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int mb = lane & 15, nb = w * 4 + (lane >> 4);
-    const int col = col0 + 8 * nb;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + 4 * mb + i;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (m < m_end && col < ncols) v = *reinterpret_cast<const u32x4*>(src + (long)m * ld + col);
-        r[i] = v;
+// ---- TN staging: the tile is 64 contraction rows x 128 columns in memory.  Thread t owns column block cb = t & 15
+// (8 columns = 16 B) and contraction block mb = t >> 4 (4 rows): 16 consecutive lanes read 256 contiguous bytes of one
+// row (coalesced), the 4 x 8 block is transposed in registers, and store j writes tile row 8*cb + j, 8-byte chunk mb.
+struct TnCursor {
+    const bf16_t* ptr;
+    long ld;
+    bool col_ok;
+    __device__ __forceinline__ void init(const bf16_t* base, long ld_, int col0, int ncols, int k_begin) {
+        const int t = threadIdx.x;
+        const int col = col0 + 8 * (t & 15);
+        ld = ld_;
+        col_ok = col < ncols;
+        ptr = base + (long)(k_begin + 4 * (t >> 4)) * ld_ + (col_ok ? col : 0);
     }
-}
+    // rows_left: contraction rows still available from this tile's first row (>= 64 for interior tiles)
+    __device__ __forceinline__ void load(u32x4 (&r)[4], int rows_left) {
+        const int mrow = 4 * (threadIdx.x >> 4);
+        if (rows_left >= GEMM_BK) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (col_ok) v = *reinterpret_cast<const u32x4*>(ptr + i * ld);
+                r[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (col_ok && mrow + i < rows_left) v = *reinterpret_cast<const u32x4*>(ptr + i * ld);
+                r[i] = v;
+            }
+        }
+        ptr += (long)GEMM_BK * ld;
+    }
+};
 __device__ __forceinline__ void gemm_store_tn(char* tile, const u32x4 (&r)[4]) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int mb = lane & 15, nb = w * 4 + (lane >> 4);
+    const int t = threadIdx.x;
+    const int cb = t & 15, mb = t >> 4;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int row = 8 * nb + j;                         // tile row = output row/column index
-        unsigned e0, e1, e2, e3;                            // element j of the four m rows
+        const int row = 8 * cb + j;                         // tile row = output row/column index
         const unsigned w0 = r[0][j >> 1], w1 = r[1][j >> 1], w2 = r[2][j >> 1], w3 = r[3][j >> 1];
-        if (j & 1) { e0 = w0 >> 16; e1 = w1 >> 16; e2 = w2 >> 16; e3 = w3 >> 16; }
-        else { e0 = w0 & 0xffffu; e1 = w1 & 0xffffu; e2 = w2 & 0xffffu; e3 = w3 & 0xffffu; }
         u32x2 o;
-        o.x = e0 | (e1 << 16);
-        o.y = e2 | (e3 << 16);
+        if (j & 1) {                                        // high halves of the four m rows
+            o.x = (w0 >> 16) | (w1 & 0xffff0000u);
+            o.y = (w2 >> 16) | (w3 & 0xffff0000u);
+        } else {
+            o.x = (w0 & 0xffffu) | (w1 << 16);
+            o.y = (w2 & 0xffffu) | (w3 << 16);
+        }
         *reinterpret_cast<u32x2*>(tile + row * 128 + gemm_swz(row, mb >> 1) * 16 + (mb & 1) * 8) = o;
     }
 }
@@ -192,14 +225,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     u32x4 ra[4], rb[4];
+    NtCursor nta, ntb;
+    TnCursor tna, tnb;
+    if (TN) {
+        tna.init(p.A, p.lda, m0, p.M, k_begin);
+        tnb.init(p.B, p.ldb, n0, p.N, k_begin);
+    } else {
+        nta.init(p.A, p.lda, m0, p.M, k_begin);
+        ntb.init(p.B, p.ldb, n0, p.N, k_begin);
+    }
     auto load = [&](int kt) {
-        const int k0 = k_begin + kt * GEMM_BK;
         if (TN) {
-            gemm_load_tn(p.A, p.lda, m0, p.M, k0, k_end, ra);
-            gemm_load_tn(p.B, p.ldb, n0, p.N, k0, k_end, rb);
+            const int left = k_end - (k_begin + kt * GEMM_BK);
+            tna.load(ra, left);
+            tnb.load(rb, left);
         } else {
-            gemm_load_nt(p.A, p.lda, m0, p.M, k0, ra);
-            gemm_load_nt(p.B, p.ldb, n0, p.N, k0, rb);
+            nta.load(ra);
+            ntb.load(rb);
         }
     };
     auto store = [&](int stage) {
@@ -255,6 +297,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
                 cs[row * GEMM_CS_LD + col] = acc[i][j][r] * p.alpha;
             }
     __syncthreads();
+    if (EPI == EPI_ATOMIC) {     // 64 consecutive lanes -> 64 consecutive floats of one row: one 256-B atomic burst
+        const int col = t & 127, gn = n0 + col;
+        if (gn < p.N) {
+#pragma unroll 4
+            for (int row = t >> 7; row < GEMM_BM; row += 2) {
+                const int gm = m0 + row;
+                if (gm < p.M) atomicAdd(reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn, cs[row * GEMM_CS_LD + col]);
+            }
+        }
+        return;
+    }
 #pragma unroll 1
     for (int pass = 0; pass < 8; ++pass) {
         const int row = pass * 16 + (t >> 4), col = (t & 15) * 8;
