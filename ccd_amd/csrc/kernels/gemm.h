@@ -185,7 +185,7 @@ __device__ __forceinline__ void gemm_epilogue_row8(const GemmParams& p, int gm, 
 }
 
 template <bool TN, int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     const int m_static = p.M;                               // the launch grid was sized for the static shape
     if (p.d_rows) {
         const int dyn = p.d_rows[0] * p.rows_mul;
@@ -224,7 +224,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    u32x4 ra[4], rb[4];
+    // Two register sets hold the k-tiles t+1 and t+2 while tile t is multiplied out of LDS: global loads are issued
+    // TWO iterations ahead of the LDS write that consumes them (the CU keeps ~2 x 32 KiB per workgroup in flight).
+    u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
     NtCursor nta, ntb;
     TnCursor tna, tnb;
     if (TN) {
@@ -234,31 +236,27 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         nta.init(p.A, p.lda, m0, p.M, k_begin);
         ntb.init(p.B, p.ldb, n0, p.N, k_begin);
     }
-    auto load = [&](int kt) {
-        if (TN) {
-            const int left = k_end - (k_begin + kt * GEMM_BK);
-            tna.load(ra, left);
-            tnb.load(rb, left);
-        } else {
-            nta.load(ra);
-            ntb.load(rb);
+    int next_tile = 0;                                      // tiles are fetched strictly in order
+    auto load = [&](u32x4 (&ra)[4], u32x4 (&rb)[4]) {
+        if (next_tile < nk) {
+            if (TN) {
+                const int left = k_end - (k_begin + next_tile * GEMM_BK);
+                tna.load(ra, left);
+                tnb.load(rb, left);
+            } else {
+                nta.load(ra);
+                ntb.load(rb);
+            }
         }
+        ++next_tile;
     };
-    auto store = [&](int stage) {
+    auto store = [&](int stage, const u32x4 (&ra)[4], const u32x4 (&rb)[4]) {
         char* as = smem + stage * 2 * GEMM_STAGE_BYTES;
         char* bs = as + GEMM_STAGE_BYTES;
         if (TN) { gemm_store_tn(as, ra); gemm_store_tn(bs, rb); }
         else { gemm_store_nt(as, ra); gemm_store_nt(bs, rb); }
     };
-
-    if (nk > 0) {
-        load(0);
-        store(0);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int stage = kt & 1;
-        if (kt + 1 < nk) load(kt + 1);                      // global loads in flight under the MFMAs
+    auto compute = [&](int stage) {
         const char* as = smem + stage * 2 * GEMM_STAGE_BYTES;
         const char* bs = as + GEMM_STAGE_BYTES;
 #pragma unroll
@@ -280,7 +278,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16_bf16(a[i], b[j], acc[i][j]);
         }
-        if (kt + 1 < nk) store(stage ^ 1);
+    };
+
+    load(ra0, rb0);                                         // tile 0
+    if (nk > 0) store(0, ra0, rb0);
+    load(ra1, rb1);                                         // tile 1 -> set 1
+    load(ra0, rb0);                                         // tile 2 -> set 0
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        compute(0);                                         // tile kt (even) lives in stage 0
+        if (kt + 1 < nk) store(1, ra1, rb1);
+        load(ra1, rb1);                                     // tile kt + 3
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        compute(1);                                         // tile kt + 1
+        if (kt + 2 < nk) store(0, ra0, rb0);
+        load(ra0, rb0);                                     // tile kt + 4
         __syncthreads();
     }
 
