@@ -72,9 +72,11 @@ int ccd_gemm_tn(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P,
     CCD_CHECK(P > 0 && Q > 0 && Mc > 0, CCD_EINVAL);
     CCD_CHECK(P % 8 == 0 && Q % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, CCD_ESHAPE);
     CCD_CHECK(epilogue == CCD_EPI_ATOMIC || epilogue == CCD_EPI_F32, CCD_EINVAL);
-    if (splits < 1) {   // pick enough slices to fill the chip (~2 WGs per CU), each a multiple of 64 rows
+    if (splits < 1) {   // as many slices as fit ONE resident wave of workgroups (2 per CU): one extra workgroup would
+                        // run alone after all others and double the kernel time
         const int tiles = ((P + 127) / 128) * ((Q + 127) / 128);
-        splits = (2 * ccd_rt_num_cus() + tiles - 1) / tiles;
+        splits = (2 * ccd_rt_num_cus()) / tiles;
+        if (splits < 1) splits = 1;
     }
     int per = (Mc + splits - 1) / splits;
     per = ((per + 63) / 64) * 64;
