@@ -47,9 +47,10 @@ const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi1"; }
 int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, int epilogue, void* C,
                 long ldc, void* C2, long ldc2, const float* bias, const float* resid, long ldr,
                 const float* rowscale, int rows_per_sample, const ccd_bf16* aux, long ldaux, float alpha,
-                int m_fastest, const int* d_rows, int rows_mul, void* stream) {
-    CCD_CHECK(A && B && C, CCD_EINVAL);
+                int m_fastest, const int* d_rows, int rows_mul, float* colsum, void* stream) {
+    CCD_CHECK(A && B && (C || (epilogue == CCD_EPI_GELU && C2)), CCD_EINVAL);
     CCD_CHECK(CCD_ALIGNED16(A) && CCD_ALIGNED16(B) && CCD_ALIGNED16(C), CCD_EINVAL);
+    CCD_CHECK(!colsum || epilogue == CCD_EPI_BF16 || epilogue == CCD_EPI_DGELU, CCD_EINVAL);
     if (M == 0 || N == 0) return CCD_OK;
     CCD_CHECK(M > 0 && N > 0 && K > 0, CCD_EINVAL);
     CCD_CHECK(K % 64 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, CCD_ESHAPE);
@@ -61,6 +62,7 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
     p.C = C; p.ldc = ldc; p.C2 = C2; p.ldc2 = ldc2; p.bias = bias; p.resid = resid; p.ldr = ldr;
     p.rowscale = rowscale; p.rows_per_sample = rows_per_sample; p.aux = aux; p.ldaux = ldaux;
     p.k_per_split = K; p.m_fastest = m_fastest; p.alpha = alpha; p.d_rows = d_rows; p.rows_mul = rows_mul;
+    p.colsum = colsum;
     return ccd_launch_gemm<false>(p, epilogue, 1, stream);
 }
 
@@ -87,6 +89,7 @@ int ccd_gemm_tn(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P,
     p.C = C; p.ldc = ldc; p.C2 = nullptr; p.ldc2 = 0; p.bias = nullptr; p.resid = nullptr; p.ldr = 0;
     p.rowscale = nullptr; p.rows_per_sample = 1; p.aux = nullptr; p.ldaux = 0;
     p.k_per_split = per; p.m_fastest = 0; p.alpha = alpha; p.d_rows = d_rows; p.rows_mul = rows_mul;
+    p.colsum = nullptr;
     return ccd_launch_gemm<true>(p, epilogue, splits, stream);
 }
 
@@ -95,27 +98,29 @@ int ccd_ln_fwd(const float* x, const float* gamma, const float* beta, ccd_bf16* 
                int E, float eps, void* stream) {
     CCD_CHECK(x && gamma && beta && y && mean && rstd, CCD_EINVAL);
     if (rows == 0) return CCD_OK;
-    CCD_CHECK(rows > 0 && E > 0 && E <= 64 * ccd::LN_MAX_PER_LANE, CCD_ESHAPE);
+    CCD_CHECK(rows > 0 && E > 0 && E % 4 == 0 && E <= 64 * ccd::LN_VEC * ccd::LN_STEPS, CCD_ESHAPE);
     CCD_LAUNCH(ccd::ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, rows, E,
                eps);
     return ccd_rt_last_error();
 }
 
 int ccd_ln_bwd(const ccd_bf16* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* g,
-               int accumulate, float* dgamma, float* dbeta, int rows, int E, void* stream) {
+               int accumulate, float* dgamma, float* dbeta, ccd_bf16* gb, const float* rowscale, int rows_per_sample,
+               float* dbias, int rows, int E, void* stream) {
     CCD_CHECK(dy && x && mean && rstd && gamma && g && dgamma && dbeta, CCD_EINVAL);
     if (rows == 0) return CCD_OK;
-    CCD_CHECK(rows > 0 && E > 0 && E <= 64 * ccd::LN_MAX_PER_LANE, CCD_ESHAPE);
+    CCD_CHECK(rows > 0 && E > 0 && E % 4 == 0 && E <= 64 * ccd::LN_VEC * ccd::LN_STEPS, CCD_ESHAPE);
+    CCD_CHECK(!rowscale || rows_per_sample > 0, CCD_EINVAL);
     int blocks = 8 * ccd_rt_num_cus();
     int rpb = (rows + blocks - 1) / blocks;
     rpb = ((rpb + 3) / 4) * 4;
     blocks = (rows + rpb - 1) / rpb;
     if (accumulate)
         CCD_LAUNCH((ccd::ln_bwd_kernel<true>), dim3(blocks), dim3(256), 0, stream, dy, x, mean, rstd, gamma, g, dgamma,
-                   dbeta, rows, E, rpb);
+                   dbeta, gb, rowscale, rows_per_sample, dbias, rows, E, rpb);
     else
         CCD_LAUNCH((ccd::ln_bwd_kernel<false>), dim3(blocks), dim3(256), 0, stream, dy, x, mean, rstd, gamma, g, dgamma,
-                   dbeta, rows, E, rpb);
+                   dbeta, gb, rowscale, rows_per_sample, dbias, rows, E, rpb);
     return ccd_rt_last_error();
 }
 

@@ -43,6 +43,7 @@ struct GemmParams {
     int k_per_split;        // TN: contraction rows handled by one blockIdx.z slice (multiple of 64)
     int m_fastest;          // tile order: 0 = column tiles fastest, 1 = row tiles fastest
     float alpha;            // scales acc before the epilogue
+    float* colsum;          // optional [N] fp32: += column sums of the (final) output tile, e.g. the bias gradient
     const int* d_rows;      // optional device-side row count: NT rows M / TN contraction length K become
     int rows_mul;           //   min(static value, d_rows[0] * rows_mul); the grid is sized for the static value
 };
@@ -151,7 +152,7 @@ __device__ __forceinline__ void gemm_epilogue_row8(const GemmParams& p, int gm, 
     if (EPI == EPI_BF16) {
         *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = pack8(v);
     } else if (EPI == EPI_GELU) {
-        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = pack8(v);
+        if (p.C) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = pack8(v);
         float g[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) g[e] = gelu_f(v[e]);
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         }
         return;
     }
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int pass = 0; pass < 8; ++pass) {
         const int row = pass * 16 + (t >> 4), col = (t & 15) * 8;
@@ -332,6 +334,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
             v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
             v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
             gemm_epilogue_row8<EPI>(p, gm, gn, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) csum[e] += v[e];
+        }
+    }
+    if ((EPI == EPI_DGELU || EPI == EPI_BF16) && p.colsum) {     // block-wide column sums of the tile -> one atomic per column
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[(t >> 4) * GEMM_BN + (t & 15) * 8 + e] = csum[e];
+        __syncthreads();
+        if (t < GEMM_BN && n0 + t < p.N) {
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a += cs[q * GEMM_BN + t];
+            atomicAdd(p.colsum + n0 + t, a);
         }
     }
 }

@@ -1,11 +1,12 @@
 // layernorm.h - LayerNorm(eps) over the fp32 residual stream, bf16 out (vision_transformer.py:99,103,156,162).
-// One wave per token row; a lane keeps its <= 8 elements in registers (E <= 512), statistics by wave shuffles.
-// HBM-bound: algorithmic bytes per row = 4*E (x) + 2*E (y) forward; 4*E (x) + 2*E (dy) + 8*E (g r/w) backward.
+// One wave per token row, 16-byte fp32 / 8-byte bf16 accesses (4 elements per lane and step, E <= 512), statistics
+// by wave shuffles.  HBM-bound: algorithmic bytes per row = 4E (x) + 2E (y) forward;
+// backward 2E (dy) + 4E (x) + 8E (g read+write) [+ 2E for the fused bf16 copy of the updated gradient stream].
 #pragma once
 
 namespace ccd {
 
-constexpr int LN_MAX_PER_LANE = 8;
+constexpr int LN_VEC = 4, LN_STEPS = 2;          // lane l owns elements 4*(l + 64*s) .. +3, s < LN_STEPS  (E <= 512)
 
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y,
@@ -15,28 +16,39 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;                       // whole waves exit together; no block barrier below
     const float* xr = x + (long)row * E;
-    float v[LN_MAX_PER_LANE];
+    f32x4v v[LN_STEPS];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = c < E ? xr[c] : 0.f;
-        s += v[i];
+    for (int i = 0; i < LN_STEPS; ++i) {
+        const int c = LN_VEC * (lane + 64 * i);
+        f32x4v t = {0.f, 0.f, 0.f, 0.f};
+        if (c < E) t = *reinterpret_cast<const f32x4v*>(xr + c);
+        v[i] = t;
+        s += (t.x + t.y) + (t.z + t.w);
     }
     const float mean = wave_sum(s) / (float)E;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
-        const int c = lane + 64 * i;
-        const float d = c < E ? v[i] - mean : 0.f;
-        q += d * d;
+    for (int i = 0; i < LN_STEPS; ++i) {
+        const int c = LN_VEC * (lane + 64 * i);
+        if (c < E) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + eps);
     bf16_t* yr = y + (long)row * E;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
-        const int c = lane + 64 * i;
-        if (c < E) yr[c] = f2bf((v[i] - mean) * rstd * gamma[c] + beta[c]);
+    for (int i = 0; i < LN_STEPS; ++i) {
+        const int c = LN_VEC * (lane + 64 * i);
+        if (c < E) {
+            const f32x4v g = *reinterpret_cast<const f32x4v*>(gamma + c);
+            const f32x4v b = *reinterpret_cast<const f32x4v*>(beta + c);
+            u32x2 o;
+            o.x = pack_bf2((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y);
+            o.y = pack_bf2((v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+            *reinterpret_cast<u32x2*>(yr + c) = o;
+        }
     }
     if (lane == 0) {
         mean_out[row] = mean;
@@ -45,67 +57,93 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // g[row,:] (+)= LN_backward(dy[row,:]) ; dgamma += sum_rows dy*xhat ; dbeta += sum_rows dy   (fp32 atomics)
-// ACCUM = true : g += dx   (residual-gradient stream of a transformer block)
-// ACCUM = false: g  = dx   (taps / final norm feeding a fresh stream)
+//   ACCUM = true : g += dx   (residual-gradient stream of a transformer block)
+//   ACCUM = false: g  = dx   (final norm: starts the stream)
+// Optional fused tail (gb != null): gb[row,:] = bf16(g_new[row,:] * rowscale[row / rows_per_sample]) - the gradient
+// entering the NEXT residual branch with that branch's DropPath scale - and dbias += column sums of gb (the bias
+// gradient of that branch's output projection).  Saves a pass over g and a pass over gb per branch.
 template <bool ACCUM>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, float* __restrict__ g,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
-                                                     int E, int rows_per_block) {
-    __shared__ float red[2][4][64 * LN_MAX_PER_LANE];
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     bf16_t* __restrict__ gb, const float* __restrict__ rowscale,
+                                                     int rows_per_sample, float* __restrict__ dbias, int rows, int E,
+                                                     int rows_per_block) {
+    __shared__ float red[3][4][64 * LN_VEC * LN_STEPS];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int row_begin = blockIdx.x * rows_per_block;
     const int row_end = row_begin + rows_per_block < rows ? row_begin + rows_per_block : rows;
-    float gam[LN_MAX_PER_LANE], dg[LN_MAX_PER_LANE], db[LN_MAX_PER_LANE];
+    f32x4v gam[LN_STEPS], dg[LN_STEPS], db[LN_STEPS], dbi[LN_STEPS];
+    const f32x4v zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
-        const int c = lane + 64 * i;
-        gam[i] = c < E ? gamma[c] : 0.f;
-        dg[i] = 0.f;
-        db[i] = 0.f;
+    for (int i = 0; i < LN_STEPS; ++i) {
+        const int c = LN_VEC * (lane + 64 * i);
+        gam[i] = c < E ? *reinterpret_cast<const f32x4v*>(gamma + c) : zero;
+        dg[i] = zero;
+        db[i] = zero;
+        dbi[i] = zero;
     }
     for (int row = row_begin + w; row < row_end; row += 4) {
         const float mu = mean[row], rs = rstd[row];
         const float* xr = x + (long)row * E;
         const bf16_t* dyr = dy + (long)row * E;
-        float xh[LN_MAX_PER_LANE], d[LN_MAX_PER_LANE];
+        f32x4v xh[LN_STEPS], d[LN_STEPS];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
-            const int c = lane + 64 * i;
-            const bool ok = c < E;
-            xh[i] = ok ? (xr[c] - mu) * rs : 0.f;
-            const float dyv = ok ? bf2f(dyr[c]) : 0.f;
-            d[i] = dyv * gam[i];
-            s1 += d[i];
-            s2 += d[i] * xh[i];
-            dg[i] += dyv * xh[i];
-            db[i] += dyv;
+        for (int i = 0; i < LN_STEPS; ++i) {
+            const int c = LN_VEC * (lane + 64 * i);
+            xh[i] = zero;
+            d[i] = zero;
+            if (c < E) {
+                const f32x4v xv = *reinterpret_cast<const f32x4v*>(xr + c);
+                const u32x2 dw = *reinterpret_cast<const u32x2*>(dyr + c);
+                const f32x4v dyv = {bf_lo(dw.x), bf_hi(dw.x), bf_lo(dw.y), bf_hi(dw.y)};
+                xh[i] = (xv - mu) * rs;
+                d[i] = dyv * gam[i];
+                dg[i] += dyv * xh[i];
+                db[i] += dyv;
+                s1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+                const f32x4v e = d[i] * xh[i];
+                s2 += (e.x + e.y) + (e.z + e.w);
+            }
         }
         s1 = wave_sum(s1) / (float)E;
         s2 = wave_sum(s2) / (float)E;
         float* gr = g + (long)row * E;
+        const float sc = (gb && rowscale) ? rowscale[row / rows_per_sample] : 1.0f;
 #pragma unroll
-        for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
-            const int c = lane + 64 * i;
+        for (int i = 0; i < LN_STEPS; ++i) {
+            const int c = LN_VEC * (lane + 64 * i);
             if (c < E) {
-                const float dx = rs * (d[i] - s1 - xh[i] * s2);
-                gr[c] = ACCUM ? gr[c] + dx : dx;
+                f32x4v dx = (d[i] - s1 - xh[i] * s2) * rs;
+                if (ACCUM) dx += *reinterpret_cast<const f32x4v*>(gr + c);
+                *reinterpret_cast<f32x4v*>(gr + c) = dx;
+                if (gb) {
+                    const f32x4v o = dx * sc;
+                    u32x2 pk;
+                    pk.x = pack_bf2(o.x, o.y);
+                    pk.y = pack_bf2(o.z, o.w);
+                    *reinterpret_cast<u32x2*>(gb + (long)row * E + c) = pk;
+                    // sum what the GEMMs will actually read (the bf16-rounded values)
+                    const f32x4v rq = {bf_lo(pk.x), bf_hi(pk.x), bf_lo(pk.y), bf_hi(pk.y)};
+                    dbi[i] += rq;
+                }
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
-        red[0][w][lane + 64 * i] = dg[i];
-        red[1][w][lane + 64 * i] = db[i];
+    for (int i = 0; i < LN_STEPS; ++i) {
+        const int c = LN_VEC * (lane + 64 * i);
+        *reinterpret_cast<f32x4v*>(&red[0][w][c]) = dg[i];
+        *reinterpret_cast<f32x4v*>(&red[1][w][c]) = db[i];
+        *reinterpret_cast<f32x4v*>(&red[2][w][c]) = dbi[i];
     }
     __syncthreads();
     for (int c = threadIdx.x; c < E; c += 256) {
-        const float a = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-        const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-        atomicAdd(dgamma + c, a);
-        atomicAdd(dbeta + c, b);
+        atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        if (gb && dbias) atomicAdd(dbias + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
     }
 }
 

@@ -96,7 +96,7 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training):
                               bias=arena.w(b + "attn.proj.bias"), resid=x, rowscale=c.ds1, rows_per_sample=256)
         c.y2, c.mean2, c.rstd2 = ops.ln_fwd(c.x_mid, arena.w(b + "norm2.weight"), arena.w(b + "norm2.bias"), spec.eps)
         c.u, c.gact = ops.gemm_nt(c.y2, arena.wb(b + "mlp.fc1.weight"), epilogue=ops.EPI_GELU,
-                                  bias=arena.w(b + "mlp.fc1.bias"))
+                                  bias=arena.w(b + "mlp.fc1.bias"), store_u=save)   # u only feeds gelu' in backward
         x = ops.gemm_nt(c.gact, arena.wb(b + "mlp.fc2.weight"), epilogue=ops.EPI_RESID,
                         bias=arena.w(b + "mlp.fc2.bias"), resid=c.x_mid, rowscale=c.ds2, rows_per_sample=256)
         if not save:
@@ -113,50 +113,66 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training):
 
 
 def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample, on_block_done=None):
-    """Consumes bf16 gradients of the final-norm tokens and the taps; fills the arena gradient slots of `pre`*."""
+    """Consumes bf16 gradients of the final-norm tokens and the taps; fills the arena gradient slots of `pre`*.
+
+    g is the fp32 gradient of the residual stream.  Every LayerNorm backward that is the LAST writer of g before a
+    residual branch also emits gb = bf16(g * DropPath scale of that branch) and the branch's output-bias gradient
+    (column sums of gb) in the same pass (layernorm.h), so no separate cast / column-sum kernels run per branch."""
     ctxs, tap_ctx, (x_last, mu, rs), img = ctx
     E, N = spec.E, img.shape[0]
     R = N * 256
     dev = img.device
     g = torch.empty((R, E), dtype=F32, device=dev)
+    gb = torch.empty((R, E), dtype=BF16, device=dev)
+    tap_at = {i: (j, x, m, r) for j, (i, x, m, r) in enumerate(tap_ctx) if d_taps[j] is not None}
+    scale = (E // spec.heads) ** -0.5
+    top = spec.depth - 1
+
+    def mlp_tail(i):            # what the MLP branch of block i wants from the writer in front of it
+        return dict(gb=gb, rowscale=ctxs[i].ds2, rows_per_sample=256, dbias=arena.g(f"{pre}blocks.{i}.mlp.fc2.bias"))
+
+    have_gb = False
     if d_tokens is not None:
+        tail = mlp_tail(top) if top not in tap_at else {}
         ops.ln_bwd(d_tokens.reshape(R, E), x_last, mu, rs, arena.w(pre + "norm.weight"), g, arena.g(pre + "norm.weight"),
-                   arena.g(pre + "norm.bias"), accumulate=False)
+                   arena.g(pre + "norm.bias"), accumulate=False, **tail)
+        have_gb = bool(tail)
     else:
         g.zero_()
-    tap_at = {i: (j, x, m, r) for j, (i, x, m, r) in enumerate(tap_ctx)}
-    scale = (E // spec.heads) ** -0.5
-    gb = torch.empty((R, E), dtype=BF16, device=dev)
     for i in reversed(range(spec.depth)):
-        if i in tap_at and d_taps[tap_at[i][0]] is not None:
-            j, xt, m, r = tap_at[i]
-            ops.ln_bwd(d_taps[j].reshape(R, E), xt, m, r, arena.w(f"{pre}norm_seg.{j}.weight"), g,
-                       arena.g(f"{pre}norm_seg.{j}.weight"), arena.g(f"{pre}norm_seg.{j}.bias"), accumulate=True)
         b = f"{pre}blocks.{i}."
         c = ctxs[i]
+        if i in tap_at:
+            j, xt, m, r = tap_at[i]
+            ops.ln_bwd(d_taps[j].reshape(R, E), xt, m, r, arena.w(f"{pre}norm_seg.{j}.weight"), g,
+                       arena.g(f"{pre}norm_seg.{j}.weight"), arena.g(f"{pre}norm_seg.{j}.bias"), accumulate=True,
+                       **mlp_tail(i))
+            have_gb = True
+        if not have_gb:          # only when no gradient reached the final norm: plain cast + column sum
+            ops.scale_cast_rows(g, gb, c.ds2, 256)
+            ops.colsum_bf16(gb, arena.g(b + "mlp.fc2.bias"))
         # ---- MLP branch: x_out = x_mid + ds2 * fc2(gelu(fc1(LN2(x_mid))))
-        ops.scale_cast_rows(g, gb, c.ds2, 256)
         ops.gemm_tn(gb, c.gact, arena.g(b + "mlp.fc2.weight"))
-        ops.colsum_bf16(gb, arena.g(b + "mlp.fc2.bias"))
-        du = ops.gemm_nt(gb, arena.wbt(b + "mlp.fc2.weight"), epilogue=ops.EPI_DGELU, aux=c.u)
+        du = ops.gemm_nt(gb, arena.wbt(b + "mlp.fc2.weight"), epilogue=ops.EPI_DGELU, aux=c.u,
+                         colsum=arena.g(b + "mlp.fc1.bias"))
         ops.gemm_tn(du, c.y2, arena.g(b + "mlp.fc1.weight"))
-        ops.colsum_bf16(du, arena.g(b + "mlp.fc1.bias"))
         dy2 = ops.gemm_nt(du, arena.wbt(b + "mlp.fc1.weight"))
         del du
         ops.ln_bwd(dy2, c.x_mid, c.mean2, c.rstd2, arena.w(b + "norm2.weight"), g, arena.g(b + "norm2.weight"),
-                   arena.g(b + "norm2.bias"), accumulate=True)
+                   arena.g(b + "norm2.bias"), accumulate=True, gb=gb, rowscale=c.ds1, rows_per_sample=256,
+                   dbias=arena.g(b + "attn.proj.bias"))
         # ---- attention branch: x_mid = x_in + ds1 * proj(attn(qkv(LN1(x_in))))
-        ops.scale_cast_rows(g, gb, c.ds1, 256)
         ops.gemm_tn(gb, c.att.view(R, E), arena.g(b + "attn.proj.weight"))
-        ops.colsum_bf16(gb, arena.g(b + "attn.proj.bias"))
         d_att = ops.gemm_nt(gb, arena.wbt(b + "attn.proj.weight"))
         d_qkv = ops.attention_bwd(c.qkv.view(N, 256, 3 * E), c.att, d_att.view(N, 256, E), c.lse, spec.heads, scale)
         d_qkv = d_qkv.view(R, 3 * E)
         ops.gemm_tn(d_qkv, c.y1, arena.g(b + "attn.qkv.weight"))
         ops.colsum_bf16(d_qkv, arena.g(b + "attn.qkv.bias"))
         dy1 = ops.gemm_nt(d_qkv, arena.wbt(b + "attn.qkv.weight"))
+        tail = mlp_tail(i - 1) if (i > 0 and (i - 1) not in tap_at) else {}
         ops.ln_bwd(dy1, c.x_in, c.mean1, c.rstd1, arena.w(b + "norm1.weight"), g, arena.g(b + "norm1.weight"),
-                   arena.g(b + "norm1.bias"), accumulate=True)
+                   arena.g(b + "norm1.bias"), accumulate=True, **tail)
+        have_gb = bool(tail)
         ctxs[i] = None
         if on_block_done is not None:
             on_block_done(b)

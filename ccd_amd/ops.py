@@ -46,7 +46,8 @@ def _chk(t, dtype, name):
 
 
 def gemm_nt(a, b, *, epilogue=EPI_BF16, out=None, out2=None, bias=None, resid=None, rowscale=None,
-            rows_per_sample=1, aux=None, alpha=1.0, m_fastest=None, d_rows=None, rows_mul=1):
+            rows_per_sample=1, aux=None, alpha=1.0, m_fastest=None, d_rows=None, rows_mul=1, colsum=None,
+            store_u=True):
     """out[M,N] = a[M,K] @ b[N,K]^T with a fused epilogue (see include/ccd_hip.h)."""
     _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(bias, F32, "bias"); _chk(resid, F32, "resid")
     _chk(rowscale, F32, "rowscale"); _chk(aux, BF16, "aux")
@@ -54,7 +55,7 @@ def gemm_nt(a, b, *, epilogue=EPI_BF16, out=None, out2=None, bias=None, resid=No
     N = b.shape[0]
     assert b.shape[1] == K
     odt = F32 if epilogue in (EPI_RESID, EPI_F32, EPI_ATOMIC) else BF16
-    if out is None:
+    if out is None and (store_u or epilogue != EPI_GELU):
         out = torch.empty((M, N), dtype=odt, device=a.device)
     _chk(out, odt, "out")
     if epilogue == EPI_GELU and out2 is None:
@@ -66,10 +67,11 @@ def gemm_nt(a, b, *, epilogue=EPI_BF16, out=None, out2=None, bias=None, resid=No
     if span:
         span[0].record()
     _lib.check(lib.ccd_gemm_nt(_lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0), M, N, K, epilogue, _lib.ptr(out),
-                               out.stride(0), _lib.ptr(out2), 0 if out2 is None else out2.stride(0), _lib.ptr(bias),
+                               N if out is None else out.stride(0), _lib.ptr(out2), 0 if out2 is None else out2.stride(0), _lib.ptr(bias),
                                _lib.ptr(resid), 0 if resid is None else resid.stride(0), _lib.ptr(rowscale),
                                rows_per_sample, _lib.ptr(aux), 0 if aux is None else aux.stride(0), float(alpha),
-                               int(m_fastest), _lib.ptr(d_rows), int(rows_mul), _lib.stream()), "gemm_nt")
+                               int(m_fastest), _lib.ptr(d_rows), int(rows_mul), _lib.ptr(colsum), _lib.stream()),
+               "gemm_nt")
     if span:
         span[1].record()
     return (out, out2) if epilogue == EPI_GELU else out
@@ -107,12 +109,14 @@ def ln_fwd(x, gamma, beta, eps=1e-6):
     return y, mean, rstd
 
 
-def ln_bwd(dy, x, mean, rstd, gamma, g, dgamma, dbeta, accumulate=True):
-    """g (+)= LN'(dy); dgamma += , dbeta += (in place)."""
-    _chk(dy, BF16, "dy"); _chk(x, F32, "x"); _chk(g, F32, "g")
+def ln_bwd(dy, x, mean, rstd, gamma, g, dgamma, dbeta, accumulate=True, gb=None, rowscale=None, rows_per_sample=1,
+           dbias=None):
+    """g (+)= LN'(dy); dgamma += , dbeta += (in place).  Optional fused tail: gb = bf16(g * rowscale), dbias += colsum(gb)."""
+    _chk(dy, BF16, "dy"); _chk(x, F32, "x"); _chk(g, F32, "g"); _chk(gb, BF16, "gb")
     rows, E = x.shape
     _lib.check(_lib.get().ccd_ln_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma),
-                                     _lib.ptr(g), 1 if accumulate else 0, _lib.ptr(dgamma), _lib.ptr(dbeta), rows, E,
+                                     _lib.ptr(g), 1 if accumulate else 0, _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                     _lib.ptr(gb), _lib.ptr(rowscale), int(rows_per_sample), _lib.ptr(dbias), rows, E,
                                      _lib.stream()), "ln_bwd")
     return g
 

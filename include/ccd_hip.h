@@ -45,7 +45,9 @@ const char* ccd_build_info(void);
 int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, int epilogue,
                 void* C, long ldc, void* C2, long ldc2, const float* bias, const float* resid, long ldr,
                 const float* rowscale, int rows_per_sample, const ccd_bf16* aux, long ldaux, float alpha,
-                int m_fastest, const int* d_rows, int rows_mul, void* stream);
+                int m_fastest, const int* d_rows, int rows_mul, float* colsum, void* stream);
+/* colsum (optional, epilogues BF16 / DGELU): [N] fp32, += column sums of the output (bias gradient of the producer).
+ * CCD_EPI_GELU accepts C == NULL (only gelu(u) is stored: forward passes that keep no activations). */
 /* C[P,Q] (+)= sum_m A[m,P] * B[m,Q]   (weight gradients dW = dY^T X of every Linear; autograd of the above)
  * P % 8 == 0, Q % 8 == 0; epilogue CCD_EPI_ATOMIC accumulates into fp32 C (split over m), CCD_EPI_F32 stores. */
 int ccd_gemm_tn(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P, int Q, int Mc, int epilogue,
@@ -56,9 +58,12 @@ int ccd_gemm_tn(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P,
 /* ---------------------------------------------------------------- LayerNorm (eps 1e-6), vit.py:99,103,156,162-166 */
 int ccd_ln_fwd(const float* x, const float* gamma, const float* beta, ccd_bf16* y, float* mean, float* rstd,
                int rows, int E, float eps, void* stream);
-/* g (+)= dx ; dgamma += ..., dbeta += ... (fp32 atomics; caller zeroes them once per step) */
+/* g (+)= dx ; dgamma += ..., dbeta += ... (fp32 atomics; caller zeroes them once per step).
+ * Optional fused tail: gb(bf16) = g_new * rowscale[row / rows_per_sample] (the gradient entering the next residual
+ * branch, DropPath scale applied) and dbias += column sums of gb. */
 int ccd_ln_bwd(const ccd_bf16* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-               float* g, int accumulate, float* dgamma, float* dbeta, int rows, int E, void* stream);
+               float* g, int accumulate, float* dgamma, float* dbeta, ccd_bf16* gb, const float* rowscale,
+               int rows_per_sample, float* dbias, int rows, int E, void* stream);
 
 /* ---------------------------------------------------------------- attention, vit.py:80-92 (T = 256, head_dim = 64)
  * qkv [views, 256, 3, heads, 64] bf16 (the layout Attention.forward reshapes to), out [views, 256, heads*64]  */

@@ -48,6 +48,15 @@ def check_gemm_nt(dev, M, N, K, seed=0):
     xx = aux.float().double().requires_grad_(True)
     F.gelu(xx).sum().backward()
     close(ops.gemm_nt(A, B_, epilogue=ops.EPI_DGELU, aux=aux.to(dev)), ref * xx.grad.float(), 1e-2, 2e-2, "nt/dgelu")
+    cs = torch.full((N,), 3.0).to(dev)
+    du = ops.gemm_nt(A, B_, epilogue=ops.EPI_DGELU, aux=aux.to(dev), colsum=cs)
+    close(cs, (ref * xx.grad.float()).sum(0) + 3.0, 1e-3, 2e-2 * (M ** 0.5), "nt/dgelu-colsum")
+    cs = torch.zeros(N).to(dev)
+    ops.gemm_nt(A, B_, epilogue=ops.EPI_BF16, bias=bias_d, colsum=cs)
+    close(cs, (ref + bias).sum(0), 1e-3, 2e-2 * (M ** 0.5), "nt/bf16-colsum")
+    none_u, g_only = ops.gemm_nt(A, B_, epilogue=ops.EPI_GELU, bias=bias_d, store_u=False)
+    assert none_u is None
+    close(g_only, F.gelu(ref + bias), 1e-2, 2e-2, "nt/gelu-only")
     # strided A (a column slice of a wider buffer) and both tile orders
     wide = torch.zeros((M, K + 64), dtype=BF); wide[:, 64:] = a
     wd = wide.to(dev)
@@ -80,13 +89,23 @@ def check_layernorm(dev, rows, E, seed=2):
     xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
     F.layer_norm(xr, (E,), gr, br, 1e-6).backward(dy.float())
     g0 = rnd((rows, E), g)
+    rows_per_sample = 4
+    rowscale = (torch.rand((rows + rows_per_sample - 1) // rows_per_sample, generator=g) > 0.3).float() * 1.25
     for acc in (True, False):
-        gbuf = g0.clone().to(dev)
-        dgam = torch.zeros(E).to(dev); dbet = torch.zeros(E).to(dev)
-        ops.ln_bwd(dy.to(dev), x.to(dev), mean, rstd, gamma.to(dev), gbuf, dgam, dbet, accumulate=acc)
-        close(gbuf, xr.grad + (g0 if acc else 0), 1e-3, 1e-4, f"ln/dx acc={acc}")
-        close(dgam, gr.grad, 1e-3, 1e-3, "ln/dgamma")
-        close(dbet, br.grad, 1e-3, 1e-3, "ln/dbeta")
+        for fused in (False, True):
+            gbuf = g0.clone().to(dev)
+            dgam = torch.zeros(E).to(dev); dbet = torch.zeros(E).to(dev)
+            gb = torch.zeros(rows, E, dtype=BF).to(dev); dbias = torch.full((E,), 0.25).to(dev)
+            kw = dict(gb=gb, rowscale=rowscale.to(dev), rows_per_sample=rows_per_sample, dbias=dbias) if fused else {}
+            ops.ln_bwd(dy.to(dev), x.to(dev), mean, rstd, gamma.to(dev), gbuf, dgam, dbet, accumulate=acc, **kw)
+            want_g = xr.grad + (g0 if acc else 0)
+            close(gbuf, want_g, 1e-3, 1e-4, f"ln/dx acc={acc}")
+            close(dgam, gr.grad, 1e-3, 1e-3, "ln/dgamma")
+            close(dbet, br.grad, 1e-3, 1e-3, "ln/dbeta")
+            if fused:
+                want_gb = (want_g * rowscale.repeat_interleave(rows_per_sample)[:rows, None]).to(BF)
+                close(gb, want_gb, 1e-2, 1e-3, "ln/gb")
+                close(dbias, gb.float().sum(0).cpu() + 0.25, 1e-4, 1e-3, "ln/dbias")
 
 
 def attention_ref(qkv, heads):
