@@ -6,6 +6,7 @@
 #include "../../include/ccd_hip.h"
 #include "kernels/common.h"
 #include "kernels/gemm.h"
+#include "kernels/gemm_ares.h"
 #include "kernels/layernorm.h"
 #include "kernels/attention_fwd.h"
 #include "kernels/attention_bwd.h"
@@ -38,6 +39,26 @@ static int ccd_launch_gemm(const ccd::GemmParams& p, int epilogue, int splits, v
     return ccd_rt_last_error();
 }
 
+// short-K products of the transformer run on the A-resident persistent kernel (gemm_ares.h)
+static int ccd_launch_gemm_ares(const ccd::GemmParams& p, int epilogue, void* stream) {
+    const int tiles_m = (p.M + 127) / 128;
+    const int cus = ccd_rt_num_cus();
+    const dim3 grid(tiles_m < cus ? tiles_m : cus), block(ccd::ARES_THREADS);
+    const size_t smem = ccd::ARES_SMEM_BYTES;
+    switch (epilogue) {
+        case CCD_EPI_BF16: CCD_LAUNCH((ccd::gemm_ares_kernel<ccd::EPI_BF16>), grid, block, smem, stream, p); break;
+        case CCD_EPI_GELU: CCD_LAUNCH((ccd::gemm_ares_kernel<ccd::EPI_GELU>), grid, block, smem, stream, p); break;
+        case CCD_EPI_RESID: CCD_LAUNCH((ccd::gemm_ares_kernel<ccd::EPI_RESID>), grid, block, smem, stream, p); break;
+        case CCD_EPI_DGELU: CCD_LAUNCH((ccd::gemm_ares_kernel<ccd::EPI_DGELU>), grid, block, smem, stream, p); break;
+        default: return CCD_EINVAL;
+    }
+    return ccd_rt_last_error();
+}
+static bool ccd_env_flag(const char* name, bool dflt) {
+    const char* v = getenv(name);
+    return v ? (v[0] != '0') : dflt;
+}
+
 extern "C" {
 
 int ccd_abi_version(void) { return 1; }
@@ -63,6 +84,11 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
     p.rowscale = rowscale; p.rows_per_sample = rows_per_sample; p.aux = aux; p.ldaux = ldaux;
     p.k_per_split = K; p.m_fastest = m_fastest; p.alpha = alpha; p.d_rows = d_rows; p.rows_mul = rows_mul;
     p.colsum = colsum;
+    static const bool use_ares = ccd_env_flag("CCD_GEMM_ARES", true);
+    const bool ares_epi = epilogue == CCD_EPI_BF16 || epilogue == CCD_EPI_GELU || epilogue == CCD_EPI_RESID ||
+                          epilogue == CCD_EPI_DGELU;
+    if (use_ares && ares_epi && !d_rows && K <= 64 * ccd::ARES_MAX_KC && M >= 1024 && N % 4 == 0)
+        return ccd_launch_gemm_ares(p, epilogue, stream);
     return ccd_launch_gemm<false>(p, epilogue, 1, stream);
 }
 

@@ -10,14 +10,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4v;
 __device__ __forceinline__ unsigned f2bits(float f) { unsigned u; __builtin_memcpy(&u, &f, 4); return u; }
 __device__ __forceinline__ float bits2f(unsigned u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 __device__ __forceinline__ float bf2f(bf16_t h) { return bits2f((unsigned)h << 16); }
-// round-to-nearest-even, NaN preserved (same rule as torch's float -> bfloat16)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = f2bits(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
-__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+// float -> bf16, round-to-nearest-even (torch's rule); cvt_bf16 / cvt_pk_bf16 come from the prelude
+// (one v_cvt_pk_bf16_f32 on gfx950; bit arithmetic in the CPU SIMT executor)
+__device__ __forceinline__ bf16_t f2bf(float f) { return cvt_bf16(f); }
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) { return cvt_pk_bf16(lo, hi); }
 __device__ __forceinline__ float bf_lo(unsigned w) { return bits2f(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return bits2f(w & 0xffff0000u); }
 

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace ccd {
 typedef __attribute__((ext_vector_type(8))) short bf16x8;    // 8 raw bf16 = one MFMA A/B fragment (4 VGPRs)
@@ -35,6 +36,13 @@ __device__ __forceinline__ f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hw_bf16x8, a), __builtin_bit_cast(hw_bf16x8, b),
                                                    c, 0, 0, 0);
 }
+// hardware float -> bf16 (RNE): clang lowers the __bf16 casts to v_cvt_pk_bf16_f32 on gfx950
+typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    hw_bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ unsigned short cvt_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __frcp_rn(x); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return rsqrtf(x); }

@@ -218,6 +218,13 @@ inline f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
     sim::wave_sync();
     return c;
 }
+inline unsigned short cvt_bf16(float f) {          // round-to-nearest-even, NaN preserved
+    uint32_t u; std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+inline unsigned cvt_pk_bf16(float lo, float hi) { return (unsigned)cvt_bf16(lo) | ((unsigned)cvt_bf16(hi) << 16); }
 inline float fast_exp(float x) { return std::exp(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 inline float fast_rsqrt(float x) { return 1.0f / std::sqrt(x); }
