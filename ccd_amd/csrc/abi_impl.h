@@ -87,7 +87,7 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
     static const bool use_ares = ccd_env_flag("CCD_GEMM_ARES", true);
     const bool ares_epi = epilogue == CCD_EPI_BF16 || epilogue == CCD_EPI_GELU || epilogue == CCD_EPI_RESID ||
                           epilogue == CCD_EPI_DGELU;
-    if (use_ares && ares_epi && !d_rows && K <= 64 * ccd::ARES_MAX_KC && M >= 1024 && N % 4 == 0)
+    if (use_ares && ares_epi && !d_rows && K <= 64 * ccd::ARES_MAX_KC && K % 128 == 0 && M >= 1024 && N % 4 == 0)
         return ccd_launch_gemm_ares(p, epilogue, stream);
     return ccd_launch_gemm<false>(p, epilogue, 1, stream);
 }

@@ -64,58 +64,110 @@ __global__ __launch_bounds__(512) void gemm_ares_kernel(GemmParams p) {
     char* b_ring = smem + ARES_MAX_KC * 16384;                  // [2 stages][2 chunks][128 n][64 k]
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, hf = lane >> 5, lq = lane & 31;
     const int wm = w >> 2, wn = w & 3;                           // wave tile: rows 64*wm .. +63, columns 32*wn .. +31
-    const int KC = p.K / 64;
-    const int steps = (KC + 1) / 2;                              // a ring stage carries two 64-wide k chunks
+    const int KC = p.K / 64;                                     // even (host guarantees K % 128 == 0)
+    const int steps = KC / 2;                                    // a ring stage carries two 64-wide k chunks
     const int tiles_m = (p.M + 127) / 128, tiles_n = (p.N + 127) / 128;
-    const int arow = t >> 3, aslot = t & 7;                      // this thread's chunk inside a [64 rows][8 slots] half
+    const int total_q = tiles_n * steps;
+    const int arow = t >> 3, aslot = t & 7;                      // this thread's 16-B chunk inside a [64 rows][8 slots] half
 
-    // ---- A panel fetch: per k chunk, thread t moves rows arow and arow + 64 (16 B each)
+    // ---- everything below is loop invariant: LDS byte offsets of this lane's fragments and staging slots
+    int a_off[2][4], b_off[4], wr_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int brow = 32 * wn + lq;
+        b_off[kk] = brow * 128 + gemm_swz(brow, 2 * kk + hf) * 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 64 * wm + 32 * i + lq;
+            a_off[i][kk] = row * 128 + gemm_swz(row, 2 * kk + hf) * 16;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) wr_off[h] = (arow + 64 * h) * 128 + gemm_swz(arow + 64 * h, aslot) * 16;
+
+    // All global loads are unconditional: out-of-range rows are clamped to the last valid row (their products land in
+    // accumulator rows/columns the epilogue never stores), so the compiler can count vmcnt exactly.
     u32x4 ar[2 * ARES_MAX_KC];
     auto fetch_a = [&](int tm) {
 #pragma unroll
-        for (int kc = 0; kc < ARES_MAX_KC; ++kc) {
+        for (int h = 0; h < 2; ++h) {
+            int row = tm * 128 + arow + 64 * h;
+            row = row < p.M ? row : p.M - 1;
+            const bf16_t* src = p.A + (long)row * p.lda + aslot * 8;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int row = tm * 128 + arow + 64 * h;
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (kc < KC && row < p.M) v = *reinterpret_cast<const u32x4*>(p.A + (long)row * p.lda + kc * 64 + aslot * 8);
-                ar[2 * kc + h] = v;
-            }
+            for (int kc = 0; kc < ARES_MAX_KC; ++kc)
+                ar[2 * kc + h] = *reinterpret_cast<const u32x4*>(src + (kc < KC ? kc : 0) * 64);
         }
     };
     auto commit_a = [&]() {
 #pragma unroll
-        for (int kc = 0; kc < ARES_MAX_KC; ++kc) {
+        for (int kc = 0; kc < ARES_MAX_KC; ++kc)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (kc < KC) *reinterpret_cast<u32x4*>(a_img + kc * 16384 + wr_off[h]) = ar[2 * kc + h];
+    };
+    // B stream cursor: item = (column tile, step); thread rows n = 128*tn + arow (+64)
+    const bf16_t* pb[2];
+    int cur_tn = 0, cur_st = 0;
+    auto reset_b = [&]() {
+        cur_tn = 0;
+        cur_st = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int n = arow + 64 * h;
+            n = n < p.N ? n : p.N - 1;
+            pb[h] = p.B + (long)n * p.ldb + aslot * 8;
+        }
+    };
+    auto fetch_b = [&](u32x4 (&br)[4]) {                         // loads the current item, then advances (clamped at the end)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            br[h] = *reinterpret_cast<const u32x4*>(pb[h]);          // chunk 2*st
+            br[2 + h] = *reinterpret_cast<const u32x4*>(pb[h] + 64);  // chunk 2*st + 1
+        }
+        if (cur_st + 1 < steps) {
+            ++cur_st;
+            pb[0] += 128;
+            pb[1] += 128;
+        } else if (cur_tn + 1 < tiles_n) {
+            ++cur_tn;
+            cur_st = 0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int row = arow + 64 * h;
-                if (kc < KC) *reinterpret_cast<u32x4*>(a_img + kc * 16384 + row * 128 + gemm_swz(row, aslot) * 16) = ar[2 * kc + h];
+                int n = cur_tn * 128 + arow + 64 * h;
+                n = n < p.N ? n : p.N - 1;
+                pb[h] = p.B + (long)n * p.ldb + aslot * 8;
             }
         }
-    };
-    // ---- B stream: item q = column tile (q / steps), step (q % steps); a stage = 2 chunks x 128 rows x 128 B
-    u32x4 br0[4], br1[4];
-    const int total_q = tiles_n * steps;
-    int fetched = 0;
-    auto fetch_b = [&](u32x4 (&br)[4]) {
-        if (fetched < total_q) {
-            const int tn = fetched / steps, st = fetched % steps;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int half = i >> 1, row = arow + 64 * (i & 1), kc = 2 * st + half;
-                const int n = tn * 128 + row;
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (kc < KC && n < p.N) v = *reinterpret_cast<const u32x4*>(p.B + (long)n * p.ldb + kc * 64 + aslot * 8);
-                br[i] = v;
-            }
-        }
-        ++fetched;
     };
     auto commit_b = [&](int stage, const u32x4 (&br)[4]) {
+        char* dst = b_ring + stage * 32768;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int half = i >> 1, row = arow + 64 * (i & 1);
-            *reinterpret_cast<u32x4*>(b_ring + (stage * 2 + half) * 16384 + row * 128 + gemm_swz(row, aslot) * 16) = br[i];
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<u32x4*>(dst + wr_off[h]) = br[h];
+            *reinterpret_cast<u32x4*>(dst + 16384 + wr_off[h]) = br[2 + h];
+        }
+    };
+
+    f32x16 acc[2];
+    auto compute = [&](int stage, int st) {                      // 2 chunks x 4 k-steps; fragments fetched one step ahead
+        const char* ai = a_img + st * 32768;
+        const char* bi = b_ring + stage * 32768;
+        bf16x8 bf = *reinterpret_cast<const bf16x8*>(bi + b_off[0]);
+        bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ai + a_off[0][0]);
+        bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ai + a_off[1][0]);
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+            bf16x8 nbf = bf, na0 = a0, na1 = a1;
+            if (s8 < 7) {
+                const int c = ((s8 + 1) >> 2) * 16384, kk = (s8 + 1) & 3;
+                nbf = *reinterpret_cast<const bf16x8*>(bi + c + b_off[kk]);
+                na0 = *reinterpret_cast<const bf16x8*>(ai + c + a_off[0][kk]);
+                na1 = *reinterpret_cast<const bf16x8*>(ai + c + a_off[1][kk]);
+            }
+            acc[0] = mfma_32x32x16_bf16(bf, a0, acc[0]);          // D[n][m]: transposed accumulator
+            acc[1] = mfma_32x32x16_bf16(bf, a1, acc[1]);
+            bf = nbf; a0 = na0; a1 = na1;
         }
     };
 
@@ -123,15 +175,15 @@ __global__ __launch_bounds__(512) void gemm_ares_kernel(GemmParams p) {
     if (tm >= tiles_m) return;
     fetch_a(tm);
     for (; tm < tiles_m; tm += gridDim.x) {
+        u32x4 br0[4], br1[4];
         __syncthreads();                                         // previous panel fully consumed
         commit_a();
-        fetched = 0;
+        reset_b();
         fetch_b(br0);                                            // item 0
         commit_b(0, br0);
         fetch_b(br1);                                            // item 1 -> set 1
         fetch_b(br0);                                            // item 2 -> set 0
         __syncthreads();
-        f32x16 acc[2];
         float row_scale[2] = {1.0f, 1.0f};                      // DropPath scale of this lane's two rows
         if (EPI == EPI_RESID && p.rowscale) {
 #pragma unroll
@@ -140,75 +192,65 @@ __global__ __launch_bounds__(512) void gemm_ares_kernel(GemmParams p) {
                 if (gm < p.M) row_scale[i] = p.rowscale[gm / p.rows_per_sample];
             }
         }
-        int q = 0;
-        for (int tn = 0; tn < tiles_n; ++tn) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-            for (int st = 0; st < steps; ++st, ++q) {
-                const int stage = q & 1;
-                // prefetch of the NEXT panel rides under the last column tile of this one
-                if (tn == tiles_n - 1 && st == 0 && tm + (int)gridDim.x < tiles_m) fetch_a(tm + gridDim.x);
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        int tn = 0, st = 0;
+        const bool more_panels = tm + (int)gridDim.x < tiles_m;
+        for (int q = 0; q < total_q; ++q) {
+            // prefetch of the NEXT panel rides under the last column tile of this one
+            if (more_panels && tn == tiles_n - 1 && st == 0) fetch_a(tm + gridDim.x);
+            if ((q & 1) == 0) {
+                compute(0, st);
+                commit_b(1, br1);                                // item q + 1
+                fetch_b(br1);                                    // item q + 3
+            } else {
+                compute(1, st);
+                commit_b(0, br0);
+                fetch_b(br0);
+            }
+            __syncthreads();
+            if (++st == steps) {
+                // ---- epilogue of column tile tn, straight from registers
+                f32x4v csum[4];
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int kc = 2 * st + half;
-                    if (kc < KC) {
-                        const char* ai = a_img + kc * 16384;
-                        const char* bi = b_ring + (stage * 2 + half) * 16384;
+                for (int g = 0; g < 4; ++g) { csum[g].x = 0.f; csum[g].y = 0.f; csum[g].z = 0.f; csum[g].w = 0.f; }
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-                            const int slot = 2 * kk + hf;
-                            const int brow = 32 * wn + lq;
-                            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bi + brow * 128 + gemm_swz(brow, slot) * 16);
+                for (int i = 0; i < 2; ++i) {
+                    const int gm = tm * 128 + 64 * wm + 32 * i + lq;
+                    if (gm < p.M) {
 #pragma unroll
-                            for (int i = 0; i < 2; ++i) {
-                                const int row = 64 * wm + 32 * i + lq;
-                                const bf16x8 af = *reinterpret_cast<const bf16x8*>(ai + row * 128 + gemm_swz(row, slot) * 16);
-                                acc[i] = mfma_32x32x16_bf16(bf, af, acc[i]);     // D[n][m]: transposed accumulator
-                            }
+                        for (int g = 0; g < 4; ++g) {
+                            const int gn = tn * 128 + 32 * wn + 8 * g + 4 * hf;
+                            if (gn < p.N)
+                                csum[g] += ares_store4<EPI>(p, gm, gn, acc[i][4 * g] * p.alpha, acc[i][4 * g + 1] * p.alpha,
+                                                            acc[i][4 * g + 2] * p.alpha, acc[i][4 * g + 3] * p.alpha,
+                                                            row_scale[i]);
                         }
                     }
                 }
-                // ring maintenance: item q+1 goes to the other stage, then refill the freed register set with item q+3
-                if (q + 1 < total_q) {
-                    if (stage == 0) commit_b(1, br1); else commit_b(0, br0);
-                }
-                if (stage == 0) fetch_b(br1); else fetch_b(br0);
-                __syncthreads();
-            }
-            // ---- epilogue of column tile tn, straight from registers
-            f32x4v csum[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) { csum[g].x = 0.f; csum[g].y = 0.f; csum[g].z = 0.f; csum[g].w = 0.f; }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int gm = tm * 128 + 64 * wm + 32 * i + lq;
-                if (gm < p.M) {
+                if ((EPI == EPI_DGELU || EPI == EPI_BF16) && p.colsum) {   // bias gradient: sum over the wave's 64 rows
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                        for (int msk = 16; msk >= 1; msk >>= 1) {
+                            csum[g].x += shfl_xor(csum[g].x, msk); csum[g].y += shfl_xor(csum[g].y, msk);
+                            csum[g].z += shfl_xor(csum[g].z, msk); csum[g].w += shfl_xor(csum[g].w, msk);
+                        }
                         const int gn = tn * 128 + 32 * wn + 8 * g + 4 * hf;
-                        if (gn < p.N)
-                            csum[g] += ares_store4<EPI>(p, gm, gn, acc[i][4 * g] * p.alpha, acc[i][4 * g + 1] * p.alpha,
-                                                        acc[i][4 * g + 2] * p.alpha, acc[i][4 * g + 3] * p.alpha,
-                                                        row_scale[i]);
+                        if (lq == 0 && gn < p.N) {
+                            atomicAdd(p.colsum + gn, csum[g].x); atomicAdd(p.colsum + gn + 1, csum[g].y);
+                            atomicAdd(p.colsum + gn + 2, csum[g].z); atomicAdd(p.colsum + gn + 3, csum[g].w);
+                        }
                     }
                 }
-            }
-            if ((EPI == EPI_DGELU || EPI == EPI_BF16) && p.colsum) {   // bias gradient: sum over the wave's 64 rows
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int msk = 16; msk >= 1; msk >>= 1) {
-                        csum[g].x += shfl_xor(csum[g].x, msk); csum[g].y += shfl_xor(csum[g].y, msk);
-                        csum[g].z += shfl_xor(csum[g].z, msk); csum[g].w += shfl_xor(csum[g].w, msk);
-                    }
-                    const int gn = tn * 128 + 32 * wn + 8 * g + 4 * hf;
-                    if (lq == 0 && gn < p.N) {
-                        atomicAdd(p.colsum + gn, csum[g].x); atomicAdd(p.colsum + gn + 1, csum[g].y);
-                        atomicAdd(p.colsum + gn + 2, csum[g].z); atomicAdd(p.colsum + gn + 3, csum[g].w);
-                    }
-                }
+                    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+                st = 0;
+                ++tn;
             }
         }
     }
