@@ -7,6 +7,7 @@
 #include "kernels/common.h"
 #include "kernels/gemm.h"
 #include "kernels/gemm_ares.h"
+#include "kernels/gemm_nt32.h"
 #include "kernels/layernorm.h"
 #include "kernels/attention_fwd.h"
 #include "kernels/attention_bwd.h"
@@ -54,6 +55,20 @@ static int ccd_launch_gemm_ares(const ccd::GemmParams& p, int epilogue, void* st
     }
     return ccd_rt_last_error();
 }
+static int ccd_launch_gemm_nt32(const ccd::GemmParams& p, int epilogue, void* stream) {
+    const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+    const dim3 grid(tiles), block(256);
+    const size_t smem = ccd::NT32_SMEM_BYTES;
+    switch (epilogue) {
+        case CCD_EPI_BF16: CCD_LAUNCH((ccd::gemm_nt32_kernel<ccd::EPI_BF16>), grid, block, smem, stream, p); break;
+        case CCD_EPI_GELU: CCD_LAUNCH((ccd::gemm_nt32_kernel<ccd::EPI_GELU>), grid, block, smem, stream, p); break;
+        case CCD_EPI_RESID: CCD_LAUNCH((ccd::gemm_nt32_kernel<ccd::EPI_RESID>), grid, block, smem, stream, p); break;
+        case CCD_EPI_F32: CCD_LAUNCH((ccd::gemm_nt32_kernel<ccd::EPI_F32>), grid, block, smem, stream, p); break;
+        case CCD_EPI_DGELU: CCD_LAUNCH((ccd::gemm_nt32_kernel<ccd::EPI_DGELU>), grid, block, smem, stream, p); break;
+        default: return CCD_EINVAL;
+    }
+    return ccd_rt_last_error();
+}
 static bool ccd_env_flag(const char* name, bool dflt) {
     const char* v = getenv(name);
     return v ? (v[0] != '0') : dflt;
@@ -84,11 +99,14 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
     p.rowscale = rowscale; p.rows_per_sample = rows_per_sample; p.aux = aux; p.ldaux = ldaux;
     p.k_per_split = K; p.m_fastest = m_fastest; p.alpha = alpha; p.d_rows = d_rows; p.rows_mul = rows_mul;
     p.colsum = colsum;
-    static const bool use_ares = ccd_env_flag("CCD_GEMM_ARES", true);
+    // kernel choice (all three are parity-tested): CCD_GEMM_NT32=0 / CCD_GEMM_ARES=1 switch variants for A/B timing
+    static const bool use_nt32 = ccd_env_flag("CCD_GEMM_NT32", true);
+    static const bool use_ares = ccd_env_flag("CCD_GEMM_ARES", false);
     const bool ares_epi = epilogue == CCD_EPI_BF16 || epilogue == CCD_EPI_GELU || epilogue == CCD_EPI_RESID ||
                           epilogue == CCD_EPI_DGELU;
     if (use_ares && ares_epi && !d_rows && K <= 64 * ccd::ARES_MAX_KC && K % 128 == 0 && M >= 1024 && N % 4 == 0)
         return ccd_launch_gemm_ares(p, epilogue, stream);
+    if (use_nt32 && epilogue != CCD_EPI_ATOMIC && N % 4 == 0) return ccd_launch_gemm_nt32(p, epilogue, stream);
     return ccd_launch_gemm<false>(p, epilogue, 1, stream);
 }
 

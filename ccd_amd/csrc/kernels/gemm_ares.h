@@ -119,7 +119,9 @@ __global__ __launch_bounds__(512) void gemm_ares_kernel(GemmParams p) {
             pb[h] = p.B + (long)n * p.ldb + aslot * 8;
         }
     };
+    const int dbg = p.m_fastest;                                 // timing ablations only (bits 2: stores 4: loads 8: LDS writes 16: barrier)
     auto fetch_b = [&](u32x4 (&br)[4]) {                         // loads the current item, then advances (clamped at the end)
+        if (dbg & 4) return;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             br[h] = *reinterpret_cast<const u32x4*>(pb[h]);          // chunk 2*st
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(512) void gemm_ares_kernel(GemmParams p) {
         }
     };
     auto commit_b = [&](int stage, const u32x4 (&br)[4]) {
+        if (dbg & 8) return;
         char* dst = b_ring + stage * 32768;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(512) void gemm_ares_kernel(GemmParams p) {
                 commit_b(0, br0);
                 fetch_b(br0);
             }
-            __syncthreads();
+            if (!(dbg & 16)) __syncthreads();
             if (++st == steps) {
                 // ---- epilogue of column tile tn, straight from registers
                 f32x4v csum[4];
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(512) void gemm_ares_kernel(GemmParams p) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int gm = tm * 128 + 64 * wm + 32 * i + lq;
-                    if (gm < p.M) {
+                    if (gm < p.M && !(p.m_fastest & 2)) {
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const int gn = tn * 128 + 32 * wn + 8 * g + 4 * hf;

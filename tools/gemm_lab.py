@@ -20,7 +20,8 @@ if kind == "tn":
 else:
     a = torch.randn(P, K, device=dev).to(BF); b = torch.randn(Q, K, device=dev).to(BF)
     out = torch.empty(P, Q, device=dev, dtype=BF)
-    fn = lambda: ops.gemm_nt(a, b, out=out)
+    mf = int(os.environ.get("LAB_MFAST", "0"))
+    fn = lambda: ops.gemm_nt(a, b, out=out, m_fastest=mf)
 for _ in range(iters):
     fn()
 torch.cuda.synchronize()
