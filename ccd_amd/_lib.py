@@ -61,6 +61,15 @@ SIGNATURES = {
     "ccd_adamw": [P, P, P, P, P, P, P, P, I, P, P, F, F, F, F, P],
     "ccd_clip_scale": [P, P, P, P, I, P, F, P],
     "ccd_ema": [P, P, P, L, F, F, P],
+    "ccd_conv_gemm": [P, L, P, P, L, I, I, P, L, P, P, P, P],
+    "ccd_im2col": [P, L, P, L, P, P],
+    "ccd_bn_finalize": [P, F, F, F, P, P, P, I, P],
+    "ccd_bn_relu_fwd": [P, L, P, P, P, P, L, L, I, P],
+    "ccd_bn_relu_bwd_reduce": [P, L, P, L, P, P, P, P, L, I, P],
+    "ccd_bn_relu_bwd_apply": [P, L, P, L, P, P, P, P, F, P, P, P, P, L, L, I, P],
+    "ccd_cls_conv_fwd": [P, P, P, P, I, I, I, I, P],
+    "ccd_cls_conv_bwd": [P, P, P, P, P, P, I, I, I, I, P],
+    "ccd_permute4": [P, L, L, L, L, I, I, I, I, P, I, P],
 }
 _RESTYPES = {"ccd_build_info": C.c_char_p}
 

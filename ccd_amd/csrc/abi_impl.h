@@ -16,6 +16,7 @@
 #include "kernels/head.h"
 #include "kernels/loss.h"
 #include "kernels/optim.h"
+#include "kernels/conv.h"
 
 #define CCD_CHECK(cond, code) \
     do {                      \
@@ -93,14 +94,14 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
     CCD_CHECK(epilogue != CCD_EPI_GELU || (C2 && ldc2 % 8 == 0), CCD_EINVAL);
     CCD_CHECK(epilogue != CCD_EPI_RESID || (resid && ldr % 4 == 0 && rows_per_sample > 0), CCD_EINVAL);
     CCD_CHECK(epilogue != CCD_EPI_DGELU || (aux && ldaux % 8 == 0), CCD_EINVAL);
-    ccd::GemmParams p;
+    ccd::GemmParams p = ccd::GemmParams();
     p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K;
     p.C = C; p.ldc = ldc; p.C2 = C2; p.ldc2 = ldc2; p.bias = bias; p.resid = resid; p.ldr = ldr;
     p.rowscale = rowscale; p.rows_per_sample = rows_per_sample; p.aux = aux; p.ldaux = ldaux;
     p.k_per_split = K; p.m_fastest = m_fastest; p.alpha = alpha; p.d_rows = d_rows; p.rows_mul = rows_mul;
     p.colsum = colsum;
     // kernel choice (all three are parity-tested): CCD_GEMM_NT32=0 / CCD_GEMM_ARES=1 switch variants for A/B timing
-    static const bool use_nt32 = ccd_env_flag("CCD_GEMM_NT32", true);
+    static const bool use_nt32 = ccd_env_flag("CCD_GEMM_NT32", false);
     static const bool use_ares = ccd_env_flag("CCD_GEMM_ARES", false);
     const bool ares_epi = epilogue == CCD_EPI_BF16 || epilogue == CCD_EPI_GELU || epilogue == CCD_EPI_RESID ||
                           epilogue == CCD_EPI_DGELU;
@@ -128,7 +129,7 @@ int ccd_gemm_tn(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P,
     per = ((per + 63) / 64) * 64;
     splits = (Mc + per - 1) / per;
     CCD_CHECK(epilogue == CCD_EPI_ATOMIC || splits == 1, CCD_EINVAL);
-    ccd::GemmParams p;
+    ccd::GemmParams p = ccd::GemmParams();
     p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.M = P; p.N = Q; p.K = Mc;
     p.C = C; p.ldc = ldc; p.C2 = nullptr; p.ldc2 = 0; p.bias = nullptr; p.resid = nullptr; p.ldr = 0;
     p.rowscale = nullptr; p.rows_per_sample = 1; p.aux = nullptr; p.ldaux = 0;
@@ -442,6 +443,137 @@ int ccd_ema(float* teacher, const float* student, ccd_bf16* mirror, long n, floa
     if (n == 0) return CCD_OK;
     CCD_LAUNCH(ccd::ema_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, teacher, student, mirror, n, m,
                one_minus_m);
+    return ccd_rt_last_error();
+}
+
+// --------------------------------------------------------------------------------- segmentation head
+static int ccd_check_conv_desc(const ccd_conv_desc* d) {
+    CCD_CHECK(d, CCD_EINVAL);
+    CCD_CHECK(d->ntaps >= 1 && d->ntaps <= 16 && d->cin > 0 && d->cin % 64 == 0, CCD_ESHAPE);
+    CCD_CHECK(d->g_h_log2 >= 0 && d->g_w_log2 >= 0 && d->g_h_log2 + d->g_w_log2 <= 24, CCD_ESHAPE);
+    CCD_CHECK(d->s_h > 0 && d->s_w > 0 && d->s_mul >= 1, CCD_ESHAPE);
+    return CCD_OK;
+}
+
+int ccd_conv_gemm(const ccd_bf16* src, long src_ld, const ccd_conv_desc* desc, const ccd_bf16* W, long ldw, int M, int N,
+                  ccd_bf16* C, long ldc, const float* bias, float* colsum, float* colsumsq, void* stream) {
+    CCD_CHECK(src && W && C, CCD_EINVAL);
+    CCD_CHECK(CCD_ALIGNED16(src) && CCD_ALIGNED16(W) && CCD_ALIGNED16(C), CCD_EINVAL);
+    const int rc = ccd_check_conv_desc(desc);
+    if (rc != CCD_OK) return rc;
+    if (M == 0 || N == 0) return CCD_OK;
+    CCD_CHECK(M > 0 && N > 0, CCD_EINVAL);
+    CCD_CHECK(N % 8 == 0 && src_ld % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && src_ld >= desc->cin, CCD_ESHAPE);
+    CCD_CHECK(M % (1 << (desc->g_h_log2 + desc->g_w_log2)) == 0, CCD_ESHAPE);
+    ccd::GemmParams p = ccd::GemmParams();
+    p.A = src; p.lda = src_ld; p.B = W; p.ldb = ldw; p.M = M; p.N = N; p.K = desc->ntaps * desc->cin;
+    p.C = C; p.ldc = ldc; p.bias = bias; p.rows_per_sample = 1; p.k_per_split = p.K; p.alpha = 1.0f; p.rows_mul = 1;
+    p.colsum = colsum; p.colsumsq = colsumsq;
+    p.g_h_log2 = desc->g_h_log2; p.g_w_log2 = desc->g_w_log2; p.s_h = desc->s_h; p.s_w = desc->s_w;
+    p.s_mul = desc->s_mul; p.cin = desc->cin;
+    for (int i = 0; i < 16; ++i) { p.dy[i] = desc->dy[i]; p.dx[i] = desc->dx[i]; }
+    p.c_map = desc->c_map; p.c_py = desc->c_py; p.c_px = desc->c_px;
+    const int tiles = ((M + ccd::GEMM_BM - 1) / ccd::GEMM_BM) * ((N + ccd::GEMM_BN - 1) / ccd::GEMM_BN);
+    CCD_LAUNCH((ccd::gemm_bf16_kernel<false, ccd::EPI_BF16, true>), dim3(tiles), dim3(256), (size_t)ccd::GEMM_SMEM_BYTES,
+               stream, p);
+    return ccd_rt_last_error();
+}
+
+int ccd_im2col(const ccd_bf16* src, long src_ld, const ccd_conv_desc* desc, long rows, ccd_bf16* cols, void* stream) {
+    CCD_CHECK(src && cols && CCD_ALIGNED16(src) && CCD_ALIGNED16(cols), CCD_EINVAL);
+    const int rc = ccd_check_conv_desc(desc);
+    if (rc != CCD_OK) return rc;
+    if (rows == 0) return CCD_OK;
+    CCD_CHECK(rows > 0 && src_ld % 8 == 0 && src_ld >= desc->cin, CCD_ESHAPE);
+    const long total = rows * desc->ntaps * (desc->cin / 8);
+    CCD_LAUNCH(ccd::im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, src_ld, *desc, rows,
+               cols);
+    return ccd_rt_last_error();
+}
+
+int ccd_bn_finalize(const float* stats, float count, float eps, float momentum, float* mean_rstd, float* running_mean,
+                    float* running_var, int C, void* stream) {
+    CCD_CHECK(stats && mean_rstd && running_mean && running_var && C > 0 && count > 1.0f, CCD_EINVAL);
+    CCD_LAUNCH(ccd::bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, stats, count, eps, momentum, mean_rstd,
+               running_mean, running_var, C);
+    return ccd_rt_last_error();
+}
+
+int ccd_bn_relu_fwd(const ccd_bf16* x, long ldx, const float* mean_rstd, const float* gamma, const float* beta,
+                    ccd_bf16* y, long ldy, long rows, int C, void* stream) {
+    CCD_CHECK(x && mean_rstd && gamma && beta && y && CCD_ALIGNED16(x) && CCD_ALIGNED16(y), CCD_EINVAL);
+    if (rows == 0) return CCD_OK;
+    CCD_CHECK(rows > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, CCD_ESHAPE);
+    const long total = rows * (C / 8);
+    CCD_LAUNCH(ccd::bn_relu_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, ldx, mean_rstd,
+               gamma, beta, y, ldy, rows, C);
+    return ccd_rt_last_error();
+}
+
+int ccd_bn_relu_bwd_reduce(const ccd_bf16* dy, long lddy, const ccd_bf16* x, long ldx, const float* mean_rstd,
+                           const float* gamma, const float* beta, float* red, long rows, int C, void* stream) {
+    CCD_CHECK(dy && x && mean_rstd && gamma && beta && red && CCD_ALIGNED16(dy) && CCD_ALIGNED16(x), CCD_EINVAL);
+    if (rows == 0) return CCD_OK;
+    CCD_CHECK(rows > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0, CCD_ESHAPE);
+    const int cblocks = (C + 255) / 256;
+    long yblocks = (8L * ccd_rt_num_cus()) / cblocks;
+    long rpb = (rows + yblocks - 1) / yblocks;
+    rpb = ((rpb + 7) / 8) * 8;
+    yblocks = (rows + rpb - 1) / rpb;
+    CCD_LAUNCH(ccd::bn_relu_bwd_reduce_kernel, dim3(cblocks, (unsigned)yblocks), dim3(256), 0, stream, dy, lddy, x, ldx,
+               mean_rstd, gamma, beta, red, rows, C, (int)rpb);
+    return ccd_rt_last_error();
+}
+
+int ccd_bn_relu_bwd_apply(const ccd_bf16* dy, long lddy, const ccd_bf16* x, long ldx, const float* mean_rstd,
+                          const float* gamma, const float* beta, const float* red, float count, const float* red_local,
+                          float* dgamma, float* dbeta, ccd_bf16* dx, long lddx, long rows, int C, void* stream) {
+    CCD_CHECK(dy && x && mean_rstd && gamma && beta && red && red_local && dgamma && dbeta && dx, CCD_EINVAL);
+    CCD_CHECK(CCD_ALIGNED16(dy) && CCD_ALIGNED16(x) && CCD_ALIGNED16(dx), CCD_EINVAL);
+    if (rows == 0) return CCD_OK;
+    CCD_CHECK(rows > 0 && C > 0 && C % 8 == 0 && C <= 256 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, CCD_ESHAPE);
+    const long total = rows * (C / 8);
+    CCD_LAUNCH(ccd::bn_relu_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dy, lddy, x,
+               ldx, mean_rstd, gamma, beta, red, count, red_local, dgamma, dbeta, dx, lddx, rows, C);
+    return ccd_rt_last_error();
+}
+
+int ccd_cls_conv_fwd(const ccd_bf16* x, const float* w, const float* bias, float* logits, int images, int H, int W, int C,
+                     void* stream) {
+    CCD_CHECK(x && w && bias && logits && CCD_ALIGNED16(x), CCD_EINVAL);
+    if (images == 0) return CCD_OK;
+    CCD_CHECK(images > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= ccd::CLS_MAX_C, CCD_ESHAPE);
+    const long total = (long)images * H * W;
+    CCD_LAUNCH(ccd::cls_conv_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, w, bias, logits,
+               images, H, W, C);
+    return ccd_rt_last_error();
+}
+
+int ccd_cls_conv_bwd(const float* dlogits, const ccd_bf16* x, const float* w, ccd_bf16* dx, float* dw, float* db,
+                     int images, int H, int W, int C, void* stream) {
+    CCD_CHECK(dlogits && x && w && dx && dw && db && CCD_ALIGNED16(x) && CCD_ALIGNED16(dx), CCD_EINVAL);
+    if (images == 0) return CCD_OK;
+    CCD_CHECK(images > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= ccd::CLS_MAX_C && 2 * C <= 1024, CCD_ESHAPE);
+    const long pixels = (long)images * H * W, total = pixels * (C / 8);
+    CCD_LAUNCH(ccd::cls_conv_bwd_data_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dlogits, w, dx,
+               images, H, W, C);
+    long blocks = 16L * ccd_rt_num_cus();
+    long ppb = (pixels + blocks - 1) / blocks;
+    blocks = (pixels + ppb - 1) / ppb;
+    CCD_LAUNCH(ccd::cls_conv_bwd_weight_kernel, dim3((unsigned)blocks), dim3(2 * C), 0, stream, dlogits, x, dw, db, images,
+               H, W, C, (int)ppb);
+    return ccd_rt_last_error();
+}
+
+int ccd_permute4(const float* src, long s0, long s1, long s2, long s3, int n0, int n1, int n2, int n3, void* dst,
+                 int accumulate, void* stream) {
+    CCD_CHECK(src && dst && n0 > 0 && n1 > 0 && n2 > 0 && n3 > 0, CCD_EINVAL);
+    const long total = (long)n0 * n1 * n2 * n3;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (accumulate)
+        CCD_LAUNCH((ccd::permute4_kernel<true>), grid, dim3(256), 0, stream, src, s0, s1, s2, s3, n1, n2, n3, total, dst);
+    else
+        CCD_LAUNCH((ccd::permute4_kernel<false>), grid, dim3(256), 0, stream, src, s0, s1, s2, s3, n1, n2, n3, total, dst);
     return ccd_rt_last_error();
 }
 

@@ -44,6 +44,14 @@ struct GemmParams {
     int m_fastest;          // tile order: 0 = column tiles fastest, 1 = row tiles fastest
     float alpha;            // scales acc before the epilogue
     float* colsum;          // optional [N] fp32: += column sums of the (final) output tile, e.g. the bias gradient
+    float* colsumsq;        // optional [N] fp32: += column sums of squares (BatchNorm batch statistics), EPI_BF16 only
+    // ---- implicit-GEMM convolution (NT, GATHER instantiation): A row r is pixel (n, oy, ox) of a 2^gh x 2^gw grid,
+    // contraction index k = tap * cin + c reads source pixel (oy*s_mul + dy[tap], ox*s_mul + dx[tap]) of an s_h x s_w
+    // image with `lda` channels per pixel (zero outside); covers 3x3 conv, its data gradient, the four parity classes
+    // of a 4x4/stride-2 transposed conv and that layer's data gradient.
+    int g_h_log2, g_w_log2, s_h, s_w, s_mul, cin;
+    signed char dy[16], dx[16];
+    int c_map, c_py, c_px;  // c_map: output row (n, oy, ox) -> (n, 2*oy + c_py, 2*ox + c_px) of the 2x upsampled grid
     const int* d_rows;      // optional device-side row count: NT rows M / TN contraction length K become
     int rows_mul;           //   min(static value, d_rows[0] * rows_mul); the grid is sized for the static value
 };
@@ -79,6 +87,42 @@ struct NtCursor {
             r[i] = v;
             ptr[i] += GEMM_BK;
         }
+    }
+};
+// gather variant of NtCursor for the implicit-GEMM convolutions (see GemmParams)
+struct GatherCursor {
+    const bf16_t* base;
+    int pix[4], oys[4], oxs[4];      // per chunk row: image base pixel index, scaled coordinates
+    bool ok[4];
+    int tap, c0;
+    __device__ __forceinline__ void init(const GemmParams& p, int row0) {
+        const int t = threadIdx.x;
+        base = p.A + (t & 7) * 8;
+        tap = 0;
+        c0 = 0;
+        const int hw = p.g_h_log2 + p.g_w_log2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + (t >> 3) + 32 * i;
+            ok[i] = row < p.M;
+            const int n = row >> hw, oy = (row >> p.g_w_log2) & ((1 << p.g_h_log2) - 1), ox = row & ((1 << p.g_w_log2) - 1);
+            pix[i] = n * p.s_h * p.s_w;
+            oys[i] = oy * p.s_mul;
+            oxs[i] = ox * p.s_mul;
+        }
+    }
+    __device__ __forceinline__ void load(const GemmParams& p, u32x4 (&r)[4]) {
+        const int dy = p.dy[tap], dx = p.dx[tap];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sy = oys[i] + dy, sx = oxs[i] + dx;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok[i] && sy >= 0 && sy < p.s_h && sx >= 0 && sx < p.s_w)
+                v = *reinterpret_cast<const u32x4*>(base + (long)(pix[i] + sy * p.s_w + sx) * p.lda + c0);
+            r[i] = v;
+        }
+        c0 += GEMM_BK;
+        if (c0 >= p.cin) { c0 = 0; ++tap; }
     }
 };
 __device__ __forceinline__ void gemm_store_nt(char* tile, const u32x4 (&r)[4]) {
@@ -185,7 +229,7 @@ __device__ __forceinline__ void gemm_epilogue_row8(const GemmParams& p, int gm, 
     }
 }
 
-template <bool TN, int EPI>
+template <bool TN, int EPI, bool GATHER = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     const int m_static = p.M;                               // the launch grid was sized for the static shape
     if (p.d_rows) {
@@ -230,11 +274,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
     NtCursor nta, ntb;
     TnCursor tna, tnb;
+    GatherCursor gta;
     if (TN) {
         tna.init(p.A, p.lda, m0, p.M, k_begin);
         tnb.init(p.B, p.ldb, n0, p.N, k_begin);
     } else {
-        nta.init(p.A, p.lda, m0, p.M, k_begin);
+        if (GATHER) gta.init(p, m0);
+        else nta.init(p.A, p.lda, m0, p.M, k_begin);
         ntb.init(p.B, p.ldb, n0, p.N, k_begin);
     }
     int next_tile = 0;                                      // tiles are fetched strictly in order
@@ -245,7 +291,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
                 tna.load(ra, left);
                 tnb.load(rb, left);
             } else {
-                nta.load(ra);
+                if (GATHER) gta.load(p, ra);
+                else nta.load(ra);
                 ntb.load(rb);
             }
         }
@@ -323,6 +370,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         return;
     }
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float csq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int pass = 0; pass < 8; ++pass) {
         const int row = pass * 16 + (t >> 4), col = (t & 15) * 8;
@@ -333,9 +381,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
             const f32x4v c1 = *reinterpret_cast<const f32x4v*>(cs + row * GEMM_CS_LD + col + 4);
             v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
             v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
-            gemm_epilogue_row8<EPI>(p, gm, gn, v);
+            int gm_out = gm;
+            if (GATHER && p.c_map) {          // transposed-conv parity class: scatter to the 2x upsampled grid
+                const int hw = p.g_h_log2 + p.g_w_log2;
+                const int n = gm >> hw, oy = (gm >> p.g_w_log2) & ((1 << p.g_h_log2) - 1), ox = gm & ((1 << p.g_w_log2) - 1);
+                gm_out = (((n << (p.g_h_log2 + 1)) + 2 * oy + p.c_py) << (p.g_w_log2 + 1)) + 2 * ox + p.c_px;
+            }
+            gemm_epilogue_row8<EPI>(p, gm_out, gn, v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) csum[e] += v[e];
+            for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * v[e]; }
+        }
+    }
+    if (EPI == EPI_BF16 && p.colsumsq) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[(t >> 4) * GEMM_BN + (t & 15) * 8 + e] = csq[e];
+        __syncthreads();
+        if (t < GEMM_BN && n0 + t < p.N) {
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a += cs[q * GEMM_BN + t];
+            atomicAdd(p.colsumsq + n0 + t, a);
         }
     }
     if ((EPI == EPI_DGELU || EPI == EPI_BF16) && p.colsum) {     // block-wide column sums of the tile -> one atomic per column

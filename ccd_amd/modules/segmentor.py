@@ -1,10 +1,10 @@
 """Segmentation head of the student (Dino/modules/segmentor.py: Conv_MLA 6-35, MLAHead 38-70, SegHead 73-95).
 
 Same parameter tree / construction order as the reference (incl. the never-executed conv_mla branch, which is why 18
-of its tensors never receive gradients).  ROUND-1 STATUS: the convolutions / BatchNorm of this head still run through
-PyTorch-ROCm library kernels (MIOpen) in bf16 on the GPU - 8 % of the step's FLOPs - while every other stage of the
-step is hand-written HIP; the implicit-GEMM conv / fused-BN kernels replace this file's forward next
-(see DESIGN.md "what is not native yet").
+of its tensors never receive gradients).  The nn.Conv2d / nn.BatchNorm2d / nn.ConvTranspose2d children only HOLD the
+parameters and running statistics (state-dict compatible, convertible by nn.SyncBatchNorm.convert_sync_batchnorm);
+the computation is ccd_amd.seghead.SegHeadFn: implicit-GEMM convolutions on the MFMA GEMM kernel, fused BatchNorm+ReLU
+passes and a VALU classifier conv, all hand-written HIP.  There is no library (MIOpen) or CPU path.
 """
 from __future__ import annotations
 
@@ -52,11 +52,11 @@ class SegHead(nn.Module):
 
     def forward(self, inputs):
         """inputs: three [N,E,8,32] feature maps (channels-last views of the bf16 taps) -> fp32 logits [N,2,32,128]."""
-        dev_type = inputs[0].device.type
-        if dev_type != "cuda":                      # CPU SIMT-executor tests: library convs in fp32
-            inputs = [t.float() for t in inputs]
-        with torch.autocast(dev_type, dtype=torch.bfloat16, enabled=dev_type == "cuda"):
-            x = self.mlahead(inputs[0], inputs[1], inputs[2])
-            x = self.unpool2(self.unpool1(x))
-            x = self.cls(x)
-        return x.float()
+        from .. import _lib
+        from ..seghead import seg_head_forward
+        if inputs[0].device.type != "cuda" and _lib._stream_override is None:
+            raise RuntimeError("ccd_amd.SegHead runs on an AMD GPU only; there is no CPU path")
+        n, e = inputs[0].shape[0], inputs[0].shape[1]
+        assert tuple(inputs[0].shape[2:]) == (8, 32), "SegHead expects the 8x32 token grid of a 32x128 crop"
+        taps = [t.permute(0, 2, 3, 1).reshape(n * 256, e).to(torch.bfloat16) for t in inputs]   # views for bf16 taps
+        return seg_head_forward(self, taps, n)

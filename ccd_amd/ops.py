@@ -2,6 +2,8 @@
 current stream; nothing here computes on the host."""
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -345,3 +347,112 @@ def clip_scale(grad, chunk_seg, chunk_begin, chunk_len, norm2, clip):
 
 def ema(teacher, student, mirror, m):
     _call("ccd_ema", _lib.ptr(teacher), _lib.ptr(student), _lib.ptr(mirror), teacher.numel(), float(m), float(1.0 - m))
+
+
+# ------------------------------------------------------------------------------------------ segmentation head
+class ConvDesc(ctypes.Structure):
+    """ccd_conv_desc of include/ccd_hip.h (host-side, passed by pointer)."""
+    _fields_ = [("g_h_log2", ctypes.c_int), ("g_w_log2", ctypes.c_int), ("s_h", ctypes.c_int), ("s_w", ctypes.c_int),
+                ("s_mul", ctypes.c_int), ("cin", ctypes.c_int), ("ntaps", ctypes.c_int),
+                ("dy", ctypes.c_byte * 16), ("dx", ctypes.c_byte * 16),
+                ("c_map", ctypes.c_int), ("c_py", ctypes.c_int), ("c_px", ctypes.c_int)]
+
+
+def conv_desc(grid_hw, src_hw, cin, taps, s_mul=1, parity=None):
+    """grid_hw: output-row grid (powers of two); taps: [(dy, dx)]; parity (py, px) turns on the 2x scatter."""
+    gh, gw = grid_hw
+    assert gh & (gh - 1) == 0 and gw & (gw - 1) == 0 and 1 <= len(taps) <= 16
+    d = ConvDesc()
+    d.g_h_log2, d.g_w_log2 = gh.bit_length() - 1, gw.bit_length() - 1
+    d.s_h, d.s_w, d.s_mul, d.cin, d.ntaps = src_hw[0], src_hw[1], s_mul, cin, len(taps)
+    for i, (a, b) in enumerate(taps):
+        d.dy[i], d.dx[i] = a, b
+    if parity is not None:
+        d.c_map, d.c_py, d.c_px = 1, parity[0], parity[1]
+    return d
+
+
+def conv_gemm(src, desc, w, rows, out, *, bias=None, colsum=None, colsumsq=None):
+    """out[rows -> c_map, N] (bf16) = gather(src)[rows, ntaps*cin] @ w[N, ntaps*cin]^T (+ bias); stats += column sums."""
+    _chk(src, BF16, "src"); _chk(w, BF16, "w"); _chk(out, BF16, "out"); _chk(bias, F32, "bias")
+    _chk(colsum, F32, "colsum"); _chk(colsumsq, F32, "colsumsq")
+    N = w.shape[0]
+    assert w.shape[1] == desc.ntaps * desc.cin and src.dim() == 2 and out.dim() == 2 and out.shape[1] >= N
+    span = TIMER.span("conv_gemm", 2.0 * rows * N * w.shape[1]) if TIMER is not None else None
+    if span:
+        span[0].record()
+    _call("ccd_conv_gemm", _lib.ptr(src), src.stride(0), ctypes.addressof(desc), _lib.ptr(w), w.stride(0), rows, N,
+          _lib.ptr(out), out.stride(0), _lib.ptr(bias), _lib.ptr(colsum), _lib.ptr(colsumsq))
+    if span:
+        span[1].record()
+    return out
+
+
+def im2col(src, desc, rows, out=None):
+    _chk(src, BF16, "src")
+    if out is None:
+        out = torch.empty((rows, desc.ntaps * desc.cin), dtype=BF16, device=src.device)
+    assert out.is_contiguous() and out.numel() == rows * desc.ntaps * desc.cin
+    _call("ccd_im2col", _lib.ptr(src), src.stride(0), ctypes.addressof(desc), rows, _lib.ptr(out))
+    return out
+
+
+def bn_finalize(stats, count, eps, momentum, mean_rstd, running_mean, running_var):
+    C = running_mean.numel()
+    assert stats.numel() == 2 * C and mean_rstd.numel() == 2 * C
+    _call("ccd_bn_finalize", _lib.ptr(stats), float(count), float(eps), float(momentum), _lib.ptr(mean_rstd),
+          _lib.ptr(running_mean), _lib.ptr(running_var), C)
+
+
+def bn_relu_fwd(x, mean_rstd, gamma, beta, out):
+    _chk(x, BF16, "x"); _chk(out, BF16, "out")
+    rows, C = x.shape
+    _call("ccd_bn_relu_fwd", _lib.ptr(x), x.stride(0), _lib.ptr(mean_rstd), _lib.ptr(gamma), _lib.ptr(beta),
+          _lib.ptr(out), out.stride(0), rows, C)
+    return out
+
+
+def bn_relu_bwd_reduce(dy, x, mean_rstd, gamma, beta, red):
+    _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(red, F32, "red")
+    rows, C = x.shape
+    _call("ccd_bn_relu_bwd_reduce", _lib.ptr(dy), dy.stride(0), _lib.ptr(x), x.stride(0), _lib.ptr(mean_rstd),
+          _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(red), rows, C)
+
+
+def bn_relu_bwd_apply(dy, x, mean_rstd, gamma, beta, red, count, red_local, dgamma, dbeta, dx):
+    _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(dx, BF16, "dx")
+    rows, C = x.shape
+    _call("ccd_bn_relu_bwd_apply", _lib.ptr(dy), dy.stride(0), _lib.ptr(x), x.stride(0), _lib.ptr(mean_rstd),
+          _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(red), float(count), _lib.ptr(red_local), _lib.ptr(dgamma),
+          _lib.ptr(dbeta), _lib.ptr(dx), dx.stride(0), rows, C)
+    return dx
+
+
+def cls_conv_fwd(x, w, bias, images, H, W):
+    _chk(x, BF16, "x"); _chk(w, F32, "w"); _chk(bias, F32, "bias")
+    C = x.shape[1]
+    assert x.is_contiguous() and w.is_contiguous() and tuple(w.shape) == (2, C, 3, 3)
+    logits = torch.empty((images, 2, H, W), dtype=F32, device=x.device)
+    _call("ccd_cls_conv_fwd", _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(logits), images, H, W, C)
+    return logits
+
+
+def cls_conv_bwd(dlogits, x, w, dw, db, images, H, W):
+    _chk(dlogits, F32, "dlogits"); _chk(x, BF16, "x")
+    assert dlogits.is_contiguous() and x.is_contiguous() and dw.is_contiguous()
+    C = x.shape[1]
+    dx = torch.empty_like(x)
+    _call("ccd_cls_conv_bwd", _lib.ptr(dlogits), _lib.ptr(x), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db),
+          images, H, W, C)
+    return dx
+
+
+def permute4(src, strides, dims, dst, accumulate=False):
+    """dst[dims] (contiguous; bf16 cast, or fp32 += when accumulate) <- src.flatten()[sum_i idx_i * strides_i]."""
+    _chk(src, F32, "src"); _chk(dst, F32 if accumulate else BF16, "dst")
+    n = list(dims) + [1] * (4 - len(dims))
+    s = list(strides) + [0] * (4 - len(strides))
+    assert dst.is_contiguous() and dst.numel() == n[0] * n[1] * n[2] * n[3]
+    _call("ccd_permute4", _lib.ptr(src), s[0], s[1], s[2], s[3], n[0], n[1], n[2], n[3], _lib.ptr(dst),
+          1 if accumulate else 0)
+    return dst

@@ -1,0 +1,210 @@
+"""Segmentation head of the student as hand-written HIP (Dino/modules/segmentor.py: MLAHead 38-70, SegHead 73-95).
+
+Activations are channels-last bf16 matrices [pixels, C] - exactly the token-major layout the backbone taps already
+have - so every convolution is a GEMM over pixels:
+
+  Conv2d 3x3 / 1x1 (bias=False)      implicit GEMM, A gathered tap by tap (ops.conv_gemm, no im2col buffer)
+  ConvTranspose2d(4, 2, 1)           four output-parity classes, each a 2x2-tap implicit GEMM whose epilogue scatters
+                                     row (n, y, x) to (n, 2y+py, 2x+px)
+  BatchNorm2d (train) + ReLU         batch statistics come out of the GEMM epilogue (column sum / sum of squares),
+                                     one elementwise pass normalises; SyncBatchNorm = all-reduce of the [2C] statistics
+  Conv2d(128, 2, 3) classifier       VALU kernel (N = 2 is no MFMA shape), fp32 NCHW logits as the loss expects
+  backward                           data gradients: implicit GEMMs with flipped / strided taps; weight gradients:
+                                     TN GEMMs against an explicit patch matrix (ops.im2col), re-laid into the parameter
+                                     layout by ops.permute4; BN backward = one reduce pass + one apply pass.
+
+Weights are read from the flat parameter arena (fp32 masters) and re-laid into bf16 GEMM operands once per step.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+TAPS3 = [(dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]            # tap = ky*3 + kx, source offset (ky-1, kx-1)
+TAPS3_FLIP = [(-dy, -dx) for dy, dx in TAPS3]                            # data gradient reads dY at p - offset
+TAPS1 = [(0, 0)]
+# ConvTranspose2d(k=4, s=2, p=1): output y = 2*iy - 1 + ky.  Parity class py of the output reads
+#   py = 0: ky = 1 (iy = q), ky = 3 (iy = q-1);   py = 1: ky = 0 (iy = q+1), ky = 2 (iy = q)
+_KY = {0: ((1, 0), (3, -1)), 1: ((0, 1), (2, 0))}                        # parity -> ((k, source offset), ...)
+TAPS_T_GRAD = [(ky - 1, kx - 1) for ky in range(4) for kx in range(4)]   # data gradient: dOut at (2iy - 1 + ky, ...)
+
+
+def _parity_taps(py, px):
+    return [(ky, kx, dy, dx) for ky, dy in _KY[py] for kx, dx in _KY[px]]
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class _BN:
+    """State of one BatchNorm2d(+ReLU) application inside a forward pass."""
+
+    def __init__(self, mod, rows, device):
+        self.mod = mod
+        self.C = mod.num_features
+        self.rows = rows
+        self.sync = isinstance(mod, nn.SyncBatchNorm) and _world() > 1
+        self.count = float(rows * (_world() if self.sync else 1))
+        self.stats = torch.zeros(2 * self.C, dtype=F32, device=device)
+        self.mean_rstd = torch.empty(2 * self.C, dtype=F32, device=device)
+
+    def finalize(self):
+        mod = self.mod
+        if not mod.training:                          # eval: running statistics (tiny host-side glue, no batch stats)
+            self.mean_rstd[: self.C] = mod.running_mean
+            self.mean_rstd[self.C:] = torch.rsqrt(mod.running_var + mod.eps)
+            return
+        if self.sync:
+            dist.all_reduce(self.stats)
+        momentum = mod.momentum if mod.momentum is not None else 1.0 / float(mod.num_batches_tracked.item() + 1)
+        ops.bn_finalize(self.stats, self.count, mod.eps, momentum, self.mean_rstd, mod.running_mean, mod.running_var)
+        mod.num_batches_tracked += 1
+
+    def forward(self, x, out):
+        return ops.bn_relu_fwd(x, self.mean_rstd, self.mod.weight, self.mod.bias, out)
+
+    def backward(self, dy, x, dx):
+        """dx (may alias dy) = gradient w.r.t. the BN input; parameter gradients accumulate into .grad (arena)."""
+        mod = self.mod
+        red = torch.zeros(2 * self.C, dtype=F32, device=x.device)
+        ops.bn_relu_bwd_reduce(dy, x, self.mean_rstd, mod.weight, mod.bias, red)
+        red_local = red
+        if self.sync:
+            red_local = red.clone()
+            dist.all_reduce(red)
+        if not mod.training:                          # eval-mode BN is an affine map: no batch terms
+            red = torch.zeros_like(red)
+        return ops.bn_relu_bwd_apply(dy, x, self.mean_rstd, mod.weight, mod.bias, red, self.count, red_local,
+                                     mod.weight.grad, mod.bias.grad, dx)
+
+
+def _ensure_grads(module):
+    for p in module.parameters():
+        if p.requires_grad and p.grad is None:
+            p.grad = torch.zeros_like(p)
+
+
+class SegHeadFn(torch.autograd.Function):
+    """(tap2, tap3, tap4: bf16 [N*256, E]) -> fp32 logits [N, 2, 32, 128]; parameter gradients go straight to .grad."""
+
+    @staticmethod
+    def forward(ctx, head, images, t2, t3, t4):
+        dev = t2.device
+        taps = [t.contiguous() for t in (t2, t3, t4)]
+        E = taps[0].shape[1]
+        gh, gw = 8, 32
+        M = images * gh * gw
+        assert taps[0].shape[0] == M
+        mla = head.mlahead
+        heads = [mla.head2, mla.head3, mla.head4]
+        mid, out_c = heads[0][0].out_channels, heads[0][3].out_channels
+        d3 = ops.conv_desc((gh, gw), (gh, gw), E, TAPS3)
+        d1 = ops.conv_desc((gh, gw), (gh, gw), mid, TAPS1)
+        cat = torch.empty((M, 3 * out_c), dtype=BF16, device=dev)
+        saved = {"taps": taps, "y1": [], "a1": [], "y2": [], "bn1": [], "bn2": [], "w2": []}
+        for i, seq in enumerate(heads):
+            w1 = ops.permute4(seq[0].weight.detach(), (E * 9, 1, 9), (mid, 9, E),
+                              torch.empty((mid, 9 * E), dtype=BF16, device=dev))
+            bn1 = _BN(seq[1], M, dev)
+            y1 = torch.empty((M, mid), dtype=BF16, device=dev)
+            ops.conv_gemm(taps[i], d3, w1, M, y1, colsum=bn1.stats[:mid], colsumsq=bn1.stats[mid:])
+            bn1.finalize()
+            a1 = bn1.forward(y1, torch.empty_like(y1))
+            w2 = torch.empty((out_c, mid), dtype=BF16, device=dev)
+            ops.permute4(seq[3].weight.detach(), (mid, 1), (out_c, mid), w2)
+            bn2 = _BN(seq[4], M, dev)
+            y2 = torch.empty((M, out_c), dtype=BF16, device=dev)
+            ops.conv_gemm(a1, d1, w2, M, y2, colsum=bn2.stats[:out_c], colsumsq=bn2.stats[out_c:])
+            bn2.finalize()
+            bn2.forward(y2, cat[:, i * out_c:(i + 1) * out_c])
+            for k, v in (("y1", y1), ("a1", a1), ("y2", y2), ("bn1", bn1), ("bn2", bn2), ("w2", w2)):
+                saved[k].append(v)
+        x, grid = cat, (gh, gw)
+        ups = []
+        for seq in (head.unpool1, head.unpool2):
+            convt, bnm = seq[0], seq[1]
+            cin, cout = convt.in_channels, convt.out_channels
+            rows = images * grid[0] * grid[1]
+            y = torch.empty((4 * rows, cout), dtype=BF16, device=dev)
+            bn = _BN(bnm, 4 * rows, dev)
+            wsrc = convt.weight.detach()                                   # [cin, cout, 4, 4]
+            for py in (0, 1):
+                for px in (0, 1):
+                    pt = _parity_taps(py, px)
+                    desc = ops.conv_desc(grid, grid, cin, [(dy, dx) for _, _, dy, dx in pt], parity=(py, px))
+                    wp = torch.empty((cout, 4 * cin), dtype=BF16, device=dev)
+                    ky0, kx0 = pt[0][0], pt[0][1]                          # taps advance by +2 in ky (outer) / kx (inner)
+                    ops.permute4(wsrc.reshape(-1)[ky0 * 4 + kx0:], (16, 8, 2, cout * 16), (cout, 2, 2, cin), wp)
+                    ops.conv_gemm(x, desc, wp, rows, y, bias=convt.bias, colsum=bn.stats[:cout],
+                                  colsumsq=bn.stats[cout:])
+            bn.finalize()
+            a = bn.forward(y, torch.empty_like(y))
+            ups.append((x, y, bn, grid))
+            x, grid = a, (2 * grid[0], 2 * grid[1])
+        logits = ops.cls_conv_fwd(x, head.cls.weight.detach(), head.cls.bias.detach(), images, grid[0], grid[1])
+        ctx.head, ctx.images, ctx.saved, ctx.ups, ctx.a_last, ctx.grid = head, images, saved, ups, x, grid
+        ctx.dims = (E, mid, out_c, M)
+        return logits
+
+    @staticmethod
+    def backward(ctx, d_logits):
+        head, images, saved = ctx.head, ctx.images, ctx.saved
+        E, mid, out_c, M = ctx.dims
+        dev = d_logits.device
+        _ensure_grads(head.mlahead)
+        for m in (head.unpool1, head.unpool2, head.cls):
+            _ensure_grads(m)
+        H, W = ctx.grid
+        d = ops.cls_conv_bwd(d_logits.contiguous().float(), ctx.a_last, head.cls.weight.detach(), head.cls.weight.grad,
+                             head.cls.bias.grad, images, H, W)
+        ctx.a_last = None
+        # ---- transposed convs, last first
+        for seq, (x_in, y, bn, grid) in zip((head.unpool2, head.unpool1), reversed(ctx.ups)):
+            convt = seq[0]
+            cin, cout = convt.in_channels, convt.out_channels
+            rows = images * grid[0] * grid[1]
+            dyc = bn.backward(d, y, d)                                              # in place: d(convT output)
+            ops.colsum_bf16(dyc, convt.bias.grad)
+            desc = ops.conv_desc(grid, (2 * grid[0], 2 * grid[1]), cout, TAPS_T_GRAD, s_mul=2)
+            cols = ops.im2col(dyc, desc, rows)                                      # [rows, 16*cout]
+            stage = torch.zeros((cin, 16 * cout), dtype=F32, device=dev)
+            ops.gemm_tn(x_in, cols, stage)                                          # [ci][tap][co]
+            del cols
+            ops.permute4(stage, (16 * cout, 1, cout), (cin, cout, 16), convt.weight.grad, accumulate=True)
+            wt = torch.empty((cin, 16 * cout), dtype=BF16, device=dev)              # [ci][tap][co] <- W[ci][co][tap]
+            ops.permute4(convt.weight.detach(), (cout * 16, 1, 16), (cin, 16, cout), wt)
+            d = ops.conv_gemm(dyc, desc, wt, rows, torch.empty((rows, cin), dtype=BF16, device=dev))
+        # ---- the three 3x3 -> 1x1 branches; d = gradient of the concatenated [M, 3*out_c] map
+        gh, gw = 8, 32
+        d3 = ops.conv_desc((gh, gw), (gh, gw), E, TAPS3)
+        d3f = ops.conv_desc((gh, gw), (gh, gw), mid, TAPS3_FLIP)
+        heads = [head.mlahead.head2, head.mlahead.head3, head.mlahead.head4]
+        d_taps = []
+        for i, seq in enumerate(heads):
+            y1, a1, y2, bn1, bn2, w2 = (saved[k][i] for k in ("y1", "a1", "y2", "bn1", "bn2", "w2"))
+            dy2 = bn2.backward(d[:, i * out_c:(i + 1) * out_c], y2, torch.empty_like(y2))
+            ops.gemm_tn(dy2, a1, seq[3].weight.grad.view(out_c, mid))              # dW2[co][ci]
+            w2t = torch.empty((mid, out_c), dtype=BF16, device=dev)
+            ops.permute4(seq[3].weight.detach(), (1, mid), (mid, out_c), w2t)
+            da1 = ops.gemm_nt(dy2, w2t)                                             # [M, mid]
+            dy1 = bn1.backward(da1, y1, da1)
+            cols = ops.im2col(saved["taps"][i], d3, M)                              # [M, 9E]
+            stage = torch.zeros((mid, 9 * E), dtype=F32, device=dev)
+            ops.gemm_tn(dy1, cols, stage)                                           # [co][tap][ci]
+            del cols
+            ops.permute4(stage, (9 * E, 1, E), (mid, E, 9), seq[0].weight.grad, accumulate=True)
+            w1d = torch.empty((E, 9 * mid), dtype=BF16, device=dev)                 # [ci][tap][co] <- W[co][ci][tap]
+            ops.permute4(seq[0].weight.detach(), (9, 1, E * 9), (E, 9, mid), w1d)
+            d_taps.append(ops.conv_gemm(dy1, d3f, w1d, M, torch.empty((M, E), dtype=BF16, device=dev)))
+        ctx.saved = ctx.ups = None
+        return (None, None, *d_taps)
+
+
+def seg_head_forward(head, taps, images):
+    """taps: three bf16 [images*256, E] token-major feature maps -> fp32 logits [images, 2, 32, 128]."""
+    return SegHeadFn.apply(head, images, *taps)

@@ -160,6 +160,49 @@ int ccd_clip_scale(float* grad, const int* chunk_seg, const long* chunk_begin, c
                    const float* norm2, float clip, void* stream);
 int ccd_ema(float* teacher, const float* student, ccd_bf16* mirror, long n, float m, float one_minus_m, void* stream);
 
+/* ---- segmentation head (Dino/modules/segmentor.py:38-95): channels-last bf16 activations [pixels, C] ----------- */
+/* Gather description of an implicit-GEMM convolution: output row r = (n, oy, ox) on a 2^g_h_log2 x 2^g_w_log2 grid;
+ * contraction index k = tap*cin + c reads source pixel (oy*s_mul + dy[tap], ox*s_mul + dx[tap]) of an s_h x s_w image
+ * (zero outside).  Covers Conv2d 3x3/1x1 forward (segmentor.py:42-45), its data gradient (flipped taps), one output
+ * parity class of ConvTranspose2d(4,2,1) (segmentor.py:82,85; c_map scatters row (n,oy,ox) to (n,2oy+c_py,2ox+c_px))
+ * and that layer's data gradient (s_mul = 2, 16 taps). */
+typedef struct ccd_conv_desc {
+    int g_h_log2, g_w_log2, s_h, s_w, s_mul, cin, ntaps;
+    signed char dy[16], dx[16];
+    int c_map, c_py, c_px;
+} ccd_conv_desc;
+/* C[rows(->c_map), N] (bf16) = gather(src)[M, ntaps*cin] . W[N, ntaps*cin]^T + bias; optional fp32 column sums /
+ * sums of squares of the output (+=) = the BatchNorm batch statistics (replaces F.conv2d / F.conv_transpose2d +
+ * the statistics pass of F.batch_norm). */
+int ccd_conv_gemm(const ccd_bf16* src, long src_ld, const ccd_conv_desc* desc, const ccd_bf16* W, long ldw, int M, int N,
+                  ccd_bf16* C, long ldc, const float* bias, float* colsum, float* colsumsq, void* stream);
+/* cols[rows, ntaps*cin] = gather(src): explicit patch matrix for the weight gradients (TN GEMM operand). */
+int ccd_im2col(const ccd_bf16* src, long src_ld, const ccd_conv_desc* desc, long rows, ccd_bf16* cols, void* stream);
+/* Train-mode BatchNorm2d + ReLU (segmentor.py:43-44,83-84).  stats = [sum x | sum x^2] over `count` pixels (reduced
+ * over ranks by the caller for SyncBatchNorm); finalize writes mean_rstd = [mean | 1/sqrt(var+eps)] and updates the
+ * running statistics with torch's rule (unbiased variance). */
+int ccd_bn_finalize(const float* stats, float count, float eps, float momentum, float* mean_rstd, float* running_mean,
+                    float* running_var, int C, void* stream);
+int ccd_bn_relu_fwd(const ccd_bf16* x, long ldx, const float* mean_rstd, const float* gamma, const float* beta,
+                    ccd_bf16* y, long ldy, long rows, int C, void* stream);
+/* red[0:C] += sum dy*[y>0], red[C:2C] += sum dy*[y>0]*xhat */
+int ccd_bn_relu_bwd_reduce(const ccd_bf16* dy, long lddy, const ccd_bf16* x, long ldx, const float* mean_rstd,
+                           const float* gamma, const float* beta, float* red, long rows, int C, void* stream);
+/* dx = gamma*rstd*(dy*[y>0] - red0/count - xhat*red1/count); dgamma += red_local[C:2C], dbeta += red_local[0:C] */
+int ccd_bn_relu_bwd_apply(const ccd_bf16* dy, long lddy, const ccd_bf16* x, long ldx, const float* mean_rstd,
+                          const float* gamma, const float* beta, const float* red, float count, const float* red_local,
+                          float* dgamma, float* dbeta, ccd_bf16* dx, long lddx, long rows, int C, void* stream);
+/* Classifier Conv2d(C, 2, 3, padding=1) (segmentor.py:86): x [images*H*W, C] bf16 -> fp32 logits [images, 2, H, W];
+ * backward writes dx (bf16) and accumulates dw [2, C, 3, 3] / db [2] (fp32, +=). */
+int ccd_cls_conv_fwd(const ccd_bf16* x, const float* w, const float* bias, float* logits, int images, int H, int W, int C,
+                     void* stream);
+int ccd_cls_conv_bwd(const float* dlogits, const ccd_bf16* x, const float* w, ccd_bf16* dx, float* dw, float* db,
+                     int images, int H, int W, int C, void* stream);
+/* dst[n0][n1][n2][n3] (contiguous) <- src[i0*s0 + i1*s1 + i2*s2 + i3*s3]; accumulate = 0: dst is bf16 (cast),
+ * accumulate = 1: dst is fp32 and += (conv weights <-> GEMM operand layouts). */
+int ccd_permute4(const float* src, long s0, long s1, long s2, long s3, int n0, int n1, int n2, int n3, void* dst,
+                 int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -396,3 +396,163 @@ def check_optimizer(dev, seed=13):
     ops.ema(Td, student.to(dev), tm, 0.9995)
     close(Td, teacher * 0.9995 + (1 - 0.9995) * student, 1e-6, 1e-7, "opt/ema")
     close(tm, Td.to(BF), 0, 0, "opt/ema-mirror")
+
+
+def _cos(a, b):
+    a, b = a.detach().double().flatten().cpu(), b.detach().double().flatten().cpu()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def check_conv_pieces(dev, seed=20):
+    """Implicit-GEMM conv / transposed-conv parity classes / im2col / BN+ReLU / classifier conv vs torch.nn.functional."""
+    from ccd_amd import seghead as sh
+    g = torch.Generator().manual_seed(seed)
+    n, gh, gw, cin, cout = 2, 4, 8, 64, 16
+    x = rnd((n, cin, gh, gw), g).to(BF)
+    w = rnd((cout, cin, 3, 3), g, 0.1)
+    rows = n * gh * gw
+    xr = x.permute(0, 2, 3, 1).reshape(rows, cin).contiguous().to(dev)
+    wq = w.to(BF).float()
+    # --- 3x3 forward with statistics
+    wb = ops.permute4(w.to(dev), (cin * 9, 1, 9), (cout, 9, cin), torch.empty((cout, 9 * cin), dtype=BF, device=dev))
+    d3 = ops.conv_desc((gh, gw), (gh, gw), cin, sh.TAPS3)
+    stats = torch.zeros(2 * cout, device=dev)
+    y = ops.conv_gemm(xr, d3, wb, rows, torch.empty((rows, cout), dtype=BF, device=dev), colsum=stats[:cout],
+                      colsumsq=stats[cout:])
+    ref = F.conv2d(x.float(), wq, padding=1).permute(0, 2, 3, 1).reshape(rows, cout)
+    close(y, ref, 1e-2, 2e-2, "conv3x3")
+    close(stats[:cout], ref.sum(0), 1e-3, 0.1, "conv3x3/colsum")
+    close(stats[cout:], (ref * ref).sum(0), 1e-2, 0.1, "conv3x3/colsumsq")
+    # --- im2col
+    cols = ops.im2col(xr, d3, rows)
+    ref_cols = F.unfold(x.float(), 3, padding=1).view(n, cin, 9, gh * gw).permute(0, 3, 2, 1).reshape(rows, 9 * cin)
+    assert torch.equal(cols.float().cpu(), ref_cols), "im2col"
+    # --- 3x3 data gradient: dX = conv_transpose(dY, W)
+    dy = rnd((n, cout * 4, gh, gw), g).to(BF)                    # 64 channels (cin of the gradient gather)
+    w2 = rnd((cout * 4, cin, 3, 3), g, 0.1)
+    dyr = dy.permute(0, 2, 3, 1).reshape(rows, cout * 4).contiguous().to(dev)
+    wd = ops.permute4(w2.to(dev), (9, 1, cin * 9), (cin, 9, cout * 4),
+                      torch.empty((cin, 9 * cout * 4), dtype=BF, device=dev))
+    d3f = ops.conv_desc((gh, gw), (gh, gw), cout * 4, sh.TAPS3_FLIP)
+    dx = ops.conv_gemm(dyr, d3f, wd, rows, torch.empty((rows, cin), dtype=BF, device=dev))
+    ref = F.conv_transpose2d(dy.float(), w2.to(BF).float(), padding=1).permute(0, 2, 3, 1).reshape(rows, cin)
+    close(dx, ref, 1e-2, 3e-2, "conv3x3/dgrad")
+    # --- transposed conv 4x4 stride 2: four parity classes + bias
+    wt = rnd((cin, cout, 4, 4), g, 0.1)
+    bias = rnd((cout,), g)
+    up = torch.zeros((4 * rows, cout), dtype=BF, device=dev)
+    for py in (0, 1):
+        for px in (0, 1):
+            pt = sh._parity_taps(py, px)
+            desc = ops.conv_desc((gh, gw), (gh, gw), cin, [(a, b) for _, _, a, b in pt], parity=(py, px))
+            wp = torch.empty((cout, 4 * cin), dtype=BF, device=dev)
+            ops.permute4(wt.to(dev).reshape(-1)[pt[0][0] * 4 + pt[0][1]:], (16, 8, 2, cout * 16), (cout, 2, 2, cin), wp)
+            ops.conv_gemm(xr, desc, wp, rows, up, bias=bias.to(dev))
+    ref = F.conv_transpose2d(x.float(), wt.to(BF).float(), bias, stride=2, padding=1)
+    close(up, ref.permute(0, 2, 3, 1).reshape(4 * rows, cout), 1e-2, 3e-2, "convT")
+    # --- transposed conv data gradient: dIn = conv2d(dOut, W^T-ish, stride 2)
+    dout = rnd((n, 64, 2 * gh, 2 * gw), g).to(BF)
+    wt2 = rnd((cin, 64, 4, 4), g, 0.1)
+    dor = dout.permute(0, 2, 3, 1).reshape(4 * rows, 64).contiguous().to(dev)
+    descg = ops.conv_desc((gh, gw), (2 * gh, 2 * gw), 64, sh.TAPS_T_GRAD, s_mul=2)
+    wg = ops.permute4(wt2.to(dev), (64 * 16, 1, 16), (cin, 16, 64), torch.empty((cin, 16 * 64), dtype=BF, device=dev))
+    din = ops.conv_gemm(dor, descg, wg, rows, torch.empty((rows, cin), dtype=BF, device=dev))
+    ref = F.conv2d(dout.float(), wt2.to(BF).float(), stride=2, padding=1).permute(0, 2, 3, 1).reshape(rows, cin)
+    close(din, ref, 1e-2, 5e-2, "convT/dgrad")
+    # --- BatchNorm + ReLU forward / backward
+    C = 16
+    xb = (rnd((rows, C), g) * 2 + 0.5).to(BF)
+    gamma, beta = rnd((C,), g).abs() + 0.5, rnd((C,), g) * 0.3
+    rm, rv = torch.zeros(C).to(dev), torch.ones(C).to(dev)
+    st = torch.cat([xb.float().sum(0), (xb.float() ** 2).sum(0)]).to(dev)
+    mr = torch.empty(2 * C, device=dev)
+    ops.bn_finalize(st, rows, 1e-5, 0.1, mr, rm, rv)
+    xt = xb.float().clone().requires_grad_(True)
+    gt, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = torch.zeros(C), torch.ones(C)
+    yt = F.relu(F.batch_norm(xt, rm_ref, rv_ref, gt, bt, True, 0.1, 1e-5))
+    close(rm, rm_ref, 1e-4, 1e-5, "bn/running_mean"); close(rv, rv_ref, 1e-4, 1e-5, "bn/running_var")
+    yb = ops.bn_relu_fwd(xb.to(dev), mr, gamma.to(dev), beta.to(dev), torch.empty((rows, C), dtype=BF, device=dev))
+    close(yb, yt, 1e-2, 1e-2, "bn/fwd")
+    dyb = rnd((rows, C), g).to(BF)
+    yt.backward(dyb.float())
+    red = torch.zeros(2 * C, device=dev)
+    ops.bn_relu_bwd_reduce(dyb.to(dev), xb.to(dev), mr, gamma.to(dev), beta.to(dev), red)
+    dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dxb = ops.bn_relu_bwd_apply(dyb.to(dev), xb.to(dev), mr, gamma.to(dev), beta.to(dev), red, rows, red, dgam, dbet,
+                                torch.empty((rows, C), dtype=BF, device=dev))
+    close(dxb, xt.grad, 1e-2, 1e-2, "bn/dx"); close(dgam, gt.grad, 1e-3, 1e-3, "bn/dgamma")
+    close(dbet, bt.grad, 1e-3, 1e-3, "bn/dbeta")
+    # --- classifier conv
+    Cc, H, W = 16, 8, 16
+    xc = rnd((n, Cc, H, W), g).to(BF)
+    wc, bc = rnd((2, Cc, 3, 3), g, 0.2), rnd((2,), g)
+    xcr = xc.permute(0, 2, 3, 1).reshape(n * H * W, Cc).contiguous().to(dev)
+    lg = ops.cls_conv_fwd(xcr, wc.to(dev), bc.to(dev), n, H, W)
+    xct = xc.float().requires_grad_(True)
+    wct, bct = wc.clone().requires_grad_(True), bc.clone().requires_grad_(True)
+    ref = F.conv2d(xct, wct, bct, padding=1)
+    close(lg, ref, 1e-4, 1e-4, "cls/fwd")
+    dl = rnd((n, 2, H, W), g)
+    ref.backward(dl)
+    dw, db = torch.zeros_like(wc).to(dev), torch.zeros(2).to(dev)
+    dxc = ops.cls_conv_bwd(dl.to(dev), xcr, wc.to(dev), dw, db, n, H, W)
+    close(dxc, xct.grad.permute(0, 2, 3, 1).reshape(n * H * W, Cc), 1e-2, 1e-2, "cls/dx")
+    close(dw, wct.grad, 1e-3, 1e-3, "cls/dw"); close(db, bct.grad, 1e-3, 1e-3, "cls/db")
+
+
+def check_seghead(dev, images=1, E=64, seed=21, build_ref=None):
+    """SegHeadFn (HIP) vs the reference-shaped nn.Module stack in fp32 (torch library convs) on the same weights."""
+    import copy
+    from ccd_amd import seghead as sh
+    from ccd_amd.modules.segmentor import SegHead
+    torch.manual_seed(seed)
+    head = SegHead(in_channels=E)
+    with torch.no_grad():                       # non-trivial BN affine parameters
+        for m in head.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+    ref = copy.deepcopy(head).float()
+    head = head.to(dev)
+    g = torch.Generator().manual_seed(seed)
+    taps = [rnd((images * 256, E), g).to(BF) for _ in range(3)]
+    tin = [t.to(dev).requires_grad_(True) for t in taps]
+    logits = sh.seg_head_forward(head, tin, images)
+    rin = [t.float().view(images, 8, 32, E).permute(0, 3, 1, 2).contiguous().detach().requires_grad_(True) for t in taps]
+    x = ref.mlahead(*rin)
+    want = ref.cls(ref.unpool2(ref.unpool1(x)))
+    close(logits, want, 3e-2, 3e-2, "seghead/logits")
+    dl = rnd(tuple(want.shape), g) / want[0].numel()
+    want.backward(dl)
+    logits.backward(dl.to(dev))
+    for i in range(3):
+        wg = rin[i].grad.permute(0, 2, 3, 1).reshape(images * 256, E)
+        c = _cos(tin[i].grad, wg)
+        print(f"d_tap{i}: cos {c:.5f}")
+        assert c > 0.99, f"seghead/d_tap{i}: cos {c}"
+        ratio = float(tin[i].grad.float().norm() / wg.norm())
+        assert 0.97 < ratio < 1.03, f"seghead/d_tap{i}: norm ratio {ratio}"
+    refp = dict(ref.named_parameters())
+    worst = (1.0, None)
+    for name, p in head.named_parameters():
+        if name.startswith("conv_mla"):
+            continue
+        gr = refp[name].grad
+        # ConvTranspose / 1x1-conv biases feeding a BatchNorm have an exactly-zero true gradient: compare absolutely
+        if name in ("unpool1.0.bias", "unpool2.0.bias"):
+            scale = float(refp[name.replace("0.bias", "0.weight")].grad.abs().max())
+            assert float(p.grad.abs().max()) < 0.05 * scale + 1e-6, f"{name}: {p.grad.abs().max()} vs scale {scale}"
+            continue
+        c = _cos(p.grad, gr)
+        print(f"{name}: cos {c:.5f} ratio {float(p.grad.float().norm() / gr.norm()):.4f}")
+        if c < worst[0]:
+            worst = (c, name)
+        assert c > 0.99, f"seghead/{name}: cos {c}"
+        ratio = float(p.grad.float().norm() / gr.norm())
+        assert 0.95 < ratio < 1.05, f"seghead/{name}: norm ratio {ratio}"
+    refb = dict(ref.named_buffers())
+    for name, b in head.named_buffers():
+        if name.startswith("conv_mla") or "num_batches" in name:
+            continue
+        close(b, refb[name], 2e-2, 2e-3, f"seghead/{name}")
+    return worst

@@ -91,3 +91,12 @@ def test_seg_loss(hip):
 
 def test_optimizer(hip):
     kc.check_optimizer(hip.device)
+
+
+def test_conv_pieces(hip):
+    kc.check_conv_pieces(hip.device)
+
+
+@pytest.mark.parametrize("images,E", [(2, 192), (8, 384)])
+def test_seghead(hip, images, E):
+    kc.check_seghead(hip.device, images=images, E=E)

@@ -86,3 +86,11 @@ def test_gemm_ares_sim(sim):
     """M >= 1024 and K <= 384 routes ccd_gemm_nt to the A-resident persistent kernel (gemm_ares.h)."""
     kc.check_gemm_nt(sim.device, M=1100, N=264, K=128)     # ragged M and N, 2 panels per workgroup
     kc.check_gemm_nt(sim.device, M=1030, N=136, K=384)
+
+
+def test_conv_pieces_sim(sim):
+    kc.check_conv_pieces(sim.device)
+
+
+def test_seghead_sim(sim):
+    kc.check_seghead(sim.device, images=1, E=64)
