@@ -67,9 +67,9 @@ SIGNATURES = {
     "ccd_bn_relu_fwd": [P, L, P, P, P, P, L, L, I, P],
     "ccd_bn_relu_bwd_reduce": [P, L, P, L, P, P, P, P, L, I, P],
     "ccd_bn_relu_bwd_apply": [P, L, P, L, P, P, P, P, F, P, P, P, P, L, L, I, P],
-    "ccd_cls_conv_fwd": [P, P, P, P, I, I, I, I, P],
-    "ccd_cls_conv_bwd": [P, P, P, P, P, P, I, I, I, I, P],
-    "ccd_permute4": [P, L, L, L, L, I, I, I, I, P, I, P],
+    "ccd_cls_gather_fwd": [P, L, P, P, I, I, I, P],
+    "ccd_cls_grad_cols": [P, P, I, I, I, P],
+    "ccd_permute4": [P, P, P, P, P, I, P],
 }
 _RESTYPES = {"ccd_build_info": C.c_char_p}
 

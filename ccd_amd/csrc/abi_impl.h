@@ -70,6 +70,23 @@ static int ccd_launch_gemm_nt32(const ccd::GemmParams& p, int epilogue, void* st
     }
     return ccd_rt_last_error();
 }
+// launch geometry of the column reductions (colsum_bf16, bn_relu_bwd_reduce): cgn = 2^cgn_log2 column groups of 8
+// per block (<= 32), every block streams >= 256 KiB, at most 2 blocks per CU
+static void ccd_reduce_geometry(long rows, int N, int* cgn_log2, int* col_blocks, int* rows_per_block, int* row_blocks) {
+    int lg = 0;
+    while (lg < 5 && (8 << lg) < N) ++lg;
+    const int cgn = 1 << lg, rln = 256 >> lg;
+    *cgn_log2 = lg;
+    *col_blocks = (N + 8 * cgn - 1) / (8 * cgn);
+    long rb = (rows * (long)(16 * cgn) + (256L << 10) - 1) / (256L << 10);       // bytes per block-column / 256 KiB
+    const long cap = (2L * ccd_rt_num_cus() + *col_blocks - 1) / *col_blocks;
+    if (rb > cap) rb = cap;
+    if (rb < 1) rb = 1;
+    long rpb = (rows + rb - 1) / rb;
+    rpb = ((rpb + rln - 1) / rln) * rln;
+    *rows_per_block = (int)rpb;
+    *row_blocks = (int)((rows + rpb - 1) / rpb);
+}
 static bool ccd_env_flag(const char* name, bool dflt) {
     const char* v = getenv(name);
     return v ? (v[0] != '0') : dflt;
@@ -225,13 +242,10 @@ int ccd_colsum_bf16(const ccd_bf16* x, long ld, int rows, int N, const int* d_ro
     CCD_CHECK(x && out, CCD_EINVAL);
     if (rows == 0 || N == 0) return CCD_OK;
     CCD_CHECK(rows > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0 && CCD_ALIGNED16(x), CCD_ESHAPE);
-    const int col_blocks = (N + 255) / 256;
-    int row_blocks = (4 * ccd_rt_num_cus() + col_blocks - 1) / col_blocks;
-    int rpb = (rows + row_blocks - 1) / row_blocks;
-    rpb = ((rpb + 7) / 8) * 8;
-    row_blocks = (rows + rpb - 1) / rpb;
+    int cgn_log2, col_blocks, rpb, row_blocks;
+    ccd_reduce_geometry(rows, N, &cgn_log2, &col_blocks, &rpb, &row_blocks);
     CCD_LAUNCH(ccd::colsum_bf16_kernel, dim3(col_blocks, row_blocks), dim3(256), 0, stream, x, ld, rows, N, d_rows,
-               rows_mul, out, rpb);
+               rows_mul, out, rpb, cgn_log2);
     return ccd_rt_last_error();
 }
 int ccd_mirror_bf16(const ccd_mirror_desc* d_descs, int ndesc, int total_tiles, void* stream) {
@@ -515,13 +529,10 @@ int ccd_bn_relu_bwd_reduce(const ccd_bf16* dy, long lddy, const ccd_bf16* x, lon
     CCD_CHECK(dy && x && mean_rstd && gamma && beta && red && CCD_ALIGNED16(dy) && CCD_ALIGNED16(x), CCD_EINVAL);
     if (rows == 0) return CCD_OK;
     CCD_CHECK(rows > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0, CCD_ESHAPE);
-    const int cblocks = (C + 255) / 256;
-    long yblocks = (8L * ccd_rt_num_cus()) / cblocks;
-    long rpb = (rows + yblocks - 1) / yblocks;
-    rpb = ((rpb + 7) / 8) * 8;
-    yblocks = (rows + rpb - 1) / rpb;
-    CCD_LAUNCH(ccd::bn_relu_bwd_reduce_kernel, dim3(cblocks, (unsigned)yblocks), dim3(256), 0, stream, dy, lddy, x, ldx,
-               mean_rstd, gamma, beta, red, rows, C, (int)rpb);
+    int cgn_log2, col_blocks, rpb, row_blocks;
+    ccd_reduce_geometry(rows, C, &cgn_log2, &col_blocks, &rpb, &row_blocks);
+    CCD_LAUNCH(ccd::bn_relu_bwd_reduce_kernel, dim3(col_blocks, row_blocks), dim3(256), 0, stream, dy, lddy, x, ldx,
+               mean_rstd, gamma, beta, red, rows, C, rpb, cgn_log2);
     return ccd_rt_last_error();
 }
 
@@ -538,42 +549,40 @@ int ccd_bn_relu_bwd_apply(const ccd_bf16* dy, long lddy, const ccd_bf16* x, long
     return ccd_rt_last_error();
 }
 
-int ccd_cls_conv_fwd(const ccd_bf16* x, const float* w, const float* bias, float* logits, int images, int H, int W, int C,
-                     void* stream) {
-    CCD_CHECK(x && w && bias && logits && CCD_ALIGNED16(x), CCD_EINVAL);
+int ccd_cls_gather_fwd(const float* zT, long ldz, const float* bias, float* logits, int images, int H, int W,
+                       void* stream) {
+    CCD_CHECK(zT && bias && logits, CCD_EINVAL);
     if (images == 0) return CCD_OK;
-    CCD_CHECK(images > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= ccd::CLS_MAX_C, CCD_ESHAPE);
+    CCD_CHECK(images > 0 && H > 0 && W > 0 && ldz >= (long)images * H * W, CCD_ESHAPE);
     const long total = (long)images * H * W;
-    CCD_LAUNCH(ccd::cls_conv_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, w, bias, logits,
-               images, H, W, C);
+    CCD_LAUNCH(ccd::cls_gather_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, zT, ldz, bias,
+               logits, images, H, W);
     return ccd_rt_last_error();
 }
 
-int ccd_cls_conv_bwd(const float* dlogits, const ccd_bf16* x, const float* w, ccd_bf16* dx, float* dw, float* db,
-                     int images, int H, int W, int C, void* stream) {
-    CCD_CHECK(dlogits && x && w && dx && dw && db && CCD_ALIGNED16(x) && CCD_ALIGNED16(dx), CCD_EINVAL);
+int ccd_cls_grad_cols(const float* dlogits, ccd_bf16* g, int images, int H, int W, void* stream) {
+    CCD_CHECK(dlogits && g && CCD_ALIGNED16(g), CCD_EINVAL);
     if (images == 0) return CCD_OK;
-    CCD_CHECK(images > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= ccd::CLS_MAX_C && 2 * C <= 1024, CCD_ESHAPE);
-    const long pixels = (long)images * H * W, total = pixels * (C / 8);
-    CCD_LAUNCH(ccd::cls_conv_bwd_data_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dlogits, w, dx,
-               images, H, W, C);
-    long blocks = 16L * ccd_rt_num_cus();
-    long ppb = (pixels + blocks - 1) / blocks;
-    blocks = (pixels + ppb - 1) / ppb;
-    CCD_LAUNCH(ccd::cls_conv_bwd_weight_kernel, dim3((unsigned)blocks), dim3(2 * C), 0, stream, dlogits, x, dw, db, images,
-               H, W, C, (int)ppb);
+    CCD_CHECK(images > 0 && H > 0 && W > 0, CCD_ESHAPE);
+    const long total = (long)images * H * W * 8;
+    CCD_LAUNCH(ccd::cls_grad_cols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dlogits, g, images,
+               H, W);
     return ccd_rt_last_error();
 }
 
-int ccd_permute4(const float* src, long s0, long s1, long s2, long s3, int n0, int n1, int n2, int n3, void* dst,
+int ccd_permute4(const float* src, const long* src_strides, const long* dst_strides, const int* dims, void* dst,
                  int accumulate, void* stream) {
-    CCD_CHECK(src && dst && n0 > 0 && n1 > 0 && n2 > 0 && n3 > 0, CCD_EINVAL);
-    const long total = (long)n0 * n1 * n2 * n3;
+    CCD_CHECK(src && dst && src_strides && dst_strides && dims, CCD_EINVAL);
+    ccd::Permute4 q;
+    long total = 1;
+    for (int i = 0; i < 4; ++i) {
+        CCD_CHECK(dims[i] > 0, CCD_EINVAL);
+        q.s[i] = src_strides[i]; q.d[i] = dst_strides[i]; q.n[i] = dims[i];
+        total *= dims[i];
+    }
     const dim3 grid((unsigned)((total + 255) / 256));
-    if (accumulate)
-        CCD_LAUNCH((ccd::permute4_kernel<true>), grid, dim3(256), 0, stream, src, s0, s1, s2, s3, n1, n2, n3, total, dst);
-    else
-        CCD_LAUNCH((ccd::permute4_kernel<false>), grid, dim3(256), 0, stream, src, s0, s1, s2, s3, n1, n2, n3, total, dst);
+    if (accumulate) CCD_LAUNCH((ccd::permute4_kernel<true>), grid, dim3(256), 0, stream, src, q, total, dst);
+    else CCD_LAUNCH((ccd::permute4_kernel<false>), grid, dim3(256), 0, stream, src, q, total, dst);
     return ccd_rt_last_error();
 }
 

@@ -6,8 +6,8 @@
 //                              train-mode BatchNorm2d (+ReLU) with batch statistics taken from the GEMM epilogue
 //                              (column sum / sum of squares); the cross-rank reduction of SyncBatchNorm happens on the
 //                              host between *_reduce/finalize and *_apply (two small all-reduces per layer)
-//   cls_conv_fwd / cls_conv_bwd_data / cls_conv_bwd_weight
-//                              the final 3x3 conv 128 -> 2 classes (N = 2 is no MFMA shape): VALU kernels,
+//   cls_gather_fwd / cls_grad_cols
+//                              the final 3x3 conv 128 -> 2 classes factored through pixel-wise GEMMs (see below),
 //                              fp32 logits in the reference's NCHW layout
 #pragma once
 
@@ -69,16 +69,17 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const bf16_t* __restri
     *reinterpret_cast<u32x4*>(y + r * ldy + c) = pack8(v);
 }
 
-// red[0:C] += sum dy*[y>0], red[C:2C] += sum dy*[y>0]*xhat     (dy [rows, lddy] bf16)
+// red[0:C] += sum dy*[y>0], red[C:2C] += sum dy*[y>0]*xhat     (dy [rows, lddy] bf16); geometry as colsum_bf16
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const bf16_t* __restrict__ dy, long lddy,
                                                                  const bf16_t* __restrict__ x, long ldx,
                                                                  const float* __restrict__ mean_rstd,
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, float* __restrict__ red,
-                                                                 long rows, int C, int rows_per_block) {
-    __shared__ float part[2][8][32][8];
-    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = (blockIdx.x * 32 + cg) * 8;
+                                                                 long rows, int C, int rows_per_block, int cgn_log2) {
+    __shared__ float part[2][256][8];
+    const int cgn = 1 << cgn_log2, rln = 256 >> cgn_log2;
+    const int cg = threadIdx.x & (cgn - 1), rl = threadIdx.x >> cgn_log2;
+    const int c = (blockIdx.x * cgn + cg) * 8;
     const long r0 = (long)blockIdx.y * rows_per_block;
     const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float s1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -86,10 +87,10 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const bf16_t* _
         float mu[8], rs[8], ga[8], be[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { mu[e] = mean_rstd[c + e]; rs[e] = mean_rstd[C + c + e]; ga[e] = gamma[c + e]; be[e] = beta[c + e]; }
-        for (long r = r0 + rl; r < r1; r += 8) {
+        auto accumulate = [&](const u32x4& xw, const u32x4& dw) {
             float xv[8], dv[8];
-            unpack8(*reinterpret_cast<const u32x4*>(x + r * ldx + c), xv);
-            unpack8(*reinterpret_cast<const u32x4*>(dy + r * lddy + c), dv);
+            unpack8(xw, xv);
+            unpack8(dw, dv);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float xh = (xv[e] - mu[e]) * rs[e];
@@ -97,17 +98,29 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const bf16_t* _
                 s1[e] += d;
                 s2[e] += d * xh;
             }
+        };
+        long r = r0 + rl;
+        for (; r + 3 * rln < r1; r += 4 * rln) {
+            u32x4 xw[4], dw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xw[u] = *reinterpret_cast<const u32x4*>(x + (r + u * rln) * ldx + c);
+                dw[u] = *reinterpret_cast<const u32x4*>(dy + (r + u * rln) * lddy + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) accumulate(xw[u], dw[u]);
         }
+        for (; r < r1; r += rln)
+            accumulate(*reinterpret_cast<const u32x4*>(x + r * ldx + c), *reinterpret_cast<const u32x4*>(dy + r * lddy + c));
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { part[0][rl][cg][e] = s1[e]; part[1][rl][cg][e] = s2[e]; }
+    for (int e = 0; e < 8; ++e) { part[0][threadIdx.x][e] = s1[e]; part[1][threadIdx.x][e] = s2[e]; }
     __syncthreads();
     if (rl == 0 && c < C) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float a = 0.f, b = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { a += part[0][j][cg][e]; b += part[1][j][cg][e]; }
+            for (int j = 0; j < rln; ++j) { a += part[0][j * cgn + cg][e]; b += part[1][j * cgn + cg][e]; }
             atomicAdd(red + c + e, a);
             atomicAdd(red + C + c + e, b);
         }
@@ -148,33 +161,28 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const bf16_t* __
 }
 
 // ------------------------------------------------------------------------------- classifier conv 3x3, C -> 2
-constexpr int CLS_MAX_C = 128;
+// N = 2 output channels is no MFMA tile, but the conv factors through a pixel-wise GEMM:
+//   forward : zT[co*9+tap, q] = sum_c w[co,c,tap] x[q,c]  (plain NT GEMM, 18 -> 32 rows, fp32 out), then
+//             logits[n,co,y,x] = bias[co] + sum_tap zT[co*9+tap, (n, y+dy, x+dx)]          (cls_gather_fwd_kernel)
+//   backward: g[q, co*9+tap] = dlogits[n, co, (y,x) - (dy,dx)]                              (cls_grad_cols_kernel)
+//             dx = g . Wd^T (NT GEMM, K = 64), dW = g^T . x (TN GEMM), db = column sums of g's centre taps.
+constexpr int CLS_ZROWS = 32, CLS_GCOLS = 64;
 
-// logits[n, co, y, x] (fp32 NCHW) = bias[co] + sum_{tap,c} x[(n, y+dy, x+dx), c] * w[co, c, tap];  w fp32 [2, C, 3, 3]
-__global__ __launch_bounds__(256) void cls_conv_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, float* __restrict__ logits,
-                                                           int images, int H, int W, int C) {
-    __shared__ float ws[2 * 9 * CLS_MAX_C];                    // [co][tap][c]
-    for (int i = threadIdx.x; i < 2 * 9 * C; i += 256) {
-        const int co = i / (9 * C), tap = (i / C) % 9, c = i % C;
-        ws[i] = w[((long)co * C + c) * 9 + tap];
-    }
-    __syncthreads();
+__global__ __launch_bounds__(256) void cls_gather_fwd_kernel(const float* __restrict__ zT, long ldz,
+                                                             const float* __restrict__ bias, float* __restrict__ logits,
+                                                             int images, int H, int W) {
     const long p = (long)blockIdx.x * 256 + threadIdx.x;
     if (p >= (long)images * H * W) return;
     const int n = (int)(p / (H * W)), yy = (int)(p / W) % H, xx = (int)(p % W);
     float a0 = bias[0], a1 = bias[1];
-    for (int tap = 0; tap < 9; ++tap) {
-        const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
-        if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
-        const bf16_t* src = x + (((long)n * H + sy) * W + sx) * C;
-        const float* w0 = ws + tap * C;
-        const float* w1 = ws + (9 + tap) * C;
-        for (int c = 0; c < C; c += 8) {
-            float v[8];
-            unpack8(*reinterpret_cast<const u32x4*>(src + c), v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { a0 += v[e] * w0[c + e]; a1 += v[e] * w1[c + e]; }
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int sy = yy + dy, sx = xx + dx;
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+            const long q = p + dy * W + dx;
+            a0 += zT[tap * ldz + q];
+            a1 += zT[(9 + tap) * ldz + q];
         }
     }
     const long plane = (long)H * W;
@@ -182,72 +190,48 @@ __global__ __launch_bounds__(256) void cls_conv_fwd_kernel(const bf16_t* __restr
     logits[((long)n * 2 + 1) * plane + (long)yy * W + xx] = a1;
 }
 
-// dx[(n,y,x), c] = sum_{tap,co} dl[n, co, y-dy, x-dx] * w[co, c, tap]        (8 channels per thread)
-__global__ __launch_bounds__(256) void cls_conv_bwd_data_kernel(const float* __restrict__ dl, const float* __restrict__ w,
-                                                                bf16_t* __restrict__ dx, int images, int H, int W, int C) {
-    __shared__ float ws[2 * 9 * CLS_MAX_C];
-    for (int i = threadIdx.x; i < 2 * 9 * C; i += 256) {
-        const int co = i / (9 * C), tap = (i / C) % 9, c = i % C;
-        ws[i] = w[((long)co * C + c) * 9 + tap];
-    }
-    __syncthreads();
-    const int c8 = C >> 3;
+// g [pixels, 64] bf16: column co*9+tap (< 18) = dlogits[n, co, y-dy, x-dx] (0 outside), columns 18..63 = 0
+__global__ __launch_bounds__(256) void cls_grad_cols_kernel(const float* __restrict__ dl, bf16_t* __restrict__ g,
+                                                            int images, int H, int W) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)images * H * W * c8) return;
-    const long p = i / c8;
-    const int c = (int)(i % c8) * 8;
-    const int n = (int)(p / (H * W)), yy = (int)(p / W) % H, xx = (int)(p % W);
-    const long plane = (long)H * W;
-    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int tap = 0; tap < 9; ++tap) {
-        const int sy = yy - (tap / 3 - 1), sx = xx - (tap % 3 - 1);     // output pixel that read (y, x) through `tap`
-        if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
-        const float d0 = dl[((long)n * 2) * plane + (long)sy * W + sx], d1 = dl[((long)n * 2 + 1) * plane + (long)sy * W + sx];
+    if (i >= (long)images * H * W * 8) return;
+    const long q = i >> 3;
+    const int chunk = (int)(i & 7);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (chunk < 3) {
+        const int n = (int)(q / (H * W)), yy = (int)(q / W) % H, xx = (int)(q % W);
+        const long plane = (long)H * W;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += d0 * ws[tap * C + c + e] + d1 * ws[(9 + tap) * C + c + e];
-    }
-    *reinterpret_cast<u32x4*>(dx + p * C + c) = pack8(o);
-}
-
-// dw[co, c, tap] += sum_pixels dl[n, co, y, x] * x[(n, y+dy, x+dx), c]; db[co] += sum dl      (thread = (co, c))
-__global__ __launch_bounds__(256) void cls_conv_bwd_weight_kernel(const float* __restrict__ dl, const bf16_t* __restrict__ x,
-                                                                  float* __restrict__ dw, float* __restrict__ db,
-                                                                  int images, int H, int W, int C, int pix_per_block) {
-    const int co = threadIdx.x / C, c = threadIdx.x % C;      // blockDim = 2*C
-    const long total = (long)images * H * W;
-    const long p0 = (long)blockIdx.x * pix_per_block;
-    const long p1 = p0 + pix_per_block < total ? p0 + pix_per_block : total;
-    const long plane = (long)H * W;
-    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
-    for (long p = p0; p < p1; ++p) {
-        const int n = (int)(p / (H * W)), yy = (int)(p / W) % H, xx = (int)(p % W);
-        const float d = dl[((long)n * 2 + co) * plane + (long)yy * W + xx];
-        bsum += d;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
-            if (sy >= 0 && sy < H && sx >= 0 && sx < W) acc[tap] += d * bf2f(x[(((long)n * H + sy) * W + sx) * C + c]);
+        for (int e = 0; e < 8; ++e) {
+            const int j = chunk * 8 + e;
+            if (j < 18) {
+                const int co = j / 9, tap = j % 9;
+                const int sy = yy - (tap / 3 - 1), sx = xx - (tap % 3 - 1);
+                if (sy >= 0 && sy < H && sx >= 0 && sx < W) v[e] = dl[((long)n * 2 + co) * plane + (long)sy * W + sx];
+            }
         }
     }
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) atomicAdd(dw + ((long)co * C + c) * 9 + tap, acc[tap]);
-    if (c == 0) atomicAdd(db + co, bsum);
+    *reinterpret_cast<u32x4*>(g + q * CLS_GCOLS + chunk * 8) = pack8(v);
 }
 
 // ------------------------------------------------------------------------------------- weight re-layouts
-// dst[i0][i1][i2][i3] (contiguous) <- src[i0*s0 + i1*s1 + i2*s2 + i3*s3];  ACC = false: dst bf16 = cast(src),
+// dst[i0*d0 + i1*d1 + i2*d2 + i3*d3] <- src[i0*s0 + i1*s1 + i2*s2 + i3*s3];  ACC = false: dst bf16 = cast(src),
 // ACC = true: dst fp32 += src   (GEMM-operand views of conv weights; weight gradients back into parameter layout)
+struct Permute4 {
+    long s[4], d[4];
+    int n[4];
+};
 template <bool ACC>
-__global__ __launch_bounds__(256) void permute4_kernel(const float* __restrict__ src, long s0, long s1, long s2, long s3,
-                                                       int n1, int n2, int n3, long total, void* __restrict__ dst) {
+__global__ __launch_bounds__(256) void permute4_kernel(const float* __restrict__ src, Permute4 q, long total,
+                                                       void* __restrict__ dst) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int i3 = (int)(i % n3), i2 = (int)((i / n3) % n2), i1 = (int)((i / ((long)n3 * n2)) % n1);
-    const long i0 = i / ((long)n3 * n2 * n1);
-    const float v = src[i0 * s0 + i1 * s1 + i2 * s2 + i3 * s3];
-    if (ACC) reinterpret_cast<float*>(dst)[i] += v;
-    else reinterpret_cast<bf16_t*>(dst)[i] = f2bf(v);
+    const int i3 = (int)(i % q.n[3]), i2 = (int)((i / q.n[3]) % q.n[2]), i1 = (int)((i / ((long)q.n[3] * q.n[2])) % q.n[1]);
+    const long i0 = i / ((long)q.n[3] * q.n[2] * q.n[1]);
+    const float v = src[i0 * q.s[0] + i1 * q.s[1] + i2 * q.s[2] + i3 * q.s[3]];
+    const long o = i0 * q.d[0] + i1 * q.d[1] + i2 * q.d[2] + i3 * q.d[3];
+    if (ACC) reinterpret_cast<float*>(dst)[o] += v;
+    else reinterpret_cast<bf16_t*>(dst)[o] = f2bf(v);
 }
 
 }  // namespace ccd

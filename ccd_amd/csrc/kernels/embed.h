@@ -103,19 +103,35 @@ __global__ void small_matmul_f32_kernel(const float* __restrict__ a, const float
     c[(long)m * N + n] = accumulate ? c[(long)m * N + n] + acc : acc;
 }
 
-// out[n] += sum_rows x[row, n]   (bias gradients); block = 32 column groups (8 cols, 16 B) x 8 row lanes
+// out[n] += sum_rows x[row, n]   (bias gradients).  Block = cgn column groups (8 cols, 16 B; cgn = power of two
+// <= 32 chosen by the host so narrow matrices keep all lanes busy) x 256/cgn row lanes, 4 loads in flight per thread;
+// the host sizes the grid so every block streams >= 256 KiB (few same-address atomics)
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, long ld, int rows, int N,
                                                           const int* __restrict__ d_rows, int rows_mul,
-                                                          float* __restrict__ out, int rows_per_block) {
-    __shared__ float red[8][32][8];
-    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int col = (blockIdx.x * 32 + cg) * 8;
+                                                          float* __restrict__ out, int rows_per_block, int cgn_log2) {
+    __shared__ float red[256][8];
+    const int cgn = 1 << cgn_log2, rln = 256 >> cgn_log2;
+    const int cg = threadIdx.x & (cgn - 1), rl = threadIdx.x >> cgn_log2;
+    const int col = (blockIdx.x * cgn + cg) * 8;
     if (d_rows) rows = d_rows[0] * rows_mul < rows ? d_rows[0] * rows_mul : rows;
     const int r0 = blockIdx.y * rows_per_block;
     const int r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (col < N) {
-        for (int r = r0 + rl; r < r1; r += 8) {
+        int r = r0 + rl;
+        for (; r + 3 * rln < r1; r += 4 * rln) {
+            u32x4 w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const u32x4*>(x + (long)(r + u * rln) * ld + col);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float v[8];
+                unpack8(w[u], v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += v[k];
+            }
+        }
+        for (; r < r1; r += rln) {
             float v[8];
             unpack8(*reinterpret_cast<const u32x4*>(x + (long)r * ld + col), v);
 #pragma unroll
@@ -123,14 +139,13 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
         }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) red[rl][cg][k] = acc[k];
+    for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = acc[k];
     __syncthreads();
     if (rl == 0 && col < N) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s += red[j][cg][k];
+            for (int j = 0; j < rln; ++j) s += red[j * cgn + cg][k];
             atomicAdd(out + col + k, s);
         }
     }

@@ -297,17 +297,31 @@ def head_backward(arena, pre, saved, d_logits, d_total, last_layer_trainable_g, 
     return d_rows_t
 
 
+# bf16 logit gradients handed from DinoLossFn.backward to HeadFn.backward, keyed by the logits buffer's address.
+# autograd insists that a gradient has its tensor's dtype (fp32 logits), which would cost a bf16 -> fp32 -> bf16 round
+# trip over the [rows, 65536] matrix (~1.7 ms per step at B = 256); the loss therefore returns a zero-stride dummy and
+# parks the real bf16 gradient here.
+_BF16_LOGIT_GRADS = {}
+
+
 class HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rows, module, d_total, rows_mul=2):
         save = ctx.needs_input_grad[0]
         logits, saved = head_forward(module.arena, module.arena_prefix, rows, d_total, save, rows_mul)
         ctx.module, ctx.saved, ctx.d_total, ctx.rows_mul = module, saved, d_total, rows_mul
+        ctx.logits_key = logits.data_ptr()
+        _BF16_LOGIT_GRADS.pop(ctx.logits_key, None)
         return logits
 
     @staticmethod
     def backward(ctx, d_logits):
         m = ctx.module
+        parked = _BF16_LOGIT_GRADS.pop(ctx.logits_key, None)
+        if parked is not None and tuple(parked.shape) == tuple(d_logits.shape):
+            if any(st != 0 for st in d_logits.stride()):          # another consumer contributed a real gradient
+                parked = parked + d_logits.to(BF16)
+            d_logits = parked
         d_rows = head_backward(m.arena, m.arena_prefix, ctx.saved, d_logits.contiguous().to(BF16), ctx.d_total,
                                m.weight_g_trainable, ctx.rows_mul)
         ctx.saved = None
@@ -321,8 +335,9 @@ class DinoLossFn(torch.autograd.Function):
     """loss (1-element fp32 tensor) of the two cross-view CE terms; d(student logits) in bf16."""
 
     @staticmethod
-    def forward(ctx, s_logits, t_logits, center, d_total, student_temp, teacher_temp):
+    def forward(ctx, s_logits, t_logits, center, d_total, student_temp, teacher_temp, park_grad=False):
         dev = s_logits.device
+        ctx.park_grad = park_grad
         stats = torch.empty((s_logits.shape[0], 4), dtype=F32, device=dev)
         loss = torch.zeros(1, dtype=F32, device=dev)
         center = center.clone()     # DINOLoss.update_center rewrites the buffer in place right after this forward
@@ -337,7 +352,10 @@ class DinoLossFn(torch.autograd.Function):
         d_logits = torch.zeros(s_logits.shape, dtype=BF16, device=s_logits.device)
         ops.dino_loss_bwd(s_logits, t_logits, center, ctx.d_total, ctx.temps[0], ctx.temps[1], stats, 1.0, d_logits,
                           d_grad_scale=d_loss.contiguous().float())      # upstream gradient stays a device scalar
-        return d_logits, None, None, None, None, None
+        if ctx.park_grad and s_logits.dtype == F32:                      # see _BF16_LOGIT_GRADS
+            _BF16_LOGIT_GRADS[s_logits.data_ptr()] = d_logits
+            d_logits = torch.zeros((), dtype=F32, device=s_logits.device).expand(s_logits.shape)
+        return d_logits, None, None, None, None, None, None
 
 
 class SegLossFn(torch.autograd.Function):

@@ -31,14 +31,14 @@ class DINOLoss(nn.Module):
     def _logits_and_count(out):
         raw = getattr(out, "raw", None)
         if raw is not None and raw("logits_buf") is not None:
-            return raw("logits_buf"), raw("selection").total
+            return raw("logits_buf"), raw("selection").total, True
         t = out["instances_view"].contiguous().float()
-        return t, torch.full((1,), t.shape[0] // 2, dtype=torch.int32, device=t.device)
+        return t, torch.full((1,), t.shape[0] // 2, dtype=torch.int32, device=t.device), False
 
     def forward(self, student_output, teacher_output, epoch):
         self.losses = {}
-        s_logits, d_total = self._logits_and_count(student_output)
-        t_logits, _ = self._logits_and_count(teacher_output)
+        s_logits, d_total, direct = self._logits_and_count(student_output)
+        t_logits, _, _ = self._logits_and_count(teacher_output)
         # --- segmentation loss against [masks, warped masks] (train.py:234-237 builds 'gt')
         gt = student_output["gt"]
         mask_a = gt[0].contiguous().float()
@@ -48,7 +48,8 @@ class DINOLoss(nn.Module):
         # --- character-to-character distillation
         temp = float(self.teacher_temp_schedule[epoch])
         center = self.center.view(-1)
-        dino_loss = engine.DinoLossFn.apply(s_logits, t_logits.detach(), center, d_total, self.student_temp, temp)[0]
+        dino_loss = engine.DinoLossFn.apply(s_logits, t_logits.detach(), center, d_total, self.student_temp, temp,
+                                            direct)[0]
         self.update_center(t_logits.detach(), d_total)
         self.losses["mask_loss"] = mask_loss
         self.losses["Dino_loss"] = dino_loss

@@ -428,31 +428,35 @@ def bn_relu_bwd_apply(dy, x, mean_rstd, gamma, beta, red, count, red_local, dgam
     return dx
 
 
-def cls_conv_fwd(x, w, bias, images, H, W):
-    _chk(x, BF16, "x"); _chk(w, F32, "w"); _chk(bias, F32, "bias")
-    C = x.shape[1]
-    assert x.is_contiguous() and w.is_contiguous() and tuple(w.shape) == (2, C, 3, 3)
-    logits = torch.empty((images, 2, H, W), dtype=F32, device=x.device)
-    _call("ccd_cls_conv_fwd", _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(logits), images, H, W, C)
+def cls_gather_fwd(zT, bias, images, H, W):
+    """zT fp32 [>=18, pixels] (row co*9+tap) -> fp32 logits [images, 2, H, W]."""
+    _chk(zT, F32, "zT"); _chk(bias, F32, "bias")
+    assert zT.shape[0] >= 18 and zT.shape[1] == images * H * W
+    logits = torch.empty((images, 2, H, W), dtype=F32, device=zT.device)
+    _call("ccd_cls_gather_fwd", _lib.ptr(zT), zT.stride(0), _lib.ptr(bias), _lib.ptr(logits), images, H, W)
     return logits
 
 
-def cls_conv_bwd(dlogits, x, w, dw, db, images, H, W):
-    _chk(dlogits, F32, "dlogits"); _chk(x, BF16, "x")
-    assert dlogits.is_contiguous() and x.is_contiguous() and dw.is_contiguous()
-    C = x.shape[1]
-    dx = torch.empty_like(x)
-    _call("ccd_cls_conv_bwd", _lib.ptr(dlogits), _lib.ptr(x), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db),
-          images, H, W, C)
-    return dx
+def cls_grad_cols(dlogits, images, H, W):
+    """fp32 dlogits [images, 2, H, W] -> bf16 g [pixels, 64] (column co*9+tap = shifted gradient plane)."""
+    _chk(dlogits, F32, "dlogits")
+    assert dlogits.is_contiguous() and tuple(dlogits.shape) == (images, 2, H, W)
+    g = torch.empty((images * H * W, 64), dtype=BF16, device=dlogits.device)
+    _call("ccd_cls_grad_cols", _lib.ptr(dlogits), _lib.ptr(g), images, H, W)
+    return g
 
 
-def permute4(src, strides, dims, dst, accumulate=False):
-    """dst[dims] (contiguous; bf16 cast, or fp32 += when accumulate) <- src.flatten()[sum_i idx_i * strides_i]."""
+def permute4(src, strides, dims, dst, accumulate=False, dst_strides=None):
+    """dst[idx . dst_strides] (bf16 cast, or fp32 += when accumulate) <- src.flatten()[idx . strides]; dst_strides
+    default to contiguous over `dims`."""
     _chk(src, F32, "src"); _chk(dst, F32 if accumulate else BF16, "dst")
     n = list(dims) + [1] * (4 - len(dims))
     s = list(strides) + [0] * (4 - len(strides))
-    assert dst.is_contiguous() and dst.numel() == n[0] * n[1] * n[2] * n[3]
-    _call("ccd_permute4", _lib.ptr(src), s[0], s[1], s[2], s[3], n[0], n[1], n[2], n[3], _lib.ptr(dst),
-          1 if accumulate else 0)
+    if dst_strides is None:
+        d = [n[1] * n[2] * n[3], n[2] * n[3], n[3], 1]
+        assert dst.is_contiguous() and dst.numel() == n[0] * n[1] * n[2] * n[3]
+    else:
+        d = list(dst_strides) + [0] * (4 - len(dst_strides))
+    arr_l, arr_i = ctypes.c_long * 4, ctypes.c_int * 4
+    _call("ccd_permute4", _lib.ptr(src), arr_l(*s), arr_l(*d), arr_i(*n), _lib.ptr(dst), 1 if accumulate else 0)
     return dst

@@ -8,7 +8,8 @@ have - so every convolution is a GEMM over pixels:
                                      row (n, y, x) to (n, 2y+py, 2x+px)
   BatchNorm2d (train) + ReLU         batch statistics come out of the GEMM epilogue (column sum / sum of squares),
                                      one elementwise pass normalises; SyncBatchNorm = all-reduce of the [2C] statistics
-  Conv2d(128, 2, 3) classifier       VALU kernel (N = 2 is no MFMA shape), fp32 NCHW logits as the loss expects
+  Conv2d(128, 2, 3) classifier       N = 2 is no MFMA tile: factored through pixel-wise GEMMs (18 tap/class planes)
+                                     plus a 9-point gather-sum; fp32 NCHW logits as the loss expects
   backward                           data gradients: implicit GEMMs with flipped / strided taps; weight gradients:
                                      TN GEMMs against an explicit patch matrix (ops.im2col), re-laid into the parameter
                                      layout by ops.permute4; BN backward = one reduce pass + one apply pass.
@@ -89,6 +90,31 @@ def _ensure_grads(module):
             p.grad = torch.zeros_like(p)
 
 
+def cls_forward(x, w, b, images, H, W):
+    """Conv2d(C, 2, 3, padding=1) on channels-last bf16 x [pixels, C] -> fp32 logits [images, 2, H, W]."""
+    C = x.shape[1]
+    wz = torch.zeros((32, C), dtype=BF16, device=x.device)                       # row co*9+tap = w[co, :, tap]
+    ops.permute4(w, (C * 9, 1, 9), (2, 9, C), wz[:18])
+    zT = ops.gemm_nt(wz, x, epilogue=ops.EPI_F32)                                 # [32, pixels] fp32
+    return ops.cls_gather_fwd(zT, b, images, H, W)
+
+
+def cls_backward(d_logits, x, w, dw, db, images, H, W):
+    """-> dx bf16 [pixels, C]; dw [2, C, 3, 3] / db [2] accumulate (fp32)."""
+    C, dev = x.shape[1], x.device
+    g = ops.cls_grad_cols(d_logits, images, H, W)                                 # [pixels, 64], col co*9+tap
+    wd = torch.zeros((C, 64), dtype=BF16, device=dev)                             # wd[c, co*9+tap] = w[co, c, tap]
+    ops.permute4(w, (9, C * 9, 1), (C, 2, 9), wd, dst_strides=(64, 9, 1))
+    dx = ops.gemm_nt(g, wd)
+    stage = torch.zeros((64, C), dtype=F32, device=dev)
+    ops.gemm_tn(g, x, stage)                                                      # [co*9+tap, c]
+    ops.permute4(stage, (9 * C, 1, C), (2, C, 9), dw, accumulate=True)
+    cs = torch.zeros(64, dtype=F32, device=dev)
+    ops.colsum_bf16(g, cs)                                                        # centre tap (always in bounds)
+    ops.permute4(cs[4:], (9,), (2,), db, accumulate=True)
+    return dx
+
+
 class SegHeadFn(torch.autograd.Function):
     """(tap2, tap3, tap4: bf16 [N*256, E]) -> fp32 logits [N, 2, 32, 128]; parameter gradients go straight to .grad."""
 
@@ -146,7 +172,7 @@ class SegHeadFn(torch.autograd.Function):
             a = bn.forward(y, torch.empty_like(y))
             ups.append((x, y, bn, grid))
             x, grid = a, (2 * grid[0], 2 * grid[1])
-        logits = ops.cls_conv_fwd(x, head.cls.weight.detach(), head.cls.bias.detach(), images, grid[0], grid[1])
+        logits = cls_forward(x, head.cls.weight.detach(), head.cls.bias.detach(), images, grid[0], grid[1])
         ctx.head, ctx.images, ctx.saved, ctx.ups, ctx.a_last, ctx.grid = head, images, saved, ups, x, grid
         ctx.dims = (E, mid, out_c, M)
         return logits
@@ -160,8 +186,8 @@ class SegHeadFn(torch.autograd.Function):
         for m in (head.unpool1, head.unpool2, head.cls):
             _ensure_grads(m)
         H, W = ctx.grid
-        d = ops.cls_conv_bwd(d_logits.contiguous().float(), ctx.a_last, head.cls.weight.detach(), head.cls.weight.grad,
-                             head.cls.bias.grad, images, H, W)
+        d = cls_backward(d_logits.contiguous().float(), ctx.a_last, head.cls.weight.detach(), head.cls.weight.grad,
+                         head.cls.bias.grad, images, H, W)
         ctx.a_last = None
         # ---- transposed convs, last first
         for seq, (x_in, y, bn, grid) in zip((head.unpool2, head.unpool1), reversed(ctx.ups)):

@@ -192,15 +192,17 @@ int ccd_bn_relu_bwd_reduce(const ccd_bf16* dy, long lddy, const ccd_bf16* x, lon
 int ccd_bn_relu_bwd_apply(const ccd_bf16* dy, long lddy, const ccd_bf16* x, long ldx, const float* mean_rstd,
                           const float* gamma, const float* beta, const float* red, float count, const float* red_local,
                           float* dgamma, float* dbeta, ccd_bf16* dx, long lddx, long rows, int C, void* stream);
-/* Classifier Conv2d(C, 2, 3, padding=1) (segmentor.py:86): x [images*H*W, C] bf16 -> fp32 logits [images, 2, H, W];
- * backward writes dx (bf16) and accumulates dw [2, C, 3, 3] / db [2] (fp32, +=). */
-int ccd_cls_conv_fwd(const ccd_bf16* x, const float* w, const float* bias, float* logits, int images, int H, int W, int C,
-                     void* stream);
-int ccd_cls_conv_bwd(const float* dlogits, const ccd_bf16* x, const float* w, ccd_bf16* dx, float* dw, float* db,
-                     int images, int H, int W, int C, void* stream);
-/* dst[n0][n1][n2][n3] (contiguous) <- src[i0*s0 + i1*s1 + i2*s2 + i3*s3]; accumulate = 0: dst is bf16 (cast),
- * accumulate = 1: dst is fp32 and += (conv weights <-> GEMM operand layouts). */
-int ccd_permute4(const float* src, long s0, long s1, long s2, long s3, int n0, int n1, int n2, int n3, void* dst,
+/* Classifier Conv2d(C, 2, 3, padding=1) (segmentor.py:86) factored through pixel-wise GEMMs:
+ *   forward : zT[co*9+tap, q] = sum_c w[co,c,tap] x[q,c] by ccd_gemm_nt (fp32, row stride ldz), then
+ *             logits[n,co,y,x] = bias[co] + sum_tap zT[co*9+tap, (n,y+dy,x+dx)]            (ccd_cls_gather_fwd)
+ *   backward: g[q, co*9+tap] = dlogits[n,co,(y,x)-(dy,dx)], bf16 [pixels, 64], columns >= 18 zero (ccd_cls_grad_cols);
+ *             dx = g . Wd^T (ccd_gemm_nt), dW = g^T . x (ccd_gemm_tn), db = column sums of the centre taps. */
+int ccd_cls_gather_fwd(const float* zT, long ldz, const float* bias, float* logits, int images, int H, int W,
+                       void* stream);
+int ccd_cls_grad_cols(const float* dlogits, ccd_bf16* g, int images, int H, int W, void* stream);
+/* dst[sum_i idx_i*dst_strides[i]] <- src[sum_i idx_i*src_strides[i]] over dims[4] (host arrays); accumulate = 0: dst
+ * is bf16 (cast), accumulate = 1: dst is fp32 and += (conv weights <-> GEMM operand layouts, weight gradients back). */
+int ccd_permute4(const float* src, const long* src_strides, const long* dst_strides, const int* dims, void* dst,
                  int accumulate, void* stream);
 
 #ifdef __cplusplus
