@@ -62,6 +62,7 @@ SIGNATURES = {
     "ccd_clip_scale": [P, P, P, P, I, P, F, P],
     "ccd_ema": [P, P, P, L, F, F, P],
     "ccd_conv_gemm": [P, L, P, P, L, I, I, P, L, P, P, P, P],
+    "ccd_conv_wgrad": [P, L, I, P, L, P, L, P, L, P],
     "ccd_im2col": [P, L, P, L, P, P],
     "ccd_bn_finalize": [P, F, F, F, P, P, P, I, P],
     "ccd_bn_relu_fwd": [P, L, P, P, P, P, L, L, I, P],

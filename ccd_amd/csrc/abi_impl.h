@@ -466,7 +466,18 @@ static int ccd_check_conv_desc(const ccd_conv_desc* d) {
     CCD_CHECK(d->ntaps >= 1 && d->ntaps <= 16 && d->cin > 0 && d->cin % 64 == 0, CCD_ESHAPE);
     CCD_CHECK(d->g_h_log2 >= 0 && d->g_w_log2 >= 0 && d->g_h_log2 + d->g_w_log2 <= 24, CCD_ESHAPE);
     CCD_CHECK(d->s_h > 0 && d->s_w > 0 && d->s_mul >= 1, CCD_ESHAPE);
+    for (int i = 0; i < d->ntaps; ++i) CCD_CHECK(d->dy[i] >= -8 && d->dy[i] <= 7 && d->dx[i] >= -8 && d->dx[i] <= 7, CCD_ESHAPE);
     return CCD_OK;
+}
+
+static void ccd_fill_gather(ccd::GemmParams& p, const ccd_conv_desc* desc) {
+    p.g_h_log2 = desc->g_h_log2; p.g_w_log2 = desc->g_w_log2; p.s_h = desc->s_h; p.s_w = desc->s_w;
+    p.s_mul = desc->s_mul; p.cin = desc->cin;
+    p.dy_pack = 0; p.dx_pack = 0;
+    for (int i = 0; i < 16; ++i) {
+        p.dy_pack |= (unsigned long long)((desc->dy[i] + 8) & 15) << (4 * i);
+        p.dx_pack |= (unsigned long long)((desc->dx[i] + 8) & 15) << (4 * i);
+    }
 }
 
 int ccd_conv_gemm(const ccd_bf16* src, long src_ld, const ccd_conv_desc* desc, const ccd_bf16* W, long ldw, int M, int N,
@@ -483,13 +494,37 @@ int ccd_conv_gemm(const ccd_bf16* src, long src_ld, const ccd_conv_desc* desc, c
     p.A = src; p.lda = src_ld; p.B = W; p.ldb = ldw; p.M = M; p.N = N; p.K = desc->ntaps * desc->cin;
     p.C = C; p.ldc = ldc; p.bias = bias; p.rows_per_sample = 1; p.k_per_split = p.K; p.alpha = 1.0f; p.rows_mul = 1;
     p.colsum = colsum; p.colsumsq = colsumsq;
-    p.g_h_log2 = desc->g_h_log2; p.g_w_log2 = desc->g_w_log2; p.s_h = desc->s_h; p.s_w = desc->s_w;
-    p.s_mul = desc->s_mul; p.cin = desc->cin;
-    for (int i = 0; i < 16; ++i) { p.dy[i] = desc->dy[i]; p.dx[i] = desc->dx[i]; }
+    ccd_fill_gather(p, desc);
     p.c_map = desc->c_map; p.c_py = desc->c_py; p.c_px = desc->c_px;
     const int tiles = ((M + ccd::GEMM_BM - 1) / ccd::GEMM_BM) * ((N + ccd::GEMM_BN - 1) / ccd::GEMM_BN);
     CCD_LAUNCH((ccd::gemm_bf16_kernel<false, ccd::EPI_BF16, true>), dim3(tiles), dim3(256), (size_t)ccd::GEMM_SMEM_BYTES,
                stream, p);
+    return ccd_rt_last_error();
+}
+
+int ccd_conv_wgrad(const ccd_bf16* A, long lda, int P, const ccd_bf16* src, long src_ld, const ccd_conv_desc* desc,
+                   long rows, float* out, long ldo, void* stream) {
+    CCD_CHECK(A && src && out, CCD_EINVAL);
+    CCD_CHECK(CCD_ALIGNED16(A) && CCD_ALIGNED16(src) && CCD_ALIGNED16(out), CCD_EINVAL);
+    const int rc = ccd_check_conv_desc(desc);
+    if (rc != CCD_OK) return rc;
+    if (rows == 0 || P == 0) return CCD_OK;
+    const int Q = desc->ntaps * desc->cin;
+    CCD_CHECK(rows > 0 && rows < (1L << 31) && P > 0, CCD_EINVAL);
+    CCD_CHECK(P % 8 == 0 && lda % 8 == 0 && src_ld % 8 == 0 && ldo % 4 == 0 && src_ld >= desc->cin, CCD_ESHAPE);
+    CCD_CHECK(desc->g_w_log2 >= 2 && rows % (1 << (desc->g_h_log2 + desc->g_w_log2)) == 0, CCD_ESHAPE);
+    const int tiles = ((P + 127) / 128) * ((Q + 127) / 128);
+    int splits = (2 * ccd_rt_num_cus()) / tiles;
+    if (splits < 1) splits = 1;
+    int per = (int)((rows + splits - 1) / splits);
+    per = ((per + 63) / 64) * 64;
+    splits = (int)((rows + per - 1) / per);
+    ccd::GemmParams p = ccd::GemmParams();
+    p.A = A; p.lda = lda; p.B = src; p.ldb = src_ld; p.M = P; p.N = Q; p.K = (int)rows;
+    p.C = out; p.ldc = ldo; p.rows_per_sample = 1; p.k_per_split = per; p.alpha = 1.0f; p.rows_mul = 1;
+    ccd_fill_gather(p, desc);
+    CCD_LAUNCH((ccd::gemm_bf16_kernel<true, ccd::EPI_ATOMIC, true>), dim3(tiles * splits), dim3(256),
+               (size_t)ccd::GEMM_SMEM_BYTES, stream, p);
     return ccd_rt_last_error();
 }
 

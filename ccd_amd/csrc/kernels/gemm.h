@@ -46,11 +46,11 @@ struct GemmParams {
     float* colsum;          // optional [N] fp32: += column sums of the (final) output tile, e.g. the bias gradient
     float* colsumsq;        // optional [N] fp32: += column sums of squares (BatchNorm batch statistics), EPI_BF16 only
     // ---- implicit-GEMM convolution (NT, GATHER instantiation): A row r is pixel (n, oy, ox) of a 2^gh x 2^gw grid,
-    // contraction index k = tap * cin + c reads source pixel (oy*s_mul + dy[tap], ox*s_mul + dx[tap]) of an s_h x s_w
+    // contraction index k = tap * cin + c reads source pixel (oy*s_mul + dy(tap), ox*s_mul + dx(tap)) of an s_h x s_w
     // image with `lda` channels per pixel (zero outside); covers 3x3 conv, its data gradient, the four parity classes
     // of a 4x4/stride-2 transposed conv and that layer's data gradient.
     int g_h_log2, g_w_log2, s_h, s_w, s_mul, cin;
-    signed char dy[16], dx[16];
+    unsigned long long dy_pack, dx_pack;   // tap offsets as 4-bit fields (d + 8), tap i in bits 4i..4i+3: register lookup
     int c_map, c_py, c_px;  // c_map: output row (n, oy, ox) -> (n, 2*oy + c_py, 2*ox + c_px) of the 2x upsampled grid
     const int* d_rows;      // optional device-side row count: NT rows M / TN contraction length K become
     int rows_mul;           //   min(static value, d_rows[0] * rows_mul); the grid is sized for the static value
@@ -92,9 +92,8 @@ struct NtCursor {
 // gather variant of NtCursor for the implicit-GEMM convolutions (see GemmParams)
 struct GatherCursor {
     const bf16_t* base;
-    int pix[4], oys[4], oxs[4];      // per chunk row: image base pixel index, scaled coordinates
-    bool ok[4];
-    int tap, c0;
+    int pix[4], pos[4];              // per chunk row: image base pixel index, (oy*s_mul) << 16 | (ox*s_mul)
+    int tap, c0;                     // wave-uniform position inside the contraction
     __device__ __forceinline__ void init(const GemmParams& p, int row0) {
         const int t = threadIdx.x;
         base = p.A + (t & 7) * 8;
@@ -104,20 +103,19 @@ struct GatherCursor {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = row0 + (t >> 3) + 32 * i;
-            ok[i] = row < p.M;
             const int n = row >> hw, oy = (row >> p.g_w_log2) & ((1 << p.g_h_log2) - 1), ox = row & ((1 << p.g_w_log2) - 1);
             pix[i] = n * p.s_h * p.s_w;
-            oys[i] = oy * p.s_mul;
-            oxs[i] = ox * p.s_mul;
+            // rows beyond the matrix get a y coordinate no image reaches: their loads are skipped (zeros)
+            pos[i] = row < p.M ? ((oy * p.s_mul) << 16) | (ox * p.s_mul) : (0x4000 << 16);
         }
     }
     __device__ __forceinline__ void load(const GemmParams& p, u32x4 (&r)[4]) {
-        const int dy = p.dy[tap], dx = p.dx[tap];
+        const int dy = (int)((p.dy_pack >> (4 * tap)) & 15ull) - 8, dx = (int)((p.dx_pack >> (4 * tap)) & 15ull) - 8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int sy = oys[i] + dy, sx = oxs[i] + dx;
+            const int sy = (pos[i] >> 16) + dy, sx = (pos[i] & 0xffff) + dx;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok[i] && sy >= 0 && sy < p.s_h && sx >= 0 && sx < p.s_w)
+            if ((unsigned)sy < (unsigned)p.s_h && (unsigned)sx < (unsigned)p.s_w)
                 v = *reinterpret_cast<const u32x4*>(base + (long)(pix[i] + sy * p.s_w + sx) * p.lda + c0);
             r[i] = v;
         }
@@ -166,6 +164,41 @@ struct TnCursor {
             }
         }
         ptr += (long)GEMM_BK * ld;
+    }
+};
+// gather variant of TnCursor for the B operand: the weight gradient of a convolution contracts over pixels, B row r is
+// the patch vector of pixel r (column tap*cin + c), read straight from the source image instead of an im2col buffer.
+// A thread's 8 columns lie inside one tap (cin % 8 == 0); its 4 contraction rows are 4 consecutive x positions of one
+// image row (grid width % 4 == 0).
+struct TnGatherCursor {
+    const bf16_t* base;
+    int prow, dy, dx;
+    bool col_ok;
+    __device__ __forceinline__ void init(const GemmParams& p, int col0, int ncols, int k_begin) {
+        const int t = threadIdx.x;
+        const int col = col0 + 8 * (t & 15);
+        col_ok = col < ncols;
+        const int tap = col_ok ? col / p.cin : 0, c = col_ok ? col % p.cin : 0;
+        dy = (int)((p.dy_pack >> (4 * tap)) & 15ull) - 8;
+        dx = (int)((p.dx_pack >> (4 * tap)) & 15ull) - 8;
+        base = p.B + c;
+        prow = k_begin + 4 * (t >> 4);
+    }
+    __device__ __forceinline__ void load(const GemmParams& p, u32x4 (&r)[4], int rows_left) {
+        const int mrow = 4 * (threadIdx.x >> 4);
+        const int hw = p.g_h_log2 + p.g_w_log2;
+        const int n = prow >> hw, oy = (prow >> p.g_w_log2) & ((1 << p.g_h_log2) - 1), ox = prow & ((1 << p.g_w_log2) - 1);
+        const int sy = oy * p.s_mul + dy;
+        const bool row_ok = col_ok && sy >= 0 && sy < p.s_h;
+        const bf16_t* src = base + ((long)n * p.s_h + sy) * p.s_w * p.ldb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sx = (ox + i) * p.s_mul + dx;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row_ok && mrow + i < rows_left && sx >= 0 && sx < p.s_w) v = *reinterpret_cast<const u32x4*>(src + (long)sx * p.ldb);
+            r[i] = v;
+        }
+        prow += GEMM_BK;
     }
 };
 __device__ __forceinline__ void gemm_store_tn(char* tile, const u32x4 (&r)[4]) {
@@ -275,9 +308,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     NtCursor nta, ntb;
     TnCursor tna, tnb;
     GatherCursor gta;
+    TnGatherCursor tgb;
     if (TN) {
         tna.init(p.A, p.lda, m0, p.M, k_begin);
-        tnb.init(p.B, p.ldb, n0, p.N, k_begin);
+        if (GATHER) tgb.init(p, n0, p.N, k_begin);
+        else tnb.init(p.B, p.ldb, n0, p.N, k_begin);
     } else {
         if (GATHER) gta.init(p, m0);
         else nta.init(p.A, p.lda, m0, p.M, k_begin);
@@ -289,7 +324,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
             if (TN) {
                 const int left = k_end - (k_begin + next_tile * GEMM_BK);
                 tna.load(ra, left);
-                tnb.load(rb, left);
+                if (GATHER) tgb.load(p, rb, left);
+                else tnb.load(rb, left);
             } else {
                 if (GATHER) gta.load(p, ra);
                 else nta.load(ra);

@@ -388,6 +388,21 @@ def conv_gemm(src, desc, w, rows, out, *, bias=None, colsum=None, colsumsq=None)
     return out
 
 
+def conv_wgrad(a, src, desc, out):
+    """out[P, ntaps*cin] (fp32) += a[rows, P]^T @ gather(src)[rows, ntaps*cin] (implicit patch matrix)."""
+    _chk(a, BF16, "a"); _chk(src, BF16, "src"); _chk(out, F32, "out")
+    rows, Pd = a.shape
+    assert tuple(out.shape) == (Pd, desc.ntaps * desc.cin)
+    span = TIMER.span("conv_wgrad", 2.0 * rows * Pd * out.shape[1]) if TIMER is not None else None
+    if span:
+        span[0].record()
+    _call("ccd_conv_wgrad", _lib.ptr(a), a.stride(0), Pd, _lib.ptr(src), src.stride(0), ctypes.addressof(desc), rows,
+          _lib.ptr(out), out.stride(0))
+    if span:
+        span[1].record()
+    return out
+
+
 def im2col(src, desc, rows, out=None):
     _chk(src, BF16, "src")
     if out is None:

@@ -11,8 +11,9 @@ have - so every convolution is a GEMM over pixels:
   Conv2d(128, 2, 3) classifier       N = 2 is no MFMA tile: factored through pixel-wise GEMMs (18 tap/class planes)
                                      plus a 9-point gather-sum; fp32 NCHW logits as the loss expects
   backward                           data gradients: implicit GEMMs with flipped / strided taps; weight gradients:
-                                     TN GEMMs against an explicit patch matrix (ops.im2col), re-laid into the parameter
-                                     layout by ops.permute4; BN backward = one reduce pass + one apply pass.
+                                     pixel-contracting TN GEMMs whose B operand is gathered from the image
+                                     (ops.conv_wgrad, no patch matrix), re-laid into the parameter layout by
+                                     ops.permute4; BN backward = one reduce pass + one apply pass.
 
 Weights are read from the flat parameter arena (fp32 masters) and re-laid into bf16 GEMM operands once per step.
 """
@@ -197,10 +198,8 @@ class SegHeadFn(torch.autograd.Function):
             dyc = bn.backward(d, y, d)                                              # in place: d(convT output)
             ops.colsum_bf16(dyc, convt.bias.grad)
             desc = ops.conv_desc(grid, (2 * grid[0], 2 * grid[1]), cout, TAPS_T_GRAD, s_mul=2)
-            cols = ops.im2col(dyc, desc, rows)                                      # [rows, 16*cout]
             stage = torch.zeros((cin, 16 * cout), dtype=F32, device=dev)
-            ops.gemm_tn(x_in, cols, stage)                                          # [ci][tap][co]
-            del cols
+            ops.conv_wgrad(x_in, dyc, desc, stage)                                  # [ci][tap][co]
             ops.permute4(stage, (16 * cout, 1, cout), (cin, cout, 16), convt.weight.grad, accumulate=True)
             wt = torch.empty((cin, 16 * cout), dtype=BF16, device=dev)              # [ci][tap][co] <- W[ci][co][tap]
             ops.permute4(convt.weight.detach(), (cout * 16, 1, 16), (cin, 16, cout), wt)
@@ -219,10 +218,8 @@ class SegHeadFn(torch.autograd.Function):
             ops.permute4(seq[3].weight.detach(), (1, mid), (mid, out_c), w2t)
             da1 = ops.gemm_nt(dy2, w2t)                                             # [M, mid]
             dy1 = bn1.backward(da1, y1, da1)
-            cols = ops.im2col(saved["taps"][i], d3, M)                              # [M, 9E]
             stage = torch.zeros((mid, 9 * E), dtype=F32, device=dev)
-            ops.gemm_tn(dy1, cols, stage)                                           # [co][tap][ci]
-            del cols
+            ops.conv_wgrad(dy1, saved["taps"][i], d3, stage)                        # [co][tap][ci]
             ops.permute4(stage, (9 * E, 1, E), (mid, E, 9), seq[0].weight.grad, accumulate=True)
             w1d = torch.empty((E, 9 * mid), dtype=BF16, device=dev)                 # [ci][tap][co] <- W[co][ci][tap]
             ops.permute4(seq[0].weight.detach(), (9, 1, E * 9), (E, 9, mid), w1d)

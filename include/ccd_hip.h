@@ -176,6 +176,11 @@ typedef struct ccd_conv_desc {
  * the statistics pass of F.batch_norm). */
 int ccd_conv_gemm(const ccd_bf16* src, long src_ld, const ccd_conv_desc* desc, const ccd_bf16* W, long ldw, int M, int N,
                   ccd_bf16* C, long ldc, const float* bias, float* colsum, float* colsumsq, void* stream);
+/* out[P, ntaps*cin] (fp32) += A[rows, P]^T . gather(src)[rows, ntaps*cin]: the weight gradient of the convolution
+ * `desc` describes, contracted over pixels and split over them (fp32 atomics); the patch matrix is never materialised.
+ * Conv2d: A = dY, src = layer input.  ConvTranspose2d: A = layer input, src = dY (desc of the data gradient). */
+int ccd_conv_wgrad(const ccd_bf16* A, long lda, int P, const ccd_bf16* src, long src_ld, const ccd_conv_desc* desc,
+                   long rows, float* out, long ldo, void* stream);
 /* cols[rows, ntaps*cin] = gather(src): explicit patch matrix for the weight gradients (TN GEMM operand). */
 int ccd_im2col(const ccd_bf16* src, long src_ld, const ccd_conv_desc* desc, long rows, ccd_bf16* cols, void* stream);
 /* Train-mode BatchNorm2d + ReLU (segmentor.py:43-44,83-84).  stats = [sum x | sum x^2] over `count` pixels (reduced

@@ -427,6 +427,11 @@ def check_conv_pieces(dev, seed=20):
     cols = ops.im2col(xr, d3, rows)
     ref_cols = F.unfold(x.float(), 3, padding=1).view(n, cin, 9, gh * gw).permute(0, 3, 2, 1).reshape(rows, 9 * cin)
     assert torch.equal(cols.float().cpu(), ref_cols), "im2col"
+    # --- weight gradient with the implicit patch matrix == TN GEMM against the explicit one
+    gy = rnd((rows, 24), g).to(BF).to(dev)
+    wg_impl = ops.conv_wgrad(gy, xr, d3, torch.zeros((24, 9 * cin), device=dev))
+    want_wg = gy.float().cpu().t() @ ref_cols
+    close(wg_impl, want_wg, 1e-3, 1e-2, "conv3x3/wgrad")
     # --- 3x3 data gradient: dX = conv_transpose(dY, W)
     dy = rnd((n, cout * 4, gh, gw), g).to(BF)                    # 64 channels (cin of the gradient gather)
     w2 = rnd((cout * 4, cin, 3, 3), g, 0.1)
@@ -459,6 +464,10 @@ def check_conv_pieces(dev, seed=20):
     din = ops.conv_gemm(dor, descg, wg, rows, torch.empty((rows, cin), dtype=BF, device=dev))
     ref = F.conv2d(dout.float(), wt2.to(BF).float(), stride=2, padding=1).permute(0, 2, 3, 1).reshape(rows, cin)
     close(din, ref, 1e-2, 5e-2, "convT/dgrad")
+    # transposed-conv weight gradient: dW[ci][tap][co] = sum_p x[p,ci] * dOut[gather(p,tap),co]
+    wg_t = ops.conv_wgrad(xr, dor, descg, torch.zeros((cin, 16 * 64), device=dev))
+    want = xr.float().cpu().t() @ ops.im2col(dor, descg, rows).float().cpu()
+    close(wg_t, want, 1e-3, 2e-2, "convT/wgrad")
     # --- BatchNorm + ReLU forward / backward
     C = 16
     xb = (rnd((rows, C), g) * 2 + 0.5).to(BF)
