@@ -23,6 +23,7 @@
         if (!(cond)) return (code); \
     } while (0)
 #define CCD_ALIGNED16(p) ((((uintptr_t)(p)) & 15u) == 0)
+#define CCD_MAX_OPERAND_BYTES 0x7ffffff0L
 
 template <bool TN>
 static int ccd_launch_gemm(const ccd::GemmParams& p, int epilogue, int splits, void* stream) {
@@ -108,6 +109,8 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
     if (M == 0 || N == 0) return CCD_OK;
     CCD_CHECK(M > 0 && N > 0 && K > 0, CCD_EINVAL);
     CCD_CHECK(K % 64 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, CCD_ESHAPE);
+    // the loaders address operands with 32-bit byte offsets below 2 GiB (buffer loads, see gemm.h)
+    CCD_CHECK(((long)M * lda + K) * 2 < CCD_MAX_OPERAND_BYTES && ((long)N * ldb + K) * 2 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
     CCD_CHECK(epilogue != CCD_EPI_GELU || (C2 && ldc2 % 8 == 0), CCD_EINVAL);
     CCD_CHECK(epilogue != CCD_EPI_RESID || (resid && ldr % 4 == 0 && rows_per_sample > 0), CCD_EINVAL);
     CCD_CHECK(epilogue != CCD_EPI_DGELU || (aux && ldaux % 8 == 0), CCD_EINVAL);
@@ -490,6 +493,11 @@ int ccd_conv_gemm(const ccd_bf16* src, long src_ld, const ccd_conv_desc* desc, c
     CCD_CHECK(M > 0 && N > 0, CCD_EINVAL);
     CCD_CHECK(N % 8 == 0 && src_ld % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && src_ld >= desc->cin, CCD_ESHAPE);
     CCD_CHECK(M % (1 << (desc->g_h_log2 + desc->g_w_log2)) == 0, CCD_ESHAPE);
+    {
+        const long images = M >> (desc->g_h_log2 + desc->g_w_log2);
+        CCD_CHECK(images * desc->s_h * desc->s_w * src_ld * 2 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
+        CCD_CHECK(((long)N * ldw + (long)desc->ntaps * desc->cin) * 2 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
+    }
     ccd::GemmParams p = ccd::GemmParams();
     p.A = src; p.lda = src_ld; p.B = W; p.ldb = ldw; p.M = M; p.N = N; p.K = desc->ntaps * desc->cin;
     p.C = C; p.ldc = ldc; p.bias = bias; p.rows_per_sample = 1; p.k_per_split = p.K; p.alpha = 1.0f; p.rows_mul = 1;
@@ -513,6 +521,8 @@ int ccd_conv_wgrad(const ccd_bf16* A, long lda, int P, const ccd_bf16* src, long
     CCD_CHECK(rows > 0 && rows < (1L << 31) && P > 0, CCD_EINVAL);
     CCD_CHECK(P % 8 == 0 && lda % 8 == 0 && src_ld % 8 == 0 && ldo % 4 == 0 && src_ld >= desc->cin, CCD_ESHAPE);
     CCD_CHECK(desc->g_w_log2 >= 2 && rows % (1 << (desc->g_h_log2 + desc->g_w_log2)) == 0, CCD_ESHAPE);
+    CCD_CHECK((rows >> (desc->g_h_log2 + desc->g_w_log2)) * desc->s_h * desc->s_w * src_ld * 2 < CCD_MAX_OPERAND_BYTES,
+              CCD_ESHAPE);
     const int tiles = ((P + 127) / 128) * ((Q + 127) / 128);
     int splits = (2 * ccd_rt_num_cus()) / tiles;
     if (splits < 1) splits = 1;

@@ -65,62 +65,56 @@ constexpr int GEMM_SMEM_BYTES = GEMM_BM * GEMM_CS_LD * 4;         // 67,584 B  (
 // ds_write_b64): fragment reads and NT staging writes conflict-free, TN staging writes 2-way.
 __device__ __forceinline__ int gemm_swz(int row, int slot) { return slot ^ (((row >> 1) ^ (row >> 4)) & 7); }
 
-// ---- NT staging: thread t moves 4 x 16 B per operand; 8 consecutive lanes cover one 128-B tile row (coalesced),
-// chunk i of thread t is tile row (t >> 3) + 32 i, slot t & 7.  Row validity is loop-invariant.
-struct NtCursor {
-    const bf16_t* ptr[4];
-    bool ok[4];
-    __device__ __forceinline__ void init(const bf16_t* base, long ld, int row0, int nrows, int k_begin) {
+// ---- operand loaders.  All global reads are 16-byte BUFFER loads (prelude: make_rsrc / buf_load16): the descriptor
+// is wave-uniform (base pointer advanced per k-tile in SGPRs), each thread keeps loop-invariant 32-bit byte offsets,
+// and every predicate - row beyond the matrix, conv tap outside the image, contraction tail, prefetch past the last
+// k-tile - is expressed as an out-of-range offset or an empty descriptor (hardware returns zeros), so the main loop
+// carries no exec-mask branches, no 64-bit pointer arithmetic and no zero-fill moves.
+//
+// NT staging: thread t moves 4 x 16 B per operand; 8 consecutive lanes cover one 128-B tile row (coalesced),
+// chunk i of thread t is tile row (t >> 3) + 32 i, slot t & 7.
+struct NtLoader {
+    unsigned off[4];
+    __device__ __forceinline__ void init(long ld, int row0, int nrows) {
         const int t = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = row0 + (t >> 3) + 32 * i;
-            ok[i] = row < nrows;
-            ptr[i] = base + (long)(ok[i] ? row : 0) * ld + k_begin + (t & 7) * 8;
+            off[i] = row < nrows ? (unsigned)(((long)row * ld + (t & 7) * 8) * 2) : BUF_OOB;
         }
     }
-    __device__ __forceinline__ void load(u32x4 (&r)[4]) {
+    __device__ __forceinline__ void load(buf_rsrc rs, u32x4 (&r)[4]) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok[i]) v = *reinterpret_cast<const u32x4*>(ptr[i]);
-            r[i] = v;
-            ptr[i] += GEMM_BK;
-        }
+        for (int i = 0; i < 4; ++i) r[i] = buf_load16(rs, off[i]);
     }
 };
-// gather variant of NtCursor for the implicit-GEMM convolutions (see GemmParams)
-struct GatherCursor {
-    const bf16_t* base;
-    int pix[4], pos[4];              // per chunk row: image base pixel index, (oy*s_mul) << 16 | (ox*s_mul)
-    int tap, c0;                     // wave-uniform position inside the contraction
+// gather variant of NtLoader for the implicit-GEMM convolutions (see GemmParams): the k-tile (tap, c0) is
+// wave-uniform, the tap's source pixel is per row
+struct GatherLoader {
+    unsigned pix[4];                 // per chunk row: element offset of the image's first pixel + this thread's slot
+    int pos[4];                      // (oy*s_mul) << 16 | (ox*s_mul); rows beyond the matrix: a y no image reaches
     __device__ __forceinline__ void init(const GemmParams& p, int row0) {
         const int t = threadIdx.x;
-        base = p.A + (t & 7) * 8;
-        tap = 0;
-        c0 = 0;
         const int hw = p.g_h_log2 + p.g_w_log2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = row0 + (t >> 3) + 32 * i;
             const int n = row >> hw, oy = (row >> p.g_w_log2) & ((1 << p.g_h_log2) - 1), ox = row & ((1 << p.g_w_log2) - 1);
-            pix[i] = n * p.s_h * p.s_w;
-            // rows beyond the matrix get a y coordinate no image reaches: their loads are skipped (zeros)
+            pix[i] = (unsigned)(n * p.s_h * p.s_w);
             pos[i] = row < p.M ? ((oy * p.s_mul) << 16) | (ox * p.s_mul) : (0x4000 << 16);
         }
     }
-    __device__ __forceinline__ void load(const GemmParams& p, u32x4 (&r)[4]) {
+    __device__ __forceinline__ void load(const GemmParams& p, buf_rsrc rs, int kt, u32x4 (&r)[4]) const {
+        const int k0 = kt * GEMM_BK, tap = (k0 / p.cin) & 15, c0 = k0 % p.cin;      // scalar (kt is wave-uniform)
         const int dy = (int)((p.dy_pack >> (4 * tap)) & 15ull) - 8, dx = (int)((p.dx_pack >> (4 * tap)) & 15ull) - 8;
+        const unsigned lane_c = (unsigned)(c0 + (threadIdx.x & 7) * 8);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int sy = (pos[i] >> 16) + dy, sx = (pos[i] & 0xffff) + dx;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if ((unsigned)sy < (unsigned)p.s_h && (unsigned)sx < (unsigned)p.s_w)
-                v = *reinterpret_cast<const u32x4*>(base + (long)(pix[i] + sy * p.s_w + sx) * p.lda + c0);
-            r[i] = v;
+            const bool ok = (unsigned)sy < (unsigned)p.s_h && (unsigned)sx < (unsigned)p.s_w;
+            const unsigned o = ((pix[i] + (unsigned)(sy * p.s_w + sx)) * (unsigned)p.lda + lane_c) * 2u;
+            r[i] = buf_load16(rs, ok ? o : BUF_OOB);
         }
-        c0 += GEMM_BK;
-        if (c0 >= p.cin) { c0 = 0; ++tap; }
     }
 };
 __device__ __forceinline__ void gemm_store_nt(char* tile, const u32x4 (&r)[4]) {
@@ -134,71 +128,58 @@ __device__ __forceinline__ void gemm_store_nt(char* tile, const u32x4 (&r)[4]) {
 // ---- TN staging: the tile is 64 contraction rows x 128 columns in memory.  Thread t owns column block cb = t & 15
 // (8 columns = 16 B) and contraction block mb = t >> 4 (4 rows): 16 consecutive lanes read 256 contiguous bytes of one
 // row (coalesced), the 4 x 8 block is transposed in registers, and store j writes tile row 8*cb + j, 8-byte chunk mb.
-struct TnCursor {
-    const bf16_t* ptr;
-    long ld;
-    bool col_ok;
-    __device__ __forceinline__ void init(const bf16_t* base, long ld_, int col0, int ncols, int k_begin) {
+// The descriptor of k-tile kt starts at that tile's first contraction row and ends at the slice's last one, so the
+// contraction tail reads zeros by itself.
+struct TnLoader {
+    unsigned off[4];
+    __device__ __forceinline__ void init(long ld, int col0, int ncols) {
         const int t = threadIdx.x;
         const int col = col0 + 8 * (t & 15);
-        ld = ld_;
-        col_ok = col < ncols;
-        ptr = base + (long)(k_begin + 4 * (t >> 4)) * ld_ + (col_ok ? col : 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            off[i] = col < ncols ? (unsigned)(((long)(4 * (t >> 4) + i) * ld + col) * 2) : BUF_OOB;
     }
-    // rows_left: contraction rows still available from this tile's first row (>= 64 for interior tiles)
-    __device__ __forceinline__ void load(u32x4 (&r)[4], int rows_left) {
-        const int mrow = 4 * (threadIdx.x >> 4);
-        if (rows_left >= GEMM_BK) {
+    __device__ __forceinline__ void load(buf_rsrc rs, u32x4 (&r)[4]) const {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (col_ok) v = *reinterpret_cast<const u32x4*>(ptr + i * ld);
-                r[i] = v;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (col_ok && mrow + i < rows_left) v = *reinterpret_cast<const u32x4*>(ptr + i * ld);
-                r[i] = v;
-            }
-        }
-        ptr += (long)GEMM_BK * ld;
+        for (int i = 0; i < 4; ++i) r[i] = buf_load16(rs, off[i]);
     }
 };
-// gather variant of TnCursor for the B operand: the weight gradient of a convolution contracts over pixels, B row r is
-// the patch vector of pixel r (column tap*cin + c), read straight from the source image instead of an im2col buffer.
+__device__ __forceinline__ buf_rsrc gemm_tn_rsrc(const bf16_t* base, long ld, int k_begin, int k_end, int kt) {
+    const long row = (long)k_begin + (long)kt * GEMM_BK;
+    long bytes = ((long)k_end - row) * ld * 2;
+    bytes = bytes < 0 ? 0 : (bytes > 0x7ffffff0L ? 0x7ffffff0L : bytes);
+    return make_rsrc(base + row * ld, (unsigned)bytes);
+}
+// gather variant for the B operand: the weight gradient of a convolution contracts over pixels, B row r is the patch
+// vector of pixel r (column tap*cin + c), read straight from the source image instead of an im2col buffer.
 // A thread's 8 columns lie inside one tap (cin % 8 == 0); its 4 contraction rows are 4 consecutive x positions of one
 // image row (grid width % 4 == 0).
-struct TnGatherCursor {
-    const bf16_t* base;
-    int prow, dy, dx;
+struct TnGatherLoader {
+    unsigned lane_c;
+    int dy, dx;
     bool col_ok;
-    __device__ __forceinline__ void init(const GemmParams& p, int col0, int ncols, int k_begin) {
-        const int t = threadIdx.x;
-        const int col = col0 + 8 * (t & 15);
+    __device__ __forceinline__ void init(const GemmParams& p, int col0, int ncols) {
+        const int col = col0 + 8 * (threadIdx.x & 15);
         col_ok = col < ncols;
-        const int tap = col_ok ? col / p.cin : 0, c = col_ok ? col % p.cin : 0;
+        const int tap = col_ok ? col / p.cin : 0;
+        lane_c = (unsigned)(col_ok ? col % p.cin : 0);
         dy = (int)((p.dy_pack >> (4 * tap)) & 15ull) - 8;
         dx = (int)((p.dx_pack >> (4 * tap)) & 15ull) - 8;
-        base = p.B + c;
-        prow = k_begin + 4 * (t >> 4);
     }
-    __device__ __forceinline__ void load(const GemmParams& p, u32x4 (&r)[4], int rows_left) {
-        const int mrow = 4 * (threadIdx.x >> 4);
+    __device__ __forceinline__ void load(const GemmParams& p, buf_rsrc rs, int k_begin, int k_end, int kt, u32x4 (&r)[4]) const {
+        const int prow = k_begin + kt * GEMM_BK + 4 * (threadIdx.x >> 4);
         const int hw = p.g_h_log2 + p.g_w_log2;
         const int n = prow >> hw, oy = (prow >> p.g_w_log2) & ((1 << p.g_h_log2) - 1), ox = prow & ((1 << p.g_w_log2) - 1);
         const int sy = oy * p.s_mul + dy;
-        const bool row_ok = col_ok && sy >= 0 && sy < p.s_h;
-        const bf16_t* src = base + ((long)n * p.s_h + sy) * p.s_w * p.ldb;
+        const bool row_ok = col_ok && (unsigned)sy < (unsigned)p.s_h;
+        const unsigned rowbase = (unsigned)((n * p.s_h + sy) * p.s_w);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int sx = (ox + i) * p.s_mul + dx;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (row_ok && mrow + i < rows_left && sx >= 0 && sx < p.s_w) v = *reinterpret_cast<const u32x4*>(src + (long)sx * p.ldb);
-            r[i] = v;
+            const bool ok = row_ok && prow + i < k_end && (unsigned)sx < (unsigned)p.s_w;
+            const unsigned o = ((rowbase + (unsigned)sx) * (unsigned)p.ldb + lane_c) * 2u;
+            r[i] = buf_load16(rs, ok ? o : BUF_OOB);
         }
-        prow += GEMM_BK;
     }
 };
 __device__ __forceinline__ void gemm_store_tn(char* tile, const u32x4 (&r)[4]) {
@@ -305,34 +286,31 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     // Two register sets hold the k-tiles t+1 and t+2 while tile t is multiplied out of LDS: global loads are issued
     // TWO iterations ahead of the LDS write that consumes them (the CU keeps ~2 x 32 KiB per workgroup in flight).
     u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
-    NtCursor nta, ntb;
-    TnCursor tna, tnb;
-    GatherCursor gta;
-    TnGatherCursor tgb;
+    NtLoader nta, ntb;
+    TnLoader tna, tnb;
+    GatherLoader gta;
+    TnGatherLoader tgb;
     if (TN) {
-        tna.init(p.A, p.lda, m0, p.M, k_begin);
-        if (GATHER) tgb.init(p, n0, p.N, k_begin);
-        else tnb.init(p.B, p.ldb, n0, p.N, k_begin);
+        tna.init(p.lda, m0, p.M);
+        if (GATHER) tgb.init(p, n0, p.N);
+        else tnb.init(p.ldb, n0, p.N);
     } else {
         if (GATHER) gta.init(p, m0);
-        else nta.init(p.A, p.lda, m0, p.M, k_begin);
-        ntb.init(p.B, p.ldb, n0, p.N, k_begin);
+        else nta.init(p.lda, m0, p.M);
+        ntb.init(p.ldb, n0, p.N);
     }
-    int next_tile = 0;                                      // tiles are fetched strictly in order
-    auto load = [&](u32x4 (&ra)[4], u32x4 (&rb)[4]) {
-        if (next_tile < nk) {
-            if (TN) {
-                const int left = k_end - (k_begin + next_tile * GEMM_BK);
-                tna.load(ra, left);
-                if (GATHER) tgb.load(p, rb, left);
-                else tnb.load(rb, left);
-            } else {
-                if (GATHER) gta.load(p, ra);
-                else nta.load(ra);
-                ntb.load(rb);
-            }
+    // k-tile kt -> registers.  Tiles past the last one (the prefetch runs two ahead) get an empty descriptor: zeros.
+    auto load = [&](int kt, u32x4 (&ra)[4], u32x4 (&rb)[4]) {
+        const unsigned whole = kt < nk ? BUF_OOB : 0u;      // "whole buffer": every valid offset is below BUF_OOB
+        if (TN) {
+            tna.load(gemm_tn_rsrc(p.A, p.lda, k_begin, kt < nk ? k_end : k_begin, kt), ra);
+            if (GATHER) tgb.load(p, make_rsrc(p.B, whole), k_begin, k_end, kt, rb);
+            else tnb.load(gemm_tn_rsrc(p.B, p.ldb, k_begin, kt < nk ? k_end : k_begin, kt), rb);
+        } else {
+            if (GATHER) gta.load(p, make_rsrc(p.A, whole), kt, ra);
+            else nta.load(make_rsrc(p.A + k_begin + kt * GEMM_BK, whole), ra);
+            ntb.load(make_rsrc(p.B + k_begin + kt * GEMM_BK, whole), rb);
         }
-        ++next_tile;
     };
     auto store = [&](int stage, const u32x4 (&ra)[4], const u32x4 (&rb)[4]) {
         char* as = smem + stage * 2 * GEMM_STAGE_BYTES;
@@ -364,20 +342,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         }
     };
 
-    load(ra0, rb0);                                         // tile 0
-    if (nk > 0) store(0, ra0, rb0);
-    load(ra1, rb1);                                         // tile 1 -> set 1
-    load(ra0, rb0);                                         // tile 2 -> set 0
+    // Branch-free steady state: LDS writes and loads past the last k-tile move zeros, an odd tile count multiplies one
+    // all-zero stage.  (A multi-exit loop made the register allocator shuttle all 64 accumulator registers between two
+    // homes every iteration - v_mov chains that wait on the MFMA results.)
+    load(0, ra0, rb0);
+    load(1, ra1, rb1);
+    store(0, ra0, rb0);
+    load(2, ra0, rb0);
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
         compute(0);                                         // tile kt (even) lives in stage 0
-        if (kt + 1 < nk) store(1, ra1, rb1);
-        load(ra1, rb1);                                     // tile kt + 3
+        store(1, ra1, rb1);                                 // tile kt + 1
+        load(kt + 3, ra1, rb1);
         __syncthreads();
-        if (kt + 1 >= nk) break;
         compute(1);                                         // tile kt + 1
-        if (kt + 2 < nk) store(0, ra0, rb0);
-        load(ra0, rb0);                                     // tile kt + 4
+        store(0, ra0, rb0);                                 // tile kt + 2
+        load(kt + 4, ra0, rb0);
         __syncthreads();
     }
 

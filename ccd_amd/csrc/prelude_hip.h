@@ -36,6 +36,18 @@ __device__ __forceinline__ f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hw_bf16x8, a), __builtin_bit_cast(hw_bf16x8, b),
                                                    c, 0, 0, 0);
 }
+// Buffer addressing (guide T8/T20): a 128-bit resource descriptor built from wave-uniform values + a 32-bit per-lane
+// byte offset.  A lane whose offset is >= the descriptor's byte count reads zeros WITHOUT touching memory - the GEMM
+// loaders turn every row / tap / tail predicate into that (offset = BUF_OOB), so their loads need no exec-mask branches.
+typedef __attribute__((ext_vector_type(4))) unsigned buf_u32x4;
+typedef __amdgpu_buffer_rsrc_t buf_rsrc;
+constexpr unsigned BUF_OOB = 0x80000000u;       // offsets of valid elements stay below 2 GiB (checked by the ABI)
+__device__ __forceinline__ buf_rsrc make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ buf_u32x4 buf_load16(buf_rsrc r, unsigned byte_offset) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_offset, 0, 0);
+}
 // hardware float -> bf16 (RNE): clang lowers the __bf16 casts to v_cvt_pk_bf16_f32 on gfx950
 typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {

@@ -133,6 +133,16 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 inline char* dynamic_smem() { return sim::curblk->dyn_smem; }
+// buffer addressing: out-of-range lanes read zeros (prelude_hip.h)
+typedef __attribute__((ext_vector_type(4))) unsigned buf_u32x4;
+struct buf_rsrc { const char* base; unsigned bytes; };
+constexpr unsigned BUF_OOB = 0x80000000u;
+inline buf_rsrc make_rsrc(const void* base, unsigned bytes) { return buf_rsrc{reinterpret_cast<const char*>(base), bytes}; }
+inline buf_u32x4 buf_load16(buf_rsrc r, unsigned byte_offset) {
+    buf_u32x4 v = {0u, 0u, 0u, 0u};
+    if ((unsigned long long)byte_offset + 16ull <= (unsigned long long)r.bytes) std::memcpy(&v, r.base + byte_offset, 16);
+    return v;
+}
 inline int lane_id() { return sim::cur->lane; }
 inline int wave_id() { return sim::cur->wave; }
 
