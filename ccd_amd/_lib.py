@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libccd_hip.so")
+LIB_PATH = os.environ.get("CCD_HIP_LIB") or os.path.join(_HERE, "libccd_hip.so")   # override: lab builds (tools/gemm_lab.py)
 
 _handle = None            # ctypes.CDLL once loaded
 _stream_override = None   # tests of the ABI may pin the stream argument

@@ -25,10 +25,17 @@
 #define CCD_ALIGNED16(p) ((((uintptr_t)(p)) & 15u) == 0)
 #define CCD_MAX_OPERAND_BYTES 0x7ffffff0L
 
+// persistent grid: one workgroup per resident slot (2 per CU), never more than there are work items
+static int ccd_gemm_grid(ccd::GemmParams& p, int tiles, int splits) {
+    p.work_items = tiles * splits;
+    const int cap = 2 * ccd_rt_num_cus();
+    return p.work_items < cap ? p.work_items : cap;
+}
+
 template <bool TN>
-static int ccd_launch_gemm(const ccd::GemmParams& p, int epilogue, int splits, void* stream) {
+static int ccd_launch_gemm(ccd::GemmParams p, int epilogue, int splits, void* stream) {
     const int tiles = ((p.M + ccd::GEMM_BM - 1) / ccd::GEMM_BM) * ((p.N + ccd::GEMM_BN - 1) / ccd::GEMM_BN);
-    const dim3 grid(tiles * splits), block(256);
+    const dim3 grid(ccd_gemm_grid(p, tiles, splits)), block(256);
     const size_t smem = ccd::GEMM_SMEM_BYTES;
     switch (epilogue) {
         case CCD_EPI_BF16: CCD_LAUNCH((ccd::gemm_bf16_kernel<TN, ccd::EPI_BF16>), grid, block, smem, stream, p); break;
@@ -505,8 +512,8 @@ int ccd_conv_gemm(const ccd_bf16* src, long src_ld, const ccd_conv_desc* desc, c
     ccd_fill_gather(p, desc);
     p.c_map = desc->c_map; p.c_py = desc->c_py; p.c_px = desc->c_px;
     const int tiles = ((M + ccd::GEMM_BM - 1) / ccd::GEMM_BM) * ((N + ccd::GEMM_BN - 1) / ccd::GEMM_BN);
-    CCD_LAUNCH((ccd::gemm_bf16_kernel<false, ccd::EPI_BF16, true>), dim3(tiles), dim3(256), (size_t)ccd::GEMM_SMEM_BYTES,
-               stream, p);
+    CCD_LAUNCH((ccd::gemm_bf16_kernel<false, ccd::EPI_BF16, true>), dim3(ccd_gemm_grid(p, tiles, 1)), dim3(256),
+               (size_t)ccd::GEMM_SMEM_BYTES, stream, p);
     return ccd_rt_last_error();
 }
 
@@ -533,7 +540,7 @@ int ccd_conv_wgrad(const ccd_bf16* A, long lda, int P, const ccd_bf16* src, long
     p.A = A; p.lda = lda; p.B = src; p.ldb = src_ld; p.M = P; p.N = Q; p.K = (int)rows;
     p.C = out; p.ldc = ldo; p.rows_per_sample = 1; p.k_per_split = per; p.alpha = 1.0f; p.rows_mul = 1;
     ccd_fill_gather(p, desc);
-    CCD_LAUNCH((ccd::gemm_bf16_kernel<true, ccd::EPI_ATOMIC, true>), dim3(tiles * splits), dim3(256),
+    CCD_LAUNCH((ccd::gemm_bf16_kernel<true, ccd::EPI_ATOMIC, true>), dim3(ccd_gemm_grid(p, tiles, splits)), dim3(256),
                (size_t)ccd::GEMM_SMEM_BYTES, stream, p);
     return ccd_rt_last_error();
 }

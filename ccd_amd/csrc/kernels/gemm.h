@@ -42,6 +42,7 @@ struct GemmParams {
     long ldaux;
     int k_per_split;        // TN: contraction rows handled by one blockIdx.z slice (multiple of 64)
     int m_fastest;          // tile order: 0 = column tiles fastest, 1 = row tiles fastest
+    int work_items;         // tiles x splits (the persistent grid may be smaller)
     float alpha;            // scales acc before the epilogue
     float* colsum;          // optional [N] fp32: += column sums of the (final) output tile, e.g. the bias gradient
     float* colsumsq;        // optional [N] fp32: += column sums of squares (BatchNorm batch statistics), EPI_BF16 only
@@ -243,9 +244,13 @@ __device__ __forceinline__ void gemm_epilogue_row8(const GemmParams& p, int gm, 
     }
 }
 
+// Persistent kernel: the grid is min(work items, 2 per CU); a workgroup walks its XCD's share of the (tile, split)
+// items.  While the accumulators of one tile go through the epilogue, the first two k-tiles of the NEXT tile are already
+// in flight (their registers are free by then), the epilogue's global stores drain under the next main loop, and the
+// ~2.5 us launch-to-first-MFMA latency of a workgroup is paid once per CU slot instead of once per tile.
 template <bool TN, int EPI, bool GATHER = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
-    const int m_static = p.M;                               // the launch grid was sized for the static shape
+    const int m_static = p.M;                               // the work list was built for the static shape
     if (p.d_rows) {
         const int dyn = p.d_rows[0] * p.rows_mul;
         if (TN) p.K = dyn < p.K ? dyn : p.K;
@@ -256,32 +261,38 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     const int wm = w >> 1, wn = w & 1;
 
     const int tiles_m = (m_static + GEMM_BM - 1) / GEMM_BM, tiles_n = (p.N + GEMM_BN - 1) / GEMM_BN;
-    // 1-D grid of tiles x splits.  After the XCD remap consecutive ids share an XCD (= an L2): for NT these are the
-    // column tiles of one A row-panel, for TN all output tiles of ONE contraction slice, which stream the same
-    // dY / X rows at the same time - the re-reads are then L2 hits instead of HBM traffic.
+    // Work items = tiles x splits, numbered so that consecutive ids share work: for NT the column tiles of one A
+    // row-panel, for TN all output tiles of ONE contraction slice (they stream the same dY / X rows).  XCD x (the
+    // hardware sends workgroup b to XCD b % 8) owns one contiguous range of ids, its workgroups take them round-robin,
+    // so neighbours run at the same time on the same L2 and the re-reads are L2 hits instead of HBM traffic.
     const unsigned ntile = (unsigned)(tiles_m * tiles_n);
-    const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
-    const unsigned tile = lin % ntile, split = lin / ntile;
-    int tm, tn;
-    if (p.m_fastest) { tm = tile % tiles_m; tn = tile / tiles_m; }
-    else { tn = tile % tiles_n; tm = tile / tiles_n; }
-    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
-    if (m0 >= p.M) return;                                  // only possible with a device-side row count
+    const unsigned total = (unsigned)p.work_items, G = gridDim.x;
+    const unsigned ng = G < 8u ? G : 8u;                                       // XCDs that received workgroups
+    const unsigned xcd = blockIdx.x % ng, slot = blockIdx.x / ng;
+    const unsigned nx = G / ng + (xcd < G % ng ? 1u : 0u);                     // workgroups on this XCD
+    const unsigned q8 = total / ng, r8 = total % ng;
+    const unsigned base_x = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const unsigned cnt_x = q8 + (xcd < r8 ? 1u : 0u);
+    if (slot >= cnt_x) return;
 
-    int k_begin = 0, k_end = p.K;
-    if (TN) {
-        k_begin = split * p.k_per_split;
-        k_end = k_begin + p.k_per_split < p.K ? k_begin + p.k_per_split : p.K;
-    }
-    const int nk = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    int m0, n0, k_begin, k_end, nk;
+    auto decode = [&](unsigned item) {
+        const unsigned lin = base_x + item;
+        const unsigned tile = lin % ntile, split = lin / ntile;
+        int tm, tn;
+        if (p.m_fastest & 1) { tm = tile % tiles_m; tn = tile / tiles_m; }
+        else { tn = tile % tiles_n; tm = tile / tiles_n; }
+        m0 = tm * GEMM_BM;
+        n0 = tn * GEMM_BN;
+        k_begin = 0;
+        k_end = p.K;
+        if (TN) {
+            k_begin = split * p.k_per_split;
+            k_end = k_begin + p.k_per_split < p.K ? k_begin + p.k_per_split : p.K;
+        }
+        nk = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
+        if (!TN && m0 >= p.M) nk = 0;                       // only possible with a device-side row count
+    };
 
     // Two register sets hold the k-tiles t+1 and t+2 while tile t is multiplied out of LDS: global loads are issued
     // TWO iterations ahead of the LDS write that consumes them (the CU keeps ~2 x 32 KiB per workgroup in flight).
@@ -290,15 +301,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     TnLoader tna, tnb;
     GatherLoader gta;
     TnGatherLoader tgb;
-    if (TN) {
-        tna.init(p.lda, m0, p.M);
-        if (GATHER) tgb.init(p, n0, p.N);
-        else tnb.init(p.ldb, n0, p.N);
-    } else {
-        if (GATHER) gta.init(p, m0);
-        else nta.init(p.lda, m0, p.M);
-        ntb.init(p.ldb, n0, p.N);
-    }
+    auto init_loaders = [&]() {
+        if (TN) {
+            tna.init(p.lda, m0, p.M);
+            if (GATHER) tgb.init(p, n0, p.N);
+            else tnb.init(p.ldb, n0, p.N);
+        } else {
+            if (GATHER) gta.init(p, m0);
+            else nta.init(p.lda, m0, p.M);
+            ntb.init(p.ldb, n0, p.N);
+        }
+    };
     // k-tile kt -> registers.  Tiles past the last one (the prefetch runs two ahead) get an empty descriptor: zeros.
     auto load = [&](int kt, u32x4 (&ra)[4], u32x4 (&rb)[4]) {
         const unsigned whole = kt < nk ? BUF_OOB : 0u;      // "whole buffer": every valid offset is below BUF_OOB
@@ -318,22 +331,23 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         if (TN) { gemm_store_tn(as, ra); gemm_store_tn(bs, rb); }
         else { gemm_store_nt(as, ra); gemm_store_nt(bs, rb); }
     };
+    f32x16 acc[2][2];
     auto compute = [&](int stage) {
         const char* as = smem + stage * 2 * GEMM_STAGE_BYTES;
         const char* bs = as + GEMM_STAGE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const int slot = 2 * kk + (lane >> 5);
+            const int slot16 = 2 * kk + (lane >> 5);
             bf16x8 a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = 64 * wm + 32 * i + (lane & 31);
-                a[i] = *reinterpret_cast<const bf16x8*>(as + row * 128 + gemm_swz(row, slot) * 16);
+                a[i] = *reinterpret_cast<const bf16x8*>(as + row * 128 + gemm_swz(row, slot16) * 16);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int row = 64 * wn + 32 * j + (lane & 31);
-                b[j] = *reinterpret_cast<const bf16x8*>(bs + row * 128 + gemm_swz(row, slot) * 16);
+                b[j] = *reinterpret_cast<const bf16x8*>(bs + row * 128 + gemm_swz(row, slot16) * 16);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -341,96 +355,127 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16_bf16(a[i], b[j], acc[i][j]);
         }
     };
+#ifdef CCD_GEMM_LAB     // timing ablations (tools/gemm_lab.py): bits of m_fastest switch phases off
+    const int lab = p.m_fastest;
+#define LAB_ON(bit) (!(lab & (bit)))
+#else
+#define LAB_ON(bit) true
+#endif
 
-    // Branch-free steady state: LDS writes and loads past the last k-tile move zeros, an odd tile count multiplies one
-    // all-zero stage.  (A multi-exit loop made the register allocator shuttle all 64 accumulator registers between two
-    // homes every iteration - v_mov chains that wait on the MFMA results.)
+    unsigned item = slot;
+    decode(item);
+    init_loaders();
     load(0, ra0, rb0);
     load(1, ra1, rb1);
-    store(0, ra0, rb0);
-    load(2, ra0, rb0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-        compute(0);                                         // tile kt (even) lives in stage 0
-        store(1, ra1, rb1);                                 // tile kt + 1
-        load(kt + 3, ra1, rb1);
+    while (true) {
+        store(0, ra0, rb0);
+        load(2, ra0, rb0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
         __syncthreads();
-        compute(1);                                         // tile kt + 1
-        store(0, ra0, rb0);                                 // tile kt + 2
-        load(kt + 4, ra0, rb0);
+        // Branch-free steady state: LDS writes and loads past the last k-tile move zeros, an odd tile count multiplies
+        // one all-zero stage.  (A multi-exit loop made the register allocator shuttle all 64 accumulator registers
+        // between two homes every iteration - v_mov chains that wait on the MFMA results.)
+        for (int kt = 0; kt < nk; kt += 2) {
+            if (LAB_ON(8)) compute(0);                      // tile kt (even) lives in stage 0
+            if (LAB_ON(16)) store(1, ra1, rb1);             // tile kt + 1
+            if (LAB_ON(32)) load(kt + 3, ra1, rb1);
+            __syncthreads();
+            if (LAB_ON(8)) compute(1);                      // tile kt + 1
+            if (LAB_ON(16)) store(0, ra0, rb0);             // tile kt + 2
+            if (LAB_ON(32)) load(kt + 4, ra0, rb0);
+            __syncthreads();
+        }
+        // ---- next work item: its first two k-tiles fly while this tile's accumulators are written out
+        const int em0 = m0, en0 = n0;
+        const unsigned next = item + nx;
+        const bool has_next = next < cnt_x;
+        if (has_next) {
+            decode(next);
+            init_loaders();
+            load(0, ra0, rb0);
+            load(1, ra1, rb1);
+        }
+        if (LAB_ON(4) || p.alpha == 12345.f) {
+        // ---- epilogue: accumulators -> fp32 LDS tile -> row-contiguous 8-wide global accesses
+        float* cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int col = 64 * wn + 32 * j + (lane & 31);
+                    cs[row * GEMM_CS_LD + col] = acc[i][j][r] * p.alpha;
+                }
         __syncthreads();
-    }
-
-    // ---- epilogue: accumulators -> fp32 LDS tile -> row-contiguous 8-wide global accesses
-    float* cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int col = 64 * wn + 32 * j + (lane & 31);
-                cs[row * GEMM_CS_LD + col] = acc[i][j][r] * p.alpha;
-            }
-    __syncthreads();
-    if (EPI == EPI_ATOMIC) {     // 64 consecutive lanes -> 64 consecutive floats of one row: one 256-B atomic burst
-        const int col = t & 127, gn = n0 + col;
-        if (gn < p.N) {
+        if (EPI == EPI_ATOMIC) {     // 64 consecutive lanes -> 64 consecutive floats of one row: one 256-B atomic burst
+            const int col = t & 127, gn = en0 + col;
+            if (gn < p.N) {
 #pragma unroll 4
-            for (int row = t >> 7; row < GEMM_BM; row += 2) {
-                const int gm = m0 + row;
-                if (gm < p.M) atomicAdd(reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn, cs[row * GEMM_CS_LD + col]);
+                for (int row = t >> 7; row < GEMM_BM; row += 2) {
+                    const int gm = em0 + row;
+                    if (gm < p.M) atomicAdd(reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn, cs[row * GEMM_CS_LD + col]);
+                }
             }
-        }
-        return;
-    }
-    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float csq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        } else {
+            float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float csq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int pass = 0; pass < 8; ++pass) {
-        const int row = pass * 16 + (t >> 4), col = (t & 15) * 8;
-        const int gm = m0 + row, gn = n0 + col;
-        if (gm < p.M && gn < p.N) {
-            float v[8];
-            const f32x4v c0 = *reinterpret_cast<const f32x4v*>(cs + row * GEMM_CS_LD + col);
-            const f32x4v c1 = *reinterpret_cast<const f32x4v*>(cs + row * GEMM_CS_LD + col + 4);
-            v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
-            v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
-            int gm_out = gm;
-            if (GATHER && p.c_map) {          // transposed-conv parity class: scatter to the 2x upsampled grid
-                const int hw = p.g_h_log2 + p.g_w_log2;
-                const int n = gm >> hw, oy = (gm >> p.g_w_log2) & ((1 << p.g_h_log2) - 1), ox = gm & ((1 << p.g_w_log2) - 1);
-                gm_out = (((n << (p.g_h_log2 + 1)) + 2 * oy + p.c_py) << (p.g_w_log2 + 1)) + 2 * ox + p.c_px;
+            for (int pass = 0; pass < 8; ++pass) {
+                const int row = pass * 16 + (t >> 4), col = (t & 15) * 8;
+                const int gm = em0 + row, gn = en0 + col;
+                if (gm < p.M && gn < p.N) {
+                    float v[8];
+                    const f32x4v c0 = *reinterpret_cast<const f32x4v*>(cs + row * GEMM_CS_LD + col);
+                    const f32x4v c1 = *reinterpret_cast<const f32x4v*>(cs + row * GEMM_CS_LD + col + 4);
+                    v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
+                    v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+                    int gm_out = gm;
+                    if (GATHER && p.c_map) {          // transposed-conv parity class: scatter to the 2x upsampled grid
+                        const int hw = p.g_h_log2 + p.g_w_log2;
+                        const int n = gm >> hw, oy = (gm >> p.g_w_log2) & ((1 << p.g_h_log2) - 1), ox = gm & ((1 << p.g_w_log2) - 1);
+                        gm_out = (((n << (p.g_h_log2 + 1)) + 2 * oy + p.c_py) << (p.g_w_log2 + 1)) + 2 * ox + p.c_px;
+                    }
+                    if (LAB_ON(2)) gemm_epilogue_row8<EPI>(p, gm_out, gn, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * v[e]; }
+                }
             }
-            gemm_epilogue_row8<EPI>(p, gm_out, gn, v);
+            if (EPI == EPI_BF16 && p.colsumsq) {
+                __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * v[e]; }
+                for (int e = 0; e < 8; ++e) cs[(t >> 4) * GEMM_BN + (t & 15) * 8 + e] = csq[e];
+                __syncthreads();
+                if (t < GEMM_BN && en0 + t < p.N) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) a += cs[q * GEMM_BN + t];
+                    atomicAdd(p.colsumsq + en0 + t, a);
+                }
+            }
+            if ((EPI == EPI_DGELU || EPI == EPI_BF16) && p.colsum) {   // block-wide column sums -> one atomic per column
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs[(t >> 4) * GEMM_BN + (t & 15) * 8 + e] = csum[e];
+                __syncthreads();
+                if (t < GEMM_BN && en0 + t < p.N) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) a += cs[q * GEMM_BN + t];
+                    atomicAdd(p.colsum + en0 + t, a);
+                }
+            }
         }
-    }
-    if (EPI == EPI_BF16 && p.colsumsq) {
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 8; ++e) cs[(t >> 4) * GEMM_BN + (t & 15) * 8 + e] = csq[e];
-        __syncthreads();
-        if (t < GEMM_BN && n0 + t < p.N) {
-            float a = 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) a += cs[q * GEMM_BN + t];
-            atomicAdd(p.colsumsq + n0 + t, a);
         }
-    }
-    if ((EPI == EPI_DGELU || EPI == EPI_BF16) && p.colsum) {     // block-wide column sums of the tile -> one atomic per column
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 8; ++e) cs[(t >> 4) * GEMM_BN + (t & 15) * 8 + e] = csum[e];
-        __syncthreads();
-        if (t < GEMM_BN && n0 + t < p.N) {
-            float a = 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) a += cs[q * GEMM_BN + t];
-            atomicAdd(p.colsum + n0 + t, a);
-        }
+        if (!has_next) break;
+        item = next;
+        __syncthreads();                                    // the staging tile is read out: LDS belongs to the stages again
     }
 }
 
