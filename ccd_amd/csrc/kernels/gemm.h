@@ -362,6 +362,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 #define LAB_ON(bit) true
 #endif
 
+#ifdef CCD_GEMM_LAB     // lab bit 64: per-phase cycle totals of wave 0 of each workgroup -> p.colsum (8 u64 per workgroup)
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#define LAB_STAMP(i) if (lab & 64) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph[i] += tn_ - tprev; tprev = tn_; }
+#else
+#define LAB_STAMP(i)
+#endif
     unsigned item = slot;
     decode(item);
     init_loaders();
@@ -376,19 +383,29 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        LAB_STAMP(0)
         __syncthreads();
+        LAB_STAMP(1)
         // Branch-free steady state: LDS writes and loads past the last k-tile move zeros, an odd tile count multiplies
         // one all-zero stage.  (A multi-exit loop made the register allocator shuttle all 64 accumulator registers
         // between two homes every iteration - v_mov chains that wait on the MFMA results.)
         for (int kt = 0; kt < nk; kt += 2) {
             if (LAB_ON(8)) compute(0);                      // tile kt (even) lives in stage 0
+            LAB_STAMP(2)
             if (LAB_ON(16)) store(1, ra1, rb1);             // tile kt + 1
+            LAB_STAMP(3)
             if (LAB_ON(32)) load(kt + 3, ra1, rb1);
+            LAB_STAMP(4)
             __syncthreads();
+            LAB_STAMP(1)
             if (LAB_ON(8)) compute(1);                      // tile kt + 1
+            LAB_STAMP(2)
             if (LAB_ON(16)) store(0, ra0, rb0);             // tile kt + 2
+            LAB_STAMP(3)
             if (LAB_ON(32)) load(kt + 4, ra0, rb0);
+            LAB_STAMP(4)
             __syncthreads();
+            LAB_STAMP(1)
         }
         // ---- next work item: its first two k-tiles fly while this tile's accumulators are written out
         const int em0 = m0, en0 = n0;
@@ -400,9 +417,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
             load(0, ra0, rb0);
             load(1, ra1, rb1);
         }
+        LAB_STAMP(5)
         if (LAB_ON(4) || p.alpha == 12345.f) {
         // ---- epilogue: accumulators -> fp32 LDS tile -> row-contiguous 8-wide global accesses
         float* cs = reinterpret_cast<float*>(smem);
+        if (p.alpha != 1.0f) {                               // wave-uniform: 64 multiplies only when asked for
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= p.alpha;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -411,9 +437,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
                 for (int r = 0; r < 16; ++r) {
                     const int row = 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const int col = 64 * wn + 32 * j + (lane & 31);
-                    cs[row * GEMM_CS_LD + col] = acc[i][j][r] * p.alpha;
+                    cs[row * GEMM_CS_LD + col] = acc[i][j][r];
                 }
+        LAB_STAMP(6)
         __syncthreads();
+        LAB_STAMP(1)
         if (EPI == EPI_ATOMIC) {     // 64 consecutive lanes -> 64 consecutive floats of one row: one 256-B atomic burst
             const int col = t & 127, gn = en0 + col;
             if (gn < p.N) {
@@ -426,6 +454,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         } else {
             float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             float csq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const bool want_stats = p.colsum != nullptr || p.colsumsq != nullptr;
 #pragma unroll 1
             for (int pass = 0; pass < 8; ++pass) {
                 const int row = pass * 16 + (t >> 4), col = (t & 15) * 8;
@@ -443,8 +472,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
                         gm_out = (((n << (p.g_h_log2 + 1)) + 2 * oy + p.c_py) << (p.g_w_log2 + 1)) + 2 * ox + p.c_px;
                     }
                     if (LAB_ON(2)) gemm_epilogue_row8<EPI>(p, gm_out, gn, v);
+                    if ((EPI == EPI_DGELU || EPI == EPI_BF16) && want_stats) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * v[e]; }
+                        for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * v[e]; }
+                    }
                 }
             }
             if (EPI == EPI_BF16 && p.colsumsq) {
@@ -459,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
                     atomicAdd(p.colsumsq + en0 + t, a);
                 }
             }
-            if ((EPI == EPI_DGELU || EPI == EPI_BF16) && p.colsum) {   // block-wide column sums -> one atomic per column
+            if ((EPI == EPI_DGELU || EPI == EPI_BF16) && p.colsum && LAB_ON(64)) {   // block-wide column sums -> one atomic per column
                 __syncthreads();
 #pragma unroll
                 for (int e = 0; e < 8; ++e) cs[(t >> 4) * GEMM_BN + (t & 15) * 8 + e] = csum[e];
@@ -473,10 +504,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
             }
         }
         }
+        LAB_STAMP(7)
         if (!has_next) break;
         item = next;
         __syncthreads();                                    // the staging tile is read out: LDS belongs to the stages again
+        LAB_STAMP(1)
     }
+#ifdef CCD_GEMM_LAB
+    if ((lab & 64) && p.colsum && t == 0)
+        for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(p.colsum)[blockIdx.x * 8 + i] = ph[i];
+#endif
 }
 
 }  // namespace ccd

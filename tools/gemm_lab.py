@@ -21,7 +21,8 @@ else:
     a = torch.randn(P, K, device=dev).to(BF); b = torch.randn(Q, K, device=dev).to(BF)
     out = torch.empty(P, Q, device=dev, dtype=BF)
     mf = int(os.environ.get("LAB_MFAST", "0"))
-    fn = lambda: ops.gemm_nt(a, b, out=out, m_fastest=mf)
+    stamps = torch.zeros(8 * 1024 * 2, device=dev) if mf & 64 else None          # 8 u64 per workgroup (lab build)
+    fn = lambda: ops.gemm_nt(a, b, out=out, m_fastest=mf, colsum=stamps)
 for _ in range(iters):
     fn()
 torch.cuda.synchronize()
@@ -33,3 +34,12 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
 print(f"{kind} {P}x{Q}x{K}: {ms:.4f} ms  {2.0 * P * Q * K / ms / 1e9:.1f} TFLOP/s")
+
+if kind == "nt" and mf & 64:
+    st = stamps.view(torch.int64).view(-1, 8)[:512].double().cpu()
+    names = ["prologue", "barrier", "compute", "lds-store", "load-issue", "next-prefetch", "epi-stage", "epi-global"]
+    tot = st.sum(1).mean().item()
+    print("per-workgroup cycles (wave 0, mean over workgroups), s_memtime ticks:")
+    for i, n in enumerate(names):
+        print(f"  {n:14s} {st[:, i].mean().item():12.0f}  {100 * st[:, i].mean().item() / tot:5.1f} %")
+    print(f"  total          {tot:12.0f}")
