@@ -455,8 +455,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
             float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             float csq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const bool want_stats = p.colsum != nullptr || p.colsumsq != nullptr;
-#pragma unroll 1
-            for (int pass = 0; pass < 8; ++pass) {
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {       // unrolled: the 16 LDS reads go out first, the stores stream
                 const int row = pass * 16 + (t >> 4), col = (t & 15) * 8;
                 const int gm = em0 + row, gn = en0 + col;
                 if (gm < p.M && gn < p.N) {

@@ -128,6 +128,52 @@ def _dp_step_worker(rank, world, port):
     dist.destroy_process_group()
 
 
+def _syncbn_worker(rank, world, port):
+    """Native SegHead with SyncBatchNorm on 2 ranks (one image each) == one process on both images: same logits,
+    same running statistics, and the ranks' weight gradients sum to the full-batch gradient."""
+    _init(rank, world, port)
+    import copy
+    from backends import Backend
+    import kernel_checks as kc
+    from ccd_amd import seghead as sh
+    from ccd_amd.modules.segmentor import SegHead
+    with Backend("sim") as b:
+        torch.manual_seed(5)
+        E = 64
+        head = SegHead(in_channels=E)
+        with torch.no_grad():
+            for m in head.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+        ref = copy.deepcopy(head).float()
+        g = torch.Generator().manual_seed(9)
+        taps = [kc.rnd((2 * 256, E), g).to(kc.BF) for _ in range(3)]
+        dl = kc.rnd((2, 2, 32, 128), g) / 4096
+        # single-process reference on both images (torch fp32 library ops)
+        rin = [t.float().view(2, 8, 32, E).permute(0, 3, 1, 2).contiguous() for t in taps]
+        want = ref.cls(ref.unpool2(ref.unpool1(ref.mlahead(*rin))))
+        want.backward(dl)
+        # this rank's shard through the HIP path with synchronised statistics
+        head = torch.nn.SyncBatchNorm.convert_sync_batchnorm(head)
+        mine = [t[rank * 256:(rank + 1) * 256].clone().requires_grad_(True) for t in taps]
+        logits = sh.seg_head_forward(head, mine, 1)
+        kc.close(logits, want[rank:rank + 1], 3e-2, 3e-2, "syncbn/logits")
+        logits.backward(dl[rank:rank + 1])
+        refp, refb = dict(ref.named_parameters()), dict(ref.named_buffers())
+        for name, buf in head.named_buffers():
+            if not name.startswith("conv_mla") and "num_batches" not in name:
+                kc.close(buf, refb[name], 2e-2, 2e-3, f"syncbn/{name}")
+        for name, p in head.named_parameters():
+            if name.startswith("conv_mla") or name in ("unpool1.0.bias", "unpool2.0.bias"):
+                continue
+            total = p.grad.clone()
+            dist.all_reduce(total)
+            c = kc._cos(total, refp[name].grad)
+            ratio = float(total.norm() / refp[name].grad.norm())
+            assert c > 0.99 and 0.95 < ratio < 1.05, (name, c, ratio)
+    dist.destroy_process_group()
+
+
 def _spawn(fn, port):
     mp.spawn(fn, args=(2, port), nprocs=2, join=True)
 
@@ -142,3 +188,7 @@ def test_center_all_reduce_world2():
 
 def test_data_parallel_iteration_world2():
     _spawn(_dp_step_worker, 29613)
+
+
+def test_seghead_syncbn_world2():
+    _spawn(_syncbn_worker, 29614)
