@@ -46,6 +46,18 @@ def cpu_baseline(arch, steps=2):
             "sample": f"{arch} B=8 fp32, {steps} timed steps after 1 warm-up, median {sec:.2f} s/step (oracle/ccd_oracle.py)"}
 
 
+def pmc_traffic(kind, a):
+    """HBM bytes per launch of the dominant GEMM kind from the committed PMC passes of this same command
+    (tools/pmc_traffic.sh -> profiles/pmc_traffic.json; counters cannot be read from inside the process).
+    Only valid for the default workload the passes were taken on; otherwise null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    if not os.path.isfile(path) or a.arch != "vit_small" or a.batch != 256:
+        return None
+    with open(path) as f:
+        rec = json.load(f).get(kind)
+    return rec["bytes_per_launch"] if rec else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,7 +153,7 @@ def main():
             achieved = d["flops"] / d["launches"] / avg_ms / 1e9
             line["roofline"] = {"bound": "mfma", "kernel": f"ccd::gemm_bf16_kernel ({key})",
                                 "achieved": round(achieved, 1), "peak": PEAK_BF16_TF, "unit": "TFLOP/s",
-                                "frac": round(achieved / PEAK_BF16_TF, 4), "traffic": None,
+                                "frac": round(achieved / PEAK_BF16_TF, 4), "traffic": pmc_traffic(key, a),
                                 "avg_launch_ms": round(avg_ms, 4), "launches_per_step": d["launches"] // a.steps,
                                 "gemm_ms_per_step": round(sum(v["ms"] for v in summ.values()) / a.steps, 3),
                                 "by_kind_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in sorted(summ.items())}}

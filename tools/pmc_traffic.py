@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Per-launch HBM traffic of the GEMM kinds from two rocprofv3 --pmc passes over bench.py (FETCH_SIZE, WRITE_SIZE).
+
+Corrections, as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes:
+  * both counters are reported in KiB -> x 1024;
+  * on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced streaming reads -> x 2;
+  * WRITE_SIZE is uncalibrated -> calibrated here on a kernel of the SAME run whose byte counts are known exactly:
+    ccd::ln_fwd_kernel over R x E fp32 rows reads 4*R*E B and writes 2*R*E + 8*R B (R = 131072, E = 384 at B = 256).
+    The same kernel also cross-checks the FETCH correction (reported as fetch_check, expected 1.0).
+Output: JSON {kind: {launches, fetch_bytes, write_bytes, bytes_per_launch}} for bench.py's `roofline.traffic`.
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+csv.field_size_limit(1 << 30)
+KINDS = {"<false, 0, false>": "gemm_nt_bf16", "<false, 1, false>": "gemm_nt_gelu", "<false, 2, false>": "gemm_nt_resid",
+         "<false, 3, false>": "gemm_nt_f32", "<true, 4, false>": "gemm_tn_atomic", "<false, 5, false>": "gemm_nt_dgelu",
+         "<false, 0, true>": "conv_gemm", "<true, 4, true>": "conv_wgrad", "<true, 3, false>": "gemm_tn_f32"}
+
+
+def collect(path, counter):
+    per = collections.defaultdict(list)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            name = r["Kernel_Name"]
+            if "gemm_bf16_kernel" in name:
+                m = re.search(r"gemm_bf16_kernel(<[^>]*>)", name)
+                key = KINDS.get(m.group(1), m.group(1)) if m else "gemm?"
+            elif "ln_fwd_kernel" in name:
+                key = "ln_fwd"
+            else:
+                continue
+            per[key].append(float(r["Counter_Value"]))
+    return per
+
+
+def steady(vals):
+    """bench.py ran 1 warm-up + 2 timed steps: keep the last two thirds of the launches."""
+    n = len(vals)
+    return vals[n // 3:]
+
+
+fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+R, E = 131072, 384
+ln_read, ln_write = 4.0 * R * E, 2.0 * R * E + 8.0 * R
+ln_f = sum(steady(fetch["ln_fwd"])) / len(steady(fetch["ln_fwd"])) * 1024 * 2
+ln_w = sum(steady(write["ln_fwd"])) / len(steady(write["ln_fwd"])) * 1024
+wcal = ln_write / ln_w
+out = {"_method": {"fetch": "FETCH_SIZE[KiB] * 1024 * 2 (gfx950 128-B requests tallied as 64 B)",
+                   "write": f"WRITE_SIZE[KiB] * 1024 * {wcal:.4f} (calibrated on ccd::ln_fwd_kernel, known {ln_write:.0f} B)",
+                   "fetch_check": round(ln_f / ln_read, 4), "source": [sys.argv[1].split("gpurun_out/")[-1],
+                                                                        sys.argv[2].split("gpurun_out/")[-1]]}}
+for k in sorted(fetch):
+    if k == "ln_fwd":
+        continue
+    fv, wv = steady(fetch[k]), steady(write.get(k, [0.0]))
+    fb = sum(fv) / len(fv) * 1024 * 2
+    wb = sum(wv) / len(wv) * 1024 * wcal
+    out[k] = {"launches": len(fv), "fetch_bytes": round(fb), "write_bytes": round(wb), "bytes_per_launch": round(fb + wb)}
+print(json.dumps(out, indent=1))
