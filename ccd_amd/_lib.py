@@ -32,7 +32,7 @@ SIGNATURES = {
     "ccd_attention_fwd": [P, P, P, I, I, F, P],
     "ccd_attention_bwd": [P, P, P, P, P, P, I, I, F, P],
     "ccd_patch_embed_fwd": [P, P, P, P, P, I, I, P],
-    "ccd_patch_embed_bwd": [P, P, P, P, P, I, I, P],
+    "ccd_patch_embed_bwd": [P, P, P, P, P, P, P, I, I, P],
     "ccd_small_matmul_f32": [P, P, P, I, I, I, I, I, P],
     "ccd_colsum_bf16": [P, L, I, I, P, I, P, P],
     "ccd_mirror_bf16": [P, I, I, P],

@@ -228,17 +228,31 @@ int ccd_patch_embed_fwd(const float* img, const float* w, const float* bias, con
     CCD_LAUNCH(ccd::patch_embed_fwd_kernel, dim3(views * ccd::PE_GH), dim3(128), 0, stream, img, w, bias, pos, out, E);
     return ccd_rt_last_error();
 }
-int ccd_patch_embed_bwd(const float* img, const float* g, float* d_w, float* d_bias, float* d_pos, int views, int E,
-                        void* stream) {
-    CCD_CHECK(img && g && d_w && d_bias && d_pos, CCD_EINVAL);
+int ccd_patch_embed_bwd(const float* img, const float* g, float* d_w, float* d_bias, float* d_pos, ccd_bf16* ws_g,
+                        ccd_bf16* ws_patches, int views, int E, void* stream) {
+    CCD_CHECK(img && g && d_w && d_bias && d_pos && ws_g && ws_patches, CCD_EINVAL);
+    CCD_CHECK(CCD_ALIGNED16(g) && CCD_ALIGNED16(img) && CCD_ALIGNED16(ws_g) && CCD_ALIGNED16(ws_patches), CCD_EINVAL);
     if (views == 0) return CCD_OK;
-    CCD_CHECK(views > 0 && E > 0, CCD_EINVAL);
-    int vpb = (views * ccd::PE_GH + 4 * ccd_rt_num_cus() - 1) / (4 * ccd_rt_num_cus());
-    if (vpb < 1) vpb = 1;
-    const int groups = (views + vpb - 1) / vpb;
-    CCD_LAUNCH(ccd::patch_embed_bwd_kernel, dim3(groups * ccd::PE_GH), dim3(128), 0, stream, img, g, d_w, d_bias, d_pos,
-               views, vpb, E);
-    return ccd_rt_last_error();
+    CCD_CHECK(views > 0 && E > 0 && E % 8 == 0, CCD_ESHAPE);
+    const int threads = 256 * (E / 4);
+    int slices = (4 * ccd_rt_num_cus() * 256 + threads - 1) / threads;       // ~4 workgroups per CU in total
+    if (slices > views) slices = views;
+    const int vps = (views + slices - 1) / slices;
+    slices = (views + vps - 1) / vps;
+    CCD_LAUNCH(ccd::pos_grad_cast_kernel, dim3((threads + 255) / 256, slices), dim3(256), 0, stream, g, d_pos, ws_g, views,
+               E, vps);
+    int rc = ccd_rt_last_error();
+    if (rc != CCD_OK) return rc;
+    const long tokens = 256L * views;
+    CCD_CHECK(tokens < (1L << 31), CCD_ESHAPE);
+    rc = ccd_colsum_bf16(ws_g, E, (int)tokens, E, nullptr, 1, d_bias, stream);
+    if (rc != CCD_OK) return rc;
+    CCD_LAUNCH(ccd::patch_rows_kernel, dim3((unsigned)((tokens * 12 + 255) / 256)), dim3(256), 0, stream, img, ws_patches,
+               tokens);
+    rc = ccd_rt_last_error();
+    if (rc != CCD_OK) return rc;
+    return ccd_gemm_tn(ws_g, E, ws_patches, ccd::PE_K, E, ccd::PE_K, (int)tokens, CCD_EPI_ATOMIC, d_w, ccd::PE_K, 1.0f, 0,
+                       nullptr, 1, stream);
 }
 int ccd_small_matmul_f32(const float* A, const float* B, float* C, int M, int N, int K, int trans_a, int accumulate,
                          void* stream) {

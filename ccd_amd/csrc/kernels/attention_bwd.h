@@ -123,7 +123,7 @@ __global__ __launch_bounds__(512) void attention_bwd_dq_kernel(const bf16_t* __r
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = fast_exp(s[r] * scale - my_lse);
+            const float p = fast_exp2(fmaf(s[r], scale * 1.4426950408889634f, -my_lse * 1.4426950408889634f));
             s[r] = p * (dp[r] - dsum) * scale;
         }
 #pragma unroll
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(512) void attention_bwd_dkv_kernel(const bf16_t* __
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qq = 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * hf;
-            const float p = fast_exp(s[r] * scale - lse_s[qq]);
+            const float p = fast_exp2(fmaf(s[r], scale * 1.4426950408889634f, -lse_s[qq] * 1.4426950408889634f));
             s[r] = p;
             dp[r] = p * (dp[r] - del_s[qq]) * scale;
         }

@@ -105,11 +105,12 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16_t* __rest
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
         mx = fmaxf(mx, shfl_xor(mx, 32));
         float sum = 0.f;
+        const float c2 = scale * 1.4426950408889634f, mc2 = mx * c2;       // exp(x) = 2^(x log2 e): one FMA + v_exp_f32
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = fast_exp((s[kt][r] - mx) * scale);
+                const float p = fast_exp2(fmaf(s[kt][r], c2, -mc2));
                 s[kt][r] = p;
                 sum += p;
             }

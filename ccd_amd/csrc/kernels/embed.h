@@ -41,56 +41,66 @@ __global__ __launch_bounds__(128) void patch_embed_fwd_kernel(const float* __res
     }
 }
 
-// d_w[e,k] += sum_tok g[tok,e]*patch[tok,k]; d_bias[e] += sum g; d_pos[tok,e] += sum_views g   (fp32 atomics)
-// one workgroup = one patch row (py) of `views_per_block` consecutive views
-__global__ __launch_bounds__(128) void patch_embed_bwd_kernel(const float* __restrict__ img, const float* __restrict__ g,
-                                                              float* __restrict__ d_w, float* __restrict__ d_bias,
-                                                              float* __restrict__ d_pos, int views,
-                                                              int views_per_block, int E) {
-    __shared__ float px[3][PE_PATCH][PE_GW * PE_PATCH];
-    const int py = blockIdx.x % PE_GH;
-    const int v0 = (blockIdx.x / PE_GH) * views_per_block;
-    const int v1 = v0 + views_per_block < views ? v0 + views_per_block : views;
-    for (int e0 = 0; e0 < E; e0 += blockDim.x) {
-        const int e = e0 + threadIdx.x;
-        float dw[PE_K];
-        float dp[PE_GW];
-        float db = 0.f;
+// Backward of the patch embedding, as three streaming passes + one MFMA product (host: ccd_patch_embed_bwd):
+//   pos_grad_cast_kernel : d_pos[tok,e] += sum_views g[view,tok,e]  and  gb = bf16(g)       (one read of g)
+//   colsum_bf16_kernel   : d_bias += column sums of gb
+//   patch_rows_kernel    : patches[tok, c*16 + r*4 + x] = bf16(img[view, c, 4*py + r, 4*px + x])  (im2col, K = 48)
+//   gemm_bf16_kernel<TN> : d_w[E,48] += gb^T . patches
+// thread = (token, 4 consecutive channels), blockIdx.y = slice of the views; 4 loads in flight
+__global__ __launch_bounds__(256) void pos_grad_cast_kernel(const float* __restrict__ g, float* __restrict__ d_pos,
+                                                            bf16_t* __restrict__ gb, int views, int E,
+                                                            int views_per_slice) {
+    const int e4 = E >> 2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 256 * e4) return;
+    const int tok = i / e4, e = (i % e4) * 4;
+    const int v0 = blockIdx.y * views_per_slice;
+    const int v1 = v0 + views_per_slice < views ? v0 + views_per_slice : views;
+    const long stride = 256L * E;
+    const long base = (long)tok * E + e;
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    int v = v0;
+    for (; v + 3 < v1; v += 4) {
+        f32x4v x[4];
 #pragma unroll
-        for (int k = 0; k < PE_K; ++k) dw[k] = 0.f;
+        for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const f32x4v*>(g + base + (v + u) * stride);
 #pragma unroll
-        for (int k = 0; k < PE_GW; ++k) dp[k] = 0.f;
-        for (int view = v0; view < v1; ++view) {
-            __syncthreads();
-            const float* src = img + (long)view * 3 * 32 * 128;
-            for (int i = threadIdx.x; i < 3 * 4 * 128; i += blockDim.x) {
-                const int c = i / 512, r = (i / 128) % 4, x = i % 128;
-                px[c][r][x] = src[(long)c * 4096 + (py * 4 + r) * 128 + x];
-            }
-            __syncthreads();
-            if (e < E) {
-#pragma unroll
-                for (int tx = 0; tx < PE_GW; ++tx) {
-                    const float gv = g[((long)view * 256 + py * PE_GW + tx) * E + e];
-                    db += gv;
-                    dp[tx] += gv;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-#pragma unroll
-                            for (int x = 0; x < 4; ++x) dw[c * 16 + r * 4 + x] += gv * px[c][r][tx * 4 + x];
-                }
-            }
-        }
-        if (e < E) {
-#pragma unroll
-            for (int k = 0; k < PE_K; ++k) atomicAdd(d_w + (long)e * PE_K + k, dw[k]);
-            atomicAdd(d_bias + e, db);
-#pragma unroll
-            for (int tx = 0; tx < PE_GW; ++tx) atomicAdd(d_pos + (long)(py * PE_GW + tx) * E + e, dp[tx]);
+        for (int u = 0; u < 4; ++u) {
+            acc += x[u];
+            u32x2 o;
+            o.x = pack_bf2(x[u].x, x[u].y);
+            o.y = pack_bf2(x[u].z, x[u].w);
+            *reinterpret_cast<u32x2*>(gb + base + (v + u) * stride) = o;
         }
     }
+    for (; v < v1; ++v) {
+        const f32x4v x = *reinterpret_cast<const f32x4v*>(g + base + v * stride);
+        acc += x;
+        u32x2 o;
+        o.x = pack_bf2(x.x, x.y);
+        o.y = pack_bf2(x.z, x.w);
+        *reinterpret_cast<u32x2*>(gb + base + v * stride) = o;
+    }
+    atomicAdd(d_pos + base, acc.x);
+    atomicAdd(d_pos + base + 1, acc.y);
+    atomicAdd(d_pos + base + 2, acc.z);
+    atomicAdd(d_pos + base + 3, acc.w);
+}
+
+// thread = (token, channel c, patch row r): 4 pixels (16 B) in, 4 bf16 (8 B) out
+__global__ __launch_bounds__(256) void patch_rows_kernel(const float* __restrict__ img, bf16_t* __restrict__ patches,
+                                                         long tokens) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= tokens * 12) return;
+    const long tok = i / 12;
+    const int cr = (int)(i % 12), c = cr >> 2, r = cr & 3;
+    const long view = tok >> 8;
+    const int py = (int)(tok >> 5) & 7, px = (int)tok & 31;
+    const f32x4v v = *reinterpret_cast<const f32x4v*>(img + ((view * 3 + c) * 32 + py * 4 + r) * 128 + px * 4);
+    u32x2 o;
+    o.x = pack_bf2(v.x, v.y);
+    o.y = pack_bf2(v.z, v.w);
+    *reinterpret_cast<u32x2*>(patches + tok * PE_K + c * 16 + r * 4) = o;
 }
 
 // C[M,N] (+)= A . B with A [M,K] (or A^T when trans_a: A stored [K,M]), B [K,N], all fp32; tiny problems only

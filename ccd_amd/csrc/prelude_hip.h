@@ -56,6 +56,7 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 }
 __device__ __forceinline__ unsigned short cvt_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // bare v_exp_f32
 __device__ __forceinline__ float fast_rcp(float x) { return __frcp_rn(x); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return rsqrtf(x); }
 }  // namespace ccd

@@ -349,10 +349,12 @@ class DinoLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_loss):
         s_logits, t_logits, center, stats = ctx.saved_tensors
-        d_logits = torch.zeros(s_logits.shape, dtype=BF16, device=s_logits.device)
+        park = ctx.park_grad and s_logits.dtype == F32
+        # parked gradients are only read through the device-side row count: rows past 2M need no zero fill (436 MB)
+        d_logits = (torch.empty if park else torch.zeros)(s_logits.shape, dtype=BF16, device=s_logits.device)
         ops.dino_loss_bwd(s_logits, t_logits, center, ctx.d_total, ctx.temps[0], ctx.temps[1], stats, 1.0, d_logits,
                           d_grad_scale=d_loss.contiguous().float())      # upstream gradient stays a device scalar
-        if ctx.park_grad and s_logits.dtype == F32:                      # see _BF16_LOGIT_GRADS
+        if park:                                                         # see _BF16_LOGIT_GRADS
             _BF16_LOGIT_GRADS[s_logits.data_ptr()] = d_logits
             d_logits = torch.zeros((), dtype=F32, device=s_logits.device).expand(s_logits.shape)
         return d_logits, None, None, None, None, None, None

@@ -166,7 +166,11 @@ def patch_embed_fwd(img, w, bias, pos, out=None):
 
 def patch_embed_bwd(img, g, d_w, d_bias, d_pos):
     views, E = img.shape[0], g.shape[-1]
-    _call("ccd_patch_embed_bwd", _lib.ptr(img), _lib.ptr(g), _lib.ptr(d_w), _lib.ptr(d_bias), _lib.ptr(d_pos), views, E)
+    assert img.dtype == F32 and img.is_contiguous() and g.dtype == F32 and g.is_contiguous()
+    ws_g = torch.empty((views * 256, E), dtype=BF16, device=g.device)
+    ws_p = torch.empty((views * 256, 48), dtype=BF16, device=g.device)
+    _call("ccd_patch_embed_bwd", _lib.ptr(img), _lib.ptr(g), _lib.ptr(d_w), _lib.ptr(d_bias), _lib.ptr(d_pos),
+          _lib.ptr(ws_g), _lib.ptr(ws_p), views, E)
 
 
 def small_matmul(a, b, out, trans_a=False, accumulate=False):

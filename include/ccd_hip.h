@@ -76,9 +76,11 @@ int ccd_attention_bwd(const ccd_bf16* qkv, const ccd_bf16* out, const ccd_bf16* 
  * img [views,3,32,128] fp32 NCHW; w [E,3,4,4]; pos [256,E] = the bicubically resampled pos_embed; out fp32 [views*256,E] */
 int ccd_patch_embed_fwd(const float* img, const float* w, const float* bias, const float* pos, float* out, int views,
                         int E, void* stream);
-/* g = d(out); d_w, d_bias, d_pos are ACCUMULATED (fp32 atomics) */
-int ccd_patch_embed_bwd(const float* img, const float* g, float* d_w, float* d_bias, float* d_pos, int views, int E,
-                        void* stream);
+/* g = d(out) fp32 [views*256,E]; d_w [E,48], d_bias [E], d_pos [256,E] are ACCUMULATED (fp32 atomics).
+ * Caller-provided workspaces: ws_g bf16 [views*256, E] (receives bf16(g)), ws_patches bf16 [views*256, 48].
+ * d_w = bf16(g)^T . bf16(patches) on the MFMA path (TN GEMM), d_bias = column sums of bf16(g). */
+int ccd_patch_embed_bwd(const float* img, const float* g, float* d_w, float* d_bias, float* d_pos, ccd_bf16* ws_g,
+                        ccd_bf16* ws_patches, int views, int E, void* stream);
 /* C[M,N] (+)= op(A) . B, fp32, tiny problems (bicubic pos-embed resampling = fixed 256x256 linear map, vit.py:182-201) */
 int ccd_small_matmul_f32(const float* A, const float* B, float* C, int M, int N, int K, int trans_a, int accumulate,
                          void* stream);

@@ -236,6 +236,7 @@ inline unsigned short cvt_bf16(float f) {          // round-to-nearest-even, NaN
 }
 inline unsigned cvt_pk_bf16(float lo, float hi) { return (unsigned)cvt_bf16(lo) | ((unsigned)cvt_bf16(hi) << 16); }
 inline float fast_exp(float x) { return std::exp(x); }
+inline float fast_exp2(float x) { return std::exp2(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 inline float fast_rsqrt(float x) { return 1.0f / std::sqrt(x); }
 }  // namespace ccd
