@@ -60,7 +60,7 @@ __device__ __forceinline__ void att_stage_transposed(const bf16_t* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, int heads, float scale) {
     char* smem = dynamic_smem();
     char* k_img = smem;
@@ -85,56 +85,70 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16_t* __rest
         for (int kk = 0; kk < 4; ++kk)
             qf[kk] = *reinterpret_cast<const bf16x8*>(q_base + (long)q * row_stride + 16 * kk + 8 * hf);
 
-        f32x16 s[8];
-#pragma unroll
-        for (int kt = 0; kt < 8; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-            const int row = 32 * kt + lq;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int slot = (2 * kk + hf) ^ ((row >> 1) & 7);
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_img + row * 128 + slot * 16);
-                s[kt] = mfma_32x32x16_bf16(kf, qf[kk], s[kt]);
-            }
-        }
-        float mx = -3.0e38f;
-#pragma unroll
-        for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
-        mx = fmaxf(mx, shfl_xor(mx, 32));
-        float sum = 0.f;
-        const float c2 = scale * 1.4426950408889634f, mc2 = mx * c2;       // exp(x) = 2^(x log2 e): one FMA + v_exp_f32
-#pragma unroll
-        for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = fast_exp2(fmaf(s[kt][r], c2, -mc2));
-                s[kt][r] = p;
-                sum += p;
-            }
-        sum += shfl_xor(sum, 32);
-
+        // Two key chunks of 128 with a running (max, sum): half the score registers of a single pass - the one-pass
+        // version needed all 512 registers (and spilled), i.e. ONE workgroup per CU.
         f32x16 o[2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        const float c2 = scale * 1.4426950408889634f;                  // exp(x) = 2^(x log2 e): one FMA + v_exp_f32
+        float mx = -3.0e38f, sum = 0.f;
+#pragma unroll 1
+        for (int ch = 0; ch < 2; ++ch) {
+            f32x16 s[4];
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt) {
+            for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 pf;
+                for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+                const int row = 128 * ch + 32 * kt + lq;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pf[e] = (short)f2bf(s[kt][8 * s2 + e]);
-                const int ks = 2 * kt + s2;
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int slot = (2 * kk + hf) ^ ((row >> 1) & 7);
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_img + row * 128 + slot * 16);
+                    s[kt] = mfma_32x32x16_bf16(kf, qf[kk], s[kt]);
+                }
+            }
+            float cm = -3.0e38f;
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const int d = 32 * dt + lq;
-                    const int slot = (2 * ks + hf) ^ (d & 15);
-                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vt_img + d * 512 + slot * 16);
-                    o[dt] = mfma_32x32x16_bf16(vf, pf, o[dt]);
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cm = fmaxf(cm, s[kt][r]);
+            cm = fmaxf(cm, shfl_xor(cm, 32));
+            const float nm = fmaxf(mx, cm);
+            const float alpha = fast_exp2((mx - nm) * c2);            // 0 for the first chunk
+            mx = nm;
+            const float mc2 = nm * c2;
+            float csum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = fast_exp2(fmaf(s[kt][r], c2, -mc2));
+                    s[kt][r] = p;
+                    csum += p;
+                }
+            csum += shfl_xor(csum, 32);
+            sum = sum * alpha + csum;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pf[e] = (short)f2bf(s[kt][8 * s2 + e]);
+                    const int ks = 2 * (4 * ch + kt) + s2;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const int d = 32 * dt + lq;
+                        const int slot = (2 * ks + hf) ^ (d & 15);
+                        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vt_img + d * 512 + slot * 16);
+                        o[dt] = mfma_32x32x16_bf16(vf, pf, o[dt]);
+                    }
                 }
             }
         }
