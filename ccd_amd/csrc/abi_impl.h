@@ -8,6 +8,7 @@
 #include "kernels/gemm.h"
 #include "kernels/gemm_ares.h"
 #include "kernels/gemm_nt32.h"
+#include "kernels/gemm256.h"
 #include "kernels/layernorm.h"
 #include "kernels/attention_fwd.h"
 #include "kernels/attention_bwd.h"
@@ -95,6 +96,23 @@ static void ccd_reduce_geometry(long rows, int N, int* cgn_log2, int* col_blocks
     *rows_per_block = (int)rpb;
     *row_blocks = (int)((rows + rpb - 1) / rpb);
 }
+static bool ccd_env_flag(const char* name, bool dflt);
+// 256x256-tile LDS-DMA kernel for the large-M products (gemm256.h): one workgroup per CU
+static int ccd_launch_gemm256(const ccd::GemmParams& p, int epilogue, void* stream) {
+    const int tiles = ((p.M + ccd::G256_BM - 1) / ccd::G256_BM) * ((p.N + ccd::G256_BN - 1) / ccd::G256_BN);
+    const int cus = ccd_rt_num_cus();
+    const dim3 grid(tiles < cus ? tiles : cus), block(ccd::G256_THREADS);
+    const size_t smem = ccd::G256_SMEM_BYTES;
+    switch (epilogue) {
+        case CCD_EPI_BF16: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_BF16>), grid, block, smem, stream, p); break;
+        case CCD_EPI_GELU: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_GELU>), grid, block, smem, stream, p); break;
+        case CCD_EPI_RESID: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_RESID>), grid, block, smem, stream, p); break;
+        case CCD_EPI_F32: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_F32>), grid, block, smem, stream, p); break;
+        case CCD_EPI_DGELU: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_DGELU>), grid, block, smem, stream, p); break;
+        default: return CCD_EINVAL;
+    }
+    return ccd_rt_last_error();
+}
 static bool ccd_env_flag(const char* name, bool dflt) {
     const char* v = getenv(name);
     return v ? (v[0] != '0') : dflt;
@@ -128,6 +146,12 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
     p.k_per_split = K; p.m_fastest = m_fastest; p.alpha = alpha; p.d_rows = d_rows; p.rows_mul = rows_mul;
     p.colsum = colsum;
     // kernel choice (all three are parity-tested): CCD_GEMM_NT32=0 / CCD_GEMM_ARES=1 switch variants for A/B timing
+    // read per call (not cached): the tests flip these to force small problems through the 256^2 kernel
+    const bool use_256 = ccd_env_flag("CCD_GEMM_256", true);
+    const int min_m_256 = getenv("CCD_GEMM_256_MIN_M") ? atoi(getenv("CCD_GEMM_256_MIN_M")) : 2048;
+    const int min_n_256 = getenv("CCD_GEMM_256_MIN_N") ? atoi(getenv("CCD_GEMM_256_MIN_N")) : 512;
+    if (use_256 && epilogue != CCD_EPI_ATOMIC && M >= min_m_256 && N >= min_n_256)
+        return ccd_launch_gemm256(p, epilogue, stream);
     static const bool use_nt32 = ccd_env_flag("CCD_GEMM_NT32", false);
     static const bool use_ares = ccd_env_flag("CCD_GEMM_ARES", false);
     const bool ares_epi = epilogue == CCD_EPI_BF16 || epilogue == CCD_EPI_GELU || epilogue == CCD_EPI_RESID ||

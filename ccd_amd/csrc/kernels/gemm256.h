@@ -1,0 +1,243 @@
+// gemm256.h - the large-M NT GEMM: 256x256 output tile, 8 waves (2 x 4, 128x64 per wave), BK = 64, operands staged
+// by LDS-DMA (global_load_lds, prelude: glds16) into two 64-KiB LDS buffers, one workgroup per CU.
+//
+// Why a second NT kernel next to gemm.h's 128x128 tile: measured on MI355X (profiles/) the 128^2
+// structure tops out near 850 TFLOP/s - per MFMA it moves too many bytes through the CU's single memory pipe and the
+// LDS (both ~30 % busy, serialised with the MFMA phase), and its register-staged operands cost a ds_write pass and
+// 32 VGPRs.  Here a wave owns 4 x 2 accumulator tiles (6 fragment reads per 8 MFMAs instead of 4 per 4), a k-tile of
+// 64 KiB feeds 4x the MFMAs of the 128^2 tile's 32 KiB, and the DMA writes LDS without touching VGPRs.
+//
+// LDS image: rows of 128 B (64 bf16), 1-KiB chunks of 8 rows written lane-linearly by one wave instruction; the
+// 16-byte slot swizzle of gemm.h (gemm_swz) is applied on the SOURCE address (lane (r, p) fetches slot p ^ f(r)), so the
+// fragment reads stay conflict-free.  Rows beyond the matrix are clamped to the last valid row (their products land in
+// rows / columns the epilogue never stores).
+//
+// Ordering: the DMA of k-tile t+1 is issued at the top of iteration t into the buffer last read in iteration t-1 (all
+// its ds_reads retired before that iteration's closing barrier); `s_waitcnt vmcnt(0)` + barrier at the bottom of
+// iteration t publish it.  Epilogue: four 64-row passes through a 64-KiB staging image in the second buffer (bf16 for
+// the bf16 / GELU-pair outputs, fp32 otherwise), then the same fused row epilogues as gemm.h (bias / GELU pair /
+// residual + DropPath / fp32 / gelu'(u) with column sums); the NEXT tile's first k-tile already streams into buffer 0.
+#pragma once
+
+namespace ccd {
+
+constexpr int G256_BM = 256, G256_BN = 256, G256_BK = 64, G256_THREADS = 512;
+constexpr int G256_OPERAND_BYTES = G256_BM * G256_BK * 2;            // 32 KiB per operand and buffer
+constexpr int G256_SMEM_BYTES = 4 * G256_OPERAND_BYTES;             // 2 buffers x (A + B) = 128 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) {
+    const int m_static = p.M;                               // the work list is built for the static shape
+    if (p.d_rows) {                                         // device-side row count: tiles past it are skipped
+        const int dyn = p.d_rows[0] * p.rows_mul;
+        p.M = dyn < p.M ? dyn : p.M;
+    }
+    char* smem = dynamic_smem();
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, hf = lane >> 5, lq = lane & 31;
+    const int wm = w >> 2, wn = w & 3;
+    const int tiles_m = (m_static + G256_BM - 1) / G256_BM, tiles_n = (p.N + G256_BN - 1) / G256_BN;
+    const unsigned total = (unsigned)(tiles_m * tiles_n), G = gridDim.x;
+    // XCD-partitioned work list (see gemm.h): consecutive tiles = the column tiles of one A row-panel
+    const unsigned ng = G < 8u ? G : 8u;
+    const unsigned xcd = blockIdx.x % ng, slot = blockIdx.x / ng;
+    const unsigned nx = G / ng + (xcd < G % ng ? 1u : 0u);
+    const unsigned q8 = total / ng, r8 = total % ng;
+    const unsigned base_x = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const unsigned cnt_x = q8 + (xcd < r8 ? 1u : 0u);
+    const int nk = p.K / G256_BK;
+
+    // fragment byte offsets inside an operand image (loop invariant)
+    int a_off[4][4], b_off[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 128 * wm + 32 * i + lq;
+            a_off[i][kk] = row * 128 + gemm_swz(row, 2 * kk + hf) * 16;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 64 * wn + 32 * j + lq;
+            b_off[j][kk] = row * 128 + gemm_swz(row, 2 * kk + hf) * 16;
+        }
+    }
+
+    if (slot >= cnt_x) return;
+    // DMA source pointers of the current item: wave w moves chunks 4w .. 4w+3 (8 rows each) of both operands
+    const bf16_t* ga[4];
+    const bf16_t* gb[4];
+    int m0, n0;
+    bool live;
+    auto setup = [&](unsigned item) {
+        const unsigned tile = base_x + item;
+        const int tn = tile % tiles_n, tm = tile / tiles_n;
+        m0 = tm * G256_BM;
+        n0 = tn * G256_BN;
+        live = m0 < p.M;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * (4 * w + i) + (lane >> 3);
+            const int src_slot = (lane & 7) ^ (((row >> 1) ^ (row >> 4)) & 7);
+            int ra = m0 + row, rb = n0 + row;
+            ra = ra < p.M ? ra : p.M - 1;
+            rb = rb < p.N ? rb : p.N - 1;
+            ga[i] = p.A + (long)ra * p.lda + src_slot * 8;
+            gb[i] = p.B + (long)rb * p.ldb + src_slot * 8;
+        }
+    };
+    auto dma = [&](int kt, int buf) {
+        char* abuf = smem + buf * 2 * G256_OPERAND_BYTES + 4 * w * 1024;
+        char* bbuf = abuf + G256_OPERAND_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(ga[i] + kt * G256_BK, abuf + i * 1024);
+            glds16(gb[i] + kt * G256_BK, bbuf + i * 1024);
+        }
+    };
+    unsigned item = slot;
+    setup(item);
+    if (live) dma(0, 0);
+    while (true) {
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        glds_wait_all();
+        __syncthreads();
+        const int nk_live = live ? nk : 0;
+        for (int kt = 0; kt < nk_live; ++kt) {
+            if (kt + 1 < nk) dma(kt + 1, (kt + 1) & 1);
+            const char* as = smem + (kt & 1) * 2 * G256_OPERAND_BYTES;
+            const char* bs = as + G256_OPERAND_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 a[4], b[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bs + b_off[j][kk]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(as + a_off[i][kk]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16_bf16(b[j], a[i], acc[i][j]);   // D^T[n][m]
+            }
+            glds_wait_all();
+            __syncthreads();
+        }
+        // ---- next item: its first k-tile streams into buffer 0 while this tile is written out through buffer 1
+        const int em0 = m0, en0 = n0;
+        const bool elive = live;
+        const unsigned next = item + nx;
+        const bool has_next = next < cnt_x;
+        if (has_next) {
+            setup(next);
+            if (live) dma(0, 0);
+        }
+        if (elive) {
+
+        // ---- epilogue (LDS-only barriers: the DMA stays in flight).  The products were accumulated TRANSPOSED, so a
+        // lane owns 4 consecutive columns of one row: 16-byte (fp32) / 8-byte (bf16) staging writes.  Four passes, pass q
+        // = the q-th 32-row slab of every wave = 64 tile rows x 256 columns, in a 16-byte-chunk XOR-swizzled image.
+        char* stg = smem + 2 * G256_OPERAND_BYTES;
+        constexpr bool STAGE_BF16 = (EPI == EPI_BF16 || EPI == EPI_GELU);   // final values are bf16: stage them packed
+        if (p.alpha != 1.0f) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= p.alpha;
+        }
+        const bool want_stats = (EPI == EPI_DGELU || EPI == EPI_BF16) && p.colsum != nullptr;
+        float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int ct = t & 31, rr = t >> 5;                  // row pass: 8 columns per thread, 16 rows per step
+        const int gn = en0 + 8 * ct;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int srow = 32 * wm + lq;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = 64 * wn + 32 * j + 8 * g + 4 * hf;      // first of this lane's 4 columns
+                    float v0 = acc[q][j][4 * g], v1 = acc[q][j][4 * g + 1], v2 = acc[q][j][4 * g + 2], v3 = acc[q][j][4 * g + 3];
+                    if (STAGE_BF16) {
+                        if (p.bias && en0 + nl < p.N) {
+                            const f32x4v b = *reinterpret_cast<const f32x4v*>(p.bias + en0 + nl);
+                            v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+                        }
+                        char* dst = stg + srow * 512 + (((nl >> 3) ^ (srow & 15)) * 16) + ((nl >> 2) & 1) * 8;
+                        u32x2 o;
+                        o.x = pack_bf2(v0, v1);
+                        o.y = pack_bf2(v2, v3);
+                        if (EPI == EPI_BF16 || p.C) *reinterpret_cast<u32x2*>(dst) = o;
+                        if (EPI == EPI_GELU) {
+                            o.x = pack_bf2(gelu_f(v0), gelu_f(v1));
+                            o.y = pack_bf2(gelu_f(v2), gelu_f(v3));
+                            *reinterpret_cast<u32x2*>(dst + 64 * 512) = o;
+                        }
+                    } else {
+                        const f32x4v o = {v0, v1, v2, v3};
+                        *reinterpret_cast<f32x4v*>(stg + srow * 1024 + (((nl >> 2) ^ (srow & 15)) * 16)) = o;
+                    }
+                }
+            lds_barrier();
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int s2 = pass * 16 + rr;
+                const int gm = em0 + (s2 < 32 ? 32 * q + s2 : 128 + 32 * q + (s2 - 32));
+                if (gm < p.M && gn < p.N) {
+                    if (STAGE_BF16) {
+                        const char* src = stg + s2 * 512 + ((ct ^ (s2 & 15)) * 16);
+                        if (EPI == EPI_BF16 || p.C) {
+                            const u32x4 wv = *reinterpret_cast<const u32x4*>(src);
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = wv;
+                            if (want_stats) {
+                                float v[8];
+                                unpack8(wv, v);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) csum[e] += v[e];
+                            }
+                        }
+                        if (EPI == EPI_GELU)
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + (long)gm * p.ldc2 + gn) =
+                                *reinterpret_cast<const u32x4*>(src + 64 * 512);
+                    } else {
+                        float v[8];
+                        const f32x4v c0 = *reinterpret_cast<const f32x4v*>(stg + s2 * 1024 + (((2 * ct) ^ (s2 & 15)) * 16));
+                        const f32x4v c1 = *reinterpret_cast<const f32x4v*>(stg + s2 * 1024 + (((2 * ct + 1) ^ (s2 & 15)) * 16));
+                        v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
+                        v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+                        gemm_epilogue_row8<EPI>(p, gm, gn, v);
+                        if (want_stats) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) csum[e] += v[e];
+                        }
+                    }
+                }
+            }
+            lds_barrier();                                   // staging image read out
+        }
+        if (want_stats) {                                    // 16 row-threads per 8-column group -> one atomic per column
+            float* red = reinterpret_cast<float*>(stg);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[rr * 256 + 8 * ct + e] = csum[e];
+            lds_barrier();
+            if (t < 256 && en0 + t < p.N) {
+                float a = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a += red[r * 256 + t];
+                atomicAdd(p.colsum + en0 + t, a);
+            }
+            lds_barrier();
+        }
+        }
+        if (!has_next) break;
+        item = next;
+    }
+}
+
+}  // namespace ccd

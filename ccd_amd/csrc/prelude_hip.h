@@ -48,6 +48,16 @@ __device__ __forceinline__ buf_rsrc make_rsrc(const void* base, unsigned bytes) 
 __device__ __forceinline__ buf_u32x4 buf_load16(buf_rsrc r, unsigned byte_offset) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_offset, 0, 0);
 }
+// LDS-DMA: one wave instruction copies 64 x 16 B from per-lane global addresses straight into LDS at
+// (wave-uniform lds_base) + lane * 16 - no VGPR round trip, counted on vmcnt like any VMEM load.
+__device__ __forceinline__ void glds16(const void* gptr, char* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt while an LDS-DMA is in flight
+// (the DMA is a pending LDS write on the VM counter); this one lets a DMA span the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // hardware float -> bf16 (RNE): clang lowers the __bf16 casts to v_cvt_pk_bf16_f32 on gfx950
 typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {

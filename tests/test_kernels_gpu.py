@@ -100,3 +100,13 @@ def test_conv_pieces(hip):
 @pytest.mark.parametrize("images,E", [(2, 192), (8, 384)])
 def test_seghead(hip, images, E):
     kc.check_seghead(hip.device, images=images, E=E)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (4096, 1152, 384), (2048, 384, 1536)])
+def test_gemm256(hip, monkeypatch, M, N, K):
+    """256x256 LDS-DMA kernel: forced onto a ragged small problem and on model shapes (repeated: the DMA is async)."""
+    monkeypatch.setenv("CCD_GEMM_256_MIN_M", "1")
+    monkeypatch.setenv("CCD_GEMM_256_MIN_N", "1")
+    for seed in range(3):
+        kc.check_gemm_nt(hip.device, M=M, N=N, K=K, seed=seed)
+    kc.check_gemm_dynamic_rows(hip.device, M=max(M, 600), N=N, K=K, live=75)

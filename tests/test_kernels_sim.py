@@ -94,3 +94,11 @@ def test_conv_pieces_sim(sim):
 
 def test_seghead_sim(sim):
     kc.check_seghead(sim.device, images=1, E=64)
+
+
+def test_gemm256_sim(sim, monkeypatch):
+    """The 256x256 LDS-DMA kernel, forced onto small ragged problems (several tiles per workgroup, edge tiles)."""
+    monkeypatch.setenv("CCD_GEMM_256_MIN_M", "1")
+    monkeypatch.setenv("CCD_GEMM_256_MIN_N", "1")
+    kc.check_gemm_nt(sim.device, M=300, N=264, K=128)
+    kc.check_gemm_dynamic_rows(sim.device, M=600, N=264, K=64, live=75)

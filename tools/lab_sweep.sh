@@ -1,6 +1,4 @@
-export CCD_HIP_LIB=/root/repo/gpurun_lab/libccd_lab.so
-for shape in "131072 1152 384"; do
-  LAB_MFAST=64 python tools/gemm_lab.py nt $shape 1 2>&1 | tail -11
+for flag in 0 1; do
+  echo "CCD_GEMM_256=$flag"
+  CCD_GEMM_256=$flag python tools/microbench.py 2>&1 | grep "gemm_nt"
 done
-unset CCD_HIP_LIB
-python tools/microbench.py 2>&1 | grep gemm
