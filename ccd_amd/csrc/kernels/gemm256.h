@@ -46,20 +46,19 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
     const unsigned cnt_x = q8 + (xcd < r8 ? 1u : 0u);
     const int nk = p.K / G256_BK;
 
-    // fragment byte offsets inside an operand image (loop invariant)
-    int a_off[4][4], b_off[2][4];
+    // Fragment addresses.  With slot = 2*kk + hf and the swizzle slot ^ f(row), the byte offset of k-step kk is
+    // base ^ (kk << 5) with base = row*128 + ((f >> 1) << 5) + ((hf ^ (f & 1)) << 4): ONE register per fragment row
+    // instead of one per (row, kk); the buffer bit (1 << 16) is folded into the same XOR.
+    unsigned base_a[4], base_b[2];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int i = 0; i < 4; ++i) {
+        const int row = 128 * wm + 32 * i + lq, f = ((row >> 1) ^ (row >> 4)) & 7;
+        base_a[i] = (unsigned)(row * 128 + ((f >> 1) << 5) + ((hf ^ (f & 1)) << 4));
+    }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 128 * wm + 32 * i + lq;
-            a_off[i][kk] = row * 128 + gemm_swz(row, 2 * kk + hf) * 16;
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = 64 * wn + 32 * j + lq;
-            b_off[j][kk] = row * 128 + gemm_swz(row, 2 * kk + hf) * 16;
-        }
+    for (int j = 0; j < 2; ++j) {
+        const int row = 64 * wn + 32 * j + lq, f = ((row >> 1) ^ (row >> 4)) & 7;
+        base_b[j] = (unsigned)(G256_OPERAND_BYTES + row * 128 + ((f >> 1) << 5) + ((hf ^ (f & 1)) << 4));
     }
 
     if (slot >= cnt_x) return;
@@ -94,6 +93,13 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
             glds16(gb[i] + kt * G256_BK, bbuf + i * 1024);
         }
     };
+#ifdef CCD_GEMM_LAB     // per-phase cycle totals of wave 0 -> p.colsum (8 u64 per workgroup) when m_fastest & 64
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#define G256_STAMP(i) if (p.m_fastest & 64) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph[i] += tn_ - tprev; tprev = tn_; }
+#else
+#define G256_STAMP(i)
+#endif
     unsigned item = slot;
     setup(item);
     if (live) dma(0, 0);
@@ -107,25 +113,38 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         glds_wait_all();
         __syncthreads();
+        G256_STAMP(0)
         const int nk_live = live ? nk : 0;
         for (int kt = 0; kt < nk_live; ++kt) {
             if (kt + 1 < nk) dma(kt + 1, (kt + 1) & 1);
-            const char* as = smem + (kt & 1) * 2 * G256_OPERAND_BYTES;
-            const char* bs = as + G256_OPERAND_BYTES;
+            const unsigned bufbit = (unsigned)(kt & 1) << 16;       // buffer 1 starts at 64 KiB
+            // fragments of k-step kk+1 are requested before the 8 MFMAs of k-step kk are issued
+            bf16x8 a[2][4], b[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[0][j] = *reinterpret_cast<const bf16x8*>(smem + (base_b[j] ^ bufbit));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[0][i] = *reinterpret_cast<const bf16x8*>(smem + (base_a[i] ^ bufbit));
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                bf16x8 a[4], b[2];
+                const int cur = kk & 1, nxt = cur ^ 1;
+                if (kk < 3) {
+                    const unsigned x = bufbit | (unsigned)((kk + 1) << 5);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bs + b_off[j][kk]);
+                    for (int j = 0; j < 2; ++j) b[nxt][j] = *reinterpret_cast<const bf16x8*>(smem + (base_b[j] ^ x));
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(as + a_off[i][kk]);
+                    for (int i = 0; i < 4; ++i) a[nxt][i] = *reinterpret_cast<const bf16x8*>(smem + (base_a[i] ^ x));
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16_bf16(b[j], a[i], acc[i][j]);   // D^T[n][m]
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = mfma_32x32x16_bf16(b[cur][j], a[cur][i], acc[i][j]);   // D^T[n][m]
             }
+            G256_STAMP(1)
             glds_wait_all();
+            G256_STAMP(2)
             __syncthreads();
+            G256_STAMP(3)
         }
         // ---- next item: its first k-tile streams into buffer 0 while this tile is written out through buffer 1
         const int em0 = m0, en0 = n0;
@@ -151,7 +170,11 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] *= p.alpha;
         }
+        #ifdef CCD_GEMM_LAB
+        const bool want_stats = (EPI == EPI_DGELU || EPI == EPI_BF16) && p.colsum != nullptr && !(p.m_fastest & 64);
+#else
         const bool want_stats = (EPI == EPI_DGELU || EPI == EPI_BF16) && p.colsum != nullptr;
+#endif
         float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int ct = t & 31, rr = t >> 5;                  // row pass: 8 columns per thread, 16 rows per step
         const int gn = en0 + 8 * ct;
@@ -184,7 +207,9 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                         *reinterpret_cast<f32x4v*>(stg + srow * 1024 + (((nl >> 2) ^ (srow & 15)) * 16)) = o;
                     }
                 }
+            G256_STAMP(4)
             lds_barrier();
+            G256_STAMP(5)
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 const int s2 = pass * 16 + rr;
@@ -219,7 +244,9 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                     }
                 }
             }
+            G256_STAMP(6)
             lds_barrier();                                   // staging image read out
+            G256_STAMP(5)
         }
         if (want_stats) {                                    // 16 row-threads per 8-column group -> one atomic per column
             float* red = reinterpret_cast<float*>(stg);
@@ -238,6 +265,10 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
         if (!has_next) break;
         item = next;
     }
+#ifdef CCD_GEMM_LAB
+    if ((p.m_fastest & 64) && p.colsum && t == 0)
+        for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(p.colsum)[blockIdx.x * 8 + i] = ph[i];
+#endif
 }
 
 }  // namespace ccd
