@@ -76,7 +76,8 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"      # the latter: 1-rank RCCL smoke of the N>1 path
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -89,7 +90,7 @@ def main():
     torch.manual_seed(0)
     student, teacher = pretrain.build_networks(arch=a.arch, out_dim=a.out_dim, drop_path_rate=0.1,
                                                norm_last_layer=False, device=dev)
-    if world > 1:
+    if use_dist:
         student = torch.nn.SyncBatchNorm.convert_sync_batchnorm(student)      # train.py:96-98
         model = DataParallel(student)
     else:
@@ -108,19 +109,19 @@ def main():
         loss = step()
     timer = None if a.no_kernel_timer else ops.KernelTimer()
     ops.TIMER = timer
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
     final_loss = loss.item()
@@ -160,7 +161,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.arch)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
