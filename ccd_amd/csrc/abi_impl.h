@@ -150,7 +150,9 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
     const bool use_256 = ccd_env_flag("CCD_GEMM_256", true);
     const int min_m_256 = getenv("CCD_GEMM_256_MIN_M") ? atoi(getenv("CCD_GEMM_256_MIN_M")) : 2048;
     const int min_n_256 = getenv("CCD_GEMM_256_MIN_N") ? atoi(getenv("CCD_GEMM_256_MIN_N")) : 512;
-    if (use_256 && epilogue != CCD_EPI_ATOMIC && M >= min_m_256 && N >= min_n_256)
+    // bf16-output epilogues only: its fp32 staging (4x the LDS bytes) loses to the 128^2 kernel on short K
+    if (use_256 && (epilogue == CCD_EPI_BF16 || epilogue == CCD_EPI_GELU || epilogue == CCD_EPI_DGELU) && M >= min_m_256 &&
+        N >= min_n_256)
         return ccd_launch_gemm256(p, epilogue, stream);
     static const bool use_nt32 = ccd_env_flag("CCD_GEMM_NT32", false);
     static const bool use_ares = ccd_env_flag("CCD_GEMM_ARES", false);

@@ -161,7 +161,8 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
         // lane owns 4 consecutive columns of one row: 16-byte (fp32) / 8-byte (bf16) staging writes.  Four passes, pass q
         // = the q-th 32-row slab of every wave = 64 tile rows x 256 columns, in a 16-byte-chunk XOR-swizzled image.
         char* stg = smem + 2 * G256_OPERAND_BYTES;
-        constexpr bool STAGE_BF16 = (EPI == EPI_BF16 || EPI == EPI_GELU);   // final values are bf16: stage them packed
+        constexpr bool STAGE_BF16 = (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU);   // bf16 outputs: staged packed
+        // (DGELU: the bf16-rounded product is multiplied by gelu'(u) in the row pass, where the aux read is coalesced)
         if (p.alpha != 1.0f) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                     const int nl = 64 * wn + 32 * j + 8 * g + 4 * hf;      // first of this lane's 4 columns
                     float v0 = acc[q][j][4 * g], v1 = acc[q][j][4 * g + 1], v2 = acc[q][j][4 * g + 2], v3 = acc[q][j][4 * g + 3];
                     if (STAGE_BF16) {
-                        if (p.bias && en0 + nl < p.N) {
+                        if (EPI != EPI_DGELU && p.bias && en0 + nl < p.N) {
                             const f32x4v b = *reinterpret_cast<const f32x4v*>(p.bias + en0 + nl);
                             v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
                         }
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                         u32x2 o;
                         o.x = pack_bf2(v0, v1);
                         o.y = pack_bf2(v2, v3);
-                        if (EPI == EPI_BF16 || p.C) *reinterpret_cast<u32x2*>(dst) = o;
+                        if (EPI != EPI_GELU || p.C) *reinterpret_cast<u32x2*>(dst) = o;
                         if (EPI == EPI_GELU) {
                             o.x = pack_bf2(gelu_f(v0), gelu_f(v1));
                             o.y = pack_bf2(gelu_f(v2), gelu_f(v3));
@@ -217,7 +218,18 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                 if (gm < p.M && gn < p.N) {
                     if (STAGE_BF16) {
                         const char* src = stg + s2 * 512 + ((ct ^ (s2 & 15)) * 16);
-                        if (EPI == EPI_BF16 || p.C) {
+                        if (EPI == EPI_DGELU) {
+                            float v[8], u[8];
+                            unpack8(*reinterpret_cast<const u32x4*>(src), v);
+                            unpack8(*reinterpret_cast<const u32x4*>(p.aux + (long)gm * p.ldaux + gn), u);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] *= dgelu_f(u[e]);
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = pack8(v);
+                            if (want_stats) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) csum[e] += v[e];
+                            }
+                        } else if (EPI == EPI_BF16 || p.C) {
                             const u32x4 wv = *reinterpret_cast<const u32x4*>(src);
                             *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = wv;
                             if (want_stats) {
