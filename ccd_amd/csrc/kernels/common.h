@@ -57,7 +57,9 @@ __device__ __forceinline__ GeluTerms gelu_terms(float x) {
     r.gauss = e;
     return r;
 }
-__device__ __forceinline__ float gelu_f(float x) { return x * gelu_terms(x).cdf; }
+// forward: libm's erff alone measured faster than the rational form (which pays a v_rcp and a v_exp); the derivative
+// needs erf AND the Gaussian, where the shared form wins
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float dgelu_f(float x) {
     const GeluTerms g = gelu_terms(x);
     return fmaf(x * 0.3989422804014327f, g.gauss, g.cdf);
