@@ -70,7 +70,7 @@ class _BlockCtx:
                  "ds1", "ds2")
 
 
-def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training):
+def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, need_taps=True):
     """img [N,3,32,128] fp32 -> (tokens bf16 [N*256,E], [tap bf16 [N*256,E]] * len(taps), ctx or None)."""
     E, N = spec.E, img.shape[0]
     R = N * 256
@@ -102,7 +102,7 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training):
         if not save:
             c.y1 = c.qkv = c.att = c.y2 = c.u = c.gact = None
         ctxs.append(c if save else None)
-        if i + 1 in spec.taps:
+        if need_taps and i + 1 in spec.taps:
             j = len(taps)
             t, mu, rs = ops.ln_fwd(x, arena.w(f"{pre}norm_seg.{j}.weight"), arena.w(f"{pre}norm_seg.{j}.bias"), spec.eps)
             taps.append(t)
@@ -188,10 +188,10 @@ class BackboneFn(torch.autograd.Function):
     """tokens, tap0, tap1, tap2 = BackboneFn.apply(anchor, img, module)   (anchor: any tensor that requires grad)."""
 
     @staticmethod
-    def forward(ctx, anchor, img, module):
+    def forward(ctx, anchor, img, module, need_taps=True):
         save = ctx.needs_input_grad[0]      # False under no_grad / frozen teacher
         tokens, taps, saved = backbone_forward(module.arena, module.arena_prefix, module.spec, img, module.resample,
-                                               save, module.training)
+                                               save, module.training, need_taps)
         ctx.module, ctx.saved = module, saved
         N, E = img.shape[0], module.spec.E
         outs = [tokens.view(N, 256, E)] + [t.view(N, 256, E) for t in taps]
@@ -204,7 +204,7 @@ class BackboneFn(torch.autograd.Function):
         backbone_backward(m.arena, m.arena_prefix, m.spec, ctx.saved, cast(d_tokens), [cast(t) for t in d_taps],
                           m.resample, m.grad_ready_hook)
         ctx.saved = None
-        return None, None, None
+        return None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------- region pooling

@@ -98,7 +98,7 @@ class ABIDINOModel(ArenaModule):
         self.ensure_arena()
         B = x.shape[0]
         views = torch.cat([x[:, 1], x[:, 2]])
-        tokens, *taps = self.backbone.tokens_and_taps(views)
+        tokens, *taps = self.backbone.tokens_and_taps(views, need_taps=clusters is None)
         if clusters is None:
             seg_in = [self.backbone.to_2D(t) for t in taps]
             seg = self.segmentation(seg_in)                                    # [2B,2,32,128] fp32

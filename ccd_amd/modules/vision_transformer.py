@@ -108,11 +108,12 @@ class VisionTransformer(ArenaModule):
                       f"blocks.{i}.mlp.fc2.weight"]
         return names
 
-    def tokens_and_taps(self, x):
-        """bf16 token tensors in the kernels' native [N,256,E] layout (what the rest of ccd_amd consumes)."""
+    def tokens_and_taps(self, x, need_taps=True):
+        """bf16 token tensors in the kernels' native [N,256,E] layout (what the rest of ccd_amd consumes).
+        need_taps=False skips the three norm_seg outputs (the teacher never feeds a segmentation head)."""
         self.ensure_arena()
         anchor = self.arena.params[self.arena_prefix + "pos_embed"]
-        return engine.BackboneFn.apply(anchor, x.contiguous().float(), self)
+        return engine.BackboneFn.apply(anchor, x.contiguous().float(), self, need_taps)
 
     def to_2D(self, t):
         return t.reshape(t.shape[0], 8, 32, -1).permute(0, 3, 1, 2)
