@@ -118,6 +118,9 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
         for (int kt = 0; kt < nk_live; ++kt) {
             if (kt + 1 < nk) dma(kt + 1, (kt + 1) & 1);
             const unsigned bufbit = (unsigned)(kt & 1) << 16;       // buffer 1 starts at 64 KiB
+#ifdef CCD_G256_PRIO
+            wave_prio<1>();
+#endif
             // fragments of k-step kk+1 are requested before the 8 MFMAs of k-step kk are issued
             bf16x8 a[2][4], b[2][2];
 #pragma unroll
@@ -140,6 +143,9 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = mfma_32x32x16_bf16(b[cur][j], a[cur][i], acc[i][j]);   // D^T[n][m]
             }
+#ifdef CCD_G256_PRIO
+            wave_prio<0>();
+#endif
             G256_STAMP(1)
             glds_wait_all();
             G256_STAMP(2)

@@ -58,6 +58,9 @@ __device__ __forceinline__ void glds_wait_all() { asm volatile("s_waitcnt vmcnt(
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt while an LDS-DMA is in flight
 // (the DMA is a pending LDS write on the VM counter); this one lets a DMA span the barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// static wave priority (guide T5): 0..3, arbitration between the waves sharing a SIMD
+template <int P>
+__device__ __forceinline__ void wave_prio() { __builtin_amdgcn_s_setprio(P); }
 // hardware float -> bf16 (RNE): clang lowers the __bf16 casts to v_cvt_pk_bf16_f32 on gfx950
 typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {

@@ -215,3 +215,53 @@ def check_properties_full_size(device, B=256):
     assert (pool(f1) + pool(f2) - pool((f1.float() + f2.float()).to(torch.bfloat16))).abs().max() < 8e-2
     # optimizer: zero learning rate leaves the weights untouched; EMA with momentum 1 leaves the teacher untouched
     return int(sel.M)
+
+
+def check_checkpoint_resume(device, tmp_path):
+    """Checkpoint in the reference's layout (train.py:190-200: DDP-prefixed student/teacher, AdamW state, DINOLoss
+    centre), restored into freshly built networks with restart_from_checkpoint: the next iteration is identical."""
+    from ccd_amd.modules import utils
+    from ccd_amd.parallel import DataParallel
+
+    def build():
+        student, teacher = tiny_networks(device)
+        s, t = DataParallel(student), DataParallel(teacher)
+        t.module.backbone.load_state_dict(s.module.backbone.state_dict())
+        t.module.head.load_state_dict(s.module.head.state_dict())
+        t.module.ensure_arena()
+        loss = DINOLoss(512, 2, 0.04, 0.04, 0, 40).to(device)
+        return s, t, loss, pretrain.make_optimizer(s.module, clip_grad=3.0)
+
+    def run(s, t, loss, opt, seed, epoch):
+        images, masks, metrics = make_batch(1, seed=seed, device=device)
+        return float(pretrain.training_iteration(s, t, loss, opt, images, masks, metrics, epoch, 2e-4, 0.05, 0.99).item())
+
+    s, t, loss, opt = build()
+    run(s, t, loss, opt, seed=21, epoch=1)
+    path = os.path.join(str(tmp_path), "checkpoint.pth")
+    torch.save({"student": s.state_dict(), "teacher": t.state_dict(), "optimizer": opt.state_dict(), "epoch": 1,
+                "iteration": 1, "dino_loss": loss.state_dict()}, path)
+    keys = list(torch.load(path, map_location="cpu", weights_only=False)["student"])
+    assert all(k.startswith("module.") for k in keys) and "module.backbone.blocks.0.attn.qkv.weight" in keys
+    snap = {"flat": s.module.arena.flat.clone(), "tflat": t.module.arena.flat.clone(), "m": opt.exp_avg.clone(),
+            "v": opt.exp_avg_sq.clone(), "steps": dict(opt.steps), "center": loss.center.clone(),
+            "buffers": {k: v.clone() for k, v in s.module.named_buffers()}}
+    want = run(s, t, loss, opt, seed=22, epoch=1)
+
+    torch.manual_seed(99)                                      # different initial weights: everything must come from the file
+    s2, t2, loss2, opt2 = build()
+    restored = {"epoch": 0, "iteration": 0}
+    utils.restart_from_checkpoint(path, run_variables=restored, student=s2, teacher=t2, optimizer=opt2, dino_loss=loss2)
+    assert restored == {"epoch": 1, "iteration": 1}
+    s2.module.ensure_arena()
+    t2.module.ensure_arena()
+    # the restored state is bit-identical to the state that was saved ...
+    assert torch.equal(s2.module.arena.flat, snap["flat"]) and torch.equal(t2.module.arena.flat, snap["tflat"])
+    assert torch.equal(opt2.exp_avg, snap["m"]) and torch.equal(opt2.exp_avg_sq, snap["v"]) and dict(opt2.steps) == snap["steps"]
+    assert torch.equal(loss2.center, snap["center"])
+    for k, v in s2.module.named_buffers():
+        assert torch.equal(v, snap["buffers"][k]), k
+    # ... and the next iteration reproduces the original run's loss (parameters only up to the fp32-atomic summation
+    # noise that two identical runs show as well - Adam turns sign flips of zero-gradient elements into +-lr moves)
+    got = run(s2, t2, loss2, opt2, seed=22, epoch=1)
+    assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (got, want)

@@ -15,3 +15,7 @@ def sim():
 
 def test_tiny_training_iteration_sim(sim):
     mc.check_tiny_step(sim.device)
+
+
+def test_checkpoint_resume_sim(sim, tmp_path):
+    mc.check_checkpoint_resume(sim.device, tmp_path)

@@ -1,4 +1,5 @@
-export CCD_HIP_LIB=/root/repo/gpurun_lab/libccd_lab.so
-for shape in "131072 1152 384" "131072 1536 384" "8192 8192 4096"; do
-  LAB_MFAST=64 python tools/gemm_lab.py nt $shape 1 2>&1 | tail -11
+for lib in "" /root/repo/gpurun_lab/libccd_lab.so; do
+  echo "lib=$lib"
+  CCD_HIP_LIB=$lib python tools/microbench.py 2>&1 | grep "gemm_nt_qkv\|fc1_gelu\|8192x8192"
+  CCD_HIP_LIB=$lib python tools/microbench.py 2>&1 | grep "gemm_nt_qkv\|fc1_gelu\|8192x8192"
 done
