@@ -112,6 +112,57 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
     return tokens, taps, ctx
 
 
+class _SideStream:
+    """Weight-gradient products (dW = dY^T X, TN GEMMs) and bias column sums have no consumer inside the backward
+    pass, so they run on a second HIP stream next to the data-gradient chain: while the main stream sits in an
+    HBM-bound LayerNorm backward, the side stream's MFMA-bound GEMM fills the matrix pipes (and vice versa for the
+    column sums).  Ordering is by events; tensors handed to the side stream are `record_stream`ed so the caching
+    allocator cannot recycle them early.  MEASURED (B=256, MI355X): no gain - 69.25 vs 69.09 ms/step - the persistent
+    GEMMs already hold every workgroup slot of every CU, so kernels of the other stream only get in as slots free up.
+    Kept as an opt-in (CCD_SIDE_STREAM=1) for later kernels that leave room; off by default and off the GPU."""
+
+    _streams = {}
+
+    def __init__(self, device):
+        import os
+        self.on = device.type == "cuda" and os.environ.get("CCD_SIDE_STREAM", "0") == "1"
+        if self.on:
+            key = device.index if device.index is not None else torch.cuda.current_device()
+            if key not in _SideStream._streams:
+                _SideStream._streams[key] = torch.cuda.Stream(device=device)
+            self.side = _SideStream._streams[key]
+            self.main = torch.cuda.current_stream(device)
+        self.pending = []                      # events of side work since the last join
+
+    def run(self, fn, *tensors):
+        """fn() is enqueued on the side stream after everything already enqueued on the main stream."""
+        if not self.on:
+            fn()
+            return None
+        ready = torch.cuda.Event()
+        ready.record(self.main)
+        self.side.wait_event(ready)
+        with torch.cuda.stream(self.side):
+            fn()
+        for t in tensors:
+            t.record_stream(self.side)
+        done = torch.cuda.Event()
+        done.record(self.side)
+        self.pending.append(done)
+        return done
+
+    def wait(self, event):
+        if self.on and event is not None:
+            self.main.wait_event(event)
+
+    def join(self):
+        """Main stream waits for all side work issued so far (gradients of a block are final after this)."""
+        if self.on:
+            for ev in self.pending:
+                self.main.wait_event(ev)
+        self.pending = []
+
+
 def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample, on_block_done=None):
     """Consumes bf16 gradients of the final-norm tokens and the taps; fills the arena gradient slots of `pre`*.
 
@@ -131,6 +182,8 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
     def mlp_tail(i):            # what the MLP branch of block i wants from the writer in front of it
         return dict(gb=gb, rowscale=ctxs[i].ds2, rows_per_sample=256, dbias=arena.g(f"{pre}blocks.{i}.mlp.fc2.bias"))
 
+    side = _SideStream(dev)
+    gb_reader = None            # event of the last side-stream product that reads gb (the next writer of gb waits for it)
     have_gb = False
     if d_tokens is not None:
         tail = mlp_tail(top) if top not in tap_at else {}
@@ -144,38 +197,49 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
         c = ctxs[i]
         if i in tap_at:
             j, xt, m, r = tap_at[i]
+            side.wait(gb_reader)
             ops.ln_bwd(d_taps[j].reshape(R, E), xt, m, r, arena.w(f"{pre}norm_seg.{j}.weight"), g,
                        arena.g(f"{pre}norm_seg.{j}.weight"), arena.g(f"{pre}norm_seg.{j}.bias"), accumulate=True,
                        **mlp_tail(i))
             have_gb = True
         if not have_gb:          # only when no gradient reached the final norm: plain cast + column sum
+            side.wait(gb_reader)
             ops.scale_cast_rows(g, gb, c.ds2, 256)
             ops.colsum_bf16(gb, arena.g(b + "mlp.fc2.bias"))
         # ---- MLP branch: x_out = x_mid + ds2 * fc2(gelu(fc1(LN2(x_mid))))
-        ops.gemm_tn(gb, c.gact, arena.g(b + "mlp.fc2.weight"))
+        gact, y2, att, y1 = c.gact, c.y2, c.att, c.y1
+        gb_reader = side.run(lambda: ops.gemm_tn(gb, gact, arena.g(b + "mlp.fc2.weight")), gb, gact)
         du = ops.gemm_nt(gb, arena.wbt(b + "mlp.fc2.weight"), epilogue=ops.EPI_DGELU, aux=c.u,
                          colsum=arena.g(b + "mlp.fc1.bias"))
-        ops.gemm_tn(du, c.y2, arena.g(b + "mlp.fc1.weight"))
+        side.run(lambda du=du: ops.gemm_tn(du, y2, arena.g(b + "mlp.fc1.weight")), du, y2)
         dy2 = ops.gemm_nt(du, arena.wbt(b + "mlp.fc1.weight"))
         del du
+        side.wait(gb_reader)                                 # norm2's backward rewrites gb
         ops.ln_bwd(dy2, c.x_mid, c.mean2, c.rstd2, arena.w(b + "norm2.weight"), g, arena.g(b + "norm2.weight"),
                    arena.g(b + "norm2.bias"), accumulate=True, gb=gb, rowscale=c.ds1, rows_per_sample=256,
                    dbias=arena.g(b + "attn.proj.bias"))
         # ---- attention branch: x_mid = x_in + ds1 * proj(attn(qkv(LN1(x_in))))
-        ops.gemm_tn(gb, c.att.view(R, E), arena.g(b + "attn.proj.weight"))
+        gb_reader = side.run(lambda: ops.gemm_tn(gb, att.view(R, E), arena.g(b + "attn.proj.weight")), gb, att)
         d_att = ops.gemm_nt(gb, arena.wbt(b + "attn.proj.weight"))
         d_qkv = ops.attention_bwd(c.qkv.view(N, 256, 3 * E), c.att, d_att.view(N, 256, E), c.lse, spec.heads, scale)
         d_qkv = d_qkv.view(R, 3 * E)
-        ops.gemm_tn(d_qkv, c.y1, arena.g(b + "attn.qkv.weight"))
-        ops.colsum_bf16(d_qkv, arena.g(b + "attn.qkv.bias"))
+
+        def qkv_grads(d_qkv=d_qkv):
+            ops.gemm_tn(d_qkv, y1, arena.g(b + "attn.qkv.weight"))
+            ops.colsum_bf16(d_qkv, arena.g(b + "attn.qkv.bias"))
+        side.run(qkv_grads, d_qkv, y1)
         dy1 = ops.gemm_nt(d_qkv, arena.wbt(b + "attn.qkv.weight"))
         tail = mlp_tail(i - 1) if (i > 0 and (i - 1) not in tap_at) else {}
+        if tail:
+            side.wait(gb_reader)                             # this LayerNorm backward rewrites gb for the next block
         ops.ln_bwd(dy1, c.x_in, c.mean1, c.rstd1, arena.w(b + "norm1.weight"), g, arena.g(b + "norm1.weight"),
                    arena.g(b + "norm1.bias"), accumulate=True, **tail)
         have_gb = bool(tail)
         ctxs[i] = None
         if on_block_done is not None:
+            side.join()                                      # the block's weight gradients are final for the reducer
             on_block_done(b)
+    side.join()
     d_pos_rs = torch.zeros((256, E), dtype=F32, device=dev)
     ops.patch_embed_bwd(img, g, arena.g(pre + "patch_embed.proj.weight").view(E, -1),
                         arena.g(pre + "patch_embed.proj.bias"), d_pos_rs)
