@@ -98,17 +98,18 @@ static void ccd_reduce_geometry(long rows, int N, int* cgn_log2, int* col_blocks
 }
 static bool ccd_env_flag(const char* name, bool dflt);
 // 256x256-tile LDS-DMA kernel for the large-M products (gemm256.h): one workgroup per CU
+template <int BN>
 static int ccd_launch_gemm256(const ccd::GemmParams& p, int epilogue, void* stream) {
-    const int tiles = ((p.M + ccd::G256_BM - 1) / ccd::G256_BM) * ((p.N + ccd::G256_BN - 1) / ccd::G256_BN);
+    const int tiles = ((p.M + ccd::G256_BM - 1) / ccd::G256_BM) * ((p.N + BN - 1) / BN);
     const int cus = ccd_rt_num_cus();
     const dim3 grid(tiles < cus ? tiles : cus), block(ccd::G256_THREADS);
     const size_t smem = ccd::G256_SMEM_BYTES;
     switch (epilogue) {
-        case CCD_EPI_BF16: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_BF16>), grid, block, smem, stream, p); break;
-        case CCD_EPI_GELU: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_GELU>), grid, block, smem, stream, p); break;
-        case CCD_EPI_RESID: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_RESID>), grid, block, smem, stream, p); break;
-        case CCD_EPI_F32: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_F32>), grid, block, smem, stream, p); break;
-        case CCD_EPI_DGELU: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_DGELU>), grid, block, smem, stream, p); break;
+        case CCD_EPI_BF16: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_BF16, BN>), grid, block, smem, stream, p); break;
+        case CCD_EPI_GELU: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_GELU, BN>), grid, block, smem, stream, p); break;
+        case CCD_EPI_RESID: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_RESID, BN>), grid, block, smem, stream, p); break;
+        case CCD_EPI_F32: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_F32, BN>), grid, block, smem, stream, p); break;
+        case CCD_EPI_DGELU: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_DGELU, BN>), grid, block, smem, stream, p); break;
         default: return CCD_EINVAL;
     }
     return ccd_rt_last_error();
@@ -146,14 +147,16 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
     p.k_per_split = K; p.m_fastest = m_fastest; p.alpha = alpha; p.d_rows = d_rows; p.rows_mul = rows_mul;
     p.colsum = colsum;
     // kernel choice (all three are parity-tested): CCD_GEMM_NT32=0 / CCD_GEMM_ARES=1 switch variants for A/B timing
-    // read per call (not cached): the tests flip these to force small problems through the 256^2 kernel
-    const bool use_256 = ccd_env_flag("CCD_GEMM_256", true);
+    // read per call (not cached): the tests flip these to force small problems through the 256-row kernels.
+    // CCD_GEMM_256: 0 = off, 1 = 256x256 tiles for N >= 512 bf16-output epilogues (default), 2 = additionally 256x128
+    // tiles for every other large-M product (lab switch; see DESIGN.md section 3 for the measurements)
+    const char* g256 = getenv("CCD_GEMM_256");
+    const int mode_256 = g256 ? atoi(g256) : 1;
     const int min_m_256 = getenv("CCD_GEMM_256_MIN_M") ? atoi(getenv("CCD_GEMM_256_MIN_M")) : 2048;
     const int min_n_256 = getenv("CCD_GEMM_256_MIN_N") ? atoi(getenv("CCD_GEMM_256_MIN_N")) : 512;
-    // bf16-output epilogues only: its fp32 staging (4x the LDS bytes) loses to the 128^2 kernel on short K
-    if (use_256 && (epilogue == CCD_EPI_BF16 || epilogue == CCD_EPI_GELU || epilogue == CCD_EPI_DGELU) && M >= min_m_256 &&
-        N >= min_n_256)
-        return ccd_launch_gemm256(p, epilogue, stream);
+    const bool bf16_out = epilogue == CCD_EPI_BF16 || epilogue == CCD_EPI_GELU || epilogue == CCD_EPI_DGELU;
+    if (mode_256 >= 1 && bf16_out && M >= min_m_256 && N >= min_n_256) return ccd_launch_gemm256<256>(p, epilogue, stream);
+    if (mode_256 >= 2 && epilogue != CCD_EPI_ATOMIC && M >= min_m_256) return ccd_launch_gemm256<128>(p, epilogue, stream);
     static const bool use_nt32 = ccd_env_flag("CCD_GEMM_NT32", false);
     static const bool use_ares = ccd_env_flag("CCD_GEMM_ARES", false);
     const bool ares_epi = epilogue == CCD_EPI_BF16 || epilogue == CCD_EPI_GELU || epilogue == CCD_EPI_RESID ||

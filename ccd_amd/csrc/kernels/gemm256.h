@@ -25,8 +25,13 @@ constexpr int G256_BM = 256, G256_BN = 256, G256_BK = 64, G256_THREADS = 512;
 constexpr int G256_OPERAND_BYTES = G256_BM * G256_BK * 2;            // 32 KiB per operand and buffer
 constexpr int G256_SMEM_BYTES = 4 * G256_OPERAND_BYTES;             // 2 buffers x (A + B) = 128 KiB
 
-template <int EPI>
+// BN = 256: waves 2 (M) x 4 (N), 128x64 per wave.  BN = 128 (the N = 384 products): waves 4 x 2, 64x64 per wave.
+template <int EPI, int BN = 256>
 __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) {
+    constexpr int WM = BN == 256 ? 2 : 4, WN = 8 / WM;     // wave grid
+    constexpr int WROWS = G256_BM / WM, WCOLS = BN / WN;    // per-wave output
+    constexpr int TI = WROWS / 32, TJ = WCOLS / 32;         // 32x32 accumulator tiles per wave
+    constexpr int BCH = BN / 64;                            // B chunks (8 rows) per wave and k-tile
     const int m_static = p.M;                               // the work list is built for the static shape
     if (p.d_rows) {                                         // device-side row count: tiles past it are skipped
         const int dyn = p.d_rows[0] * p.rows_mul;
@@ -34,8 +39,8 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
     }
     char* smem = dynamic_smem();
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, hf = lane >> 5, lq = lane & 31;
-    const int wm = w >> 2, wn = w & 3;
-    const int tiles_m = (m_static + G256_BM - 1) / G256_BM, tiles_n = (p.N + G256_BN - 1) / G256_BN;
+    const int wm = w / WN, wn = w % WN;
+    const int tiles_m = (m_static + G256_BM - 1) / G256_BM, tiles_n = (p.N + BN - 1) / BN;
     const unsigned total = (unsigned)(tiles_m * tiles_n), G = gridDim.x;
     // XCD-partitioned work list (see gemm.h): consecutive tiles = the column tiles of one A row-panel
     const unsigned ng = G < 8u ? G : 8u;
@@ -49,49 +54,54 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
     // Fragment addresses.  With slot = 2*kk + hf and the swizzle slot ^ f(row), the byte offset of k-step kk is
     // base ^ (kk << 5) with base = row*128 + ((f >> 1) << 5) + ((hf ^ (f & 1)) << 4): ONE register per fragment row
     // instead of one per (row, kk); the buffer bit (1 << 16) is folded into the same XOR.
-    unsigned base_a[4], base_b[2];
+    unsigned base_a[TI], base_b[TJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 128 * wm + 32 * i + lq, f = ((row >> 1) ^ (row >> 4)) & 7;
+    for (int i = 0; i < TI; ++i) {
+        const int row = WROWS * wm + 32 * i + lq, f = ((row >> 1) ^ (row >> 4)) & 7;
         base_a[i] = (unsigned)(row * 128 + ((f >> 1) << 5) + ((hf ^ (f & 1)) << 4));
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = 64 * wn + 32 * j + lq, f = ((row >> 1) ^ (row >> 4)) & 7;
+    for (int j = 0; j < TJ; ++j) {
+        const int row = WCOLS * wn + 32 * j + lq, f = ((row >> 1) ^ (row >> 4)) & 7;
         base_b[j] = (unsigned)(G256_OPERAND_BYTES + row * 128 + ((f >> 1) << 5) + ((hf ^ (f & 1)) << 4));
     }
 
     if (slot >= cnt_x) return;
     // DMA source pointers of the current item: wave w moves chunks 4w .. 4w+3 (8 rows each) of both operands
     const bf16_t* ga[4];
-    const bf16_t* gb[4];
+    const bf16_t* gb[BCH];
     int m0, n0;
     bool live;
     auto setup = [&](unsigned item) {
         const unsigned tile = base_x + item;
         const int tn = tile % tiles_n, tm = tile / tiles_n;
         m0 = tm * G256_BM;
-        n0 = tn * G256_BN;
+        n0 = tn * BN;
         live = m0 < p.M;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = 8 * (4 * w + i) + (lane >> 3);
             const int src_slot = (lane & 7) ^ (((row >> 1) ^ (row >> 4)) & 7);
-            int ra = m0 + row, rb = n0 + row;
+            int ra = m0 + row;
             ra = ra < p.M ? ra : p.M - 1;
-            rb = rb < p.N ? rb : p.N - 1;
             ga[i] = p.A + (long)ra * p.lda + src_slot * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int row = 8 * (BCH * w + i) + (lane >> 3);
+            const int src_slot = (lane & 7) ^ (((row >> 1) ^ (row >> 4)) & 7);
+            int rb = n0 + row;
+            rb = rb < p.N ? rb : p.N - 1;
             gb[i] = p.B + (long)rb * p.ldb + src_slot * 8;
         }
     };
     auto dma = [&](int kt, int buf) {
         char* abuf = smem + buf * 2 * G256_OPERAND_BYTES + 4 * w * 1024;
-        char* bbuf = abuf + G256_OPERAND_BYTES;
+        char* bbuf = smem + buf * 2 * G256_OPERAND_BYTES + G256_OPERAND_BYTES + BCH * w * 1024;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            glds16(ga[i] + kt * G256_BK, abuf + i * 1024);
-            glds16(gb[i] + kt * G256_BK, bbuf + i * 1024);
-        }
+        for (int i = 0; i < 4; ++i) glds16(ga[i] + kt * G256_BK, abuf + i * 1024);
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) glds16(gb[i] + kt * G256_BK, bbuf + i * 1024);
     };
 #ifdef CCD_GEMM_LAB     // per-phase cycle totals of wave 0 -> p.colsum (8 u64 per workgroup) when m_fastest & 64
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -104,11 +114,11 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
     setup(item);
     if (live) dma(0, 0);
     while (true) {
-        f32x16 acc[4][2];
+        f32x16 acc[TI][TJ];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         glds_wait_all();
@@ -122,25 +132,25 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
             wave_prio<1>();
 #endif
             // fragments of k-step kk+1 are requested before the 8 MFMAs of k-step kk are issued
-            bf16x8 a[2][4], b[2][2];
+            bf16x8 a[2][TI], b[2][TJ];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[0][j] = *reinterpret_cast<const bf16x8*>(smem + (base_b[j] ^ bufbit));
+            for (int j = 0; j < TJ; ++j) b[0][j] = *reinterpret_cast<const bf16x8*>(smem + (base_b[j] ^ bufbit));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[0][i] = *reinterpret_cast<const bf16x8*>(smem + (base_a[i] ^ bufbit));
+            for (int i = 0; i < TI; ++i) a[0][i] = *reinterpret_cast<const bf16x8*>(smem + (base_a[i] ^ bufbit));
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int cur = kk & 1, nxt = cur ^ 1;
                 if (kk < 3) {
                     const unsigned x = bufbit | (unsigned)((kk + 1) << 5);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) b[nxt][j] = *reinterpret_cast<const bf16x8*>(smem + (base_b[j] ^ x));
+                    for (int j = 0; j < TJ; ++j) b[nxt][j] = *reinterpret_cast<const bf16x8*>(smem + (base_b[j] ^ x));
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) a[nxt][i] = *reinterpret_cast<const bf16x8*>(smem + (base_a[i] ^ x));
+                    for (int i = 0; i < TI; ++i) a[nxt][i] = *reinterpret_cast<const bf16x8*>(smem + (base_a[i] ^ x));
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < TI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < TJ; ++j)
                         acc[i][j] = mfma_32x32x16_bf16(b[cur][j], a[cur][i], acc[i][j]);   // D^T[n][m]
             }
 #ifdef CCD_G256_PRIO
@@ -164,42 +174,47 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
         if (elive) {
 
         // ---- epilogue (LDS-only barriers: the DMA stays in flight).  The products were accumulated TRANSPOSED, so a
-        // lane owns 4 consecutive columns of one row: 16-byte (fp32) / 8-byte (bf16) staging writes.  Four passes, pass q
-        // = the q-th 32-row slab of every wave = 64 tile rows x 256 columns, in a 16-byte-chunk XOR-swizzled image.
+        // lane owns 4 consecutive columns of one row: 16-byte (fp32) / 8-byte (bf16) staging writes.  TI passes, pass q
+        // = the q-th 32-row slab of every wave = 32*WM tile rows x BN columns, in a 16-byte-chunk XOR-swizzled image
+        // (at most 64 KiB: 64 x 256 or 128 x 128 fp32).
         char* stg = smem + 2 * G256_OPERAND_BYTES;
         constexpr bool STAGE_BF16 = (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU);   // bf16 outputs: staged packed
         // (DGELU: the bf16-rounded product is multiplied by gelu'(u) in the row pass, where the aux read is coalesced)
+        constexpr int SROWS = 32 * WM;                        // staged rows per pass
+        constexpr int ROWB = STAGE_BF16 ? BN * 2 : BN * 4;    // bytes per staged row
+        constexpr int CT = BN / 8;                            // column threads (8 columns each) in the row pass
+        constexpr int RSTEP = G256_THREADS / CT;              // rows per row-pass step
         if (p.alpha != 1.0f) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] *= p.alpha;
         }
-        #ifdef CCD_GEMM_LAB
+#ifdef CCD_GEMM_LAB
         const bool want_stats = (EPI == EPI_DGELU || EPI == EPI_BF16) && p.colsum != nullptr && !(p.m_fastest & 64);
 #else
         const bool want_stats = (EPI == EPI_DGELU || EPI == EPI_BF16) && p.colsum != nullptr;
 #endif
         float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const int ct = t & 31, rr = t >> 5;                  // row pass: 8 columns per thread, 16 rows per step
+        const int ct = t % CT, rr = t / CT;                   // row pass: 8 columns per thread, RSTEP rows per step
         const int gn = en0 + 8 * ct;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < TI; ++q) {
             const int srow = 32 * wm + lq;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TJ; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int nl = 64 * wn + 32 * j + 8 * g + 4 * hf;      // first of this lane's 4 columns
+                    const int nl = WCOLS * wn + 32 * j + 8 * g + 4 * hf;   // first of this lane's 4 columns
                     float v0 = acc[q][j][4 * g], v1 = acc[q][j][4 * g + 1], v2 = acc[q][j][4 * g + 2], v3 = acc[q][j][4 * g + 3];
                     if (STAGE_BF16) {
                         if (EPI != EPI_DGELU && p.bias && en0 + nl < p.N) {
                             const f32x4v b = *reinterpret_cast<const f32x4v*>(p.bias + en0 + nl);
                             v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
                         }
-                        char* dst = stg + srow * 512 + (((nl >> 3) ^ (srow & 15)) * 16) + ((nl >> 2) & 1) * 8;
+                        char* dst = stg + srow * ROWB + (((nl >> 3) ^ (srow & 15)) * 16) + ((nl >> 2) & 1) * 8;
                         u32x2 o;
                         o.x = pack_bf2(v0, v1);
                         o.y = pack_bf2(v2, v3);
@@ -207,23 +222,23 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                         if (EPI == EPI_GELU) {
                             o.x = pack_bf2(gelu_f(v0), gelu_f(v1));
                             o.y = pack_bf2(gelu_f(v2), gelu_f(v3));
-                            *reinterpret_cast<u32x2*>(dst + 64 * 512) = o;
+                            *reinterpret_cast<u32x2*>(dst + SROWS * ROWB) = o;
                         }
                     } else {
                         const f32x4v o = {v0, v1, v2, v3};
-                        *reinterpret_cast<f32x4v*>(stg + srow * 1024 + (((nl >> 2) ^ (srow & 15)) * 16)) = o;
+                        *reinterpret_cast<f32x4v*>(stg + srow * ROWB + (((nl >> 2) ^ (srow & 15)) * 16)) = o;
                     }
                 }
             G256_STAMP(4)
             lds_barrier();
             G256_STAMP(5)
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int s2 = pass * 16 + rr;
-                const int gm = em0 + (s2 < 32 ? 32 * q + s2 : 128 + 32 * q + (s2 - 32));
+            for (int pass = 0; pass < SROWS / RSTEP; ++pass) {
+                const int s2 = pass * RSTEP + rr;
+                const int gm = em0 + WROWS * (s2 >> 5) + 32 * q + (s2 & 31);
                 if (gm < p.M && gn < p.N) {
                     if (STAGE_BF16) {
-                        const char* src = stg + s2 * 512 + ((ct ^ (s2 & 15)) * 16);
+                        const char* src = stg + s2 * ROWB + ((ct ^ (s2 & 15)) * 16);
                         if (EPI == EPI_DGELU) {
                             float v[8], u[8];
                             unpack8(*reinterpret_cast<const u32x4*>(src), v);
@@ -247,11 +262,11 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                         }
                         if (EPI == EPI_GELU)
                             *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + (long)gm * p.ldc2 + gn) =
-                                *reinterpret_cast<const u32x4*>(src + 64 * 512);
+                                *reinterpret_cast<const u32x4*>(src + SROWS * ROWB);
                     } else {
                         float v[8];
-                        const f32x4v c0 = *reinterpret_cast<const f32x4v*>(stg + s2 * 1024 + (((2 * ct) ^ (s2 & 15)) * 16));
-                        const f32x4v c1 = *reinterpret_cast<const f32x4v*>(stg + s2 * 1024 + (((2 * ct + 1) ^ (s2 & 15)) * 16));
+                        const f32x4v c0 = *reinterpret_cast<const f32x4v*>(stg + s2 * ROWB + (((2 * ct) ^ (s2 & 15)) * 16));
+                        const f32x4v c1 = *reinterpret_cast<const f32x4v*>(stg + s2 * ROWB + (((2 * ct + 1) ^ (s2 & 15)) * 16));
                         v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
                         v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
                         gemm_epilogue_row8<EPI>(p, gm, gn, v);
@@ -266,15 +281,15 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
             lds_barrier();                                   // staging image read out
             G256_STAMP(5)
         }
-        if (want_stats) {                                    // 16 row-threads per 8-column group -> one atomic per column
+        if (want_stats) {                                    // RSTEP row-threads per 8-column group -> one atomic per column
             float* red = reinterpret_cast<float*>(stg);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[rr * 256 + 8 * ct + e] = csum[e];
+            for (int e = 0; e < 8; ++e) red[rr * BN + 8 * ct + e] = csum[e];
             lds_barrier();
-            if (t < 256 && en0 + t < p.N) {
+            if (t < BN && en0 + t < p.N) {
                 float a = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a += red[r * 256 + t];
+#pragma unroll 8
+                for (int r = 0; r < RSTEP; ++r) a += red[r * BN + t];
                 atomicAdd(p.colsum + en0 + t, a);
             }
             lds_barrier();

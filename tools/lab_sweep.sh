@@ -1,5 +1,4 @@
-for lib in "" /root/repo/gpurun_lab/libccd_lab.so; do
-  echo "lib=$lib"
-  CCD_HIP_LIB=$lib python tools/microbench.py 2>&1 | grep "gemm_nt_qkv\|fc1_gelu\|8192x8192"
-  CCD_HIP_LIB=$lib python tools/microbench.py 2>&1 | grep "gemm_nt_qkv\|fc1_gelu\|8192x8192"
+for mode in 1 2; do
+  echo "CCD_GEMM_256=$mode"
+  CCD_GEMM_256=$mode python tools/microbench.py 2>&1 | grep "gemm_nt"
 done
