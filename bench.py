@@ -136,7 +136,8 @@ def main():
         m_rows = engine.Selection(torch.cat([ids, ops.warp_idmap(ids, metrics)]), B).M / B
         body, per_row = GF_PER_IMAGE.get(a.arch, GF_PER_IMAGE["vit_small"])
         gf_img = body + per_row * 2 * m_rows
-        line = {"metric": "images/sec (32x128 crops, 2 views) CCD-ViT-Small pretrain step", "value": round(ips, 2),
+        arch_name = {"vit_small": "CCD-ViT-Small", "vit_base": "CCD-ViT-Base", "vit_tiny": "CCD-ViT-Tiny"}.get(a.arch, a.arch)
+        line = {"metric": f"images/sec (32x128 crops, 2 views) {arch_name} pretrain step", "value": round(ips, 2),
                 "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16", "data": "synthetic",
@@ -152,7 +153,7 @@ def main():
             key, d = top
             avg_ms = d["ms"] / d["launches"]
             achieved = d["flops"] / d["launches"] / avg_ms / 1e9
-            line["roofline"] = {"bound": "mfma", "kernel": f"ccd::gemm_bf16_kernel ({key})",
+            line["roofline"] = {"bound": "mfma", "kernel": f"ccd::gemm_bf16_kernel / ccd::gemm256_kernel ({key})",
                                 "achieved": round(achieved, 1), "peak": PEAK_BF16_TF, "unit": "TFLOP/s",
                                 "frac": round(achieved / PEAK_BF16_TF, 4), "traffic": pmc_traffic(key, a),
                                 "avg_launch_ms": round(avg_ms, 4), "launches_per_step": d["launches"] // a.steps,

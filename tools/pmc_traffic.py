@@ -31,6 +31,10 @@ def collect(path, counter):
             if "gemm_bf16_kernel" in name:
                 m = re.search(r"gemm_bf16_kernel(<[^>]*>)", name)
                 key = KINDS.get(m.group(1), m.group(1)) if m else "gemm?"
+            elif "gemm256_kernel" in name:                   # same kinds as bench.py's KernelTimer keys
+                m = re.search(r"gemm256_kernel<(\d+)", name)
+                key = {"0": "gemm_nt_bf16", "1": "gemm_nt_gelu", "2": "gemm_nt_resid", "3": "gemm_nt_f32",
+                       "5": "gemm_nt_dgelu"}.get(m.group(1), "gemm256?") if m else "gemm256?"
             elif "ln_fwd_kernel" in name:
                 key = "ln_fwd"
             else:
