@@ -180,10 +180,30 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
         char* stg = smem + 2 * G256_OPERAND_BYTES;
         constexpr bool STAGE_BF16 = (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_DGELU);   // bf16 outputs: staged packed
         // (DGELU: the bf16-rounded product is multiplied by gelu'(u) in the row pass, where the aux read is coalesced)
+        // GELU / gelu' by table: their argument is a bf16 value (the stored pre-activation u), and Phi / gelu' need only
+        // |u| in [2^-8, 16) = 1536 bf16 bit patterns (below: Phi ~ 0.5 to 6e-6 in the product, above: exactly 0 / 1;
+        // f(-u) = 1 - f(u) for both).  One LDS gather + ~8 VALU per element instead of ~20-25 VALU of erf / exp:
+        // the transcendental epilogue used to cost as many cycles as the K = 384 main loop.
+        constexpr unsigned LUT_LO = 0x3B80u, LUT_HI = 0x4180u;
+        constexpr bool USE_LUT = (EPI == EPI_GELU || EPI == EPI_DGELU);
         constexpr int SROWS = 32 * WM;                        // staged rows per pass
         constexpr int ROWB = STAGE_BF16 ? BN * 2 : BN * 4;    // bytes per staged row
         constexpr int CT = BN / 8;                            // column threads (8 columns each) in the row pass
         constexpr int RSTEP = G256_THREADS / CT;              // rows per row-pass step
+        float* lut = reinterpret_cast<float*>(stg + SROWS * ROWB);        // behind the (single) bf16 staging image
+        if (USE_LUT) {
+            for (unsigned i = t; i < LUT_HI - LUT_LO; i += G256_THREADS) {
+                const float x = bf2f((bf16_t)(LUT_LO + i));
+                const GeluTerms gt = gelu_terms(x);
+                lut[i] = EPI == EPI_GELU ? gt.cdf : fmaf(x * 0.3989422804014327f, gt.gauss, gt.cdf);
+            }
+        }
+        auto lut_at = [&](unsigned bits16) -> float {         // f(u) for the bf16 bit pattern of u
+            const unsigned mag = bits16 & 0x7fffu;
+            const unsigned idx = (mag < LUT_LO ? LUT_LO : (mag > LUT_HI - 1u ? LUT_HI - 1u : mag)) - LUT_LO;
+            const float f = lut[idx];
+            return (bits16 & 0x8000u) ? 1.0f - f : f;
+        };
         if (p.alpha != 1.0f) {
 #pragma unroll
             for (int i = 0; i < TI; ++i)
@@ -218,12 +238,7 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                         u32x2 o;
                         o.x = pack_bf2(v0, v1);
                         o.y = pack_bf2(v2, v3);
-                        if (EPI != EPI_GELU || p.C) *reinterpret_cast<u32x2*>(dst) = o;
-                        if (EPI == EPI_GELU) {
-                            o.x = pack_bf2(gelu_f(v0), gelu_f(v1));
-                            o.y = pack_bf2(gelu_f(v2), gelu_f(v3));
-                            *reinterpret_cast<u32x2*>(dst + SROWS * ROWB) = o;
-                        }
+                        *reinterpret_cast<u32x2*>(dst) = o;
                     } else {
                         const f32x4v o = {v0, v1, v2, v3};
                         *reinterpret_cast<f32x4v*>(stg + srow * ROWB + (((nl >> 2) ^ (srow & 15)) * 16)) = o;
@@ -240,11 +255,11 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                     if (STAGE_BF16) {
                         const char* src = stg + s2 * ROWB + ((ct ^ (s2 & 15)) * 16);
                         if (EPI == EPI_DGELU) {
-                            float v[8], u[8];
+                            float v[8];
                             unpack8(*reinterpret_cast<const u32x4*>(src), v);
-                            unpack8(*reinterpret_cast<const u32x4*>(p.aux + (long)gm * p.ldaux + gn), u);
+                            const u32x4 uw = *reinterpret_cast<const u32x4*>(p.aux + (long)gm * p.ldaux + gn);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] *= dgelu_f(u[e]);
+                            for (int e = 0; e < 8; ++e) v[e] *= lut_at((uw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
                             *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = pack8(v);
                             if (want_stats) {
 #pragma unroll
@@ -260,9 +275,14 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                                 for (int e = 0; e < 8; ++e) csum[e] += v[e];
                             }
                         }
-                        if (EPI == EPI_GELU)
-                            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + (long)gm * p.ldc2 + gn) =
-                                *reinterpret_cast<const u32x4*>(src + SROWS * ROWB);
+                        if (EPI == EPI_GELU) {                // gelu(u) of the bf16 pre-activation that backward will see
+                            const u32x4 uw = *reinterpret_cast<const u32x4*>(src);
+                            float gq[8];
+                            unpack8(uw, gq);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) gq[e] *= lut_at((uw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + (long)gm * p.ldc2 + gn) = pack8(gq);
+                        }
                     } else {
                         float v[8];
                         const f32x4v c0 = *reinterpret_cast<const f32x4v*>(stg + s2 * ROWB + (((2 * ct) ^ (s2 & 15)) * 16));
