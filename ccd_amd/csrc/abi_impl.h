@@ -148,14 +148,16 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
     p.colsum = colsum;
     // kernel choice (all three are parity-tested): CCD_GEMM_NT32=0 / CCD_GEMM_ARES=1 switch variants for A/B timing
     // read per call (not cached): the tests flip these to force small problems through the 256-row kernels.
-    // CCD_GEMM_256: 0 = off, 1 = 256x256 tiles for N >= 512 bf16-output epilogues (default), 2 = additionally 256x128
+    // CCD_GEMM_256: 0 = off, 1 = 256x256 tiles for N >= 384 bf16-output epilogues (default), 2 = additionally 256x128
     // tiles for every other large-M product (lab switch; see DESIGN.md section 3 for the measurements)
     const char* g256 = getenv("CCD_GEMM_256");
     const int mode_256 = g256 ? atoi(g256) : 1;
     const int min_m_256 = getenv("CCD_GEMM_256_MIN_M") ? atoi(getenv("CCD_GEMM_256_MIN_M")) : 2048;
-    const int min_n_256 = getenv("CCD_GEMM_256_MIN_N") ? atoi(getenv("CCD_GEMM_256_MIN_N")) : 512;
+    const int min_n_256 = getenv("CCD_GEMM_256_MIN_N") ? atoi(getenv("CCD_GEMM_256_MIN_N")) : 384;
+    const bool f32_too = ccd_env_flag("CCD_GEMM_256_F32", false);
     const bool bf16_out = epilogue == CCD_EPI_BF16 || epilogue == CCD_EPI_GELU || epilogue == CCD_EPI_DGELU;
-    if (mode_256 >= 1 && bf16_out && M >= min_m_256 && N >= min_n_256) return ccd_launch_gemm256<256>(p, epilogue, stream);
+    if (mode_256 >= 1 && (bf16_out || (f32_too && epilogue != CCD_EPI_ATOMIC)) && M >= min_m_256 && N >= min_n_256)
+        return ccd_launch_gemm256<256>(p, epilogue, stream);
     if (mode_256 >= 2 && epilogue != CCD_EPI_ATOMIC && M >= min_m_256) return ccd_launch_gemm256<128>(p, epilogue, stream);
     static const bool use_nt32 = ccd_env_flag("CCD_GEMM_NT32", false);
     static const bool use_ares = ccd_env_flag("CCD_GEMM_ARES", false);

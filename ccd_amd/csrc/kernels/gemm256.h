@@ -39,7 +39,9 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
     }
     char* smem = dynamic_smem();
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, hf = lane >> 5, lq = lane & 31;
-    const int wm = w / WN, wn = w % WN;
+    // wave w runs on SIMD w % 4: with wm fastest, the waves of any column sub-range cover all four SIMDs, so a column-
+    // partial tile (N = 384: 256 + 128) whose right-hand waves have nothing to multiply finishes in half the time
+    const int wm = w % WM, wn = w / WM;
     const int tiles_m = (m_static + G256_BM - 1) / G256_BM, tiles_n = (p.N + BN - 1) / BN;
     const unsigned total = (unsigned)(tiles_m * tiles_n), G = gridDim.x;
     // XCD-partitioned work list (see gemm.h): consecutive tiles = the column tiles of one A row-panel
@@ -125,9 +127,11 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
         __syncthreads();
         G256_STAMP(0)
         const int nk_live = live ? nk : 0;
+        const bool wave_live = n0 + WCOLS * wn < p.N;         // this wave's columns exist (column-partial tiles)
         for (int kt = 0; kt < nk_live; ++kt) {
             if (kt + 1 < nk) dma(kt + 1, (kt + 1) & 1);
             const unsigned bufbit = (unsigned)(kt & 1) << 16;       // buffer 1 starts at 64 KiB
+            if (wave_live) {
 #ifdef CCD_G256_PRIO
             wave_prio<1>();
 #endif
@@ -153,6 +157,7 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                     for (int j = 0; j < TJ; ++j)
                         acc[i][j] = mfma_32x32x16_bf16(b[cur][j], a[cur][i], acc[i][j]);   // D^T[n][m]
             }
+            }
 #ifdef CCD_G256_PRIO
             wave_prio<0>();
 #endif
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
         }
         // ---- next item: its first k-tile streams into buffer 0 while this tile is written out through buffer 1
         const int em0 = m0, en0 = n0;
-        const bool elive = live;
+        const bool elive = live, ewave_live = wave_live;
         const unsigned next = item + nx;
         const bool has_next = next < cnt_x;
         if (has_next) {
@@ -223,6 +228,7 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
 #pragma unroll
         for (int q = 0; q < TI; ++q) {
             const int srow = 32 * wm + lq;
+            if (ewave_live)
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
 #pragma unroll

@@ -38,7 +38,7 @@ print(f"{kind} {P}x{Q}x{K}: {ms:.4f} ms  {2.0 * P * Q * K / ms / 1e9:.1f} TFLOP/
 if kind == "nt" and mf & 64:
     st = stamps.view(torch.int64).view(-1, 8)[:512].double().cpu()
     names = ["prologue", "barrier", "compute", "lds-store", "load-issue", "next-prefetch", "epi-stage", "epi-global"]
-    if os.environ.get("CCD_GEMM_256", "1") != "0" and Q >= int(os.environ.get("CCD_GEMM_256_MIN_N", "512")):
+    if os.environ.get("CCD_GEMM_256", "1") != "0" and Q >= int(os.environ.get("CCD_GEMM_256_MIN_N", "384")):
         names = ["first-tile wait", "compute+dma issue", "vmcnt wait", "k barrier", "epi stage", "epi barriers", "epi rows", "-"]
         st = stamps.view(torch.int64).view(-1, 8)[:256].double().cpu()
     tot = st.sum(1).mean().item()
