@@ -21,7 +21,8 @@ sys.path.insert(0, ROOT)
 import torch
 import torch.distributed as dist
 
-PEAK_BF16_TF = 2500.0          # MI355X dense bf16 MFMA peak (guide: MI355X_MICROARCH.md)
+PEAK_BF16_TF = 2500.0       # MI355X dense bf16 MFMA peak (guide: MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (~6.3 TB/s achievable)
 GF_PER_IMAGE = {"vit_small": (96.7 + 8.7, 44.56e-3 * 4), "vit_base": (167.6 + 10.1, 45.09e-3 * 4),
                 "vit_tiny": (25.6 + 6.6, 43.9e-3 * 4)}   # (backbone+seg GF/img, head GF per selected row pair) SURVEY 8d
 
@@ -149,16 +150,30 @@ def main():
                            "final_loss": round(final_loss, 4)}}
         if timer is not None:
             summ = timer.summary()
-            top = max(summ.items(), key=lambda kv: kv[1]["ms"])
-            key, d = top
+            key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])          # the GEMM kind with the largest total time
             avg_ms = d["ms"] / d["launches"]
-            achieved = d["flops"] / d["launches"] / avg_ms / 1e9
-            line["roofline"] = {"bound": "mfma", "kernel": f"ccd::gemm_bf16_kernel / ccd::gemm256_kernel ({key})",
-                                "achieved": round(achieved, 1), "peak": PEAK_BF16_TF, "unit": "TFLOP/s",
-                                "frac": round(achieved / PEAK_BF16_TF, 4), "traffic": pmc_traffic(key, a),
+            tflops = d["flops"] / d["launches"] / avg_ms / 1e9
+            gbs = d["bytes"] / d["launches"] / avg_ms / 1e6
+            # which roof binds this kind: arithmetic intensity of its ALGORITHMIC work against the machine ridge
+            ridge = PEAK_BF16_TF * 1e12 / (PEAK_HBM_GBS * 1e9)                # 312 flop/B on MI355X
+            intensity = d["flops"] / max(d["bytes"], 1.0)
+            hbm_bound = intensity < ridge
+            line["roofline"] = {"bound": "hbm" if hbm_bound else "mfma",
+                                "kernel": f"ccd::gemm_bf16_kernel / ccd::gemm256_kernel ({key})",
+                                "achieved": round(gbs if hbm_bound else tflops, 1),
+                                "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TF,
+                                "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                                "frac": round(gbs / PEAK_HBM_GBS if hbm_bound else tflops / PEAK_BF16_TF, 4),
+                                "traffic": pmc_traffic(key, a),
+                                "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
+                                "algorithmic_flops_per_launch": round(d["flops"] / d["launches"]),
+                                "arithmetic_intensity_flop_per_byte": round(intensity, 1),
+                                "mfma_tflops": round(tflops, 1), "mfma_frac": round(tflops / PEAK_BF16_TF, 4),
+                                "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
                                 "avg_launch_ms": round(avg_ms, 4), "launches_per_step": d["launches"] // a.steps,
                                 "gemm_ms_per_step": round(sum(v["ms"] for v in summ.values()) / a.steps, 3),
-                                "by_kind_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in sorted(summ.items())}}
+                                "by_kind_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in sorted(summ.items())},
+                                "by_kind_tflops": {k: round(v["flops"] / v["ms"] / 1e9, 1) for k, v in sorted(summ.items())}}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.arch)
         print(json.dumps(line), flush=True)

@@ -18,20 +18,21 @@ class KernelTimer:
     only read after the timed region has been synchronised, so recording them never stalls the stream."""
 
     def __init__(self):
-        self.records = []          # (key, flops, start_event, end_event)
+        self.records = []          # (key, flops, algorithmic bytes, start_event, end_event)
 
-    def span(self, key, flops):
+    def span(self, key, flops, nbytes=0.0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.records.append((key, flops, e0, e1))
+        self.records.append((key, flops, nbytes, e0, e1))
         return e0, e1
 
     def summary(self):
         out = {}
-        for key, flops, e0, e1 in self.records:
-            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0})
+        for key, flops, nbytes, e0, e1 in self.records:
+            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flops"] += flops
+            d["bytes"] += nbytes
         return out
 
 
@@ -65,7 +66,12 @@ def gemm_nt(a, b, *, epilogue=EPI_BF16, out=None, out2=None, bias=None, resid=No
     if m_fastest is None:
         m_fastest = 1 if N > M else 0
     lib = _lib.get()
-    span = TIMER.span("gemm_nt_" + _EPI_NAMES[epilogue], 2.0 * M * N * K) if TIMER is not None and d_rows is None else None
+    span = None
+    if TIMER is not None and d_rows is None:
+        # algorithmic bytes: each operand read once, each output written once (bf16 = 2 B, fp32 = 4 B)
+        nbytes = 2.0 * (M * K + N * K) + M * N * {EPI_BF16: 2, EPI_GELU: 2 + (2 if store_u else 0), EPI_RESID: 8, EPI_F32: 4,
+                                                   EPI_ATOMIC: 8, EPI_DGELU: 4}[epilogue]
+        span = TIMER.span("gemm_nt_" + _EPI_NAMES[epilogue], 2.0 * M * N * K, nbytes)
     if span:
         span[0].record()
     _lib.check(lib.ccd_gemm_nt(_lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0), M, N, K, epilogue, _lib.ptr(out),
@@ -86,7 +92,8 @@ def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, splits=0, d_rows=None, row
     Q = b.shape[1]
     assert b.shape[0] == Mc and tuple(out.shape) == (Pd, Q)
     lib = _lib.get()
-    span = TIMER.span("gemm_tn_" + ("atomic" if accumulate else "f32"), 2.0 * Mc * Pd * Q) \
+    span = TIMER.span("gemm_tn_" + ("atomic" if accumulate else "f32"), 2.0 * Mc * Pd * Q,
+                      2.0 * Mc * (Pd + Q) + 4.0 * Pd * Q) \
         if TIMER is not None and d_rows is None else None
     if span:
         span[0].record()
@@ -382,7 +389,8 @@ def conv_gemm(src, desc, w, rows, out, *, bias=None, colsum=None, colsumsq=None)
     _chk(colsum, F32, "colsum"); _chk(colsumsq, F32, "colsumsq")
     N = w.shape[0]
     assert w.shape[1] == desc.ntaps * desc.cin and src.dim() == 2 and out.dim() == 2 and out.shape[1] >= N
-    span = TIMER.span("conv_gemm", 2.0 * rows * N * w.shape[1]) if TIMER is not None else None
+    span = TIMER.span("conv_gemm", 2.0 * rows * N * w.shape[1],
+                      2.0 * (src.numel() + w.numel() + rows * N)) if TIMER is not None else None
     if span:
         span[0].record()
     _call("ccd_conv_gemm", _lib.ptr(src), src.stride(0), ctypes.addressof(desc), _lib.ptr(w), w.stride(0), rows, N,
@@ -397,7 +405,8 @@ def conv_wgrad(a, src, desc, out):
     _chk(a, BF16, "a"); _chk(src, BF16, "src"); _chk(out, F32, "out")
     rows, Pd = a.shape
     assert tuple(out.shape) == (Pd, desc.ntaps * desc.cin)
-    span = TIMER.span("conv_wgrad", 2.0 * rows * Pd * out.shape[1]) if TIMER is not None else None
+    span = TIMER.span("conv_wgrad", 2.0 * rows * Pd * out.shape[1],
+                      2.0 * (a.numel() + src.numel()) + 4.0 * out.numel()) if TIMER is not None else None
     if span:
         span[0].record()
     _call("ccd_conv_wgrad", _lib.ptr(a), a.stride(0), Pd, _lib.ptr(src), src.stride(0), ctypes.addressof(desc), rows,
