@@ -9,6 +9,7 @@
 #include "kernels/gemm_ares.h"
 #include "kernels/gemm_nt32.h"
 #include "kernels/gemm256.h"
+#include "kernels/gemm_row384.h"
 #include "kernels/layernorm.h"
 #include "kernels/attention_fwd.h"
 #include "kernels/attention_bwd.h"
@@ -114,6 +115,20 @@ static int ccd_launch_gemm256(const ccd::GemmParams& p, int epilogue, void* stre
     }
     return ccd_rt_last_error();
 }
+// full-row kernel for N <= 384 (gemm_row384.h): one workgroup per CU
+static int ccd_launch_gemm_row384(const ccd::GemmParams& p, int epilogue, void* stream) {
+    const int tiles = (p.M + ccd::GR_BM - 1) / ccd::GR_BM;
+    const int cus = ccd_rt_num_cus();
+    const dim3 grid(tiles < cus ? tiles : cus), block(ccd::GR_THREADS);
+    const size_t smem = ccd::GR_SMEM_BYTES;
+    switch (epilogue) {
+        case CCD_EPI_BF16: CCD_LAUNCH((ccd::gemm_row384_kernel<ccd::EPI_BF16>), grid, block, smem, stream, p); break;
+        case CCD_EPI_RESID: CCD_LAUNCH((ccd::gemm_row384_kernel<ccd::EPI_RESID>), grid, block, smem, stream, p); break;
+        case CCD_EPI_F32: CCD_LAUNCH((ccd::gemm_row384_kernel<ccd::EPI_F32>), grid, block, smem, stream, p); break;
+        default: return CCD_EINVAL;
+    }
+    return ccd_rt_last_error();
+}
 static bool ccd_env_flag(const char* name, bool dflt) {
     const char* v = getenv(name);
     return v ? (v[0] != '0') : dflt;
@@ -154,6 +169,11 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
     const int mode_256 = g256 ? atoi(g256) : 1;
     const int min_m_256 = getenv("CCD_GEMM_256_MIN_M") ? atoi(getenv("CCD_GEMM_256_MIN_M")) : 2048;
     const int min_n_256 = getenv("CCD_GEMM_256_MIN_N") ? atoi(getenv("CCD_GEMM_256_MIN_N")) : 384;
+    // CCD_GEMM_ROW384: 1 = full-row kernel for N <= 384 (residual / fp32 / bf16 epilogues)
+    const int mode_row = getenv("CCD_GEMM_ROW384") ? atoi(getenv("CCD_GEMM_ROW384")) : 0;
+    if (mode_row >= 1 && N <= ccd::GR_BN && M >= min_m_256 &&
+        (epilogue == CCD_EPI_RESID || epilogue == CCD_EPI_F32 || (epilogue == CCD_EPI_BF16 && mode_row >= 2)))
+        return ccd_launch_gemm_row384(p, epilogue, stream);
     const bool f32_too = ccd_env_flag("CCD_GEMM_256_F32", false);
     const bool bf16_out = epilogue == CCD_EPI_BF16 || epilogue == CCD_EPI_GELU || epilogue == CCD_EPI_DGELU;
     if (mode_256 >= 1 && (bf16_out || (f32_too && epilogue != CCD_EPI_ATOMIC)) && M >= min_m_256 && N >= min_n_256)

@@ -1,0 +1,247 @@
+// gemm_row384.h - NT GEMM for the N <= 384 products of the transformer (proj / fc2 with the fp32 residual epilogue,
+// the data gradients of qkv / fc1 / proj): one workgroup owns FULL output rows - a 128 x 384 tile, 8 waves (2 x 4,
+// 64 x 96 per wave), BK = 64, one workgroup per CU.
+//
+// Why: with 128-wide column tiles (gemm.h) the A row-panel of such a product is streamed three times, by three
+// workgroups that drift apart in the persistent schedule, so the re-reads miss the XCD's L2 (PMC: 859 MB moved per
+// launch for 655 MB of algorithmic traffic on the residual GEMMs, the step's dominant and HBM-bound kernel kind).
+// Here A is read exactly once, there is no column-partial tile, and an epilogue that owns whole rows can later take
+// the following LayerNorm with it.
+//
+// Structure = gemm.h's: operands by buffer loads (branch-free predicates, zero VALU in the loop), two register sets
+// hold k-tiles t+1 / t+2 (2 + 6 sixteen-byte pieces per thread and set) while tile t is multiplied out of one of two
+// 64-KiB LDS stages, persistent work list with the next tile's first k-tiles in flight under the epilogue.  The
+// products are accumulated transposed (lane = one row, 4 consecutive columns), staged through a swizzled LDS image
+// (bf16 64 rows / fp32 32 rows per pass) and written out by the shared row epilogue.
+#pragma once
+
+namespace ccd {
+
+constexpr int GR_BM = 128, GR_BN = 384, GR_BK = 64, GR_THREADS = 512;
+constexpr int GR_A_BYTES = GR_BM * GR_BK * 2, GR_B_BYTES = GR_BN * GR_BK * 2;   // 16 KiB + 48 KiB per stage
+constexpr int GR_STAGE_BYTES = GR_A_BYTES + GR_B_BYTES;                          // 64 KiB
+constexpr int GR_SMEM_BYTES = 2 * GR_STAGE_BYTES;                                // 128 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p) {
+    const int m_static = p.M;
+    if (p.d_rows) {
+        const int dyn = p.d_rows[0] * p.rows_mul;
+        p.M = dyn < p.M ? dyn : p.M;
+    }
+    char* smem = dynamic_smem();
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, hf = lane >> 5, lq = lane & 31;
+    const int wm = w & 1, wn = w >> 1;                       // wm fastest: any column range covers all four SIMDs
+    const unsigned total = (unsigned)((m_static + GR_BM - 1) / GR_BM), G = gridDim.x;
+    const unsigned ng = G < 8u ? G : 8u;
+    const unsigned xcd = blockIdx.x % ng, slot = blockIdx.x / ng;
+    const unsigned nx = G / ng + (xcd < G % ng ? 1u : 0u);
+    const unsigned q8 = total / ng, r8 = total % ng;
+    const unsigned base_x = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const unsigned cnt_x = q8 + (xcd < r8 ? 1u : 0u);
+    if (slot >= cnt_x) return;
+    const int nk_full = p.K / GR_BK;
+
+    // staging pieces of this thread: A rows (t >> 3) + 64 i, B rows (t >> 3) + 64 i, 16-byte slot t & 7
+    unsigned offa[2], offb[6];
+    const int srow = t >> 3, sslot = t & 7;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int row = srow + 64 * i;
+        offb[i] = row < p.N ? (unsigned)(((long)row * p.ldb + sslot * 8) * 2) : BUF_OOB;
+    }
+    int m0, nk;
+    auto setup = [&](unsigned item) {
+        m0 = (int)(base_x + item) * GR_BM;
+        nk = m0 < p.M ? nk_full : 0;                        // tiles past a device-side row count do nothing
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = m0 + srow + 64 * i;
+            offa[i] = row < p.M ? (unsigned)(((long)row * p.lda + sslot * 8) * 2) : BUF_OOB;
+        }
+    };
+    u32x4 ra0[2], rb0[6], ra1[2], rb1[6];
+    auto load = [&](int kt, u32x4 (&ra)[2], u32x4 (&rb)[6]) {
+        const unsigned whole = kt < nk ? BUF_OOB : 0u;
+        const buf_rsrc rsa = make_rsrc(p.A + kt * GR_BK, whole), rsb = make_rsrc(p.B + kt * GR_BK, whole);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ra[i] = buf_load16(rsa, offa[i]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) rb[i] = buf_load16(rsb, offb[i]);
+    };
+    auto store = [&](int stage, const u32x4 (&ra)[2], const u32x4 (&rb)[6]) {
+        char* as = smem + stage * GR_STAGE_BYTES;
+        char* bs = as + GR_A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = srow + 64 * i;
+            *reinterpret_cast<u32x4*>(as + row * 128 + gemm_swz(row, sslot) * 16) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int row = srow + 64 * i;
+            *reinterpret_cast<u32x4*>(bs + row * 128 + gemm_swz(row, sslot) * 16) = rb[i];
+        }
+    };
+    // fragment addresses: offset(kk) = base ^ (kk << 5) (see gemm256.h), stage bit 1 << 16 folded into the XOR
+    unsigned base_a[2], base_b[3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 64 * wm + 32 * i + lq, f = ((row >> 1) ^ (row >> 4)) & 7;
+        base_a[i] = (unsigned)(row * 128 + ((f >> 1) << 5) + ((hf ^ (f & 1)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int row = 96 * wn + 32 * j + lq, f = ((row >> 1) ^ (row >> 4)) & 7;
+        base_b[j] = (unsigned)(GR_A_BYTES + row * 128 + ((f >> 1) << 5) + ((hf ^ (f & 1)) << 4));
+    }
+    f32x16 acc[2][3];
+    auto compute = [&](unsigned stagebit) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const unsigned x = stagebit | (unsigned)(kk << 5);
+            bf16x8 a[2], b[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) b[j] = *reinterpret_cast<const bf16x8*>(smem + (base_b[j] ^ x));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(smem + (base_a[i] ^ x));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i][j] = mfma_32x32x16_bf16(b[j], a[i], acc[i][j]);   // D^T[n][m]
+        }
+    };
+
+    unsigned item = slot;
+    setup(item);
+    load(0, ra0, rb0);
+    load(1, ra1, rb1);
+    while (true) {
+        store(0, ra0, rb0);
+        load(2, ra0, rb0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {                // branch-free steady state, as gemm.h
+            const unsigned s0 = opaque_u32(0u), s1 = opaque_u32(1u << 16);
+            compute(s0);
+            store(1, ra1, rb1);
+            load(kt + 3, ra1, rb1);
+            __syncthreads();
+            compute(s1);
+            store(0, ra0, rb0);
+            load(kt + 4, ra0, rb0);
+            __syncthreads();
+        }
+        const int em0 = m0;
+        const bool elive = nk > 0;
+        const unsigned next = item + nx;
+        const bool has_next = next < cnt_x;
+        if (has_next) {                                      // next tile's first two k-tiles fly under the epilogue
+            setup(next);
+            load(0, ra0, rb0);
+            load(1, ra1, rb1);
+        }
+        if (elive) {
+            // ---- epilogue: staged rows per pass: bf16 64 (both wm halves), fp32 32 (one wm half) -> <= 48 KiB
+            constexpr bool STAGE_BF16 = (EPI == EPI_BF16);
+            constexpr int ROWB = STAGE_BF16 ? GR_BN * 2 : GR_BN * 4;
+            constexpr int WMP = STAGE_BF16 ? 2 : 1;          // wm halves staged together
+            constexpr int SROWS = 32 * WMP;
+            constexpr int CT = GR_BN / 8, RSTEP = GR_THREADS / CT;       // 48 column threads, 10 rows per step
+            char* stg = smem;
+            if (p.alpha != 1.0f) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] *= p.alpha;
+            }
+            const bool want_stats = EPI == EPI_BF16 && p.colsum != nullptr;
+            float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const int ct = t % CT, rr = t / CT;
+            const int gn = 8 * ct;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int h = 0; h < 2 / WMP; ++h) {
+                    const int sr = (WMP == 2 ? 32 * wm : 0) + lq;
+                    if (WMP == 2 || wm == h) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int nl = 96 * wn + 32 * j + 8 * g + 4 * hf;
+                                float v0 = acc[q][j][4 * g], v1 = acc[q][j][4 * g + 1], v2 = acc[q][j][4 * g + 2],
+                                      v3 = acc[q][j][4 * g + 3];
+                                if (STAGE_BF16) {
+                                    if (p.bias && nl < p.N) {
+                                        const f32x4v b = *reinterpret_cast<const f32x4v*>(p.bias + nl);
+                                        v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+                                    }
+                                    u32x2 o;
+                                    o.x = pack_bf2(v0, v1);
+                                    o.y = pack_bf2(v2, v3);
+                                    *reinterpret_cast<u32x2*>(stg + sr * ROWB + (((nl >> 3) ^ (sr & 15)) * 16) +
+                                                              ((nl >> 2) & 1) * 8) = o;
+                                } else {
+                                    const f32x4v o = {v0, v1, v2, v3};
+                                    *reinterpret_cast<f32x4v*>(stg + sr * ROWB + (((nl >> 2) ^ (sr & 15)) * 16)) = o;
+                                }
+                            }
+                    }
+                    lds_barrier();
+                    if (rr < RSTEP) {
+                        for (int s2 = rr; s2 < SROWS; s2 += RSTEP) {
+                            const int gm = em0 + 64 * (WMP == 2 ? (s2 >> 5) : h) + 32 * q + (s2 & 31);
+                            if (gm < p.M && gn < p.N) {
+                                if (STAGE_BF16) {
+                                    const u32x4 wv = *reinterpret_cast<const u32x4*>(stg + s2 * ROWB + ((ct ^ (s2 & 15)) * 16));
+                                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = wv;
+                                    if (want_stats) {
+                                        float v[8];
+                                        unpack8(wv, v);
+#pragma unroll
+                                        for (int e = 0; e < 8; ++e) csum[e] += v[e];
+                                    }
+                                } else {
+                                    float v[8];
+                                    const f32x4v c0 = *reinterpret_cast<const f32x4v*>(stg + s2 * ROWB + (((2 * ct) ^ (s2 & 15)) * 16));
+                                    const f32x4v c1 = *reinterpret_cast<const f32x4v*>(stg + s2 * ROWB + (((2 * ct + 1) ^ (s2 & 15)) * 16));
+                                    v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
+                                    v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+                                    gemm_epilogue_row8<EPI>(p, gm, gn, v);
+                                }
+                            }
+                        }
+                    }
+                    lds_barrier();
+                }
+            }
+            if (want_stats) {
+                float* red = reinterpret_cast<float*>(stg);
+                if (rr < RSTEP) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) red[rr * GR_BN + 8 * ct + e] = csum[e];
+                }
+                lds_barrier();
+                if (t < GR_BN && t < p.N) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int r = 0; r < RSTEP; ++r) a += red[r * GR_BN + t];
+                    atomicAdd(p.colsum + t, a);
+                }
+                lds_barrier();
+            }
+        }
+        if (!has_next) break;
+        item = next;
+    }
+}
+
+}  // namespace ccd

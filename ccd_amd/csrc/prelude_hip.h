@@ -61,6 +61,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // static wave priority (guide T5): 0..3, arbitration between the waves sharing a SIMD
 template <int P>
 __device__ __forceinline__ void wave_prio() { __builtin_amdgcn_s_setprio(P); }
+// value the optimiser must treat as unknown (keeps `base ^ constant` address arithmetic inside a loop instead of
+// hoisting one register per combination)
+__device__ __forceinline__ unsigned opaque_u32(unsigned x) { asm volatile("" : "+s"(x)); return x; }
 // hardware float -> bf16 (RNE): clang lowers the __bf16 casts to v_cvt_pk_bf16_f32 on gfx950
 typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {

@@ -115,3 +115,12 @@ def test_gemm256(hip, monkeypatch, M, N, K):
     for seed in range(2):
         kc.check_gemm_nt(hip.device, M=M, N=N, K=K, seed=seed)
     kc.check_gemm_dynamic_rows(hip.device, M=max(M, 600), N=N, K=K, live=75)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 136, 128), (4096, 384, 1536), (2048, 384, 384)])
+def test_gemm_row384(hip, monkeypatch, M, N, K):
+    monkeypatch.setenv("CCD_GEMM_256_MIN_M", "1")
+    monkeypatch.setenv("CCD_GEMM_ROW384", "2")
+    for seed in range(2):
+        kc.check_gemm_nt(hip.device, M=M, N=N, K=K, seed=seed)
+    kc.check_gemm_dynamic_rows(hip.device, M=max(M, 600), N=N, K=K, live=75)

@@ -107,3 +107,12 @@ def test_gemm256_sim(sim, monkeypatch):
     monkeypatch.setenv("CCD_GEMM_256_MIN_N", "1000000")
     kc.check_gemm_nt(sim.device, M=300, N=136, K=128)
     kc.check_gemm_dynamic_rows(sim.device, M=600, N=136, K=64, live=75)
+
+
+def test_gemm_row384_sim(sim, monkeypatch):
+    """Full-row kernel (128 x 384 tile), forced onto small ragged problems."""
+    monkeypatch.setenv("CCD_GEMM_256_MIN_M", "1")
+    monkeypatch.setenv("CCD_GEMM_ROW384", "2")
+    kc.check_gemm_nt(sim.device, M=300, N=136, K=128)
+    kc.check_gemm_nt(sim.device, M=140, N=384, K=192)
+    kc.check_gemm_dynamic_rows(sim.device, M=600, N=264, K=64, live=75)
