@@ -81,14 +81,15 @@ static int ccd_launch_gemm_nt32(const ccd::GemmParams& p, int epilogue, void* st
     return ccd_rt_last_error();
 }
 // launch geometry of the column reductions (colsum_bf16, bn_relu_bwd_reduce): cgn = 2^cgn_log2 column groups of 8
-// per block (<= 32), every block streams >= 256 KiB, at most 2 blocks per CU
+// per 1024-thread block (<= 32), every block streams >= 1 MiB, at most 2 blocks per CU (the publishing atomics are
+// the expensive part: few, fat blocks)
 static void ccd_reduce_geometry(long rows, int N, int* cgn_log2, int* col_blocks, int* rows_per_block, int* row_blocks) {
     int lg = 0;
     while (lg < 5 && (8 << lg) < N) ++lg;
-    const int cgn = 1 << lg, rln = 256 >> lg;
+    const int cgn = 1 << lg, rln = ccd::COLSUM_THREADS >> lg;
     *cgn_log2 = lg;
     *col_blocks = (N + 8 * cgn - 1) / (8 * cgn);
-    long rb = (rows * (long)(16 * cgn) + (256L << 10) - 1) / (256L << 10);       // bytes per block-column / 256 KiB
+    long rb = (rows * (long)(16 * cgn) + (1L << 20) - 1) / (1L << 20);           // bytes per block-column / 1 MiB
     const long cap = (2L * ccd_rt_num_cus() + *col_blocks - 1) / *col_blocks;
     if (rb > cap) rb = cap;
     if (rb < 1) rb = 1;
@@ -319,7 +320,7 @@ int ccd_colsum_bf16(const ccd_bf16* x, long ld, int rows, int N, const int* d_ro
     CCD_CHECK(rows > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0 && CCD_ALIGNED16(x), CCD_ESHAPE);
     int cgn_log2, col_blocks, rpb, row_blocks;
     ccd_reduce_geometry(rows, N, &cgn_log2, &col_blocks, &rpb, &row_blocks);
-    CCD_LAUNCH(ccd::colsum_bf16_kernel, dim3(col_blocks, row_blocks), dim3(256), 0, stream, x, ld, rows, N, d_rows,
+    CCD_LAUNCH(ccd::colsum_bf16_kernel, dim3(col_blocks, row_blocks), dim3(ccd::COLSUM_THREADS), 0, stream, x, ld, rows, N, d_rows,
                rows_mul, out, rpb, cgn_log2);
     return ccd_rt_last_error();
 }
@@ -648,7 +649,7 @@ int ccd_bn_relu_bwd_reduce(const ccd_bf16* dy, long lddy, const ccd_bf16* x, lon
     CCD_CHECK(rows > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0, CCD_ESHAPE);
     int cgn_log2, col_blocks, rpb, row_blocks;
     ccd_reduce_geometry(rows, C, &cgn_log2, &col_blocks, &rpb, &row_blocks);
-    CCD_LAUNCH(ccd::bn_relu_bwd_reduce_kernel, dim3(col_blocks, row_blocks), dim3(256), 0, stream, dy, lddy, x, ldx,
+    CCD_LAUNCH(ccd::bn_relu_bwd_reduce_kernel, dim3(col_blocks, row_blocks), dim3(ccd::COLSUM_THREADS), 0, stream, dy, lddy, x, ldx,
                mean_rstd, gamma, beta, red, rows, C, rpb, cgn_log2);
     return ccd_rt_last_error();
 }

@@ -70,14 +70,14 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const bf16_t* __restri
 }
 
 // red[0:C] += sum dy*[y>0], red[C:2C] += sum dy*[y>0]*xhat     (dy [rows, lddy] bf16); geometry as colsum_bf16
-__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const bf16_t* __restrict__ dy, long lddy,
+__global__ __launch_bounds__(COLSUM_THREADS) void bn_relu_bwd_reduce_kernel(const bf16_t* __restrict__ dy, long lddy,
                                                                  const bf16_t* __restrict__ x, long ldx,
                                                                  const float* __restrict__ mean_rstd,
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, float* __restrict__ red,
                                                                  long rows, int C, int rows_per_block, int cgn_log2) {
-    __shared__ float part[2][256][8];
-    const int cgn = 1 << cgn_log2, rln = 256 >> cgn_log2;
+    __shared__ float part[2][COLSUM_THREADS][8];
+    const int cgn = 1 << cgn_log2, rln = COLSUM_THREADS >> cgn_log2;
     const int cg = threadIdx.x & (cgn - 1), rl = threadIdx.x >> cgn_log2;
     const int c = (blockIdx.x * cgn + cg) * 8;
     const long r0 = (long)blockIdx.y * rows_per_block;

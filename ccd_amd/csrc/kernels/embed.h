@@ -113,14 +113,16 @@ __global__ void small_matmul_f32_kernel(const float* __restrict__ a, const float
     c[(long)m * N + n] = accumulate ? c[(long)m * N + n] + acc : acc;
 }
 
-// out[n] += sum_rows x[row, n]   (bias gradients).  Block = cgn column groups (8 cols, 16 B; cgn = power of two
-// <= 32 chosen by the host so narrow matrices keep all lanes busy) x 256/cgn row lanes, 4 loads in flight per thread;
-// the host sizes the grid so every block streams >= 256 KiB (few same-address atomics)
-__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, long ld, int rows, int N,
+// out[n] += sum_rows x[row, n]   (bias gradients).  Block = 1024 threads = cgn column groups (8 cols, 16 B; cgn = power
+// of two <= 32 chosen by the host so narrow matrices keep all lanes busy) x 1024/cgn row lanes, 8 loads in flight per
+// thread.  Big blocks on purpose: the fp32 atomics that publish a block's sums cost ~0.3 ns each chip-wide (measured:
+// 131 k atomics = 44 us), so the grid is sized for few blocks (2 per CU) rather than many.
+constexpr int COLSUM_THREADS = 1024;
+__global__ __launch_bounds__(COLSUM_THREADS) void colsum_bf16_kernel(const bf16_t* __restrict__ x, long ld, int rows, int N,
                                                           const int* __restrict__ d_rows, int rows_mul,
                                                           float* __restrict__ out, int rows_per_block, int cgn_log2) {
-    __shared__ float red[256][8];
-    const int cgn = 1 << cgn_log2, rln = 256 >> cgn_log2;
+    __shared__ float red[COLSUM_THREADS][8];
+    const int cgn = 1 << cgn_log2, rln = COLSUM_THREADS >> cgn_log2;
     const int cg = threadIdx.x & (cgn - 1), rl = threadIdx.x >> cgn_log2;
     const int col = (blockIdx.x * cgn + cg) * 8;
     if (d_rows) rows = d_rows[0] * rows_mul < rows ? d_rows[0] * rows_mul : rows;
@@ -129,12 +131,12 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (col < N) {
         int r = r0 + rl;
-        for (; r + 3 * rln < r1; r += 4 * rln) {
-            u32x4 w[4];
+        for (; r + 7 * rln < r1; r += 8 * rln) {              // 8 x 16 B in flight per thread
+            u32x4 w[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const u32x4*>(x + (long)(r + u * rln) * ld + col);
+            for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const u32x4*>(x + (long)(r + u * rln) * ld + col);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 float v[8];
                 unpack8(w[u], v);
 #pragma unroll
