@@ -228,6 +228,18 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
 #pragma unroll
         for (int q = 0; q < TI; ++q) {
             const int srow = 32 * wm + lq;
+            // gelu'(u) epilogue: the pre-activations of this pass's rows are requested BEFORE the staging writes and the
+            // barrier, so their HBM latency is spent there and not serially in front of every row of the row pass
+            u32x4 auxw[SROWS / RSTEP];
+            if (EPI == EPI_DGELU) {
+#pragma unroll
+                for (int pass = 0; pass < SROWS / RSTEP; ++pass) {
+                    const int s2 = pass * RSTEP + rr;
+                    const int gm = em0 + WROWS * (s2 >> 5) + 32 * q + (s2 & 31);
+                    auxw[pass] = u32x4{0u, 0u, 0u, 0u};
+                    if (gm < p.M && gn < p.N) auxw[pass] = *reinterpret_cast<const u32x4*>(p.aux + (long)gm * p.ldaux + gn);
+                }
+            }
             if (ewave_live)
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
@@ -263,7 +275,7 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                         if (EPI == EPI_DGELU) {
                             float v[8];
                             unpack8(*reinterpret_cast<const u32x4*>(src), v);
-                            const u32x4 uw = *reinterpret_cast<const u32x4*>(p.aux + (long)gm * p.ldaux + gn);
+                            const u32x4 uw = auxw[pass];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] *= lut_at((uw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
                             *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = pack8(v);

@@ -1,0 +1,19 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ccd_amd import ops
+dev = torch.device("cuda:0"); BF = torch.bfloat16
+M, N, K = 131072, 1536, 384
+a = torch.randn(M, K, device=dev).to(BF); b = (torch.randn(N, K, device=dev) * 0.1).to(BF)
+aux = torch.randn(M, N, device=dev).to(BF); cs = torch.zeros(N, device=dev); out = torch.empty(M, N, device=dev, dtype=BF)
+def t(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+print("dgelu + colsum", round(t(lambda: ops.gemm_nt(a, b, epilogue=ops.EPI_DGELU, aux=aux, colsum=cs, out=out)), 4), "ms")
+print("dgelu         ", round(t(lambda: ops.gemm_nt(a, b, epilogue=ops.EPI_DGELU, aux=aux, out=out)), 4), "ms")
+print("bf16          ", round(t(lambda: ops.gemm_nt(a, b, epilogue=ops.EPI_BF16, out=out)), 4), "ms")
