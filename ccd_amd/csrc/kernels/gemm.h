@@ -369,6 +369,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 #else
 #define LAB_STAMP(i)
 #endif
+    // column statistics (bias gradients / BatchNorm sums): with a single column tile (N <= 128: every convolution of the
+    // segmentation head) all of a workgroup's tiles cover the same columns, so the sums stay in registers across tiles
+    // and are published once - same-address fp32 atomics cost ~0.3 ns each chip-wide and there were 4 M of them per step
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float csq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     unsigned item = slot;
     decode(item);
     init_loaders();
@@ -452,9 +457,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
                 }
             }
         } else {
-            float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            float csq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const bool want_stats = p.colsum != nullptr || p.colsumsq != nullptr;
+            const bool publish = tiles_n > 1 || !has_next;   // defer while the next tile has the same columns
 #pragma unroll
             for (int pass = 0; pass < 8; ++pass) {       // unrolled: the 16 LDS reads go out first, the stores stream
                 const int row = pass * 16 + (t >> 4), col = (t & 15) * 8;
@@ -478,10 +482,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
                     }
                 }
             }
-            if (EPI == EPI_BF16 && p.colsumsq) {
+            if (EPI == EPI_BF16 && p.colsumsq && publish) {
                 __syncthreads();
 #pragma unroll
-                for (int e = 0; e < 8; ++e) cs[(t >> 4) * GEMM_BN + (t & 15) * 8 + e] = csq[e];
+                for (int e = 0; e < 8; ++e) { cs[(t >> 4) * GEMM_BN + (t & 15) * 8 + e] = csq[e]; csq[e] = 0.f; }
                 __syncthreads();
                 if (t < GEMM_BN && en0 + t < p.N) {
                     float a = 0.f;
@@ -490,10 +494,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
                     atomicAdd(p.colsumsq + en0 + t, a);
                 }
             }
-            if ((EPI == EPI_DGELU || EPI == EPI_BF16) && p.colsum && LAB_ON(64)) {   // block-wide column sums -> one atomic per column
+            if ((EPI == EPI_DGELU || EPI == EPI_BF16) && p.colsum && publish && LAB_ON(64)) {   // block-wide column sums -> one atomic per column
                 __syncthreads();
 #pragma unroll
-                for (int e = 0; e < 8; ++e) cs[(t >> 4) * GEMM_BN + (t & 15) * 8 + e] = csum[e];
+                for (int e = 0; e < 8; ++e) { cs[(t >> 4) * GEMM_BN + (t & 15) * 8 + e] = csum[e]; csum[e] = 0.f; }
                 __syncthreads();
                 if (t < GEMM_BN && en0 + t < p.N) {
                     float a = 0.f;
