@@ -116,13 +116,14 @@ __global__ __launch_bounds__(COLSUM_THREADS) void bn_relu_bwd_reduce_kernel(cons
 #pragma unroll
     for (int e = 0; e < 8; ++e) { part[0][threadIdx.x][e] = s1[e]; part[1][threadIdx.x][e] = s2[e]; }
     __syncthreads();
-    if (rl == 0 && c < C) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
+    if ((int)threadIdx.x < 8 * cgn) {                        // coalesced publication, one column per thread
+        const int c_local = threadIdx.x, g = c_local >> 3, e = c_local & 7;
+        const int cc = blockIdx.x * cgn * 8 + c_local;
+        if (cc < C) {
             float a = 0.f, b = 0.f;
-            for (int j = 0; j < rln; ++j) { a += part[0][j * cgn + cg][e]; b += part[1][j * cgn + cg][e]; }
-            atomicAdd(red + c + e, a);
-            atomicAdd(red + C + c + e, b);
+            for (int j = 0; j < rln; ++j) { a += part[0][j * cgn + g][e]; b += part[1][j * cgn + g][e]; }
+            atomicAdd(red + cc, a);
+            atomicAdd(red + C + cc, b);
         }
     }
 }

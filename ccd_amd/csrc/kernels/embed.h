@@ -153,12 +153,14 @@ __global__ __launch_bounds__(COLSUM_THREADS) void colsum_bf16_kernel(const bf16_
 #pragma unroll
     for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = acc[k];
     __syncthreads();
-    if (rl == 0 && col < N) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
+    // thread t < 8*cgn publishes column t of this block's column range: consecutive lanes -> consecutive addresses
+    if ((int)threadIdx.x < 8 * cgn) {
+        const int c_local = threadIdx.x, g = c_local >> 3, k = c_local & 7;
+        const int c = blockIdx.x * cgn * 8 + c_local;
+        if (c < N) {
             float s = 0.f;
-            for (int j = 0; j < rln; ++j) s += red[j * cgn + cg][k];
-            atomicAdd(out + col + k, s);
+            for (int j = 0; j < rln; ++j) s += red[j * cgn + g][k];
+            atomicAdd(out + c, s);
         }
     }
 }
