@@ -508,7 +508,9 @@ int ccd_seg_loss(const float* logits, const float* mask_a, const uint8_t* idmap_
 int ccd_seg_sumsq(const float* grad, const int* chunk_seg, const long* chunk_begin, const int* chunk_len, int nchunks,
                   float* norm2, void* stream) {
     CCD_CHECK(grad && chunk_seg && chunk_begin && chunk_len && norm2 && nchunks > 0, CCD_EINVAL);
-    CCD_LAUNCH(ccd::seg_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, grad, chunk_seg, chunk_begin, chunk_len, norm2);
+    const int cpb = 32;                                     // 128 KiB of gradients per workgroup
+    CCD_LAUNCH(ccd::seg_sumsq_kernel, dim3((nchunks + cpb - 1) / cpb), dim3(256), 0, stream, grad, chunk_seg, chunk_begin,
+               chunk_len, norm2, nchunks, cpb);
     return ccd_rt_last_error();
 }
 int ccd_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, ccd_bf16* mirror,

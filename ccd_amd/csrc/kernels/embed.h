@@ -108,8 +108,20 @@ __global__ void small_matmul_f32_kernel(const float* __restrict__ a, const float
                                         int M, int N, int K, int trans_a, int accumulate) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
     if (n >= N) return;
-    float acc = 0.f;
-    for (int k = 0; k < K; ++k) acc += (trans_a ? a[(long)k * M + m] : a[(long)m * K + k]) * b[(long)k * N + n];
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;   // four independent chains: the loop is latency-bound
+    int k = 0;
+    for (; k + 3 < K; k += 4) {
+        const float a0 = trans_a ? a[(long)k * M + m] : a[(long)m * K + k];
+        const float a1 = trans_a ? a[(long)(k + 1) * M + m] : a[(long)m * K + k + 1];
+        const float a2 = trans_a ? a[(long)(k + 2) * M + m] : a[(long)m * K + k + 2];
+        const float a3 = trans_a ? a[(long)(k + 3) * M + m] : a[(long)m * K + k + 3];
+        acc0 += a0 * b[(long)k * N + n];
+        acc1 += a1 * b[(long)(k + 1) * N + n];
+        acc2 += a2 * b[(long)(k + 2) * N + n];
+        acc3 += a3 * b[(long)(k + 3) * N + n];
+    }
+    for (; k < K; ++k) acc0 += (trans_a ? a[(long)k * M + m] : a[(long)m * K + k]) * b[(long)k * N + n];
+    const float acc = (acc0 + acc1) + (acc2 + acc3);
     c[(long)m * N + n] = accumulate ? c[(long)m * N + n] + acc : acc;
 }
 
