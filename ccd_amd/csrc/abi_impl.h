@@ -160,6 +160,9 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
     p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K;
     p.C = C; p.ldc = ldc; p.C2 = C2; p.ldc2 = ldc2; p.bias = bias; p.resid = resid; p.ldr = ldr;
     p.rowscale = rowscale; p.rows_per_sample = rows_per_sample; p.aux = aux; p.ldaux = ldaux;
+    p.rps_shift = -1;
+    if (rows_per_sample > 0 && (rows_per_sample & (rows_per_sample - 1)) == 0)
+        for (int sft = 0; sft < 31; ++sft) if ((1 << sft) == rows_per_sample) p.rps_shift = sft;
     p.k_per_split = K; p.m_fastest = m_fastest; p.alpha = alpha; p.d_rows = d_rows; p.rows_mul = rows_mul;
     p.colsum = colsum;
     // kernel choice (all three are parity-tested): CCD_GEMM_NT32=0 / CCD_GEMM_ARES=1 switch variants for A/B timing
@@ -211,7 +214,7 @@ int ccd_gemm_tn(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P,
     ccd::GemmParams p = ccd::GemmParams();
     p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.M = P; p.N = Q; p.K = Mc;
     p.C = C; p.ldc = ldc; p.C2 = nullptr; p.ldc2 = 0; p.bias = nullptr; p.resid = nullptr; p.ldr = 0;
-    p.rowscale = nullptr; p.rows_per_sample = 1; p.aux = nullptr; p.ldaux = 0;
+    p.rowscale = nullptr; p.rows_per_sample = 1; p.rps_shift = 0; p.aux = nullptr; p.ldaux = 0;
     p.k_per_split = per; p.m_fastest = 0; p.alpha = alpha; p.d_rows = d_rows; p.rows_mul = rows_mul;
     p.colsum = nullptr;
     return ccd_launch_gemm<true>(p, epilogue, splits, stream);

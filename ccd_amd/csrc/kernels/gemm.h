@@ -38,6 +38,8 @@ struct GemmParams {
     long ldr;
     const float* rowscale;  // EPI_RESID: per-sample scale (DropPath), or null
     int rows_per_sample;
+    int rps_shift;          // log2(rows_per_sample) when it is a power of two (256 tokens per view), else -1: avoids a
+                            // ~40-instruction integer division per output row in the residual epilogue
     const bf16_t* aux;      // EPI_DGELU
     long ldaux;
     int k_per_split;        // TN: contraction rows handled by one blockIdx.z slice (multiple of 64)
@@ -217,7 +219,7 @@ __device__ __forceinline__ void gemm_epilogue_row8(const GemmParams& p, int gm, 
         for (int e = 0; e < 8; ++e) g[e] = gelu_f(v[e]);
         *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + (long)gm * p.ldc2 + gn) = pack8(g);
     } else if (EPI == EPI_RESID) {
-        const float s = p.rowscale ? p.rowscale[gm / p.rows_per_sample] : 1.0f;
+        const float s = p.rowscale ? p.rowscale[p.rps_shift >= 0 ? gm >> p.rps_shift : gm / p.rows_per_sample] : 1.0f;
         const f32x4v* rp = reinterpret_cast<const f32x4v*>(p.resid + (long)gm * p.ldr + gn);
         f32x4v r0 = rp[0], r1 = rp[1];
         f32x4v o0 = {r0.x + v[0] * s, r0.y + v[1] * s, r0.z + v[2] * s, r0.w + v[3] * s};
