@@ -268,8 +268,10 @@ int ccd_attention_bwd(const ccd_bf16* qkv, const ccd_bf16* out, const ccd_bf16* 
     CCD_CHECK(qkv && out && d_out && lse && delta_ws && d_qkv, CCD_EINVAL);
     if (views == 0) return CCD_OK;
     CCD_CHECK(views > 0 && heads > 0, CCD_EINVAL);
-    CCD_LAUNCH(ccd::attention_bwd_dq_kernel, dim3(views * heads), dim3(512), ccd::ATTB_DQ_SMEM, stream, qkv, out, d_out,
-               lse, delta_ws, d_qkv, heads, scale);
+    const int nblocks = views * heads;                      // persistent: one workgroup per CU walks the (view, head) blocks
+    const int cus = ccd_rt_num_cus();
+    CCD_LAUNCH(ccd::attention_bwd_dq_kernel, dim3(nblocks < cus ? nblocks : cus), dim3(512), ccd::ATTB_DQ_SMEM, stream, qkv,
+               out, d_out, lse, delta_ws, d_qkv, heads, scale, nblocks);
     CCD_LAUNCH(ccd::attention_bwd_dkv_kernel, dim3(views * heads), dim3(512), ccd::ATTB_DKV_SMEM, stream, qkv, d_out, lse,
                delta_ws, d_qkv, heads, scale);
     return ccd_rt_last_error();

@@ -64,79 +64,147 @@ __device__ __forceinline__ void attb_store_t(bf16_t* row_ptr, const f32x16 (&acc
         }
 }
 
+// Register images of one (view, head) block's operands: what a thread moves to LDS / consumes itself.  The kernels are
+// persistent (one workgroup per CU walks the blocks) and request block b+1's pieces right after block b's have been
+// written to LDS, so the HBM / L2 latency of the staging is spent under block b's MFMAs instead of in front of them
+// (measured before: 16 us per block for ~5 us of MFMA + softmax work).
+struct AttbRows { u32x4 r[4]; };
+__device__ __forceinline__ void attb_load_rows(const bf16_t* __restrict__ src, long row_stride, AttbRows& x) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = t + ATTB_THREADS * i, row = id >> 3, slot = id & 7;
+        x.r[i] = *reinterpret_cast<const u32x4*>(src + (long)row * row_stride + slot * 8);
+    }
+}
+__device__ __forceinline__ void attb_store_rows(const AttbRows& x, char* img) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = t + ATTB_THREADS * i, row = id >> 3, slot = id & 7;
+        *reinterpret_cast<u32x4*>(img + row * 128 + ((slot ^ ((row >> 1) & 7)) * 16)) = x.r[i];
+    }
+}
+__device__ __forceinline__ void attb_load_transposed(const bf16_t* __restrict__ src, long row_stride, AttbRows& x) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int kb = 16 * (w & 3) + (lane & 15);
+    const int db = (lane >> 4) + 4 * (w >> 2);
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq)
+        x.r[kq] = *reinterpret_cast<const u32x4*>(src + (long)(4 * kb + kq) * row_stride + db * 8);
+}
+__device__ __forceinline__ void attb_store_transposed(const AttbRows& x, char* img) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int kb = 16 * (w & 3) + (lane & 15);
+    const int db = (lane >> 4) + 4 * (w >> 2);
+    const int chunk = 4 * (kb >> 2) + att_chunk_pos(kb & 3);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int d = 8 * db + j;
+        const unsigned w0 = x.r[0][j >> 1], w1 = x.r[1][j >> 1], w2 = x.r[2][j >> 1], w3 = x.r[3][j >> 1];
+        unsigned e0, e1, e2, e3;
+        if (j & 1) { e0 = w0 >> 16; e1 = w1 >> 16; e2 = w2 >> 16; e3 = w3 >> 16; }
+        else { e0 = w0 & 0xffffu; e1 = w1 & 0xffffu; e2 = w2 & 0xffffu; e3 = w3 & 0xffffu; }
+        u32x2 o;
+        o.x = e0 | (e1 << 16);
+        o.y = e2 | (e3 << 16);
+        const int slot = (chunk >> 1) ^ (d & 15);
+        *reinterpret_cast<u32x2*>(img + d * 512 + slot * 16 + (chunk & 1) * 8) = o;
+    }
+}
+
 __global__ __launch_bounds__(512) void attention_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
                                                                const bf16_t* __restrict__ o,
                                                                const bf16_t* __restrict__ d_o,
                                                                const float* __restrict__ lse,
                                                                float* __restrict__ delta, bf16_t* __restrict__ dqkv,
-                                                               int heads, float scale) {
+                                                               int heads, float scale, int nblocks) {
     char* smem = dynamic_smem();
     char* k_img = smem;
     char* v_img = smem + ATTB_IMG;
     char* kt_img = smem + 2 * ATTB_IMG;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hf = lane >> 5, lq = lane & 31;
-    const int view = blockIdx.x / heads, head = blockIdx.x % heads;
     const int E = heads * ATT_D;
     const long rs3 = 3L * E;
-    const bf16_t* q_base = qkv + (long)view * ATT_T * rs3 + head * ATT_D;
-    attb_stage_rows(q_base + E, rs3, k_img);
-    attb_stage_rows(q_base + 2 * E, rs3, v_img);
-    attb_stage_transposed(q_base + E, rs3, kt_img);
-
     const int q = 32 * w + lq;
-    const long orow = ((long)view * ATT_T + q) * E + head * ATT_D;
-    bf16x8 qf[4], dof[4];
-    float dsum = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        qf[kk] = *reinterpret_cast<const bf16x8*>(q_base + (long)q * rs3 + 16 * kk + 8 * hf);
-        const u32x4 dw = *reinterpret_cast<const u32x4*>(d_o + orow + 16 * kk + 8 * hf);
-        const u32x4 ow = *reinterpret_cast<const u32x4*>(o + orow + 16 * kk + 8 * hf);
-        dof[kk] = __builtin_bit_cast(bf16x8, dw);
-        float a[8], b[8];
-        unpack8(dw, a);
-        unpack8(ow, b);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dsum += a[e] * b[e];
-    }
-    dsum += shfl_xor(dsum, 32);
-    const long stat = ((long)view * heads + head) * ATT_T + q;
-    const float my_lse = lse[stat];
-    if (hf == 0) delta[stat] = dsum;
-    __syncthreads();
-
-    f32x16 dq[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
-#pragma unroll 1
-    for (int kt = 0; kt < 8; ++kt) {
-        f32x16 s, dp;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-        const int row = 32 * kt + lq;
+    AttbRows kr, vr, ktr;
+    u32x4 qw[4], dw[4], ow[4];
+    float lse_n = 0.f;
+    auto request = [&](int blk) {                             // everything this thread needs of block `blk`
+        const int view = blk / heads, head = blk % heads;
+        const bf16_t* q_base = qkv + (long)view * ATT_T * rs3 + head * ATT_D;
+        attb_load_rows(q_base + E, rs3, kr);
+        attb_load_rows(q_base + 2 * E, rs3, vr);
+        attb_load_transposed(q_base + E, rs3, ktr);
+        const long orow = ((long)view * ATT_T + q) * E + head * ATT_D;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            s = mfma_32x32x16_bf16(attb_row_frag(k_img, row, kk, hf), qf[kk], s);
-            dp = mfma_32x32x16_bf16(attb_row_frag(v_img, row, kk, hf), dof[kk], dp);
+            qw[kk] = *reinterpret_cast<const u32x4*>(q_base + (long)q * rs3 + 16 * kk + 8 * hf);
+            dw[kk] = *reinterpret_cast<const u32x4*>(d_o + orow + 16 * kk + 8 * hf);
+            ow[kk] = *reinterpret_cast<const u32x4*>(o + orow + 16 * kk + 8 * hf);
         }
+        lse_n = lse[((long)view * heads + head) * ATT_T + q];
+    };
+    int blk = blockIdx.x;
+    if (blk < nblocks) request(blk);
+    for (; blk < nblocks; blk += gridDim.x) {
+        const int view = blk / heads, head = blk % heads;
+        attb_store_rows(kr, k_img);
+        attb_store_rows(vr, v_img);
+        attb_store_transposed(ktr, kt_img);
+        bf16x8 qf[4], dof[4];
+        float dsum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = fast_exp2(fmaf(s[r], scale * 1.4426950408889634f, -my_lse * 1.4426950408889634f));
-            s[r] = p * (dp[r] - dsum) * scale;
+        for (int kk = 0; kk < 4; ++kk) {
+            qf[kk] = __builtin_bit_cast(bf16x8, qw[kk]);
+            dof[kk] = __builtin_bit_cast(bf16x8, dw[kk]);
+            float a[8], b[8];
+            unpack8(dw[kk], a);
+            unpack8(ow[kk], b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dsum += a[e] * b[e];
         }
+        dsum += shfl_xor(dsum, 32);
+        const long stat = ((long)view * heads + head) * ATT_T + q;
+        const float my_lse = lse_n;
+        if (hf == 0) delta[stat] = dsum;
+        __syncthreads();
+        if (blk + (int)gridDim.x < nblocks) request(blk + gridDim.x);      // flies under this block's MFMAs
+
+        f32x16 dq[2];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 dsf;
+        for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dsf[e] = (short)f2bf(s[8 * s2 + e]);
+            for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+#pragma unroll 1
+        for (int kt = 0; kt < 8; ++kt) {
+            f32x16 s, dp;
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-                dq[dt] = mfma_32x32x16_bf16(attb_tr_frag(kt_img, 32 * dt + lq, 2 * kt + s2, hf), dsf, dq[dt]);
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            const int row = 32 * kt + lq;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                s = mfma_32x32x16_bf16(attb_row_frag(k_img, row, kk, hf), qf[kk], s);
+                dp = mfma_32x32x16_bf16(attb_row_frag(v_img, row, kk, hf), dof[kk], dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = fast_exp2(fmaf(s[r], scale * 1.4426950408889634f, -my_lse * 1.4426950408889634f));
+                s[r] = p * (dp[r] - dsum) * scale;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 dsf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dsf[e] = (short)f2bf(s[8 * s2 + e]);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    dq[dt] = mfma_32x32x16_bf16(attb_tr_frag(kt_img, 32 * dt + lq, 2 * kt + s2, hf), dsf, dq[dt]);
+            }
         }
+        attb_store_t(dqkv + ((long)view * ATT_T + q) * rs3 + head * ATT_D, dq, hf);
+        __syncthreads();                                     // the images are rewritten by the next block
     }
-    attb_store_t(dqkv + ((long)view * ATT_T + q) * rs3 + head * ATT_D, dq, hf);
 }
 
 __global__ __launch_bounds__(512) void attention_bwd_dkv_kernel(const bf16_t* __restrict__ qkv,
