@@ -260,4 +260,10 @@ inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
     sim::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
 inline int ccd_rt_memset_async(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return 0; }
 inline int ccd_rt_last_error() { return 0; }
-inline int ccd_rt_num_cus() { return 1; }   // tiny "chip": persistent kernels walk several work items per workgroup
+// size of the emulated chip: 4 "CUs" by default (persistent kernels then run 4-8 workgroups on as many host
+// threads); tests that want every workgroup to walk several work items set CCD_SIM_CUS=1
+inline int ccd_rt_num_cus() {
+    const char* v = getenv("CCD_SIM_CUS");
+    const int n = v ? atoi(v) : 4;
+    return n > 0 ? n : 1;
+}

@@ -12,6 +12,12 @@ def sim():
         yield b
 
 
+@pytest.fixture(autouse=True)
+def one_cu(monkeypatch):
+    """Kernel tests run on a 1-CU chip: persistent kernels then walk several work items per workgroup."""
+    monkeypatch.setenv("CCD_SIM_CUS", "1")
+
+
 def test_gemm_nt_sim(sim):
     kc.check_gemm_nt(sim.device, M=200, N=136, K=128)
 

@@ -97,7 +97,7 @@ def _dp_step_worker(rank, world, port):
         teacher.head.load_state_dict(student.head.state_dict())
         dino_loss = DINOLoss(512, 2, 0.04, 0.04, 0, 40)
         opt = pretrain.make_optimizer(student, clip_grad=3.0)
-        images, masks, metrics = make_batch(2, seed=11 + rank)       # every rank its own shard
+        images, masks, metrics = make_batch(1, seed=11 + rank)       # every rank its own shard (1 image: CPU executor)
         # local gradients without synchronisation
         s_out = student(images, metrics, masks, 1)
         with torch.no_grad():
