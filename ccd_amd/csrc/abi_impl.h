@@ -126,6 +126,7 @@ static int ccd_launch_gemm_row384(const ccd::GemmParams& p, int epilogue, void* 
         case CCD_EPI_BF16: CCD_LAUNCH((ccd::gemm_row384_kernel<ccd::EPI_BF16>), grid, block, smem, stream, p); break;
         case CCD_EPI_RESID: CCD_LAUNCH((ccd::gemm_row384_kernel<ccd::EPI_RESID>), grid, block, smem, stream, p); break;
         case CCD_EPI_F32: CCD_LAUNCH((ccd::gemm_row384_kernel<ccd::EPI_F32>), grid, block, smem, stream, p); break;
+        case 7: CCD_LAUNCH((ccd::gemm_row384_kernel<ccd::EPI_RESID_LN>), grid, block, smem, stream, p); break;
         default: return CCD_EINVAL;
     }
     return ccd_rt_last_error();
@@ -191,6 +192,27 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
         return ccd_launch_gemm_ares(p, epilogue, stream);
     if (use_nt32 && epilogue != CCD_EPI_ATOMIC && N % 4 == 0) return ccd_launch_gemm_nt32(p, epilogue, stream);
     return ccd_launch_gemm<false>(p, epilogue, 1, stream);
+}
+
+int ccd_gemm_nt_resid_ln(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, float* C, long ldc,
+                         const float* bias, const float* resid, long ldr, const float* rowscale, int rows_per_sample,
+                         const float* ln_gamma, const float* ln_beta, float ln_eps, ccd_bf16* y, long ldy, float* mean,
+                         float* rstd, void* stream) {
+    CCD_CHECK(A && B && C && resid && ln_gamma && ln_beta && y && mean && rstd, CCD_EINVAL);
+    CCD_CHECK(CCD_ALIGNED16(A) && CCD_ALIGNED16(B) && CCD_ALIGNED16(C) && CCD_ALIGNED16(resid) && CCD_ALIGNED16(y), CCD_EINVAL);
+    if (M == 0) return CCD_OK;
+    CCD_CHECK(M > 0 && N > 0 && K > 0 && rows_per_sample > 0, CCD_EINVAL);
+    CCD_CHECK(N <= ccd::GR_BN && N % 8 == 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && ldr % 4 == 0 &&
+              ldy % 8 == 0, CCD_ESHAPE);
+    CCD_CHECK(((long)M * lda + K) * 2 < CCD_MAX_OPERAND_BYTES && ((long)N * ldb + K) * 2 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
+    ccd::GemmParams p = ccd::GemmParams();
+    p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.C = C; p.ldc = ldc; p.bias = bias;
+    p.resid = resid; p.ldr = ldr; p.rowscale = rowscale; p.rows_per_sample = rows_per_sample; p.alpha = 1.0f; p.rows_mul = 1;
+    p.k_per_split = K;
+    p.rps_shift = -1;
+    for (int sft = 0; sft < 31; ++sft) if ((1 << sft) == rows_per_sample) p.rps_shift = sft;
+    p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_eps = ln_eps; p.ln_y = y; p.ld_y = ldy; p.ln_mean = mean; p.ln_rstd = rstd;
+    return ccd_launch_gemm_row384(p, 7 /* EPI_RESID_LN */, stream);
 }
 
 int ccd_gemm_tn(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P, int Q, int Mc, int epilogue, float* C,

@@ -21,7 +21,8 @@ enum GemmEpilogue {
     EPI_F32 = 3,        // C(f32)  = acc + bias
     EPI_ATOMIC = 4,     // C(f32) += acc                       (split-K partial sums)
     EPI_DGELU = 5,      // C(bf16) = acc * gelu'(aux)          (aux = saved pre-activation u, bf16)
-    EPI_BF16_ADDF32 = 6 // C(bf16) = acc + bias ; C2(f32) += acc (unused hook kept for head experiments)
+    EPI_BF16_ADDF32 = 6, // C(bf16) = acc + bias ; C2(f32) += acc (unused hook kept for head experiments)
+    EPI_RESID_LN = 7     // EPI_RESID + LayerNorm of the finished rows (gemm_row384.h only)
 };
 
 struct GemmParams {
@@ -55,6 +56,15 @@ struct GemmParams {
     int g_h_log2, g_w_log2, s_h, s_w, s_mul, cin;
     unsigned long long dy_pack, dx_pack;   // tap offsets as 4-bit fields (d + 8), tap i in bits 4i..4i+3: register lookup
     int c_map, c_py, c_px;  // c_map: output row (n, oy, ox) -> (n, 2*oy + c_py, 2*ox + c_px) of the 2x upsampled grid
+    // ---- LayerNorm of the output rows folded into the residual epilogue (full-row kernel gemm_row384.h only):
+    // y = LN(C row) * ln_gamma + ln_beta (bf16, row stride ld_y), statistics for the backward pass
+    const float* ln_gamma;
+    const float* ln_beta;
+    bf16_t* ln_y;
+    long ld_y;
+    float* ln_mean;
+    float* ln_rstd;
+    float ln_eps;
     const int* d_rows;      // optional device-side row count: NT rows M / TN contraction length K become
     int rows_mul;           //   min(static value, d_rows[0] * rows_mul); the grid is sized for the static value
 };

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
         const bool elive = nk > 0;
         const unsigned next = item + nx;
         const bool has_next = next < cnt_x;
-        if (has_next) {                                      // next tile's first two k-tiles fly under the epilogue
+        if (has_next && EPI != EPI_RESID_LN) {               // next tile's first two k-tiles fly under the epilogue
             setup(next);
             load(0, ra0, rb0);
             load(1, ra1, rb1);
@@ -171,6 +171,22 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
 #pragma unroll
                 for (int h = 0; h < 2 / WMP; ++h) {
                     const int sr = (WMP == 2 ? 32 * wm : 0) + lq;
+                    // fused-LayerNorm epilogue: the residual rows of this pass are requested before the staging writes
+                    // and the barrier, so their latency is not paid serially inside the row sweep
+                    f32x4v rpre[2][3];
+                    if (EPI == EPI_RESID_LN) {
+#pragma unroll
+                        for (int step = 0; step < 2; ++step) {
+                            const int gm = em0 + 64 * h + 32 * q + 16 * step + 2 * w + hf;
+#pragma unroll
+                            for (int c3 = 0; c3 < 3; ++c3) {
+                                const int gnc = 4 * ((lane & 31) + 32 * c3);
+                                rpre[step][c3] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                                if (gm < p.M && gnc < p.N)
+                                    rpre[step][c3] = *reinterpret_cast<const f32x4v*>(p.resid + (long)gm * p.ldr + gnc);
+                            }
+                        }
+                    }
                     if (WMP == 2 || wm == h) {
 #pragma unroll
                         for (int j = 0; j < 3; ++j)
@@ -195,7 +211,59 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
                                 }
                             }
                     }
+                    constexpr bool fuse_ln = EPI == EPI_RESID_LN;
                     lds_barrier();
+                    if (fuse_ln) {
+                        // residual epilogue + LayerNorm of the finished rows.  Half a wave owns one row (32 lanes x three
+                        // 16-byte chunks = 384 columns): the row sums are five shuffles, no LDS traffic, one sweep.
+                        const int L = lane & 31;
+                        const float inv_n = 1.0f / (float)p.N;
+#pragma unroll
+                        for (int step = 0; step < 2; ++step) {
+                            const int s2 = 16 * step + 2 * w + hf;
+                            const int gm = em0 + 64 * h + 32 * q + s2;
+                            const bool row_ok = gm < p.M;
+                            const float sc = (row_ok && p.rowscale)
+                                                 ? p.rowscale[p.rps_shift >= 0 ? gm >> p.rps_shift : gm / p.rows_per_sample] : 1.0f;
+                            f32x4v o[3];
+                            float s1 = 0.f, sq = 0.f;
+#pragma unroll
+                            for (int c3 = 0; c3 < 3; ++c3) {
+                                const int chunk = L + 32 * c3, gnc = 4 * chunk;
+                                o[c3] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                                if (row_ok && gnc < p.N) {
+                                    const f32x4v v = *reinterpret_cast<const f32x4v*>(stg + s2 * ROWB + ((chunk ^ (s2 & 15)) * 16));
+                                    const f32x4v r = rpre[step][c3];
+                                    f32x4v b = {0.f, 0.f, 0.f, 0.f};
+                                    if (p.bias) b = *reinterpret_cast<const f32x4v*>(p.bias + gnc);
+                                    o[c3] = r + (v + b) * sc;
+                                    *reinterpret_cast<f32x4v*>(reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gnc) = o[c3];
+                                    s1 += (o[c3].x + o[c3].y) + (o[c3].z + o[c3].w);
+                                    sq += (o[c3].x * o[c3].x + o[c3].y * o[c3].y) + (o[c3].z * o[c3].z + o[c3].w * o[c3].w);
+                                }
+                            }
+#pragma unroll
+                            for (int msk = 16; msk >= 1; msk >>= 1) { s1 += shfl_xor(s1, msk); sq += shfl_xor(sq, msk); }
+                            const float mean = s1 * inv_n;
+                            float var = sq * inv_n - mean * mean;
+                            var = var > 0.f ? var : 0.f;
+                            const float rstd = 1.0f / sqrtf(var + p.ln_eps);
+#pragma unroll
+                            for (int c3 = 0; c3 < 3; ++c3) {
+                                const int gnc = 4 * (L + 32 * c3);
+                                if (row_ok && gnc < p.N) {
+                                    const f32x4v ga = *reinterpret_cast<const f32x4v*>(p.ln_gamma + gnc);
+                                    const f32x4v be = *reinterpret_cast<const f32x4v*>(p.ln_beta + gnc);
+                                    const f32x4v yv = (o[c3] - mean) * rstd * ga + be;
+                                    u32x2 pk;
+                                    pk.x = pack_bf2(yv.x, yv.y);
+                                    pk.y = pack_bf2(yv.z, yv.w);
+                                    *reinterpret_cast<u32x2*>(p.ln_y + (long)gm * p.ld_y + gnc) = pk;
+                                }
+                            }
+                            if (L == 0 && row_ok) { p.ln_mean[gm] = mean; p.ln_rstd[gm] = rstd; }
+                        }
+                    } else
                     if (rr < RSTEP) {
                         for (int s2 = rr; s2 < SROWS; s2 += RSTEP) {
                             const int gm = em0 + 64 * (WMP == 2 ? (s2 >> 5) : h) + 32 * q + (s2 & 31);
@@ -215,7 +283,7 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
                                     const f32x4v c1 = *reinterpret_cast<const f32x4v*>(stg + s2 * ROWB + (((2 * ct + 1) ^ (s2 & 15)) * 16));
                                     v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
                                     v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
-                                    gemm_epilogue_row8<EPI>(p, gm, gn, v);
+                                    gemm_epilogue_row8<(EPI == EPI_RESID_LN ? EPI_RESID : EPI)>(p, gm, gn, v);
                                 }
                             }
                         }
@@ -240,6 +308,11 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
             }
         }
         if (!has_next) break;
+        if (EPI == EPI_RESID_LN) {                           // (its epilogue needs the registers the prefetch would hold)
+            setup(next);
+            load(0, ra0, rb0);
+            load(1, ra1, rb1);
+        }
         item = next;
     }
 }

@@ -12,6 +12,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import torch
 
 from . import ops
@@ -79,6 +81,10 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
     x = ops.patch_embed_fwd(img, arena.w(pre + "patch_embed.proj.weight"), arena.w(pre + "patch_embed.proj.bias"), pos)
     ctxs, taps, tap_ctx = [], [], []
     scale = (E // spec.heads) ** -0.5
+    # LayerNorm folded into the epilogue of the residual product that finishes its input rows (full-row kernel,
+    # E <= 384): proj -> norm2 of the same block, fc2 -> norm1 of the next block / the final norm
+    fuse_ln = E <= 384 and os.environ.get("CCD_FUSE_LN", "1") != "0"
+    pending = None                               # (y, mean, rstd) of the coming norm1, made by the previous fc2
     for i in range(spec.depth):
         b = f"{pre}blocks.{i}."
         c = _BlockCtx()
@@ -89,16 +95,31 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
             m = torch.floor(r + keep) / keep
             c.ds1, c.ds2 = m[0].contiguous(), m[1].contiguous()
         c.x_in = x
-        c.y1, c.mean1, c.rstd1 = ops.ln_fwd(x, arena.w(b + "norm1.weight"), arena.w(b + "norm1.bias"), spec.eps)
+        if pending is None:
+            c.y1, c.mean1, c.rstd1 = ops.ln_fwd(x, arena.w(b + "norm1.weight"), arena.w(b + "norm1.bias"), spec.eps)
+        else:
+            c.y1, c.mean1, c.rstd1 = pending
         c.qkv = ops.gemm_nt(c.y1, arena.wb(b + "attn.qkv.weight"), bias=arena.w(b + "attn.qkv.bias"))
         c.att, c.lse = ops.attention_fwd(c.qkv.view(N, 256, 3 * E), spec.heads, scale)
-        c.x_mid = ops.gemm_nt(c.att.view(R, E), arena.wb(b + "attn.proj.weight"), epilogue=ops.EPI_RESID,
-                              bias=arena.w(b + "attn.proj.bias"), resid=x, rowscale=c.ds1, rows_per_sample=256)
-        c.y2, c.mean2, c.rstd2 = ops.ln_fwd(c.x_mid, arena.w(b + "norm2.weight"), arena.w(b + "norm2.bias"), spec.eps)
+        if fuse_ln:
+            c.x_mid, c.y2, c.mean2, c.rstd2 = ops.gemm_nt_resid_ln(
+                c.att.view(R, E), arena.wb(b + "attn.proj.weight"), bias=arena.w(b + "attn.proj.bias"), resid=x,
+                rowscale=c.ds1, rows_per_sample=256, gamma=arena.w(b + "norm2.weight"), beta=arena.w(b + "norm2.bias"),
+                eps=spec.eps)
+        else:
+            c.x_mid = ops.gemm_nt(c.att.view(R, E), arena.wb(b + "attn.proj.weight"), epilogue=ops.EPI_RESID,
+                                  bias=arena.w(b + "attn.proj.bias"), resid=x, rowscale=c.ds1, rows_per_sample=256)
+            c.y2, c.mean2, c.rstd2 = ops.ln_fwd(c.x_mid, arena.w(b + "norm2.weight"), arena.w(b + "norm2.bias"), spec.eps)
         c.u, c.gact = ops.gemm_nt(c.y2, arena.wb(b + "mlp.fc1.weight"), epilogue=ops.EPI_GELU,
                                   bias=arena.w(b + "mlp.fc1.bias"), store_u=save)   # u only feeds gelu' in backward
-        x = ops.gemm_nt(c.gact, arena.wb(b + "mlp.fc2.weight"), epilogue=ops.EPI_RESID,
-                        bias=arena.w(b + "mlp.fc2.bias"), resid=c.x_mid, rowscale=c.ds2, rows_per_sample=256)
+        if fuse_ln:
+            nxt = f"{pre}blocks.{i + 1}.norm1." if i + 1 < spec.depth else pre + "norm."
+            x, *pending = ops.gemm_nt_resid_ln(
+                c.gact, arena.wb(b + "mlp.fc2.weight"), bias=arena.w(b + "mlp.fc2.bias"), resid=c.x_mid, rowscale=c.ds2,
+                rows_per_sample=256, gamma=arena.w(nxt + "weight"), beta=arena.w(nxt + "bias"), eps=spec.eps)
+        else:
+            x = ops.gemm_nt(c.gact, arena.wb(b + "mlp.fc2.weight"), epilogue=ops.EPI_RESID,
+                            bias=arena.w(b + "mlp.fc2.bias"), resid=c.x_mid, rowscale=c.ds2, rows_per_sample=256)
         if not save:
             c.y1 = c.qkv = c.att = c.y2 = c.u = c.gact = None
         ctxs.append(c if save else None)
@@ -107,7 +128,10 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
             t, mu, rs = ops.ln_fwd(x, arena.w(f"{pre}norm_seg.{j}.weight"), arena.w(f"{pre}norm_seg.{j}.bias"), spec.eps)
             taps.append(t)
             tap_ctx.append((i, x, mu, rs))
-    tokens, mu, rs = ops.ln_fwd(x, arena.w(pre + "norm.weight"), arena.w(pre + "norm.bias"), spec.eps)
+    if pending is None:
+        tokens, mu, rs = ops.ln_fwd(x, arena.w(pre + "norm.weight"), arena.w(pre + "norm.bias"), spec.eps)
+    else:
+        tokens, mu, rs = pending
     ctx = (ctxs, tap_ctx, (x, mu, rs), img) if save else None
     return tokens, taps, ctx
 

@@ -85,6 +85,29 @@ def gemm_nt(a, b, *, epilogue=EPI_BF16, out=None, out2=None, bias=None, resid=No
     return (out, out2) if epilogue == EPI_GELU else out
 
 
+def gemm_nt_resid_ln(a, b, *, bias, resid, rowscale, rows_per_sample, gamma, beta, eps, out=None):
+    """out (fp32) = resid + (a @ b^T + bias) * rowscale[row // rows_per_sample];  y = LayerNorm(out) * gamma + beta.
+    -> (out, y bf16, mean, rstd): the residual product with the following LayerNorm folded into its epilogue."""
+    _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(bias, F32, "bias"); _chk(resid, F32, "resid"); _chk(rowscale, F32, "rowscale")
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and N <= 384
+    if out is None:
+        out = torch.empty((M, N), dtype=F32, device=a.device)
+    y = torch.empty((M, N), dtype=BF16, device=a.device)
+    mean = torch.empty(M, dtype=F32, device=a.device)
+    rstd = torch.empty(M, dtype=F32, device=a.device)
+    span = TIMER.span("gemm_nt_resid", 2.0 * M * N * K, 2.0 * (M * K + N * K) + 10.0 * M * N) if TIMER is not None else None
+    if span:
+        span[0].record()
+    _call("ccd_gemm_nt_resid_ln", _lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0), M, N, K, _lib.ptr(out), out.stride(0),
+          _lib.ptr(bias), _lib.ptr(resid), resid.stride(0), _lib.ptr(rowscale), int(rows_per_sample), _lib.ptr(gamma),
+          _lib.ptr(beta), float(eps), _lib.ptr(y), y.stride(0), _lib.ptr(mean), _lib.ptr(rstd))
+    if span:
+        span[1].record()
+    return out, y, mean, rstd
+
+
 def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, splits=0, d_rows=None, rows_mul=1):
     """out[P,Q] (+)= a[Mc,P]^T @ b[Mc,Q]  (fp32 out; accumulate=True adds with fp32 atomics, split over Mc)."""
     _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(out, F32, "out")

@@ -46,6 +46,15 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
                 void* C, long ldc, void* C2, long ldc2, const float* bias, const float* resid, long ldr,
                 const float* rowscale, int rows_per_sample, const ccd_bf16* aux, long ldaux, float alpha,
                 int m_fastest, const int* d_rows, int rows_mul, float* colsum, void* stream);
+/* Residual product with the NEXT LayerNorm folded into its epilogue (Block.forward, vision_transformer.py:107-113:
+ * x = x + drop_path(f(...)); the following norm1 / norm2 / norm of the stream):
+ *   C[M,N] (f32) = resid + (A . B^T + bias) * rowscale[row / rows_per_sample]
+ *   y[M,N] (bf16) = (C - mean) * rstd * ln_gamma + ln_beta,  mean / rstd [M] saved for ccd_ln_bwd
+ * One workgroup owns whole rows (N <= 384, N % 8 == 0, K % 64 == 0); replaces ccd_gemm_nt(EPI_RESID) + ccd_ln_fwd. */
+int ccd_gemm_nt_resid_ln(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, float* C, long ldc,
+                         const float* bias, const float* resid, long ldr, const float* rowscale, int rows_per_sample,
+                         const float* ln_gamma, const float* ln_beta, float ln_eps, ccd_bf16* y, long ldy, float* mean,
+                         float* rstd, void* stream);
 /* colsum (optional, epilogues BF16 / DGELU): [N] fp32, += column sums of the output (bias gradient of the producer).
  * CCD_EPI_GELU accepts C == NULL (only gelu(u) is stored: forward passes that keep no activations). */
 /* C[P,Q] (+)= sum_m A[m,P] * B[m,Q]   (weight gradients dW = dY^T X of every Linear; autograd of the above)

@@ -587,3 +587,22 @@ def check_seghead(dev, images=1, E=64, seed=21, build_ref=None):
             continue
         close(b, refb[name], 2e-2, 2e-3, f"seghead/{name}")
     return worst
+
+
+def check_gemm_resid_ln(dev, M, N, K, seed=30):
+    """Residual product + folded LayerNorm == gemm_nt(EPI_RESID) followed by ln_fwd (and the plain fp32 math)."""
+    g = torch.Generator().manual_seed(seed)
+    a = rnd((M, K), g).to(BF); b = rnd((N, K), g, 0.2).to(BF)
+    bias, resid = rnd((N,), g), rnd((M, N), g) * 3 + 0.5
+    rps = 16
+    rowscale = (torch.rand((M + rps - 1) // rps, generator=g) > 0.3).float() * 1.25
+    gamma, beta = rnd((N,), g).abs() + 0.5, rnd((N,), g) * 0.3
+    out, y, mean, rstd = ops.gemm_nt_resid_ln(a.to(dev), b.to(dev), bias=bias.to(dev), resid=resid.to(dev),
+                                              rowscale=rowscale.to(dev), rows_per_sample=rps, gamma=gamma.to(dev),
+                                              beta=beta.to(dev), eps=1e-6)
+    want = resid + (a.float() @ b.float().t() + bias) * rowscale.repeat_interleave(rps)[:M, None]
+    close(out, want, 1e-4, 1e-4, "resid_ln/out")
+    mu, var = want.mean(1), want.var(1, unbiased=False)
+    close(mean, mu, 1e-4, 1e-4, "resid_ln/mean")
+    close(rstd, (var + 1e-6).rsqrt(), 1e-3, 1e-4, "resid_ln/rstd")
+    close(y, F.layer_norm(want, (N,), gamma, beta, 1e-6), 1e-2, 2e-2, "resid_ln/y")

@@ -124,3 +124,8 @@ def test_gemm_row384(hip, monkeypatch, M, N, K):
     for seed in range(2):
         kc.check_gemm_nt(hip.device, M=M, N=N, K=K, seed=seed)
     kc.check_gemm_dynamic_rows(hip.device, M=max(M, 600), N=N, K=K, live=75)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 384, 128), (4096, 384, 1536), (2048, 192, 768)])
+def test_gemm_resid_ln(hip, M, N, K):
+    kc.check_gemm_resid_ln(hip.device, M=M, N=N, K=K)

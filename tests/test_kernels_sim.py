@@ -122,3 +122,8 @@ def test_gemm_row384_sim(sim, monkeypatch):
     kc.check_gemm_nt(sim.device, M=300, N=136, K=128)
     kc.check_gemm_nt(sim.device, M=140, N=384, K=192)
     kc.check_gemm_dynamic_rows(sim.device, M=600, N=264, K=64, live=75)
+
+
+def test_gemm_resid_ln_sim(sim):
+    kc.check_gemm_resid_ln(sim.device, M=300, N=384, K=128)
+    kc.check_gemm_resid_ln(sim.device, M=140, N=192, K=64)
