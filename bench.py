@@ -159,7 +159,7 @@ def main():
             intensity = d["flops"] / max(d["bytes"], 1.0)
             hbm_bound = intensity < ridge
             line["roofline"] = {"bound": "hbm" if hbm_bound else "mfma",
-                                "kernel": f"ccd::gemm_bf16_kernel / ccd::gemm256_kernel ({key})",
+                                "kernel": f"ccd::gemm_bf16_kernel / gemm256_kernel / gemm_row384_kernel ({key})",
                                 "achieved": round(gbs if hbm_bound else tflops, 1),
                                 "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TF,
                                 "unit": "GB/s" if hbm_bound else "TFLOP/s",

@@ -35,6 +35,10 @@ def collect(path, counter):
                 m = re.search(r"gemm256_kernel<(\d+)", name)
                 key = {"0": "gemm_nt_bf16", "1": "gemm_nt_gelu", "2": "gemm_nt_resid", "3": "gemm_nt_f32",
                        "5": "gemm_nt_dgelu"}.get(m.group(1), "gemm256?") if m else "gemm256?"
+            elif "gemm_row384_kernel" in name:               # full-row kernel: residual (+ LayerNorm) products
+                m = re.search(r"gemm_row384_kernel<(\d+)", name)
+                key = {"0": "gemm_nt_bf16", "2": "gemm_nt_resid", "3": "gemm_nt_f32", "7": "gemm_nt_resid"}.get(
+                    m.group(1), "gemm_row384?") if m else "gemm_row384?"
             elif "ln_fwd_kernel" in name:
                 key = "ln_fwd"
             else:
