@@ -272,13 +272,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wm = w >> 1, wn = w & 1;
 
-    const int tiles_m = (m_static + GEMM_BM - 1) / GEMM_BM, tiles_n = (p.N + GEMM_BN - 1) / GEMM_BN;
+    // NT with a device-side row count: only the LIVE row tiles are enumerated (the head runs with a static bound of
+    // 2*26*B rows of which ~25 % exist; walking the dead tiles one by one cost ~12 % of the logits product)
+    const int tiles_m = ((TN ? m_static : p.M) + GEMM_BM - 1) / GEMM_BM, tiles_n = (p.N + GEMM_BN - 1) / GEMM_BN;
     // Work items = tiles x splits, numbered so that consecutive ids share work: for NT the column tiles of one A
     // row-panel, for TN all output tiles of ONE contraction slice (they stream the same dY / X rows).  XCD x (the
     // hardware sends workgroup b to XCD b % 8) owns one contiguous range of ids, its workgroups take them round-robin,
     // so neighbours run at the same time on the same L2 and the re-reads are L2 hits instead of HBM traffic.
     const unsigned ntile = (unsigned)(tiles_m * tiles_n);
-    const unsigned total = (unsigned)p.work_items, G = gridDim.x;
+    const unsigned total = TN ? (unsigned)p.work_items : ntile, G = gridDim.x;
     const unsigned ng = G < 8u ? G : 8u;                                       // XCDs that received workgroups
     const unsigned xcd = blockIdx.x % ng, slot = blockIdx.x / ng;
     const unsigned nx = G / ng + (xcd < G % ng ? 1u : 0u);                     // workgroups on this XCD

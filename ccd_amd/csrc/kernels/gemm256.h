@@ -42,7 +42,7 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
     // wave w runs on SIMD w % 4: with wm fastest, the waves of any column sub-range cover all four SIMDs, so a column-
     // partial tile (N = 384: 256 + 128) whose right-hand waves have nothing to multiply finishes in half the time
     const int wm = w % WM, wn = w / WM;
-    const int tiles_m = (m_static + G256_BM - 1) / G256_BM, tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + G256_BM - 1) / G256_BM, tiles_n = (p.N + BN - 1) / BN;   // live row tiles only
     const unsigned total = (unsigned)(tiles_m * tiles_n), G = gridDim.x;
     // XCD-partitioned work list (see gemm.h): consecutive tiles = the column tiles of one A row-panel
     const unsigned ng = G < 8u ? G : 8u;

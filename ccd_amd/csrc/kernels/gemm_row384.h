@@ -32,7 +32,7 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
     char* smem = dynamic_smem();
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, hf = lane >> 5, lq = lane & 31;
     const int wm = w & 1, wn = w >> 1;                       // wm fastest: any column range covers all four SIMDs
-    const unsigned total = (unsigned)((m_static + GR_BM - 1) / GR_BM), G = gridDim.x;
+    const unsigned total = (unsigned)((p.M + GR_BM - 1) / GR_BM), G = gridDim.x;       // live row tiles only
     const unsigned ng = G < 8u ? G : 8u;
     const unsigned xcd = blockIdx.x % ng, slot = blockIdx.x / ng;
     const unsigned nx = G / ng + (xcd < G % ng ? 1u : 0u);
