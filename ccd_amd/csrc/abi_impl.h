@@ -100,18 +100,18 @@ static void ccd_reduce_geometry(long rows, int N, int* cgn_log2, int* col_blocks
 }
 static bool ccd_env_flag(const char* name, bool dflt);
 // 256x256-tile LDS-DMA kernel for the large-M products (gemm256.h): one workgroup per CU
-template <int BN>
+template <int BN, bool DEEP = false>
 static int ccd_launch_gemm256(const ccd::GemmParams& p, int epilogue, void* stream) {
     const int tiles = ((p.M + ccd::G256_BM - 1) / ccd::G256_BM) * ((p.N + BN - 1) / BN);
     const int cus = ccd_rt_num_cus();
     const dim3 grid(tiles < cus ? tiles : cus), block(ccd::G256_THREADS);
     const size_t smem = ccd::G256_SMEM_BYTES;
     switch (epilogue) {
-        case CCD_EPI_BF16: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_BF16, BN>), grid, block, smem, stream, p); break;
-        case CCD_EPI_GELU: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_GELU, BN>), grid, block, smem, stream, p); break;
-        case CCD_EPI_RESID: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_RESID, BN>), grid, block, smem, stream, p); break;
-        case CCD_EPI_F32: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_F32, BN>), grid, block, smem, stream, p); break;
-        case CCD_EPI_DGELU: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_DGELU, BN>), grid, block, smem, stream, p); break;
+        case CCD_EPI_BF16: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_BF16, BN, DEEP>), grid, block, smem, stream, p); break;
+        case CCD_EPI_GELU: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_GELU, BN, DEEP>), grid, block, smem, stream, p); break;
+        case CCD_EPI_RESID: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_RESID, BN, DEEP>), grid, block, smem, stream, p); break;
+        case CCD_EPI_F32: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_F32, BN, DEEP>), grid, block, smem, stream, p); break;
+        case CCD_EPI_DGELU: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_DGELU, BN, DEEP>), grid, block, smem, stream, p); break;
         default: return CCD_EINVAL;
     }
     return ccd_rt_last_error();
@@ -181,8 +181,11 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
         return ccd_launch_gemm_row384(p, epilogue, stream);
     const bool f32_too = ccd_env_flag("CCD_GEMM_256_F32", false);
     const bool bf16_out = epilogue == CCD_EPI_BF16 || epilogue == CCD_EPI_GELU || epilogue == CCD_EPI_DGELU;
-    if (mode_256 >= 1 && (bf16_out || (f32_too && epilogue != CCD_EPI_ATOMIC)) && M >= min_m_256 && N >= min_n_256)
+    if (mode_256 >= 1 && (bf16_out || (f32_too && epilogue != CCD_EPI_ATOMIC)) && M >= min_m_256 && N >= min_n_256) {
+        // CCD_GEMM_256_DEEP: BK = 32 x 4 buffers (three k-steps of DMA in flight) instead of BK = 64 x 2
+        if (ccd_env_flag("CCD_GEMM_256_DEEP", false)) return ccd_launch_gemm256<256, true>(p, epilogue, stream);
         return ccd_launch_gemm256<256>(p, epilogue, stream);
+    }
     if (mode_256 >= 2 && epilogue != CCD_EPI_ATOMIC && M >= min_m_256) return ccd_launch_gemm256<128>(p, epilogue, stream);
     static const bool use_nt32 = ccd_env_flag("CCD_GEMM_NT32", false);
     static const bool use_ares = ccd_env_flag("CCD_GEMM_ARES", false);

@@ -26,12 +26,19 @@ constexpr int G256_OPERAND_BYTES = G256_BM * G256_BK * 2;            // 32 KiB p
 constexpr int G256_SMEM_BYTES = 4 * G256_OPERAND_BYTES;             // 2 buffers x (A + B) = 128 KiB
 
 // BN = 256: waves 2 (M) x 4 (N), 128x64 per wave.  BN = 128 (the N = 384 products): waves 4 x 2, 64x64 per wave.
-template <int EPI, int BN = 256>
+// DEEP = true: BK = 32 and FOUR 32-KiB buffers instead of BK = 64 and two 64-KiB ones - three k-steps of DMA in flight
+// (counted vmcnt, LDS-only barriers) instead of one.  Measured on the plain variant: of ~4.0 k cycles per 64-deep k-tile
+// only ~2.2 k are MFMA issue, ~1.8 k are spent waiting for the single in-flight DMA (own vmcnt + the other waves').
+template <int EPI, int BN = 256, bool DEEP = false>
 __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) {
     constexpr int WM = BN == 256 ? 2 : 4, WN = 8 / WM;     // wave grid
     constexpr int WROWS = G256_BM / WM, WCOLS = BN / WN;    // per-wave output
     constexpr int TI = WROWS / 32, TJ = WCOLS / 32;         // 32x32 accumulator tiles per wave
     constexpr int BCH = BN / 64;                            // B chunks (8 rows) per wave and k-tile
+    constexpr int BK = DEEP ? 32 : 64;                      // contraction depth of one LDS buffer
+    constexpr int ROW = BK * 2;                             // bytes per image row
+    constexpr int A_IMG = G256_BM * ROW;                    // A image bytes inside a buffer (B follows)
+    constexpr int BUF_SHIFT = DEEP ? 15 : 16;               // buffer b starts at b << BUF_SHIFT
     const int m_static = p.M;                               // the work list is built for the static shape
     if (p.d_rows) {                                         // device-side row count: tiles past it are skipped
         const int dyn = p.d_rows[0] * p.rows_mul;
@@ -51,7 +58,7 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
     const unsigned q8 = total / ng, r8 = total % ng;
     const unsigned base_x = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     const unsigned cnt_x = q8 + (xcd < r8 ? 1u : 0u);
-    const int nk = p.K / G256_BK;
+    const int nk = p.K / BK;
 
     // Fragment addresses.  With slot = 2*kk + hf and the swizzle slot ^ f(row), the byte offset of k-step kk is
     // base ^ (kk << 5) with base = row*128 + ((f >> 1) << 5) + ((hf ^ (f & 1)) << 4): ONE register per fragment row
@@ -59,19 +66,24 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
     unsigned base_a[TI], base_b[TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
-        const int row = WROWS * wm + 32 * i + lq, f = ((row >> 1) ^ (row >> 4)) & 7;
-        base_a[i] = (unsigned)(row * 128 + ((f >> 1) << 5) + ((hf ^ (f & 1)) << 4));
+        const int row = WROWS * wm + 32 * i + lq;
+        const int f = DEEP ? ((row >> 2) & 3) : (((row >> 1) ^ (row >> 4)) & 7);     // 64-B rows: 4 slots, 128-B rows: 8
+        base_a[i] = (unsigned)(row * ROW + ((f >> 1) << 5) + ((hf ^ (f & 1)) << 4));
     }
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
-        const int row = WCOLS * wn + 32 * j + lq, f = ((row >> 1) ^ (row >> 4)) & 7;
-        base_b[j] = (unsigned)(G256_OPERAND_BYTES + row * 128 + ((f >> 1) << 5) + ((hf ^ (f & 1)) << 4));
+        const int row = WCOLS * wn + 32 * j + lq;
+        const int f = DEEP ? ((row >> 2) & 3) : (((row >> 1) ^ (row >> 4)) & 7);
+        base_b[j] = (unsigned)(A_IMG + row * ROW + ((f >> 1) << 5) + ((hf ^ (f & 1)) << 4));
     }
 
     if (slot >= cnt_x) return;
     // DMA source pointers of the current item: wave w moves chunks 4w .. 4w+3 (8 rows each) of both operands
-    const bf16_t* ga[4];
-    const bf16_t* gb[BCH];
+    // a 1-KiB DMA chunk = 8 rows of 128 B (BK = 64) or 16 rows of 64 B (BK = 32); wave w moves ACH / BCHK chunks per buffer
+    constexpr int RPC = 1024 / ROW;                         // rows per chunk
+    constexpr int ACH = G256_BM / RPC / 8, BCHK = BN / RPC / 8;
+    const bf16_t* ga[ACH];
+    const bf16_t* gb[BCHK];
     int m0, n0;
     bool live;
     auto setup = [&](unsigned item) {
@@ -80,30 +92,31 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
         m0 = tm * G256_BM;
         n0 = tn * BN;
         live = m0 < p.M;
+        const int rin = DEEP ? (lane >> 2) : (lane >> 3), pos = DEEP ? (lane & 3) : (lane & 7);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 8 * (4 * w + i) + (lane >> 3);
-            const int src_slot = (lane & 7) ^ (((row >> 1) ^ (row >> 4)) & 7);
+        for (int i = 0; i < ACH; ++i) {
+            const int row = RPC * (ACH * w + i) + rin;
+            const int src_slot = pos ^ (DEEP ? ((row >> 2) & 3) : (((row >> 1) ^ (row >> 4)) & 7));
             int ra = m0 + row;
             ra = ra < p.M ? ra : p.M - 1;
             ga[i] = p.A + (long)ra * p.lda + src_slot * 8;
         }
 #pragma unroll
-        for (int i = 0; i < BCH; ++i) {
-            const int row = 8 * (BCH * w + i) + (lane >> 3);
-            const int src_slot = (lane & 7) ^ (((row >> 1) ^ (row >> 4)) & 7);
+        for (int i = 0; i < BCHK; ++i) {
+            const int row = RPC * (BCHK * w + i) + rin;
+            const int src_slot = pos ^ (DEEP ? ((row >> 2) & 3) : (((row >> 1) ^ (row >> 4)) & 7));
             int rb = n0 + row;
             rb = rb < p.N ? rb : p.N - 1;
             gb[i] = p.B + (long)rb * p.ldb + src_slot * 8;
         }
     };
     auto dma = [&](int kt, int buf) {
-        char* abuf = smem + buf * 2 * G256_OPERAND_BYTES + 4 * w * 1024;
-        char* bbuf = smem + buf * 2 * G256_OPERAND_BYTES + G256_OPERAND_BYTES + BCH * w * 1024;
+        char* abuf = smem + (buf << BUF_SHIFT) + ACH * w * 1024;
+        char* bbuf = smem + (buf << BUF_SHIFT) + A_IMG + BCHK * w * 1024;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(ga[i] + kt * G256_BK, abuf + i * 1024);
+        for (int i = 0; i < ACH; ++i) glds16(ga[i] + kt * BK, abuf + i * 1024);
 #pragma unroll
-        for (int i = 0; i < BCH; ++i) glds16(gb[i] + kt * G256_BK, bbuf + i * 1024);
+        for (int i = 0; i < BCHK; ++i) glds16(gb[i] + kt * BK, bbuf + i * 1024);
     };
 #ifdef CCD_GEMM_LAB     // per-phase cycle totals of wave 0 -> p.colsum (8 u64 per workgroup) when m_fastest & 64
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -112,9 +125,21 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
 #else
 #define G256_STAMP(i)
 #endif
+    // DEEP: wait until at most `tiles_in_flight` k-steps of DMA (ACH + BCHK pieces each) are still outstanding
+    auto wait_steps = [&](int tiles_in_flight) {
+        constexpr int PER = ACH + BCHK;
+        if (tiles_in_flight >= 2) glds_wait<2 * PER>();
+        else if (tiles_in_flight == 1) glds_wait<PER>();
+        else glds_wait_all();
+    };
     unsigned item = slot;
     setup(item);
-    if (live) dma(0, 0);
+    if (live) {
+        dma(0, 0);
+        if (DEEP) {
+            if (nk > 1) dma(1, 1);
+        }
+    }
     while (true) {
         f32x16 acc[TI][TJ];
 #pragma unroll
@@ -123,11 +148,51 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
             for (int j = 0; j < TJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int nk_live = live ? nk : 0;
+        const bool wave_live = n0 + WCOLS * wn < p.N;         // this wave's columns exist (column-partial tiles)
+        if (DEEP) {
+            // steps 0 and 1 were requested before (prologue / under the previous epilogue); step 2 goes out now that the
+            // staging image (buffers 2, 3) has been read out.  vmcnt(0) once per tile also retires the epilogue's stores.
+            if (nk_live > 2) dma(2, 2);
+            wait_steps(nk_live > 2 ? 2 : (nk_live > 1 ? 1 : 0));     // step 0 landed
+            lds_barrier();
+            G256_STAMP(0)
+            for (int kt = 0; kt < nk_live; ++kt) {
+                if (kt + 3 < nk_live) dma(kt + 3, (kt + 3) & 3);      // buffer last read in step kt-1 (barrier passed)
+                const unsigned bufbit = (unsigned)(kt & 3) << BUF_SHIFT;
+                if (wave_live) {
+                    bf16x8 a[2][TI], b[2][TJ];
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) b[0][j] = *reinterpret_cast<const bf16x8*>(smem + (base_b[j] ^ bufbit));
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) a[0][i] = *reinterpret_cast<const bf16x8*>(smem + (base_a[i] ^ bufbit));
+                    {
+                        const unsigned x = bufbit | 32u;
+#pragma unroll
+                        for (int j = 0; j < TJ; ++j) b[1][j] = *reinterpret_cast<const bf16x8*>(smem + (base_b[j] ^ x));
+#pragma unroll
+                        for (int i = 0; i < TI; ++i) a[1][i] = *reinterpret_cast<const bf16x8*>(smem + (base_a[i] ^ x));
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int i = 0; i < TI; ++i)
+#pragma unroll
+                            for (int j = 0; j < TJ; ++j)
+                                acc[i][j] = mfma_32x32x16_bf16(b[kk][j], a[kk][i], acc[i][j]);   // D^T[n][m]
+                }
+                G256_STAMP(1)
+                // step kt+1 must have landed: after this step's issue min(3, remaining) steps are in flight
+                const int rem = nk_live - 1 - kt;
+                if (rem > 0) wait_steps((rem < 3 ? rem : 3) - 1);
+                G256_STAMP(2)
+                lds_barrier();
+                G256_STAMP(3)
+            }
+        } else {
         glds_wait_all();
         __syncthreads();
         G256_STAMP(0)
-        const int nk_live = live ? nk : 0;
-        const bool wave_live = n0 + WCOLS * wn < p.N;         // this wave's columns exist (column-partial tiles)
         for (int kt = 0; kt < nk_live; ++kt) {
             if (kt + 1 < nk) dma(kt + 1, (kt + 1) & 1);
             const unsigned bufbit = (unsigned)(kt & 1) << 16;       // buffer 1 starts at 64 KiB
@@ -167,6 +232,7 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
             __syncthreads();
             G256_STAMP(3)
         }
+        }
         // ---- next item: its first k-tile streams into buffer 0 while this tile is written out through buffer 1
         const int em0 = m0, en0 = n0;
         const bool elive = live, ewave_live = wave_live;
@@ -174,7 +240,12 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
         const bool has_next = next < cnt_x;
         if (has_next) {
             setup(next);
-            if (live) dma(0, 0);
+            if (live) {
+                dma(0, 0);
+                if (DEEP) {
+                    if (nk > 1) dma(1, 1);                   // buffers 0 and 1; the staging image owns buffers 2 and 3
+                }
+            }
         }
         if (elive) {
 

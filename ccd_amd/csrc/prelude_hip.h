@@ -55,6 +55,8 @@ __device__ __forceinline__ void glds16(const void* gptr, char* lds_base) {
                                      (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
 __device__ __forceinline__ void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }   // <= N VMEM ops outstanding
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt while an LDS-DMA is in flight
 // (the DMA is a pending LDS write on the VM counter); this one lets a DMA span the barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

@@ -136,6 +136,8 @@ inline char* dynamic_smem() { return sim::curblk->dyn_smem; }
 // LDS-DMA (prelude_hip.h): the executor copies synchronously, lane by lane
 inline void glds16(const void* gptr, char* lds_base) { std::memcpy(lds_base + 16 * sim::cur->lane, gptr, 16); }
 inline void glds_wait_all() {}
+template <int N>
+inline void glds_wait() {}
 inline unsigned opaque_u32(unsigned x) { return x; }
 template <int P>
 inline void wave_prio() {}

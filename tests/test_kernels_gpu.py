@@ -110,6 +110,11 @@ def test_gemm256(hip, monkeypatch, M, N, K):
     for seed in range(3):
         kc.check_gemm_nt(hip.device, M=M, N=N, K=K, seed=seed)
     kc.check_gemm_dynamic_rows(hip.device, M=max(M, 600), N=N, K=K, live=75)
+    monkeypatch.setenv("CCD_GEMM_256_DEEP", "1")              # BK = 32 x 4 buffers, counted vmcnt (async: repeat)
+    for seed in range(4):
+        kc.check_gemm_nt(hip.device, M=M, N=N, K=K, seed=seed)
+    kc.check_gemm_dynamic_rows(hip.device, M=max(M, 600), N=N, K=K, live=75)
+    monkeypatch.delenv("CCD_GEMM_256_DEEP")
     monkeypatch.setenv("CCD_GEMM_256", "2")                   # the 256x128 variant, every epilogue
     monkeypatch.setenv("CCD_GEMM_256_MIN_N", "1000000")
     for seed in range(2):

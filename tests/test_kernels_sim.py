@@ -108,6 +108,14 @@ def test_gemm256_sim(sim, monkeypatch):
     monkeypatch.setenv("CCD_GEMM_256_MIN_N", "1")
     kc.check_gemm_nt(sim.device, M=300, N=264, K=128)
     kc.check_gemm_dynamic_rows(sim.device, M=600, N=264, K=64, live=75)
+    # deep-prefetch variant (BK = 32, four buffers)
+    monkeypatch.setenv("CCD_GEMM_256_DEEP", "1")
+    monkeypatch.setenv("CCD_GEMM_256_F32", "1")
+    kc.check_gemm_nt(sim.device, M=300, N=264, K=128)
+    kc.check_gemm_nt(sim.device, M=260, N=256, K=64)
+    kc.check_gemm_dynamic_rows(sim.device, M=600, N=264, K=192, live=75)
+    monkeypatch.delenv("CCD_GEMM_256_DEEP")
+    monkeypatch.delenv("CCD_GEMM_256_F32")
     # the 256x128 variant (all epilogues, incl. fp32 residual / fp32 stores)
     monkeypatch.setenv("CCD_GEMM_256", "2")
     monkeypatch.setenv("CCD_GEMM_256_MIN_N", "1000000")
