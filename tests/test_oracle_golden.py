@@ -130,3 +130,38 @@ def test_small_step(golden_dir):
     src = torch.from_numpy(ccl_np.idmap_to_planes(ids))
     clusters = torch.cat([src, O.warp_planes(src, torch.from_numpy(g["pred/metrics"]))])
     np.testing.assert_array_equal(ccl_np.planes_to_idmap(clusters.numpy()), g["pred/zero_idmap"])
+
+
+@pytest.mark.parametrize("tag,arch,n_layers,B", [("tiny", "vit_tiny", 2, 4), ("small", "vit_small", 6, 8)])
+def test_finetune_step(golden_dir, tag, arch, n_layers, B):
+    """DINO_Finetune - two AdamW iterations + greedy decoding (train_finetune.py:262-289)."""
+    from oracle import finetune_oracle as FO
+    g = np.load(os.path.join(golden_dir, "finetune_step.npz"))
+    np.testing.assert_array_equal(FO.cosine_scheduler(0.0005, 1e-6, 3, 20, warmup_epochs=1), g["sched"])
+    spec = FO.FtSpec(vit=O.Spec(**O.ARCH[arch]), n_layers=n_layers)
+    net = FO.init_finetune(spec, seed=0)
+    _check_stats(g[f"{tag}/init_names"], g[f"{tag}/init_stats"], net.P, rtol=0, atol=0, what="init")
+    words = [str(w) for w in g["words"][:B]]
+    targets = FO.str2tensor(words)
+    np.testing.assert_array_equal(targets.numpy(), g[f"{tag}/targets"])
+    opt = O.AdamWState()
+    gen = torch.Generator().manual_seed(1234)
+    for step in range(2):
+        p = f"{tag}/s{step}/"
+        img = torch.randn(B, 3, 32, 128, generator=gen)
+        np.testing.assert_allclose(_stat(img), g[p + "image_stat"], rtol=1e-12)
+        loss_ref, lr = g[p + "loss"]
+        rec = FO.train_iteration(net, opt, img, targets, lr)
+        np.testing.assert_allclose(rec["loss"], loss_ref, rtol=2e-6)
+        np.testing.assert_allclose(rec["attn"].mean(1).numpy(), g[p + "attn_mean"], rtol=1e-3, atol=1e-6)
+        _check_stats(g[p + "grad_names"], g[p + "grad_stats"], rec["grads_raw"], rtol=1e-3, atol=2e-7, what="grad")
+        assert set(rec["grads_raw"]) == set(str(n) for n in g[p + "grad_names"])
+        _check_stats(g[p + "post_names"], g[p + "post_stats"], net.P, rtol=1e-4, atol=1e-6, what="post")
+    img = torch.randn(B, 3, 32, 128, generator=gen)
+    np.testing.assert_allclose(_stat(img), g[f"{tag}/eval_image_stat"], rtol=1e-12)
+    with torch.no_grad():
+        _, logits, _ = FO.forward_train(net.P, spec, img, targets)
+        probs = FO.forward_test(net.P, spec, img)
+    np.testing.assert_allclose(logits.numpy(), g[f"{tag}/logits"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(probs.numpy(), g[f"{tag}/test_probs"], rtol=2e-3, atol=1e-5)
+    np.testing.assert_array_equal(probs.argmax(-1).numpy(), g[f"{tag}/test_probs"].argmax(-1))

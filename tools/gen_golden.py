@@ -14,6 +14,7 @@ Fixtures (all small):
   tiny_step.npz    3-block E=192 model, B=2: full tensors of every stage + grads
   small_step.npz   CCD_pretrain_ViT_small hyper-parameters, B=8, 2 iterations: losses, index maps,
                    sampled logits, per-parameter grad norms / post-step checksums
+  finetune_step.npz  DINO_Finetune (vit_tiny/2 layers, vit_small/6 layers): 2 AdamW iterations + greedy decoding
 """
 import argparse
 import os
@@ -25,16 +26,23 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 sys.dont_write_bytecode = True
+# REPO is NOT put on sys.path: its `Dino/` alias package (a regular package) would shadow the reference's namespace package
 sys.path.insert(0, os.path.join(HERE, "oracle_stubs"))
 sys.path.insert(0, "/root/reference")
-sys.path.insert(0, REPO)
+sys.path = [p for p in sys.path if os.path.realpath(p or os.getcwd()) != REPO]
 
 import torch
 import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ccd_amd.synthetic import make_batch  # our generator, not reference code
+import importlib.util
+_spec = importlib.util.spec_from_file_location("ccd_synthetic", os.path.join(REPO, "ccd_amd", "synthetic.py"))
+_syn = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_syn)
+make_batch = _syn.make_batch              # our generator, not reference code
+import Dino as _ref_dino
+assert all(os.path.realpath(p).startswith("/root/reference") for p in _ref_dino.__path__), _ref_dino
 
 GOLD = os.path.join(REPO, "tests", "golden")
 
@@ -360,6 +368,76 @@ def gen_keys():
     print("state_keys.json written", {k: len(v["student"]) for k, v in table.items()})
 
 
+FT_WORDS = ["hello", "Wor1d!", "MI355X", "a", "text-recognition", "CCD", "~{unknown}", "0123456789abcdefghijklmnopqrstuvwxyz"]
+
+
+def build_reference_finetune(arch, n_layers, seed):
+    """DINO_Finetune (Dino/model/dino_vision.py:134-185) with every nn.Dropout set to p = 0 and drop_path_rate 0."""
+    from Dino.model.dino_vision import DINO_Finetune
+
+    class Cfg:
+        pass
+    c = Cfg()
+    c.arch, c.patch_size, c.drop_path_rate = arch, 4, 0.0
+    c.decoder_max_seq_len, c.decoder_n_layers, c.decoder_d_embedding, c.decoder_n_head = 25, n_layers, 512, 8
+    c.decoder_d_k = c.decoder_d_v = 64
+    c.decoder_d_model, c.decoder_d_inner = 512, 256
+    torch.manual_seed(seed)
+    model = DINO_Finetune(c)
+    for m in model.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+    model.train()
+    return model
+
+
+def gen_finetune():
+    """finetune_step.npz: two iterations of train_finetune.py:262-289 (AdamW, no clipping) + greedy decoding, for
+    vit_tiny/2 decoder layers (full tensors) and vit_small/6 layers (the shipped CCD_vision_model_ARD configuration)."""
+    from Dino.modules import utils as rutils
+    out = {"words": np.array(FT_WORDS)}
+    out["sched"] = rutils.cosine_scheduler(0.0005, 1e-6, 3, 20, warmup_epochs=1)
+    for tag, arch, n_layers, B in (("tiny", "vit_tiny", 2, 4), ("small", "vit_small", 6, 8)):
+        model = build_reference_finetune(arch, n_layers, seed=0)
+        names, stats = state_stats(model.state_dict().items())
+        out[f"{tag}/init_names"], out[f"{tag}/init_stats"] = names, stats
+        targets = model.label_convertor.str2tensor(FT_WORDS[:B])
+        out[f"{tag}/targets"] = targets.numpy()
+        opt = torch.optim.AdamW(rutils.get_params_groups(model), lr=0.0005, betas=(0.9, 0.999), weight_decay=0.05)
+        g = torch.Generator().manual_seed(1234)
+        for step in range(2):
+            img = torch.randn(B, 3, 32, 128, generator=g)
+            lr = float(out["sched"][step + 3])
+            for grp in opt.param_groups:
+                grp["lr"] = lr
+            losses, attn = model(img, targets, return_loss=True)
+            loss = losses.mean()
+            model.zero_grad()
+            loss.backward()
+            opt.step()
+            p = f"{tag}/s{step}/"
+            out[p + "image_stat"] = stat(img)
+            out[p + "loss"] = np.array([loss.item(), lr])
+            out[p + "attn_mean"] = attn.detach().mean(1).numpy().astype(np.float32)
+            gn, gs = state_stats([(n, q.grad) for n, q in model.named_parameters() if q.grad is not None])
+            out[p + "grad_names"], out[p + "grad_stats"] = gn, gs
+            pn, ps = state_stats(model.named_parameters())
+            out[p + "post_names"], out[p + "post_stats"] = pn, ps
+        # train-mode logits + greedy decoding on a fresh batch with the updated weights
+        img = torch.randn(B, 3, 32, 128, generator=g)
+        with torch.no_grad():
+            feat = model.extract_feat(img)
+            logits, _ = model.decoder(feat, model.encoder(feat), {"padded_targets": targets}, train_mode=True)
+            model.eval()
+            probs = model(img, None, return_loss=False)
+        out[f"{tag}/eval_image_stat"] = stat(img)
+        out[f"{tag}/logits"] = logits.numpy().astype(np.float32)
+        out[f"{tag}/test_probs"] = probs.numpy().astype(np.float32)
+        print(tag, "losses", out[f"{tag}/s0/loss"], out[f"{tag}/s1/loss"], "decoded", probs.argmax(-1)[0, :8].tolist())
+    np.savez_compressed(os.path.join(GOLD, "finetune_step.npz"), **out)
+    print("finetune_step.npz written")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -367,6 +445,7 @@ if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     os.chdir("/root/reference")  # Config() and friends use relative paths; we never write here
     torch.set_num_threads(8)
-    todo = [a.only] if a.only else ["sched", "ccl", "tiny", "small", "keys"]
+    todo = [a.only] if a.only else ["sched", "ccl", "tiny", "small", "keys", "finetune"]
     for t in todo:
-        {"sched": gen_sched, "ccl": gen_ccl, "tiny": gen_tiny, "small": gen_small, "keys": gen_keys}[t]()
+        {"sched": gen_sched, "ccl": gen_ccl, "tiny": gen_tiny, "small": gen_small, "keys": gen_keys,
+         "finetune": gen_finetune}[t]()
