@@ -20,6 +20,7 @@ P = C.c_void_p
 I = C.c_int
 L = C.c_long
 F = C.c_float
+U64 = C.c_uint64
 
 # name -> argtypes (restype is always int unless listed in _RESTYPES); mirrors include/ccd_hip.h
 SIGNATURES = {
@@ -72,6 +73,14 @@ SIGNATURES = {
     "ccd_cls_gather_fwd": [P, L, P, P, I, I, I, P],
     "ccd_cls_grad_cols": [P, P, I, I, I, P],
     "ccd_permute4": [P, P, P, P, P, I, P],
+    "ccd_dropout": [P, I, P, P, I, L, U64, F, P],
+    "ccd_dec_embed_fwd": [P, P, P, P, I, I, I, I, U64, F, P],
+    "ccd_dec_embed_bwd": [P, P, P, I, I, I, I, U64, F, P],
+    "ccd_dec_attn_fwd": [P, L, P, L, P, L, P, L, P, P, P, P, I, I, I, I, I, I, F, U64, F, P],
+    "ccd_dec_attn_bwd": [P, L, P, L, P, L, P, P, L, P, P, P, I, I, I, I, I, I, F, U64, F, P, L, P, L, P, L, P],
+    "ccd_tf_loss_fwd": [P, L, I, P, I, I, I, P, P, P],
+    "ccd_tf_loss_bwd": [P, L, I, P, I, I, I, P, P, F, P, L, P],
+    "ccd_greedy_step": [P, L, I, I, P, I, I, P, I, P],
 }
 _RESTYPES = {"ccd_build_info": C.c_char_p}
 

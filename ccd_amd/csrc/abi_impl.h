@@ -19,6 +19,7 @@
 #include "kernels/loss.h"
 #include "kernels/optim.h"
 #include "kernels/conv.h"
+#include "kernels/decoder.h"
 
 #define CCD_CHECK(cond, code) \
     do {                      \
@@ -734,6 +735,125 @@ int ccd_permute4(const float* src, const long* src_strides, const long* dst_stri
     const dim3 grid((unsigned)((total + 255) / 256));
     if (accumulate) CCD_LAUNCH((ccd::permute4_kernel<true>), grid, dim3(256), 0, stream, src, q, total, dst);
     else CCD_LAUNCH((ccd::permute4_kernel<false>), grid, dim3(256), 0, stream, src, q, total, dst);
+    return ccd_rt_last_error();
+}
+
+// ------------------------------------------------------------------------------------------ finetune path
+static void ccd_drop_consts(float p, unsigned* thr, float* scale) {
+    if (!(p > 0.f)) { *thr = 0u; *scale = 1.0f; return; }
+    const double t = (double)p * 4294967296.0;
+    *thr = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    *scale = 1.0f / (1.0f - p);
+}
+int ccd_dropout(const void* src, int src_bf16, const float* resid, void* dst, int dst_bf16, long n, uint64_t seed, float p,
+                void* stream) {
+    CCD_CHECK(src && dst && n >= 0 && p >= 0.f && p < 1.f, CCD_EINVAL);
+    if (n == 0) return CCD_OK;
+    CCD_CHECK(n % 4 == 0 && CCD_ALIGNED16(resid), CCD_ESHAPE);
+    CCD_CHECK((((uintptr_t)src) & (src_bf16 ? 7u : 15u)) == 0 && (((uintptr_t)dst) & (dst_bf16 ? 7u : 15u)) == 0, CCD_EINVAL);
+    unsigned thr; float scale;
+    ccd_drop_consts(p, &thr, &scale);
+    const dim3 grid((unsigned)((n / 4 + 255) / 256)), block(256);
+    const unsigned long long sd = seed;
+    if (src_bf16 && dst_bf16) CCD_LAUNCH((ccd::dropout_kernel<true, true>), grid, block, 0, stream, src, resid, dst, n, sd, thr, scale);
+    else if (src_bf16) CCD_LAUNCH((ccd::dropout_kernel<true, false>), grid, block, 0, stream, src, resid, dst, n, sd, thr, scale);
+    else if (dst_bf16) CCD_LAUNCH((ccd::dropout_kernel<false, true>), grid, block, 0, stream, src, resid, dst, n, sd, thr, scale);
+    else CCD_LAUNCH((ccd::dropout_kernel<false, false>), grid, block, 0, stream, src, resid, dst, n, sd, thr, scale);
+    return ccd_rt_last_error();
+}
+int ccd_dec_embed_fwd(const int64_t* tokens, const float* emb, const float* pos, float* x, int rows, int T, int D,
+                      int num_classes, uint64_t seed, float p, void* stream) {
+    CCD_CHECK(tokens && emb && pos && x && rows >= 0 && p >= 0.f && p < 1.f, CCD_EINVAL);
+    if (rows == 0) return CCD_OK;
+    CCD_CHECK(T > 0 && D > 0 && D % 4 == 0 && num_classes > 0, CCD_ESHAPE);
+    CCD_CHECK(CCD_ALIGNED16(emb) && CCD_ALIGNED16(pos) && CCD_ALIGNED16(x), CCD_EINVAL);
+    unsigned thr; float scale;
+    ccd_drop_consts(p, &thr, &scale);
+    CCD_LAUNCH(ccd::dec_embed_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const long long*)tokens, emb, pos, x,
+               rows, T, D, num_classes, (unsigned long long)seed, thr, scale);
+    return ccd_rt_last_error();
+}
+int ccd_dec_embed_bwd(const int64_t* tokens, const float* dx, float* demb, int rows, int D, int num_classes, int padding_idx,
+                      uint64_t seed, float p, void* stream) {
+    CCD_CHECK(tokens && dx && demb && rows >= 0 && p >= 0.f && p < 1.f, CCD_EINVAL);
+    if (rows == 0) return CCD_OK;
+    CCD_CHECK(D > 0 && D <= 1024 && num_classes > 0, CCD_ESHAPE);
+    unsigned thr; float scale;
+    ccd_drop_consts(p, &thr, &scale);
+    CCD_LAUNCH(ccd::dec_embed_bwd_kernel, dim3(num_classes), dim3(256), 0, stream, (const long long*)tokens, dx, demb, rows, D,
+               padding_idx, (unsigned long long)seed, thr, scale);
+    return ccd_rt_last_error();
+}
+static int ccd_dec_attn_check(const ccd::DecAttnParams& p) {
+    CCD_CHECK(p.B >= 0 && p.H > 0, CCD_EINVAL);
+    CCD_CHECK(p.Tq > 0 && p.Tq <= ccd::DA_MAXQ && p.Tk > 0 && p.Tk <= ccd::DA_MAXK, CCD_ESHAPE);
+    CCD_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldq >= 64L * p.H && p.ldk >= 64L * p.H &&
+              p.ldv >= 64L * p.H && p.ldo >= 64L * p.H, CCD_ESHAPE);
+    CCD_CHECK(CCD_ALIGNED16(p.q) && CCD_ALIGNED16(p.k) && CCD_ALIGNED16(p.v), CCD_EINVAL);
+    return CCD_OK;
+}
+int ccd_dec_attn_fwd(const ccd_bf16* q, long ldq, const ccd_bf16* k, long ldk, const ccd_bf16* v, long ldv, ccd_bf16* out,
+                     long ldo, float* lse, float* probs, const int64_t* tokens, const int* key_len, int pad_idx, int causal,
+                     int B, int H, int Tq, int Tk, float scale, uint64_t seed, float p, void* stream) {
+    CCD_CHECK(q && k && v && out && lse && p >= 0.f && p < 1.f, CCD_EINVAL);
+    ccd::DecAttnParams a = ccd::DecAttnParams();
+    a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.out = out; a.ldo = ldo; a.lse = lse; a.probs = probs;
+    a.tokens = (const long long*)tokens; a.key_len = key_len; a.pad_idx = pad_idx; a.causal = causal;
+    a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.scale = scale; a.seed = seed;
+    ccd_drop_consts(p, &a.thr, &a.keep_scale);
+    const int rc = ccd_dec_attn_check(a);
+    if (rc != CCD_OK) return rc;
+    if (B == 0) return CCD_OK;
+    CCD_LAUNCH(ccd::dec_attn_fwd_kernel, dim3(B * H), dim3(256), (size_t)ccd::dec_attn_fwd_smem(Tq, Tk), stream, a);
+    return ccd_rt_last_error();
+}
+int ccd_dec_attn_bwd(const ccd_bf16* q, long ldq, const ccd_bf16* k, long ldk, const ccd_bf16* v, long ldv,
+                     const ccd_bf16* out, const ccd_bf16* d_out, long ldo, const float* lse, const int64_t* tokens,
+                     const int* key_len, int pad_idx, int causal, int B, int H, int Tq, int Tk, float scale, uint64_t seed,
+                     float p, ccd_bf16* dq, long lddq, ccd_bf16* dk, long lddk, ccd_bf16* dv, long lddv, void* stream) {
+    CCD_CHECK(q && k && v && out && d_out && lse && dq && dk && dv && p >= 0.f && p < 1.f, CCD_EINVAL);
+    ccd::DecAttnParams a = ccd::DecAttnParams();
+    a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.out = const_cast<ccd_bf16*>(out); a.ldo = ldo;
+    a.lse = const_cast<float*>(lse); a.d_out = d_out;
+    a.tokens = (const long long*)tokens; a.key_len = key_len; a.pad_idx = pad_idx; a.causal = causal;
+    a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.scale = scale; a.seed = seed;
+    a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+    ccd_drop_consts(p, &a.thr, &a.keep_scale);
+    const int rc = ccd_dec_attn_check(a);
+    if (rc != CCD_OK) return rc;
+    CCD_CHECK(lddk % 8 == 0 && lddv % 8 == 0 && CCD_ALIGNED16(dk) && CCD_ALIGNED16(dv) && CCD_ALIGNED16(d_out) && ldo % 8 == 0,
+              CCD_ESHAPE);
+    if (B == 0) return CCD_OK;
+    CCD_LAUNCH(ccd::dec_attn_bwd_kernel, dim3(B * H), dim3(256), (size_t)ccd::dec_attn_bwd_smem(Tq, Tk), stream, a);
+    return ccd_rt_last_error();
+}
+int ccd_tf_loss_fwd(const float* logits, long ldl, int C, const int64_t* targets, int rows, int T, int pad_idx,
+                    float* row_lse, float* acc, void* stream) {
+    CCD_CHECK(logits && targets && row_lse && acc && rows >= 0, CCD_EINVAL);
+    CCD_CHECK(C > 0 && C <= 128 && ldl >= C && T > 0 && rows % T == 0, CCD_ESHAPE);
+    const int rc = ccd_rt_memset_async(acc, 0, 2 * sizeof(float), stream);
+    if (rc) return rc;
+    if (rows == 0) return CCD_OK;
+    CCD_LAUNCH(ccd::tf_loss_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, ldl, C, (const long long*)targets,
+               rows, T, pad_idx, row_lse, acc);
+    return ccd_rt_last_error();
+}
+int ccd_tf_loss_bwd(const float* logits, long ldl, int C, const int64_t* targets, int rows, int T, int pad_idx,
+                    const float* row_lse, const float* acc, float upstream, ccd_bf16* d_logits, long ldd, void* stream) {
+    CCD_CHECK(logits && targets && row_lse && acc && d_logits && rows >= 0, CCD_EINVAL);
+    CCD_CHECK(C > 0 && C <= 128 && ldl >= C && ldd >= C && T > 0 && rows % T == 0, CCD_ESHAPE);
+    if (rows == 0) return CCD_OK;
+    CCD_LAUNCH(ccd::tf_loss_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, ldl, C, (const long long*)targets,
+               rows, T, pad_idx, row_lse, acc, upstream, d_logits, ldd);
+    return ccd_rt_last_error();
+}
+int ccd_greedy_step(const float* logits, long ldl, int C, int B, float* probs, int steps, int step, int64_t* seq,
+                    int seq_len, void* stream) {
+    CCD_CHECK(logits && probs && seq && B >= 0 && step >= 0 && step < steps, CCD_EINVAL);
+    CCD_CHECK(C > 0 && C <= 128 && ldl >= C, CCD_ESHAPE);
+    if (B == 0) return CCD_OK;
+    CCD_LAUNCH(ccd::greedy_step_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, logits, ldl, C, B, probs, steps, step,
+               (long long*)seq, seq_len);
     return ccd_rt_last_error();
 }
 

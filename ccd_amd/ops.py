@@ -511,3 +511,93 @@ def permute4(src, strides, dims, dst, accumulate=False, dst_strides=None):
     arr_l, arr_i = ctypes.c_long * 4, ctypes.c_int * 4
     _call("ccd_permute4", _lib.ptr(src), arr_l(*s), arr_l(*d), arr_i(*n), _lib.ptr(dst), 1 if accumulate else 0)
     return dst
+
+
+# ------------------------------------------------------------------------------------------------ finetune path
+I64 = torch.int64
+
+
+def dropout(src, p, seed, *, resid=None, out=None, out_dtype=None):
+    """out = (resid if given) + Dropout_p(src) with the counter-based mask of `seed` (ccd_hip.h: ccd_dropout)."""
+    assert src.is_contiguous() and src.dtype in (F32, BF16)
+    if out is None:
+        out = torch.empty(src.shape, dtype=out_dtype or src.dtype, device=src.device)
+    assert out.is_contiguous() and out.shape == src.shape and out.dtype in (F32, BF16)
+    _chk(resid, F32, "resid")
+    _call("ccd_dropout", _lib.ptr(src), int(src.dtype == BF16), _lib.ptr(resid), _lib.ptr(out), int(out.dtype == BF16),
+          src.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF, float(p))
+    return out
+
+
+def dec_embed_fwd(tokens, emb, pos, p=0.0, seed=0):
+    """tokens int64 [B,T] -> x fp32 [B*T, D] = dropout(emb[tokens] + pos[:T])."""
+    assert tokens.dtype == I64 and tokens.is_contiguous()
+    _chk(emb, F32, "emb"); _chk(pos, F32, "pos")
+    B, T = tokens.shape
+    D = emb.shape[1]
+    x = torch.empty((B * T, D), dtype=F32, device=emb.device)
+    _call("ccd_dec_embed_fwd", _lib.ptr(tokens), _lib.ptr(emb), _lib.ptr(pos), _lib.ptr(x), B * T, T, D, emb.shape[0],
+          int(seed) & 0xFFFFFFFFFFFFFFFF, float(p))
+    return x
+
+
+def dec_embed_bwd(tokens, dx, demb, padding_idx, p=0.0, seed=0):
+    _chk(dx, F32, "dx"); _chk(demb, F32, "demb")
+    _call("ccd_dec_embed_bwd", _lib.ptr(tokens), _lib.ptr(dx), _lib.ptr(demb), tokens.numel(), dx.shape[1], demb.shape[0],
+          int(padding_idx), int(seed) & 0xFFFFFFFFFFFFFFFF, float(p))
+
+
+def dec_attn_fwd(q, k, v, B, H, Tq, Tk, scale, *, tokens=None, key_len=None, pad_idx=-1, causal=False, p=0.0, seed=0,
+                 want_probs=False):
+    """q [B*Tq, >=64H] / k, v [B*Tk, >=64H] bf16 2-D views (row stride = .stride(0)) -> (out bf16 [B*Tq, 64H], lse, probs)."""
+    for t_ in (q, k, v):
+        assert t_.dtype == BF16 and t_.dim() == 2 and t_.stride(1) == 1
+    out = torch.empty((B * Tq, 64 * H), dtype=BF16, device=q.device)
+    lse = torch.empty((B, H, Tq), dtype=F32, device=q.device)
+    probs = torch.empty((B, H, Tq, Tk), dtype=F32, device=q.device) if want_probs else None
+    _call("ccd_dec_attn_fwd", _lib.ptr(q), q.stride(0), _lib.ptr(k), k.stride(0), _lib.ptr(v), v.stride(0), _lib.ptr(out),
+          out.stride(0), _lib.ptr(lse), _lib.ptr(probs), _lib.ptr(tokens), _lib.ptr(key_len), int(pad_idx), int(causal),
+          B, H, Tq, Tk, float(scale), int(seed) & 0xFFFFFFFFFFFFFFFF, float(p))
+    return out, lse, probs
+
+
+def dec_attn_bwd(q, k, v, out, d_out, lse, dq, dk, dv, B, H, Tq, Tk, scale, *, tokens=None, key_len=None, pad_idx=-1,
+                 causal=False, p=0.0, seed=0):
+    """dq / dk / dv: preallocated bf16 2-D views the gradients are written into (all rows, head columns only)."""
+    for t_ in (q, k, v, dq, dk, dv):
+        assert t_.dtype == BF16 and t_.dim() == 2 and t_.stride(1) == 1
+    _chk(out, BF16, "out"); _chk(d_out, BF16, "d_out")
+    assert out.stride(0) == d_out.stride(0)
+    _call("ccd_dec_attn_bwd", _lib.ptr(q), q.stride(0), _lib.ptr(k), k.stride(0), _lib.ptr(v), v.stride(0), _lib.ptr(out),
+          _lib.ptr(d_out), out.stride(0), _lib.ptr(lse), _lib.ptr(tokens), _lib.ptr(key_len), int(pad_idx), int(causal),
+          B, H, Tq, Tk, float(scale), int(seed) & 0xFFFFFFFFFFFFFFFF, float(p), _lib.ptr(dq), dq.stride(0), _lib.ptr(dk),
+          dk.stride(0), _lib.ptr(dv), dv.stride(0))
+
+
+def tf_loss_fwd(logits, C, targets, pad_idx):
+    """logits fp32 [B*T, ld>=C], targets int64 [B,T] -> (row_lse [B*T], acc [2] = (sum of NLL, counted rows))."""
+    _chk(logits, F32, "logits")
+    assert targets.dtype == I64 and targets.is_contiguous()
+    B, T = targets.shape
+    row_lse = torch.empty(B * T, dtype=F32, device=logits.device)
+    acc = torch.empty(2, dtype=F32, device=logits.device)
+    _call("ccd_tf_loss_fwd", _lib.ptr(logits), logits.stride(0), int(C), _lib.ptr(targets), B * T, T, int(pad_idx),
+          _lib.ptr(row_lse), _lib.ptr(acc))
+    return row_lse, acc
+
+
+def tf_loss_bwd(logits, C, targets, pad_idx, row_lse, acc, upstream, ldd):
+    B, T = targets.shape
+    d = torch.empty((B * T, ldd), dtype=BF16, device=logits.device)
+    _call("ccd_tf_loss_bwd", _lib.ptr(logits), logits.stride(0), int(C), _lib.ptr(targets), B * T, T, int(pad_idx),
+          _lib.ptr(row_lse), _lib.ptr(acc), float(upstream), _lib.ptr(d), ldd)
+    return d
+
+
+def greedy_step(logits, C, probs, step, seq):
+    """probs fp32 [B, steps, C], seq int64 [B, seq_len]: writes probs[:, step] and seq[:, step+1]."""
+    _chk(logits, F32, "logits"); _chk(probs, F32, "probs")
+    assert seq.dtype == I64 and seq.is_contiguous() and probs.is_contiguous()
+    B = seq.shape[0]
+    _call("ccd_greedy_step", _lib.ptr(logits), logits.stride(0), int(C), B, _lib.ptr(probs), probs.shape[1], int(step),
+          _lib.ptr(seq), seq.shape[1])

@@ -221,6 +221,47 @@ int ccd_cls_grad_cols(const float* dlogits, ccd_bf16* g, int images, int H, int 
 int ccd_permute4(const float* src, const long* src_strides, const long* dst_strides, const int* dims, void* dst,
                  int accumulate, void* stream);
 
+/* ---- finetune path: DINO_Finetune = ViT encoder + Mlp + NRTR decoder + TFLoss ---------------
+ * Reference: Dino/model/dino_vision.py:134-246, Dino/decoder/nrtr_decoder.py:92-170, transformer_module.py:8-97,
+ * transformer_layers.py:150-163, Dino/loss/ce_loss.py:94-128, train_finetune.py:262-289.  The Linear layers run on
+ * ccd_gemm_nt / ccd_gemm_tn, the LayerNorms on ccd_ln_fwd / ccd_ln_bwd. */
+/* nn.Dropout(p) without a mask tensor: element i is kept iff hash(seed, i) >= p * 2^32 and scaled by 1/(1-p); the
+ * backward pass calls the same function on the gradient with the same seed.  dst = (resid ? resid : 0) + drop(src).
+ * src / dst: fp32 or bf16 (flags), resid fp32 or NULL; n % 4 == 0; dst may alias src. */
+int ccd_dropout(const void* src, int src_bf16, const float* resid, void* dst, int dst_bf16, long n, uint64_t seed, float p,
+                void* stream);
+/* x[r,:] = dropout(trg_word_emb[tokens[r]] + position_table[r % T])   (nrtr_decoder.py:93-95); D % 4 == 0 */
+int ccd_dec_embed_fwd(const int64_t* tokens, const float* emb, const float* pos, float* x, int rows, int T, int D,
+                      int num_classes, uint64_t seed, float p, void* stream);
+/* demb[c,:] += sum_{r: tokens[r]==c} drop(dx[r,:]) for c != padding_idx (nn.Embedding(padding_idx)); D <= 1024 */
+int ccd_dec_embed_bwd(const int64_t* tokens, const float* dx, float* demb, int rows, int D, int num_classes, int padding_idx,
+                      uint64_t seed, float p, void* stream);
+/* MultiHeadAttention core (transformer_module.py:22-32, 84-92) for Tq <= 32 queries, Tk <= 256 keys, d_k = d_v = 64:
+ *   out[b*Tq+t, 64h:64h+64] = dropout(softmax(mask(scale * q.k^T))) . v      lse[b,h,t] saved for the backward pass
+ * q rows b*Tq+t (stride ldq), k / v rows b*Tk+j (strides ldk / ldv), head h at column 64h of each.  Mask: key j is
+ * hidden from query t if causal && j > t, if tokens && tokens[b,j] == pad_idx (get_pad_mask & get_subsequent_mask,
+ * nrtr_decoder.py:77-90), or if key_len && j >= key_len[b] (_get_mask :113-127).  probs (optional, fp32
+ * [B,H,Tq,Tk]) receives the attention weights after dropout - what MultiHeadAttention returns as `attn`. */
+int ccd_dec_attn_fwd(const ccd_bf16* q, long ldq, const ccd_bf16* k, long ldk, const ccd_bf16* v, long ldv, ccd_bf16* out,
+                     long ldo, float* lse, float* probs, const int64_t* tokens, const int* key_len, int pad_idx, int causal,
+                     int B, int H, int Tq, int Tk, float scale, uint64_t seed, float p, void* stream);
+int ccd_dec_attn_bwd(const ccd_bf16* q, long ldq, const ccd_bf16* k, long ldk, const ccd_bf16* v, long ldv,
+                     const ccd_bf16* out, const ccd_bf16* d_out, long ldo, const float* lse, const int64_t* tokens,
+                     const int* key_len, int pad_idx, int causal, int B, int H, int Tq, int Tk, float scale, uint64_t seed,
+                     float p, ccd_bf16* dq, long lddq, ccd_bf16* dk, long lddk, ccd_bf16* dv, long lddv, void* stream);
+/* TFLoss (ce_loss.py:94-128): rows r = (b,t) of logits [B*T, ldl] (C <= 128 classes) against targets[b,t+1]; rows with
+ * t == T-1 or target == pad_idx do not count.  fwd: acc[0] = sum of -log softmax[target], acc[1] = count (acc is
+ * cleared first), row_lse[r] saved; the loss is acc[0]/acc[1].  bwd: d_logits (bf16 [B*T, ldd], zero beyond C) =
+ * (softmax - onehot) * upstream / count. */
+int ccd_tf_loss_fwd(const float* logits, long ldl, int C, const int64_t* targets, int rows, int T, int pad_idx,
+                    float* row_lse, float* acc, void* stream);
+int ccd_tf_loss_bwd(const float* logits, long ldl, int C, const int64_t* targets, int rows, int T, int pad_idx,
+                    const float* row_lse, const float* acc, float upstream, ccd_bf16* d_logits, long ldd, void* stream);
+/* One greedy decoding position (nrtr_decoder.py:160-168): probs[b,step,:] = softmax(logits[b,:C]),
+ * seq[b,step+1] = argmax (first maximum). */
+int ccd_greedy_step(const float* logits, long ldl, int C, int B, float* probs, int steps, int step, int64_t* seq,
+                    int seq_len, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

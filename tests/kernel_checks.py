@@ -606,3 +606,149 @@ def check_gemm_resid_ln(dev, M, N, K, seed=30):
     close(mean, mu, 1e-4, 1e-4, "resid_ln/mean")
     close(rstd, (var + 1e-6).rsqrt(), 1e-3, 1e-4, "resid_ln/rstd")
     close(y, F.layer_norm(want, (N,), gamma, beta, 1e-6), 1e-2, 2e-2, "resid_ln/y")
+
+
+# ------------------------------------------------------------------------------------------------ finetune path
+def drop_keep_ref(seed, n, p):
+    """Python mirror of decoder.h: drop_keep (splitmix64 finaliser on seed + index)."""
+    import numpy as np
+    if p <= 0:
+        return torch.ones(n, dtype=torch.bool)
+    thr = min(int(p * 4294967296.0), 4294967295)
+    with np.errstate(over="ignore"):
+        z = np.arange(n, dtype=np.uint64) + np.uint64(seed & 0xFFFFFFFFFFFFFFFF)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)
+        z ^= z >> np.uint64(31)
+    return torch.from_numpy(((z >> np.uint64(32)) >= np.uint64(thr)))
+
+
+def check_dropout(dev, seed=40):
+    g = torch.Generator().manual_seed(seed)
+    n, p, sd = 4096 * 6, 0.1, 0x1234_5678_9abc_def1
+    x = rnd((n,), g)
+    keep = drop_keep_ref(sd, n, p)
+    assert 0.88 < keep.float().mean().item() < 0.92
+    want = torch.where(keep, x / (1 - p), torch.zeros(()))
+    close(ops.dropout(x.to(dev), p, sd), want, 1e-6, 1e-6, "dropout/f32")
+    r = rnd((n,), g)
+    close(ops.dropout(x.to(dev), p, sd, resid=r.to(dev)), want + r, 1e-6, 1e-6, "dropout/resid")
+    close(ops.dropout(x.to(dev), p, sd, out_dtype=BF), want.to(BF), 1e-6, 1e-6, "dropout/f32->bf16")
+    xb = x.to(BF).to(dev)
+    ops.dropout(xb, p, sd, out=xb)                                    # in place
+    close(xb, torch.where(keep, x.to(BF).float() / (1 - p), torch.zeros(())).to(BF), 1e-6, 1e-6, "dropout/bf16")
+    close(ops.dropout(x.to(dev), 0.0, sd), x, 0, 0, "dropout/p0")
+    assert (drop_keep_ref(sd + 1, n, p) != keep).any()
+
+
+def check_dec_embed(dev, B=5, T=25, D=128, C=93, seed=41):
+    g = torch.Generator().manual_seed(seed)
+    tok = torch.randint(0, C - 1, (B, T), generator=g)
+    tok[:, 0] = 91
+    tok[:, T // 2:] = 92                                              # padding rows
+    emb, pos = rnd((C, D), g), rnd((40, D), g)
+    want = emb[tok] + pos[:T]
+    close(ops.dec_embed_fwd(tok.to(dev), emb.to(dev), pos.to(dev)).view(B, T, D), want, 1e-6, 1e-6, "embed/fwd")
+    p, sd = 0.25, 77
+    keep = drop_keep_ref(sd, B * T * D, p).view(B, T, D)
+    close(ops.dec_embed_fwd(tok.to(dev), emb.to(dev), pos.to(dev), p, sd).view(B, T, D),
+          torch.where(keep, want / (1 - p), torch.zeros(())), 1e-6, 1e-6, "embed/fwd-drop")
+    dx = rnd((B * T, D), g)
+    demb = torch.full((C, D), 0.5).to(dev)
+    ops.dec_embed_bwd(tok.to(dev), dx.to(dev), demb, 92, p, sd)
+    ref = torch.zeros(C, D)
+    ref.index_add_(0, tok.view(-1), torch.where(keep.view(B * T, D), dx / (1 - p), torch.zeros(())))
+    ref[92] = 0
+    close(demb, ref + 0.5, 1e-5, 1e-5, "embed/bwd")
+
+
+def _dec_attn_ref(q, k, v, mask, scale, keep=None, keep_scale=1.0):
+    """q [B,H,Tq,64], k/v [B,H,Tk,64] fp32; mask [B,1,Tq,Tk] bool or None -> (out, probs after dropout)."""
+    s = (q * scale) @ k.transpose(-1, -2)
+    if mask is not None:
+        s = s.masked_fill(~mask, float("-inf"))
+    pr = torch.softmax(s, -1)
+    if keep is not None:
+        pr = pr * keep * keep_scale
+    return pr @ v, pr
+
+
+def check_dec_attn(dev, B=3, H=2, Tq=25, Tk=25, self_attn=True, p=0.0, seed=42):
+    g = torch.Generator().manual_seed(seed)
+    E = 64 * H
+    ld = 3 * E + 8                                                    # exercises the row strides
+    qkv = rnd((B * max(Tq, Tk), ld), g).to(BF)
+    if self_attn:
+        qv, kv_, vv = qkv[:B * Tq, 0:E], qkv[:B * Tk, E:2 * E], qkv[:B * Tk, 2 * E:3 * E]
+    else:
+        qv = rnd((B * Tq, E), g).to(BF)
+        kvb = rnd((B * Tk, 2 * E + 16), g).to(BF)
+        kv_, vv = kvb[:, 0:E], kvb[:, E:2 * E]
+    tok = mask = None
+    if self_attn:
+        tok = torch.randint(0, 90, (B, Tk), generator=g)
+        for b in range(B):
+            tok[b, 3 + 5 * b:] = 92
+        pad = (tok != 92)[:, None, None, :]
+        causal = torch.tril(torch.ones(Tq, Tk)).bool()[None, None]
+        mask = pad & causal
+    sd = 991
+    keep = drop_keep_ref(sd, B * H * Tq * Tk, p).view(B, H, Tq, Tk).float() if p > 0 else None
+    sp = lambda t_, T: t_.float().reshape(B, T, H, 64).transpose(1, 2).clone().requires_grad_(True)
+    qf, kf, vf = sp(qv, Tq), sp(kv_, Tk), sp(vv, Tk)
+    out_ref, pr_ref = _dec_attn_ref(qf, kf, vf, mask, 0.125, keep, 1.0 / (1.0 - p))
+    kw = dict(tokens=None if tok is None else tok.to(dev), pad_idx=92, causal=self_attn, p=p, seed=sd)
+    qd, kd, vd = (qkv.to(dev)[:B * Tq, 0:E], qkv.to(dev)[:B * Tk, E:2 * E], qkv.to(dev)[:B * Tk, 2 * E:3 * E]) if self_attn \
+        else (qv.to(dev), kvb.to(dev)[:, 0:E], kvb.to(dev)[:, E:2 * E])
+    out, lse, probs = ops.dec_attn_fwd(qd, kd, vd, B, H, Tq, Tk, 0.125, want_probs=True, **kw)
+    close(probs, pr_ref, 2e-3, 1e-5, "dec_attn/probs")
+    close(out.view(B, Tq, H, 64).transpose(1, 2), out_ref, 1e-2, 1e-2, "dec_attn/out")
+    d_out = rnd((B * Tq, E), g).to(BF)
+    out_ref.backward(d_out.float().view(B, Tq, H, 64).transpose(1, 2))
+    dq = torch.zeros((B * Tq, E + 8), dtype=BF).to(dev)
+    dkv = torch.zeros((B * Tk, 2 * E + 24), dtype=BF).to(dev)
+    ops.dec_attn_bwd(qd, kd, vd, out, d_out.to(dev), lse, dq[:, :E], dkv[:, :E], dkv[:, E:2 * E], B, H, Tq, Tk, 0.125, **kw)
+    un = lambda t_, T: t_.transpose(1, 2).reshape(B * T, E)
+    tol = lambda w: 2e-2 * float(w.abs().max()) + 1e-6
+    close(dq[:, :E], un(qf.grad, Tq), 2e-2, tol(qf.grad), "dec_attn/dq")
+    close(dkv[:, :E], un(kf.grad, Tk), 2e-2, tol(kf.grad), "dec_attn/dk")
+    close(dkv[:, E:2 * E], un(vf.grad, Tk), 2e-2, tol(vf.grad), "dec_attn/dv")
+    assert (dq[:, E:] == 0).all() and (dkv[:, 2 * E:] == 0).all()
+
+
+def check_tf_loss(dev, B=6, T=25, C=92, seed=43):
+    g = torch.Generator().manual_seed(seed)
+    ld = 128
+    logits = rnd((B * T, ld), g, 2.0)
+    tgt = torch.randint(0, C, (B, T), generator=g)
+    tgt[:, 0] = 91
+    for b in range(B):
+        tgt[b, 4 + 3 * b:] = 92
+    lg = logits[:, :C].clone().view(B, T, C).requires_grad_(True)
+    ref = F.cross_entropy(lg[:, :-1].reshape(-1, C), tgt[:, 1:].reshape(-1), ignore_index=92)
+    ref.backward()
+    row_lse, acc = ops.tf_loss_fwd(logits.to(dev), C, tgt.to(dev), 92)
+    close(acc[0] / acc[1], ref, 1e-5, 1e-6, "tf_loss/fwd")
+    assert float(acc[1]) == float((tgt[:, 1:] != 92).sum())
+    d = ops.tf_loss_bwd(logits.to(dev), C, tgt.to(dev), 92, row_lse, acc, 0.5, 128)
+    close(d[:, :C].view(B, T, C), 0.5 * lg.grad, 1e-2, 1e-5, "tf_loss/bwd")
+    assert (d[:, C:] == 0).all()
+    # greedy step
+    probs = torch.zeros(B, T, C).to(dev)
+    seq = torch.full((B, T + 1), 92, dtype=torch.int64).to(dev)
+    lg2 = logits[:B].clone()
+    lg2[1, 7] = lg2[1, 70] = 50.0                                      # tie: first index wins
+    ops.greedy_step(lg2.to(dev), C, probs, 3, seq)
+    close(probs[:, 3], torch.softmax(lg2[:, :C], -1), 1e-5, 1e-7, "greedy/probs")
+    assert torch.equal(seq[:, 4].cpu(), lg2[:, :C].argmax(-1)) and int(seq[1, 4]) == 7
+    assert (seq[:, :4] == 92).all() and (seq[:, 5:] == 92).all()
+
+
+def check_decoder_pieces(dev):
+    check_dropout(dev)
+    check_dec_embed(dev)
+    check_dec_attn(dev, self_attn=True)
+    check_dec_attn(dev, B=2, H=2, Tq=26, Tk=26, self_attn=True, p=0.1)
+    check_dec_attn(dev, B=2, H=3, Tq=25, Tk=256, self_attn=False)
+    check_dec_attn(dev, B=1, H=2, Tq=25, Tk=256, self_attn=False, p=0.1)
+    check_tf_loss(dev)

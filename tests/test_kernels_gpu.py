@@ -97,6 +97,13 @@ def test_conv_pieces(hip):
     kc.check_conv_pieces(hip.device)
 
 
+def test_decoder_pieces(hip):
+    """finetune path: dropout, target embedding, short-query attention (masks, dropout), TFLoss, greedy step."""
+    kc.check_decoder_pieces(hip.device)
+    kc.check_dec_attn(hip.device, B=64, H=8, Tq=25, Tk=256, self_attn=False, p=0.1)
+    kc.check_dec_attn(hip.device, B=64, H=8, Tq=25, Tk=25, self_attn=True, p=0.1)
+
+
 @pytest.mark.parametrize("images,E", [(2, 192), (8, 384)])
 def test_seghead(hip, images, E):
     kc.check_seghead(hip.device, images=images, E=E)

@@ -135,3 +135,7 @@ def test_gemm_row384_sim(sim, monkeypatch):
 def test_gemm_resid_ln_sim(sim):
     kc.check_gemm_resid_ln(sim.device, M=300, N=384, K=128)
     kc.check_gemm_resid_ln(sim.device, M=140, N=192, K=64)
+
+
+def test_decoder_pieces_sim(sim):
+    kc.check_decoder_pieces(sim.device)
