@@ -79,7 +79,7 @@ SIGNATURES = {
     "ccd_dec_attn_fwd": [P, L, P, L, P, L, P, L, P, P, P, P, I, I, I, I, I, I, F, U64, F, P],
     "ccd_dec_attn_bwd": [P, L, P, L, P, L, P, P, L, P, P, P, I, I, I, I, I, I, F, U64, F, P, L, P, L, P, L, P],
     "ccd_tf_loss_fwd": [P, L, I, P, I, I, I, P, P, P],
-    "ccd_tf_loss_bwd": [P, L, I, P, I, I, I, P, P, F, P, L, P],
+    "ccd_tf_loss_bwd": [P, L, I, P, I, I, I, P, P, P, P, L, P],
     "ccd_greedy_step": [P, L, I, I, P, I, I, P, I, P],
 }
 _RESTYPES = {"ccd_build_info": C.c_char_p}

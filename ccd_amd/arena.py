@@ -84,6 +84,22 @@ class ParamArena:
         s = self.segments[name]
         return self.mirror_t[s.t_offset:s.t_offset + s.numel].view(s.shape[1], s.shape[0])
 
+    def span(self, first, rows, which="wb"):
+        """[rows, cols] view over CONSECUTIVE 2-D tensors of equal width starting at `first` (e.g. linear_q/k/v stacked
+        into one [3*512, 512] operand).  which: 'w' fp32 weights, 'g' fp32 gradients, 'wb' bf16 mirror."""
+        names = list(self.segments)
+        i = names.index(first)
+        cols = self.segments[first].shape[1]
+        off, have = self.segments[first].offset, 0
+        while have < rows:
+            s = self.segments[names[i]]
+            assert len(s.shape) == 2 and s.shape[1] == cols and s.offset == off + have * cols, (first, names[i])
+            have += s.shape[0]
+            i += 1
+        assert have == rows, (first, rows, have)
+        buf = {"w": self.flat, "g": self.grad, "wb": self.mirror}[which]
+        return buf[off:off + rows * cols].view(rows, cols)
+
     def range_of(self, prefix):
         """[lo, hi) element range covered by the parameters whose name starts with `prefix` (contiguous by construction)."""
         segs = [s for n, s in self.segments.items() if n.startswith(prefix)]

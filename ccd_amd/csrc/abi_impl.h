@@ -839,7 +839,7 @@ int ccd_tf_loss_fwd(const float* logits, long ldl, int C, const int64_t* targets
     return ccd_rt_last_error();
 }
 int ccd_tf_loss_bwd(const float* logits, long ldl, int C, const int64_t* targets, int rows, int T, int pad_idx,
-                    const float* row_lse, const float* acc, float upstream, ccd_bf16* d_logits, long ldd, void* stream) {
+                    const float* row_lse, const float* acc, const float* upstream, ccd_bf16* d_logits, long ldd, void* stream) {
     CCD_CHECK(logits && targets && row_lse && acc && d_logits && rows >= 0, CCD_EINVAL);
     CCD_CHECK(C > 0 && C <= 128 && ldl >= C && ldd >= C && T > 0 && rows % T == 0, CCD_ESHAPE);
     if (rows == 0) return CCD_OK;

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void tf_loss_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void tf_loss_bwd_kernel(const float* __restrict__ logits, long ldl, int C,
                                                           const long long* __restrict__ targets, int rows, int T,
                                                           int pad_idx, const float* __restrict__ row_lse,
-                                                          const float* __restrict__ acc, float upstream,
+                                                          const float* __restrict__ acc, const float* __restrict__ upstream,
                                                           bf16_t* __restrict__ d_logits, long ldd) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void tf_loss_bwd_kernel(const float* __restric
         if (tgt == pad_idx || tgt < 0 || tgt >= C) tgt = -1;
     }
     const float cnt = acc[1];
-    const float sc = (tgt >= 0 && cnt > 0.f) ? upstream / cnt : 0.f;
+    const float sc = (tgt >= 0 && cnt > 0.f) ? (upstream ? upstream[0] : 1.0f) / cnt : 0.f;
     const float lse = row_lse[r];
     for (int c = lane; c < ldd; c += 64) {
         float g = 0.f;

@@ -1,0 +1,139 @@
+"""NRTR transformer decoder behind the reference's module surface (Dino/decoder/nrtr_decoder.py:12-203,
+transformer_layers.py:78-164, transformer_module.py:35-147, base_decoder.py).
+
+The nn.Module tree only CARRIES the parameters - same names, shapes, construction order and init RNG stream as the
+reference (state dicts and seeds are interchangeable); the computation is ccd_amd.finetune_engine on the HIP kernels.
+There is no PyTorch-eager fallback.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import finetune_engine as fe
+from ..modules.vision_transformer import ArenaModule, _holder
+
+
+def sinusoid_table(n_position, d_hid):
+    """transformer_module.py:132-145 (same float32 arithmetic: the table is a persistent buffer of the checkpoints)."""
+    denominator = torch.Tensor([1.0 / np.power(10000, 2 * (j // 2) / d_hid) for j in range(d_hid)]).view(1, -1)
+    table = torch.arange(n_position).unsqueeze(-1).float() * denominator
+    table[:, 0::2] = torch.sin(table[:, 0::2])
+    table[:, 1::2] = torch.cos(table[:, 1::2])
+    return table.unsqueeze(0)
+
+
+def _mha(d_model, n_head, d_k, d_v):
+    # linear_q / linear_k / linear_v / fc, all bias-free (qkv_bias=False): transformer_module.py:64-70
+    return _holder(linear_q=nn.Linear(n_head * d_k, n_head * d_k, bias=False),
+                   linear_k=nn.Linear(n_head * d_k, n_head * d_k, bias=False),
+                   linear_v=nn.Linear(n_head * d_v, n_head * d_v, bias=False),
+                   fc=nn.Linear(n_head * d_v, d_model, bias=False))
+
+
+class _DropoutSeeds:
+    """Per-module stream of dropout seeds: host integers derived from torch's seeded generator at first use, so that
+    torch.manual_seed() makes a run reproducible without any device-side RNG state."""
+
+    _base = None
+    _calls = 0
+
+    def next_dropout_seed(self):
+        if self._base is None:
+            self._base = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self._calls += 1
+        return self._base + self._calls * 0x2545F4914F6CDD1D
+
+
+class Mlp(ArenaModule, _DropoutSeeds):
+    """fc1 -> GELU -> Dropout -> fc2 -> Dropout (Dino/model/dino_vision.py:117-132)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        if act_layer is not nn.GELU or in_features % 64 or hidden_features % 64 or out_features % 8:
+            raise NotImplementedError("HIP Mlp: GELU, feature counts that are multiples of 64")
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+        self.drop_p = float(drop)
+
+    def _transposed_names(self):
+        return ["fc1.weight", "fc2.weight"]
+
+    def forward(self, x):
+        self.ensure_arena()
+        self.drop_p = float(self.drop.p)
+        return fe.MlpFn.apply(x.to(torch.bfloat16), self)
+
+
+class NRTRDecoder(ArenaModule, _DropoutSeeds):
+    def __init__(self, n_layers=6, d_embedding=512, n_head=8, d_k=64, d_v=64, d_model=512, d_inner=256, n_position=200,
+                 dropout=0.1, num_classes=93, max_seq_len=40, start_idx=1, padding_idx=92, init_cfg=None, **kwargs):
+        super().__init__()
+        if kwargs or d_embedding != d_model or d_v != d_k:
+            raise NotImplementedError("HIP NRTRDecoder covers the shipped configuration: pre-norm layers, "
+                                      "d_embedding == d_model, d_v == d_k, qkv_bias=False")
+        self.padding_idx, self.start_idx, self.max_seq_len = padding_idx, start_idx, max_seq_len
+        # construction order == reference order (nrtr_decoder.py:60-75, transformer_layers.py:112-124)
+        self.trg_word_emb = nn.Embedding(num_classes, d_embedding, padding_idx=padding_idx)
+        self.position_enc = nn.Module()
+        self.position_enc.register_buffer("position_table", sinusoid_table(n_position, d_embedding))
+        self.dropout = nn.Dropout(p=dropout)
+        self.layer_stack = nn.ModuleList([
+            _holder(norm1=nn.LayerNorm(d_model), norm2=nn.LayerNorm(d_model), norm3=nn.LayerNorm(d_model),
+                    self_attn=_mha(d_model, n_head, d_k, d_v), enc_attn=_mha(d_model, n_head, d_k, d_v),
+                    mlp=_holder(w_1=nn.Linear(d_model, d_inner), w_2=nn.Linear(d_inner, d_model)))
+            for _ in range(n_layers)])
+        self.layer_norm = nn.LayerNorm(d_model, eps=1e-6)
+        self.classifier = nn.Linear(d_model, num_classes - 1)          # <PAD> is never predicted
+        self.dec_spec = fe.DecoderSpec(embed_dim=d_model, n_layers=n_layers, d_model=d_model, n_head=n_head, d_k=d_k,
+                                       d_inner=d_inner, num_classes=num_classes, max_seq_len=max_seq_len,
+                                       start_idx=start_idx, padding_idx=padding_idx, dropout=dropout)
+        self.packed = None
+
+    def _transposed_names(self):
+        names = []
+        for i in range(self.dec_spec.L):
+            b = f"layer_stack.{i}."
+            names += [b + "self_attn.fc.weight", b + "enc_attn.linear_q.weight", b + "enc_attn.fc.weight",
+                      b + "mlp.w_1.weight", b + "mlp.w_2.weight"]
+        return names
+
+    @property
+    def pos_table(self):
+        return self.position_enc.position_table[0]
+
+    def _ready(self):
+        self.ensure_arena()
+        self.dec_spec.p = float(self.dropout.p)
+        if self.packed is None or self.packed.cls.device != self.arena.device:
+            self.packed = fe.PackedOperands(self.dec_spec, self.arena.device)
+
+    # ---------------------------------------------------------------------------------- reference surface
+    def forward_train(self, feat, out_enc, targets_dict, img_metas=None):
+        """out_enc [N,256,D]; targets_dict['padded_targets'] int64 [N,T] -> (logits [N,T,C-1] fp32, attn [N,H,T,256])."""
+        if img_metas is not None:
+            raise NotImplementedError("valid_ratio masks (img_metas) are not used by DINO_Finetune")
+        self._ready()
+        targets = targets_dict["padded_targets"].to(out_enc.device).long().contiguous()
+        return fe.DecoderFn.apply(out_enc.to(torch.bfloat16), self, targets)
+
+    def forward_test(self, feat, out_enc, img_metas=None):
+        self._ready()
+        return fe.greedy_decode(self, out_enc.to(torch.bfloat16))
+
+    def forward_test_speed(self, feat, out_enc, img_metas=None):
+        self._ready()
+        return fe.greedy_decode(self, out_enc.to(torch.bfloat16), stop_on_eos_of_first=True)
+
+    def forward(self, feat, out_enc, targets_dict=None, img_metas=None, train_mode=True, test_speed=False):
+        self.train_mode = train_mode
+        if train_mode:
+            return self.forward_train(feat, out_enc, targets_dict, img_metas)
+        if test_speed:
+            return self.forward_test_speed(feat, out_enc, img_metas)
+        return self.forward_test(feat, out_enc, img_metas)

@@ -1,0 +1,352 @@
+"""Forward / backward drivers of the FINETUNE path on the HIP kernels: the Mlp "encoder" on top
+of the ViT tokens (MlpFn), the NRTR transformer decoder (DecoderFn) and TFLoss (TFLossFn) - autograd.Functions whose
+backward passes write parameter gradients straight into the arena; the token gradient continues into
+ccd_amd.engine.BackboneFn.
+
+Reference call sites: Dino/model/dino_vision.py:206-231 (forward_train), :233-262 (forward_test),
+Dino/decoder/nrtr_decoder.py:92-170, Dino/decoder/transformer_layers.py:150-163 (pre-norm TFDecoderLayer),
+Dino/decoder/transformer_module.py:22-32,73-97,114-120, Dino/loss/ce_loss.py:116-127.
+
+Layout: R = B*256 encoder rows, Rt = B*T decoder rows (T = 25 when training, 26 when decoding); fp32 residual stream
+of the decoder, bf16 GEMM / attention operands.  The encoder-side keys and values of ALL decoder layers live in one
+[R, L*1024] bf16 buffer: their data gradient is a single K = L*1024 product against the packed W_kv^T operand.
+Dropout (p = 0.1 everywhere in the reference) is a counter-based mask: sites only remember their seed.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+_GOLD = 0x9E3779B97F4A7C15
+_MASK = 0xFFFFFFFFFFFFFFFF
+CLS_PAD = 128                       # classifier columns padded to a GEMM-friendly width (92 live classes)
+
+
+class DecoderSpec:
+    def __init__(self, embed_dim, n_layers=6, d_model=512, n_head=8, d_k=64, d_inner=256, enc_hidden=512,
+                 num_classes=93, max_seq_len=25, start_idx=91, padding_idx=92, dropout=0.1):
+        if d_k != 64 or d_model != n_head * d_k or d_model % 64 or d_inner % 64 or enc_hidden % 64 or \
+                num_classes - 1 > CLS_PAD or max_seq_len + 1 > 32:
+            raise NotImplementedError("HIP decoder kernels cover d_k = d_v = 64, d_model = n_head * 64, <= 128 classes, "
+                                      "sequences of <= 32 positions")
+        self.E, self.L, self.D, self.H, self.d_inner, self.enc_hidden = embed_dim, n_layers, d_model, n_head, d_inner, enc_hidden
+        self.num_classes, self.max_seq_len, self.start_idx, self.padding_idx = num_classes, max_seq_len, start_idx, padding_idx
+        self.C = num_classes - 1                            # the classifier never predicts <PAD> (nrtr_decoder.py:73-74)
+        self.p = dropout
+
+
+class _Seeds:
+    """Dropout sites draw consecutive seeds from one per-step base (host integers only)."""
+
+    def __init__(self, base):
+        self.base, self.k = base & _MASK, 0
+
+    def next(self):
+        self.k += 1
+        return (self.base + self.k * _GOLD) & _MASK
+
+
+class PackedOperands:
+    """bf16 GEMM operands that are re-laid-out copies of arena weights: the zero-padded classifier (and its transpose),
+    the stacked transposes [512, 3*512] of every layer's self-attention q/k/v weights and [512, L*1024] of all
+    encoder-decoder k/v weights.  Refreshed from the fp32 master weights once per forward pass."""
+
+    def __init__(self, spec: DecoderSpec, device):
+        D, L = spec.D, spec.L
+        self.cls = torch.zeros((CLS_PAD, D), dtype=BF16, device=device)
+        self.cls_t = torch.zeros((D, CLS_PAD), dtype=BF16, device=device)
+        self.cls_bias = torch.zeros(CLS_PAD, dtype=F32, device=device)
+        self.qkv_t = torch.zeros((L, D, 3 * D), dtype=BF16, device=device)
+        self.kv_t = torch.zeros((D, L * 2 * D), dtype=BF16, device=device)
+
+    def refresh(self, arena, pre, spec: DecoderSpec):
+        D, L, C = spec.D, spec.L, spec.C
+        w = arena.w(pre + "classifier.weight")
+        ops.permute4(w, (D, 1), (C, D), self.cls, dst_strides=(D, 1))
+        ops.permute4(w, (1, D), (D, C), self.cls_t, dst_strides=(CLS_PAD, 1))
+        self.cls_bias[:C].copy_(arena.w(pre + "classifier.bias"))
+        for l in range(L):
+            b = f"{pre}layer_stack.{l}."
+            ops.permute4(arena.span(b + "self_attn.linear_q.weight", 3 * D, "w"), (1, D), (D, 3 * D), self.qkv_t[l],
+                         dst_strides=(3 * D, 1))
+            ops.permute4(arena.span(b + "enc_attn.linear_k.weight", 2 * D, "w"), (1, D), (D, 2 * D),
+                         self.kv_t[:, l * 2 * D:], dst_strides=(L * 2 * D, 1))
+
+
+def _resid(x, a, w, bias, p, seed):
+    """x + Dropout(a @ w^T + bias)  (fp32 residual stream)."""
+    if p == 0.0:
+        return ops.gemm_nt(a, w, epilogue=ops.EPI_RESID, bias=bias, resid=x, rows_per_sample=1)
+    t = ops.gemm_nt(a, w, epilogue=ops.EPI_F32, bias=bias)
+    return ops.dropout(t, p, seed, resid=x, out=t)
+
+
+def mlp_forward(arena, pre, x, p, seeds: _Seeds, save):
+    """Mlp (dino_vision.py:117-132): x bf16 [R,E] -> Dropout(fc2(Dropout(gelu(fc1(x))))) bf16 [R,D]."""
+    u, h = ops.gemm_nt(x, arena.wb(pre + "fc1.weight"), epilogue=ops.EPI_GELU, bias=arena.w(pre + "fc1.bias"), store_u=save)
+    s_h, s_out = seeds.next(), seeds.next()
+    if p:
+        ops.dropout(h, p, s_h, out=h)
+    out = ops.gemm_nt(h, arena.wb(pre + "fc2.weight"), bias=arena.w(pre + "fc2.bias"))
+    if p:
+        ops.dropout(out, p, s_out, out=out)
+    return out, (u, h, s_h, s_out)
+
+
+def mlp_backward(arena, pre, x, d_out, saved, p):
+    """d_out bf16 [R,D] -> d_x bf16 [R,E]; gradients of fc1 / fc2 into the arena."""
+    u, h, s_h, s_out = saved
+    if p:
+        d_out = ops.dropout(d_out, p, s_out)
+    ops.colsum_bf16(d_out, arena.g(pre + "fc2.bias"))
+    ops.gemm_tn(d_out, h, arena.g(pre + "fc2.weight"))
+    if p:
+        du = ops.gemm_nt(d_out, arena.wbt(pre + "fc2.weight"), epilogue=ops.EPI_DGELU, aux=u)
+        ops.dropout(du, p, s_h, out=du)
+        ops.colsum_bf16(du, arena.g(pre + "fc1.bias"))
+    else:
+        du = ops.gemm_nt(d_out, arena.wbt(pre + "fc2.weight"), epilogue=ops.EPI_DGELU, aux=u,
+                         colsum=arena.g(pre + "fc1.bias"))
+    ops.gemm_tn(du, x, arena.g(pre + "fc1.weight"))
+    return ops.gemm_nt(du, arena.wbt(pre + "fc1.weight"))
+
+
+def encoder_kv(arena, pre, spec: DecoderSpec, out_enc):
+    """Keys and values of every decoder layer's encoder-decoder attention: out_enc bf16 [R,D] -> [R, L*2D]
+    (layer l: columns l*2D .. l*2D+D keys, the next D values; transformer_module.py:79-80)."""
+    D, L = spec.D, spec.L
+    kv = torch.empty((out_enc.shape[0], L * 2 * D), dtype=BF16, device=out_enc.device)
+    for l in range(L):
+        wkv = arena.span(f"{pre}layer_stack.{l}.enc_attn.linear_k.weight", 2 * D, "wb")
+        ops.gemm_nt(out_enc, wkv, out=kv[:, l * 2 * D:(l + 1) * 2 * D])
+    return kv
+
+
+def decoder_states(arena, pre, spec: DecoderSpec, pos, seq, kv, p, seeds: _Seeds, save, want_attn):
+    """seq int64 [B,T], kv bf16 [B*256, L*2D], pos fp32 [n_position, D] -> (y bf16 [B*T, D] = layer_norm(decoder
+    output), attn, saved).  `pre` is the decoder's parameter prefix."""
+    D, H, L = spec.D, spec.H, spec.L
+    B, T = seq.shape
+    scale = 64 ** -0.5
+    s_emb = seeds.next()
+    x = ops.dec_embed_fwd(seq, arena.w(pre + "trg_word_emb.weight"), pos, p, s_emb)
+    layers, attn = [], None
+    for l in range(L):
+        b = f"{pre}layer_stack.{l}."
+        c = {"x0": x}
+        c["y1"], c["m1"], c["r1"] = ops.ln_fwd(x, arena.w(b + "norm1.weight"), arena.w(b + "norm1.bias"), 1e-5)
+        c["qkv"] = ops.gemm_nt(c["y1"], arena.span(b + "self_attn.linear_q.weight", 3 * D, "wb"))
+        c["s_sa"], c["s_sp"] = seeds.next(), seeds.next()
+        qkv = c["qkv"]
+        c["att1"], c["lse1"], _ = ops.dec_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, T, T, scale, tokens=seq,
+                                                   pad_idx=spec.padding_idx, causal=True, p=p, seed=c["s_sa"])
+        x = _resid(x, c["att1"], arena.wb(b + "self_attn.fc.weight"), None, p, c["s_sp"])
+        c["x1"] = x
+        c["y2"], c["m2"], c["r2"] = ops.ln_fwd(x, arena.w(b + "norm2.weight"), arena.w(b + "norm2.bias"), 1e-5)
+        c["q2"] = ops.gemm_nt(c["y2"], arena.wb(b + "enc_attn.linear_q.weight"))
+        c["s_ea"], c["s_ep"] = seeds.next(), seeds.next()
+        k2, v2 = kv[:, l * 2 * D:l * 2 * D + D], kv[:, l * 2 * D + D:(l + 1) * 2 * D]
+        c["att2"], c["lse2"], pr = ops.dec_attn_fwd(c["q2"], k2, v2, B, H, T, 256, scale, p=p, seed=c["s_ea"],
+                                                    want_probs=want_attn and l == L - 1)
+        attn = pr if pr is not None else attn
+        x = _resid(x, c["att2"], arena.wb(b + "enc_attn.fc.weight"), None, p, c["s_ep"])
+        c["x2"] = x
+        c["y3"], c["m3"], c["r3"] = ops.ln_fwd(x, arena.w(b + "norm3.weight"), arena.w(b + "norm3.bias"), 1e-5)
+        c["u3"], c["g3"] = ops.gemm_nt(c["y3"], arena.wb(b + "mlp.w_1.weight"), epilogue=ops.EPI_GELU,
+                                       bias=arena.w(b + "mlp.w_1.bias"), store_u=save)
+        c["s_ff"] = seeds.next()
+        x = _resid(x, c["g3"], arena.wb(b + "mlp.w_2.weight"), arena.w(b + "mlp.w_2.bias"), p, c["s_ff"])
+        layers.append(c if save else None)
+    y, m, r = ops.ln_fwd(x, arena.w(pre + "layer_norm.weight"), arena.w(pre + "layer_norm.bias"), 1e-6)
+    return y, attn, (layers, (x, m, r), s_emb) if save else None
+
+
+def decoder_backward(arena, pre, spec: DecoderSpec, packed: PackedOperands, seq, kv, saved, dy, p):
+    """dy bf16 [B*T, D] = gradient of the final layer_norm output -> d_kv bf16 [R, L*2D]; parameter gradients into the
+    arena (everything but the classifier and enc_attn.linear_{k,v}, which the caller owns)."""
+    D, H, L = spec.D, spec.H, spec.L
+    B, T = seq.shape
+    Rt = B * T
+    scale = 64 ** -0.5
+    layers, (x_last, m, r), s_emb = saved
+    dev = dy.device
+    g = torch.empty((Rt, D), dtype=F32, device=dev)
+    ops.ln_bwd(dy, x_last, m, r, arena.w(pre + "layer_norm.weight"), g, arena.g(pre + "layer_norm.weight"),
+               arena.g(pre + "layer_norm.bias"), accumulate=False)
+    d_kv = torch.empty_like(kv)
+    for l in reversed(range(L)):
+        b = f"{pre}layer_stack.{l}."
+        c = layers[l]
+        # ---- feed-forward branch: x3 = x2 + Dropout(w_2(gelu(w_1(norm3(x2)))))
+        gb = ops.dropout(g, p, c["s_ff"], out_dtype=BF16)
+        ops.colsum_bf16(gb, arena.g(b + "mlp.w_2.bias"))
+        ops.gemm_tn(gb, c["g3"], arena.g(b + "mlp.w_2.weight"))
+        du = ops.gemm_nt(gb, arena.wbt(b + "mlp.w_2.weight"), epilogue=ops.EPI_DGELU, aux=c["u3"],
+                         colsum=arena.g(b + "mlp.w_1.bias"))
+        ops.gemm_tn(du, c["y3"], arena.g(b + "mlp.w_1.weight"))
+        dy3 = ops.gemm_nt(du, arena.wbt(b + "mlp.w_1.weight"))
+        ops.ln_bwd(dy3, c["x2"], c["m3"], c["r3"], arena.w(b + "norm3.weight"), g, arena.g(b + "norm3.weight"),
+                   arena.g(b + "norm3.bias"), accumulate=True)
+        # ---- encoder-decoder attention: x2 = x1 + Dropout(fc(attn(linear_q(norm2(x1)), k, v)))
+        gb = ops.dropout(g, p, c["s_ep"], out_dtype=BF16)
+        ops.gemm_tn(gb, c["att2"], arena.g(b + "enc_attn.fc.weight"))
+        d_att = ops.gemm_nt(gb, arena.wbt(b + "enc_attn.fc.weight"))
+        dq2 = torch.empty((Rt, D), dtype=BF16, device=dev)
+        k2, v2 = kv[:, l * 2 * D:l * 2 * D + D], kv[:, l * 2 * D + D:(l + 1) * 2 * D]
+        ops.dec_attn_bwd(c["q2"], k2, v2, c["att2"], d_att, c["lse2"], dq2, d_kv[:, l * 2 * D:l * 2 * D + D],
+                         d_kv[:, l * 2 * D + D:(l + 1) * 2 * D], B, H, T, 256, scale, p=p, seed=c["s_ea"])
+        ops.gemm_tn(dq2, c["y2"], arena.g(b + "enc_attn.linear_q.weight"))
+        dy2 = ops.gemm_nt(dq2, arena.wbt(b + "enc_attn.linear_q.weight"))
+        ops.ln_bwd(dy2, c["x1"], c["m2"], c["r2"], arena.w(b + "norm2.weight"), g, arena.g(b + "norm2.weight"),
+                   arena.g(b + "norm2.bias"), accumulate=True)
+        # ---- masked self-attention: x1 = x0 + Dropout(fc(attn(q, k, v = linear_{q,k,v}(norm1(x0)))))
+        gb = ops.dropout(g, p, c["s_sp"], out_dtype=BF16)
+        ops.gemm_tn(gb, c["att1"], arena.g(b + "self_attn.fc.weight"))
+        d_att = ops.gemm_nt(gb, arena.wbt(b + "self_attn.fc.weight"))
+        qkv = c["qkv"]
+        d_qkv = torch.empty_like(qkv)
+        ops.dec_attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], c["att1"], d_att, c["lse1"], d_qkv[:, :D],
+                         d_qkv[:, D:2 * D], d_qkv[:, 2 * D:], B, H, T, T, scale, tokens=seq, pad_idx=spec.padding_idx,
+                         causal=True, p=p, seed=c["s_sa"])
+        ops.gemm_tn(d_qkv, c["y1"], arena.span(b + "self_attn.linear_q.weight", 3 * D, "g"))
+        dy1 = ops.gemm_nt(d_qkv, packed.qkv_t[l])
+        ops.ln_bwd(dy1, c["x0"], c["m1"], c["r1"], arena.w(b + "norm1.weight"), g, arena.g(b + "norm1.weight"),
+                   arena.g(b + "norm1.bias"), accumulate=True)
+        layers[l] = None
+    ops.dec_embed_bwd(seq, g, arena.g(pre + "trg_word_emb.weight"), spec.padding_idx, p, s_emb)
+    return d_kv
+
+
+class MlpFn(torch.autograd.Function):
+    """out = MlpFn.apply(x bf16 [..., E], module)  ->  bf16 [..., D]   (module: ccd_amd Mlp holder)."""
+
+    @staticmethod
+    def forward(ctx, x, module):
+        save = ctx.needs_input_grad[0]
+        p = module.drop_p if module.training else 0.0
+        x2 = x.reshape(-1, x.shape[-1])
+        out, saved = mlp_forward(module.arena, module.arena_prefix, x2, p, _Seeds(module.next_dropout_seed()), save)
+        if save:
+            ctx.module, ctx.p, ctx.saved, ctx.shape = module, p, (x2, saved), x.shape
+        return out.view(*x.shape[:-1], out.shape[-1])
+
+    @staticmethod
+    def backward(ctx, d_out):
+        m = ctx.module
+        x2, saved = ctx.saved
+        ctx.saved = None
+        d = d_out.reshape(-1, d_out.shape[-1]).contiguous().to(BF16)
+        dx = mlp_backward(m.arena, m.arena_prefix, x2, d, saved, ctx.p)
+        if m.grad_ready_hook is not None:
+            m.grad_ready_hook(m.arena_prefix)
+        return dx.view(ctx.shape), None
+
+
+# bf16, column-padded gradient of the decoder logits parked by TFLossFn for DecoderFn (autograd would force the fp32,
+# unpadded layout of the logits view and two conversion passes); keyed by the data pointer of the padded logits
+_PARKED_LOGIT_GRADS = {}
+
+
+class DecoderFn(torch.autograd.Function):
+    """logits, attn = DecoderFn.apply(out_enc bf16 [B,256,D], module, targets int64 [B,T])
+    logits: fp32 [B,T,C] view of a [B*T, 128] buffer;  attn: last layer's encoder-decoder attention [B,H,T,256]."""
+
+    @staticmethod
+    def forward(ctx, out_enc, module, targets):
+        arena, pre, spec, packed = module.arena, module.arena_prefix, module.dec_spec, module.packed
+        save = ctx.needs_input_grad[0]
+        p = spec.p if module.training else 0.0
+        B, T = targets.shape
+        enc2 = out_enc.reshape(-1, spec.D)
+        packed.refresh(arena, pre, spec)
+        kv = encoder_kv(arena, pre, spec, enc2)
+        y, attn, saved = decoder_states(arena, pre, spec, module.pos_table, targets, kv, p,
+                                        _Seeds(module.next_dropout_seed()), save, want_attn=True)
+        logits = ops.gemm_nt(y, packed.cls, epilogue=ops.EPI_F32, bias=packed.cls_bias)          # [B*T, 128] fp32
+        out = logits.view(B, T, CLS_PAD)[:, :, :spec.C]
+        if save:
+            ctx.module, ctx.p, ctx.saved, ctx.key = module, p, (enc2, targets, kv, saved, y), logits.data_ptr()
+            _PARKED_LOGIT_GRADS.pop(ctx.key, None)
+        ctx.mark_non_differentiable(attn)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, d_logits, _da):
+        module, p = ctx.module, ctx.p
+        arena, pre, spec, packed = module.arena, module.arena_prefix, module.dec_spec, module.packed
+        enc2, targets, kv, saved, y = ctx.saved
+        ctx.saved = None
+        C, D, L = spec.C, spec.D, spec.L
+        d_pad = _PARKED_LOGIT_GRADS.pop(ctx.key, None)
+        if d_pad is None or any(st != 0 for st in d_logits.stride()):
+            extra = torch.zeros((y.shape[0], CLS_PAD), dtype=BF16, device=y.device)
+            extra[:, :C] = d_logits.reshape(-1, C).to(BF16)
+            d_pad = extra if d_pad is None else d_pad + extra
+        dw = torch.empty((CLS_PAD, D), dtype=F32, device=y.device)
+        ops.gemm_tn(d_pad, y, dw, accumulate=False)
+        ops.permute4(dw, (D, 1), (C, D), arena.g(pre + "classifier.weight"), accumulate=True)
+        db = torch.zeros(CLS_PAD, dtype=F32, device=y.device)
+        ops.colsum_bf16(d_pad, db)
+        arena.g(pre + "classifier.bias").add_(db[:C])
+        dy = ops.gemm_nt(d_pad, packed.cls_t)
+        d_kv = decoder_backward(arena, pre, spec, packed, targets, kv, saved, dy, p)
+        for l in range(L):
+            ops.gemm_tn(d_kv[:, l * 2 * D:(l + 1) * 2 * D], enc2,
+                        arena.span(f"{pre}layer_stack.{l}.enc_attn.linear_k.weight", 2 * D, "g"))
+        d_enc = ops.gemm_nt(d_kv, packed.kv_t)
+        if module.grad_ready_hook is not None:
+            module.grad_ready_hook(pre)
+        return d_enc.view(-1, 256, D), None, None
+
+
+class TFLossFn(torch.autograd.Function):
+    """TFLoss (ce_loss.py:94-128): loss = TFLossFn.apply(logits fp32 [B,T,C] (row stride >= C), targets, pad_idx)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, pad_idx):
+        B, T, C = logits.shape
+        assert logits.dtype == F32 and logits.stride(2) == 1 and logits.stride(0) == T * logits.stride(1)
+        lg2 = logits.as_strided((B * T, C), (logits.stride(1), 1))
+        row_lse, acc = ops.tf_loss_fwd(lg2, C, targets, pad_idx)
+        ctx.saved, ctx.pad_idx = (logits, lg2, targets, row_lse, acc), pad_idx
+        return acc[0] / acc[1]
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        logits, lg2, targets, row_lse, acc = ctx.saved
+        ctx.saved = None
+        B, T, C = logits.shape
+        ldd = CLS_PAD if lg2.stride(0) == CLS_PAD else (C + 7) // 8 * 8
+        d = ops.tf_loss_bwd(lg2, C, targets, ctx.pad_idx, row_lse, acc, d_loss.reshape(1).to(F32).contiguous(), ldd)
+        if lg2.stride(0) == CLS_PAD and logits._base is not None:      # produced by DecoderFn: hand the bf16 buffer over
+            _PARKED_LOGIT_GRADS[logits._base.data_ptr()] = d
+            return torch.zeros((), dtype=F32, device=d.device).expand(logits.shape), None, None
+        return d[:, :C].float().view(B, T, C), None, None
+
+
+@torch.no_grad()
+def greedy_decode(module, out_enc, stop_on_eos_of_first=False):
+    """NRTRDecoder.forward_test (nrtr_decoder.py:148-170): max_seq_len greedy steps over a [B, max_seq_len+1] sequence.
+    The encoder-side keys / values are computed ONCE (the reference recomputes them every step - same values).
+    stop_on_eos_of_first: forward_test_speed's early exit (:193-194, `step_result.argmax() == 91` over the flattened
+    [B, C] tensor, i.e. sample 0 predicting <EOS>); costs one host sync per step."""
+    arena, pre, spec, packed = module.arena, module.arena_prefix, module.dec_spec, module.packed
+    B = out_enc.shape[0]
+    steps, T = spec.max_seq_len, spec.max_seq_len + 1
+    seeds = _Seeds(0)
+    packed.refresh(arena, pre, spec)
+    kv = encoder_kv(arena, pre, spec, out_enc.reshape(-1, spec.D))
+    seq = torch.full((B, T), spec.padding_idx, dtype=torch.int64, device=out_enc.device)
+    seq[:, 0] = spec.start_idx
+    probs = torch.zeros((B, steps, spec.C), dtype=F32, device=out_enc.device)
+    done = steps
+    for step in range(steps):
+        y, _, _ = decoder_states(arena, pre, spec, module.pos_table, seq, kv, 0.0, seeds, False, want_attn=False)
+        logits = ops.gemm_nt(y.view(B, T, spec.D)[:, step], packed.cls, epilogue=ops.EPI_F32, bias=packed.cls_bias)
+        ops.greedy_step(logits, spec.C, probs, step, seq)
+        if stop_on_eos_of_first and int(probs[:, step].argmax()) == spec.start_idx:
+            done = step + 1
+            break
+    return probs[:, :done]

@@ -119,3 +119,80 @@ class ABIDINOModel(ArenaModule):
         return ModelOutput({"logits_buf": logits, "selection": sel},
                            {"instances_view": lambda: logits[: 2 * sel.M],
                             "feature": lambda: self.backbone.to_2D(tokens).float()})
+
+
+# ------------------------------------------------------------------------------------------------ finetune
+class DINO_Finetune(ArenaModule):
+    """Text recogniser of the finetune stage (Dino/model/dino_vision.py:134-290): ViT backbone -> Mlp "encoder" ->
+    NRTR decoder -> TFLoss.  Same constructor (a config object), parameter names and init RNG order as the reference."""
+
+    def __init__(self, config):
+        super().__init__()
+        from ..convertor.attn import AttnConvertor
+        from ..decoder.nrtr_decoder import Mlp, NRTRDecoder
+        from ..loss.ce_loss import TFLoss
+        from ..modules import vision_transformer as vits
+        self.label_convertor = AttnConvertor(dict_type='DICT90', max_seq_len=config.decoder_max_seq_len, with_unknown=True)
+        config.arch = config.arch.replace("deit", "vit")
+        if config.arch not in vits.__dict__:
+            raise NotImplementedError(f"Unknow architecture: {config.arch} (HIP kernels cover vit_tiny / vit_small / vit_base)")
+        self.backbone = vits.__dict__[config.arch](patch_size=config.patch_size, drop_path_rate=config.drop_path_rate)
+        embed_dim = self.backbone.embed_dim
+        self.encoder = Mlp(in_features=embed_dim, hidden_features=512, out_features=512, act_layer=nn.GELU, drop=0.1)
+        config.decoder_num_classes = self.label_convertor.num_classes()
+        config.decoder_start_idx = self.label_convertor.start_idx
+        config.decoder_padding_idx = self.label_convertor.padding_idx
+        self.decoder = NRTRDecoder(
+            n_layers=config.decoder_n_layers, d_embedding=config.decoder_d_embedding, n_head=config.decoder_n_head,
+            d_k=config.decoder_d_k, d_v=config.decoder_d_v, d_model=config.decoder_d_model, d_inner=config.decoder_d_inner,
+            n_position=200, dropout=0.1, num_classes=config.decoder_num_classes, max_seq_len=config.decoder_max_seq_len,
+            start_idx=config.decoder_start_idx, padding_idx=config.decoder_padding_idx)
+        self.loss = TFLoss(ignore_index=self.label_convertor.padding_idx)
+
+    # ------------------------------------------------------------------------------------------- arena
+    def _transposed_names(self):
+        return ["backbone." + n for n in self.backbone._transposed_names()] + \
+               ["encoder." + n for n in self.encoder._transposed_names()] + \
+               ["decoder." + n for n in self.decoder._transposed_names()]
+
+    def attach_arena(self, arena, prefix):
+        super().attach_arena(arena, prefix)
+        self.backbone.attach_arena(arena, prefix + "backbone.")
+        self.encoder.attach_arena(arena, prefix + "encoder.")
+        self.decoder.attach_arena(arena, prefix + "decoder.")
+
+    def unused_parameter_names(self):
+        """cls_token and the three norm_seg LayerNorms never take part in this forward pass (their .grad stays None in
+        the reference, so torch's AdamW skips them)."""
+        pre = self.arena_prefix
+        return [pre + "backbone.cls_token"] + [pre + f"backbone.norm_seg.{j}.{k}" for j in range(3) for k in ("weight", "bias")]
+
+    # ------------------------------------------------------------------------------ reference surface
+    def forward(self, img, text, return_loss=True, test_speed=False):
+        if return_loss:
+            return self.forward_train(img, text)
+        if test_speed:
+            return self.forward_test_speed(img)
+        return self.forward_test(img)
+
+    def extract_feat(self, img):
+        """Final-norm tokens [N,256,E] (bf16, the kernels' native layout)."""
+        self.ensure_arena()
+        tokens, = self.backbone.tokens_and_taps(img, need_taps=False)
+        return tokens
+
+    def forward_train(self, img, img_metas):
+        """img [N,3,32,128], img_metas = padded target indices int64 [N,T] -> (loss, attn [N,H,T,256])."""
+        feat = self.extract_feat(img)
+        targets_dict = {'padded_targets': img_metas}
+        out_enc = self.encoder(feat)
+        out_dec, attn = self.decoder(feat, out_enc, targets_dict, train_mode=True)
+        return self.loss(out_dec, targets_dict), attn
+
+    def forward_test(self, img):
+        feat = self.extract_feat(img)
+        return self.decoder(feat, self.encoder(feat), None, train_mode=False)
+
+    def forward_test_speed(self, img):
+        feat = self.extract_feat(img)
+        return self.decoder(feat, self.encoder(feat), None, train_mode=False, test_speed=True)

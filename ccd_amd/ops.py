@@ -587,10 +587,12 @@ def tf_loss_fwd(logits, C, targets, pad_idx):
 
 
 def tf_loss_bwd(logits, C, targets, pad_idx, row_lse, acc, upstream, ldd):
+    """upstream: fp32 device scalar (the gradient arriving at the loss) or None for 1."""
+    _chk(upstream, F32, "upstream")
     B, T = targets.shape
     d = torch.empty((B * T, ldd), dtype=BF16, device=logits.device)
     _call("ccd_tf_loss_bwd", _lib.ptr(logits), logits.stride(0), int(C), _lib.ptr(targets), B * T, T, int(pad_idx),
-          _lib.ptr(row_lse), _lib.ptr(acc), float(upstream), _lib.ptr(d), ldd)
+          _lib.ptr(row_lse), _lib.ptr(acc), _lib.ptr(upstream), _lib.ptr(d), ldd)
     return d
 
 

@@ -15,9 +15,13 @@ from .arena import ParamArena
 
 
 class FusedClipAdamW:
-    def __init__(self, arena: ParamArena, betas=(0.9, 0.999), eps=1e-8, clip_grad=0.0, lr=1e-3, weight_decay=1e-2):
+    def __init__(self, arena: ParamArena, betas=(0.9, 0.999), eps=1e-8, clip_grad=0.0, lr=1e-3, weight_decay=1e-2,
+                 global_norm=False):
+        """clip_grad: 0 = off.  global_norm=False: every tensor clipped on its OWN L2 norm (clip_gradients,
+        modules/utils.py:132-141, the pretraining rule); True: torch.nn.utils.clip_grad_norm_ over all tensors
+        (train_finetune.py:281-282)."""
         self.arena = arena
-        self.betas, self.eps, self.clip_grad = betas, eps, clip_grad
+        self.betas, self.eps, self.clip_grad, self.global_norm = betas, eps, clip_grad, global_norm
         names = list(arena.segments)
         decayed = [n for n in names if arena.params[n].requires_grad and not (n.endswith(".bias") or arena.params[n].dim() == 1)]
         plain = [n for n in names if arena.params[n].requires_grad and (n.endswith(".bias") or arena.params[n].dim() == 1)]
@@ -67,6 +71,8 @@ class FusedClipAdamW:
         self._norm2.zero_()
         if self.clip_grad:
             ops.seg_sumsq(arena.grad, cs, cb, cl, self._norm2)
+            if self.global_norm:                   # every tensor sees the total norm: same coefficient everywhere
+                self._norm2.copy_(self._norm2.sum().expand_as(self._norm2))
         ops.adamw(arena.flat, arena.grad, self.exp_avg, self.exp_avg_sq, arena.mirror, cs, cb, cl, self._hyper_dev,
                   self._norm2, float(self.clip_grad or 0.0), b1, b2, self.eps)
         arena.refresh_transposes()

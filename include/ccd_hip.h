@@ -252,11 +252,11 @@ int ccd_dec_attn_bwd(const ccd_bf16* q, long ldq, const ccd_bf16* k, long ldk, c
 /* TFLoss (ce_loss.py:94-128): rows r = (b,t) of logits [B*T, ldl] (C <= 128 classes) against targets[b,t+1]; rows with
  * t == T-1 or target == pad_idx do not count.  fwd: acc[0] = sum of -log softmax[target], acc[1] = count (acc is
  * cleared first), row_lse[r] saved; the loss is acc[0]/acc[1].  bwd: d_logits (bf16 [B*T, ldd], zero beyond C) =
- * (softmax - onehot) * upstream / count. */
+ * (softmax - onehot) * upstream[0] / count (upstream: device scalar, NULL = 1). */
 int ccd_tf_loss_fwd(const float* logits, long ldl, int C, const int64_t* targets, int rows, int T, int pad_idx,
                     float* row_lse, float* acc, void* stream);
 int ccd_tf_loss_bwd(const float* logits, long ldl, int C, const int64_t* targets, int rows, int T, int pad_idx,
-                    const float* row_lse, const float* acc, float upstream, ccd_bf16* d_logits, long ldd, void* stream);
+                    const float* row_lse, const float* acc, const float* upstream, ccd_bf16* d_logits, long ldd, void* stream);
 /* One greedy decoding position (nrtr_decoder.py:160-168): probs[b,step,:] = softmax(logits[b,:C]),
  * seq[b,step+1] = argmax (first maximum). */
 int ccd_greedy_step(const float* logits, long ldl, int C, int B, float* probs, int steps, int step, int64_t* seq,

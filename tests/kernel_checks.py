@@ -730,7 +730,7 @@ def check_tf_loss(dev, B=6, T=25, C=92, seed=43):
     row_lse, acc = ops.tf_loss_fwd(logits.to(dev), C, tgt.to(dev), 92)
     close(acc[0] / acc[1], ref, 1e-5, 1e-6, "tf_loss/fwd")
     assert float(acc[1]) == float((tgt[:, 1:] != 92).sum())
-    d = ops.tf_loss_bwd(logits.to(dev), C, tgt.to(dev), 92, row_lse, acc, 0.5, 128)
+    d = ops.tf_loss_bwd(logits.to(dev), C, tgt.to(dev), 92, row_lse, acc, torch.tensor([0.5]).to(dev), 128)
     close(d[:, :C].view(B, T, C), 0.5 * lg.grad, 1e-2, 1e-5, "tf_loss/bwd")
     assert (d[:, C:] == 0).all()
     # greedy step

@@ -265,3 +265,226 @@ def check_checkpoint_resume(device, tmp_path):
     # noise that two identical runs show as well - Adam turns sign flips of zero-gradient elements into +-lr moves)
     got = run(s2, t2, loss2, opt2, seed=22, epoch=1)
     assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (got, want)
+
+
+# ------------------------------------------------------------------------------------------------ finetune path
+FT_WORDS = ["hello", "Wor1d!", "MI355X", "a", "text-recognition", "CCD", "~{unknown}", "0123456789abcdefghijklmnopqrstuvwxyz"]
+
+
+def _register_test_arch():
+    """A 2-block E=192 backbone under the name 'vit_test2' (DINO_Finetune looks architectures up by name)."""
+    from functools import partial
+    import torch.nn as nn
+    from ccd_amd.modules import vision_transformer as vits
+    if "vit_test2" not in vits.__dict__:
+        vits.vit_test2 = lambda patch_size=16, **kw: vits.VisionTransformer(
+            patch_size=patch_size, embed_dim=192, depth=2, num_heads=3, mlp_ratio=4, qkv_bias=True,
+            norm_layer=partial(nn.LayerNorm, eps=1e-6), **kw)
+
+
+def _cosine(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def check_finetune_against_oracle(device, arch="vit_test2", vit_kw=None, n_layers=2, B=3, steps=2, loss_tol=2e-3,
+                                  decode=True, max_seq_len=25):
+    """Product (HIP kernels) vs the pinned CPU oracle on the same seed / inputs: initial weights bit-identical, loss,
+    logits, attention map, every gradient, AdamW-updated weights, greedy decoding."""
+    from ccd_amd import finetune as ft
+    from oracle import ccd_oracle as O
+    from oracle import finetune_oracle as FO
+    _register_test_arch()
+    vit_kw = vit_kw or dict(embed_dim=192, depth=2, heads=3)
+    spec = FO.FtSpec(vit=O.Spec(**vit_kw), n_layers=n_layers, max_seq_len=max_seq_len)
+    net = FO.init_finetune(spec, seed=5)
+    torch.manual_seed(5)
+    model = ft.build_model(ft.FinetuneConfig(arch=arch, drop_path_rate=0.0, decoder_n_layers=n_layers,
+                                             decoder_max_seq_len=max_seq_len), device, dropout=0.0)
+    sd = model.state_dict()
+    assert set(sd) == set(net.P), set(sd) ^ set(net.P)
+    for k, v in net.P.items():
+        assert torch.equal(sd[k].detach().cpu().float(), v.detach()), f"init differs: {k}"
+    opt = ft.make_optimizer(model)
+    o_opt = O.AdamWState()
+    targets = model.label_convertor.str2tensor(FT_WORDS[:B])
+    assert torch.equal(targets, FO.str2tensor(FT_WORDS[:B], max_seq_len=max_seq_len))
+    gen = torch.Generator().manual_seed(77)
+    for step in range(steps):
+        img = torch.randn(B, 3, 32, 128, generator=gen)
+        lr = 3e-4
+        rec = FO.train_iteration(net, o_opt, img, targets, lr)
+        # forward pieces with gradients kept, then the optimizer step
+        for g_ in opt.param_groups:
+            g_["lr"] = lr
+        loss, attn = model(img.to(device), targets.to(device), return_loss=True)
+        opt.zero_grad()
+        loss.backward()
+        assert abs(loss.item() - rec["loss"]) < loss_tol, (step, loss.item(), rec["loss"])
+        a_ref = rec["attn"]
+        assert attn.shape == a_ref.shape
+        assert (attn.float().cpu() - a_ref).abs().max() < 2e-2 * a_ref.max() + 1e-4
+        worst = (1.0, "")
+        for k, g_ref in rec["grads_raw"].items():
+            got = model.arena.g(k).detach().cpu()
+            nr = g_ref.norm().item()
+            if nr < 1e-7:
+                assert got.norm().item() < 1e-4, k
+                continue
+            c = _cosine(got, g_ref)
+            worst = min(worst, (c, k))
+            assert abs(got.norm().item() / nr - 1) < 8e-2, (step, k, got.norm().item(), nr)
+        assert worst[0] > 0.97, worst
+        for k in model.unused_parameter_names():
+            assert float(model.arena.g(k).abs().max()) == 0.0 and k not in rec["grads_raw"], k
+        before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        opt.step()
+        after = model.state_dict()
+        for k in rec["grads_raw"]:
+            mine, ref = after[k].detach().cpu(), net.P[k].detach()
+            # Adam's first steps move EVERY element by ~lr, also where only rounding noise decides the gradient's sign:
+            # two implementations can be 2*lr apart per step there, and never more
+            assert (mine - ref).abs().max() <= 2.2 * lr * (step + 1) + 1e-6, (k, (mine - ref).abs().max().item())
+            moved = (ref - before[k].cpu()).abs() > 0.5 * lr
+            if moved.any() and step == 0:
+                agree = (torch.sign(mine - before[k].cpu()) == torch.sign(ref - before[k].cpu()))[moved].float().mean()
+                assert agree > 0.9, (k, float(agree))
+        assert all(torch.equal(before[k].cpu(), after[k].cpu()) for k in model.unused_parameter_names())
+    if decode:
+        img = torch.randn(B, 3, 32, 128, generator=gen)
+        # decode with IDENTICAL weights: load the oracle's into the product
+        model.load_state_dict({k: v.detach() for k, v in net.P.items()})
+        model.eval()
+        with torch.no_grad():
+            probs = model(img.to(device), None, return_loss=False)
+            ref = FO.forward_test(net.P, spec, img)
+            _, logits_ref, _ = FO.forward_train(net.P, spec, img, targets)
+            model.train()
+            feat = model.extract_feat(img.to(device))
+            logits, _ = model.decoder(feat, model.encoder(feat), {"padded_targets": targets.to(device)}, train_mode=True)
+        assert probs.shape == ref.shape == (B, max_seq_len, 92)
+        probs = probs.cpu()
+        # greedy decoding feeds its own argmax back: compare a position only while the decoded prefixes agree
+        same_prefix = torch.ones(B, dtype=torch.bool)
+        compared = 0
+        for t in range(max_seq_len):
+            if same_prefix.any():
+                d = (probs[same_prefix, t] - ref[same_prefix, t]).abs().max()
+                assert d < 4e-2, (t, float(d))
+                compared += int(same_prefix.sum())
+            same_prefix &= probs[:, t].argmax(-1) == ref[:, t].argmax(-1)
+        assert compared >= B * 4, compared
+        assert (logits.float().cpu() - logits_ref).abs().max() < 6e-2 * max(1.0, logits_ref.abs().max().item())
+        clear = ref.topk(2, -1).values
+        clear = (clear[..., 0] - clear[..., 1]) > 0.1
+        assert torch.equal(probs.cpu().argmax(-1)[clear], ref.argmax(-1)[clear])
+
+
+def check_finetune_dropout(device, B=2, n_layers=1):
+    """Training with the reference's dropout (p = 0.1): masks are a pure function of the seeds, so two runs with the same
+    seeds are identical and the analytic gradient matches a central finite difference of the loss taken with the SAME
+    seeds; eval mode switches dropout off."""
+    from ccd_amd import finetune as ft
+    _register_test_arch()
+    torch.manual_seed(9)
+    model = ft.build_model(ft.FinetuneConfig(arch="vit_test2", drop_path_rate=0.0, decoder_n_layers=n_layers,
+                                             decoder_max_seq_len=12), device)
+    targets = model.label_convertor.str2tensor(FT_WORDS[:B]).to(device)
+    img = torch.randn(B, 3, 32, 128, generator=torch.Generator().manual_seed(3)).to(device)
+
+    def reseed():
+        for m in (model.encoder, model.decoder):
+            m._base, m._calls = 12345, 0
+
+    outs = []
+    for rep in range(2):
+        reseed()
+        loss, _ = model(img, targets)
+        model.arena.zero_grad()
+        loss.backward()
+        outs.append((loss.item(), model.arena.grad.clone()))
+    assert abs(outs[0][0] - outs[1][0]) < 1e-5, (outs[0][0], outs[1][0])         # the loss sum uses fp32 atomics
+    assert (outs[0][1] - outs[1][1]).abs().max() <= 1e-3 * outs[0][1].abs().max()      # fp32 atomics reorder sums
+    model.eval()
+    with torch.no_grad():
+        l_eval, _ = model(img, targets)
+    assert abs(l_eval.item() - outs[0][0]) > 1e-4                                      # dropout really was on
+    model.train()
+    name = "decoder.layer_stack.0.mlp.w_2.weight"
+    g = model.arena.g(name).clone()
+    w = model.arena.w(name)
+    w0 = w.clone()
+    direction = g / g.norm()
+    eps = 2e-2
+    vals = []
+    for sgn in (+1, -1):
+        w.copy_(w0 + sgn * eps * direction)
+        model.arena.refresh_mirrors()
+        reseed()
+        with torch.no_grad():
+            vals.append(model(img, targets)[0].item())
+    w.copy_(w0)
+    model.arena.refresh_mirrors()
+    analytic = float((g * direction).sum())
+    numeric = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(analytic - numeric) < 0.15 * abs(numeric) + 2e-3, (analytic, numeric)
+
+
+def check_finetune_golden(device, tag="tiny", loss_tol=2e-3):
+    """Product vs the REAL reference's recorded run (tests/golden/finetune_step.npz, tools/gen_golden.py): initial
+    weights, two AdamW iterations (loss, attention map, every gradient norm), then greedy decoding."""
+    from ccd_amd import finetune as ft
+    g = np.load(os.path.join(GOLD, "finetune_step.npz"))
+    arch, n_layers, B = {"tiny": ("vit_tiny", 2, 4), "small": ("vit_small", 6, 8)}[tag]
+    torch.manual_seed(0)
+    model = ft.build_model(ft.FinetuneConfig(arch=arch, drop_path_rate=0.0, decoder_n_layers=n_layers), device, dropout=0.0)
+    sd = model.state_dict()
+    for n, row in zip(g[f"{tag}/init_names"], g[f"{tag}/init_stats"]):
+        assert_init_stat(stat(sd[str(n)]), row, n)
+    targets = model.label_convertor.str2tensor([str(w) for w in g["words"][:B]])
+    np.testing.assert_array_equal(targets.numpy(), g[f"{tag}/targets"])
+    targets = targets.to(device)
+    opt = ft.make_optimizer(model)
+    gen = torch.Generator().manual_seed(1234)
+    for step in range(2):
+        p = f"{tag}/s{step}/"
+        img = torch.randn(B, 3, 32, 128, generator=gen)
+        np.testing.assert_allclose(stat(img), g[p + "image_stat"], rtol=1e-12)
+        loss_ref, lr = g[p + "loss"]
+        for grp in opt.param_groups:
+            grp["lr"] = float(lr)
+        loss, attn = model(img.to(device), targets, return_loss=True)
+        opt.zero_grad()
+        loss.backward()
+        assert abs(loss.item() - loss_ref) < loss_tol, (step, loss.item(), loss_ref)
+        am = attn.float().mean(1).cpu().numpy()
+        assert np.abs(am - g[p + "attn_mean"]).max() < 2e-2 * g[p + "attn_mean"].max() + 1e-4
+        names = [str(n) for n in g[p + "grad_names"]]
+        for n, row in zip(names, g[p + "grad_stats"]):
+            got = stat(model.arena.g(n))
+            if row[2] < 1e-7:
+                assert got[2] < 1e-4, n
+            else:
+                assert abs(got[2] / row[2] - 1) < 8e-2, (step, n, got[2], row[2])
+        assert set(names) == {n for n, q in model.named_parameters()} - set(model.unused_parameter_names())
+        opt.step()
+        lr_sum = float(sum(g[f"{tag}/s{i}/loss"][1] for i in range(step + 1)))
+        for n, row in zip(g[p + "post_names"], g[p + "post_stats"]):
+            t_ = model.state_dict()[str(n)]
+            got = stat(t_)
+            # Adam moves every element by ~lr per step whatever the gradient's size: sign noise bounds the difference
+            assert abs(got[2] - row[2]) <= 2e-3 * row[2] + 0.5 * lr_sum * t_.numel() ** 0.5 + 1e-6, (step, n, got[2], row[2])
+    img = torch.randn(B, 3, 32, 128, generator=gen)
+    np.testing.assert_allclose(stat(img), g[f"{tag}/eval_image_stat"], rtol=1e-12)
+    model.eval()
+    with torch.no_grad():
+        probs = model(img.to(device), None, return_loss=False).cpu()
+    ref = torch.from_numpy(g[f"{tag}/test_probs"])
+    same_prefix = torch.ones(B, dtype=torch.bool)
+    compared = 0
+    for t in range(25):
+        if same_prefix.any():
+            assert (probs[same_prefix, t] - ref[same_prefix, t]).abs().max() < 5e-2, t
+            compared += int(same_prefix.sum())
+        same_prefix &= probs[:, t].argmax(-1) == ref[:, t].argmax(-1)
+    assert compared >= 4 * B, compared

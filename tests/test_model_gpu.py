@@ -39,3 +39,18 @@ def test_properties_at_full_batch(hip):
 def test_smoke_entry(hip):
     import __graft_entry__ as g
     g.smoke()
+
+
+@pytest.mark.parametrize("tag", ["tiny", "small"])
+def test_finetune_vs_reference(hip, tag):
+    """DINO_Finetune against the real reference's recorded iterations (vit_tiny/2 layers, vit_small/6)."""
+    mc.check_finetune_golden(hip.device, tag)
+
+
+def test_finetune_vs_oracle(hip):
+    from oracle import ccd_oracle as O
+    mc.check_finetune_against_oracle(hip.device, arch="vit_small", vit_kw=O.ARCH["vit_small"], n_layers=6, B=8, steps=1)
+
+
+def test_finetune_dropout(hip):
+    mc.check_finetune_dropout(hip.device, B=8, n_layers=2)
