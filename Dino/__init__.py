@@ -1,7 +1,8 @@
 """`Dino.*` import paths of the reference (TongkunGuan/CCD) mapped onto the MI355X-native implementation in
 `ccd_amd`, so `from Dino.modules import vision_transformer as vits`, `from Dino.model.dino_vision import
 ABIDINOModel`, `from Dino.loss.Dino_loss import DINOLoss`, `from Dino.utils.utils import Config` keep working.
-Only the pretraining path exists here."""
+The pretraining path and the finetune path (8f row 1: DINO_Finetune, NRTRDecoder, TFLoss,
+AttnConvertor) exist here."""
 import importlib
 import sys
 
@@ -14,6 +15,11 @@ _ALIASES = {
     "Dino.model.dino_vision": "ccd_amd.model.dino_vision",
     "Dino.loss": "ccd_amd.loss",
     "Dino.loss.Dino_loss": "ccd_amd.loss.Dino_loss",
+    "Dino.loss.ce_loss": "ccd_amd.loss.ce_loss",
+    "Dino.decoder": "ccd_amd.decoder",
+    "Dino.decoder.nrtr_decoder": "ccd_amd.decoder.nrtr_decoder",
+    "Dino.convertor": "ccd_amd.convertor",
+    "Dino.convertor.attn": "ccd_amd.convertor.attn",
     "Dino.utils": "ccd_amd.utils",
     "Dino.utils.utils": "ccd_amd.utils.utils",
 }

@@ -59,6 +59,111 @@ def pmc_traffic(kind, a):
     return rec["bytes_per_launch"] if rec else None
 
 
+def finetune_cpu_baseline(arch, B=8, steps=2):
+    """The CPU oracle of the finetune step (oracle/finetune_oracle.py) on this host: B=8, fp32, dropout off."""
+    from oracle import ccd_oracle as O
+    from oracle import finetune_oracle as FO
+    spec = FO.FtSpec(vit=O.Spec(**O.ARCH[arch]))
+    net = FO.init_finetune(spec, seed=0)
+    opt = O.AdamWState()
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(B, 3, 32, 128, generator=g)
+    targets = FO.str2tensor(["benchmark%d" % i for i in range(B)])
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        FO.train_iteration(net, opt, img, targets, 1e-4)
+        if i:
+            times.append(time.perf_counter() - t0)
+    sec = sorted(times)[len(times) // 2]
+    return {"value": round(B / sec, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{arch} finetune B={B} fp32, {steps} timed steps after 1 warm-up, median {sec:.2f} s/step "
+                      "(oracle/finetune_oracle.py)"}
+
+
+def main_finetune(a, world, rank, dev, use_dist):
+    """BASELINE config #5: CCD_vision_model finetune step (train_finetune.py:262-289) - ViT encoder fwd/bwd, Mlp, 6-layer
+    NRTR decoder, TFLoss, AdamW - on a resident synthetic labelled batch; dropout 0.1 and drop_path 0.1 ON as shipped."""
+    from ccd_amd import finetune as ft, ops
+    from ccd_amd.parallel import DataParallel
+    torch.manual_seed(0)
+    model = ft.build_model(ft.FinetuneConfig(arch=a.arch, drop_path_rate=0.1), dev)
+    net = DataParallel(model) if use_dist else model
+    opt = ft.make_optimizer(model)
+    B = a.batch
+    g = torch.Generator().manual_seed(1000 + rank)
+    images = torch.randn(B, 3, 32, 128, generator=g).to(dev)
+    words = ["".join(model.label_convertor.idx2char[int(c)] for c in torch.randint(0, 90, (int(n),), generator=g))
+             for n in torch.randint(3, 16, (B,), generator=g)]
+    labels = model.label_convertor.str2tensor(words).to(dev)
+
+    def step():
+        return ft.training_iteration(net, opt, images, labels, 1e-4)[0]
+
+    for _ in range(a.warmup):
+        loss = step()
+    timer = None if a.no_kernel_timer else ops.KernelTimer()
+    ops.TIMER = timer
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+    final_loss = loss.item()
+    assert final_loss == final_loss and abs(final_loss) < 1e4, f"non-finite loss {final_loss}"
+    if rank == 0:
+        ms = elapsed / a.steps * 1e3
+        ips = B * world * a.steps / elapsed
+        E = model.backbone.embed_dim
+        L, D, T = model.decoder.dec_spec.L, 512, 25
+        # FLOPs per image (multiply-add = 2, backward = 2x forward): backbone 12.09 GF/view fwd (SURVEY 8d, E=384),
+        # Mlp, per-layer K/V over the 256 tokens, decoder rows (self/cross projections, FFN), attention products
+        vit_fwd = {"vit_small": 12.09e9, "vit_base": 20.95e9, "vit_tiny": 3.2e9}.get(a.arch, 12.09e9)
+        enc = 2 * 256 * (E * 512 + 512 * D) + 2 * 256 * L * 2 * D * D
+        dec = L * (2 * T * (4 * D * D + 2 * D * D + 2 * D * 256) + 4 * T * T * D + 4 * T * 256 * D) + 2 * T * D * 92
+        gf_img = 3 * (vit_fwd + enc + dec) / 1e9
+        line = {"metric": "images/sec (32x128 crops) CCD finetune step (ViT encoder + NRTR decoder)", "value": round(ips, 2),
+                "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": f"CCD_vision_model finetune {a.arch} bf16, bs={B}/GPU, 6-layer NRTR decoder, T=25, "
+                                       "dropout 0.1, drop_path 0.1, AdamW, synthetic labelled batch in HBM (BASELINE config #5)",
+                           "global_batch": B * world, "parallelism": f"dp{world}", "gflop_per_image": round(gf_img, 1),
+                           "step_frac_of_mfma_peak": round(ips / world * gf_img / 1e3 / PEAK_BF16_TF, 4),
+                           "final_loss": round(final_loss, 4)}}
+        if timer is not None:
+            summ = timer.summary()
+            key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+            avg_ms = d["ms"] / d["launches"]
+            tflops = d["flops"] / d["launches"] / avg_ms / 1e9
+            gbs = d["bytes"] / d["launches"] / avg_ms / 1e6
+            intensity = d["flops"] / max(d["bytes"], 1.0)
+            hbm_bound = intensity < PEAK_BF16_TF * 1e12 / (PEAK_HBM_GBS * 1e9)
+            line["roofline"] = {"bound": "hbm" if hbm_bound else "mfma", "kernel": f"GEMM kind {key}",
+                                "achieved": round(gbs if hbm_bound else tflops, 1),
+                                "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TF,
+                                "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                                "frac": round(gbs / PEAK_HBM_GBS if hbm_bound else tflops / PEAK_BF16_TF, 4), "traffic": None,
+                                "avg_launch_ms": round(avg_ms, 4), "launches_per_step": d["launches"] // a.steps,
+                                "gemm_ms_per_step": round(sum(v["ms"] for v in summ.values()) / a.steps, 3),
+                                "by_kind_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in sorted(summ.items())},
+                                "by_kind_tflops": {k: round(v["flops"] / v["ms"] / 1e9, 1) for k, v in sorted(summ.items())}}
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = finetune_cpu_baseline(a.arch)
+        print(json.dumps(line), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +172,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--arch", default="vit_small")
     ap.add_argument("--out-dim", type=int, default=65536)
+    ap.add_argument("--workload", default="pretrain", choices=["pretrain", "finetune"],
+                    help="pretrain = the BASELINE metric (default); finetune = BASELINE config #5 (SURVEY 8f row 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     a = ap.parse_args()
@@ -82,6 +189,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if a.workload == "finetune":
+        return main_finetune(a, world, rank, dev, use_dist)
 
     from ccd_amd import ops, pretrain
     from ccd_amd.loss.Dino_loss import DINOLoss

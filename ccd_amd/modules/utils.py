@@ -51,6 +51,16 @@ def cosine_iter_scheduler(base_value, final_value, niter, warmup_iters=0, start_
     return schedule
 
 
+def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0):
+    """Per-EPOCH-parameterised cosine schedule of the finetune script (modules/utils.py:187-198)."""
+    warmup_iters = int(warmup_epochs * niter_per_ep)
+    warm = np.linspace(start_warmup_value, base_value, warmup_iters) if warmup_epochs > 0 else np.array([])
+    steps = np.arange(epochs * niter_per_ep - warmup_iters)
+    schedule = np.concatenate((warm, final_value + 0.5 * (base_value - final_value) * (1 + np.cos(np.pi * steps / len(steps)))))
+    assert len(schedule) == epochs * niter_per_ep
+    return schedule
+
+
 def bool_flag(s):
     if s.lower() in {"off", "false", "0"}:
         return False

@@ -174,6 +174,49 @@ def _syncbn_worker(rank, world, port):
     dist.destroy_process_group()
 
 
+def _finetune_dp_worker(rank, world, port):
+    """Finetune path under data parallelism: rank-0 broadcast, gradients == mean of the ranks' local gradients (the
+    decoder / encoder ranges are announced by FinetuneFn's hooks, the backbone blocks by BackboneFn's), replicas equal."""
+    _init(rank, world, port)
+    from backends import Backend
+    import model_checks as mc
+    from ccd_amd import finetune as ft
+    from ccd_amd.parallel import DataParallel
+    with Backend("sim") as b:
+        mc._register_test_arch()
+        torch.manual_seed(3 + 100 * rank)
+        model = ft.build_model(ft.FinetuneConfig(arch="vit_test2", drop_path_rate=0.0, decoder_n_layers=1,
+                                                 decoder_max_seq_len=10), b.device, dropout=0.0)
+        net = DataParallel(model)
+        flat = model.arena.flat.clone()
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert torch.equal(gathered[0], gathered[1]), "parameters not broadcast from rank 0"
+        opt = ft.make_optimizer(net)
+        g = torch.Generator().manual_seed(50 + rank)
+        img = torch.randn(1, 3, 32, 128, generator=g)
+        labels = model.label_convertor.str2tensor([mc.FT_WORDS[rank]])
+        loss, _ = model(img, labels)
+        model.arena.zero_grad()
+        loss.backward()                                               # hooks fire, but nothing waits: grads stay local
+        net.reducer._works, net.reducer._pending, net.reducer._done = [], [], []
+        local = model.arena.grad.clone()
+        both = [torch.zeros_like(local) for _ in range(world)]
+        dist.barrier()
+        dist.all_gather(both, local)
+        seen = {}
+        orig_step = opt.step
+        opt.step = lambda: seen.setdefault("grad", model.arena.grad.clone()) is None or orig_step()
+        ft.training_iteration(net, opt, img, labels, 2e-4)
+        mean = (both[0] + both[1]) / 2
+        err, scale = (seen["grad"] - mean).abs().max().item(), mean.abs().max().item()
+        assert err <= 2e-3 * scale + 1e-7, (err, scale)
+        flat = model.arena.flat.clone()
+        dist.all_gather(gathered, flat)
+        assert torch.allclose(gathered[0], gathered[1], atol=1e-7), "replicas diverged after the optimizer step"
+    dist.destroy_process_group()
+
+
 def _spawn(fn, port):
     mp.spawn(fn, args=(2, port), nprocs=2, join=True)
 
@@ -192,3 +235,7 @@ def test_data_parallel_iteration_world2():
 
 def test_seghead_syncbn_world2():
     _spawn(_syncbn_worker, 29614)
+
+
+def test_finetune_data_parallel_world2():
+    _spawn(_finetune_dp_worker, 29615)
