@@ -20,6 +20,7 @@
 #include "kernels/optim.h"
 #include "kernels/conv.h"
 #include "kernels/decoder.h"
+#include "kernels/decoder_xattn.h"
 
 #define CCD_CHECK(cond, code) \
     do {                      \
@@ -780,9 +781,17 @@ int ccd_dec_embed_bwd(const int64_t* tokens, const float* dx, float* demb, int r
     CCD_CHECK(D > 0 && D <= 1024 && num_classes > 0, CCD_ESHAPE);
     unsigned thr; float scale;
     ccd_drop_consts(p, &thr, &scale);
-    CCD_LAUNCH(ccd::dec_embed_bwd_kernel, dim3(num_classes), dim3(256), 0, stream, (const long long*)tokens, dx, demb, rows, D,
-               padding_idx, (unsigned long long)seed, thr, scale);
+    const int rows_per_block = 1024;
+    CCD_LAUNCH(ccd::dec_embed_bwd_kernel, dim3(num_classes, (rows + rows_per_block - 1) / rows_per_block), dim3(256), 0, stream,
+               (const long long*)tokens, dx, demb, rows, D, padding_idx, (unsigned long long)seed, thr, scale, rows_per_block);
     return ccd_rt_last_error();
+}
+// the MFMA kernels (decoder_xattn.h) cover the unmasked 256-key case; CCD_DEC_ATTN_SIMT=1 forces the general kernels
+static bool ccd_dec_attn_mfma(const ccd::DecAttnParams& p) {
+    return p.Tk == ccd::XA_TK && !p.tokens && !p.key_len && !p.causal && !ccd_env_flag("CCD_DEC_ATTN_SIMT", false);
+}
+static bool ccd_sattn_mfma(const ccd::DecAttnParams& p) {
+    return p.Tk <= ccd::XA_TQ && !ccd_env_flag("CCD_DEC_ATTN_SIMT", false);
 }
 static int ccd_dec_attn_check(const ccd::DecAttnParams& p) {
     CCD_CHECK(p.B >= 0 && p.H > 0, CCD_EINVAL);
@@ -804,6 +813,14 @@ int ccd_dec_attn_fwd(const ccd_bf16* q, long ldq, const ccd_bf16* k, long ldk, c
     const int rc = ccd_dec_attn_check(a);
     if (rc != CCD_OK) return rc;
     if (B == 0) return CCD_OK;
+    if (ccd_sattn_mfma(a) && ldo % 4 == 0) {                             // short key sequences: one wave per (sample, head)
+        CCD_LAUNCH(ccd::sattn_fwd_kernel, dim3((B * H + 3) / 4), dim3(256), (size_t)ccd::SA_FWD_SMEM, stream, a);
+        return ccd_rt_last_error();
+    }
+    if (ccd_dec_attn_mfma(a) && ldo % 8 == 0 && CCD_ALIGNED16(out)) {   // encoder-decoder attention: MFMA kernel
+        CCD_LAUNCH(ccd::xattn_fwd_kernel, dim3(B * H), dim3(256), (size_t)ccd::XA_FWD_SMEM, stream, a);
+        return ccd_rt_last_error();
+    }
     CCD_LAUNCH(ccd::dec_attn_fwd_kernel, dim3(B * H), dim3(256), (size_t)ccd::dec_attn_fwd_smem(Tq, Tk), stream, a);
     return ccd_rt_last_error();
 }
@@ -824,6 +841,14 @@ int ccd_dec_attn_bwd(const ccd_bf16* q, long ldq, const ccd_bf16* k, long ldk, c
     CCD_CHECK(lddk % 8 == 0 && lddv % 8 == 0 && CCD_ALIGNED16(dk) && CCD_ALIGNED16(dv) && CCD_ALIGNED16(d_out) && ldo % 8 == 0,
               CCD_ESHAPE);
     if (B == 0) return CCD_OK;
+    if (ccd_sattn_mfma(a) && lddq % 4 == 0 && CCD_ALIGNED16(out)) {
+        CCD_LAUNCH(ccd::sattn_bwd_kernel, dim3((B * H + 3) / 4), dim3(256), (size_t)ccd::SA_BWD_SMEM, stream, a);
+        return ccd_rt_last_error();
+    }
+    if (ccd_dec_attn_mfma(a) && lddq % 8 == 0 && CCD_ALIGNED16(dq) && CCD_ALIGNED16(out)) {
+        CCD_LAUNCH(ccd::xattn_bwd_kernel, dim3(B * H), dim3(256), (size_t)ccd::XA_BWD_SMEM, stream, a);
+        return ccd_rt_last_error();
+    }
     CCD_LAUNCH(ccd::dec_attn_bwd_kernel, dim3(B * H), dim3(256), (size_t)ccd::dec_attn_bwd_smem(Tq, Tk), stream, a);
     return ccd_rt_last_error();
 }
@@ -834,7 +859,8 @@ int ccd_tf_loss_fwd(const float* logits, long ldl, int C, const int64_t* targets
     const int rc = ccd_rt_memset_async(acc, 0, 2 * sizeof(float), stream);
     if (rc) return rc;
     if (rows == 0) return CCD_OK;
-    CCD_LAUNCH(ccd::tf_loss_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, ldl, C, (const long long*)targets,
+    const int tf_blocks = (rows + 3) / 4 < 2 * ccd_rt_num_cus() ? (rows + 3) / 4 : 2 * ccd_rt_num_cus();
+    CCD_LAUNCH(ccd::tf_loss_fwd_kernel, dim3(tf_blocks), dim3(256), 0, stream, logits, ldl, C, (const long long*)targets,
                rows, T, pad_idx, row_lse, acc);
     return ccd_rt_last_error();
 }

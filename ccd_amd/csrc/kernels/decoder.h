@@ -82,21 +82,28 @@ __global__ __launch_bounds__(256) void dec_embed_fwd_kernel(const long long* __r
     }
 }
 // demb[c, :] += sum over rows with tok == c of keep * scale * dx[r, :]   (c != padding_idx: nn.Embedding(padding_idx)).
-// One workgroup per class scans the token list (ballots, no atomics, deterministic); thread t owns columns t, t+256, ...
+// Workgroup (c, chunk) scans rows [chunk * rows_per_block, ...) for class c (ballots; hits summed in row order) and
+// publishes its partial row with fp32 atomics - the <BOS/EOS> class collects 2 hits per sample, all others a handful.
+// Thread t owns columns t, t+256, ...
 __global__ __launch_bounds__(256) void dec_embed_bwd_kernel(const long long* __restrict__ tok, const float* __restrict__ dx,
                                                             float* __restrict__ demb, int rows, int D, int padding_idx,
-                                                            unsigned long long seed, unsigned thr, float scale) {
+                                                            unsigned long long seed, unsigned thr, float scale,
+                                                            int rows_per_block) {
     __shared__ unsigned long long match[4];
     const int c = blockIdx.x;
     if (c == padding_idx) return;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};                              // D <= 1024
-    for (int base = 0; base < rows; base += 256) {
+    bool any = false;
+    const int row0 = blockIdx.y * rows_per_block;
+    const int row1 = row0 + rows_per_block < rows ? row0 + rows_per_block : rows;
+    for (int base = row0; base < row1; base += 256) {
         const int r = base + threadIdx.x;
-        const unsigned long long m = ballot(r < rows && tok[r] == c);
+        const unsigned long long m = ballot(r < row1 && tok[r] == c);
         if ((threadIdx.x & 63) == 0) match[threadIdx.x >> 6] = m;
         __syncthreads();
-        for (int wv = 0; wv < 4; ++wv) {                              // hits in row order: a deterministic sum
+        for (int wv = 0; wv < 4; ++wv) {
             unsigned long long mm = match[wv];
+            any = any || mm != 0ull;
             for (int bit = 0; mm; ++bit, mm >>= 1) {
                 if (!(mm & 1ull)) continue;
                 const int rr = base + 64 * wv + bit;
@@ -113,10 +120,11 @@ __global__ __launch_bounds__(256) void dec_embed_bwd_kernel(const long long* __r
         }
         __syncthreads();
     }
+    if (!any) return;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int d = threadIdx.x + 256 * k;
-        if (d < D) demb[(long)c * D + d] += acc[k];
+        if (d < D) atomicAdd(demb + (long)c * D + d, acc[k]);
     }
 }
 
@@ -411,24 +419,32 @@ __global__ __launch_bounds__(256) void tf_loss_fwd_kernel(const float* __restric
                                                           const long long* __restrict__ targets, int rows, int T,
                                                           int pad_idx, float* __restrict__ row_lse,
                                                           float* __restrict__ acc) {
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
-    const int t = r % T;
-    const float a = lane < C ? logits[(long)r * ldl + lane] : -INFINITY;
-    const float bq = lane + 64 < C ? logits[(long)r * ldl + lane + 64] : -INFINITY;
-    const float mx = wave_max(fmaxf(a, bq));
-    const float sum = wave_sum((lane < C ? expf(a - mx) : 0.f) + (lane + 64 < C ? expf(bq - mx) : 0.f));
-    const float lse = mx + logf(sum);
-    if (lane == 0) {
-        row_lse[r] = lse;
-        if (t < T - 1) {
-            const long long tgt = targets[r + 1];
-            if (tgt != pad_idx && tgt >= 0 && tgt < C) {
-                atomicAdd(acc, lse - logits[(long)r * ldl + tgt]);
-                atomicAdd(acc + 1, 1.0f);
+    __shared__ float red[8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float nll = 0.f, cnt = 0.f;                                       // lane 0 of each wave accumulates its rows
+    for (int r = blockIdx.x * 4 + w; r < rows; r += gridDim.x * 4) {
+        const int t = r % T;
+        const float a = lane < C ? logits[(long)r * ldl + lane] : -INFINITY;
+        const float bq = lane + 64 < C ? logits[(long)r * ldl + lane + 64] : -INFINITY;
+        const float mx = wave_max(fmaxf(a, bq));
+        const float sum = wave_sum((lane < C ? expf(a - mx) : 0.f) + (lane + 64 < C ? expf(bq - mx) : 0.f));
+        const float lse = mx + logf(sum);
+        if (lane == 0) {
+            row_lse[r] = lse;
+            if (t < T - 1) {
+                const long long tgt = targets[r + 1];
+                if (tgt != pad_idx && tgt >= 0 && tgt < C) {
+                    nll += lse - logits[(long)r * ldl + tgt];
+                    cnt += 1.0f;
+                }
             }
         }
+    }
+    if (lane == 0) { red[w] = nll; red[4 + w] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                           // one pair of atomics per workgroup
+        atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+        atomicAdd(acc + 1, red[4] + red[5] + red[6] + red[7]);
     }
 }
 // d_logits[r, c] (bf16, ldd columns, zero beyond C and on uncounted rows) = (softmax - onehot) * upstream / count

@@ -60,6 +60,13 @@ __device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(%0)"
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt while an LDS-DMA is in flight
 // (the DMA is a pending LDS write on the VM counter); this one lets a DMA span the barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Orders LDS traffic between the LANES OF ONE WAVE (a wave that stages an image for itself needs no workgroup barrier:
+// its LDS operations execute in program order; this only stops the compiler from moving the reads above the writes).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 // static wave priority (guide T5): 0..3, arbitration between the waves sharing a SIMD
 template <int P>
 __device__ __forceinline__ void wave_prio() { __builtin_amdgcn_s_setprio(P); }

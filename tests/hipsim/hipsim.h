@@ -186,6 +186,8 @@ inline unsigned long long ballot(bool p) {
     sim::wave_sync();
     return all;
 }
+// lanes of a wave are separate fibers here: a wave-level LDS fence is a wave rendezvous
+inline void wave_lds_fence() { (void)ballot(true); }
 inline float bf16_bits_to_f32(unsigned short h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
 
 // v_mfma_f32_32x32x16_bf16: A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31],

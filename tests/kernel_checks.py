@@ -745,10 +745,19 @@ def check_tf_loss(dev, B=6, T=25, C=92, seed=43):
 
 
 def check_decoder_pieces(dev):
+    import os
+    os.environ["CCD_DEC_ATTN_SIMT"] = "1"                              # the general (masked / short) kernels on the 256-key case
+    try:
+        check_dec_attn(dev, B=1, H=2, Tq=25, Tk=256, self_attn=False, p=0.1)
+        check_dec_attn(dev, B=2, H=2, Tq=26, Tk=26, self_attn=True, p=0.1)
+    finally:
+        del os.environ["CCD_DEC_ATTN_SIMT"]
     check_dropout(dev)
     check_dec_embed(dev)
+    check_dec_embed(dev, B=50, D=64)                                   # 1250 rows: two row chunks per class
     check_dec_attn(dev, self_attn=True)
     check_dec_attn(dev, B=2, H=2, Tq=26, Tk=26, self_attn=True, p=0.1)
+    check_dec_attn(dev, B=3, H=3, Tq=32, Tk=32, self_attn=True, p=0.1)  # 9 (sample, head) items: a ragged last workgroup
     check_dec_attn(dev, B=2, H=3, Tq=25, Tk=256, self_attn=False)
     check_dec_attn(dev, B=1, H=2, Tq=25, Tk=256, self_attn=False, p=0.1)
     check_tf_loss(dev)
