@@ -109,3 +109,61 @@ def test_dino_import_paths_alias_the_product():
     from Dino.modules import vision_transformer as vits
     import ccd_amd.modules.vision_transformer as native
     assert vits is native and ABIDINOModel.__module__.startswith("ccd_amd") and DINOLoss.__module__.startswith("ccd_amd")
+
+
+def test_finetune_state_dict_matches_reference(golden_dir):
+    """DINO_Finetune's state dict has exactly the reference's keys, in its order (fixture written by
+    the real reference), and the reference's AttnConvertor indices."""
+    import numpy as np
+    from ccd_amd.finetune import FinetuneConfig
+    from ccd_amd.model.dino_vision import DINO_Finetune
+    g = np.load(os.path.join(golden_dir, "finetune_step.npz"))
+    for tag, arch, layers in (("tiny", "vit_tiny", 2), ("small", "vit_small", 6)):
+        torch.manual_seed(0)
+        m = DINO_Finetune(FinetuneConfig(arch=arch, decoder_n_layers=layers))
+        assert list(m.state_dict().keys()) == [str(n) for n in g[f"{tag}/init_names"]]
+        conv = m.label_convertor
+        assert (conv.num_classes(), conv.start_idx, conv.end_idx, conv.padding_idx, conv.unknown_idx) == (93, 91, 91, 92, 90)
+        words = [str(w) for w in g["words"]]
+        np.testing.assert_array_equal(conv.str2tensor(words[:4 if tag == "tiny" else 8]).numpy(), g[f"{tag}/targets"])
+    idx, scores = conv.tensor2idx(torch.nn.functional.one_hot(conv.str2tensor(["Wor1d!"])[:, 1:], 93).float() * 20)
+    assert conv.idx2str(idx) == ["Wor1d!"] and len(scores[0]) == 6
+
+
+def test_reference_checkpoint_layout_round_trip(golden_dir, tmp_path):
+    """a checkpoint in the published layout ({student, teacher, ...}, DDP `module.` prefix, the key /
+    shape table of the real reference) loads strictly into the build, exports bit-identically, and its teacher is picked
+    up by the finetune model the way train_finetune.py:190-198 does it."""
+    from ccd_amd.finetune import FinetuneConfig
+    from ccd_amd.model.dino_vision import ABIDINOModel, DINO_Finetune
+    from ccd_amd.modules import vision_transformer as vits
+    from ccd_amd.modules.segmentor import SegHead
+    from ccd_amd.parallel import DataParallel
+    keys = json.load(open(os.path.join(golden_dir, "state_keys.json")))["vit_small"]
+    gen = torch.Generator().manual_seed(7)
+
+    def fabricate(table):
+        sd = {}
+        for k, shape, dt in table:
+            sd["module." + k] = torch.randn(shape, generator=gen) if dt == "torch.float32" else torch.tensor(3, dtype=torch.int64)
+        return sd
+    ckpt = {"student": fabricate(keys["student"]), "teacher": fabricate(keys["teacher"]), "epoch": 3, "iteration": 1234}
+    path = tmp_path / "checkpoint.pth"
+    torch.save(ckpt, path)
+    loaded = torch.load(path, map_location="cpu", weights_only=False)
+    student = DataParallel(ABIDINOModel(vits.vit_small(patch_size=4, drop_path_rate=0.1),
+                                        SegHead(in_channels=384, mla_channels=128, mlahead_channels=64, num_classes=2),
+                                        vits.DINOHead(384, 1024, norm_last_layer=False)))
+    teacher = DataParallel(ABIDINOModel(vits.vit_small(patch_size=4), None, vits.DINOHead(384, 1024)))
+    for net, key in ((student, "student"), (teacher, "teacher")):
+        msg = net.load_state_dict(loaded[key], strict=True)
+        assert not msg.missing_keys and not msg.unexpected_keys
+        out = net.state_dict()
+        assert list(out) == list(loaded[key])
+        assert all(torch.equal(out[k], loaded[key][k]) for k in out)
+    ft = DataParallel(DINO_Finetune(FinetuneConfig(arch="vit_small")))
+    dd = ft.state_dict()
+    picked = [n for n in dd if n in loaded["teacher"]]
+    ft.load_state_dict({n: loaded["teacher"].get(n, v) for n, v in dd.items()})
+    assert len(picked) == 156 and all(n.startswith("module.backbone.") for n in picked)      # the whole ViT backbone
+    assert all(torch.equal(ft.state_dict()[n], loaded["teacher"][n]) for n in picked)
