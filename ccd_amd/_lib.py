@@ -74,6 +74,7 @@ SIGNATURES = {
     "ccd_cls_grad_cols": [P, P, I, I, I, P],
     "ccd_permute4": [P, P, P, P, P, I, P],
     "ccd_dropout": [P, I, P, P, I, L, U64, F, P],
+    "ccd_droppath_scales": [P, P, I, I, U64, P],
     "ccd_dec_embed_fwd": [P, P, P, P, I, I, I, I, U64, F, P],
     "ccd_dec_embed_bwd": [P, P, P, I, I, I, I, U64, F, P],
     "ccd_dec_attn_fwd": [P, L, P, L, P, L, P, L, P, P, P, P, I, I, I, I, I, I, F, U64, F, P],

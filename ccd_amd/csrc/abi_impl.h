@@ -762,6 +762,15 @@ int ccd_dropout(const void* src, int src_bf16, const float* resid, void* dst, in
     else CCD_LAUNCH((ccd::dropout_kernel<false, false>), grid, block, 0, stream, src, resid, dst, n, sd, thr, scale);
     return ccd_rt_last_error();
 }
+int ccd_droppath_scales(const float* keep, float* out, int per_block, int nblocks, uint64_t seed, void* stream) {
+    CCD_CHECK(keep && out && per_block >= 0 && nblocks >= 0, CCD_EINVAL);
+    const long n = (long)per_block * nblocks;
+    if (n == 0) return CCD_OK;
+    CCD_CHECK(n < (1L << 31), CCD_ESHAPE);
+    CCD_LAUNCH(ccd::droppath_scales_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, keep, out, per_block, nblocks,
+               (unsigned long long)seed);
+    return ccd_rt_last_error();
+}
 int ccd_dec_embed_fwd(const int64_t* tokens, const float* emb, const float* pos, float* x, int rows, int T, int D,
                       int num_classes, uint64_t seed, float p, void* stream) {
     CCD_CHECK(tokens && emb && pos && x && rows >= 0 && p >= 0.f && p < 1.f, CCD_EINVAL);

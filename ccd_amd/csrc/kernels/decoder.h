@@ -57,6 +57,19 @@ __global__ __launch_bounds__(256) void dropout_kernel(const void* __restrict__ s
     }
 }
 
+// DropPath (vision_transformer.py:27-35) for a whole backbone pass: out[blk][j] = Bernoulli(keep[blk]) / keep[blk], one
+// value per (block, branch, sample); consumed as the GEMM epilogues' per-sample row scale.
+__global__ __launch_bounds__(256) void droppath_scales_kernel(const float* __restrict__ keep, float* __restrict__ out,
+                                                              int per_block, int nblocks, unsigned long long seed) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_block * nblocks) return;
+    const float k = keep[i / per_block];
+    if (k >= 1.0f) { out[i] = 1.0f; return; }
+    const double t = (1.0 - (double)k) * 4294967296.0;
+    const unsigned thr = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    out[i] = drop_keep(seed, (unsigned long long)i, thr) ? 1.0f / k : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------- embedding
 // x[r, :] = emb[tok[r], :] + pos[r % T, :]   then dropout;  one wave per row, D % 4 == 0
 __global__ __launch_bounds__(256) void dec_embed_fwd_kernel(const long long* __restrict__ tok, const float* __restrict__ emb,

@@ -25,6 +25,24 @@ class VitSpec:
     def __init__(self, embed_dim, depth, heads, taps, patch=4, eps=1e-6, drop_path_rate=0.0):
         self.E, self.depth, self.heads, self.taps, self.patch, self.eps = embed_dim, depth, heads, tuple(taps), patch, eps
         self.dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]   # vision_transformer.py:150
+        self._keep = {}
+
+    def keep_probs(self, device):
+        """1 - drop probability of every block, fp32 on `device` (cached)."""
+        if device not in self._keep:
+            self._keep[device] = torch.tensor([1.0 - d for d in self.dpr], dtype=F32, device=device)
+        return self._keep[device]
+
+
+_DROPPATH_SEED = {"base": None, "calls": 0}
+
+
+def _next_droppath_seed():
+    """Host-side seed stream: the base is drawn from torch's (seedable) CPU generator at first use."""
+    if _DROPPATH_SEED["base"] is None:
+        _DROPPATH_SEED["base"] = int(torch.randint(0, 2 ** 62, (1,)).item())
+    _DROPPATH_SEED["calls"] += 1
+    return _DROPPATH_SEED["base"] + _DROPPATH_SEED["calls"] * 0x632BE59BD9B4E019
 
 
 # ------------------------------------------------------------------------------------------------ pos-embed resampling
@@ -85,15 +103,14 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
     # E <= 384): proj -> norm2 of the same block, fc2 -> norm1 of the next block / the final norm
     fuse_ln = E <= 384 and os.environ.get("CCD_FUSE_LN", "1") != "0"
     pending = None                               # (y, mean, rstd) of the coming norm1, made by the previous fc2
+    # DropPath: per-(block, branch, sample) keep mask / keep_prob (vision_transformer.py:27-35), one kernel per pass
+    scales = ops.droppath_scales(spec.keep_probs(dev), N, _next_droppath_seed()) if training and max(spec.dpr) > 0.0 else None
     for i in range(spec.depth):
         b = f"{pre}blocks.{i}."
         c = _BlockCtx()
         c.ds1 = c.ds2 = None
-        if training and spec.dpr[i] > 0.0:       # DropPath: per-sample keep mask / keep_prob (vision_transformer.py:27-35)
-            keep = 1.0 - spec.dpr[i]
-            r = torch.rand((2, N), device=dev)
-            m = torch.floor(r + keep) / keep
-            c.ds1, c.ds2 = m[0].contiguous(), m[1].contiguous()
+        if scales is not None and spec.dpr[i] > 0.0:
+            c.ds1, c.ds2 = scales[i, 0], scales[i, 1]
         c.x_in = x
         if pending is None:
             c.y1, c.mean1, c.rstd1 = ops.ln_fwd(x, arena.w(b + "norm1.weight"), arena.w(b + "norm1.bias"), spec.eps)

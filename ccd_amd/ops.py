@@ -529,6 +529,14 @@ def dropout(src, p, seed, *, resid=None, out=None, out_dtype=None):
     return out
 
 
+def droppath_scales(keep, samples, seed):
+    """keep fp32 [depth] (device) -> fp32 [depth, 2, samples]: per-(block, branch, sample) DropPath scale (0 or 1/keep)."""
+    _chk(keep, F32, "keep")
+    out = torch.empty((keep.shape[0], 2, samples), dtype=F32, device=keep.device)
+    _call("ccd_droppath_scales", _lib.ptr(keep), _lib.ptr(out), 2 * samples, keep.shape[0], int(seed) & 0xFFFFFFFFFFFFFFFF)
+    return out
+
+
 def dec_embed_fwd(tokens, emb, pos, p=0.0, seed=0):
     """tokens int64 [B,T] -> x fp32 [B*T, D] = dropout(emb[tokens] + pos[:T])."""
     assert tokens.dtype == I64 and tokens.is_contiguous()

@@ -230,6 +230,9 @@ int ccd_permute4(const float* src, const long* src_strides, const long* dst_stri
  * src / dst: fp32 or bf16 (flags), resid fp32 or NULL; n % 4 == 0; dst may alias src. */
 int ccd_dropout(const void* src, int src_bf16, const float* resid, void* dst, int dst_bf16, long n, uint64_t seed, float p,
                 void* stream);
+/* DropPath scales of one backbone pass (vision_transformer.py:27-35,107-113): out[blk*per_block + j] = keep_j / keep[blk]
+ * with keep_j ~ Bernoulli(keep[blk]) from the same counter-based generator (keep: device array [nblocks]). */
+int ccd_droppath_scales(const float* keep, float* out, int per_block, int nblocks, uint64_t seed, void* stream);
 /* x[r,:] = dropout(trg_word_emb[tokens[r]] + position_table[r % T])   (nrtr_decoder.py:93-95); D % 4 == 0 */
 int ccd_dec_embed_fwd(const int64_t* tokens, const float* emb, const float* pos, float* x, int rows, int T, int D,
                       int num_classes, uint64_t seed, float p, void* stream);

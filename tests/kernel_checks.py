@@ -641,6 +641,19 @@ def check_dropout(dev, seed=40):
     assert (drop_keep_ref(sd + 1, n, p) != keep).any()
 
 
+def check_droppath(dev):
+    keep = torch.tensor([1.0, 0.9, 0.5])
+    out = ops.droppath_scales(keep.to(dev), 4000, 99).cpu()
+    assert out.shape == (3, 2, 4000) and (out[0] == 1).all()
+    for i, k in ((1, 0.9), (2, 0.5)):
+        vals = set(out[i].unique().tolist())
+        assert vals == {0.0, float(torch.tensor(1.0) / torch.tensor(k))}, vals
+        assert abs((out[i] > 0).float().mean().item() - k) < 0.03
+    ref = drop_keep_ref(99, 3 * 8000, 0.5).view(3, 2, 4000)
+    assert torch.equal(out[2] > 0, ref[2])
+    assert not torch.equal(out, ops.droppath_scales(keep.to(dev), 4000, 100).cpu())
+
+
 def check_dec_embed(dev, B=5, T=25, D=128, C=93, seed=41):
     g = torch.Generator().manual_seed(seed)
     tok = torch.randint(0, C - 1, (B, T), generator=g)
@@ -753,6 +766,7 @@ def check_decoder_pieces(dev):
     finally:
         del os.environ["CCD_DEC_ATTN_SIMT"]
     check_dropout(dev)
+    check_droppath(dev)
     check_dec_embed(dev)
     check_dec_embed(dev, B=50, D=64)                                   # 1250 rows: two row chunks per class
     check_dec_attn(dev, self_attn=True)
