@@ -164,6 +164,50 @@ def main_finetune(a, world, rank, dev, use_dist):
         dist.destroy_process_group()
 
 
+def main_recognize(a, world, rank, dev, use_dist):
+    """Inference of the recogniser: DINO_Finetune.forward_test (dino_vision.py:233-262) = encoder forward + Mlp + 25
+    greedy decoding steps of the 6-layer decoder on a resident synthetic batch; replicas only (no collective)."""
+    from ccd_amd import finetune as ft
+    torch.manual_seed(0)
+    model = ft.build_model(ft.FinetuneConfig(arch=a.arch, drop_path_rate=0.1), dev)
+    model.eval()
+    B = a.batch
+    images = torch.randn(B, 3, 32, 128, generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
+
+    def step():
+        with torch.no_grad():
+            return model(images, None, return_loss=False)
+
+    for _ in range(a.warmup):
+        probs = step()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        probs = step()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+    assert tuple(probs.shape) == (B, 25, 92) and bool(torch.isfinite(probs).all())
+    if rank == 0:
+        line = {"metric": "images/sec (32x128 crops) CCD text recognition, greedy decoding (25 steps)",
+                "value": round(B * world * a.steps / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": f"DINO_Finetune.forward_test {a.arch} bf16, bs={B}/GPU, 6-layer NRTR decoder, 25 greedy "
+                                       f"steps, HIP graph {'on' if os.environ.get('CCD_DECODE_GRAPH', '1') != '0' else 'off'}",
+                           "global_batch": B * world, "parallelism": f"replicas x{world}"}}
+        print(json.dumps(line), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,8 +216,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--arch", default="vit_small")
     ap.add_argument("--out-dim", type=int, default=65536)
-    ap.add_argument("--workload", default="pretrain", choices=["pretrain", "finetune"],
-                    help="pretrain = the BASELINE metric (default); finetune = BASELINE config #5 (SURVEY 8f row 1)")
+    ap.add_argument("--workload", default="pretrain", choices=["pretrain", "finetune", "recognize"],
+                    help="pretrain = the BASELINE metric (default); finetune = BASELINE config #5 (SURVEY 8f row 1); "
+                         "recognize = greedy-decoding inference of the finetuned model (forward_test)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     a = ap.parse_args()
@@ -192,6 +237,8 @@ def main():
 
     if a.workload == "finetune":
         return main_finetune(a, world, rank, dev, use_dist)
+    if a.workload == "recognize":
+        return main_recognize(a, world, rank, dev, use_dist)
 
     from ccd_amd import ops, pretrain
     from ccd_amd.loss.Dino_loss import DINOLoss

@@ -7,6 +7,8 @@ There is no PyTorch-eager fallback.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -94,6 +96,7 @@ class NRTRDecoder(ArenaModule, _DropoutSeeds):
                                        d_inner=d_inner, num_classes=num_classes, max_seq_len=max_seq_len,
                                        start_idx=start_idx, padding_idx=padding_idx, dropout=dropout)
         self.packed = None
+        self._graphs = {}
 
     def _transposed_names(self):
         names = []
@@ -124,7 +127,36 @@ class NRTRDecoder(ArenaModule, _DropoutSeeds):
 
     def forward_test(self, feat, out_enc, img_metas=None):
         self._ready()
-        return fe.greedy_decode(self, out_enc.to(torch.bfloat16))
+        out_enc = out_enc.to(torch.bfloat16)
+        if out_enc.is_cuda and os.environ.get("CCD_DECODE_GRAPH", "1") != "0":
+            return self._graphed_decode(out_enc)
+        return fe.greedy_decode(self, out_enc)
+
+    def _graphed_decode(self, out_enc):
+        """The 25 greedy steps launch ~1 800 small kernels (6 layers x ~12 kernels per step): launch-bound when issued one
+        by one.  The whole loop is captured ONCE per (batch size, arena) into a HIP graph and replayed; the graph reads
+        the arena / packed operands in place, so optimizer steps between evaluations need no re-capture."""
+        key = (tuple(out_enc.shape), out_enc.device, self.arena.flat.data_ptr())
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_in = torch.empty_like(out_enc)
+            static_in.copy_(out_enc)
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream(device=out_enc.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):                  # warm-up outside the capture (lazy one-time kernel attributes)
+                fe.greedy_decode(self, static_in)
+            cur.wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = fe.greedy_decode(self, static_in)
+            if len(self._graphs) >= 4:                     # a few batch shapes at most (last partial batch, ...)
+                self._graphs.pop(next(iter(self._graphs)))
+            entry = self._graphs[key] = (graph, static_in, static_out)
+        graph, static_in, static_out = entry
+        static_in.copy_(out_enc)
+        graph.replay()
+        return static_out.clone()
 
     def forward_test_speed(self, feat, out_enc, img_metas=None):
         self._ready()

@@ -363,6 +363,13 @@ def check_finetune_against_oracle(device, arch="vit_test2", vit_kw=None, n_layer
             feat = model.extract_feat(img.to(device))
             logits, _ = model.decoder(feat, model.encoder(feat), {"padded_targets": targets.to(device)}, train_mode=True)
         assert probs.shape == ref.shape == (B, max_seq_len, 92)
+        # the product decodes incrementally (one new position per step); the reference's full re-run is kept as a checker
+        from ccd_amd import finetune_engine as fe
+        model.eval()
+        with torch.no_grad():
+            full = fe.greedy_decode_full(model.decoder, model.encoder(model.extract_feat(img.to(device))))
+        model.train()
+        assert (full.cpu() - probs).abs().max() < 5e-3, float((full.cpu() - probs).abs().max())
         probs = probs.cpu()
         # greedy decoding feeds its own argmax back: compare a position only while the decoded prefixes agree
         same_prefix = torch.ones(B, dtype=torch.bool)

@@ -54,3 +54,25 @@ def test_finetune_vs_oracle(hip):
 
 def test_finetune_dropout(hip):
     mc.check_finetune_dropout(hip.device, B=8, n_layers=2)
+
+
+def test_greedy_decoding_hip_graph_matches_eager(hip, monkeypatch):
+    """forward_test replays the 25 decoding steps from a captured HIP graph: identical output to issuing the kernels one by
+    one, also after the weights changed (the graph reads the arena in place) and for a second batch shape."""
+    from ccd_amd import finetune as ft
+    torch.manual_seed(2)
+    model = ft.build_model(ft.FinetuneConfig(arch="vit_tiny", drop_path_rate=0.0, decoder_n_layers=2), hip.device)
+    model.eval()
+    g = torch.Generator().manual_seed(5)
+    for B in (16, 16, 5):
+        img = torch.randn(B, 3, 32, 128, generator=g).to(hip.device)
+        with torch.no_grad():
+            monkeypatch.setenv("CCD_DECODE_GRAPH", "1")
+            graphed = model(img, None, return_loss=False)
+            monkeypatch.setenv("CCD_DECODE_GRAPH", "0")
+            eager = model(img, None, return_loss=False)
+        assert graphed.shape == (B, 25, 92) and torch.equal(graphed, eager)
+        with torch.no_grad():                                   # perturb the weights in place between evaluations
+            model.arena.flat.mul_(1.01)
+        model.arena.refresh_mirrors()
+    assert len(model.decoder._graphs) == 2
