@@ -50,7 +50,7 @@ __device__ __forceinline__ bf16x8 xa_zero_frag() {
 // key of accumulator register r in tile kt for a lane of half hf (rows of the 32x32 MFMA result)
 __device__ __forceinline__ int xa_acc_row(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
 
-__global__ __launch_bounds__(256) void xattn_fwd_kernel(DecAttnParams p) {
+__global__ __launch_bounds__(256, 4) void xattn_fwd_kernel(DecAttnParams p) {
     char* smem = dynamic_smem();
     char* vt_img = smem;                                               // later: the merge buffer
     float* st_m = reinterpret_cast<float*>(smem + XA_MERGE);

@@ -369,7 +369,7 @@ def check_finetune_against_oracle(device, arch="vit_test2", vit_kw=None, n_layer
         with torch.no_grad():
             full = fe.greedy_decode_full(model.decoder, model.encoder(model.extract_feat(img.to(device))))
         model.train()
-        assert (full.cpu() - probs).abs().max() < 5e-3, float((full.cpu() - probs).abs().max())
+        assert (full.cpu() - probs.cpu()).abs().max() < 5e-3, float((full.cpu() - probs.cpu()).abs().max())
         probs = probs.cpu()
         # greedy decoding feeds its own argmax back: compare a position only while the decoded prefixes agree
         same_prefix = torch.ones(B, dtype=torch.bool)
