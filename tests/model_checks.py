@@ -495,3 +495,42 @@ def check_finetune_golden(device, tag="tiny", loss_tol=2e-3):
             compared += int(same_prefix.sum())
         same_prefix &= probs[:, t].argmax(-1) == ref[:, t].argmax(-1)
     assert compared >= 4 * B, compared
+
+
+def check_pretrain_arch_vs_oracle(device, arch="vit_base", B=4, out_dim=4096, loss_tol=2e-3):
+    """One pretraining iteration of another shipped architecture (BASELINE config #4: vit_base = E 512 / 8 heads, which
+    takes the non-fused residual / LayerNorm kernels) against the pinned CPU oracle: index maps bit-exact, losses,
+    every gradient norm, centre."""
+    from oracle import ccd_oracle as O
+    torch.manual_seed(0)
+    np.random.seed(0)
+    student, teacher = pretrain.build_networks(arch=arch, out_dim=out_dim, drop_path_rate=0.0, norm_last_layer=False,
+                                               device=device)
+    spec = O.Spec(norm_last_layer=False, out_dim=out_dim, seg_in=O.ARCH[arch]["embed_dim"], **O.ARCH[arch])
+    o_student, o_teacher = O.build_pair(spec, seed=0)
+    sd = student.state_dict()
+    for k in o_student.trainable:
+        assert torch.equal(sd[k].detach().cpu(), o_student.P[k].detach()), f"init differs: {k}"
+    dino_loss = DINOLoss(out_dim, 2, 0.04, 0.04, 0, 40).to(device)
+    opt = pretrain.make_optimizer(student, clip_grad=3.0)
+    images, masks, metrics = make_batch(B, seed=21, device=device)
+    captured = {}
+    orig = student.forward
+    student.forward = lambda *a, **k: captured.setdefault("out", orig(*a, **k))
+    loss = pretrain.training_iteration(student, teacher, dino_loss, opt, images, masks, metrics, 1, 1e-4, 0.04, 0.9995)
+    student.forward = orig
+    rec = O.train_iteration(o_student, o_teacher, torch.zeros(1, out_dim), O.AdamWState(), make_batch(B, seed=21), 1, 1e-4,
+                            0.04, 0.9995, exact_zero_rows=True)
+    out = captured["out"]
+    np.testing.assert_array_equal(out.raw("selection").idmap.cpu().numpy(), rec["s_out"]["idmap"])
+    np.testing.assert_array_equal(out["index"].cpu().numpy(), rec["s_out"]["index"].numpy())
+    got = np.array([loss.item(), dino_loss.last_losses["mask_loss"].item(), dino_loss.last_losses["Dino_loss"].item()])
+    want = np.array([rec["loss"], rec["mask_loss"], rec["dino_loss"]])
+    np.testing.assert_allclose(got, want, atol=loss_tol, rtol=0)
+    assert float((dino_loss.center.cpu() - rec["center"]).abs().max()) < 3e-3
+    for name, g_ref in rec["grads_raw"].items():
+        want_l2 = g_ref.double().pow(2).sum().sqrt().item()
+        got_l2 = student.arena.g(name).double().pow(2).sum().sqrt().item()
+        if want_l2 > 1e-5 and name not in NOISE_DOMINATED:
+            assert abs(got_l2 - want_l2) <= 8e-2 * want_l2, f"grad norm {name}: {got_l2} vs oracle {want_l2}"
+    return {"hip": got.tolist(), "oracle": want.tolist()}

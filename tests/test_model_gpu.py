@@ -76,3 +76,10 @@ def test_greedy_decoding_hip_graph_matches_eager(hip, monkeypatch):
             model.arena.flat.mul_(1.01)
         model.arena.refresh_mirrors()
     assert len(model.decoder._graphs) == 2
+
+
+@pytest.mark.parametrize("arch", ["vit_base", "vit_tiny"])
+def test_other_archs_pretrain_iteration_vs_oracle(hip, arch):
+    """BASELINE config #4's architecture (vit_base: E 512 / 8 heads, unfused residual + LayerNorm path) and vit_tiny."""
+    rep = mc.check_pretrain_arch_vs_oracle(hip.device, arch)
+    print(arch, rep)
