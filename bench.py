@@ -159,9 +159,11 @@ def main_finetune(a, world, rank, dev, use_dist):
                                 "by_kind_tflops": {k: round(v["flops"] / v["ms"] / 1e9, 1) for k, v in sorted(summ.items())}}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = finetune_cpu_baseline(a.arch)
-        print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:                      # after the teardown: the JSON line is the LAST thing on stdout (RCCL logs its path)
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 def main_recognize(a, world, rank, dev, use_dist):
@@ -203,9 +205,11 @@ def main_recognize(a, world, rank, dev, use_dist):
                 "config": {"workload": f"DINO_Finetune.forward_test {a.arch} bf16, bs={B}/GPU, 6-layer NRTR decoder, 25 greedy "
                                        f"steps, HIP graph {'on' if os.environ.get('CCD_DECODE_GRAPH', '1') != '0' else 'off'}",
                            "global_batch": B * world, "parallelism": f"replicas x{world}"}}
-        print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:                      # after the teardown: the JSON line is the LAST thing on stdout (RCCL logs its path)
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 def main():
@@ -333,9 +337,11 @@ def main():
                                 "by_kind_tflops": {k: round(v["flops"] / v["ms"] / 1e9, 1) for k, v in sorted(summ.items())}}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.arch)
-        print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:                      # after the teardown: the JSON line is the LAST thing on stdout (RCCL logs its path)
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
