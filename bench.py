@@ -59,6 +59,18 @@ def pmc_traffic(kind, a):
     return rec["bytes_per_launch"] if rec else None
 
 
+def emit(line):
+    """Print the result as the LAST line of stdout: librccl logs its path through C stdio, which is block-buffered on a
+    pipe and would otherwise be flushed after Python's output at exit."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    print(json.dumps(line), flush=True)
+
+
 def finetune_cpu_baseline(arch, B=8, steps=2):
     """The CPU oracle of the finetune step (oracle/finetune_oracle.py) on this host: B=8, fp32, dropout off."""
     from oracle import ccd_oracle as O
@@ -161,9 +173,8 @@ def main_finetune(a, world, rank, dev, use_dist):
             line["cpu_baseline"] = finetune_cpu_baseline(a.arch)
     if use_dist:
         dist.destroy_process_group()
-    if rank == 0:                      # after the teardown: the JSON line is the LAST thing on stdout (RCCL logs its path)
-        sys.stdout.flush()
-        print(json.dumps(line), flush=True)
+    if rank == 0:
+        emit(line)
 
 
 def main_recognize(a, world, rank, dev, use_dist):
@@ -207,9 +218,8 @@ def main_recognize(a, world, rank, dev, use_dist):
                            "global_batch": B * world, "parallelism": f"replicas x{world}"}}
     if use_dist:
         dist.destroy_process_group()
-    if rank == 0:                      # after the teardown: the JSON line is the LAST thing on stdout (RCCL logs its path)
-        sys.stdout.flush()
-        print(json.dumps(line), flush=True)
+    if rank == 0:
+        emit(line)
 
 
 def main():
@@ -339,9 +349,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(a.arch)
     if use_dist:
         dist.destroy_process_group()
-    if rank == 0:                      # after the teardown: the JSON line is the LAST thing on stdout (RCCL logs its path)
-        sys.stdout.flush()
-        print(json.dumps(line), flush=True)
+    if rank == 0:
+        emit(line)
 
 
 if __name__ == "__main__":
