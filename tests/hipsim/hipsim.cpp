@@ -4,12 +4,55 @@
 #include <sys/mman.h>
 
 #include <mutex>
+#include <vector>
 
 namespace sim {
 thread_local Lane* cur = nullptr;
 thread_local Block* curblk = nullptr;
 
 static constexpr size_t STACK_BYTES = 256 * 1024;
+
+// void sim_switch(Ctx* from, Ctx* to): push the SysV callee-saved registers, swap stack pointers, pop, return.
+asm(R"(
+    .text
+    .globl sim_switch
+    .type sim_switch,@function
+sim_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq (%rsi), %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size sim_switch, .-sim_switch
+)");
+
+// Fiber stacks are recycled between launches (a fresh mmap per launch paid its page faults again every time).
+static std::mutex stack_mu;
+static std::vector<void*> stack_pool;
+static void* stack_get() {
+    {
+        std::lock_guard<std::mutex> g(stack_mu);
+        if (!stack_pool.empty()) { void* s = stack_pool.back(); stack_pool.pop_back(); return s; }
+    }
+    void* s = mmap(nullptr, STACK_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
+    if (s == MAP_FAILED) { std::perror("mmap"); std::abort(); }
+    return s;
+}
+static void stack_put(std::vector<void*>& v) {
+    std::lock_guard<std::mutex> g(stack_mu);
+    for (void* s : v) stack_pool.push_back(s);
+    v.clear();
+}
 
 static void lane_entry() {
     Lane* l = cur;
@@ -22,7 +65,8 @@ static void lane_entry() {
     if (w.alive > 0 && w.arrived >= w.alive) { w.arrived = 0; ++w.gen; }
     --b->alive;
     if (b->alive > 0 && b->arrived >= b->alive) { b->arrived = 0; ++b->gen; }
-    swapcontext(&l->ctx, &b->sched);
+    sim_switch(&l->ctx, &b->sched);
+    std::abort();                                    // a finished lane is never resumed
 }
 
 static void run_block(Block& b, std::vector<void*>& stacks) {
@@ -42,11 +86,14 @@ static void run_block(Block& b, std::vector<void*>& stacks) {
         l.blk = &b;
         l.stack = stacks[t];
         b.waves[l.wave].alive++;
-        getcontext(&l.ctx);
-        l.ctx.uc_stack.ss_sp = l.stack;
-        l.ctx.uc_stack.ss_size = STACK_BYTES;
-        l.ctx.uc_link = nullptr;
-        makecontext(&l.ctx, (void (*)())lane_entry, 0);
+        // initial frame: six zeroed callee-saved registers, then lane_entry as the "return address"; after that `ret`
+        // rsp == top - 8, i.e. the alignment a function sees right after a call
+        uintptr_t top = (reinterpret_cast<uintptr_t>(l.stack) + STACK_BYTES) & ~uintptr_t(15);
+        void** frame = reinterpret_cast<void**>(top - 64);
+        for (int i = 0; i < 6; ++i) frame[i] = nullptr;
+        frame[6] = reinterpret_cast<void*>(&lane_entry);
+        frame[7] = nullptr;
+        l.ctx.rsp = frame;
     }
     curblk = &b;
     int remaining = nthreads;
@@ -59,7 +106,7 @@ static void run_block(Block& b, std::vector<void*>& stacks) {
             if (l.wait_kind == 2 && b.gen == l.wait_gen) continue;
             l.wait_kind = 0;
             cur = &l;
-            swapcontext(&b.sched, &l.ctx);
+            sim_switch(&b.sched, &l.ctx);
             progressed = true;
             if (l.done) --remaining;
         }
@@ -82,10 +129,7 @@ void launch(dim3 grid, dim3 block, size_t dyn_smem, const std::function<void()>&
     std::atomic<size_t> next{0};
     auto worker = [&]() {
         std::vector<void*> stacks(nthreads);
-        for (auto& s : stacks) {
-            s = mmap(nullptr, STACK_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
-            if (s == MAP_FAILED) { std::perror("mmap"); std::abort(); }
-        }
+        for (auto& s : stacks) s = stack_get();
         std::vector<char> smem(dyn_smem + 64);
         Block b;
         b.bdim = block;
@@ -98,7 +142,7 @@ void launch(dim3 grid, dim3 block, size_t dyn_smem, const std::function<void()>&
             b.bid = dim3(i % grid.x, (i / grid.x) % grid.y, i / ((size_t)grid.x * grid.y));
             run_block(b, stacks);
         }
-        for (auto& s : stacks) munmap(s, STACK_BYTES);
+        stack_put(stacks);
     };
     std::vector<std::thread> pool;
     for (size_t w = 1; w < nworkers; ++w) pool.emplace_back(worker);

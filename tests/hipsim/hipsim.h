@@ -5,10 +5,10 @@
 // time is scarce).  It provides the handful of names ccd_amd/csrc/prelude_hip.h provides on the device:
 // __global__/__shared__/threadIdx/.../__syncthreads, wave64 shuffles, atomics and an emulation of the
 // MFMA instructions with the documented gfx950 operand/accumulator layouts (MI355X guide section 3).
-// Every lane is a ucontext fiber; a workgroup is run by one OS thread, workgroups run in parallel.
+// Every lane is a fiber (a hand-rolled x86-64 context switch: no signal-mask system calls, unlike swapcontext); a
+// workgroup is run by one OS thread, workgroups run in parallel.
 // It is NOT a compatibility layer of the product: ccd_amd never loads anything built from this file.
 #pragma once
-#include <ucontext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -37,12 +37,14 @@ typedef void* hipStream_t;
 namespace sim {
 constexpr int WAVE = 64;
 struct Block;
+struct Ctx { void* rsp = nullptr; };                 // callee-saved registers live on the fiber's own stack
+extern "C" void sim_switch(Ctx* from, Ctx* to);
 struct Lane {
     dim3 tid;
     int linear = 0;
     int wave = 0;
     int lane = 0;
-    ucontext_t ctx;
+    Ctx ctx;
     bool done = false;
     int wait_kind = 0;       // 0 runnable, 1 waiting wave barrier, 2 waiting block barrier
     unsigned wait_gen = 0;
@@ -60,14 +62,14 @@ struct Block {
     std::vector<WaveState> waves;
     int alive = 0, arrived = 0;
     unsigned gen = 0;
-    ucontext_t sched;
+    Ctx sched;
     char* dyn_smem = nullptr;
     const std::function<void()>* body = nullptr;
 };
 extern thread_local Lane* cur;
 extern thread_local Block* curblk;
 
-inline void yield_to_scheduler() { swapcontext(&cur->ctx, &cur->blk->sched); }
+inline void yield_to_scheduler() { sim_switch(&cur->ctx, &cur->blk->sched); }
 
 inline void wave_sync() {
     Lane* l = cur;
