@@ -23,7 +23,7 @@ def test_checkpoint_resume_sim(sim, tmp_path):
 
 def test_finetune_against_oracle_sim(sim):
     """DINO_Finetune (2-block backbone, 2 decoder layers) - loss, gradients, AdamW, greedy decoding."""
-    mc.check_finetune_against_oracle(sim.device, B=2, max_seq_len=9, steps=1)
+    mc.check_finetune_against_oracle(sim.device, B=3, max_seq_len=25, steps=2)
 
 
 def test_finetune_dropout_sim(sim):
