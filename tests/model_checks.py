@@ -534,3 +534,68 @@ def check_pretrain_arch_vs_oracle(device, arch="vit_base", B=4, out_dim=4096, lo
         if want_l2 > 1e-5 and name not in NOISE_DOMINATED:
             assert abs(got_l2 - want_l2) <= 8e-2 * want_l2, f"grad norm {name}: {got_l2} vs oracle {want_l2}"
     return {"hip": got.tolist(), "oracle": want.tolist()}
+
+
+def check_finetune_properties_full_size(device, B=512):
+    """BASELINE config #5 at its full batch (vit_small, 6 layers, B = 512): size-independent properties.
+    (a) the returned loss equals torch's TFLoss on the returned logits; (b) eval-mode attention rows sum to 1 and the
+    counter-based dropout keeps ~90 %; (c) same seeds -> same loss, finite gradients everywhere they should be;
+    (d) decoded probabilities sum to 1, the incremental decoder equals the reference schedule, forward_test_speed stops
+    at sample 0's <EOS>."""
+    import torch.nn.functional as F
+    from ccd_amd import finetune as ft, finetune_engine as fe
+    torch.manual_seed(0)
+    model = ft.build_model(ft.FinetuneConfig(arch="vit_small", drop_path_rate=0.1), device)
+    g = torch.Generator().manual_seed(8)
+    img = torch.randn(B, 3, 32, 128, generator=g).to(device)
+    words = ["".join(model.label_convertor.idx2char[int(c)] for c in torch.randint(0, 90, (int(n),), generator=g))
+             for n in torch.randint(1, 30, (B,), generator=g)]                       # some longer than max_seq_len
+    targets = model.label_convertor.str2tensor(words).to(device)
+    pad = model.label_convertor.padding_idx
+    # (a) + (b, eval)
+    model.eval()
+    feat = model.extract_feat(img)
+    logits, attn = model.decoder(feat, model.encoder(feat), {"padded_targets": targets}, train_mode=True)
+    loss = model.loss(logits, {"padded_targets": targets})
+    ref = F.cross_entropy(logits.float()[:, :-1].reshape(-1, 92), targets[:, 1:].reshape(-1), ignore_index=pad)
+    assert abs(loss.item() - ref.item()) < 1e-4, (loss.item(), ref.item())
+    assert attn.shape == (B, 8, 25, 256) and (attn.sum(-1) - 1).abs().max() < 2e-3
+    # (b, train) + (c)
+    model.train()
+    outs = []
+    for rep in range(2):
+        for m in (model.encoder, model.decoder):
+            m._base, m._calls = 4242, 0
+        from ccd_amd import engine
+        engine._DROPPATH_SEED.update(base=77, calls=0)
+        l, a = model(img, targets)
+        model.arena.zero_grad()
+        l.backward()
+        outs.append(l.item())
+    assert abs(outs[0] - outs[1]) < 1e-5, outs
+    kept = (a != 0).float().mean().item()
+    assert 0.89 < kept < 0.91, kept
+    assert (a.sum(-1) - 1).abs().mean() < 0.05                                     # E[dropout(p)/0.9] = p
+    grad = model.arena.grad
+    assert torch.isfinite(grad).all()
+    for n in ("backbone.patch_embed.proj.weight", "encoder.fc1.weight", "decoder.trg_word_emb.weight",
+              "decoder.layer_stack.0.self_attn.linear_k.weight", "decoder.layer_stack.5.enc_attn.linear_v.weight",
+              "decoder.classifier.bias"):
+        assert float(model.arena.g(n).abs().max()) > 0, n
+    assert float(model.arena.g("decoder.trg_word_emb.weight")[pad].abs().max()) == 0.0      # padding_idx row frozen
+    for n in model.unused_parameter_names():
+        assert float(model.arena.g(n).abs().max()) == 0.0, n
+    # (d)
+    model.eval()
+    with torch.no_grad():
+        probs = model(img, None, return_loss=False)
+        enc = model.encoder(model.extract_feat(img))
+        full = fe.greedy_decode_full(model.decoder, enc[:64])
+        speed = model(img, None, return_loss=False, test_speed=True)
+    assert probs.shape == (B, 25, 92) and (probs.sum(-1) - 1).abs().max() < 1e-4
+    assert (full - probs[:64]).abs().max() < 5e-3
+    n = speed.shape[1]
+    assert torch.equal(speed, probs[:, :n])
+    first = probs[0].argmax(-1).tolist()
+    flat_hit = [int(probs[:, t].reshape(-1).argmax()) == 91 for t in range(25)]
+    assert n == (flat_hit.index(True) + 1 if True in flat_hit else 25), (n, first)

@@ -83,3 +83,7 @@ def test_other_archs_pretrain_iteration_vs_oracle(hip, arch):
     """BASELINE config #4's architecture (vit_base: E 512 / 8 heads, unfused residual + LayerNorm path) and vit_tiny."""
     rep = mc.check_pretrain_arch_vs_oracle(hip.device, arch)
     print(arch, rep)
+
+
+def test_finetune_properties_at_full_batch(hip):
+    mc.check_finetune_properties_full_size(hip.device)
