@@ -140,8 +140,8 @@ static bool ccd_env_flag(const char* name, bool dflt) {
 
 extern "C" {
 
-int ccd_abi_version(void) { return 1; }
-const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi1"; }
+int ccd_abi_version(void) { return 2; }   // 2: finetune-path entry points (ccd_dropout ... ccd_greedy_step, ccd_droppath_scales)
+const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi2"; }
 
 // ----------------------------------------------------------------------------------------------- GEMM
 int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, int epilogue, void* C,
