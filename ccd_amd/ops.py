@@ -17,10 +17,13 @@ class KernelTimer:
     """Optional per-launch timing with HIP events on the launching stream (bench.py's roofline leg).  Events are
     only read after the timed region has been synchronised, so recording them never stalls the stream."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []          # (key, flops, algorithmic bytes, start_event, end_event)
+        self.only = only           # optional set of keys: every other launch runs without events
 
     def span(self, key, flops, nbytes=0.0):
+        if self.only is not None and key not in self.only:
+            return None
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.records.append((key, flops, nbytes, e0, e1))
         return e0, e1
