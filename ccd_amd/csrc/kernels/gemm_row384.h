@@ -141,11 +141,14 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
         const bool elive = nk > 0;
         const unsigned next = item + nx;
         const bool has_next = next < cnt_x;
-        if (has_next && EPI != EPI_RESID_LN) {               // next tile's first two k-tiles fly under the epilogue
+        if (has_next) {                                      // next tile's first two k-tiles fly under the epilogue
             setup(next);
-            load(0, ra0, rb0);
-            load(1, ra1, rb1);
+            if (EPI != EPI_RESID_LN) {                       // (the fused-LayerNorm epilogue requests them itself, below)
+                load(0, ra0, rb0);
+                load(1, ra1, rb1);
+            }
         }
+        bool prefetched = false;                             // EPI_RESID_LN: next tile requested from inside the epilogue
         if (elive) {
             // ---- epilogue: staged rows per pass: bf16 64 (both wm halves), fp32 32 (one wm half) -> <= 48 KiB
             constexpr bool STAGE_BF16 = (EPI == EPI_BF16);
@@ -171,8 +174,12 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
 #pragma unroll
                 for (int h = 0; h < 2 / WMP; ++h) {
                     const int sr = (WMP == 2 ? 32 * wm : 0) + lq;
-                    // fused-LayerNorm epilogue: the residual rows of this pass are requested before the staging writes
-                    // and the barrier, so their latency is not paid serially inside the row sweep
+                    // fused-LayerNorm epilogue: the next tile's first two k-tiles are requested after the LAST staging write
+                    // below (all accumulators dead: their registers hold the pieces) - before the global stores of the last
+                    // pass, so the loads do not queue behind those (gfx950 counts stores and loads on one in-order vmcnt).
+                    // (Requesting the first k-tile two passes earlier, when half of the accumulators are dead, spills.)
+                    // the residual rows of this pass are requested before the staging writes and the barrier, so their
+                    // latency is not paid serially inside the row sweep
                     f32x4v rpre[2][3];
                     if (EPI == EPI_RESID_LN) {
 #pragma unroll
@@ -213,6 +220,10 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
                     }
                     constexpr bool fuse_ln = EPI == EPI_RESID_LN;
                     lds_barrier();
+                    if (fuse_ln && q == 1 && h == 1 && has_next) {       // every accumulator has been staged
+                        load(0, ra0, rb0);
+                        prefetched = true;
+                    }
                     if (fuse_ln) {
                         // residual epilogue + LayerNorm of the finished rows.  Half a wave owns one row (32 lanes x three
                         // 16-byte chunks = 384 columns): the row sums are five shuffles, no LDS traffic, one sweep.
@@ -308,9 +319,8 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
             }
         }
         if (!has_next) break;
-        if (EPI == EPI_RESID_LN) {                           // (its epilogue needs the registers the prefetch would hold)
-            setup(next);
-            load(0, ra0, rb0);
+        if (EPI == EPI_RESID_LN) {
+            if (!prefetched) load(0, ra0, rb0);              // tile without work: nothing was requested in its epilogue
             load(1, ra1, rb1);
         }
         item = next;
