@@ -813,6 +813,7 @@ static int ccd_dec_attn_check(const ccd::DecAttnParams& p) {
 int ccd_dec_attn_fwd(const ccd_bf16* q, long ldq, const ccd_bf16* k, long ldk, const ccd_bf16* v, long ldv, ccd_bf16* out,
                      long ldo, float* lse, float* probs, const int64_t* tokens, const int* key_len, int pad_idx, int causal,
                      int B, int H, int Tq, int Tk, float scale, uint64_t seed, float p, void* stream) {
+    if (B == 0) return CCD_OK;                               // empty batch: nothing to do (pointers may be null)
     CCD_CHECK(q && k && v && out && lse && p >= 0.f && p < 1.f, CCD_EINVAL);
     ccd::DecAttnParams a = ccd::DecAttnParams();
     a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.out = out; a.ldo = ldo; a.lse = lse; a.probs = probs;
@@ -837,6 +838,7 @@ int ccd_dec_attn_bwd(const ccd_bf16* q, long ldq, const ccd_bf16* k, long ldk, c
                      const ccd_bf16* out, const ccd_bf16* d_out, long ldo, const float* lse, const int64_t* tokens,
                      const int* key_len, int pad_idx, int causal, int B, int H, int Tq, int Tk, float scale, uint64_t seed,
                      float p, ccd_bf16* dq, long lddq, ccd_bf16* dk, long lddk, ccd_bf16* dv, long lddv, void* stream) {
+    if (B == 0) return CCD_OK;
     CCD_CHECK(q && k && v && out && d_out && lse && dq && dk && dv && p >= 0.f && p < 1.f, CCD_EINVAL);
     ccd::DecAttnParams a = ccd::DecAttnParams();
     a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.out = const_cast<ccd_bf16*>(out); a.ldo = ldo;

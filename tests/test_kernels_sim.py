@@ -139,3 +139,27 @@ def test_gemm_resid_ln_sim(sim):
 
 def test_decoder_pieces_sim(sim):
     kc.check_decoder_pieces(sim.device)
+
+
+def test_decoder_abi_rejects_unsupported_arguments(sim):
+    """Argument errors of the finetune-path entry points come back as error codes (-> RuntimeError), never as launches."""
+    import torch
+    from ccd_amd import ops
+    bf = torch.bfloat16
+    q = torch.zeros((2 * 40, 128), dtype=bf)
+    with pytest.raises(RuntimeError, match="unsupported shape"):          # 40 queries > 32
+        ops.dec_attn_fwd(q, q, q, 2, 2, 40, 40, 0.125)
+    k = torch.zeros((2 * 300, 128), dtype=bf)
+    with pytest.raises(RuntimeError, match="unsupported shape"):          # 300 keys > 256
+        ops.dec_attn_fwd(q[:2 * 25], k, k, 2, 2, 25, 300, 0.125)
+    with pytest.raises(RuntimeError, match="invalid argument"):           # dropout probability outside [0, 1)
+        ops.dropout(torch.zeros(64), 1.0, 1)
+    with pytest.raises(RuntimeError, match="unsupported shape"):          # element count not a multiple of 4
+        ops.dropout(torch.zeros(6), 0.1, 1)
+    logits = torch.zeros((50, 200))
+    with pytest.raises(RuntimeError, match="unsupported shape"):          # more than 128 classes
+        ops.tf_loss_fwd(logits, 200, torch.zeros((2, 25), dtype=torch.int64), 92)
+    # empty batches are a no-op, not an error
+    e = torch.zeros((0, 128), dtype=bf)
+    out, lse, _ = ops.dec_attn_fwd(e, e, e, 0, 2, 25, 25, 0.125)
+    assert out.shape == (0, 128)
