@@ -748,8 +748,9 @@ static void ccd_drop_consts(float p, unsigned* thr, float* scale) {
 }
 int ccd_dropout(const void* src, int src_bf16, const float* resid, void* dst, int dst_bf16, long n, uint64_t seed, float p,
                 void* stream) {
-    CCD_CHECK(src && dst && n >= 0 && p >= 0.f && p < 1.f, CCD_EINVAL);
+    CCD_CHECK(n >= 0 && p >= 0.f && p < 1.f, CCD_EINVAL);
     if (n == 0) return CCD_OK;
+    CCD_CHECK(src && dst, CCD_EINVAL);
     CCD_CHECK(n % 4 == 0 && CCD_ALIGNED16(resid), CCD_ESHAPE);
     CCD_CHECK((((uintptr_t)src) & (src_bf16 ? 7u : 15u)) == 0 && (((uintptr_t)dst) & (dst_bf16 ? 7u : 15u)) == 0, CCD_EINVAL);
     unsigned thr; float scale;
@@ -773,8 +774,9 @@ int ccd_droppath_scales(const float* keep, float* out, int per_block, int nblock
 }
 int ccd_dec_embed_fwd(const int64_t* tokens, const float* emb, const float* pos, float* x, int rows, int T, int D,
                       int num_classes, uint64_t seed, float p, void* stream) {
-    CCD_CHECK(tokens && emb && pos && x && rows >= 0 && p >= 0.f && p < 1.f, CCD_EINVAL);
+    CCD_CHECK(rows >= 0 && p >= 0.f && p < 1.f, CCD_EINVAL);
     if (rows == 0) return CCD_OK;
+    CCD_CHECK(tokens && emb && pos && x, CCD_EINVAL);
     CCD_CHECK(T > 0 && D > 0 && D % 4 == 0 && num_classes > 0, CCD_ESHAPE);
     CCD_CHECK(CCD_ALIGNED16(emb) && CCD_ALIGNED16(pos) && CCD_ALIGNED16(x), CCD_EINVAL);
     unsigned thr; float scale;
@@ -785,8 +787,9 @@ int ccd_dec_embed_fwd(const int64_t* tokens, const float* emb, const float* pos,
 }
 int ccd_dec_embed_bwd(const int64_t* tokens, const float* dx, float* demb, int rows, int D, int num_classes, int padding_idx,
                       uint64_t seed, float p, void* stream) {
-    CCD_CHECK(tokens && dx && demb && rows >= 0 && p >= 0.f && p < 1.f, CCD_EINVAL);
+    CCD_CHECK(rows >= 0 && p >= 0.f && p < 1.f, CCD_EINVAL);
     if (rows == 0) return CCD_OK;
+    CCD_CHECK(tokens && dx && demb, CCD_EINVAL);
     CCD_CHECK(D > 0 && D <= 1024 && num_classes > 0, CCD_ESHAPE);
     unsigned thr; float scale;
     ccd_drop_consts(p, &thr, &scale);

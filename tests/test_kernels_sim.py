@@ -163,3 +163,4 @@ def test_decoder_abi_rejects_unsupported_arguments(sim):
     e = torch.zeros((0, 128), dtype=bf)
     out, lse, _ = ops.dec_attn_fwd(e, e, e, 0, 2, 25, 25, 0.125)
     assert out.shape == (0, 128)
+    assert ops.dropout(torch.zeros(0), 0.1, 1).numel() == 0
