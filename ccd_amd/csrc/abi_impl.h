@@ -10,6 +10,7 @@
 #include "kernels/gemm_nt32.h"
 #include "kernels/gemm256.h"
 #include "kernels/gemm_row384.h"
+#include "kernels/mlp_fused.h"
 #include "kernels/layernorm.h"
 #include "kernels/attention_fwd.h"
 #include "kernels/attention_bwd.h"
@@ -218,6 +219,37 @@ int ccd_gemm_nt_resid_ln(const ccd_bf16* A, long lda, const ccd_bf16* B, long ld
     for (int sft = 0; sft < 31; ++sft) if ((1 << sft) == rows_per_sample) p.rps_shift = sft;
     p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_eps = ln_eps; p.ln_y = y; p.ld_y = ldy; p.ln_mean = mean; p.ln_rstd = rstd;
     return ccd_launch_gemm_row384(p, 7 /* EPI_RESID_LN */, stream);
+}
+
+int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, const float* b1, const ccd_bf16* w2, long ld2,
+                  const float* b2, const float* resid, long ldr, const float* rowscale, int rows_per_sample, float* out,
+                  long ldc, const float* ln_gamma, const float* ln_beta, float ln_eps, ccd_bf16* ln_y, long ld_y,
+                  float* ln_mean, float* ln_rstd, ccd_bf16* u, long ldu, int M, int E, int H, void* stream) {
+    CCD_CHECK(y && w1 && b1 && w2 && b2 && resid && out && ln_gamma && ln_beta && ln_y && ln_mean && ln_rstd, CCD_EINVAL);
+    CCD_CHECK(CCD_ALIGNED16(y) && CCD_ALIGNED16(w1) && CCD_ALIGNED16(w2) && CCD_ALIGNED16(resid) && CCD_ALIGNED16(out) &&
+              CCD_ALIGNED16(ln_y) && CCD_ALIGNED16(u), CCD_EINVAL);
+    if (M == 0) return CCD_OK;
+    CCD_CHECK(M > 0 && H > 0 && (!rowscale || rows_per_sample > 0), CCD_EINVAL);
+    CCD_CHECK((E == 192 || E == 384) && H % 64 == 0 && ldy % 8 == 0 && ld1 % 8 == 0 && ld2 % 8 == 0 && ldr % 4 == 0 &&
+              ldc % 4 == 0 && ld_y % 8 == 0 && (!u || ldu % 8 == 0), CCD_ESHAPE);
+    CCD_CHECK((long)H * ld1 * 2 < CCD_MAX_OPERAND_BYTES && (long)E * ld2 * 2 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
+    const int smem = ccd::mlp_smem_bytes(E, H);
+    CCD_CHECK(smem <= 160 * 1024, CCD_ESHAPE);
+    ccd::MlpParams p;
+    p.y = y; p.ldy_in = ldy; p.w1 = w1; p.ld1 = ld1; p.b1 = b1; p.w2 = w2; p.ld2 = ld2; p.b2 = b2; p.resid = resid; p.ldr = ldr;
+    p.rowscale = rowscale; p.rows_per_sample = rowscale ? rows_per_sample : 1; p.out = out; p.ldc = ldc;
+    p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_eps = ln_eps; p.ln_y = ln_y; p.ld_y = ld_y; p.ln_mean = ln_mean;
+    p.ln_rstd = ln_rstd; p.u = u; p.ldu = ldu; p.M = M; p.H = H;
+    const int tiles = (M + ccd::MLP_BM - 1) / ccd::MLP_BM, cus = ccd_rt_num_cus();
+    const dim3 grid(tiles < cus ? tiles : cus), block(ccd::MLP_THREADS);
+    if (E == 384) {
+        if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<384, true>), grid, block, smem, stream, p);
+        else CCD_LAUNCH((ccd::mlp_fused_kernel<384, false>), grid, block, smem, stream, p);
+    } else {
+        if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<192, true>), grid, block, smem, stream, p);
+        else CCD_LAUNCH((ccd::mlp_fused_kernel<192, false>), grid, block, smem, stream, p);
+    }
+    return ccd_rt_last_error();
 }
 
 int ccd_gemm_tn(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P, int Q, int Mc, int epilogue, float* C,

@@ -1,0 +1,391 @@
+// mlp_fused.h - the whole MLP branch of a transformer block in ONE kernel (vision_transformer.py:59-65 inside
+// Block.forward :107-113):
+//     x_out = x_mid + rowscale * (gelu(y2 . W1^T + b1) . W2^T + b2) ;   y_next = LayerNorm(x_out) * gamma + beta
+// The [rows, 4E] hidden activation never touches HBM (the teacher needs nothing else; the student additionally stores
+// the bf16 pre-activation u, the one tensor its backward pass needs).  Per 131 072 rows at E = 384 the unfused pair
+// (fc1 + GELU, fc2 + residual + LayerNorm) moves 1.4 GB; this kernel moves 0.6 GB (+ 0.4 GB for u).
+//
+// Structure ("row owners"): one workgroup = 4 waves = 128 rows, one wave per SIMD with the full 512-register file.
+// A wave OWNS 32 rows for the whole kernel: their y2 values live in registers as MFMA operands (E/4 VGPRs), their
+// x_out accumulators too (E/2 VGPRs); nothing of a row is ever exchanged between waves.  Only the WEIGHTS move: W1 and
+// W2 (L2-resident, 2.4 MB at E = 384) stream through a ring of LDS slots by LDS-DMA, in "pieces" of 32 * E * 2 bytes that
+// all four waves consume in lock step, 24 MFMAs per wave and piece (E = 384):
+//     hidden chunk c (64 units):  P1(c,0) P1(c,1)  -> H^T[64 hidden][32 rows] = W1[chunk] . y2^T          (K = E)
+//                                 GELU in registers: the accumulator layout of H^T IS the B-operand layout of the next
+//                                 product once W1's rows are fed in an order that swaps bits 2 and 3 of the row index
+//                                 P2(c,0) P2(c,1)  -> OUT^T[E][32 rows] += W2[:, chunk] . H                (K = 64)
+// Ring protocol (NSLOT = 5 slots, every wave issues 1/4 of every piece and all waves consume every piece): step q waits
+// for its own quarter of piece q (counted vmcnt: the three younger pieces stay in flight), passes ONE LDS-only barrier
+// (everybody's quarter has landed AND everybody is done reading piece q-1), re-fills the slot of piece q-1 with piece
+// q+4 and multiplies.  The piece sequence only depends on the position inside a row tile, so the ring runs seamlessly
+// across the tiles of the persistent loop.
+//
+// LDS images are the GEMM family's: 128-byte rows, 16-byte slots XOR-swizzled by f(row) on the DMA's SOURCE address
+// (LDS-DMA writes lane-linearly), conflict-free ds_read_b128 fragment reads.
+#pragma once
+
+namespace ccd {
+
+struct MlpParams {
+    const bf16_t* y;        // [M, E] bf16: LayerNorm-2 output
+    long ldy_in;
+    const bf16_t* w1;       // fc1.weight [H, E] bf16
+    long ld1;
+    const float* b1;        // [H]
+    const bf16_t* w2;       // fc2.weight [E, H] bf16
+    long ld2;
+    const float* b2;        // [E]
+    const float* resid;     // x_mid [M, E] fp32
+    long ldr;
+    const float* rowscale;  // DropPath scale per sample, or null
+    int rows_per_sample;
+    float* out;             // x_out [M, E] fp32
+    long ldc;
+    const float* ln_gamma;  // LayerNorm that follows (norm1 of the next block / final norm)
+    const float* ln_beta;
+    float ln_eps;
+    bf16_t* ln_y;           // [M, E] bf16
+    long ld_y;
+    float* ln_mean;
+    float* ln_rstd;
+    bf16_t* u;              // optional [M, H] bf16 pre-activation (STORE_U)
+    long ldu;
+    int M, H;
+};
+
+constexpr int MLP_NSLOT = 5, MLP_SCRATCH = 4096, MLP_THREADS = 256, MLP_BM = 128;
+__host__ __device__ constexpr int mlp_piece_bytes(int E) { return 32 * E * 2; }
+__host__ __device__ inline int mlp_smem_bytes(int E, int H) {
+    return MLP_NSLOT * mlp_piece_bytes(E) + 4 * MLP_SCRATCH + (H + 3 * E) * 4;
+}
+// 16-byte slot swizzle of a 128-byte image row (rows taken modulo 32: a piece is a stack of 32-row blocks)
+__device__ __forceinline__ int mlp_swz(int row) { return (((row & 31) >> 1) ^ ((row & 31) >> 4)) & 7; }
+
+// 24 (N) MFMAs of one piece with their A fragments read DEPTH steps ahead; the sched_group_barrier sequence pins the
+// issue order (reads of step k + DEPTH right behind MFMA k) - left alone, the scheduler serialised read -> wait -> MFMA
+template <int N, int DEPTH, typename Addr, typename Mma>
+__device__ __forceinline__ void mlp_piece_product(Addr addr, Mma mma) {
+    bf16x8 a[DEPTH];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) a[k] = *reinterpret_cast<const bf16x8*>(addr(k));
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        mma(k, a[k % DEPTH]);
+        if (k + DEPTH < N) a[k % DEPTH] = *reinterpret_cast<const bf16x8*>(addr(k + DEPTH));
+    }
+    CCD_SGB_DS_READ(DEPTH);
+#pragma unroll
+    for (int k = 0; k < N - DEPTH; ++k) {
+        CCD_SGB_MFMA(1);
+        CCD_SGB_DS_READ(1);
+    }
+    CCD_SGB_MFMA(DEPTH);
+}
+
+template <int E, bool STORE_U>
+__global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) {
+    constexpr int KT = E / 64;             // 64-wide k-tiles of a W1 piece = DMA instructions per wave and piece
+    constexpr int KJ = E / 16;             // MFMA k-steps of the first product
+    constexpr int NT = E / 32;             // 32-column output tiles of a row
+    constexpr int NTH = NT / 2;            // ... per W2 piece
+    constexpr int PIECE = mlp_piece_bytes(E);
+    constexpr int AHEAD = MLP_NSLOT - 1;   // pieces issued ahead of the one being consumed (= one hidden chunk)
+    constexpr int DEPTH = 6;               // fragment reads in flight ahead of their MFMA
+    static_assert(E % 64 == 0 && AHEAD == 4, "piece bookkeeping assumes four pieces per hidden chunk");
+    char* smem = dynamic_smem();
+    const int t = threadIdx.x, lane = t & 63, hf = lane >> 5, lq = lane & 31;
+    const int w = uniform_i32(t >> 6);     // wave index as a scalar: everything derived from it stays in SGPRs
+    char* scratch = smem + MLP_NSLOT * PIECE + w * MLP_SCRATCH;
+    float* vb1 = reinterpret_cast<float*>(smem + MLP_NSLOT * PIECE + 4 * MLP_SCRATCH);
+    float* vb2 = vb1 + p.H;
+    float* vga = vb2 + E;
+    float* vbe = vga + E;
+    for (int i = t; i < p.H; i += MLP_THREADS) vb1[i] = p.b1[i];
+    for (int i = t; i < E; i += MLP_THREADS) { vb2[i] = p.b2[i]; vga[i] = p.ln_gamma[i]; vbe[i] = p.ln_beta[i]; }
+    __syncthreads();                       // (plain loads only so far: nothing in flight that a drain would hurt)
+
+    const int NC = p.H / 64, NP = 4 * NC;  // hidden chunks, pieces per row tile
+    const int tiles = (p.M + MLP_BM - 1) / MLP_BM, G = gridDim.x;
+    const int my_tiles = (int)blockIdx.x < tiles ? (tiles - (int)blockIdx.x + G - 1) / G : 0;
+    const int limit = my_tiles * NP;       // pieces this workgroup may request
+
+    // ---- DMA: a piece is 4*KT wave instructions of 1 KiB (8 image rows x 128 B).  Wave w moves the instructions whose
+    // 8-row block index is w modulo 4, so ONE per-lane offset per weight matrix serves all of its instructions:
+    //   W1 piece [KT k-tiles][32 hidden rows][128 B]: instruction i = rows 8w .. 8w+7 of k-tile i
+    //   W2 piece [E/2 output rows][128 B = 64 hidden units]: instruction i = rows 32 i + 8w .. + 7
+    const int dr = lane >> 3, dp = lane & 7;
+    const int drow = 8 * w + dr;
+    const unsigned lsrc1 = (unsigned)(drow * p.ld1 + ((dp ^ mlp_swz(drow)) * 8));
+    const unsigned lsrc2 = (unsigned)(drow * p.ld2 + ((dp ^ mlp_swz(drow)) * 8));
+    int qi = 0, qc = 0;                    // pieces requested / consumed so far
+    int slot_i = 0, slot_c = 0, ci = 0;    // ring slots of the next request / next consumption, chunk of the next request
+    auto issue = [&](int j) {              // piece j (0,1: W1 halves; 2,3: W2 halves) of chunk ci into slot_i
+        char* sb = smem + slot_i * PIECE + w * 1024;
+        if (j < 2) {
+            const bf16_t* base = p.w1 + (long)(64 * ci + 32 * j) * p.ld1 + lsrc1;
+#pragma unroll
+            for (int i = 0; i < KT; ++i) glds16(base + 64 * i, sb + 4096 * i);
+        } else {
+            const bf16_t* base = p.w2 + (long)((j - 2) * (E / 2)) * p.ld2 + 64 * ci + lsrc2;
+#pragma unroll
+            for (int i = 0; i < KT; ++i) glds16(base + (long)(32 * i) * p.ld2, sb + 4096 * i);
+        }
+        ++qi;
+        slot_i = slot_i + 1 == MLP_NSLOT ? 0 : slot_i + 1;
+        if (j == 3) ci = ci + 1 == NC ? 0 : ci + 1;
+    };
+    // step q of the ring: returns the slot base of the piece that may now be read
+    auto acquire = [&](int j) -> const char* {
+        const int ahead = qi - qc - 1;     // younger pieces in flight behind the one we need (KT instructions each)
+        if (ahead >= 3) glds_wait<3 * KT>();
+        else if (ahead == 2) glds_wait<2 * KT>();
+        else if (ahead == 1) glds_wait<KT>();
+        else glds_wait_all();
+        lds_barrier();                     // everybody's quarter landed; everybody finished the previous piece
+        if (qi < limit) issue(j);          // AHEAD = 4 pieces = one chunk ahead: the same j, into the slot just freed
+        const char* sb = smem + slot_c * PIECE;
+        ++qc;
+        slot_c = slot_c + 1 == MLP_NSLOT ? 0 : slot_c + 1;
+        return sb;
+    };
+    if (my_tiles > 0) {
+#pragma unroll
+        for (int j = 0; j < AHEAD; ++j) issue(j);
+    }
+
+    // ---- fragment read offsets inside a piece (one register per k-step; tiles / k-tiles are immediate offsets)
+    const int prow = (lq & 19) | ((lq & 4) << 1) | ((lq & 8) >> 1);      // bits 2 and 3 of the row index swapped
+    unsigned off1[4], off2[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        off1[kk] = (unsigned)(prow * 128 + (((2 * kk + hf) ^ mlp_swz(prow)) * 16));
+        off2[kk] = (unsigned)(lq * 128 + (((2 * kk + hf) ^ mlp_swz(lq)) * 16));
+    }
+    const float inv_e = 1.0f / (float)E;
+    // global traffic of the row tiles goes through buffer descriptors: one per-lane offset register per tensor, the tile /
+    // column part of every address in SGPRs, and rows beyond M cost no predicate (loads return 0, stores are dropped)
+    const buf_rsrc rs_y = make_rsrc(p.y, (unsigned)((((long)p.M - 1) * p.ldy_in + E) * 2));
+    const buf_rsrc rs_x = make_rsrc(p.resid, (unsigned)((((long)p.M - 1) * p.ldr + E) * 4));
+    const buf_rsrc rs_o = make_rsrc(p.out, (unsigned)((((long)p.M - 1) * p.ldc + E) * 4));
+    const buf_rsrc rs_n = make_rsrc(p.ln_y, (unsigned)((((long)p.M - 1) * p.ld_y + E) * 2));
+    const buf_rsrc rs_u = make_rsrc(STORE_U ? p.u : nullptr, STORE_U ? (unsigned)((((long)p.M - 1) * p.ldu + p.H) * 2) : 0u);
+    const unsigned lo_y = (unsigned)((lq * p.ldy_in + 8 * hf) * 2), lo_x = (unsigned)((lq * p.ldr + 4 * hf) * 4);
+    const unsigned lo_o = (unsigned)(dr * p.ldc * 4 + dp * 16), lo_n = (unsigned)(dr * p.ld_y * 2 + dp * 16);
+    const unsigned lo_u = STORE_U ? (unsigned)(dr * p.ldu * 2 + dp * 16) : 0u;
+
+    for (int tile = blockIdx.x; tile < tiles; tile += G) {
+        const int m0 = tile * MLP_BM, r0 = m0 + 32 * w;
+        const int row = r0 + lq, grow = row < p.M ? row : p.M - 1;
+        // DropPath: out = x + sc * f(x).  sc != 0: acc starts at x / sc and (acc + b2) is scaled by sc at the end; sc == 0
+        // (dropped sample): acc starts at x and this row's column of H is zeroed.  A tile of dropped samples only
+        // (rows_per_sample a multiple of the tile height) skips the products altogether.
+        float sc = 1.0f;
+        if (p.rowscale) sc = p.rowscale[grow / p.rows_per_sample];
+        const bool dead = sc == 0.0f;
+        const float inv = dead ? 1.0f : 1.0f / sc, osc = dead ? 1.0f : sc;
+        const unsigned keep = dead ? 0u : 0xffffffffu;
+        const bool tile_dead = p.rowscale != nullptr && p.rows_per_sample % MLP_BM == 0 &&
+                               p.rowscale[m0 / p.rows_per_sample] == 0.0f;
+
+        if (tile_dead) {
+            // x_out = x, y_next = LayerNorm(x): half a wave per row, row sums by shuffles (as gemm_row384.h's epilogue)
+            constexpr int C3 = (E / 4 + 31) / 32;              // 16-byte chunks of a row per lane
+#pragma unroll 1
+            for (int it = 0; it < 16; ++it) {
+                const unsigned rr = (unsigned)(r0 + 2 * it + hf);
+                f32x4v o[C3];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int c3 = 0; c3 < C3; ++c3) {
+                    const int chunk = lq + 32 * c3;
+                    o[c3] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                    if (chunk < E / 4) o[c3] = __builtin_bit_cast(f32x4v, buf_load16(rs_x, (unsigned)(chunk * 16), rr * (unsigned)(p.ldr * 4)));
+                    s1 += (o[c3].x + o[c3].y) + (o[c3].z + o[c3].w);
+                    s2 += (o[c3].x * o[c3].x + o[c3].y * o[c3].y) + (o[c3].z * o[c3].z + o[c3].w * o[c3].w);
+                }
+#pragma unroll
+                for (int msk = 16; msk >= 1; msk >>= 1) { s1 += shfl_xor(s1, msk); s2 += shfl_xor(s2, msk); }
+                const float mean = s1 * inv_e;
+                float var = s2 * inv_e - mean * mean;
+                var = var > 0.f ? var : 0.f;
+                const float rstd = 1.0f / sqrtf(var + p.ln_eps);
+#pragma unroll
+                for (int c3 = 0; c3 < C3; ++c3) {
+                    const int chunk = lq + 32 * c3;
+                    if (chunk < E / 4) {
+                        buf_store16(rs_o, (unsigned)(chunk * 16), rr * (unsigned)(p.ldc * 4), __builtin_bit_cast(u32x4, o[c3]));
+                        const f32x4v ga = *reinterpret_cast<const f32x4v*>(vga + 4 * chunk), be = *reinterpret_cast<const f32x4v*>(vbe + 4 * chunk);
+                        u32x2 pk;
+                        pk.x = pack_bf2((o[c3].x - mean) * rstd * ga.x + be.x, (o[c3].y - mean) * rstd * ga.y + be.y);
+                        pk.y = pack_bf2((o[c3].z - mean) * rstd * ga.z + be.z, (o[c3].w - mean) * rstd * ga.w + be.w);
+                        if (rr < (unsigned)p.M) *reinterpret_cast<u32x2*>(p.ln_y + (long)rr * p.ld_y + 4 * chunk) = pk;
+                    }
+                }
+                if (lq == 0 && rr < (unsigned)p.M) { p.ln_mean[rr] = mean; p.ln_rstd[rr] = rstd; }
+            }
+            if (STORE_U) {
+                // the backward pass multiplies a zero gradient by gelu'(u) for these rows: u must be finite
+#pragma unroll 1
+                for (int cc = 0; cc < p.H / 64; ++cc)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        buf_store16(rs_u, lo_u, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldu * 2) + 128 * cc, u32x4{0u, 0u, 0u, 0u});
+            }
+            continue;
+        }
+        // the residual rows go straight into the accumulators (scaled by 1 / sc; b2 joins in the epilogue)
+        f32x16 acc[NT];
+        {
+            const unsigned so = (unsigned)r0 * (unsigned)(p.ldr * 4);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4v x = __builtin_bit_cast(f32x4v, buf_load16(rs_x, lo_x, so + (32 * nt + 8 * g) * 4));
+                    acc[nt][4 * g + 0] = x.x * inv;
+                    acc[nt][4 * g + 1] = x.y * inv;
+                    acc[nt][4 * g + 2] = x.z * inv;
+                    acc[nt][4 * g + 3] = x.w * inv;
+                }
+                if (nt % 4 == 3) CCD_SCHED_FENCE();      // four tiles' worth of loads (64 VGPRs) in flight at a time
+            }
+        }
+        CCD_SCHED_FENCE();
+        {
+            bf16x8 yf[KJ];                 // this lane's row of y2 as B operands: k = 16 j + 8 hf .. + 7
+            {
+                const unsigned so = (unsigned)r0 * (unsigned)(p.ldy_in * 2);
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) yf[j] = __builtin_bit_cast(bf16x8, buf_load16(rs_y, lo_y, so + 32 * j));
+            }
+#pragma unroll 1
+            for (int c = 0; c < NC; ++c) {
+                f32x16 h[2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) h[tt][r] = 0.f;
+                    const char* sb = acquire(tt);
+                    mlp_piece_product<KJ, DEPTH>(
+                        [&](int j) { return sb + (j >> 2) * 4096 + off1[j & 3]; },
+                        [&](int j, const bf16x8& a) { h[tt] = mfma_32x32x16_bf16(a, yf[j], h[tt]); });   // H^T[hidden][row]
+                }
+                // GELU of the bf16-rounded pre-activation (what the backward pass will see), packed as B operands:
+                // registers 8 s .. 8 s + 7 of tile tt are hidden units 64 c + 32 tt + 16 s + 8 hf + (0 .. 7)
+                bf16x8 hb[4];
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const int tt = k4 >> 1, s = k4 & 1;
+                    const float* bp = vb1 + 64 * c + 16 * k4 + 8 * hf;
+                    const f32x4v ba = *reinterpret_cast<const f32x4v*>(bp), bb = *reinterpret_cast<const f32x4v*>(bp + 4);
+                    const float bias[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+                    u32x4 gw, uw;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned upk = pack_bf2(h[tt][8 * s + 2 * e] + bias[2 * e], h[tt][8 * s + 2 * e + 1] + bias[2 * e + 1]);
+                        const float u0 = bf_lo(upk), u1 = bf_hi(upk);
+                        uw[e] = upk;
+                        gw[e] = pack_bf2(u0 * gelu_terms(u0).cdf, u1 * gelu_terms(u1).cdf) & keep;
+                    }
+                    hb[k4] = __builtin_bit_cast(bf16x8, gw);
+                    if (STORE_U)           // [32 rows][64 hidden] bf16 image in the wave's scratch
+                        *reinterpret_cast<u32x4*>(scratch + lq * 128 + (((2 * k4 + hf) ^ (lq & 7)) * 16)) = uw;
+                    CCD_SCHED_FENCE();     // one group of 8 at a time: bounded temporaries
+                }
+                if (STORE_U) {             // ... leaves as 128-byte row segments
+                    wave_lds_fence();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(scratch + (dr + 8 * i) * 128 + ((dp ^ dr) * 16));
+                        buf_store16(rs_u, lo_u, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldu * 2) + 128 * c, v);
+                    }
+                    wave_lds_fence();
+                }
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const char* sb = acquire(2 + hh);
+                    mlp_piece_product<4 * NTH, DEPTH>(
+                        [&](int k) { return sb + (k % NTH) * 4096 + off2[k / NTH]; },
+                        [&](int k, const bf16x8& a) {
+                            acc[NTH * hh + k % NTH] = mfma_32x32x16_bf16(a, hb[k / NTH], acc[NTH * hh + k % NTH]);   // OUT^T[n][row]
+                        });
+                }
+            }
+        }
+        // ---- epilogue: rows are complete inside their two lanes (lane, lane ^ 32): LayerNorm statistics in registers.
+        // out = (acc + b2) * sc (a dropped row is x itself); the accumulators are only READ here (they stay where
+        // the matrix pipe left them), each pass recomputes the few values it stores.
+        const float bsc = dead ? 0.0f : osc;
+        auto outv = [&](int nt, int g, float k_osc, float k_bsc, float (&v)[4]) {
+            const f32x4v b = *reinterpret_cast<const f32x4v*>(vb2 + 32 * nt + 8 * g + 4 * hf);
+            v[0] = fmaf(acc[nt][4 * g + 0], k_osc, b.x * k_bsc);
+            v[1] = fmaf(acc[nt][4 * g + 1], k_osc, b.y * k_bsc);
+            v[2] = fmaf(acc[nt][4 * g + 2], k_osc, b.z * k_bsc);
+            v[3] = fmaf(acc[nt][4 * g + 3], k_osc, b.w * k_bsc);
+        };
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+                outv(nt, g, osc, bsc, v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
+            }
+        s1 += shfl_xor(s1, 32);
+        s2 += shfl_xor(s2, 32);
+        const float mean = s1 * inv_e;
+        float var = s2 * inv_e - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        const float rstd = 1.0f / sqrtf(var + p.ln_eps);
+        if (hf == 0 && row < p.M) { p.ln_mean[row] = mean; p.ln_rstd[row] = rstd; }
+        // (the second pass must RECOMPUTE its values: were the compiler to keep the first pass's 6 E / 8 results alive,
+        // they would not fit the register file - its scale factors are therefore opaque copies)
+        float osc2 = osc, bsc2 = bsc;
+        asm volatile("" : "+v"(osc2), "+v"(bsc2));
+        // per pair of 32-column tiles: x_out (fp32, one tile at a time) and y_next (bf16, both tiles) through the scratch
+        // image, leaving as 128-byte row segments
+#pragma unroll
+        for (int np = 0; np < NT / 2; ++np) {
+            u32x2 ypk[2][4];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int nt = 2 * np + tt;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+                    outv(nt, g, osc2, bsc2, v);
+                    const f32x4v o = {v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4v*>(scratch + lq * 128 + (((2 * g + hf) ^ (lq & 7)) * 16)) = o;
+                    const int n = 32 * nt + 8 * g + 4 * hf;
+                    const f32x4v ga = *reinterpret_cast<const f32x4v*>(vga + n), be = *reinterpret_cast<const f32x4v*>(vbe + n);
+                    ypk[tt][g].x = pack_bf2((v[0] - mean) * rstd * ga.x + be.x, (v[1] - mean) * rstd * ga.y + be.y);
+                    ypk[tt][g].y = pack_bf2((v[2] - mean) * rstd * ga.z + be.z, (v[3] - mean) * rstd * ga.w + be.w);
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(scratch + (dr + 8 * i) * 128 + ((dp ^ dr) * 16));
+                    buf_store16(rs_o, lo_o, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldc * 4) + 128 * nt, v);
+                }
+                wave_lds_fence();
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<u32x2*>(scratch + lq * 128 + (((4 * tt + g) ^ (lq & 7)) * 16) + 8 * hf) = ypk[tt][g];
+            wave_lds_fence();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(scratch + (dr + 8 * i) * 128 + ((dp ^ dr) * 16));
+                buf_store16(rs_n, lo_n, (unsigned)(r0 + 8 * i) * (unsigned)(p.ld_y * 2) + 128 * np, v);
+            }
+            wave_lds_fence();
+        }
+    }
+    glds_wait_all();                       // requested pieces that no tile consumed must not outlive the workgroup's LDS
+}
+
+}  // namespace ccd

@@ -48,6 +48,14 @@ __device__ __forceinline__ buf_rsrc make_rsrc(const void* base, unsigned bytes) 
 __device__ __forceinline__ buf_u32x4 buf_load16(buf_rsrc r, unsigned byte_offset) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_offset, 0, 0);
 }
+// the same with a wave-uniform (SGPR) part of the offset: address = base + lane_offset + uniform_offset, the bounds check
+// (reads return zeros, writes are dropped) applies to the sum
+__device__ __forceinline__ buf_u32x4 buf_load16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_offset, (int)uniform_offset, 0);
+}
+__device__ __forceinline__ void buf_store16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset, buf_u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)lane_offset, (int)uniform_offset, 0);
+}
 // LDS-DMA: one wave instruction copies 64 x 16 B from per-lane global addresses straight into LDS at
 // (wave-uniform lds_base) + lane * 16 - no VGPR round trip, counted on vmcnt like any VMEM load.
 __device__ __forceinline__ void glds16(const void* gptr, char* lds_base) {
@@ -82,7 +90,13 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 __device__ __forceinline__ unsigned short cvt_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // bare v_exp_f32
-__device__ __forceinline__ float fast_rcp(float x) { return __frcp_rn(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // bare v_rcp_f32 (1 ulp); __frcp_rn expands to an 11-instruction IEEE division
+// scheduling hints (guide T19): pin the issue order of an unrolled block as groups of instruction kinds
+#define CCD_SGB_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x8, (n), 0)
+#define CCD_SGB_DS_READ(n) __builtin_amdgcn_sched_group_barrier(0x100, (n), 0)
+#define CCD_SGB_VALU(n) __builtin_amdgcn_sched_group_barrier(0x2, (n), 0)
+#define CCD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ int uniform_i32(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return rsqrtf(x); }
 }  // namespace ccd
 

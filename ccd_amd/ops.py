@@ -111,6 +111,36 @@ def gemm_nt_resid_ln(a, b, *, bias, resid, rowscale, rows_per_sample, gamma, bet
     return out, y, mean, rstd
 
 
+def mlp_fused(y, w1, b1, w2, b2, *, resid, rowscale, rows_per_sample, gamma, beta, eps, store_u=False, out=None):
+    """out (fp32) = resid + (gelu(y @ w1^T + b1) @ w2^T + b2) * rowscale[row // rows_per_sample];
+    y_next = LayerNorm(out) * gamma + beta  ->  (out, y_next bf16, mean, rstd, u bf16 | None).
+    The hidden activation never reaches HBM; `u` (the bf16 pre-activation) is written only when store_u."""
+    _chk(y, BF16, "y"); _chk(w1, BF16, "w1"); _chk(w2, BF16, "w2"); _chk(b1, F32, "b1"); _chk(b2, F32, "b2")
+    _chk(resid, F32, "resid"); _chk(rowscale, F32, "rowscale")
+    M, E = y.shape
+    H = w1.shape[0]
+    assert tuple(w1.shape) == (H, E) and tuple(w2.shape) == (E, H) and tuple(resid.shape) == (M, E)
+    dev = y.device
+    if out is None:
+        out = torch.empty((M, E), dtype=F32, device=dev)
+    yn = torch.empty((M, E), dtype=BF16, device=dev)
+    mean = torch.empty(M, dtype=F32, device=dev)
+    rstd = torch.empty(M, dtype=F32, device=dev)
+    u = torch.empty((M, H), dtype=BF16, device=dev) if store_u else None
+    # algorithmic bytes: y read, resid read, out + y_next written (+ u), weights once
+    nbytes = M * E * (2.0 + 4.0 + 4.0 + 2.0) + (2.0 * M * H if store_u else 0.0) + 4.0 * E * H
+    span = TIMER.span("mlp_fused", 4.0 * M * E * H, nbytes) if TIMER is not None else None
+    if span:
+        span[0].record()
+    _call("ccd_mlp_fused", _lib.ptr(y), y.stride(0), _lib.ptr(w1), w1.stride(0), _lib.ptr(b1), _lib.ptr(w2), w2.stride(0),
+          _lib.ptr(b2), _lib.ptr(resid), resid.stride(0), _lib.ptr(rowscale), int(rows_per_sample), _lib.ptr(out),
+          out.stride(0), _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(yn), yn.stride(0), _lib.ptr(mean),
+          _lib.ptr(rstd), _lib.ptr(u), 0 if u is None else u.stride(0), M, E, H)
+    if span:
+        span[1].record()
+    return out, yn, mean, rstd, u
+
+
 def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, splits=0, d_rows=None, rows_mul=1):
     """out[P,Q] (+)= a[Mc,P]^T @ b[Mc,Q]  (fp32 out; accumulate=True adds with fp32 atomics, split over Mc)."""
     _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(out, F32, "out")

@@ -55,6 +55,17 @@ int ccd_gemm_nt_resid_ln(const ccd_bf16* A, long lda, const ccd_bf16* B, long ld
                          const float* bias, const float* resid, long ldr, const float* rowscale, int rows_per_sample,
                          const float* ln_gamma, const float* ln_beta, float ln_eps, ccd_bf16* y, long ldy, float* mean,
                          float* rstd, void* stream);
+/* The whole MLP branch of a transformer block in one launch (Mlp.forward + the residual of Block.forward,
+ * Dino/modules/vision_transformer.py:59-65,107-113, and the LayerNorm that consumes the stream next, :99/:156):
+ *   h = gelu(bf16(y . W1^T + b1)) ;  out (f32) = resid + (h . W2^T + b2) * rowscale[row / rows_per_sample]
+ *   ln_y (bf16) = (out - mean) * rstd * ln_gamma + ln_beta ;  ln_mean / ln_rstd [M] saved for ccd_ln_bwd
+ * The [M, H] hidden activation stays on chip; `u` (optional, [M, H] bf16) receives the pre-activation the backward
+ * pass needs.  W1 = fc1.weight [H, E], W2 = fc2.weight [E, H] (bf16).  E in {192, 384}, H % 64 == 0.
+ * Replaces ccd_gemm_nt(EPI_GELU) + ccd_gemm_nt_resid_ln. */
+int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, const float* b1, const ccd_bf16* w2, long ld2,
+                  const float* b2, const float* resid, long ldr, const float* rowscale, int rows_per_sample, float* out,
+                  long ldc, const float* ln_gamma, const float* ln_beta, float ln_eps, ccd_bf16* ln_y, long ld_y,
+                  float* ln_mean, float* ln_rstd, ccd_bf16* u, long ldu, int M, int E, int H, void* stream);
 /* colsum (optional, epilogues BF16 / DGELU): [N] fp32, += column sums of the output (bias gradient of the producer).
  * CCD_EPI_GELU accepts C == NULL (only gelu(u) is stored: forward passes that keep no activations). */
 /* C[P,Q] (+)= sum_m A[m,P] * B[m,Q]   (weight gradients dW = dY^T X of every Linear; autograd of the above)

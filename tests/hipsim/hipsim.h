@@ -154,6 +154,16 @@ inline buf_u32x4 buf_load16(buf_rsrc r, unsigned byte_offset) {
     if ((unsigned long long)byte_offset + 16ull <= (unsigned long long)r.bytes) std::memcpy(&v, r.base + byte_offset, 16);
     return v;
 }
+inline buf_u32x4 buf_load16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset) {
+    const unsigned long long o = (unsigned long long)lane_offset + uniform_offset;
+    buf_u32x4 v = {0u, 0u, 0u, 0u};
+    if (o + 16ull <= (unsigned long long)r.bytes) std::memcpy(&v, r.base + o, 16);
+    return v;
+}
+inline void buf_store16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset, buf_u32x4 v) {
+    const unsigned long long o = (unsigned long long)lane_offset + uniform_offset;
+    if (o + 16ull <= (unsigned long long)r.bytes) std::memcpy(const_cast<char*>(r.base) + o, &v, 16);
+}
 inline int lane_id() { return sim::cur->lane; }
 inline int wave_id() { return sim::cur->wave; }
 
@@ -251,6 +261,11 @@ inline unsigned cvt_pk_bf16(float lo, float hi) { return (unsigned)cvt_bf16(lo) 
 inline float fast_exp(float x) { return std::exp(x); }
 inline float fast_exp2(float x) { return std::exp2(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
+#define CCD_SGB_MFMA(n)
+#define CCD_SGB_DS_READ(n)
+#define CCD_SGB_VALU(n)
+#define CCD_SCHED_FENCE()
+inline int uniform_i32(int x) { return x; }
 inline float fast_rsqrt(float x) { return 1.0f / std::sqrt(x); }
 }  // namespace ccd
 

@@ -608,6 +608,46 @@ def check_gemm_resid_ln(dev, M, N, K, seed=30):
     close(y, F.layer_norm(want, (N,), gamma, beta, 1e-6), 1e-2, 2e-2, "resid_ln/y")
 
 
+def check_mlp_fused(dev, M, E, H, rps=128, seed=31, store_u=True):
+    """One launch == fc1 + GELU + fc2 + residual (DropPath scale) + LayerNorm, in plain fp32 math on the same
+    bf16-rounded operands (the hidden activation is rounded to bf16 twice, as the unfused kernels do)."""
+    g = torch.Generator().manual_seed(seed)
+    y = rnd((M, E), g).to(BF); w1 = rnd((H, E), g, 0.08).to(BF); w2 = rnd((E, H), g, 0.05).to(BF)
+    b1, b2 = rnd((H,), g) * 0.5, rnd((E,), g)
+    resid = rnd((M, E), g) * 3 + 0.5
+    rowscale = (torch.rand((M + rps - 1) // rps, generator=g) > 0.3).float() * 1.25
+    if rowscale.numel() > 1:
+        rowscale[1] = 0.0                                  # a dropped sample is always present
+    gamma, beta = rnd((E,), g).abs() + 0.5, rnd((E,), g) * 0.3
+    for rs in (rowscale, None):
+        out, yn, mean, rstd, u = ops.mlp_fused(y.to(dev), w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), resid=resid.to(dev),
+                                               rowscale=None if rs is None else rs.to(dev), rows_per_sample=rps,
+                                               gamma=gamma.to(dev), beta=beta.to(dev), eps=1e-6, store_u=store_u)
+        u_ref = (y.float() @ w1.float().t() + b1).to(BF)
+        h_ref = F.gelu(u_ref.float()).to(BF).float()
+        scale = 1.0 if rs is None else rs.repeat_interleave(rps)[:M, None]
+        want = resid + (h_ref @ w2.float().t() + b2) * scale
+        tag = "mlp_fused" + ("" if rs is not None else "/noscale")
+        if store_u:
+            # bf16 rounding of an fp32 sum taken in a different order: allow one bf16 ulp on a few elements;
+            # row tiles that consist of dropped samples only skip the products and store u = 0 (finite: the
+            # backward pass multiplies a zero gradient by gelu'(u) there)
+            u_want = u_ref.clone()
+            if rs is not None and rps % 128 == 0:
+                for t0 in range(0, M, 128):
+                    if rs[t0 // rps] == 0:
+                        u_want[t0:t0 + 128] = 0
+            close(u, u_want, 8e-3, 1e-3, tag + "/u")
+        close(out, want, 2e-3, 2e-3, tag + "/out")
+        mu, var = want.mean(1), want.var(1, unbiased=False)
+        close(mean, mu, 1e-3, 1e-3, tag + "/mean")
+        close(rstd, (var + 1e-6).rsqrt(), 2e-3, 1e-4, tag + "/rstd")
+        close(yn, F.layer_norm(want, (E,), gamma, beta, 1e-6), 1e-2, 2e-2, tag + "/y")
+        if rs is not None and rs.numel() > 1:
+            lo, hi = rps, min(2 * rps, M)
+            assert torch.equal(out[lo:hi].cpu(), resid[lo:hi]), "dropped sample: the stream must pass through unchanged"
+
+
 # ------------------------------------------------------------------------------------------------ finetune path
 def drop_keep_ref(seed, n, p):
     """Python mirror of decoder.h: drop_keep (splitmix64 finaliser on seed + index)."""

@@ -141,3 +141,33 @@ def test_gemm_row384(hip, monkeypatch, M, N, K):
 @pytest.mark.parametrize("M,N,K", [(300, 384, 128), (4096, 384, 1536), (2048, 192, 768)])
 def test_gemm_resid_ln(hip, M, N, K):
     kc.check_gemm_resid_ln(hip.device, M=M, N=N, K=K)
+
+
+@pytest.mark.parametrize("M,E,H,rps", [(300, 192, 256, 128), (200, 384, 128, 8), (40000, 384, 1536, 256), (4096, 192, 768, 256)])
+def test_mlp_fused(hip, M, E, H, rps):
+    """fc1 + GELU + fc2 + residual + LayerNorm in one launch: ragged tiles, many tiles per workgroup (the ring of weight
+    pieces runs across them), dropped samples, with and without the stored pre-activation."""
+    for store_u in (True, False):
+        kc.check_mlp_fused(hip.device, M=M, E=E, H=H, rps=rps, store_u=store_u)
+
+
+def test_mlp_fused_repeatable(hip):
+    """The weight ring is ordered by counted vmcnt + barriers only: 20 launches on the same operands must agree bit for bit
+    (a piece read before its DMA landed would show up as run-to-run differences)."""
+    from ccd_amd import ops
+    g = torch.Generator().manual_seed(5)
+    M, E, H = 131072, 384, 1536
+    dev = hip.device
+    y = kc.rnd((M, E), g).to(kc.BF).to(dev); w1 = kc.rnd((H, E), g, 0.08).to(kc.BF).to(dev)
+    w2 = kc.rnd((E, H), g, 0.05).to(kc.BF).to(dev)
+    b1, b2 = kc.rnd((H,), g).to(dev), kc.rnd((E,), g).to(dev)
+    resid = kc.rnd((M, E), g).to(dev); gamma, beta = torch.ones(E, device=dev), torch.zeros(E, device=dev)
+    ref = None
+    for _ in range(20):
+        out, yn, mean, rstd, u = ops.mlp_fused(y, w1, b1, w2, b2, resid=resid, rowscale=None, rows_per_sample=256,
+                                               gamma=gamma, beta=beta, eps=1e-6, store_u=True)
+        cur = (out.clone(), yn.clone(), u.clone())
+        if ref is None:
+            ref = cur
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(ref, cur)), "mlp_fused is not run-to-run deterministic"

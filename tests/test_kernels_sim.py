@@ -164,3 +164,9 @@ def test_decoder_abi_rejects_unsupported_arguments(sim):
     out, lse, _ = ops.dec_attn_fwd(e, e, e, 0, 2, 25, 25, 0.125)
     assert out.shape == (0, 128)
     assert ops.dropout(torch.zeros(0), 0.1, 1).numel() == 0
+
+
+def test_mlp_fused_sim(sim):
+    """Ragged last tile, several tiles per workgroup (1 CU), a dropped sample, both instantiations of E."""
+    kc.check_mlp_fused(sim.device, M=300, E=192, H=256, rps=128)
+    kc.check_mlp_fused(sim.device, M=200, E=384, H=128, rps=8, store_u=False)     # per-row DropPath scales
