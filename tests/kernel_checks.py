@@ -638,7 +638,8 @@ def check_mlp_fused(dev, M, E, H, rps=128, seed=31, store_u=True):
                     if rs[t0 // rps] == 0:
                         u_want[t0:t0 + 128] = 0
             close(u, u_want, 8e-3, 1e-3, tag + "/u")
-        close(out, want, 2e-3, 2e-3, tag + "/out")
+        # bf16 roundings of u / gelu(u) that flip by one ulp move a row sum by ~2e-4 each: tolerance grows with sqrt(H)
+        close(out, want, 2e-3, 3e-3 * max(1.0, (H / 128) ** 0.5), tag + "/out")
         mu, var = want.mean(1), want.var(1, unbiased=False)
         close(mean, mu, 1e-3, 1e-3, tag + "/mean")
         close(rstd, (var + 1e-6).rsqrt(), 2e-3, 1e-4, tag + "/rstd")
