@@ -19,6 +19,10 @@
 // (everybody's quarter has landed AND everybody is done reading piece q-1), re-fills the slot of piece q-1 with piece
 // q+4 and multiplies.  The piece sequence only depends on the position inside a row tile, so the ring runs seamlessly
 // across the tiles of the persistent loop.
+// Software pipeline: the pieces are consumed in the order P1(0) | P1(1) P2(0) | P1(2) P2(1) | ... | P2(last), and the GELU
+// of chunk c (a 1536-entry LDS table of Phi over bf16 magnitudes, 8 VALU + 1 gather per element) is spread between the
+// MFMAs of P1(c+1): with one wave per SIMD nothing else could cover it.  Fragment reads are issued by hand 6 steps ahead
+// of their MFMA and retired by counted lgkmcnt waits (the compiler's own waits drain the LDS queue to zero).
 //
 // LDS images are the GEMM family's: 128-byte rows, 16-byte slots XOR-swizzled by f(row) on the DMA's SOURCE address
 // (LDS-DMA writes lane-linearly), conflict-free ds_read_b128 fragment reads.
@@ -56,31 +60,47 @@ struct MlpParams {
 constexpr int MLP_NSLOT = 5, MLP_SCRATCH = 4096, MLP_THREADS = 256, MLP_BM = 128;
 __host__ __device__ constexpr int mlp_piece_bytes(int E) { return 32 * E * 2; }
 __host__ __device__ inline int mlp_smem_bytes(int E, int H) {
-    return MLP_NSLOT * mlp_piece_bytes(E) + 4 * MLP_SCRATCH + (H + 3 * E) * 4;
+    return MLP_NSLOT * mlp_piece_bytes(E) + 4 * MLP_SCRATCH + (1536 + H + 3 * E) * 4;    // ring, scratch, Phi table, vectors
 }
 // 16-byte slot swizzle of a 128-byte image row (rows taken modulo 32: a piece is a stack of 32-row blocks)
 __device__ __forceinline__ int mlp_swz(int row) { return (((row & 31) >> 1) ^ ((row & 31) >> 4)) & 7; }
 
-// 24 (N) MFMAs of one piece with their A fragments read DEPTH steps ahead; the sched_group_barrier sequence pins the
-// issue order (reads of step k + DEPTH right behind MFMA k) - left alone, the scheduler serialised read -> wait -> MFMA
-template <int N, int DEPTH, typename Addr, typename Mma>
-__device__ __forceinline__ void mlp_piece_product(Addr addr, Mma mma) {
-    bf16x8 a[DEPTH];
-#pragma unroll
-    for (int k = 0; k < DEPTH; ++k) a[k] = *reinterpret_cast<const bf16x8*>(addr(k));
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        mma(k, a[k % DEPTH]);
-        if (k + DEPTH < N) a[k % DEPTH] = *reinterpret_cast<const bf16x8*>(addr(k + DEPTH));
+template <int I, int N, typename F>
+__device__ __forceinline__ void mlp_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        mlp_static_for<I + 1, N>(f);
     }
-    CCD_SGB_DS_READ(DEPTH);
-#pragma unroll
-    for (int k = 0; k < N - DEPTH; ++k) {
-        CCD_SGB_MFMA(1);
-        CCD_SGB_DS_READ(1);
-    }
-    CCD_SGB_MFMA(DEPTH);
 }
+// fragment k of a piece: address register and immediate offset
+struct MlpMapP1 {                                  // [KT k-tiles][32 rows][128 B]: k-step j = (k-tile j >> 2, slot pair j & 3)
+    static constexpr int reg(int k) { return k & 3; }
+    static constexpr int off(int k) { return (k >> 2) * 4096; }
+};
+template <int NTH>
+struct MlpMapP2 {                                  // [NTH tiles of 32 rows][128 B]: step k = (k-step k / NTH, tile k % NTH)
+    static constexpr int reg(int k) { return k / NTH; }
+    static constexpr int off(int k) { return (k % NTH) * 4096; }
+};
+// N MFMAs of one piece: fragments requested DEPTH steps ahead, each retired by a counted wait right before its MFMA
+// (reads issued behind fragment k at that point: min(N - 1 - k, DEPTH - 1)); filler(k) places other work between them
+template <int N, int DEPTH, typename Map, typename Mma, typename Filler>
+__device__ __forceinline__ void mlp_product(const unsigned (&areg)[4], Mma mma, Filler filler) {
+    bf16x8 fr[DEPTH];
+    mlp_static_for<0, DEPTH>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        lds_read_frag<Map::off(k)>(fr[k], areg[Map::reg(k)]);
+    });
+    mlp_static_for<0, N>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        lds_wait_frag<(N - 1 - k < DEPTH - 1 ? N - 1 - k : DEPTH - 1)>(fr[k % DEPTH]);
+        mma(K, fr[k % DEPTH]);
+        if constexpr (k + DEPTH < N) lds_read_frag<Map::off(k + DEPTH)>(fr[k % DEPTH], areg[Map::reg(k + DEPTH)]);
+        filler(K);
+    });
+}
+
+constexpr unsigned MLP_LUT_LO = 0x3B80u, MLP_LUT_HI = 0x4180u;      // bf16 magnitudes 2^-8 .. 16: 1536 table entries
 
 template <int E, bool STORE_U>
 __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) {
@@ -89,25 +109,26 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
     constexpr int NT = E / 32;             // 32-column output tiles of a row
     constexpr int NTH = NT / 2;            // ... per W2 piece
     constexpr int PIECE = mlp_piece_bytes(E);
-    constexpr int AHEAD = MLP_NSLOT - 1;   // pieces issued ahead of the one being consumed (= one hidden chunk)
+    constexpr int AHEAD = MLP_NSLOT - 1;   // pieces issued ahead of the one being consumed
     constexpr int DEPTH = 6;               // fragment reads in flight ahead of their MFMA
-    static_assert(E % 64 == 0 && AHEAD == 4, "piece bookkeeping assumes four pieces per hidden chunk");
+    static_assert(E % 64 == 0 && AHEAD == 4, "ring bookkeeping");
     char* smem = dynamic_smem();
     const int t = threadIdx.x, lane = t & 63, hf = lane >> 5, lq = lane & 31;
     const int w = uniform_i32(t >> 6);     // wave index as a scalar: everything derived from it stays in SGPRs
     char* scratch = smem + MLP_NSLOT * PIECE + w * MLP_SCRATCH;
-    float* vb1 = reinterpret_cast<float*>(smem + MLP_NSLOT * PIECE + 4 * MLP_SCRATCH);
+    float* lut = reinterpret_cast<float*>(smem + MLP_NSLOT * PIECE + 4 * MLP_SCRATCH);
+    float* vb1 = lut + (MLP_LUT_HI - MLP_LUT_LO);
     float* vb2 = vb1 + p.H;
     float* vga = vb2 + E;
     float* vbe = vga + E;
     for (int i = t; i < p.H; i += MLP_THREADS) vb1[i] = p.b1[i];
     for (int i = t; i < E; i += MLP_THREADS) { vb2[i] = p.b2[i]; vga[i] = p.ln_gamma[i]; vbe[i] = p.ln_beta[i]; }
+    for (unsigned i = t; i < MLP_LUT_HI - MLP_LUT_LO; i += MLP_THREADS) lut[i] = gelu_terms(bf2f((bf16_t)(MLP_LUT_LO + i))).cdf;
     __syncthreads();                       // (plain loads only so far: nothing in flight that a drain would hurt)
+    const float* lut_biased = lut - MLP_LUT_LO;
 
     const int NC = p.H / 64, NP = 4 * NC;  // hidden chunks, pieces per row tile
     const int tiles = (p.M + MLP_BM - 1) / MLP_BM, G = gridDim.x;
-    const int my_tiles = (int)blockIdx.x < tiles ? (tiles - (int)blockIdx.x + G - 1) / G : 0;
-    const int limit = my_tiles * NP;       // pieces this workgroup may request
 
     // ---- DMA: a piece is 4*KT wave instructions of 1 KiB (8 image rows x 128 B).  Wave w moves the instructions whose
     // 8-row block index is w modulo 4, so ONE per-lane offset per weight matrix serves all of its instructions:
@@ -117,41 +138,43 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
     const int drow = 8 * w + dr;
     const unsigned lsrc1 = (unsigned)(drow * p.ld1 + ((dp ^ mlp_swz(drow)) * 8));
     const unsigned lsrc2 = (unsigned)(drow * p.ld2 + ((dp ^ mlp_swz(drow)) * 8));
-    int qi = 0, qc = 0;                    // pieces requested / consumed so far
-    int slot_i = 0, slot_c = 0, ci = 0;    // ring slots of the next request / next consumption, chunk of the next request
-    auto issue = [&](int j) {              // piece j (0,1: W1 halves; 2,3: W2 halves) of chunk ci into slot_i
+    int slot_i = 0, slot_c = 0, pos_i = 0; // ring slots of the next request / consumption, stream position of the next request
+    // stream of a row tile (NP pieces): P1(0)a P1(0)b | P1(1)a P1(1)b P2(0)a P2(0)b | ... | P2(NC-1)a P2(NC-1)b
+    auto issue = [&]() {
         char* sb = smem + slot_i * PIECE + w * 1024;
-        if (j < 2) {
-            const bf16_t* base = p.w1 + (long)(64 * ci + 32 * j) * p.ld1 + lsrc1;
+        int is_p2, chunk, half;
+        if (pos_i < 2) { is_p2 = 0; chunk = 0; half = pos_i; }
+        else {
+            const int q = pos_i - 2, grp = q >> 2, r = q & 3;
+            if (grp < NC - 1) { is_p2 = r >> 1; chunk = is_p2 ? grp : grp + 1; half = r & 1; }
+            else { is_p2 = 1; chunk = NC - 1; half = r; }
+        }
+        if (!is_p2) {
+            const bf16_t* base = p.w1 + (long)(64 * chunk + 32 * half) * p.ld1 + lsrc1;
 #pragma unroll
             for (int i = 0; i < KT; ++i) glds16(base + 64 * i, sb + 4096 * i);
         } else {
-            const bf16_t* base = p.w2 + (long)((j - 2) * (E / 2)) * p.ld2 + 64 * ci + lsrc2;
+            const bf16_t* base = p.w2 + (long)(half * (E / 2)) * p.ld2 + 64 * chunk + lsrc2;
 #pragma unroll
             for (int i = 0; i < KT; ++i) glds16(base + (long)(32 * i) * p.ld2, sb + 4096 * i);
         }
-        ++qi;
         slot_i = slot_i + 1 == MLP_NSLOT ? 0 : slot_i + 1;
-        if (j == 3) ci = ci + 1 == NC ? 0 : ci + 1;
+        pos_i = pos_i + 1 == NP ? 0 : pos_i + 1;
     };
-    // step q of the ring: returns the slot base of the piece that may now be read
-    auto acquire = [&](int j) -> const char* {
-        const int ahead = qi - qc - 1;     // younger pieces in flight behind the one we need (KT instructions each)
-        if (ahead >= 3) glds_wait<3 * KT>();
-        else if (ahead == 2) glds_wait<2 * KT>();
-        else if (ahead == 1) glds_wait<KT>();
-        else glds_wait_all();
-        lds_barrier();                     // everybody's quarter landed; everybody finished the previous piece
-        if (qi < limit) issue(j);          // AHEAD = 4 pieces = one chunk ahead: the same j, into the slot just freed
-        const char* sb = smem + slot_c * PIECE;
-        ++qc;
+    // step of the ring: my quarter of the next piece has landed (three younger pieces stay in flight), everybody's has
+    // and everybody is done with the previous piece (barrier), whose slot is re-filled 4 pieces ahead.  Requests run past
+    // the last tile (the weights are the same for every tile; the surplus is drained at the end).
+    const unsigned smem_addr = lds_addr_of(smem);
+    auto acquire = [&]() -> unsigned {
+        glds_wait<(AHEAD - 1) * KT>();
+        lds_barrier();
+        issue();
+        const unsigned sb = smem_addr + (unsigned)(slot_c * PIECE);
         slot_c = slot_c + 1 == MLP_NSLOT ? 0 : slot_c + 1;
         return sb;
     };
-    if (my_tiles > 0) {
 #pragma unroll
-        for (int j = 0; j < AHEAD; ++j) issue(j);
-    }
+    for (int j = 0; j < AHEAD; ++j) issue();
 
     // ---- fragment read offsets inside a piece (one register per k-step; tiles / k-tiles are immediate offsets)
     const int prow = (lq & 19) | ((lq & 4) << 1) | ((lq & 8) >> 1);      // bits 2 and 3 of the row index swapped
@@ -186,7 +209,6 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
         const unsigned keep = dead ? 0u : 0xffffffffu;
         const bool tile_dead = p.rowscale != nullptr && p.rows_per_sample % MLP_BM == 0 &&
                                p.rowscale[m0 / p.rows_per_sample] == 0.0f;
-
         if (tile_dead) {
             // x_out = x, y_next = LayerNorm(x): half a wave per row, row sums by shuffles (as gemm_row384.h's epilogue)
             constexpr int C3 = (E / 4 + 31) / 32;              // 16-byte chunks of a row per lane
@@ -258,39 +280,102 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
 #pragma unroll
                 for (int j = 0; j < KJ; ++j) yf[j] = __builtin_bit_cast(bf16x8, buf_load16(rs_y, lo_y, so + 32 * j));
             }
+            f32x16 h[2];                   // H^T of the chunk being produced: 2 tiles of [32 hidden][32 rows]
+            u32x4 hbw[4];                  // gelu(H) of the chunk being consumed, as packed bf16 B operands (k-step s = hbw[s])
+            const unsigned lut_addr = lds_addr_of(lut) - 4u * MLP_LUT_LO;       // byte address of entry "magnitude 0"
+            auto p1_piece = [&](auto TT, int chunk, auto filler) {   // h[tt] = b1 + W1 piece . y2^T
+                constexpr int tt = decltype(TT)::value;
+                const unsigned sb = acquire();
+                const unsigned areg[4] = {sb + off1[0], sb + off1[1], sb + off1[2], sb + off1[3]};
+                // the accumulator starts at the bias: register r is hidden unit 32 tt + 16 (r >> 3) + 8 hf + (r & 7) for
+                // every row (column of H^T).  Read here, with the LDS queue empty, not between the MFMAs.
+                const float* bp = vb1 + 64 * chunk + 32 * tt + 8 * hf;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4v b = *reinterpret_cast<const f32x4v*>(bp + 16 * (q >> 1) + 4 * (q & 1));
+                    h[tt][4 * q] = b.x; h[tt][4 * q + 1] = b.y; h[tt][4 * q + 2] = b.z; h[tt][4 * q + 3] = b.w;
+                }
+                mlp_product<KJ, DEPTH, MlpMapP1>(
+                    areg, [&](auto K, const bf16x8& a) { h[tt] = mfma_32x32x16_bf16(a, yf[decltype(K)::value], h[tt]); }, filler);
+            };
+            auto p2_piece = [&](auto HH) {                   // acc[half hh] += W2 piece . gelu(H)
+                constexpr int hh = decltype(HH)::value;
+                const unsigned sb = acquire();
+                const unsigned areg[4] = {sb + off2[0], sb + off2[1], sb + off2[2], sb + off2[3]};
+                mlp_product<4 * NTH, DEPTH, MlpMapP2<NTH>>(
+                    areg,
+                    [&](auto K, const bf16x8& a) {
+                        constexpr int k = decltype(K)::value;
+                        acc[NTH * hh + k % NTH] = mfma_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, hbw[k / NTH]), acc[NTH * hh + k % NTH]);
+                    },
+                    [](auto) {});
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            p1_piece(I0{}, 0, [](auto) {});
+            p1_piece(I1{}, 0, [](auto) {});
 #pragma unroll 1
             for (int c = 0; c < NC; ++c) {
-                f32x16 h[2];
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) h[tt][r] = 0.f;
-                    const char* sb = acquire(tt);
-                    mlp_piece_product<KJ, DEPTH>(
-                        [&](int j) { return sb + (j >> 2) * 4096 + off1[j & 3]; },
-                        [&](int j, const bf16x8& a) { h[tt] = mfma_32x32x16_bf16(a, yf[j], h[tt]); });   // H^T[hidden][row]
-                }
-                // GELU of the bf16-rounded pre-activation (what the backward pass will see), packed as B operands:
-                // registers 8 s .. 8 s + 7 of tile tt are hidden units 64 c + 32 tt + 16 s + 8 hf + (0 .. 7)
-                bf16x8 hb[4];
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
-                    const int tt = k4 >> 1, s = k4 & 1;
-                    const float* bp = vb1 + 64 * c + 16 * k4 + 8 * hf;
-                    const f32x4v ba = *reinterpret_cast<const f32x4v*>(bp), bb = *reinterpret_cast<const f32x4v*>(bp + 4);
-                    const float bias[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
-                    u32x4 gw, uw;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const unsigned upk = pack_bf2(h[tt][8 * s + 2 * e] + bias[2 * e], h[tt][8 * s + 2 * e + 1] + bias[2 * e + 1]);
-                        const float u0 = bf_lo(upk), u1 = bf_hi(upk);
-                        uw[e] = upk;
-                        gw[e] = pack_bf2(u0 * gelu_terms(u0).cdf, u1 * gelu_terms(u1).cdf) & keep;
+                // GELU of the bf16-rounded pre-activation (what the backward pass will see) of chunk c, two elements at a
+                // time ("pairs", 8 per tile): registers 8 s + (0 .. 7) of tile tt are hidden units 64 c + 32 tt + 16 s + 8 hf
+                // + (0 .. 7), and the 16 values of a (tt, s) pair ARE the B operand of k-step 2 tt + s of the second product.
+                //   gelu(u) = |u| Phi(|u|) + min(u, 0),  Phi(|u|) gathered from the LDS table by the bf16 magnitude.
+                // A pair is ISSUED (pack, index, two hand-issued gathers) at one MFMA step and FINISHED DEPTH + 1 steps later,
+                // when the counted wait of a fragment read that was issued behind its gathers has passed (LDS returns in
+                // order) - no wait of its own, nothing the compiler would turn into lgkmcnt(0) between the MFMAs.
+                const f32x16 hv[2] = {h[0], h[1]};
+                unsigned upk[8];               // (up to LAG / S + 1 pairs are in flight; slots are static indices)
+                float f0[8], f1[8];
+                u32x4 uw;
+                auto pair_issue = [&](auto PI) {
+                    constexpr int pi = decltype(PI)::value, k4 = pi >> 2, e = pi & 3, r = 8 * (k4 & 1) + 2 * e, sl = pi & 7;
+                    upk[sl] = pack_bf2(hv[k4 >> 1][r], hv[k4 >> 1][r + 1]);
+                    unsigned m0_ = upk[sl] & 0x7fffu, m1_ = (upk[sl] >> 16) & 0x7fffu;
+                    m0_ = m0_ < MLP_LUT_LO ? MLP_LUT_LO : (m0_ > MLP_LUT_HI - 1u ? MLP_LUT_HI - 1u : m0_);
+                    m1_ = m1_ < MLP_LUT_LO ? MLP_LUT_LO : (m1_ > MLP_LUT_HI - 1u ? MLP_LUT_HI - 1u : m1_);
+                    lds_gather_f32(f0[sl], lut_addr + 4u * m0_);
+                    lds_gather_f32(f1[sl], lut_addr + 4u * m1_);
+                };
+                auto pair_finish = [&](auto PI) {
+                    constexpr int pi = decltype(PI)::value, k4 = pi >> 2, e = pi & 3, sl = pi & 7;
+                    lds_landed(f0[sl], f1[sl]);
+                    const float u0 = bf_lo(upk[sl]), u1 = bf_hi(upk[sl]);
+                    const float g0 = fmaf(fabsf(u0), f0[sl], fminf(u0, 0.f));
+                    const float g1 = fmaf(fabsf(u1), f1[sl], fminf(u1, 0.f));
+                    hbw[k4][e] = pack_bf2(g0, g1) & keep;
+                    if (STORE_U) {
+                        uw[e] = upk[sl];
+                        if (e == 3)        // [32 rows][64 hidden] bf16 image in the wave's scratch
+                            *reinterpret_cast<u32x4*>(scratch + lq * 128 + (((2 * k4 + hf) ^ (lq & 7)) * 16)) = uw;
                     }
-                    hb[k4] = __builtin_bit_cast(bf16x8, gw);
-                    if (STORE_U)           // [32 rows][64 hidden] bf16 image in the wave's scratch
-                        *reinterpret_cast<u32x4*>(scratch + lq * 128 + (((2 * k4 + hf) ^ (lq & 7)) * 16)) = uw;
-                    CCD_SCHED_FENCE();     // one group of 8 at a time: bounded temporaries
+                };
+                if (c + 1 < NC) {
+                    // chunk c+1's first product with chunk c's GELU between its MFMAs: pair q of a piece (8 per piece) is
+                    // issued at step q * S and finished at step q * S + DEPTH + 1 when that step exists, else after the piece
+                    constexpr int S = (KJ - DEPTH - 2) / 8 > 0 ? (KJ - DEPTH - 2) / 8 : 1, LAG = DEPTH + 1;
+                    auto piece_with_gelu = [&](auto TT) {
+                        constexpr int tt = decltype(TT)::value;
+                        p1_piece(TT, c + 1, [&](auto K) {
+                            constexpr int k = decltype(K)::value;
+                            if constexpr (k >= LAG && (k - LAG) % S == 0 && (k - LAG) / S < 8)
+                                pair_finish(std::integral_constant<int, 8 * tt + (k - LAG) / S>{});
+                            if constexpr (k % S == 0 && k / S < 8) pair_issue(std::integral_constant<int, 8 * tt + k / S>{});
+                        });
+                        constexpr int first_late = (KJ - 1 - LAG) / S + 1;       // pairs whose finishing step does not exist
+                        if constexpr (first_late < 8) {
+                            lds_drain();
+                            mlp_static_for<8 * tt + (first_late < 0 ? 0 : first_late), 8 * tt + 8>(pair_finish);
+                        }
+                    };
+                    piece_with_gelu(I0{});
+                    piece_with_gelu(I1{});
+                } else {
+                    mlp_static_for<0, 4>([&](auto Gq) {
+                        constexpr int gq = decltype(Gq)::value;
+                        mlp_static_for<4 * gq, 4 * gq + 4>(pair_issue);
+                        lds_drain();
+                        mlp_static_for<4 * gq, 4 * gq + 4>(pair_finish);
+                    });
                 }
                 if (STORE_U) {             // ... leaves as 128-byte row segments
                     wave_lds_fence();
@@ -301,15 +386,8 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                     }
                     wave_lds_fence();
                 }
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const char* sb = acquire(2 + hh);
-                    mlp_piece_product<4 * NTH, DEPTH>(
-                        [&](int k) { return sb + (k % NTH) * 4096 + off2[k / NTH]; },
-                        [&](int k, const bf16x8& a) {
-                            acc[NTH * hh + k % NTH] = mfma_32x32x16_bf16(a, hb[k / NTH], acc[NTH * hh + k % NTH]);   // OUT^T[n][row]
-                        });
-                }
+                p2_piece(I0{});
+                p2_piece(I1{});
             }
         }
         // ---- epilogue: rows are complete inside their two lanes (lane, lane ^ 32): LayerNorm statistics in registers.

@@ -75,6 +75,27 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// LDS fragment reads the compiler must not wait for with lgkmcnt(0): issued by hand, retired by a counted wait that names
+// the fragment (guide 5.7 form (ii): the consumer cannot be scheduled above the wait).  LDS returns in order, so with D
+// reads issued behind the one needed, lds_wait_frag<D> is exact; compiler-issued LDS operations in between only make it
+// conservative.  lds_addr = byte address inside the workgroup's LDS.
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_frag(bf16x8& dst, unsigned lds_addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_frag(bf16x8& frag) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N)); }
+// a 4-byte LDS gather issued by hand (same in-order queue as the fragment reads), and the two ways its result becomes
+// visible to the compiler: after a counted wait that some LATER hand-issued read has passed (lds_landed: no instruction,
+// only a dependency), or after draining the queue (lds_drain)
+__device__ __forceinline__ void lds_gather_f32(float& dst, unsigned lds_addr) {
+    asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(lds_addr));
+}
+__device__ __forceinline__ void lds_landed(float& a, float& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // static wave priority (guide T5): 0..3, arbitration between the waves sharing a SIMD
 template <int P>
 __device__ __forceinline__ void wave_prio() { __builtin_amdgcn_s_setprio(P); }

@@ -141,6 +141,15 @@ inline void glds_wait_all() {}
 template <int N>
 inline void glds_wait() {}
 inline unsigned opaque_u32(unsigned x) { return x; }
+// hand-issued LDS fragment reads (prelude_hip.h): synchronous here; LDS "addresses" are offsets from the block's dynamic LDS
+inline unsigned lds_addr_of(const void* p) { return (unsigned)(reinterpret_cast<const char*>(p) - sim::curblk->dyn_smem); }
+template <int OFF>
+inline void lds_read_frag(bf16x8& dst, unsigned lds_addr) { std::memcpy(&dst, sim::curblk->dyn_smem + lds_addr + OFF, 16); }
+template <int N>
+inline void lds_wait_frag(bf16x8&) {}
+inline void lds_gather_f32(float& dst, unsigned lds_addr) { std::memcpy(&dst, sim::curblk->dyn_smem + lds_addr, 4); }
+inline void lds_landed(float&, float&) {}
+inline void lds_drain() {}
 template <int P>
 inline void wave_prio() {}
 inline void lds_barrier() { __syncthreads(); }
