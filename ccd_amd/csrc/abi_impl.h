@@ -230,7 +230,7 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
               CCD_ALIGNED16(ln_y) && CCD_ALIGNED16(u), CCD_EINVAL);
     if (M == 0) return CCD_OK;
     CCD_CHECK(M > 0 && H > 0 && (!rowscale || rows_per_sample > 0), CCD_EINVAL);
-    CCD_CHECK((E == 192 || E == 384) && H % 64 == 0 && ldy % 8 == 0 && ld1 % 8 == 0 && ld2 % 8 == 0 && ldr % 4 == 0 &&
+    CCD_CHECK((E == 128 || E == 256 || E == 384) && H % 64 == 0 && ldy % 8 == 0 && ld1 % 8 == 0 && ld2 % 8 == 0 && ldr % 4 == 0 &&
               ldc % 4 == 0 && ld_y % 8 == 0 && (!u || ldu % 8 == 0), CCD_ESHAPE);
     CCD_CHECK((long)H * ld1 * 2 < CCD_MAX_OPERAND_BYTES && (long)E * ld2 * 2 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
     const int smem = ccd::mlp_smem_bytes(E, H);
@@ -245,9 +245,12 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
     if (E == 384) {
         if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<384, true>), grid, block, smem, stream, p);
         else CCD_LAUNCH((ccd::mlp_fused_kernel<384, false>), grid, block, smem, stream, p);
+    } else if (E == 256) {
+        if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<256, true>), grid, block, smem, stream, p);
+        else CCD_LAUNCH((ccd::mlp_fused_kernel<256, false>), grid, block, smem, stream, p);
     } else {
-        if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<192, true>), grid, block, smem, stream, p);
-        else CCD_LAUNCH((ccd::mlp_fused_kernel<192, false>), grid, block, smem, stream, p);
+        if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<128, true>), grid, block, smem, stream, p);
+        else CCD_LAUNCH((ccd::mlp_fused_kernel<128, false>), grid, block, smem, stream, p);
     }
     return ccd_rt_last_error();
 }

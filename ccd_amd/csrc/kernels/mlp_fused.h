@@ -10,7 +10,10 @@
 // x_out accumulators too (E/2 VGPRs); nothing of a row is ever exchanged between waves.  Only the WEIGHTS move: W1 and
 // W2 (L2-resident, 2.4 MB at E = 384) stream through a ring of LDS slots by LDS-DMA, in "pieces" of 32 * E * 2 bytes that
 // all four waves consume in lock step, 24 MFMAs per wave and piece (E = 384):
-//     hidden chunk c (64 units):  P1(c,0) P1(c,1)  -> H^T[64 hidden][32 rows] = W1[chunk] . y2^T          (K = E)
+//     hidden chunk c (64 units):  P1(c,0) P1(c,1)  -> H^T[64 hidden][32 rows] = W1[chunk] . y2^T          (K = E,
+//                                 one piece per K half, both 32-unit tiles in each: consecutive MFMAs alternate between
+//                                 two accumulators - a chain on ONE accumulator with other instructions in between
+//                                 pays the full write-back latency per MFMA)
 //                                 GELU in registers: the accumulator layout of H^T IS the B-operand layout of the next
 //                                 product once W1's rows are fed in an order that swaps bits 2 and 3 of the row index
 //                                 P2(c,0) P2(c,1)  -> OUT^T[E][32 rows] += W2[:, chunk] . H                (K = 64)
@@ -73,18 +76,33 @@ __device__ __forceinline__ void mlp_static_for(F&& f) {
     }
 }
 // fragment k of a piece: address register and immediate offset
-struct MlpMapP1 {                                  // [KT k-tiles][32 rows][128 B]: k-step j = (k-tile j >> 2, slot pair j & 3)
-    static constexpr int reg(int k) { return k & 3; }
-    static constexpr int off(int k) { return (k >> 2) * 4096; }
+template <int KTH>
+struct MlpMapP1 {          // [KTH k-tiles][64 hidden rows][128 B]; MFMA k = (tile k & 1, k-step k >> 1 of this K half)
+    static constexpr int reg(int k) { return (k >> 1) & 3; }
+    static constexpr int off(int k) { return (k & 1) * 4096 + (k >> 3) * 8192; }
 };
 template <int NTH>
-struct MlpMapP2 {                                  // [NTH tiles of 32 rows][128 B]: step k = (k-step k / NTH, tile k % NTH)
+struct MlpMapP2 {          // [NTH tiles of 32 rows][128 B]: MFMA k = (k-step k / NTH, tile k % NTH)
     static constexpr int reg(int k) { return k / NTH; }
     static constexpr int off(int k) { return (k % NTH) * 4096; }
 };
-// N MFMAs of one piece: fragments requested DEPTH steps ahead, each retired by a counted wait right before its MFMA
-// (reads issued behind fragment k at that point: min(N - 1 - k, DEPTH - 1)); filler(k) places other work between them
-template <int N, int DEPTH, typename Map, typename Mma, typename Filler>
+// N MFMAs of one piece: fragments requested DEPTH steps ahead, each retired by a counted wait right before its MFMA.
+// Step j is [wait j][MFMA j][read j + DEPTH][filler j], and filler j issues Extra::at(j) further LDS operations by hand
+// (GELU gathers): the wait of step k must leave exactly the operations issued BEHIND read k in flight, whoever issued them.
+struct MlpNoExtra { static constexpr int at(int) { return 0; } };
+template <int N, int DEPTH, typename Extra>
+constexpr int mlp_behind(int k) {
+    int n = 0;
+    if (k < DEPTH) {
+        n += DEPTH - 1 - k;
+        for (int j = 0; j < k; ++j) n += (j + DEPTH < N ? 1 : 0) + Extra::at(j);
+    } else {
+        n += Extra::at(k - DEPTH);
+        for (int j = k - DEPTH + 1; j < k; ++j) n += (j + DEPTH < N ? 1 : 0) + Extra::at(j);
+    }
+    return n;
+}
+template <int N, int DEPTH, typename Map, typename Extra, typename Mma, typename Filler>
 __device__ __forceinline__ void mlp_product(const unsigned (&areg)[4], Mma mma, Filler filler) {
     bf16x8 fr[DEPTH];
     mlp_static_for<0, DEPTH>([&](auto K) {
@@ -93,13 +111,21 @@ __device__ __forceinline__ void mlp_product(const unsigned (&areg)[4], Mma mma, 
     });
     mlp_static_for<0, N>([&](auto K) {
         constexpr int k = decltype(K)::value;
-        lds_wait_frag<(N - 1 - k < DEPTH - 1 ? N - 1 - k : DEPTH - 1)>(fr[k % DEPTH]);
+        constexpr int behind = mlp_behind<N, DEPTH, Extra>(k);
+        lds_wait_frag<(behind < 15 ? behind : 15)>(fr[k % DEPTH]);      // 4-bit counter: waiting for less is still correct
         mma(K, fr[k % DEPTH]);
         if constexpr (k + DEPTH < N) lds_read_frag<Map::off(k + DEPTH)>(fr[k % DEPTH], areg[Map::reg(k + DEPTH)]);
         filler(K);
     });
 }
 
+// GELU pairs between the MFMAs of a first-product piece: pair q (8 per piece) is issued at step q * S (two gathers) and
+// finished LAG steps later
+template <int KJ, int DEPTH>
+struct MlpGeluSchedule {
+    static constexpr int S = (KJ - DEPTH - 2) / 8 > 0 ? (KJ - DEPTH - 2) / 8 : 1, LAG = DEPTH + 1;
+    static constexpr int at(int k) { return (k % S == 0 && k / S < 8) ? 2 : 0; }
+};
 constexpr unsigned MLP_LUT_LO = 0x3B80u, MLP_LUT_HI = 0x4180u;      // bf16 magnitudes 2^-8 .. 16: 1536 table entries
 
 template <int E, bool STORE_U>
@@ -111,7 +137,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
     constexpr int PIECE = mlp_piece_bytes(E);
     constexpr int AHEAD = MLP_NSLOT - 1;   // pieces issued ahead of the one being consumed
     constexpr int DEPTH = 6;               // fragment reads in flight ahead of their MFMA
-    static_assert(E % 64 == 0 && AHEAD == 4, "ring bookkeeping");
+    static_assert(E % 128 == 0 && AHEAD == 4, "ring bookkeeping; a W1 piece is one K half in whole 64-wide k-tiles");
     char* smem = dynamic_smem();
     const int t = threadIdx.x, lane = t & 63, hf = lane >> 5, lq = lane & 31;
     const int w = uniform_i32(t >> 6);     // wave index as a scalar: everything derived from it stays in SGPRs
@@ -132,7 +158,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
 
     // ---- DMA: a piece is 4*KT wave instructions of 1 KiB (8 image rows x 128 B).  Wave w moves the instructions whose
     // 8-row block index is w modulo 4, so ONE per-lane offset per weight matrix serves all of its instructions:
-    //   W1 piece [KT k-tiles][32 hidden rows][128 B]: instruction i = rows 8w .. 8w+7 of k-tile i
+    //   W1 piece [KT/2 k-tiles of one K half][64 hidden rows][128 B]: instruction i = rows 32 (i & 1) + 8w .. + 7 of k-tile i >> 1
     //   W2 piece [E/2 output rows][128 B = 64 hidden units]: instruction i = rows 32 i + 8w .. + 7
     const int dr = lane >> 3, dp = lane & 7;
     const int drow = 8 * w + dr;
@@ -150,9 +176,9 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
             else { is_p2 = 1; chunk = NC - 1; half = r; }
         }
         if (!is_p2) {
-            const bf16_t* base = p.w1 + (long)(64 * chunk + 32 * half) * p.ld1 + lsrc1;
+            const bf16_t* base = p.w1 + (long)(64 * chunk) * p.ld1 + half * (E / 2) + lsrc1;
 #pragma unroll
-            for (int i = 0; i < KT; ++i) glds16(base + 64 * i, sb + 4096 * i);
+            for (int i = 0; i < KT; ++i) glds16(base + (long)(32 * (i & 1)) * p.ld1 + 64 * (i >> 1), sb + 8192 * (i >> 1) + 4096 * (i & 1));
         } else {
             const bf16_t* base = p.w2 + (long)(half * (E / 2)) * p.ld2 + 64 * chunk + lsrc2;
 #pragma unroll
@@ -283,26 +309,36 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
             f32x16 h[2];                   // H^T of the chunk being produced: 2 tiles of [32 hidden][32 rows]
             u32x4 hbw[4];                  // gelu(H) of the chunk being consumed, as packed bf16 B operands (k-step s = hbw[s])
             const unsigned lut_addr = lds_addr_of(lut) - 4u * MLP_LUT_LO;       // byte address of entry "magnitude 0"
-            auto p1_piece = [&](auto TT, int chunk, auto filler) {   // h[tt] = b1 + W1 piece . y2^T
-                constexpr int tt = decltype(TT)::value;
+            auto p1_piece = [&](auto KH, int chunk, auto extra, auto filler) {   // h += W1[chunk][:, K half kh] . y2[K half kh]^T
+                constexpr int kh = decltype(KH)::value;
+                using Extra = decltype(extra);
                 const unsigned sb = acquire();
                 const unsigned areg[4] = {sb + off1[0], sb + off1[1], sb + off1[2], sb + off1[3]};
-                // the accumulator starts at the bias: register r is hidden unit 32 tt + 16 (r >> 3) + 8 hf + (r & 7) for
-                // every row (column of H^T).  Read here, with the LDS queue empty, not between the MFMAs.
-                const float* bp = vb1 + 64 * chunk + 32 * tt + 8 * hf;
+                if constexpr (kh == 0) {
+                    // the accumulators start at the bias: register r of tile tt is hidden unit 32 tt + 16 (r >> 3) + 8 hf +
+                    // (r & 7) for every row (column of H^T).  Read here, with the LDS queue empty, not between the MFMAs.
+                    const float* bp = vb1 + 64 * chunk + 8 * hf;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4v b = *reinterpret_cast<const f32x4v*>(bp + 16 * (q >> 1) + 4 * (q & 1));
-                    h[tt][4 * q] = b.x; h[tt][4 * q + 1] = b.y; h[tt][4 * q + 2] = b.z; h[tt][4 * q + 3] = b.w;
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4v b = *reinterpret_cast<const f32x4v*>(bp + 32 * tt + 16 * (q >> 1) + 4 * (q & 1));
+                            h[tt][4 * q] = b.x; h[tt][4 * q + 1] = b.y; h[tt][4 * q + 2] = b.z; h[tt][4 * q + 3] = b.w;
+                        }
                 }
-                mlp_product<KJ, DEPTH, MlpMapP1>(
-                    areg, [&](auto K, const bf16x8& a) { h[tt] = mfma_32x32x16_bf16(a, yf[decltype(K)::value], h[tt]); }, filler);
+                mlp_product<KJ, DEPTH, MlpMapP1<KT / 2>, Extra>(
+                    areg,
+                    [&](auto K, const bf16x8& a) {
+                        constexpr int k = decltype(K)::value;
+                        h[k & 1] = mfma_32x32x16_bf16(a, yf[(KJ / 2) * kh + (k >> 1)], h[k & 1]);
+                    },
+                    filler);
             };
             auto p2_piece = [&](auto HH) {                   // acc[half hh] += W2 piece . gelu(H)
                 constexpr int hh = decltype(HH)::value;
                 const unsigned sb = acquire();
                 const unsigned areg[4] = {sb + off2[0], sb + off2[1], sb + off2[2], sb + off2[3]};
-                mlp_product<4 * NTH, DEPTH, MlpMapP2<NTH>>(
+                mlp_product<4 * NTH, DEPTH, MlpMapP2<NTH>, MlpNoExtra>(
                     areg,
                     [&](auto K, const bf16x8& a) {
                         constexpr int k = decltype(K)::value;
@@ -312,8 +348,8 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
             };
             using I0 = std::integral_constant<int, 0>;
             using I1 = std::integral_constant<int, 1>;
-            p1_piece(I0{}, 0, [](auto) {});
-            p1_piece(I1{}, 0, [](auto) {});
+            p1_piece(I0{}, 0, MlpNoExtra{}, [](auto) {});
+            p1_piece(I1{}, 0, MlpNoExtra{}, [](auto) {});
 #pragma unroll 1
             for (int c = 0; c < NC; ++c) {
                 // GELU of the bf16-rounded pre-activation (what the backward pass will see) of chunk c, two elements at a
@@ -352,19 +388,19 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                 if (c + 1 < NC) {
                     // chunk c+1's first product with chunk c's GELU between its MFMAs: pair q of a piece (8 per piece) is
                     // issued at step q * S and finished at step q * S + DEPTH + 1 when that step exists, else after the piece
-                    constexpr int S = (KJ - DEPTH - 2) / 8 > 0 ? (KJ - DEPTH - 2) / 8 : 1, LAG = DEPTH + 1;
-                    auto piece_with_gelu = [&](auto TT) {
-                        constexpr int tt = decltype(TT)::value;
-                        p1_piece(TT, c + 1, [&](auto K) {
+                    auto piece_with_gelu = [&](auto KH) {
+                        constexpr int kh = decltype(KH)::value;
+                        p1_piece(KH, c + 1, MlpGeluSchedule<KJ, DEPTH>{}, [&](auto K) {
                             constexpr int k = decltype(K)::value;
-                            if constexpr (k >= LAG && (k - LAG) % S == 0 && (k - LAG) / S < 8)
-                                pair_finish(std::integral_constant<int, 8 * tt + (k - LAG) / S>{});
-                            if constexpr (k % S == 0 && k / S < 8) pair_issue(std::integral_constant<int, 8 * tt + k / S>{});
+                            using Sch = MlpGeluSchedule<KJ, DEPTH>;
+                            if constexpr (k >= Sch::LAG && (k - Sch::LAG) % Sch::S == 0 && (k - Sch::LAG) / Sch::S < 8)
+                                pair_finish(std::integral_constant<int, 8 * kh + (k - Sch::LAG) / Sch::S>{});
+                            if constexpr (Sch::at(k) != 0) pair_issue(std::integral_constant<int, 8 * kh + k / Sch::S>{});
                         });
-                        constexpr int first_late = (KJ - 1 - LAG) / S + 1;       // pairs whose finishing step does not exist
-                        if constexpr (first_late < 8) {
+                        constexpr int first_late = (KJ - 1 - MlpGeluSchedule<KJ, DEPTH>::LAG) / MlpGeluSchedule<KJ, DEPTH>::S + 1;
+                        if constexpr (first_late < 8) {      // pairs whose finishing step does not exist
                             lds_drain();
-                            mlp_static_for<8 * tt + (first_late < 0 ? 0 : first_late), 8 * tt + 8>(pair_finish);
+                            mlp_static_for<8 * kh + (first_late < 0 ? 0 : first_late), 8 * kh + 8>(pair_finish);
                         }
                     };
                     piece_with_gelu(I0{});

@@ -60,7 +60,7 @@ int ccd_gemm_nt_resid_ln(const ccd_bf16* A, long lda, const ccd_bf16* B, long ld
  *   h = gelu(bf16(y . W1^T + b1)) ;  out (f32) = resid + (h . W2^T + b2) * rowscale[row / rows_per_sample]
  *   ln_y (bf16) = (out - mean) * rstd * ln_gamma + ln_beta ;  ln_mean / ln_rstd [M] saved for ccd_ln_bwd
  * The [M, H] hidden activation stays on chip; `u` (optional, [M, H] bf16) receives the pre-activation the backward
- * pass needs.  W1 = fc1.weight [H, E], W2 = fc2.weight [E, H] (bf16).  E in {192, 384}, H % 64 == 0.
+ * pass needs.  W1 = fc1.weight [H, E], W2 = fc2.weight [E, H] (bf16).  E in {128, 256, 384}, H % 64 == 0.
  * Replaces ccd_gemm_nt(EPI_GELU) + ccd_gemm_nt_resid_ln. */
 int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, const float* b1, const ccd_bf16* w2, long ld2,
                   const float* b2, const float* resid, long ldr, const float* rowscale, int rows_per_sample, float* out,

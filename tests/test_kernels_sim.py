@@ -168,5 +168,5 @@ def test_decoder_abi_rejects_unsupported_arguments(sim):
 
 def test_mlp_fused_sim(sim):
     """Ragged last tile, several tiles per workgroup (1 CU), a dropped sample, both instantiations of E."""
-    kc.check_mlp_fused(sim.device, M=300, E=192, H=256, rps=128)
+    kc.check_mlp_fused(sim.device, M=300, E=128, H=256, rps=128)
     kc.check_mlp_fused(sim.device, M=200, E=384, H=128, rps=8, store_u=False)     # per-row DropPath scales
