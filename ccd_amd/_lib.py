@@ -26,6 +26,8 @@ U64 = C.c_uint64
 SIGNATURES = {
     "ccd_abi_version": [],
     "ccd_build_info": [],
+    "ccd_policy_set": [C.c_char_p, I],
+    "ccd_policy_get": [C.c_char_p, P],
     "ccd_gemm_nt": [P, L, P, L, I, I, I, I, P, L, P, L, P, P, L, P, I, P, L, F, I, P, I, P, P],
     "ccd_gemm_nt_resid_ln": [P, L, P, L, I, I, I, P, L, P, P, L, P, I, P, P, F, P, L, P, P, P],
     "ccd_gemm_tn": [P, L, P, L, I, I, I, I, P, L, F, I, P, I, P],

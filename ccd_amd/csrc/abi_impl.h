@@ -6,8 +6,6 @@
 #include "../../include/ccd_hip.h"
 #include "kernels/common.h"
 #include "kernels/gemm.h"
-#include "kernels/gemm_ares.h"
-#include "kernels/gemm_nt32.h"
 #include "kernels/gemm256.h"
 #include "kernels/gemm_row384.h"
 #include "kernels/mlp_fused.h"
@@ -54,35 +52,6 @@ static int ccd_launch_gemm(ccd::GemmParams p, int epilogue, int splits, void* st
     return ccd_rt_last_error();
 }
 
-// short-K products of the transformer run on the A-resident persistent kernel (gemm_ares.h)
-static int ccd_launch_gemm_ares(const ccd::GemmParams& p, int epilogue, void* stream) {
-    const int tiles_m = (p.M + 127) / 128;
-    const int cus = ccd_rt_num_cus();
-    const dim3 grid(tiles_m < cus ? tiles_m : cus), block(ccd::ARES_THREADS);
-    const size_t smem = ccd::ARES_SMEM_BYTES;
-    switch (epilogue) {
-        case CCD_EPI_BF16: CCD_LAUNCH((ccd::gemm_ares_kernel<ccd::EPI_BF16>), grid, block, smem, stream, p); break;
-        case CCD_EPI_GELU: CCD_LAUNCH((ccd::gemm_ares_kernel<ccd::EPI_GELU>), grid, block, smem, stream, p); break;
-        case CCD_EPI_RESID: CCD_LAUNCH((ccd::gemm_ares_kernel<ccd::EPI_RESID>), grid, block, smem, stream, p); break;
-        case CCD_EPI_DGELU: CCD_LAUNCH((ccd::gemm_ares_kernel<ccd::EPI_DGELU>), grid, block, smem, stream, p); break;
-        default: return CCD_EINVAL;
-    }
-    return ccd_rt_last_error();
-}
-static int ccd_launch_gemm_nt32(const ccd::GemmParams& p, int epilogue, void* stream) {
-    const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
-    const dim3 grid(tiles), block(256);
-    const size_t smem = ccd::NT32_SMEM_BYTES;
-    switch (epilogue) {
-        case CCD_EPI_BF16: CCD_LAUNCH((ccd::gemm_nt32_kernel<ccd::EPI_BF16>), grid, block, smem, stream, p); break;
-        case CCD_EPI_GELU: CCD_LAUNCH((ccd::gemm_nt32_kernel<ccd::EPI_GELU>), grid, block, smem, stream, p); break;
-        case CCD_EPI_RESID: CCD_LAUNCH((ccd::gemm_nt32_kernel<ccd::EPI_RESID>), grid, block, smem, stream, p); break;
-        case CCD_EPI_F32: CCD_LAUNCH((ccd::gemm_nt32_kernel<ccd::EPI_F32>), grid, block, smem, stream, p); break;
-        case CCD_EPI_DGELU: CCD_LAUNCH((ccd::gemm_nt32_kernel<ccd::EPI_DGELU>), grid, block, smem, stream, p); break;
-        default: return CCD_EINVAL;
-    }
-    return ccd_rt_last_error();
-}
 // launch geometry of the column reductions (colsum_bf16, bn_relu_bwd_reduce): cgn = 2^cgn_log2 column groups of 8
 // per 1024-thread block (<= 32), every block streams >= 1 MiB, at most 2 blocks per CU (the publishing atomics are
 // the expensive part: few, fat blocks)
@@ -101,7 +70,37 @@ static void ccd_reduce_geometry(long rows, int N, int* cgn_log2, int* col_blocks
     *rows_per_block = (int)rpb;
     *row_blocks = (int)((rows + rpb - 1) / rpb);
 }
-static bool ccd_env_flag(const char* name, bool dflt);
+// Kernel-selection policy: a small table of integers parsed ONCE from the environment (CCD_<KEY in upper case>) and
+// changeable at run time through ccd_policy_set (include/ccd_hip.h) - no getenv on the launch path.
+struct CcdPolicy {
+    int gemm_256 = 1;           // 0 off, 1 = 256x256 tiles for N >= gemm_256_min_n bf16-output products, 2 = also 256x128 tiles
+    int gemm_256_min_m = 2048, gemm_256_min_n = 384;
+    int gemm_256_f32 = 0;       // 256-row kernels also for the fp32 / residual epilogues
+    int gemm_256_deep = 0;      // BK = 32 x 4 buffers (three k-steps of DMA in flight) instead of BK = 64 x 2
+    int gemm_row384 = 0;        // 1 = full-row kernel for N <= 384 residual / fp32 epilogues, 2 = bf16 too
+    int ln_bwd_bpc = 5;         // LayerNorm backward: blocks per CU (one resident wave; more blocks = more dgamma/dbeta atomics)
+    int dec_attn_simt = 0;      // decoder attention: force the general SIMT kernels
+};
+struct CcdPolicyKey { const char* name; int CcdPolicy::*field; };
+static const CcdPolicyKey ccd_policy_keys[] = {
+    {"gemm_256", &CcdPolicy::gemm_256}, {"gemm_256_min_m", &CcdPolicy::gemm_256_min_m},
+    {"gemm_256_min_n", &CcdPolicy::gemm_256_min_n}, {"gemm_256_f32", &CcdPolicy::gemm_256_f32},
+    {"gemm_256_deep", &CcdPolicy::gemm_256_deep}, {"gemm_row384", &CcdPolicy::gemm_row384},
+    {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}};
+static CcdPolicy& ccd_policy() {
+    static CcdPolicy pol = [] {
+        CcdPolicy q;
+        for (const CcdPolicyKey& k : ccd_policy_keys) {
+            char env[64] = "CCD_";
+            size_t n = 4;
+            for (const char* c = k.name; *c && n + 1 < sizeof(env); ++c) env[n++] = (char)(*c >= 'a' && *c <= 'z' ? *c - 32 : *c);
+            env[n] = 0;
+            if (const char* v = getenv(env)) q.*(k.field) = atoi(v);
+        }
+        return q;
+    }();
+    return pol;
+}
 // 256x256-tile LDS-DMA kernel for the large-M products (gemm256.h): one workgroup per CU
 template <int BN, bool DEEP = false>
 static int ccd_launch_gemm256(const ccd::GemmParams& p, int epilogue, void* stream) {
@@ -134,15 +133,23 @@ static int ccd_launch_gemm_row384(const ccd::GemmParams& p, int epilogue, void* 
     }
     return ccd_rt_last_error();
 }
-static bool ccd_env_flag(const char* name, bool dflt) {
-    const char* v = getenv(name);
-    return v ? (v[0] != '0') : dflt;
-}
 
 extern "C" {
 
-int ccd_abi_version(void) { return 2; }   // 2: finetune-path entry points (ccd_dropout ... ccd_greedy_step, ccd_droppath_scales)
-const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi2"; }
+int ccd_abi_version(void) { return 3; }   // 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
+const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi3"; }
+int ccd_policy_set(const char* key, int value) {
+    CCD_CHECK(key, CCD_EINVAL);
+    for (const CcdPolicyKey& k : ccd_policy_keys)
+        if (!strcmp(k.name, key)) { ccd_policy().*(k.field) = value; return CCD_OK; }
+    return CCD_EINVAL;
+}
+int ccd_policy_get(const char* key, int* value) {
+    CCD_CHECK(key && value, CCD_EINVAL);
+    for (const CcdPolicyKey& k : ccd_policy_keys)
+        if (!strcmp(k.name, key)) { *value = ccd_policy().*(k.field); return CCD_OK; }
+    return CCD_EINVAL;
+}
 
 // ----------------------------------------------------------------------------------------------- GEMM
 int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, int epilogue, void* C,
@@ -169,34 +176,19 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
         for (int sft = 0; sft < 31; ++sft) if ((1 << sft) == rows_per_sample) p.rps_shift = sft;
     p.k_per_split = K; p.m_fastest = m_fastest; p.alpha = alpha; p.d_rows = d_rows; p.rows_mul = rows_mul;
     p.colsum = colsum;
-    // kernel choice (all three are parity-tested): CCD_GEMM_NT32=0 / CCD_GEMM_ARES=1 switch variants for A/B timing
-    // read per call (not cached): the tests flip these to force small problems through the 256-row kernels.
-    // CCD_GEMM_256: 0 = off, 1 = 256x256 tiles for N >= 384 bf16-output epilogues (default), 2 = additionally 256x128
-    // tiles for every other large-M product (lab switch; see DESIGN.md section 3 for the measurements)
-    const char* g256 = getenv("CCD_GEMM_256");
-    const int mode_256 = g256 ? atoi(g256) : 1;
-    const int min_m_256 = getenv("CCD_GEMM_256_MIN_M") ? atoi(getenv("CCD_GEMM_256_MIN_M")) : 2048;
-    const int min_n_256 = getenv("CCD_GEMM_256_MIN_N") ? atoi(getenv("CCD_GEMM_256_MIN_N")) : 384;
-    // CCD_GEMM_ROW384: 1 = full-row kernel for N <= 384 (residual / fp32 / bf16 epilogues)
-    const int mode_row = getenv("CCD_GEMM_ROW384") ? atoi(getenv("CCD_GEMM_ROW384")) : 0;
-    if (mode_row >= 1 && N <= ccd::GR_BN && M >= min_m_256 &&
-        (epilogue == CCD_EPI_RESID || epilogue == CCD_EPI_F32 || (epilogue == CCD_EPI_BF16 && mode_row >= 2)))
+    // kernel choice by the policy table (defaults measured in DESIGN.md section 3; the tests change it through
+    // ccd_policy_set to force small problems through the 256-row kernels)
+    const CcdPolicy& pol = ccd_policy();
+    if (pol.gemm_row384 >= 1 && N <= ccd::GR_BN && M >= pol.gemm_256_min_m &&
+        (epilogue == CCD_EPI_RESID || epilogue == CCD_EPI_F32 || (epilogue == CCD_EPI_BF16 && pol.gemm_row384 >= 2)))
         return ccd_launch_gemm_row384(p, epilogue, stream);
-    const bool f32_too = ccd_env_flag("CCD_GEMM_256_F32", false);
     const bool bf16_out = epilogue == CCD_EPI_BF16 || epilogue == CCD_EPI_GELU || epilogue == CCD_EPI_DGELU;
-    if (mode_256 >= 1 && (bf16_out || (f32_too && epilogue != CCD_EPI_ATOMIC)) && M >= min_m_256 && N >= min_n_256) {
-        // CCD_GEMM_256_DEEP: BK = 32 x 4 buffers (three k-steps of DMA in flight) instead of BK = 64 x 2
-        if (ccd_env_flag("CCD_GEMM_256_DEEP", false)) return ccd_launch_gemm256<256, true>(p, epilogue, stream);
+    if (pol.gemm_256 >= 1 && (bf16_out || (pol.gemm_256_f32 && epilogue != CCD_EPI_ATOMIC)) && M >= pol.gemm_256_min_m &&
+        N >= pol.gemm_256_min_n) {
+        if (pol.gemm_256_deep) return ccd_launch_gemm256<256, true>(p, epilogue, stream);
         return ccd_launch_gemm256<256>(p, epilogue, stream);
     }
-    if (mode_256 >= 2 && epilogue != CCD_EPI_ATOMIC && M >= min_m_256) return ccd_launch_gemm256<128>(p, epilogue, stream);
-    static const bool use_nt32 = ccd_env_flag("CCD_GEMM_NT32", false);
-    static const bool use_ares = ccd_env_flag("CCD_GEMM_ARES", false);
-    const bool ares_epi = epilogue == CCD_EPI_BF16 || epilogue == CCD_EPI_GELU || epilogue == CCD_EPI_RESID ||
-                          epilogue == CCD_EPI_DGELU;
-    if (use_ares && ares_epi && !d_rows && K <= 64 * ccd::ARES_MAX_KC && K % 128 == 0 && M >= 1024 && N % 4 == 0)
-        return ccd_launch_gemm_ares(p, epilogue, stream);
-    if (use_nt32 && epilogue != CCD_EPI_ATOMIC && N % 4 == 0) return ccd_launch_gemm_nt32(p, epilogue, stream);
+    if (pol.gemm_256 >= 2 && epilogue != CCD_EPI_ATOMIC && M >= pol.gemm_256_min_m) return ccd_launch_gemm256<128>(p, epilogue, stream);
     return ccd_launch_gemm<false>(p, epilogue, 1, stream);
 }
 
@@ -300,8 +292,7 @@ int ccd_ln_bwd(const ccd_bf16* dy, const float* x, const float* mean, const floa
     if (rows == 0) return CCD_OK;
     CCD_CHECK(rows > 0 && E > 0 && E % 4 == 0 && E <= 64 * ccd::LN_VEC * ccd::LN_STEPS, CCD_ESHAPE);
     CCD_CHECK(!rowscale || rows_per_sample > 0, CCD_EINVAL);
-    static const int ln_bpc = getenv("CCD_LN_BWD_BPC") ? atoi(getenv("CCD_LN_BWD_BPC")) : 5;   // one resident wave of blocks; more blocks = more dgamma/dbeta atomics (measured 187 -> 165 us)
-    int blocks = ln_bpc * ccd_rt_num_cus();
+    int blocks = ccd_policy().ln_bwd_bpc * ccd_rt_num_cus();   // one resident wave of blocks (measured 187 -> 165 us vs 8 / CU)
     int rpb = (rows + blocks - 1) / blocks;
     rpb = ((rpb + 3) / 4) * 4;
     blocks = (rows + rpb - 1) / rpb;
@@ -835,10 +826,10 @@ int ccd_dec_embed_bwd(const int64_t* tokens, const float* dx, float* demb, int r
 }
 // the MFMA kernels (decoder_xattn.h) cover the unmasked 256-key case; CCD_DEC_ATTN_SIMT=1 forces the general kernels
 static bool ccd_dec_attn_mfma(const ccd::DecAttnParams& p) {
-    return p.Tk == ccd::XA_TK && !p.tokens && !p.key_len && !p.causal && !ccd_env_flag("CCD_DEC_ATTN_SIMT", false);
+    return p.Tk == ccd::XA_TK && !p.tokens && !p.key_len && !p.causal && !ccd_policy().dec_attn_simt;
 }
 static bool ccd_sattn_mfma(const ccd::DecAttnParams& p) {
-    return p.Tk <= ccd::XA_TQ && !ccd_env_flag("CCD_DEC_ATTN_SIMT", false);
+    return p.Tk <= ccd::XA_TQ && !ccd_policy().dec_attn_simt;
 }
 static int ccd_dec_attn_check(const ccd::DecAttnParams& p) {
     CCD_CHECK(p.B >= 0 && p.H > 0, CCD_EINVAL);

@@ -218,21 +218,26 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
     const buf_rsrc rs_o = make_rsrc(p.out, (unsigned)((((long)p.M - 1) * p.ldc + E) * 4));
     const buf_rsrc rs_n = make_rsrc(p.ln_y, (unsigned)((((long)p.M - 1) * p.ld_y + E) * 2));
     const buf_rsrc rs_u = make_rsrc(STORE_U ? p.u : nullptr, STORE_U ? (unsigned)((((long)p.M - 1) * p.ldu + p.H) * 2) : 0u);
-    const unsigned lo_y = (unsigned)((lq * p.ldy_in + 8 * hf) * 2), lo_x = (unsigned)((lq * p.ldr + 4 * hf) * 4);
-    const unsigned lo_o = (unsigned)(dr * p.ldc * 4 + dp * 16), lo_n = (unsigned)(dr * p.ld_y * 2 + dp * 16);
-    const unsigned lo_u = STORE_U ? (unsigned)(dr * p.ldu * 2 + dp * 16) : 0u;
-
+    // per-lane offsets of the row-tile traffic are recomputed from the lane id where they are used (LaneOff below): kept in
+    // registers across the main loop they were the first values the allocator spilled, and a scratch reload in front of
+    // every store (s_waitcnt vmcnt(0)!) serialised the whole epilogue
+    struct LaneOff {
+        int lane, hf, lq, dr, dp;
+        __device__ __forceinline__ explicit LaneOff(int t) {
+            lane = opaque_vgpr(t) & 63; hf = lane >> 5; lq = lane & 31; dr = lane >> 3; dp = lane & 7;
+        }
+        __device__ __forceinline__ unsigned frag(long ld, int elt, int per_hf) const { return (unsigned)((lq * ld + per_hf * hf) * elt); }
+        __device__ __forceinline__ unsigned rows8(long ld, int elt) const { return (unsigned)(dr * ld * elt + dp * 16); }
+        __device__ __forceinline__ unsigned scr_rd(int i) const { return (unsigned)((dr + 8 * i) * 128 + ((dp ^ dr) * 16)); }
+        __device__ __forceinline__ unsigned scr_wr(int slot16) const { return (unsigned)(lq * 128 + ((slot16 ^ (lq & 7)) * 16)); }
+    };
     for (int tile = blockIdx.x; tile < tiles; tile += G) {
         const int m0 = tile * MLP_BM, r0 = m0 + 32 * w;
         const int row = r0 + lq, grow = row < p.M ? row : p.M - 1;
-        // DropPath: out = x + sc * f(x).  sc != 0: acc starts at x / sc and (acc + b2) is scaled by sc at the end; sc == 0
-        // (dropped sample): acc starts at x and this row's column of H is zeroed.  A tile of dropped samples only
+        // DropPath: out = x + sc * (h . W2^T + b2), sc per sample (0 for a dropped one).  A tile of dropped samples only
         // (rows_per_sample a multiple of the tile height) skips the products altogether.
         float sc = 1.0f;
         if (p.rowscale) sc = p.rowscale[grow / p.rows_per_sample];
-        const bool dead = sc == 0.0f;
-        const float inv = dead ? 1.0f : 1.0f / sc, osc = dead ? 1.0f : sc;
-        const unsigned keep = dead ? 0u : 0xffffffffu;
         const bool tile_dead = p.rowscale != nullptr && p.rows_per_sample % MLP_BM == 0 &&
                                p.rowscale[m0 / p.rows_per_sample] == 0.0f;
         if (tile_dead) {
@@ -273,6 +278,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
             }
             if (STORE_U) {
                 // the backward pass multiplies a zero gradient by gelu'(u) for these rows: u must be finite
+                const unsigned lo_u = LaneOff(t).rows8(p.ldu, 2);
 #pragma unroll 1
                 for (int cc = 0; cc < p.H / 64; ++cc)
 #pragma unroll
@@ -281,28 +287,15 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
             }
             continue;
         }
-        // the residual rows go straight into the accumulators (scaled by 1 / sc; b2 joins in the epilogue)
         f32x16 acc[NT];
-        {
-            const unsigned so = (unsigned)r0 * (unsigned)(p.ldr * 4);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4v x = __builtin_bit_cast(f32x4v, buf_load16(rs_x, lo_x, so + (32 * nt + 8 * g) * 4));
-                    acc[nt][4 * g + 0] = x.x * inv;
-                    acc[nt][4 * g + 1] = x.y * inv;
-                    acc[nt][4 * g + 2] = x.z * inv;
-                    acc[nt][4 * g + 3] = x.w * inv;
-                }
-                if (nt % 4 == 3) CCD_SCHED_FENCE();      // four tiles' worth of loads (64 VGPRs) in flight at a time
-            }
-        }
-        CCD_SCHED_FENCE();
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
         {
-            bf16x8 yf[KJ];                 // this lane's row of y2 as B operands: k = 16 j + 8 hf .. + 7
+            bf16x8 yf[KJ];                 // this lane's row of y2 as B operands of the first product: k = 16 j + 8 hf .. + 7
             {
-                const unsigned so = (unsigned)r0 * (unsigned)(p.ldy_in * 2);
+                const unsigned so = (unsigned)r0 * (unsigned)(p.ldy_in * 2), lo_y = LaneOff(t).frag(p.ldy_in, 2, 8);
 #pragma unroll
                 for (int j = 0; j < KJ; ++j) yf[j] = __builtin_bit_cast(bf16x8, buf_load16(rs_y, lo_y, so + 32 * j));
             }
@@ -378,11 +371,13 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                     const float u0 = bf_lo(upk[sl]), u1 = bf_hi(upk[sl]);
                     const float g0 = fmaf(fabsf(u0), f0[sl], fminf(u0, 0.f));
                     const float g1 = fmaf(fabsf(u1), f1[sl], fminf(u1, 0.f));
-                    hbw[k4][e] = pack_bf2(g0, g1) & keep;
+                    hbw[k4][e] = pack_bf2(g0, g1);
                     if (STORE_U) {
                         uw[e] = upk[sl];
-                        if (e == 3)        // [32 rows][64 hidden] bf16 image in the wave's scratch
-                            *reinterpret_cast<u32x4*>(scratch + lq * 128 + (((2 * k4 + hf) ^ (lq & 7)) * 16)) = uw;
+                        if (e == 3) {      // [32 rows][64 hidden] bf16 image in the wave's scratch
+                            const LaneOff lo(t);
+                            *reinterpret_cast<u32x4*>(scratch + lo.scr_wr(2 * k4 + lo.hf)) = uw;
+                        }
                     }
                 };
                 if (c + 1 < NC) {
@@ -415,9 +410,11 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                 }
                 if (STORE_U) {             // ... leaves as 128-byte row segments
                     wave_lds_fence();
+                    const LaneOff lo(t);
+                    const unsigned lo_u = lo.rows8(p.ldu, 2);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const u32x4 v = *reinterpret_cast<const u32x4*>(scratch + (dr + 8 * i) * 128 + ((dp ^ dr) * 16));
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(scratch + lo.scr_rd(i));
                         buf_store16(rs_u, lo_u, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldu * 2) + 128 * c, v);
                     }
                     wave_lds_fence();
@@ -426,27 +423,37 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                 p2_piece(I1{});
             }
         }
-        // ---- epilogue: rows are complete inside their two lanes (lane, lane ^ 32): LayerNorm statistics in registers.
-        // out = (acc + b2) * sc (a dropped row is x itself); the accumulators are only READ here (they stay where
-        // the matrix pipe left them), each pass recomputes the few values it stores.
-        const float bsc = dead ? 0.0f : osc;
-        auto outv = [&](int nt, int g, float k_osc, float k_bsc, float (&v)[4]) {
-            const f32x4v b = *reinterpret_cast<const f32x4v*>(vb2 + 32 * nt + 8 * g + 4 * hf);
-            v[0] = fmaf(acc[nt][4 * g + 0], k_osc, b.x * k_bsc);
-            v[1] = fmaf(acc[nt][4 * g + 1], k_osc, b.y * k_bsc);
-            v[2] = fmaf(acc[nt][4 * g + 2], k_osc, b.z * k_bsc);
-            v[3] = fmaf(acc[nt][4 * g + 3], k_osc, b.w * k_bsc);
-        };
+        // ---- epilogue: rows are complete inside their two lanes (lane, lane ^ 32).
+        // Pass A: out = x + (acc + b2) * sc written back into the accumulators, LayerNorm statistics on the way; the
+        // residual rows stream in two tiles ahead of their use.
         float s1 = 0.f, s2 = 0.f;
+        {
+            const unsigned so = (unsigned)r0 * (unsigned)(p.ldr * 4), lo_x = LaneOff(t).frag(p.ldr, 4, 4);
+            u32x4 xb[3][4];
+            auto load_x = [&](int nt) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+                for (int g = 0; g < 4; ++g) xb[nt % 3][g] = buf_load16(rs_x, lo_x, so + (32 * nt + 8 * g) * 4);
+            };
+            load_x(0);
+            if (NT > 1) load_x(1);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v[4];
-                outv(nt, g, osc, bsc, v);
+            for (int nt = 0; nt < NT; ++nt) {
+                if (nt + 2 < NT) load_x(nt + 2);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4v x = __builtin_bit_cast(f32x4v, xb[nt % 3][g]);
+                    const f32x4v b = *reinterpret_cast<const f32x4v*>(vb2 + 32 * nt + 8 * g + 4 * hf);
+                    const float xx[4] = {x.x, x.y, x.z, x.w}, bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = xx[e] + (acc[nt][4 * g + e] + bb[e]) * sc;
+                        acc[nt][4 * g + e] = v;
+                        s1 += v;
+                        s2 = fmaf(v, v, s2);
+                    }
+                }
             }
+        }
         s1 += shfl_xor(s1, 32);
         s2 += shfl_xor(s2, 32);
         const float mean = s1 * inv_e;
@@ -454,10 +461,9 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
         var = var > 0.f ? var : 0.f;
         const float rstd = 1.0f / sqrtf(var + p.ln_eps);
         if (hf == 0 && row < p.M) { p.ln_mean[row] = mean; p.ln_rstd[row] = rstd; }
-        // (the second pass must RECOMPUTE its values: were the compiler to keep the first pass's 6 E / 8 results alive,
-        // they would not fit the register file - its scale factors are therefore opaque copies)
-        float osc2 = osc, bsc2 = bsc;
-        asm volatile("" : "+v"(osc2), "+v"(bsc2));
+        const LaneOff lo(t);
+        const unsigned lo_o = lo.rows8(p.ldc, 4), lo_n = lo.rows8(p.ld_y, 2);
+        // Pass B:
         // per pair of 32-column tiles: x_out (fp32, one tile at a time) and y_next (bf16, both tiles) through the scratch
         // image, leaving as 128-byte row segments
 #pragma unroll
@@ -468,10 +474,9 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                 const int nt = 2 * np + tt;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    float v[4];
-                    outv(nt, g, osc2, bsc2, v);
+                    const float v[4] = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
                     const f32x4v o = {v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4v*>(scratch + lq * 128 + (((2 * g + hf) ^ (lq & 7)) * 16)) = o;
+                    *reinterpret_cast<f32x4v*>(scratch + lo.scr_wr(2 * g + lo.hf)) = o;
                     const int n = 32 * nt + 8 * g + 4 * hf;
                     const f32x4v ga = *reinterpret_cast<const f32x4v*>(vga + n), be = *reinterpret_cast<const f32x4v*>(vbe + n);
                     ypk[tt][g].x = pack_bf2((v[0] - mean) * rstd * ga.x + be.x, (v[1] - mean) * rstd * ga.y + be.y);
@@ -480,7 +485,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                 wave_lds_fence();
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(scratch + (dr + 8 * i) * 128 + ((dp ^ dr) * 16));
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(scratch + lo.scr_rd(i));
                     buf_store16(rs_o, lo_o, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldc * 4) + 128 * nt, v);
                 }
                 wave_lds_fence();
@@ -489,11 +494,11 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<u32x2*>(scratch + lq * 128 + (((4 * tt + g) ^ (lq & 7)) * 16) + 8 * hf) = ypk[tt][g];
+                    *reinterpret_cast<u32x2*>(scratch + lo.scr_wr(4 * tt + g) + 8 * lo.hf) = ypk[tt][g];
             wave_lds_fence();
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(scratch + (dr + 8 * i) * 128 + ((dp ^ dr) * 16));
+                const u32x4 v = *reinterpret_cast<const u32x4*>(scratch + lo.scr_rd(i));
                 buf_store16(rs_n, lo_n, (unsigned)(r0 + 8 * i) * (unsigned)(p.ld_y * 2) + 128 * np, v);
             }
             wave_lds_fence();

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace ccd {
 typedef __attribute__((ext_vector_type(8))) short bf16x8;    // 8 raw bf16 = one MFMA A/B fragment (4 VGPRs)
@@ -56,6 +57,15 @@ __device__ __forceinline__ buf_u32x4 buf_load16(buf_rsrc r, unsigned lane_offset
 __device__ __forceinline__ void buf_store16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset, buf_u32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)lane_offset, (int)uniform_offset, 0);
 }
+// streaming variants: non-temporal cache policy (aux = 2, "nt"): data that is touched once must not push the L2-resident
+// operands (weights) of the same kernel out of the XCD's 4-MiB L2
+__device__ __forceinline__ buf_u32x4 buf_load16_nt(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_offset, (int)uniform_offset, 2);
+}
+__device__ __forceinline__ void buf_store16_nt(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset, buf_u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)lane_offset, (int)uniform_offset, 2);
+}
+__device__ __forceinline__ void wave_sleep(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127); }   // ~n * 8 k cycles
 // LDS-DMA: one wave instruction copies 64 x 16 B from per-lane global addresses straight into LDS at
 // (wave-uniform lds_base) + lane * 16 - no VGPR round trip, counted on vmcnt like any VMEM load.
 __device__ __forceinline__ void glds16(const void* gptr, char* lds_base) {
@@ -102,6 +112,9 @@ __device__ __forceinline__ void wave_prio() { __builtin_amdgcn_s_setprio(P); }
 // value the optimiser must treat as unknown (keeps `base ^ constant` address arithmetic inside a loop instead of
 // hoisting one register per combination)
 __device__ __forceinline__ unsigned opaque_u32(unsigned x) { asm volatile("" : "+s"(x)); return x; }
+// the same for a per-lane value, and NOT hoistable out of a loop: address arithmetic derived from it is redone where it is
+// used instead of living in a register (or, worse, in scratch) across a register-starved main loop
+__device__ __forceinline__ int opaque_vgpr(int x) { asm volatile("" : "+v"(x)); return x; }
 // hardware float -> bf16 (RNE): clang lowers the __bf16 casts to v_cvt_pk_bf16_f32 on gfx950
 typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {

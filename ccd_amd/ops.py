@@ -42,6 +42,34 @@ class KernelTimer:
 TIMER = None     # set to a KernelTimer to time every GEMM launch
 
 
+def policy_set(key, value):
+    """Kernel-selection policy of the library (include/ccd_hip.h: ccd_policy_set), e.g. policy_set('gemm_256_min_m', 1)."""
+    _lib.check(_lib.get().ccd_policy_set(key.encode(), int(value)), f"policy_set({key})")
+
+
+def policy_get(key):
+    v = ctypes.c_int(0)
+    _lib.check(_lib.get().ccd_policy_get(key.encode(), ctypes.byref(v)), f"policy_get({key})")
+    return v.value
+
+
+class policy:
+    """with ops.policy(gemm_256_min_m=1, gemm_row384=2): ...   (restores the previous values on exit)"""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.saved = {k: policy_get(k) for k in self.kw}
+        for k, v in self.kw.items():
+            policy_set(k, v)
+        return self
+
+    def __exit__(self, *a):
+        for k, v in self.saved.items():
+            policy_set(k, v)
+
+
 def _chk(t, dtype, name):
     if t is None:
         return

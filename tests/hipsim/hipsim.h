@@ -141,6 +141,7 @@ inline void glds_wait_all() {}
 template <int N>
 inline void glds_wait() {}
 inline unsigned opaque_u32(unsigned x) { return x; }
+inline int opaque_vgpr(int x) { return x; }
 // hand-issued LDS fragment reads (prelude_hip.h): synchronous here; LDS "addresses" are offsets from the block's dynamic LDS
 inline unsigned lds_addr_of(const void* p) { return (unsigned)(reinterpret_cast<const char*>(p) - sim::curblk->dyn_smem); }
 template <int OFF>
@@ -173,6 +174,9 @@ inline void buf_store16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offse
     const unsigned long long o = (unsigned long long)lane_offset + uniform_offset;
     if (o + 16ull <= (unsigned long long)r.bytes) std::memcpy(const_cast<char*>(r.base) + o, &v, 16);
 }
+inline buf_u32x4 buf_load16_nt(buf_rsrc r, unsigned a, unsigned b) { return buf_load16(r, a, b); }
+inline void buf_store16_nt(buf_rsrc r, unsigned a, unsigned b, buf_u32x4 v) { buf_store16(r, a, b, v); }
+inline void wave_sleep(int) {}
 inline int lane_id() { return sim::cur->lane; }
 inline int wave_id() { return sim::cur->wave; }
 

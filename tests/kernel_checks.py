@@ -799,13 +799,9 @@ def check_tf_loss(dev, B=6, T=25, C=92, seed=43):
 
 
 def check_decoder_pieces(dev):
-    import os
-    os.environ["CCD_DEC_ATTN_SIMT"] = "1"                              # the general (masked / short) kernels on the 256-key case
-    try:
+    with ops.policy(dec_attn_simt=1):                                  # the general (masked / short) kernels on the 256-key case
         check_dec_attn(dev, B=1, H=2, Tq=25, Tk=256, self_attn=False, p=0.1)
         check_dec_attn(dev, B=2, H=2, Tq=26, Tk=26, self_attn=True, p=0.1)
-    finally:
-        del os.environ["CCD_DEC_ATTN_SIMT"]
     check_dropout(dev)
     check_droppath(dev)
     check_dec_embed(dev)

@@ -110,32 +110,30 @@ def test_seghead(hip, images, E):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 264, 128), (4096, 1152, 384), (2048, 384, 1536)])
-def test_gemm256(hip, monkeypatch, M, N, K):
+def test_gemm256(hip, M, N, K):
     """256x256 LDS-DMA kernel: forced onto a ragged small problem and on model shapes (repeated: the DMA is async)."""
-    monkeypatch.setenv("CCD_GEMM_256_MIN_M", "1")
-    monkeypatch.setenv("CCD_GEMM_256_MIN_N", "1")
-    for seed in range(3):
-        kc.check_gemm_nt(hip.device, M=M, N=N, K=K, seed=seed)
-    kc.check_gemm_dynamic_rows(hip.device, M=max(M, 600), N=N, K=K, live=75)
-    monkeypatch.setenv("CCD_GEMM_256_DEEP", "1")              # BK = 32 x 4 buffers, counted vmcnt (async: repeat)
-    for seed in range(4):
-        kc.check_gemm_nt(hip.device, M=M, N=N, K=K, seed=seed)
-    kc.check_gemm_dynamic_rows(hip.device, M=max(M, 600), N=N, K=K, live=75)
-    monkeypatch.delenv("CCD_GEMM_256_DEEP")
-    monkeypatch.setenv("CCD_GEMM_256", "2")                   # the 256x128 variant, every epilogue
-    monkeypatch.setenv("CCD_GEMM_256_MIN_N", "1000000")
-    for seed in range(2):
-        kc.check_gemm_nt(hip.device, M=M, N=N, K=K, seed=seed)
-    kc.check_gemm_dynamic_rows(hip.device, M=max(M, 600), N=N, K=K, live=75)
+    from ccd_amd import ops
+    with ops.policy(gemm_256_min_m=1, gemm_256_min_n=1):
+        for seed in range(3):
+            kc.check_gemm_nt(hip.device, M=M, N=N, K=K, seed=seed)
+        kc.check_gemm_dynamic_rows(hip.device, M=max(M, 600), N=N, K=K, live=75)
+        with ops.policy(gemm_256_deep=1):                         # BK = 32 x 4 buffers, counted vmcnt (async: repeat)
+            for seed in range(4):
+                kc.check_gemm_nt(hip.device, M=M, N=N, K=K, seed=seed)
+            kc.check_gemm_dynamic_rows(hip.device, M=max(M, 600), N=N, K=K, live=75)
+    with ops.policy(gemm_256=2, gemm_256_min_m=1, gemm_256_min_n=1000000):   # the 256x128 variant, every epilogue
+        for seed in range(2):
+            kc.check_gemm_nt(hip.device, M=M, N=N, K=K, seed=seed)
+        kc.check_gemm_dynamic_rows(hip.device, M=max(M, 600), N=N, K=K, live=75)
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 136, 128), (4096, 384, 1536), (2048, 384, 384)])
-def test_gemm_row384(hip, monkeypatch, M, N, K):
-    monkeypatch.setenv("CCD_GEMM_256_MIN_M", "1")
-    monkeypatch.setenv("CCD_GEMM_ROW384", "2")
-    for seed in range(2):
-        kc.check_gemm_nt(hip.device, M=M, N=N, K=K, seed=seed)
-    kc.check_gemm_dynamic_rows(hip.device, M=max(M, 600), N=N, K=K, live=75)
+def test_gemm_row384(hip, M, N, K):
+    from ccd_amd import ops
+    with ops.policy(gemm_256_min_m=1, gemm_row384=2):
+        for seed in range(2):
+            kc.check_gemm_nt(hip.device, M=M, N=N, K=K, seed=seed)
+        kc.check_gemm_dynamic_rows(hip.device, M=max(M, 600), N=N, K=K, live=75)
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 384, 128), (4096, 384, 1536), (2048, 192, 768)])

@@ -88,12 +88,6 @@ def test_optimizer_sim(sim):
     kc.check_optimizer(sim.device)
 
 
-def test_gemm_ares_sim(sim):
-    """M >= 1024 and K <= 384 routes ccd_gemm_nt to the A-resident persistent kernel (gemm_ares.h)."""
-    kc.check_gemm_nt(sim.device, M=1100, N=264, K=128)     # ragged M and N, 2 panels per workgroup
-    kc.check_gemm_nt(sim.device, M=1030, N=136, K=384)
-
-
 def test_conv_pieces_sim(sim):
     kc.check_conv_pieces(sim.device)
 
@@ -102,34 +96,40 @@ def test_seghead_sim(sim):
     kc.check_seghead(sim.device, images=1, E=64)
 
 
-def test_gemm256_sim(sim, monkeypatch):
+def test_gemm256_sim(sim):
     """The 256x256 LDS-DMA kernel, forced onto small ragged problems (several tiles per workgroup, edge tiles)."""
-    monkeypatch.setenv("CCD_GEMM_256_MIN_M", "1")
-    monkeypatch.setenv("CCD_GEMM_256_MIN_N", "1")
-    kc.check_gemm_nt(sim.device, M=300, N=264, K=128)
-    kc.check_gemm_dynamic_rows(sim.device, M=600, N=264, K=64, live=75)
-    # deep-prefetch variant (BK = 32, four buffers)
-    monkeypatch.setenv("CCD_GEMM_256_DEEP", "1")
-    monkeypatch.setenv("CCD_GEMM_256_F32", "1")
-    kc.check_gemm_nt(sim.device, M=300, N=264, K=128)
-    kc.check_gemm_nt(sim.device, M=260, N=256, K=64)
-    kc.check_gemm_dynamic_rows(sim.device, M=600, N=264, K=192, live=75)
-    monkeypatch.delenv("CCD_GEMM_256_DEEP")
-    monkeypatch.delenv("CCD_GEMM_256_F32")
+    from ccd_amd import ops
+    with ops.policy(gemm_256_min_m=1, gemm_256_min_n=1):
+        kc.check_gemm_nt(sim.device, M=300, N=264, K=128)
+        kc.check_gemm_dynamic_rows(sim.device, M=600, N=264, K=64, live=75)
+        with ops.policy(gemm_256_deep=1, gemm_256_f32=1):       # deep-prefetch variant (BK = 32, four buffers)
+            kc.check_gemm_nt(sim.device, M=300, N=264, K=128)
+            kc.check_gemm_nt(sim.device, M=260, N=256, K=64)
+            kc.check_gemm_dynamic_rows(sim.device, M=600, N=264, K=192, live=75)
     # the 256x128 variant (all epilogues, incl. fp32 residual / fp32 stores)
-    monkeypatch.setenv("CCD_GEMM_256", "2")
-    monkeypatch.setenv("CCD_GEMM_256_MIN_N", "1000000")
-    kc.check_gemm_nt(sim.device, M=300, N=136, K=128)
-    kc.check_gemm_dynamic_rows(sim.device, M=600, N=136, K=64, live=75)
+    with ops.policy(gemm_256=2, gemm_256_min_m=1, gemm_256_min_n=1000000):
+        kc.check_gemm_nt(sim.device, M=300, N=136, K=128)
+        kc.check_gemm_dynamic_rows(sim.device, M=600, N=136, K=64, live=75)
 
 
-def test_gemm_row384_sim(sim, monkeypatch):
+def test_gemm_row384_sim(sim):
     """Full-row kernel (128 x 384 tile), forced onto small ragged problems."""
-    monkeypatch.setenv("CCD_GEMM_256_MIN_M", "1")
-    monkeypatch.setenv("CCD_GEMM_ROW384", "2")
-    kc.check_gemm_nt(sim.device, M=300, N=136, K=128)
-    kc.check_gemm_nt(sim.device, M=140, N=384, K=192)
-    kc.check_gemm_dynamic_rows(sim.device, M=600, N=264, K=64, live=75)
+    from ccd_amd import ops
+    with ops.policy(gemm_256_min_m=1, gemm_row384=2):
+        kc.check_gemm_nt(sim.device, M=300, N=136, K=128)
+        kc.check_gemm_nt(sim.device, M=140, N=384, K=192)
+        kc.check_gemm_dynamic_rows(sim.device, M=600, N=264, K=64, live=75)
+
+
+def test_policy_table_sim(sim):
+    """ccd_policy_set / _get: known keys round-trip, unknown keys are rejected, the context manager restores."""
+    from ccd_amd import ops
+    before = ops.policy_get("gemm_256_min_m")
+    with ops.policy(gemm_256_min_m=7):
+        assert ops.policy_get("gemm_256_min_m") == 7
+    assert ops.policy_get("gemm_256_min_m") == before
+    with pytest.raises(RuntimeError):
+        ops.policy_set("no_such_key", 1)
 
 
 def test_gemm_resid_ln_sim(sim):

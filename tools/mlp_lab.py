@@ -50,6 +50,16 @@ def main():
                                           beta=beta, eps=1e-6, store_u=store_u))
         rec("mlp_fused" + ("+u" if store_u else ""), ms, R * E * 12.0 + (2.0 * R * H if store_u else 0.0))
 
+    # per-chunk slope and per-tile intercept: the same launch with fewer hidden units
+    for Hs in (64, 256, 512, 1024):
+        w1s, w2s, b1s = w1[:Hs].contiguous(), w2[:, :Hs].contiguous(), b1[:Hs].contiguous()
+        for store_u in (False, True):
+            ms = timeit(lambda: ops.mlp_fused(y, w1s, b1s, w2s, b2, resid=resid, rowscale=None, rows_per_sample=256, gamma=gamma,
+                                              beta=beta, eps=1e-6, store_u=store_u))
+            print(json.dumps({"kernel": "mlp_fused H=%d%s" % (Hs, "+u" if store_u else ""), "ms": round(ms, 4)}), flush=True)
+    if os.environ.get("MLP_LAB_ONLY_FUSED"):
+        return
+
     def unfused(store_u):
         u, gact = ops.gemm_nt(y, w1, epilogue=ops.EPI_GELU, bias=b1, store_u=store_u)
         return ops.gemm_nt_resid_ln(gact, w2, bias=b2, resid=resid, rowscale=None, rows_per_sample=256, gamma=gamma,
