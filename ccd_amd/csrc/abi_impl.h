@@ -80,13 +80,14 @@ struct CcdPolicy {
     int gemm_row384 = 0;        // 1 = full-row kernel for N <= 384 residual / fp32 epilogues, 2 = bf16 too
     int ln_bwd_bpc = 5;         // LayerNorm backward: blocks per CU (one resident wave; more blocks = more dgamma/dbeta atomics)
     int dec_attn_simt = 0;      // decoder attention: force the general SIMT kernels
+    int lab = 0;                // scratch switch for kernel experiments (tools/*_lab.py); 0 in production
 };
 struct CcdPolicyKey { const char* name; int CcdPolicy::*field; };
 static const CcdPolicyKey ccd_policy_keys[] = {
     {"gemm_256", &CcdPolicy::gemm_256}, {"gemm_256_min_m", &CcdPolicy::gemm_256_min_m},
     {"gemm_256_min_n", &CcdPolicy::gemm_256_min_n}, {"gemm_256_f32", &CcdPolicy::gemm_256_f32},
     {"gemm_256_deep", &CcdPolicy::gemm_256_deep}, {"gemm_row384", &CcdPolicy::gemm_row384},
-    {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}};
+    {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"lab", &CcdPolicy::lab}};
 static CcdPolicy& ccd_policy() {
     static CcdPolicy pol = [] {
         CcdPolicy q;
@@ -166,7 +167,7 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
     CCD_CHECK(((long)M * lda + K) * 2 < CCD_MAX_OPERAND_BYTES && ((long)N * ldb + K) * 2 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
     CCD_CHECK(epilogue != CCD_EPI_GELU || (C2 && ldc2 % 8 == 0), CCD_EINVAL);
     CCD_CHECK(epilogue != CCD_EPI_RESID || (resid && ldr % 4 == 0 && rows_per_sample > 0), CCD_EINVAL);
-    CCD_CHECK(epilogue != CCD_EPI_DGELU || (aux && ldaux % 8 == 0), CCD_EINVAL);
+    CCD_CHECK(epilogue != CCD_EPI_DGELU || (aux && ldaux % 8 == 0 && (!C2 || ldc2 % 8 == 0)), CCD_EINVAL);
     ccd::GemmParams p = ccd::GemmParams();
     p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K;
     p.C = C; p.ldc = ldc; p.C2 = C2; p.ldc2 = ldc2; p.bias = bias; p.resid = resid; p.ldr = ldr;
@@ -231,7 +232,7 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
     p.y = y; p.ldy_in = ldy; p.w1 = w1; p.ld1 = ld1; p.b1 = b1; p.w2 = w2; p.ld2 = ld2; p.b2 = b2; p.resid = resid; p.ldr = ldr;
     p.rowscale = rowscale; p.rows_per_sample = rowscale ? rows_per_sample : 1; p.out = out; p.ldc = ldc;
     p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_eps = ln_eps; p.ln_y = ln_y; p.ld_y = ld_y; p.ln_mean = ln_mean;
-    p.ln_rstd = ln_rstd; p.u = u; p.ldu = ldu; p.M = M; p.H = H;
+    p.ln_rstd = ln_rstd; p.u = u; p.ldu = ldu; p.M = M; p.H = H; p.lab = ccd_policy().lab;
     const int tiles = (M + ccd::MLP_BM - 1) / ccd::MLP_BM, cus = ccd_rt_num_cus();
     const dim3 grid(tiles < cus ? tiles : cus), block(ccd::MLP_THREADS);
     if (E == 384) {

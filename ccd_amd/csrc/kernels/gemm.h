@@ -20,7 +20,7 @@ enum GemmEpilogue {
     EPI_RESID = 2,      // C(f32)  = resid + (acc + bias) * rowscale[row / rows_per_sample]
     EPI_F32 = 3,        // C(f32)  = acc + bias
     EPI_ATOMIC = 4,     // C(f32) += acc                       (split-K partial sums)
-    EPI_DGELU = 5,      // C(bf16) = acc * gelu'(aux)          (aux = saved pre-activation u, bf16)
+    EPI_DGELU = 5,      // C(bf16) = acc * gelu'(aux) ; optional C2(bf16) = gelu(aux)   (aux = saved pre-activation u, bf16)
     EPI_BF16_ADDF32 = 6, // C(bf16) = acc + bias ; C2(f32) += acc (unused hook kept for head experiments)
     EPI_RESID_LN = 7     // EPI_RESID + LayerNorm of the finished rows (gemm_row384.h only)
 };
@@ -253,6 +253,12 @@ __device__ __forceinline__ void gemm_epilogue_row8(const GemmParams& p, int gm, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= dgelu_f(u[e]);
         *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = pack8(v);
+        if (p.C2) {                  // gelu(u) for the weight-gradient product that follows (the forward pass kept only u)
+            float g[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = u[e] * gelu_terms(u[e]).cdf;
+            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + (long)gm * p.ldc2 + gn) = pack8(g);
+        }
     }
 }
 

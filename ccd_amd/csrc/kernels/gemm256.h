@@ -267,19 +267,23 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
         constexpr int CT = BN / 8;                            // column threads (8 columns each) in the row pass
         constexpr int RSTEP = G256_THREADS / CT;              // rows per row-pass step
         float* lut = reinterpret_cast<float*>(stg + SROWS * ROWB);        // behind the (single) bf16 staging image
+        float* lut_cdf = lut + (LUT_HI - LUT_LO);             // gelu'(u) epilogue that also emits gelu(u): second table, Phi
+        const bool want_gelu = EPI == EPI_DGELU && p.C2 != nullptr;
         if (USE_LUT) {
             for (unsigned i = t; i < LUT_HI - LUT_LO; i += G256_THREADS) {
                 const float x = bf2f((bf16_t)(LUT_LO + i));
                 const GeluTerms gt = gelu_terms(x);
                 lut[i] = EPI == EPI_GELU ? gt.cdf : fmaf(x * 0.3989422804014327f, gt.gauss, gt.cdf);
+                if (want_gelu) lut_cdf[i] = gt.cdf;
             }
         }
-        auto lut_at = [&](unsigned bits16) -> float {         // f(u) for the bf16 bit pattern of u
+        auto lut_from = [&](const float* table, unsigned bits16) -> float {     // f(u) for the bf16 bit pattern of u
             const unsigned mag = bits16 & 0x7fffu;
             const unsigned idx = (mag < LUT_LO ? LUT_LO : (mag > LUT_HI - 1u ? LUT_HI - 1u : mag)) - LUT_LO;
-            const float f = lut[idx];
+            const float f = table[idx];
             return (bits16 & 0x8000u) ? 1.0f - f : f;
         };
+        auto lut_at = [&](unsigned bits16) -> float { return lut_from(lut, bits16); };
         if (p.alpha != 1.0f) {
 #pragma unroll
             for (int i = 0; i < TI; ++i)
@@ -353,6 +357,13 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                             if (want_stats) {
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) csum[e] += v[e];
+                            }
+                            if (want_gelu) {                  // gelu(u) = u Phi(u) for the weight-gradient product that follows
+                                float gq[8];
+                                unpack8(uw, gq);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) gq[e] *= lut_from(lut_cdf, (uw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+                                *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + (long)gm * p.ldc2 + gn) = pack8(gq);
                             }
                         } else if (EPI == EPI_BF16 || p.C) {
                             const u32x4 wv = *reinterpret_cast<const u32x4*>(src);

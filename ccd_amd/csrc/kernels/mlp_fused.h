@@ -58,6 +58,7 @@ struct MlpParams {
     bf16_t* u;              // optional [M, H] bf16 pre-activation (STORE_U)
     long ldu;
     int M, H;
+    int lab;                // experiment switch (policy key "lab"): n > 0 delays odd workgroups by ~n * 8 k cycles
 };
 
 constexpr int MLP_NSLOT = 5, MLP_SCRATCH = 4096, MLP_THREADS = 256, MLP_BM = 128;
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
         __device__ __forceinline__ unsigned scr_rd(int i) const { return (unsigned)((dr + 8 * i) * 128 + ((dp ^ dr) * 16)); }
         __device__ __forceinline__ unsigned scr_wr(int slot16) const { return (unsigned)(lq * 128 + ((slot16 ^ (lq & 7)) * 16)); }
     };
+    if (p.lab > 0 && (blockIdx.x & 1)) wave_sleep(p.lab);
     for (int tile = blockIdx.x; tile < tiles; tile += G) {
         const int m0 = tile * MLP_BM, r0 = m0 + 32 * w;
         const int row = r0 + lq, grow = row < p.M ? row : p.M - 1;

@@ -102,6 +102,10 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
     # LayerNorm folded into the epilogue of the residual product that finishes its input rows (full-row kernel,
     # E <= 384): proj -> norm2 of the same block, fc2 -> norm1 of the next block / the final norm
     fuse_ln = E <= 384 and os.environ.get("CCD_FUSE_LN", "1") != "0"
+    # the whole MLP branch in one kernel (csrc/kernels/mlp_fused.h): the hidden activation never reaches HBM; when
+    # activations are saved only the bf16 pre-activation u is stored and backward re-derives gelu(u) in the epilogue
+    # that already reads u (ccd_gemm_nt, EPI_DGELU with a second output)
+    fuse_mlp = fuse_ln and E % 128 == 0 and os.environ.get("CCD_FUSE_MLP", "1") != "0"
     pending = None                               # (y, mean, rstd) of the coming norm1, made by the previous fc2
     # DropPath: per-(block, branch, sample) keep mask / keep_prob (vision_transformer.py:27-35), one kernel per pass
     scales = ops.droppath_scales(spec.keep_probs(dev), N, _next_droppath_seed()) if training and max(spec.dpr) > 0.0 else None
@@ -127,14 +131,24 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
             c.x_mid = ops.gemm_nt(c.att.view(R, E), arena.wb(b + "attn.proj.weight"), epilogue=ops.EPI_RESID,
                                   bias=arena.w(b + "attn.proj.bias"), resid=x, rowscale=c.ds1, rows_per_sample=256)
             c.y2, c.mean2, c.rstd2 = ops.ln_fwd(c.x_mid, arena.w(b + "norm2.weight"), arena.w(b + "norm2.bias"), spec.eps)
-        c.u, c.gact = ops.gemm_nt(c.y2, arena.wb(b + "mlp.fc1.weight"), epilogue=ops.EPI_GELU,
-                                  bias=arena.w(b + "mlp.fc1.bias"), store_u=save)   # u only feeds gelu' in backward
-        if fuse_ln:
+        if fuse_mlp:
+            nxt = f"{pre}blocks.{i + 1}.norm1." if i + 1 < spec.depth else pre + "norm."
+            x, y_n, mean_n, rstd_n, c.u = ops.mlp_fused(
+                c.y2, arena.wb(b + "mlp.fc1.weight"), arena.w(b + "mlp.fc1.bias"), arena.wb(b + "mlp.fc2.weight"),
+                arena.w(b + "mlp.fc2.bias"), resid=c.x_mid, rowscale=c.ds2, rows_per_sample=256,
+                gamma=arena.w(nxt + "weight"), beta=arena.w(nxt + "bias"), eps=spec.eps, store_u=save)
+            pending = [y_n, mean_n, rstd_n]
+            c.gact = None
+        elif fuse_ln:
+            c.u, c.gact = ops.gemm_nt(c.y2, arena.wb(b + "mlp.fc1.weight"), epilogue=ops.EPI_GELU,
+                                      bias=arena.w(b + "mlp.fc1.bias"), store_u=save)   # u only feeds gelu' in backward
             nxt = f"{pre}blocks.{i + 1}.norm1." if i + 1 < spec.depth else pre + "norm."
             x, *pending = ops.gemm_nt_resid_ln(
                 c.gact, arena.wb(b + "mlp.fc2.weight"), bias=arena.w(b + "mlp.fc2.bias"), resid=c.x_mid, rowscale=c.ds2,
                 rows_per_sample=256, gamma=arena.w(nxt + "weight"), beta=arena.w(nxt + "bias"), eps=spec.eps)
         else:
+            c.u, c.gact = ops.gemm_nt(c.y2, arena.wb(b + "mlp.fc1.weight"), epilogue=ops.EPI_GELU,
+                                      bias=arena.w(b + "mlp.fc1.bias"), store_u=save)
             x = ops.gemm_nt(c.gact, arena.wb(b + "mlp.fc2.weight"), epilogue=ops.EPI_RESID,
                             bias=arena.w(b + "mlp.fc2.bias"), resid=c.x_mid, rowscale=c.ds2, rows_per_sample=256)
         if not save:
@@ -249,9 +263,15 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
             ops.colsum_bf16(gb, arena.g(b + "mlp.fc2.bias"))
         # ---- MLP branch: x_out = x_mid + ds2 * fc2(gelu(fc1(LN2(x_mid))))
         gact, y2, att, y1 = c.gact, c.y2, c.att, c.y1
-        gb_reader = side.run(lambda: ops.gemm_tn(gb, gact, arena.g(b + "mlp.fc2.weight")), gb, gact)
-        du = ops.gemm_nt(gb, arena.wbt(b + "mlp.fc2.weight"), epilogue=ops.EPI_DGELU, aux=c.u,
-                         colsum=arena.g(b + "mlp.fc1.bias"))
+        if gact is None:            # fused-MLP forward kept only u: gelu(u) comes out of the gelu'(u) epilogue below
+            gact = torch.empty_like(c.u)
+            du = ops.gemm_nt(gb, arena.wbt(b + "mlp.fc2.weight"), epilogue=ops.EPI_DGELU, aux=c.u, out2=gact,
+                             colsum=arena.g(b + "mlp.fc1.bias"))
+            gb_reader = side.run(lambda: ops.gemm_tn(gb, gact, arena.g(b + "mlp.fc2.weight")), gb, gact)
+        else:
+            gb_reader = side.run(lambda: ops.gemm_tn(gb, gact, arena.g(b + "mlp.fc2.weight")), gb, gact)
+            du = ops.gemm_nt(gb, arena.wbt(b + "mlp.fc2.weight"), epilogue=ops.EPI_DGELU, aux=c.u,
+                             colsum=arena.g(b + "mlp.fc1.bias"))
         side.run(lambda du=du: ops.gemm_tn(du, y2, arena.g(b + "mlp.fc1.weight")), du, y2)
         dy2 = ops.gemm_nt(du, arena.wbt(b + "mlp.fc1.weight"))
         del du

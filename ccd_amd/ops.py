@@ -113,7 +113,7 @@ def gemm_nt(a, b, *, epilogue=EPI_BF16, out=None, out2=None, bias=None, resid=No
                "gemm_nt")
     if span:
         span[1].record()
-    return (out, out2) if epilogue == EPI_GELU else out
+    return (out, out2) if epilogue == EPI_GELU else out      # (EPI_DGELU: out2, when given, receives gelu(aux))
 
 
 def gemm_nt_resid_ln(a, b, *, bias, resid, rowscale, rows_per_sample, gamma, beta, eps, out=None):

@@ -48,6 +48,9 @@ def check_gemm_nt(dev, M, N, K, seed=0):
     xx = aux.float().double().requires_grad_(True)
     F.gelu(xx).sum().backward()
     close(ops.gemm_nt(A, B_, epilogue=ops.EPI_DGELU, aux=aux.to(dev)), ref * xx.grad.float(), 1e-2, 2e-2, "nt/dgelu")
+    g2 = torch.empty((M, N), dtype=BF).to(dev)         # optional second output: gelu(aux), for the weight-gradient product
+    close(ops.gemm_nt(A, B_, epilogue=ops.EPI_DGELU, aux=aux.to(dev), out2=g2), ref * xx.grad.float(), 1e-2, 2e-2, "nt/dgelu+g")
+    close(g2, F.gelu(aux.float()), 1e-2, 1e-3, "nt/dgelu-gelu(u)")
     cs = torch.full((N,), 3.0).to(dev)
     du = ops.gemm_nt(A, B_, epilogue=ops.EPI_DGELU, aux=aux.to(dev), colsum=cs)
     rms_d = float((ref * xx.grad.float()).pow(2).mean().sqrt())

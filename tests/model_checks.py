@@ -280,6 +280,10 @@ def _register_test_arch():
         vits.vit_test2 = lambda patch_size=16, **kw: vits.VisionTransformer(
             patch_size=patch_size, embed_dim=192, depth=2, num_heads=3, mlp_ratio=4, qkv_bias=True,
             norm_layer=partial(nn.LayerNorm, eps=1e-6), **kw)
+    if "vit_test128" not in vits.__dict__:      # E % 128 == 0: the MLP branch runs on the fused kernel (mlp_fused.h)
+        vits.vit_test128 = lambda patch_size=16, **kw: vits.VisionTransformer(
+            patch_size=patch_size, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4, qkv_bias=True,
+            norm_layer=partial(nn.LayerNorm, eps=1e-6), **kw)
 
 
 def _cosine(a, b):

@@ -28,3 +28,19 @@ def test_finetune_against_oracle_sim(sim):
 
 def test_finetune_dropout_sim(sim):
     mc.check_finetune_dropout(sim.device)
+
+
+def test_finetune_fused_mlp_sim(sim, monkeypatch):
+    """A backbone whose width is a multiple of 128 takes the fused MLP kernel in both passes (forward keeps only the
+    pre-activation, backward re-derives gelu(u)): the whole iteration against the oracle, gradients included."""
+    from ccd_amd import ops
+    calls = []
+    real = ops.mlp_fused
+    monkeypatch.setattr(ops, "mlp_fused", lambda *a, **k: (calls.append(k.get("store_u")), real(*a, **k))[1])
+    _run_fused(sim)
+    assert calls and any(calls), "the fused MLP kernel was not on the path"
+
+
+def _run_fused(sim):
+    mc.check_finetune_against_oracle(sim.device, arch="vit_test128", vit_kw=dict(embed_dim=128, depth=2, heads=2), B=2,
+                                     max_seq_len=25, steps=2, decode=False)

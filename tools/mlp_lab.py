@@ -50,9 +50,16 @@ def main():
                                           beta=beta, eps=1e-6, store_u=store_u))
         rec("mlp_fused" + ("+u" if store_u else ""), ms, R * E * 12.0 + (2.0 * R * H if store_u else 0.0))
 
-    # per-chunk slope and per-tile intercept: the same launch with fewer hidden units
-    for Hs in (64, 256, 512, 1024):
-        w1s, w2s, b1s = w1[:Hs].contiguous(), w2[:, :Hs].contiguous(), b1[:Hs].contiguous()
+    for lab in [int(x) for x in os.environ.get("MLP_LAB", "").split(",") if x]:
+        with ops.policy(lab=lab):
+            for store_u in (False, True):
+                ms = timeit(lambda: ops.mlp_fused(y, w1, b1, w2, b2, resid=resid, rowscale=None, rows_per_sample=256, gamma=gamma,
+                                                  beta=beta, eps=1e-6, store_u=store_u))
+                print(json.dumps({"kernel": "mlp_fused lab=%d%s" % (lab, "+u" if store_u else ""), "ms": round(ms, 4)}), flush=True)
+    # per-chunk slope and per-tile intercept: the same launch with other hidden sizes
+    for Hs in [int(x) for x in os.environ.get("MLP_HS", "64,256,512,1024").split(",")]:
+        w1s = (torch.randn(Hs, E, generator=g) * 0.05).to(BF).to(dev); w2s = (torch.randn(E, Hs, generator=g) * 0.03).to(BF).to(dev)
+        b1s = torch.randn(Hs, generator=g).to(dev) * 0.1
         for store_u in (False, True):
             ms = timeit(lambda: ops.mlp_fused(y, w1s, b1s, w2s, b2, resid=resid, rowscale=None, rows_per_sample=256, gamma=gamma,
                                               beta=beta, eps=1e-6, store_u=store_u))
