@@ -6,8 +6,10 @@
 //   select_scan_kernel      length clamp + new_index + row offsets      Dino/model/dino_vision.py:82-85
 //   region_pool_fwd/bwd     bmm of the normalised maps with the tokens + row gather   :44-47, 87
 // Integer work is exact; the only floating-point decisions are the two thresholds of the warp (documented there).
-// Two kept components are never 8-adjacent, so every 2x2 pixel block (the bilinear footprint of the warp and the
-// centre of a 4x4 down-sampling cell alike) touches at most ONE plane: that is why an id map is lossless.
+// Two kept components are never 8-adjacent, so every 2x2 block of the LABELLED map - the bilinear footprint of the warp -
+// touches at most ONE plane: a warped pixel lies on at most one plane and an id map represents the warped view without
+// loss too.  Neighbouring pixels of the warped map may carry different ids though (a one-pixel gap can close under a
+// sub-pixel shift or a zoom-out), so the x1/4 down-sampling keeps up to four planes per token (region_stats_kernel).
 #pragma once
 
 namespace ccd {
@@ -184,10 +186,13 @@ __global__ __launch_bounds__(256) void warp_idmap_kernel(const unsigned char* __
     dst[(long)img * CM_PIX + pix] = (id != CM_BG && v > 0.1f) ? (unsigned char)id : CM_BG;
 }
 
-// ---- per view: token -> (plane, coefficient), plane presence ------------------------------------------------
+// ---- per view: token -> up to 4 (plane, coefficient) pairs, plane presence -----------------------------------
 // bilinear x1/4 with align_corners=False samples exactly the mean of the central 2x2 of each 4x4 cell
-// (verified bit-exact), so w_t = (#central pixels on the plane) / 4 and
-// coef_t = w_t / sum_t' w_t' (fp32 division like the reference's `clusters / max_cluster_index`).
+// (verified bit-exact), so for plane j  w_t(j) = (#central pixels of token t on plane j) / 4 and
+// coef_t(j) = w_t(j) / sum_t' w_t'(j) (fp32 division like the reference's `clusters / max_cluster_index`).
+// In the labelled view the central 2x2 touches at most one plane (kept components are never 8-adjacent); in the WARPED
+// view two components that were one pixel apart can end up side by side (sub-pixel shift, zoom-out), and the reference
+// then credits the token to both planes - hence up to four pairs per token, slot s of token t at [t][s].
 __global__ __launch_bounds__(256) void region_stats_kernel(const unsigned char* __restrict__ idmap,
                                                            unsigned char* __restrict__ tok_plane,
                                                            float* __restrict__ tok_coef,
@@ -198,19 +203,30 @@ __global__ __launch_bounds__(256) void region_stats_kernel(const unsigned char* 
     if (t < CM_PLANES) plane_sum[t] = 0.0f;
     __syncthreads();
     const int ty = t >> 5, tx = t & 31;
-    int id = CM_BG, cnt = 0;
+    int id[4] = {CM_BG, CM_BG, CM_BG, CM_BG}, cnt[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int dy = 1; dy <= 2; ++dy)
 #pragma unroll
         for (int dx = 1; dx <= 2; ++dx) {
-            const unsigned char p = im[(4 * ty + dy) * CM_W + 4 * tx + dx];
-            if (p != CM_BG) { id = p; ++cnt; }
+            const int p = im[(4 * ty + dy) * CM_W + 4 * tx + dx];
+            if (p == CM_BG) continue;
+            bool placed = false;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (placed) continue;
+                if (id[s] == p) { ++cnt[s]; placed = true; }
+                else if (id[s] == CM_BG) { id[s] = p; cnt[s] = 1; placed = true; }
+            }
         }
-    const float w = 0.25f * (float)cnt;
-    if (id != CM_BG) atomicAdd(&plane_sum[id], w);     // multiples of 0.25: exact in any order
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (id[s] != CM_BG) atomicAdd(&plane_sum[id[s]], 0.25f * (float)cnt[s]);     // multiples of 0.25: exact in any order
     __syncthreads();
-    tok_plane[(long)blockIdx.x * 256 + t] = (unsigned char)id;
-    tok_coef[(long)blockIdx.x * 256 + t] = id != CM_BG ? w / plane_sum[id] : 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        tok_plane[((long)blockIdx.x * 256 + t) * 4 + s] = (unsigned char)id[s];
+        tok_coef[((long)blockIdx.x * 256 + t) * 4 + s] = id[s] != CM_BG ? (0.25f * (float)cnt[s]) / plane_sum[id[s]] : 0.0f;
+    }
     if (t < CM_PLANES) present[(long)blockIdx.x * CM_PLANES + t] = plane_sum[t] > 0.0f ? 1 : 0;
 }
 
@@ -252,7 +268,7 @@ __global__ __launch_bounds__(256) void select_scan_kernel(const unsigned char* _
     }
 }
 
-// ---- masked region pooling + row gather: rows[half*M + off_b + j, :] = sum_t [plane_t == j] coef_t * feat[t, :]
+// ---- masked region pooling + row gather: rows[half*M + off_b + j, :] = sum over pairs (t, s) with plane_t(s) == j of coef_t(s) * feat[t, :]
 __global__ __launch_bounds__(256) void region_pool_fwd_kernel(const bf16_t* __restrict__ feat,
                                                               const unsigned char* __restrict__ tok_plane,
                                                               const float* __restrict__ tok_coef,
@@ -260,20 +276,28 @@ __global__ __launch_bounds__(256) void region_pool_fwd_kernel(const bf16_t* __re
                                                               const int* __restrict__ total, bf16_t* __restrict__ rows,
                                                               int batch, int E) {
     float* acc = reinterpret_cast<float*>(dynamic_smem());      // [26][E]
-    __shared__ unsigned char s_plane[256];
-    __shared__ float s_coef[256];
+    __shared__ unsigned char s_plane[256 * 4];
+    __shared__ float s_coef[256 * 4];
     const int view = blockIdx.x, b = view % batch, half = view / batch;
     const int t = threadIdx.x;
-    s_plane[t] = tok_plane[(long)view * 256 + t];
-    s_coef[t] = tok_coef[(long)view * 256 + t];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        s_plane[4 * t + s] = tok_plane[((long)view * 256 + t) * 4 + s];
+        s_coef[4 * t + s] = tok_coef[((long)view * 256 + t) * 4 + s];
+    }
     const int n = nsel[b];
     for (int i = t; i < n * E; i += 256) acc[i] = 0.0f;
     __syncthreads();
     const bf16_t* f = feat + (long)view * 256 * E;
     for (int e = t; e < E; e += 256) {
         for (int tok = 0; tok < 256; ++tok) {
-            const int p = s_plane[tok];
-            if (p < n) acc[p * E + e] += s_coef[tok] * bf2f(f[(long)tok * E + e]);
+            if (s_plane[4 * tok] == CM_BG) continue;                   // slots fill from 0: no pair at all
+            const float x = bf2f(f[(long)tok * E + e]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int p = s_plane[4 * tok + s];
+                if (p < n) acc[p * E + e] += s_coef[4 * tok + s] * x;
+            }
         }
     }
     __syncthreads();
@@ -281,7 +305,7 @@ __global__ __launch_bounds__(256) void region_pool_fwd_kernel(const bf16_t* __re
     for (int i = t; i < n * E; i += 256) out[i] = f2bf(acc[i]);
 }
 
-// d_feat[t, :] = [plane_t < nsel] coef_t * d_rows[row(plane_t), :]
+// d_feat[t, :] = sum over the token's pairs s with plane_t(s) < nsel of coef_t(s) * d_rows[row(plane_t(s)), :]
 __global__ __launch_bounds__(256) void region_pool_bwd_kernel(const bf16_t* __restrict__ d_rows,
                                                               const unsigned char* __restrict__ tok_plane,
                                                               const float* __restrict__ tok_coef,
@@ -295,17 +319,19 @@ __global__ __launch_bounds__(256) void region_pool_bwd_kernel(const bf16_t* __re
     const int e8 = E >> 3;
     for (int i = threadIdx.x; i < 256 * e8; i += 256) {
         const int tok = i / e8, c = i % e8;
-        const int p = tok_plane[(long)view * 256 + tok];
-        u32x4 o = {0u, 0u, 0u, 0u};
-        if (p < n) {
-            const float coef = tok_coef[(long)view * 256 + tok];
-            float v[8];
-            unpack8(*reinterpret_cast<const u32x4*>(base + (long)p * E + c * 8), v);
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] *= coef;
-            o = pack8(v);
+        for (int s = 0; s < 4; ++s) {
+            const int p = tok_plane[((long)view * 256 + tok) * 4 + s];
+            if (p < n) {
+                const float coef = tok_coef[((long)view * 256 + tok) * 4 + s];
+                float v[8];
+                unpack8(*reinterpret_cast<const u32x4*>(base + (long)p * E + c * 8), v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] += v[k] * coef;
+            }
         }
-        *reinterpret_cast<u32x4*>(out + (long)tok * E + c * 8) = o;
+        *reinterpret_cast<u32x4*>(out + (long)tok * E + c * 8) = pack8(a);
     }
 }
 

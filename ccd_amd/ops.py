@@ -325,8 +325,8 @@ def warp_idmap(src, theta):
 def region_stats(idmap):
     views = idmap.shape[0]
     dev = idmap.device
-    tok_plane = torch.empty((views, 256), dtype=U8, device=dev)
-    tok_coef = torch.empty((views, 256), dtype=F32, device=dev)
+    tok_plane = torch.empty((views, 256, 4), dtype=U8, device=dev)      # up to 4 (plane, coefficient) pairs per token
+    tok_coef = torch.empty((views, 256, 4), dtype=F32, device=dev)
     present = torch.empty((views, 26), dtype=U8, device=dev)
     _call("ccd_region_stats", _lib.ptr(idmap), _lib.ptr(tok_plane), _lib.ptr(tok_coef), _lib.ptr(present), views)
     return tok_plane, tok_coef, present

@@ -35,8 +35,15 @@ class FusedClipAdamW:
         self.steps = {n: 0 for n in names}
         self.never_used = set()            # tensors that have never received a gradient (conv_mla.*, cls_token)
         self._norm2 = torch.zeros(len(names), dtype=torch.float32, device=arena.device)
-        self._hyper_host = torch.zeros((len(names), 4), dtype=torch.float32).pin_memory() \
-            if arena.device.type == "cuda" else torch.zeros((len(names), 4), dtype=torch.float32)
+        # Per-tensor hyper-parameters travel host -> device as one small async copy per step.  The host runs ahead of the
+        # stream (train.py reads the loss one iteration late), so a single pinned staging buffer would be overwritten by
+        # step N+1 before the DMA of step N has read it: a ring of staging buffers, each guarded by the event recorded
+        # behind its copy (waited for - normally long complete - before the buffer is refilled).
+        on_gpu = arena.device.type == "cuda"
+        self._hyper_ring = [torch.zeros((len(names), 4), dtype=torch.float32).pin_memory() if on_gpu
+                            else torch.zeros((len(names), 4), dtype=torch.float32) for _ in range(4 if on_gpu else 1)]
+        self._hyper_events = [None] * len(self._hyper_ring)
+        self._hyper_next = 0
         self._hyper_dev = torch.zeros((len(names), 4), dtype=torch.float32, device=arena.device)
 
     def zero_grad(self, set_to_none: bool = False):
@@ -51,7 +58,11 @@ class FusedClipAdamW:
         arena = self.arena
         b1, b2 = self.betas
         skip = arena.skip_substrings
-        h = self._hyper_host
+        slot = self._hyper_next
+        self._hyper_next = (slot + 1) % len(self._hyper_ring)
+        if self._hyper_events[slot] is not None:
+            self._hyper_events[slot].synchronize()          # the copy that last read this buffer has executed
+        h = self._hyper_ring[slot]
         for n, seg in arena.segments.items():
             gi = self._group_of.get(n)
             active = gi is not None and n not in self.never_used and not any(s in n for s in skip)
@@ -67,6 +78,9 @@ class FusedClipAdamW:
             h[seg.index, 3] = 1.0
         arena.skip_substrings = set()
         self._hyper_dev.copy_(h, non_blocking=True)
+        if h.is_pinned():
+            self._hyper_events[slot] = torch.cuda.Event()
+            self._hyper_events[slot].record()
         cs, cb, cl = arena.opt_tables()
         self._norm2.zero_()
         if self.clip_grad:

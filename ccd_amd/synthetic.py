@@ -62,3 +62,21 @@ def make_batch(batch: int, seed: int = 0, device: str | torch.device = "cpu"):
     masks = torch.from_numpy(make_masks(batch, rs))
     metrics = torch.from_numpy(np.stack([_affine_theta(rs) for _ in range(batch)]))
     return images.to(device), masks.to(device), metrics.to(device)
+
+
+def make_text_like_batch(batch: int, seed: int = 0, amp: float = 2.0, noise: float = 0.3,
+                         device: str | torch.device = "cpu"):
+    """As make_batch, but the images CARRY the characters (bright rectangles on a dark ground + a little noise; view 2 is
+    the affine warp of views 0/1 by the same theta the batch hands to the model).  On pure-noise images a randomly
+    initialised segmentation head predicts salt and pepper - no component of 30 pixels survives - so the predicted-mask
+    branch (epoch >= 30, dino_vision.py:64-70) is only exercised in earnest by images with structure."""
+    import torch.nn.functional as F
+    images, masks, metrics = make_batch(batch, seed)
+    pattern = (masks * 2.0 - 1.0) * amp
+    grid = F.affine_grid(metrics[:, :2, :], size=(batch, 1, IMG_H, IMG_W), align_corners=False)
+    warped = F.grid_sample(pattern.unsqueeze(1), grid, align_corners=False).squeeze(1)
+    images = images * noise
+    images[:, 0] += pattern[:, None]
+    images[:, 1] += pattern[:, None]
+    images[:, 2] += warped[:, None]
+    return images.to(device), masks.to(device), metrics.to(device)

@@ -138,7 +138,9 @@ int ccd_mask_to_idmap(const float* mask, uint8_t* idmap, int images, void* strea
 int ccd_seg_to_mask(const float* seg_logits, float* mask, int images, void* stream);
 /* affine_grid(theta[:, :2]) + grid_sample(bilinear) > 0.1, dino_vision.py:72-77 / train.py:234-236; theta row stride in floats */
 int ccd_warp_idmap(const uint8_t* src, const float* theta, int theta_stride, uint8_t* dst, int images, void* stream);
-/* ABIDINOModel.attention, dino_vision.py:38-49, in sparse form: per token its plane and normalised weight */
+/* ABIDINOModel.attention, dino_vision.py:38-49, in sparse form: per token up to 4 (plane, normalised weight) pairs -
+ * tok_plane [views,256,4] (255 = unused slot), tok_coef [views,256,4]; the central 2x2 of a 4x4 cell touches one plane in
+ * the labelled view, possibly several in the warped view (components one pixel apart can end up side by side) */
 int ccd_region_stats(const uint8_t* idmap, uint8_t* tok_plane, float* tok_coef, uint8_t* present, int views,
                      void* stream);
 /* dino_vision.py:82-85: nsel[b], offset[b], total[0] = M, new_index [batch,26] */

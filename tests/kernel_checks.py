@@ -208,6 +208,55 @@ def check_warp(dev):
     np.testing.assert_array_equal(got, ids[B:])
 
 
+def check_seg_to_mask(dev, seed=23):
+    """Predicted-mask branch (dino_vision.py:64-66): softmax(seg, dim=1)[:, 1] > 0.5 on fp32 logits - random values,
+    exact ties, huge magnitudes, infinities / NaNs (the reference's softmax turns those into NaN -> False)."""
+    g = torch.Generator().manual_seed(seed)
+    images = 3
+    seg = rnd((images + 1, 2, 32, 128), g) * 3.0                   # one image more than asked for: must stay untouched
+    flat = seg.view(images + 1, 2, -1)
+    flat[0, 1, :512] = flat[0, 0, :512]                            # exact ties -> 0.5 > 0.5 is False
+    flat[0, :, 512:1024] *= 1.0e4                                  # large magnitudes: the max is subtracted first
+    flat[0, :, 1024:1536] *= 1.0e30
+    flat[1, 1, :256] = flat[1, 0, :256] + 2.0 ** -12               # small but decidable margins, both signs
+    flat[1, 1, 256:512] = flat[1, 0, 256:512] - 2.0 ** -12
+    flat[1, 0, 600] = float("inf"); flat[1, 1, 601] = float("inf"); flat[1, :, 602] = float("inf")
+    flat[1, 0, 603] = float("-inf"); flat[1, 1, 604] = float("-inf"); flat[1, :, 605] = float("-inf")
+    flat[1, 0, 606] = float("nan"); flat[1, 1, 607] = float("nan")
+    want = (F.softmax(seg[:images], dim=1)[:, 1] > 0.5).float()
+    got = ops.seg_to_mask(seg.to(dev), images)
+    assert got.shape == (images, 32, 128)
+    np.testing.assert_array_equal(got.cpu().numpy(), want.numpy())
+    # margins below the resolution of exp() near 1 may go either way in any implementation; they must still be a
+    # decision between the two classes that agrees with the sign of the margin or with "not greater" (0)
+    tiny = rnd((1, 2, 32, 128), g)
+    tiny[0, 1] = tiny[0, 0] + (torch.rand(32, 128, generator=g) - 0.5) * 2.0e-7
+    got_t = ops.seg_to_mask(tiny.to(dev), 1).cpu()
+    sign = (tiny[0, 1] > tiny[0, 0]).float()
+    assert bool(((got_t[0] == sign) | (got_t[0] == 0)).all())
+
+
+def check_predicted_mask_chain(dev):
+    """The whole predicted-mask branch on the device, from the REFERENCE's own fp32 segmentation logits (recorded by
+    tools/gen_golden.py at epoch 30): softmax > 0.5, connected components, warp to view 2 and row selection reproduce the
+    reference's `zero` / `index` bit for bit (dino_vision.py:64-87)."""
+    g = np.load(os.path.join(GOLD, "small3_step.npz"))
+    step = [k for k in range(4) if g[f"s{k}/hyper"][0] >= 30][0]
+    p = f"s{step}/"
+    seg = torch.from_numpy(g[p + "seg_logits_view1"])                      # [B,2,32,128]
+    B = seg.shape[0]
+    mask = ops.seg_to_mask(seg.to(dev), B)
+    np.testing.assert_array_equal(mask.cpu().numpy().astype(np.uint8), g[p + "pred_mask"])
+    idm1 = ops.ccl_label(mask)
+    idm2 = ops.warp_idmap(idm1, torch.from_numpy(g[p + "metrics"]).to(dev))
+    both = torch.cat([idm1, idm2])
+    np.testing.assert_array_equal(both.cpu().numpy(), g[p + "zero_idmap"])
+    assert len(np.unique(g[p + "zero_idmap"])) > 3
+    _, _, present = ops.region_stats(both)
+    _, _, _, new_index = ops.select_scan(present, B)
+    np.testing.assert_array_equal(new_index.cpu().numpy().astype(bool), g[p + "new_index"])
+
+
 def check_region(dev, E=128, seed=7):
     g = np.load(os.path.join(GOLD, "small_step.npz"))
     ids = np.concatenate([g["s0/zero_idmap"], g["pred/zero_idmap"]])          # two different kinds of maps
@@ -239,6 +288,53 @@ def check_region(dev, E=128, seed=7):
     # dense-plane round trip
     np.testing.assert_array_equal(ops.idmap_to_planes(idm).cpu().numpy(), planes.numpy())
     np.testing.assert_array_equal(ops.planes_to_idmap(planes.to(dev)).cpu().numpy(), ids)
+
+
+def check_region_adjacent_planes(dev, E=64, seed=17):
+    """View 2 of the reference is a warp of 26 separate planes: components that were one pixel apart can end up side by
+    side (zoom-out, sub-pixel shift), and a token whose central 2x2 straddles them is credited to BOTH planes
+    (dino_vision.py:38-49).  Labelled masks with 1-px gaps + zoom-out / half-pixel thetas, against the dense path."""
+    gen = torch.Generator().manual_seed(seed)
+    B = 4
+    mask = np.zeros((B, 32, 128), dtype=np.float32)
+    for b in range(B):
+        x = 2 + b
+        for k in range(6):                     # 6 characters, 12 wide, separated by ONE background column
+            mask[b, 6:26, x:x + 12] = 1.0
+            x += 13
+    ids1 = ccl_np.label_batch_idmap(mask) if hasattr(ccl_np, "label_batch_idmap") else None
+    idm1 = ops.ccl_label(torch.from_numpy(mask).to(dev))
+    if ids1 is not None:
+        np.testing.assert_array_equal(idm1.cpu().numpy(), ids1)
+    theta = torch.tensor([[[1.55, 0.0, 0.0], [0.0, 1.3, 0.0]],          # zoom-out: gaps of the source close
+                          [[1.0, 0.0, 1.0 / 128], [0.0, 1.0, 0.0]],      # half-pixel shift
+                          [[1.4, 0.12, 0.02], [0.05, 1.2, -0.03]],
+                          [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]], dtype=torch.float32)
+    planes1 = torch.from_numpy(ccl_np.idmap_to_planes(idm1.cpu().numpy()))
+    planes2 = (O.warp_planes(planes1, theta) > 0.1).float()
+    idm2 = ops.warp_idmap(idm1, theta.to(dev))
+    np.testing.assert_array_equal(ops.idmap_to_planes(idm2).cpu().numpy(), planes2.numpy())     # the id map loses nothing
+    # some token of the warped view must really straddle two planes, or this test pins nothing
+    c = F.interpolate(planes2, size=(8, 32), mode="bilinear", align_corners=None)
+    assert int(((c > 0).sum(1) > 1).sum()) > 0, "no token touches two planes: strengthen the fixture"
+    feat = rnd((2 * B, 256, E), gen).to(BF)
+    region_f = feat.float().reshape(2 * B, 8, 32, E).permute(0, 3, 1, 2).requires_grad_(True)
+    vecs, index = O.region_pool(region_f, torch.cat([planes1, planes2]))
+    rows_ref, new_index_ref = O.select_rows(vecs, index)
+    tok_plane, tok_coef, present = ops.region_stats(torch.cat([idm1, idm2]))
+    np.testing.assert_array_equal(present.cpu().numpy().astype(bool), index.numpy())
+    nsel, offset, total, new_index = ops.select_scan(present, B)
+    M = int(total.cpu().item())
+    assert 2 * M == rows_ref.shape[0]
+    rows = torch.zeros((2 * 26 * B, E), dtype=BF).to(dev)
+    ops.region_pool_fwd(feat.to(dev), tok_plane, tok_coef, nsel, offset, total, rows, B)
+    close(rows[:2 * M], rows_ref, 1e-2, 1e-2, "pool-adjacent/rows")
+    d_rows = torch.zeros((2 * 26 * B, E), dtype=BF)
+    d_rows[:2 * M] = rnd((2 * M, E), gen).to(BF)
+    rows_ref.backward(d_rows[:2 * M].float())
+    d_feat = torch.empty((2 * B, 256, E), dtype=BF).to(dev)
+    ops.region_pool_bwd(d_rows.to(dev), tok_plane, tok_coef, nsel, offset, total, d_feat, B)
+    close(d_feat, region_f.grad.permute(0, 2, 3, 1).reshape(2 * B, 256, E), 1e-2, 1e-3, "pool-adjacent/d_feat")
 
 
 def check_patch_embed(dev, views=3, E=192, seed=8):

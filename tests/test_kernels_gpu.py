@@ -57,6 +57,12 @@ def test_ccl(hip):
     kc.check_ccl(hip.device)
 
 
+
+def test_seg_to_mask(hip):
+    kc.check_seg_to_mask(hip.device)
+    kc.check_predicted_mask_chain(hip.device)
+
+
 def test_warp(hip):
     kc.check_warp(hip.device)
 
@@ -64,6 +70,7 @@ def test_warp(hip):
 @pytest.mark.parametrize("E", [128, 384])
 def test_region(hip, E):
     kc.check_region(hip.device, E=E)
+    kc.check_region_adjacent_planes(hip.device)
 
 
 @pytest.mark.parametrize("views,E", [(3, 192), (32, 384)])

@@ -56,12 +56,18 @@ def test_ccl_sim(sim):
     kc.check_ccl(sim.device)
 
 
+def test_seg_to_mask_sim(sim):
+    kc.check_seg_to_mask(sim.device)
+    kc.check_predicted_mask_chain(sim.device)
+
+
 def test_warp_sim(sim):
     kc.check_warp(sim.device)
 
 
 def test_region_sim(sim):
     kc.check_region(sim.device)
+    kc.check_region_adjacent_planes(sim.device)
 
 
 def test_patch_embed_sim(sim):

@@ -31,6 +31,18 @@ def test_vit_small_b8_two_iterations_vs_reference(hip):
         json.dump(report, f)
 
 
+def test_vit_small_b8_four_iterations_vs_reference_nonzero_head_biases(hip):
+    """Multi-iteration parity against the real reference with no excluded tensor (see check_small3_steps)."""
+    report = mc.check_small3_steps(hip.device, loss_tol=1e-3)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_small3_step.json", "w") as f:
+        json.dump(report, f)
+
+
+def test_optimizer_host_runs_ahead(hip):
+    mc.check_optimizer_host_runs_ahead(hip.device)
+
+
 def test_properties_at_full_batch(hip):
     m = mc.check_properties_full_size(hip.device, B=256)
     assert 3 * 256 < m < 10 * 256

@@ -17,6 +17,10 @@ def test_tiny_training_iteration_sim(sim):
     mc.check_tiny_step(sim.device)
 
 
+def test_optimizer_steps_sim(sim):
+    mc.check_optimizer_host_runs_ahead(sim.device, steps=3)
+
+
 def test_checkpoint_resume_sim(sim, tmp_path):
     mc.check_checkpoint_resume(sim.device, tmp_path)
 

@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from ccd_amd.synthetic import make_batch
 from oracle import ccd_oracle as O
@@ -130,6 +131,51 @@ def test_small_step(golden_dir):
     src = torch.from_numpy(ccl_np.idmap_to_planes(ids))
     clusters = torch.cat([src, O.warp_planes(src, torch.from_numpy(g["pred/metrics"]))])
     np.testing.assert_array_equal(ccl_np.planes_to_idmap(clusters.numpy()), g["pred/zero_idmap"])
+
+
+def perturb_head_biases(P, seed, scale):
+    """The fixture's deterministic head-bias perturbation (tools/gen_golden.py: perturb_head_biases) on a name -> tensor map."""
+    g = torch.Generator().manual_seed(int(seed))
+    with torch.no_grad():
+        for n, p in P.items():
+            if n.startswith("head.") and n.endswith(".bias"):
+                p.add_(float(scale) * torch.randn(p.shape, generator=g))
+
+
+def test_small3_steps(golden_dir):
+    """The same model with NON-ZERO head biases (no pooled row is an exact zero vector entering F.normalize, so none of the
+    reference's gradients is amplified rounding residue): three consecutive iterations and a fourth on the predicted-mask
+    branch (epoch 30), every loss, every gradient norm, every post-step tensor against the real reference - no exclusions."""
+    from ccd_amd.synthetic import make_text_like_batch
+    g = np.load(os.path.join(golden_dir, "small3_step.npz"))
+    spec = O.Spec(norm_last_layer=False, **O.ARCH["vit_small"])
+    student, teacher = O.build_pair(spec, seed=0)
+    perturb_head_biases(student.P, *g["perturb"])
+    for k in teacher.P:
+        if k.startswith("head."):
+            teacher.P[k] = student.P[k].detach().clone()
+    _check_stats(g["init_names"], g["init_stats"], student.P, rtol=0, atol=0, what="init")
+    center, opt = torch.zeros(1, spec.out_dim), O.AdamWState()
+    for step in range(4):
+        p = f"s{step}/"
+        epoch, lr, wd, mom, clip, freeze, seed = g[p + "hyper"]
+        batch = (make_text_like_batch if epoch >= 30 else make_batch)(8, seed=int(seed))
+        np.testing.assert_array_equal(batch[1].numpy().astype(np.uint8), g[p + "masks"])
+        rec = O.train_iteration(student, teacher, center, opt, batch, int(epoch), lr, wd, mom, clip=clip,
+                                freeze_last_layer=int(freeze))
+        center = rec["center"]
+        s = rec["s_out"]
+        if epoch >= 30:
+            seg1 = s["mask"].detach()[:8]
+            np.testing.assert_allclose(seg1.numpy(), g[p + "seg_logits_view1"], rtol=1e-3, atol=2e-5)
+            np.testing.assert_array_equal((F.softmax(seg1, 1)[:, 1] > 0.5).numpy().astype(np.uint8), g[p + "pred_mask"])
+            assert len(np.unique(g[p + "zero_idmap"])) > 3, "fixture: the predicted masks must hold components"
+        np.testing.assert_array_equal(s["idmap"], g[p + "zero_idmap"])
+        np.testing.assert_array_equal(s["index"].numpy(), g[p + "new_index"])
+        np.testing.assert_allclose([rec["loss"], rec["mask_loss"], rec["dino_loss"]], g[p + "losses"], rtol=5e-6)
+        _check_stats(g[p + "grad_names"], g[p + "grad_stats"], rec["grads_raw"], rtol=2e-3, atol=5e-7, what="grad")
+        _check_stats(g[p + "post_names"], g[p + "post_stats"], student.P, rtol=1e-4, atol=1e-6, what="post")
+        _check_stats(g[p + "teacher_post_names"], g[p + "teacher_post_stats"], teacher.P, rtol=1e-5, atol=1e-6, what="ema")
 
 
 @pytest.mark.parametrize("tag,arch,n_layers,B", [("tiny", "vit_tiny", 2, 4), ("small", "vit_small", 6, 8)])

@@ -14,6 +14,7 @@ Fixtures (all small):
   tiny_step.npz    3-block E=192 model, B=2: full tensors of every stage + grads
   small_step.npz   CCD_pretrain_ViT_small hyper-parameters, B=8, 2 iterations: losses, index maps,
                    sampled logits, per-parameter grad norms / post-step checksums
+  small3_step.npz  the same model with perturbed head biases: 3 consecutive iterations + one at epoch 30 (predicted masks)
   finetune_step.npz  DINO_Finetune (vit_tiny/2 layers, vit_small/6 layers): 2 AdamW iterations + greedy decoding
 """
 import argparse
@@ -40,7 +41,8 @@ import importlib.util
 _spec = importlib.util.spec_from_file_location("ccd_synthetic", os.path.join(REPO, "ccd_amd", "synthetic.py"))
 _syn = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(_syn)
-make_batch = _syn.make_batch              # our generator, not reference code
+make_batch = _syn.make_batch              # our generators, not reference code
+make_text_like_batch = _syn.make_text_like_batch
 import Dino as _ref_dino
 assert all(os.path.realpath(p).startswith("/root/reference") for p in _ref_dino.__path__), _ref_dino
 
@@ -349,6 +351,76 @@ def gen_small():
     print("small_step.npz written")
 
 
+HEAD_BIAS_PERTURB = dict(seed=1234, scale=0.02)
+
+
+def perturb_head_biases(named_parameters):
+    """In place: every bias of the DINO head += scale * N(0,1) from a seeded generator, in parameter order.  With non-zero
+    head biases no pooled row reaches F.normalize as an exact zero vector, so the reference's head-bias gradients are not
+    rounding residue amplified by 1/eps and multi-iteration parity can be asserted tensor by tensor."""
+    g = torch.Generator().manual_seed(HEAD_BIAS_PERTURB["seed"])
+    with torch.no_grad():
+        for n, p in named_parameters:
+            if n.startswith("head.") and n.endswith(".bias"):
+                p.add_(HEAD_BIAS_PERTURB["scale"] * torch.randn(p.shape, generator=g))
+
+
+def gen_small3():
+    """CCD_pretrain_ViT_small, B=8, head biases perturbed before the first step: one iteration at epoch 30 (predicted-mask
+    branch, dino_vision.py:64-70, on images that carry the characters) followed by THREE consecutive iterations on the
+    dataset-mask branch, all on the same model and optimizer state -> small3_step.npz."""
+    ensure_pg()
+    from Dino.modules import utils as rutils
+    from Dino.loss.Dino_loss import DINOLoss
+    B, K = 8, 65536
+    student, teacher = build_reference_pair(dict(arch="vit_small"), dict(out_dim=K), 384, seed=0,
+                                            drop_path_rate=0.0, tiny=False)
+    perturb_head_biases(student.named_parameters())
+    teacher.head.load_state_dict(student.head.state_dict())
+    out = {"perturb": np.array([HEAD_BIAS_PERTURB["seed"], HEAD_BIAS_PERTURB["scale"]])}
+    out["init_names"], out["init_stats"] = state_stats(student.state_dict().items())
+    dino_loss = DINOLoss(K, 2, 0.04, 0.04, 0, 40)
+    optimizer = torch.optim.AdamW(rutils.get_params_groups(student))
+    lr_s = rutils.cosine_iter_scheduler(0.0005 * B / 256.0, 1e-6, 50, warmup_iters=10)
+    wd_s = rutils.cosine_iter_scheduler(0.04, 0.4, 50)
+    mom_s = rutils.cosine_iter_scheduler(0.9995, 1, 50)
+    rows = np.array([0, 5, 17, 40, 47, 63, 80, 95])
+    cols = np.arange(0, K, 1024)
+    # the predicted-mask step comes FIRST: a few AdamW steps on the mask loss push an untrained segmentation head to
+    # "background everywhere" (75 % of the pixels are background), after which the branch has no component left to label
+    for step, (it, epoch, seed) in enumerate([(5, 30, 13), (6, 0, 10), (7, 0, 11), (8, 1, 12)]):
+        # the predicted-mask step runs on images that carry the characters (pure noise gives no 30-pixel component)
+        batch = make_text_like_batch(B, seed=seed) if epoch >= 30 else make_batch(B, seed=seed)
+        rec = reference_iteration(student, teacher, dino_loss, optimizer, batch, epoch=epoch, lr=lr_s[it],
+                                  wd=wd_s[it], mom=mom_s[it], clip=3.0, freeze_last_layer=1, record={})
+        p = f"s{step}/"
+        s_out, t_out = rec["s_out"], rec["t_out"]
+        out[p + "hyper"] = np.array([epoch, lr_s[it], wd_s[it], mom_s[it], 3.0, 1, seed])
+        out[p + "masks"] = batch[1].numpy().astype(np.uint8)
+        out[p + "metrics"] = batch[2].numpy()
+        out[p + "zero_idmap"] = planes_to_idmap(s_out["zero"].numpy())
+        out[p + "new_index"] = s_out["index"].numpy()
+        out[p + "losses"] = np.array([rec["loss"], rec["mask_loss"], rec["dino_loss"]])
+        sl, tl = s_out["instances_view"].detach(), t_out["instances_view"].detach()
+        r = rows[rows < sl.shape[0]]
+        out[p + "rows"], out[p + "cols"] = r, cols
+        out[p + "student_logits_sample"] = sl[r][:, cols].numpy()
+        out[p + "teacher_logits_sample"] = tl[r][:, cols].numpy()
+        out[p + "center_stat"] = stat(dino_loss.center)
+        out[p + "grad_names"], out[p + "grad_stats"] = state_stats(rec["grads_raw"].items())
+        out[p + "post_names"], out[p + "post_stats"] = state_stats(student.state_dict().items())
+        out[p + "teacher_post_names"], out[p + "teacher_post_stats"] = state_stats(teacher.state_dict().items())
+        if epoch >= 30:     # the branch thresholds the student's own segmentation: keep the logits of view 1 in full
+            seg = s_out["mask"].detach()[:B]
+            out[p + "seg_logits_view1"] = seg.numpy()
+            out[p + "pred_mask"] = (F.softmax(seg, dim=1)[:, 1] > 0.5).numpy().astype(np.uint8)
+            out[p + "pred_margin_min"] = np.array([(seg[:, 1] - seg[:, 0]).abs().min().item()])
+        print(f"small3 step {step} (epoch {epoch}): losses {out[p + 'losses']}  M={int(s_out['index'].sum())}"
+              f"  planes/img={[int((np.unique(m) != 255).sum()) for m in out[p + 'zero_idmap'][:B]]}")
+    np.savez_compressed(os.path.join(GOLD, "small3_step.npz"), **out)
+    print("small3_step.npz written")
+
+
 def gen_keys():
     """State-dict key names + shapes of student/teacher for the three shipped archs."""
     import json
@@ -445,7 +517,7 @@ if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     os.chdir("/root/reference")  # Config() and friends use relative paths; we never write here
     torch.set_num_threads(8)
-    todo = [a.only] if a.only else ["sched", "ccl", "tiny", "small", "keys", "finetune"]
+    todo = [a.only] if a.only else ["sched", "ccl", "tiny", "small", "small3", "keys", "finetune"]
     for t in todo:
-        {"sched": gen_sched, "ccl": gen_ccl, "tiny": gen_tiny, "small": gen_small, "keys": gen_keys,
+        {"sched": gen_sched, "ccl": gen_ccl, "tiny": gen_tiny, "small": gen_small, "small3": gen_small3, "keys": gen_keys,
          "finetune": gen_finetune}[t]()

@@ -39,6 +39,8 @@ def collect(path, counter):
                 m = re.search(r"gemm_row384_kernel<(\d+)", name)
                 key = {"0": "gemm_nt_bf16", "2": "gemm_nt_resid", "3": "gemm_nt_f32", "7": "gemm_nt_resid"}.get(
                     m.group(1), "gemm_row384?") if m else "gemm_row384?"
+            elif "mlp_fused_kernel" in name:                 # fc1 + GELU + fc2 + residual + LayerNorm in one launch
+                key = "mlp_fused"
             elif "ln_fwd_kernel" in name:
                 key = "ln_fwd"
             else:
@@ -70,4 +72,9 @@ for k in sorted(fetch):
     fb = sum(fv) / len(fv) * 1024 * 2
     wb = sum(wv) / len(wv) * 1024 * wcal
     out[k] = {"launches": len(fv), "fetch_bytes": round(fb), "write_bytes": round(wb), "bytes_per_launch": round(fb + wb)}
+# identify the kernels these passes were taken on: bench.py reports `traffic` only while the digest still matches
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_sources_digest
+out["_kernel_sources_sha256"] = kernel_sources_digest()
 print(json.dumps(out, indent=1))
