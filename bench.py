@@ -296,7 +296,10 @@ def main():
                                                norm_last_layer=False, device=dev)
     if use_dist:
         student = torch.nn.SyncBatchNorm.convert_sync_batchnorm(student)      # train.py:96-98
-        model = DataParallel(student)
+        if world == 1:           # BENCH_FORCE_DIST=1: the N > 1 code path on one rank - every collective is really issued
+            from ccd_amd import seghead
+            seghead.FORCE_SYNC = True
+        model = DataParallel(student, reduce_at_world1=(world == 1))
     else:
         model = student
     dino_loss = DINOLoss(a.out_dim, 2, 0.04, 0.04, 0, 100).to(dev)

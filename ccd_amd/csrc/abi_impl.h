@@ -28,10 +28,11 @@
 #define CCD_ALIGNED16(p) ((((uintptr_t)(p)) & 15u) == 0)
 #define CCD_MAX_OPERAND_BYTES 0x7ffffff0L
 
+static int ccd_grid_cus();
 // persistent grid: one workgroup per resident slot (2 per CU), never more than there are work items
 static int ccd_gemm_grid(ccd::GemmParams& p, int tiles, int splits) {
     p.work_items = tiles * splits;
-    const int cap = 2 * ccd_rt_num_cus();
+    const int cap = 2 * ccd_grid_cus();
     return p.work_items < cap ? p.work_items : cap;
 }
 
@@ -80,6 +81,7 @@ struct CcdPolicy {
     int gemm_row384 = 0;        // 1 = full-row kernel for N <= 384 residual / fp32 epilogues, 2 = bf16 too
     int ln_bwd_bpc = 5;         // LayerNorm backward: blocks per CU (one resident wave; more blocks = more dgamma/dbeta atomics)
     int dec_attn_simt = 0;      // decoder attention: force the general SIMT kernels
+    int cu_reserve = 0;         // compute units the persistent grids leave free (set while an RCCL gradient reducer is attached)
     int lab = 0;                // scratch switch for kernel experiments (tools/*_lab.py); 0 in production
 };
 struct CcdPolicyKey { const char* name; int CcdPolicy::*field; };
@@ -87,7 +89,7 @@ static const CcdPolicyKey ccd_policy_keys[] = {
     {"gemm_256", &CcdPolicy::gemm_256}, {"gemm_256_min_m", &CcdPolicy::gemm_256_min_m},
     {"gemm_256_min_n", &CcdPolicy::gemm_256_min_n}, {"gemm_256_f32", &CcdPolicy::gemm_256_f32},
     {"gemm_256_deep", &CcdPolicy::gemm_256_deep}, {"gemm_row384", &CcdPolicy::gemm_row384},
-    {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"lab", &CcdPolicy::lab}};
+    {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"lab", &CcdPolicy::lab}};
 static CcdPolicy& ccd_policy() {
     static CcdPolicy pol = [] {
         CcdPolicy q;
@@ -102,11 +104,16 @@ static CcdPolicy& ccd_policy() {
     }();
     return pol;
 }
+// compute units a persistent grid may occupy: all of them, minus the ones reserved for concurrently running RCCL kernels
+static int ccd_grid_cus() {
+    const int cus = ccd_rt_num_cus() - ccd_policy().cu_reserve;
+    return cus > 1 ? cus : 1;
+}
 // 256x256-tile LDS-DMA kernel for the large-M products (gemm256.h): one workgroup per CU
 template <int BN, bool DEEP = false>
 static int ccd_launch_gemm256(const ccd::GemmParams& p, int epilogue, void* stream) {
     const int tiles = ((p.M + ccd::G256_BM - 1) / ccd::G256_BM) * ((p.N + BN - 1) / BN);
-    const int cus = ccd_rt_num_cus();
+    const int cus = ccd_grid_cus();
     const dim3 grid(tiles < cus ? tiles : cus), block(ccd::G256_THREADS);
     const size_t smem = ccd::G256_SMEM_BYTES;
     switch (epilogue) {
@@ -122,7 +129,7 @@ static int ccd_launch_gemm256(const ccd::GemmParams& p, int epilogue, void* stre
 // full-row kernel for N <= 384 (gemm_row384.h): one workgroup per CU
 static int ccd_launch_gemm_row384(const ccd::GemmParams& p, int epilogue, void* stream) {
     const int tiles = (p.M + ccd::GR_BM - 1) / ccd::GR_BM;
-    const int cus = ccd_rt_num_cus();
+    const int cus = ccd_grid_cus();
     const dim3 grid(tiles < cus ? tiles : cus), block(ccd::GR_THREADS);
     const size_t smem = ccd::GR_SMEM_BYTES;
     switch (epilogue) {
@@ -233,7 +240,7 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
     p.rowscale = rowscale; p.rows_per_sample = rowscale ? rows_per_sample : 1; p.out = out; p.ldc = ldc;
     p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_eps = ln_eps; p.ln_y = ln_y; p.ld_y = ld_y; p.ln_mean = ln_mean;
     p.ln_rstd = ln_rstd; p.u = u; p.ldu = ldu; p.M = M; p.H = H; p.lab = ccd_policy().lab;
-    const int tiles = (M + ccd::MLP_BM - 1) / ccd::MLP_BM, cus = ccd_rt_num_cus();
+    const int tiles = (M + ccd::MLP_BM - 1) / ccd::MLP_BM, cus = ccd_grid_cus();
     const dim3 grid(tiles < cus ? tiles : cus), block(ccd::MLP_THREADS);
     if (E == 384) {
         if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<384, true>), grid, block, smem, stream, p);

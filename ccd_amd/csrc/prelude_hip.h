@@ -136,15 +136,18 @@ __device__ __forceinline__ float fast_rsqrt(float x) { return rsqrtf(x); }
 
 template <typename F>
 static inline const void* ccd_fn_ptr(F* f) { return reinterpret_cast<const void*>(f); }
-// dynamic LDS above 64 KiB has to be opted into once per kernel (gfx950 allows up to 160 KiB per workgroup)
+// dynamic LDS above 64 KiB has to be opted into once per kernel and device (gfx950 allows up to 160 KiB per workgroup)
 #define CCD_LAUNCH(kernel, grid, block, smem, stream, ...)                                                      \
     do {                                                                                                        \
         if ((smem) > 65536) {                                                                                   \
-            static bool ccd_once_ = false;                                                                      \
-            if (!ccd_once_) {                                                                                   \
+            static unsigned long long ccd_devs_ = 0; /* the attribute is per function AND per device */         \
+            int ccd_dev_ = 0;                                                                                   \
+            (void)hipGetDevice(&ccd_dev_);                                                                      \
+            const unsigned long long ccd_bit_ = 1ull << (ccd_dev_ & 63);                                        \
+            if (!(ccd_devs_ & ccd_bit_)) {                                                                      \
                 (void)hipFuncSetAttribute(ccd_fn_ptr(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                           (int)(smem));                                                         \
-                ccd_once_ = true;                                                                               \
+                ccd_devs_ |= ccd_bit_;                                                                          \
             }                                                                                                   \
         }                                                                                                       \
         hipLaunchKernelGGL(kernel, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__);                \

@@ -16,14 +16,17 @@ import torch.nn as nn
 
 
 class GradReducer:
-    def __init__(self, arena, process_group=None, bucket_elems=8 * 1024 * 1024):
+    def __init__(self, arena, process_group=None, bucket_elems=8 * 1024 * 1024, at_world1=False):
+        """at_world1: issue the collectives even on a single rank (they are identities there) - the 1-GPU smoke of the
+        N > 1 path (bench.py BENCH_FORCE_DIST=1, tests/test_model_gpu.py)."""
         self.arena, self.pg, self.bucket_elems = arena, process_group, bucket_elems
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = dist.is_initialized() and (self.world > 1 or at_world1)
         self._pending, self._works, self._done = [], [], []
         self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
 
     def _launch(self, lo, hi):
-        if self.world == 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return
         buf = self.arena.grad[lo:hi]
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
@@ -76,7 +79,9 @@ class DataParallel(nn.Module):
     construction, overlapped gradient averaging."""
 
     def __init__(self, module, device_ids=None, find_unused_parameters=False, process_group=None,
-                 bucket_elems=8 * 1024 * 1024):
+                 bucket_elems=8 * 1024 * 1024, reduce_at_world1=False, cu_reserve=8):
+        """cu_reserve: compute units the persistent GEMM grids leave free while a reducer is attached, so that the RCCL
+        kernels of the bucket all-reduces find a slot next to them (policy key `cu_reserve`; 0 = take every CU)."""
         super().__init__()
         self.module = module
         self.reducer = None
@@ -87,8 +92,16 @@ class DataParallel(nn.Module):
                 if b.is_floating_point() or b.dtype in (torch.int64, torch.int32):
                     dist.broadcast(b, src=0, group=process_group)
             arena.refresh_mirrors()
-            if any(p.requires_grad for p in module.parameters()) and dist.get_world_size(process_group) > 1:
-                self.reducer = GradReducer(arena, process_group, bucket_elems)
+            world = dist.get_world_size(process_group)
+            if any(p.requires_grad for p in module.parameters()) and (world > 1 or reduce_at_world1):
+                # gradient buckets travel on their OWN process group (= their own RCCL stream): the blocking SyncBatchNorm
+                # exchanges of the segmentation head's backward pass must not queue behind a 22 M-element bucket
+                ranks = list(range(dist.get_world_size())) if process_group is None else dist.get_process_group_ranks(process_group)
+                grad_pg = dist.new_group(ranks=ranks, backend=dist.get_backend(process_group))
+                self.reducer = GradReducer(arena, grad_pg, bucket_elems, at_world1=reduce_at_world1)
+                if arena.device.type == "cuda" and cu_reserve:
+                    from . import ops
+                    ops.policy_set("cu_reserve", int(cu_reserve))
                 hook = self.reducer.mark_ready
                 for m in module.modules():
                     if hasattr(m, "grad_ready_hook"):

@@ -39,30 +39,35 @@ def _parity_taps(py, px):
     return [(ky, kx, dy, dx) for ky, dy in _KY[py] for kx, dx in _KY[px]]
 
 
+FORCE_SYNC = False      # 1-GPU smoke of the N > 1 path: SyncBatchNorm layers exchange their statistics on a single rank too
+
+
 def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 class _BN:
-    """State of one BatchNorm2d(+ReLU) application inside a forward pass."""
+    """State of one BatchNorm2d(+ReLU) application inside a forward pass.  The batch statistics (forward) and the two
+    reduction sums of the backward pass live in slices of a `_BNGroup` buffer, so that the SyncBatchNorm exchanges of
+    independent layers (the three MLA branches) travel in ONE all-reduce per level and direction: 4 + 4 small collectives
+    per step instead of 8 + 8."""
 
-    def __init__(self, mod, rows, device):
+    def __init__(self, mod, rows, device, stats=None):
         self.mod = mod
         self.C = mod.num_features
         self.rows = rows
-        self.sync = isinstance(mod, nn.SyncBatchNorm) and _world() > 1
+        self.sync = isinstance(mod, nn.SyncBatchNorm) and (_world() > 1 or (FORCE_SYNC and dist.is_initialized()))
         self.count = float(rows * (_world() if self.sync else 1))
-        self.stats = torch.zeros(2 * self.C, dtype=F32, device=device)
+        self.stats = stats if stats is not None else torch.zeros(2 * self.C, dtype=F32, device=device)
         self.mean_rstd = torch.empty(2 * self.C, dtype=F32, device=device)
 
     def finalize(self):
+        """Batch statistics (already summed over the ranks by the group) -> mean / rstd + running statistics."""
         mod = self.mod
         if not mod.training:                          # eval: running statistics (tiny host-side glue, no batch stats)
             self.mean_rstd[: self.C] = mod.running_mean
             self.mean_rstd[self.C:] = torch.rsqrt(mod.running_var + mod.eps)
             return
-        if self.sync:
-            dist.all_reduce(self.stats)
         momentum = mod.momentum if mod.momentum is not None else 1.0 / float(mod.num_batches_tracked.item() + 1)
         ops.bn_finalize(self.stats, self.count, mod.eps, momentum, self.mean_rstd, mod.running_mean, mod.running_var)
         mod.num_batches_tracked += 1
@@ -70,19 +75,48 @@ class _BN:
     def forward(self, x, out):
         return ops.bn_relu_fwd(x, self.mean_rstd, self.mod.weight, self.mod.bias, out)
 
-    def backward(self, dy, x, dx):
-        """dx (may alias dy) = gradient w.r.t. the BN input; parameter gradients accumulate into .grad (arena)."""
+    def backward_reduce(self, dy, x, red):
+        """red [2C] (a group slice, zeroed) += the two sums BatchNorm's input gradient needs."""
+        ops.bn_relu_bwd_reduce(dy, x, self.mean_rstd, self.mod.weight, self.mod.bias, red)
+
+    def backward_apply(self, dy, x, dx, red, red_local):
+        """dx (may alias dy) = gradient w.r.t. the BN input; parameter gradients (from the LOCAL sums) accumulate into .grad."""
         mod = self.mod
-        red = torch.zeros(2 * self.C, dtype=F32, device=x.device)
-        ops.bn_relu_bwd_reduce(dy, x, self.mean_rstd, mod.weight, mod.bias, red)
-        red_local = red
-        if self.sync:
-            red_local = red.clone()
-            dist.all_reduce(red)
         if not mod.training:                          # eval-mode BN is an affine map: no batch terms
             red = torch.zeros_like(red)
         return ops.bn_relu_bwd_apply(dy, x, self.mean_rstd, mod.weight, mod.bias, red, self.count, red_local,
                                      mod.weight.grad, mod.bias.grad, dx)
+
+
+class _BNGroup:
+    """BatchNorm layers of one level whose statistics are exchanged together."""
+
+    def __init__(self, mods, rows, device):
+        sizes = [2 * m.num_features for m in mods]
+        self.buf = torch.zeros(sum(sizes), dtype=F32, device=device)
+        offs = [sum(sizes[:i]) for i in range(len(sizes))]
+        self.bns = [_BN(m, rows, device, self.buf[o:o + n]) for m, o, n in zip(mods, offs, sizes)]
+        self.sync = any(b.sync for b in self.bns)
+        self._offs, self._sizes = offs, sizes
+
+    def finalize(self):
+        if self.sync and self.bns[0].mod.training:
+            dist.all_reduce(self.buf)                 # one collective for the whole level
+        for b in self.bns:
+            b.finalize()
+
+    def backward(self, dys, xs, dxs):
+        """dys / xs / dxs: per layer.  Reduce all layers, ONE all-reduce, apply all layers."""
+        red = torch.zeros_like(self.buf)
+        slices = [red[o:o + n] for o, n in zip(self._offs, self._sizes)]
+        for b, dy, x, r in zip(self.bns, dys, xs, slices):
+            b.backward_reduce(dy, x, r)
+        red_local = red
+        if self.sync:
+            red_local = red.clone()
+            dist.all_reduce(red)
+        loc = [red_local[o:o + n] for o, n in zip(self._offs, self._sizes)]
+        return [b.backward_apply(dy, x, dx, r, rl) for b, dy, x, dx, r, rl in zip(self.bns, dys, xs, dxs, slices, loc)]
 
 
 def _ensure_grads(module):
@@ -133,24 +167,29 @@ class SegHeadFn(torch.autograd.Function):
         d3 = ops.conv_desc((gh, gw), (gh, gw), E, TAPS3)
         d1 = ops.conv_desc((gh, gw), (gh, gw), mid, TAPS1)
         cat = torch.empty((M, 3 * out_c), dtype=BF16, device=dev)
-        saved = {"taps": taps, "y1": [], "a1": [], "y2": [], "bn1": [], "bn2": [], "w2": []}
+        saved = {"taps": taps, "y1": [], "a1": [], "y2": [], "w2": []}
+        # level 1 of the three independent branches (3x3 conv), ONE statistics exchange, then level 2 (1x1 conv), ONE more
+        g1 = _BNGroup([seq[1] for seq in heads], M, dev)
         for i, seq in enumerate(heads):
             w1 = ops.permute4(seq[0].weight.detach(), (E * 9, 1, 9), (mid, 9, E),
                               torch.empty((mid, 9 * E), dtype=BF16, device=dev))
-            bn1 = _BN(seq[1], M, dev)
             y1 = torch.empty((M, mid), dtype=BF16, device=dev)
-            ops.conv_gemm(taps[i], d3, w1, M, y1, colsum=bn1.stats[:mid], colsumsq=bn1.stats[mid:])
-            bn1.finalize()
-            a1 = bn1.forward(y1, torch.empty_like(y1))
+            ops.conv_gemm(taps[i], d3, w1, M, y1, colsum=g1.bns[i].stats[:mid], colsumsq=g1.bns[i].stats[mid:])
+            saved["y1"].append(y1)
+        g1.finalize()
+        g2 = _BNGroup([seq[4] for seq in heads], M, dev)
+        for i, seq in enumerate(heads):
+            a1 = g1.bns[i].forward(saved["y1"][i], torch.empty_like(saved["y1"][i]))
             w2 = torch.empty((out_c, mid), dtype=BF16, device=dev)
             ops.permute4(seq[3].weight.detach(), (mid, 1), (out_c, mid), w2)
-            bn2 = _BN(seq[4], M, dev)
             y2 = torch.empty((M, out_c), dtype=BF16, device=dev)
-            ops.conv_gemm(a1, d1, w2, M, y2, colsum=bn2.stats[:out_c], colsumsq=bn2.stats[out_c:])
-            bn2.finalize()
-            bn2.forward(y2, cat[:, i * out_c:(i + 1) * out_c])
-            for k, v in (("y1", y1), ("a1", a1), ("y2", y2), ("bn1", bn1), ("bn2", bn2), ("w2", w2)):
+            ops.conv_gemm(a1, d1, w2, M, y2, colsum=g2.bns[i].stats[:out_c], colsumsq=g2.bns[i].stats[out_c:])
+            for k, v in (("a1", a1), ("y2", y2), ("w2", w2)):
                 saved[k].append(v)
+        g2.finalize()
+        for i in range(3):
+            g2.bns[i].forward(saved["y2"][i], cat[:, i * out_c:(i + 1) * out_c])
+        saved["g1"], saved["g2"] = g1, g2
         x, grid = cat, (gh, gw)
         ups = []
         for seq in (head.unpool1, head.unpool2):
@@ -158,7 +197,8 @@ class SegHeadFn(torch.autograd.Function):
             cin, cout = convt.in_channels, convt.out_channels
             rows = images * grid[0] * grid[1]
             y = torch.empty((4 * rows, cout), dtype=BF16, device=dev)
-            bn = _BN(bnm, 4 * rows, dev)
+            grp = _BNGroup([bnm], 4 * rows, dev)
+            bn = grp.bns[0]
             wsrc = convt.weight.detach()                                   # [cin, cout, 4, 4]
             for py in (0, 1):
                 for px in (0, 1):
@@ -169,9 +209,9 @@ class SegHeadFn(torch.autograd.Function):
                     ops.permute4(wsrc.reshape(-1)[ky0 * 4 + kx0:], (16, 8, 2, cout * 16), (cout, 2, 2, cin), wp)
                     ops.conv_gemm(x, desc, wp, rows, y, bias=convt.bias, colsum=bn.stats[:cout],
                                   colsumsq=bn.stats[cout:])
-            bn.finalize()
+            grp.finalize()
             a = bn.forward(y, torch.empty_like(y))
-            ups.append((x, y, bn, grid))
+            ups.append((x, y, grp, grid))
             x, grid = a, (2 * grid[0], 2 * grid[1])
         logits = cls_forward(x, head.cls.weight.detach(), head.cls.bias.detach(), images, grid[0], grid[1])
         ctx.head, ctx.images, ctx.saved, ctx.ups, ctx.a_last, ctx.grid = head, images, saved, ups, x, grid
@@ -191,11 +231,11 @@ class SegHeadFn(torch.autograd.Function):
                          head.cls.bias.grad, images, H, W)
         ctx.a_last = None
         # ---- transposed convs, last first
-        for seq, (x_in, y, bn, grid) in zip((head.unpool2, head.unpool1), reversed(ctx.ups)):
+        for seq, (x_in, y, grp, grid) in zip((head.unpool2, head.unpool1), reversed(ctx.ups)):
             convt = seq[0]
             cin, cout = convt.in_channels, convt.out_channels
             rows = images * grid[0] * grid[1]
-            dyc = bn.backward(d, y, d)                                              # in place: d(convT output)
+            dyc = grp.backward([d], [y], [d])[0]                                    # in place: d(convT output)
             ops.colsum_bf16(dyc, convt.bias.grad)
             desc = ops.conv_desc(grid, (2 * grid[0], 2 * grid[1]), cout, TAPS_T_GRAD, s_mul=2)
             stage = torch.zeros((cin, 16 * cout), dtype=F32, device=dev)
@@ -209,21 +249,24 @@ class SegHeadFn(torch.autograd.Function):
         d3 = ops.conv_desc((gh, gw), (gh, gw), E, TAPS3)
         d3f = ops.conv_desc((gh, gw), (gh, gw), mid, TAPS3_FLIP)
         heads = [head.mlahead.head2, head.mlahead.head3, head.mlahead.head4]
-        d_taps = []
+        # level 2 of all three branches (one exchange), their 1x1 products, level 1 (one exchange), their 3x3 products
+        dy2s = saved["g2"].backward([d[:, i * out_c:(i + 1) * out_c] for i in range(3)], saved["y2"],
+                                    [torch.empty_like(y) for y in saved["y2"]])
+        da1s = []
         for i, seq in enumerate(heads):
-            y1, a1, y2, bn1, bn2, w2 = (saved[k][i] for k in ("y1", "a1", "y2", "bn1", "bn2", "w2"))
-            dy2 = bn2.backward(d[:, i * out_c:(i + 1) * out_c], y2, torch.empty_like(y2))
-            ops.gemm_tn(dy2, a1, seq[3].weight.grad.view(out_c, mid))              # dW2[co][ci]
+            ops.gemm_tn(dy2s[i], saved["a1"][i], seq[3].weight.grad.view(out_c, mid))  # dW2[co][ci]
             w2t = torch.empty((mid, out_c), dtype=BF16, device=dev)
             ops.permute4(seq[3].weight.detach(), (1, mid), (mid, out_c), w2t)
-            da1 = ops.gemm_nt(dy2, w2t)                                             # [M, mid]
-            dy1 = bn1.backward(da1, y1, da1)
+            da1s.append(ops.gemm_nt(dy2s[i], w2t))                                  # [M, mid]
+        dy1s = saved["g1"].backward(da1s, saved["y1"], da1s)
+        d_taps = []
+        for i, seq in enumerate(heads):
             stage = torch.zeros((mid, 9 * E), dtype=F32, device=dev)
-            ops.conv_wgrad(dy1, saved["taps"][i], d3, stage)                        # [co][tap][ci]
+            ops.conv_wgrad(dy1s[i], saved["taps"][i], d3, stage)                    # [co][tap][ci]
             ops.permute4(stage, (9 * E, 1, E), (mid, E, 9), seq[0].weight.grad, accumulate=True)
             w1d = torch.empty((E, 9 * mid), dtype=BF16, device=dev)                 # [ci][tap][co] <- W[co][ci][tap]
             ops.permute4(seq[0].weight.detach(), (9, 1, E * 9), (E, 9, mid), w1d)
-            d_taps.append(ops.conv_gemm(dy1, d3f, w1d, M, torch.empty((M, E), dtype=BF16, device=dev)))
+            d_taps.append(ops.conv_gemm(dy1s[i], d3f, w1d, M, torch.empty((M, E), dtype=BF16, device=dev)))
         ctx.saved = ctx.ups = None
         return (None, None, *d_taps)
 

@@ -33,7 +33,7 @@ const char* ccd_build_info(void);
 
 /* Kernel-selection policy.  Which tile shape serves a product is decided by a small table of integers that is read ONCE
  * from the environment (CCD_GEMM_256, CCD_GEMM_256_MIN_M, CCD_GEMM_256_MIN_N, CCD_GEMM_256_F32, CCD_GEMM_256_DEEP,
- * CCD_GEMM_ROW384, CCD_LN_BWD_BPC, CCD_DEC_ATTN_SIMT) and can be changed at run time by key (lower case,
+ * CCD_GEMM_ROW384, CCD_LN_BWD_BPC, CCD_DEC_ATTN_SIMT, CCD_CU_RESERVE) and can be changed at run time by key (lower case,
  * without the prefix) - the launch path never calls getenv.  Unknown key: CCD_EINVAL.  No reference counterpart: the
  * reference leaves kernel selection to ATen / cuDNN heuristics. */
 int ccd_policy_set(const char* key, int value);

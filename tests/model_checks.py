@@ -290,6 +290,104 @@ def check_small3_steps(device, loss_tol=1e-3):
     return report
 
 
+def check_dist_world1(device, port=29611):
+    """The N > 1 path on the one GPU there is: a 1-rank `nccl` (= RCCL) group, SyncBatchNorm conversion, DataParallel with
+    its bucketed asynchronous all-reduces on a dedicated process group and reserved compute units, the centre all-reduce -
+    every collective really issued (identities on one rank).  One iteration must equal the non-distributed one (up to the
+    fp32-atomic summation order both runs share)."""
+    import torch.distributed as dist
+    from ccd_amd import ops, seghead
+    from ccd_amd.parallel import DataParallel
+    results = {}
+    for mode in ("plain", "dist"):
+        student, teacher = tiny_networks(device)
+        dino_loss = DINOLoss(512, 2, 0.04, 0.04, 0, 40).to(device)
+        images, masks, metrics = make_batch(4, seed=11, device=device)
+        model = student
+        calls = []
+        if mode == "dist":
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                    device_id=device if device.type == "cuda" else None)
+            student = torch.nn.SyncBatchNorm.convert_sync_batchnorm(student)
+            seghead.FORCE_SYNC = True
+            model = DataParallel(student, reduce_at_world1=True, bucket_elems=1 << 18)
+            assert model.reducer is not None and ops.policy_get("cu_reserve") == 8
+            real = dist.all_reduce
+            dist.all_reduce = lambda *a, **k: (calls.append(int(a[0].numel())), real(*a, **k))[1]
+        try:
+            opt = pretrain.make_optimizer(student, clip_grad=3.0)
+            loss = pretrain.training_iteration(model, teacher, dino_loss, opt, images, masks, metrics, 1, 2e-4, 0.05, 0.99)
+            if device.type == "cuda":
+                torch.cuda.synchronize()
+            results[mode] = (loss.item(), student.arena.flat.clone(), dino_loss.center.clone())
+        finally:
+            if mode == "dist":
+                dist.all_reduce = real
+                seghead.FORCE_SYNC = False
+                ops.policy_set("cu_reserve", 0)
+                dist.destroy_process_group()
+        if mode == "dist":
+            # gradient buckets (several, the arena is cut at 2^18 elements), 4 + 4 SyncBatchNorm exchanges, the centre
+            assert sum(1 for n in calls if n >= 1 << 17) >= 2 and len(calls) >= 2 + 8 + 1, calls
+    (l0, w0, c0), (l1, w1, c1) = results["plain"], results["dist"]
+    assert abs(l0 - l1) < 1e-5, (l0, l1)
+    move = (w0 - tiny_networks(device)[0].arena.flat).abs().max().item()
+    assert (w0 - w1).abs().max().item() <= 2e-3 * move, "the distributed iteration updated the weights differently"
+    assert (c0 - c1).abs().max().item() < 1e-6
+    return {"loss_plain": l0, "loss_dist": l1, "collectives": len(calls)}
+
+
+def check_full_batch_equals_micro_batches(device, B=256, mb=8):
+    """BASELINE config #2's size, checked by more than isfinite: with BatchNorm in eval mode every image is independent, so
+    the B = 256 forward pass + losses (512-view backbone launches, the worst-case-row head launch driven by the device-side
+    row count, d_rows tile enumeration at M ~ 3.3 k) must reproduce the row-weighted mean of the same images run as 32
+    micro-batches of 8 through the B = 8 path that the reference fixtures pin; M is recomputed on the host."""
+    from ccd_amd import ops
+    torch.manual_seed(0)
+    np.random.seed(0)
+    student, teacher = pretrain.build_networks(arch="vit_small", out_dim=65536, drop_path_rate=0.0,
+                                               norm_last_layer=False, device=device)
+    student.eval()
+    teacher.eval()
+    images, masks, metrics = make_batch(B, seed=77, device=device)
+
+    def run(sl):
+        dino_loss = DINOLoss(65536, 2, 0.04, 0.04, 0, 40).to(device)          # fresh centre for every call
+        with torch.no_grad():
+            s_out = student(images[sl], metrics[sl].float(), masks[sl], 1, clusters=None)
+            t_out = teacher(images[sl], metrics[sl].float(), None, None, clusters=s_out["zero"], index=None)
+            s_out["gt"] = [masks[sl], ops.warp_idmap(ops.mask_to_idmap(masks[sl].contiguous().float()), metrics[sl].contiguous())]
+            dino_loss(s_out, t_out, 1)
+        m = int(s_out.raw("selection").total.item())
+        return dino_loss.last_losses["mask_loss"].item(), dino_loss.last_losses["Dino_loss"].item(), m
+
+    mask_full, dino_full, m_full = run(slice(0, B))
+    # M on the host: rows per view = sum over images of min(#components of the mask, 26 planes, clamp 3) + 1
+    from oracle import ccl_np
+    ids = np.stack([ccl_np.label_idmap(m) for m in masks.cpu().numpy()])
+    counts = [len(set(np.unique(i).tolist()) - {255}) for i in ids]
+    m_host = sum(min(max(c, 3), 26) + 1 if c < 26 else 26 for c in counts)
+    assert m_full == m_host, (m_full, m_host)
+    acc_mask = acc_dino = 0.0
+    m_sum = 0
+    for lo in range(0, B, mb):
+        ml, dl, m = run(slice(lo, lo + mb))
+        acc_mask += ml * mb
+        acc_dino += dl * m
+        m_sum += m
+    assert m_sum == m_full
+    assert abs(mask_full - acc_mask / B) < 1e-3, (mask_full, acc_mask / B)
+    assert abs(dino_full - acc_dino / m_sum) < 1e-3, (dino_full, acc_dino / m_sum)
+    # and one real training iteration at this size: finite, and it moves the loss it optimises
+    student.train()
+    dino_loss = DINOLoss(65536, 2, 0.04, 0.04, 0, 40).to(device)
+    opt = pretrain.make_optimizer(student, clip_grad=3.0)
+    l0 = pretrain.training_iteration(student, teacher, dino_loss, opt, images, masks, metrics, 1, 5e-4, 0.04, 0.9995).item()
+    l1 = pretrain.training_iteration(student, teacher, dino_loss, opt, images, masks, metrics, 1, 5e-4, 0.04, 0.9995).item()
+    assert np.isfinite([l0, l1]).all() and l1 < l0, (l0, l1)
+    return {"M": m_full, "mask_loss": [mask_full, acc_mask / B], "dino_loss": [dino_full, acc_dino / m_sum], "train": [l0, l1]}
+
+
 def check_properties_full_size(device, B=256):
     """Size-independent properties at BASELINE's full batch (where the oracle is too slow to be the checker)."""
     from ccd_amd import engine, ops

@@ -39,8 +39,23 @@ def test_vit_small_b8_four_iterations_vs_reference_nonzero_head_biases(hip):
         json.dump(report, f)
 
 
+def test_distributed_path_on_one_rank(hip):
+    """RCCL init, SyncBatchNorm, bucketed async all-reduces against the persistent GEMM grids: executed once on this GPU."""
+    report = mc.check_dist_world1(hip.device)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/dist_world1.json", "w") as f:
+        json.dump(report, f)
+
+
 def test_optimizer_host_runs_ahead(hip):
     mc.check_optimizer_host_runs_ahead(hip.device)
+
+
+def test_full_batch_iteration_equals_micro_batches(hip):
+    report = mc.check_full_batch_equals_micro_batches(hip.device, B=256)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/full_batch_check.json", "w") as f:
+        json.dump(report, f)
 
 
 def test_properties_at_full_batch(hip):

@@ -156,9 +156,16 @@ def _syncbn_worker(rank, world, port):
         # this rank's shard through the HIP path with synchronised statistics
         head = torch.nn.SyncBatchNorm.convert_sync_batchnorm(head)
         mine = [t[rank * 256:(rank + 1) * 256].clone().requires_grad_(True) for t in taps]
+        calls = []
+        real_all_reduce = dist.all_reduce
+        dist.all_reduce = lambda *a, **k: (calls.append(a[0].numel()), real_all_reduce(*a, **k))[1]
         logits = sh.seg_head_forward(head, mine, 1)
+        fwd_calls = len(calls)
         kc.close(logits, want[rank:rank + 1], 3e-2, 3e-2, "syncbn/logits")
         logits.backward(dl[rank:rank + 1])
+        dist.all_reduce = real_all_reduce
+        # statistics of independent layers travel together: one exchange per level and direction
+        assert fwd_calls <= 4 and len(calls) - fwd_calls <= 4, calls
         refp, refb = dict(ref.named_parameters()), dict(ref.named_buffers())
         for name, buf in head.named_buffers():
             if not name.startswith("conv_mla") and "num_batches" not in name:
