@@ -156,6 +156,13 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
 
     const int NC = p.H / 64, NP = 4 * NC;  // hidden chunks, pieces per row tile
     const int tiles = (p.M + MLP_BM - 1) / MLP_BM, G = gridDim.x;
+#ifdef CCD_MLP_LAB      // lab build only: cycle totals of wave 0 per phase -> first 64 bytes per workgroup of ln_mean (destroyed)
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#define MLP_STAMP(i) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph[i] += tn_ - tprev; tprev = tn_; }
+#else
+#define MLP_STAMP(i)
+#endif
 
     // ---- DMA: a piece is 4*KT wave instructions of 1 KiB (8 image rows x 128 B).  Wave w moves the instructions whose
     // 8-row block index is w modulo 4, so ONE per-lane offset per weight matrix serves all of its instructions:
@@ -195,7 +202,9 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
     auto acquire = [&]() -> unsigned {
         glds_wait<(AHEAD - 1) * KT>();
         lds_barrier();
+        MLP_STAMP(1)                         // lab: wait for the DMA + barrier
         issue();
+        MLP_STAMP(2)                         // lab: DMA issue
         const unsigned sb = smem_addr + (unsigned)(slot_c * PIECE);
         slot_c = slot_c + 1 == MLP_NSLOT ? 0 : slot_c + 1;
         return sb;
@@ -343,8 +352,11 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
             };
             using I0 = std::integral_constant<int, 0>;
             using I1 = std::integral_constant<int, 1>;
+            MLP_STAMP(0)
             p1_piece(I0{}, 0, MlpNoExtra{}, [](auto) {});
+            MLP_STAMP(3)
             p1_piece(I1{}, 0, MlpNoExtra{}, [](auto) {});
+            MLP_STAMP(3)
 #pragma unroll 1
             for (int c = 0; c < NC; ++c) {
                 // GELU of the bf16-rounded pre-activation (what the backward pass will see) of chunk c, two elements at a
@@ -401,7 +413,9 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                         }
                     };
                     piece_with_gelu(I0{});
+                    MLP_STAMP(4)
                     piece_with_gelu(I1{});
+                    MLP_STAMP(4)
                 } else {
                     mlp_static_for<0, 4>([&](auto Gq) {
                         constexpr int gq = decltype(Gq)::value;
@@ -421,8 +435,11 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                     }
                     wave_lds_fence();
                 }
+                MLP_STAMP(5)
                 p2_piece(I0{});
+                MLP_STAMP(6)
                 p2_piece(I1{});
+                MLP_STAMP(6)
             }
         }
         // ---- epilogue: rows are complete inside their two lanes (lane, lane ^ 32).
@@ -505,8 +522,13 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
             }
             wave_lds_fence();
         }
+        MLP_STAMP(7)
     }
     glds_wait_all();                       // requested pieces that no tile consumed must not outlive the workgroup's LDS
+#ifdef CCD_MLP_LAB
+    if (t == 0)
+        for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(p.ln_mean)[blockIdx.x * 8 + i] = ph[i];
+#endif
 }
 
 }  // namespace ccd

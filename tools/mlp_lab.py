@@ -50,6 +50,17 @@ def main():
                                           beta=beta, eps=1e-6, store_u=store_u))
         rec("mlp_fused" + ("+u" if store_u else ""), ms, R * E * 12.0 + (2.0 * R * H if store_u else 0.0))
 
+    if os.environ.get("MLP_PHASES"):      # lab build (-DCCD_MLP_LAB via CCD_HIP_LIB): cycle totals of wave 0 per phase
+        names = ["tile prologue", "acquire wait+barrier", "dma issue", "P1 plain", "P1 + gelu", "gelu tail / u store", "P2", "epilogue"]
+        for store_u in (False, True):
+            out = ops.mlp_fused(y, w1, b1, w2, b2, resid=resid, rowscale=None, rows_per_sample=256, gamma=gamma, beta=beta,
+                                eps=1e-6, store_u=store_u)
+            torch.cuda.synchronize()
+            ph = out[2].view(torch.int64)[:256 * 8].view(256, 8).double()
+            tot = ph.sum(1).mean().item()
+            print(json.dumps({"kernel": "phases" + ("+u" if store_u else ""), "cycles_per_wg": round(tot),
+                              "share": {n: round(100 * ph[:, i].mean().item() / tot, 1) for i, n in enumerate(names)}}), flush=True)
+        return
     for lab in [int(x) for x in os.environ.get("MLP_LAB", "").split(",") if x]:
         with ops.policy(lab=lab):
             for store_u in (False, True):
