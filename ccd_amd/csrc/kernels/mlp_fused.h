@@ -170,12 +170,20 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
     //   W2 piece [E/2 output rows][128 B = 64 hidden units]: instruction i = rows 32 i + 8w .. + 7
     const int dr = lane >> 3, dp = lane & 7;
     const int drow = 8 * w + dr;
-    const unsigned lsrc1 = (unsigned)(drow * p.ld1 + ((dp ^ mlp_swz(drow)) * 8));
-    const unsigned lsrc2 = (unsigned)(drow * p.ld2 + ((dp ^ mlp_swz(drow)) * 8));
+    // per-lane byte offset of a request = drow2 * (row stride of the matrix) + swz16: one multiply-add where it is needed
+    // (two precomputed offsets selected by the piece type became a scratch array)
+    const unsigned drow2 = (unsigned)(2 * drow), swz16 = (unsigned)((dp ^ mlp_swz(drow)) * 16);
     int slot_i = 0, slot_c = 0, pos_i = 0; // ring slots of the next request / consumption, stream position of the next request
     // stream of a row tile (NP pieces): P1(0)a P1(0)b | P1(1)a P1(1)b P2(0)a P2(0)b | ... | P2(NC-1)a P2(NC-1)b
-    auto issue = [&]() {
-        char* sb = smem + slot_i * PIECE + w * 1024;
+    // A request is PREPARED once (scalar state: where the piece starts, its two strides, its ring slot) and its KT
+    // instructions are then issued one at a time between the MFMAs of the piece being consumed: an LDS-DMA instruction keeps
+    // the issuing wave busy for tens of cycles, and 6 of them back to back (with their address arithmetic) measured a quarter
+    // of the kernel.  Instruction i moves the 8 rows at  base + (i & 1) * step_a + (i >> 1) * step_b  to  slot + 4096 * i.
+    const char* req_base = nullptr;
+    long req_step_a = 0, req_step_b = 0;
+    unsigned req_lane = 0;
+    char* req_lds = nullptr;
+    auto issue_prepare = [&]() {
         int is_p2, chunk, half;
         if (pos_i < 2) { is_p2 = 0; chunk = 0; half = pos_i; }
         else {
@@ -183,34 +191,50 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
             if (grp < NC - 1) { is_p2 = r >> 1; chunk = is_p2 ? grp : grp + 1; half = r & 1; }
             else { is_p2 = 1; chunk = NC - 1; half = r; }
         }
-        if (!is_p2) {
-            const bf16_t* base = p.w1 + (long)(64 * chunk) * p.ld1 + half * (E / 2) + lsrc1;
-#pragma unroll
-            for (int i = 0; i < KT; ++i) glds16(base + (long)(32 * (i & 1)) * p.ld1 + 64 * (i >> 1), sb + 8192 * (i >> 1) + 4096 * (i & 1));
-        } else {
-            const bf16_t* base = p.w2 + (long)(half * (E / 2)) * p.ld2 + 64 * chunk + lsrc2;
-#pragma unroll
-            for (int i = 0; i < KT; ++i) glds16(base + (long)(32 * i) * p.ld2, sb + 4096 * i);
+        if (!is_p2) {      // rows 64 chunk + 32 (i & 1) + .., K half `half`, k-tile i >> 1
+            req_base = reinterpret_cast<const char*>(p.w1) + ((long)(64 * chunk) * p.ld1 + half * (E / 2)) * 2;
+            req_step_a = 64 * p.ld1;
+            req_step_b = 128;
+            req_lane = drow2 * (unsigned)p.ld1 + swz16;
+        } else {           // rows half * E/2 + 32 i + .., hidden units 64 chunk ..
+            req_base = reinterpret_cast<const char*>(p.w2) + ((long)(half * (E / 2)) * p.ld2 + 64 * chunk) * 2;
+            req_step_a = 64 * p.ld2;
+            req_step_b = 128 * p.ld2;
+            req_lane = drow2 * (unsigned)p.ld2 + swz16;
         }
+        req_lds = smem + slot_i * PIECE + w * 1024;
         slot_i = slot_i + 1 == MLP_NSLOT ? 0 : slot_i + 1;
         pos_i = pos_i + 1 == NP ? 0 : pos_i + 1;
     };
+    auto issue_one = [&](int i) {
+        glds16(req_base + ((i & 1) * req_step_a + (i >> 1) * req_step_b) + req_lane, req_lds + 4096 * i);
+    };
     // step of the ring: my quarter of the next piece has landed (three younger pieces stay in flight), everybody's has
-    // and everybody is done with the previous piece (barrier), whose slot is re-filled 4 pieces ahead.  Requests run past
-    // the last tile (the weights are the same for every tile; the surplus is drained at the end).
+    // and everybody is done with the previous piece (barrier), whose slot is re-filled 4 pieces ahead - by the instructions
+    // the caller spreads over its product (dma_slot below).  Requests run past the last tile (the weights are the same for
+    // every tile; the surplus is drained at the end).
     const unsigned smem_addr = lds_addr_of(smem);
     auto acquire = [&]() -> unsigned {
         glds_wait<(AHEAD - 1) * KT>();
         lds_barrier();
         MLP_STAMP(1)                         // lab: wait for the DMA + barrier
-        issue();
-        MLP_STAMP(2)                         // lab: DMA issue
+        issue_prepare();
+        MLP_STAMP(2)                         // lab: request bookkeeping
         const unsigned sb = smem_addr + (unsigned)(slot_c * PIECE);
         slot_c = slot_c + 1 == MLP_NSLOT ? 0 : slot_c + 1;
         return sb;
     };
+    // DMA instruction i of the prepared request goes out behind MFMA step 1 + i * (N / KT) of an N-step product
+    auto dma_slot = [&](auto K, auto NSTEPS) {
+        constexpr int k = decltype(K)::value, stride = decltype(NSTEPS)::value / KT;
+        if constexpr (k % stride == 1 && k / stride < KT) issue_one(k / stride);
+    };
 #pragma unroll
-    for (int j = 0; j < AHEAD; ++j) issue();
+    for (int j = 0; j < AHEAD; ++j) {
+        issue_prepare();
+#pragma unroll
+        for (int i = 0; i < KT; ++i) issue_one(i);
+    }
 
     // ---- fragment read offsets inside a piece (one register per k-step; tiles / k-tiles are immediate offsets)
     const int prow = (lq & 19) | ((lq & 4) << 1) | ((lq & 8) >> 1);      // bits 2 and 3 of the row index swapped
@@ -336,7 +360,10 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                         constexpr int k = decltype(K)::value;
                         h[k & 1] = mfma_32x32x16_bf16(a, yf[(KJ / 2) * kh + (k >> 1)], h[k & 1]);
                     },
-                    filler);
+                    [&](auto K) {
+                        dma_slot(K, std::integral_constant<int, KJ>{});
+                        filler(K);
+                    });
             };
             auto p2_piece = [&](auto HH) {                   // acc[half hh] += W2 piece . gelu(H)
                 constexpr int hh = decltype(HH)::value;
@@ -348,7 +375,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                         constexpr int k = decltype(K)::value;
                         acc[NTH * hh + k % NTH] = mfma_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, hbw[k / NTH]), acc[NTH * hh + k % NTH]);
                     },
-                    [](auto) {});
+                    [&](auto K) { dma_slot(K, std::integral_constant<int, 4 * NTH>{}); });
             };
             using I0 = std::integral_constant<int, 0>;
             using I1 = std::integral_constant<int, 1>;
