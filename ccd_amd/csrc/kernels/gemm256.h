@@ -132,8 +132,18 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
         else if (tiles_in_flight == 1) glds_wait<PER>();
         else glds_wait_all();
     };
+    // bias of the tile's columns: one value per thread, requested a whole tile ahead (right after `setup`) and parked in
+    // LDS at the start of the epilogue - read from global memory inside the staging loop, each 16-byte piece was a
+    // serialised L2 round trip behind `s_waitcnt vmcnt(0)` (which also drained the next tile's DMA)
+    constexpr bool BIAS_LDS = (EPI == EPI_BF16 || EPI == EPI_GELU);
+    float bias_r = 0.f;
+    auto load_bias = [&]() {
+        bias_r = 0.f;
+        if (BIAS_LDS && p.bias && t < BN && n0 + t < p.N) bias_r = p.bias[n0 + t];
+    };
     unsigned item = slot;
     setup(item);
+    load_bias();
     if (live) {
         dma(0, 0);
         if (DEEP) {
@@ -238,8 +248,14 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
         const bool elive = live, ewave_live = wave_live;
         const unsigned next = item + nx;
         const bool has_next = next < cnt_x;
+        float* bias_s = reinterpret_cast<float*>(smem + 2 * G256_OPERAND_BYTES + 45056);     // behind staging image + two tables
+        if (BIAS_LDS && elive) {
+            if (t < BN) bias_s[t] = bias_r;                  // (no DMA in flight here: the wait for bias_r drains nothing)
+            lds_barrier();
+        }
         if (has_next) {
             setup(next);
+            load_bias();
             if (live) {
                 dma(0, 0);
                 if (DEEP) {
@@ -323,8 +339,8 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                     const int nl = WCOLS * wn + 32 * j + 8 * g + 4 * hf;   // first of this lane's 4 columns
                     float v0 = acc[q][j][4 * g], v1 = acc[q][j][4 * g + 1], v2 = acc[q][j][4 * g + 2], v3 = acc[q][j][4 * g + 3];
                     if (STAGE_BF16) {
-                        if (EPI != EPI_DGELU && p.bias && en0 + nl < p.N) {
-                            const f32x4v b = *reinterpret_cast<const f32x4v*>(p.bias + en0 + nl);
+                        if (BIAS_LDS) {
+                            const f32x4v b = *reinterpret_cast<const f32x4v*>(bias_s + nl);
                             v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
                         }
                         char* dst = stg + srow * ROWB + (((nl >> 3) ^ (srow & 15)) * 16) + ((nl >> 2) & 1) * 8;

@@ -20,7 +20,8 @@ namespace ccd {
 constexpr int GR_BM = 128, GR_BN = 384, GR_BK = 64, GR_THREADS = 512;
 constexpr int GR_A_BYTES = GR_BM * GR_BK * 2, GR_B_BYTES = GR_BN * GR_BK * 2;   // 16 KiB + 48 KiB per stage
 constexpr int GR_STAGE_BYTES = GR_A_BYTES + GR_B_BYTES;                          // 64 KiB
-constexpr int GR_SMEM_BYTES = 2 * GR_STAGE_BYTES;                                // 128 KiB
+constexpr int GR_VEC_BYTES = 3 * GR_BN * 4;                                      // bias, LayerNorm gamma / beta (fp32)
+constexpr int GR_SMEM_BYTES = 2 * GR_STAGE_BYTES + GR_VEC_BYTES;                 // 128 KiB + 4.5 KiB
 
 template <int EPI>
 __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p) {
@@ -41,6 +42,17 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
     const unsigned cnt_x = q8 + (xcd < r8 ? 1u : 0u);
     if (slot >= cnt_x) return;
     const int nk_full = p.K / GR_BK;
+    // the per-column vectors of the epilogue live in LDS for the whole (persistent) kernel: fetched from global memory
+    // inside the row sweep, every one of them was a serialised L2 round trip behind `s_waitcnt vmcnt(0)`
+    float* vbias = reinterpret_cast<float*>(smem + 2 * GR_STAGE_BYTES);
+    float* vgamma = vbias + GR_BN;
+    float* vbeta = vgamma + GR_BN;
+    for (int i = t; i < GR_BN; i += GR_THREADS) {
+        vbias[i] = (p.bias && i < p.N) ? p.bias[i] : 0.f;
+        vgamma[i] = (EPI == EPI_RESID_LN && i < p.N) ? p.ln_gamma[i] : 0.f;
+        vbeta[i] = (EPI == EPI_RESID_LN && i < p.N) ? p.ln_beta[i] : 0.f;
+    }
+    __syncthreads();
 
     // staging pieces of this thread: A rows (t >> 3) + 64 i, B rows (t >> 3) + 64 i, 16-byte slot t & 7
     unsigned offa[2], offb[6];
@@ -203,8 +215,8 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
                                 float v0 = acc[q][j][4 * g], v1 = acc[q][j][4 * g + 1], v2 = acc[q][j][4 * g + 2],
                                       v3 = acc[q][j][4 * g + 3];
                                 if (STAGE_BF16) {
-                                    if (p.bias && nl < p.N) {
-                                        const f32x4v b = *reinterpret_cast<const f32x4v*>(p.bias + nl);
+                                    {
+                                        const f32x4v b = *reinterpret_cast<const f32x4v*>(vbias + nl);
                                         v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
                                     }
                                     u32x2 o;
@@ -245,8 +257,7 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
                                 if (row_ok && gnc < p.N) {
                                     const f32x4v v = *reinterpret_cast<const f32x4v*>(stg + s2 * ROWB + ((chunk ^ (s2 & 15)) * 16));
                                     const f32x4v r = rpre[step][c3];
-                                    f32x4v b = {0.f, 0.f, 0.f, 0.f};
-                                    if (p.bias) b = *reinterpret_cast<const f32x4v*>(p.bias + gnc);
+                                    const f32x4v b = *reinterpret_cast<const f32x4v*>(vbias + gnc);
                                     o[c3] = r + (v + b) * sc;
                                     *reinterpret_cast<f32x4v*>(reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gnc) = o[c3];
                                     s1 += (o[c3].x + o[c3].y) + (o[c3].z + o[c3].w);
@@ -263,8 +274,8 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
                             for (int c3 = 0; c3 < 3; ++c3) {
                                 const int gnc = 4 * (L + 32 * c3);
                                 if (row_ok && gnc < p.N) {
-                                    const f32x4v ga = *reinterpret_cast<const f32x4v*>(p.ln_gamma + gnc);
-                                    const f32x4v be = *reinterpret_cast<const f32x4v*>(p.ln_beta + gnc);
+                                    const f32x4v ga = *reinterpret_cast<const f32x4v*>(vgamma + gnc);
+                                    const f32x4v be = *reinterpret_cast<const f32x4v*>(vbeta + gnc);
                                     const f32x4v yv = (o[c3] - mean) * rstd * ga + be;
                                     u32x2 pk;
                                     pk.x = pack_bf2(yv.x, yv.y);
