@@ -137,6 +137,7 @@ static int ccd_launch_gemm_row384(const ccd::GemmParams& p, int epilogue, void* 
         case CCD_EPI_RESID: CCD_LAUNCH((ccd::gemm_row384_kernel<ccd::EPI_RESID>), grid, block, smem, stream, p); break;
         case CCD_EPI_F32: CCD_LAUNCH((ccd::gemm_row384_kernel<ccd::EPI_F32>), grid, block, smem, stream, p); break;
         case 7: CCD_LAUNCH((ccd::gemm_row384_kernel<ccd::EPI_RESID_LN>), grid, block, smem, stream, p); break;
+        case 8: CCD_LAUNCH((ccd::gemm_row384_kernel<ccd::EPI_LNBWD>), grid, block, smem, stream, p); break;
         default: return CCD_EINVAL;
     }
     return ccd_rt_last_error();
@@ -219,6 +220,28 @@ int ccd_gemm_nt_resid_ln(const ccd_bf16* A, long lda, const ccd_bf16* B, long ld
     for (int sft = 0; sft < 31; ++sft) if ((1 << sft) == rows_per_sample) p.rps_shift = sft;
     p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_eps = ln_eps; p.ln_y = y; p.ld_y = ldy; p.ln_mean = mean; p.ln_rstd = rstd;
     return ccd_launch_gemm_row384(p, 7 /* EPI_RESID_LN */, stream);
+}
+
+int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, const float* x, long ldx,
+                      const float* mean, const float* rstd, const float* gamma, float* g, long ldg, int accumulate,
+                      float* dgamma, float* dbeta, ccd_bf16* gb, long ldgb, const float* rowscale, int rows_per_sample,
+                      float* dbias, void* stream) {
+    CCD_CHECK(A && B && x && mean && rstd && gamma && g && dgamma && dbeta, CCD_EINVAL);
+    CCD_CHECK(CCD_ALIGNED16(A) && CCD_ALIGNED16(B) && CCD_ALIGNED16(x) && CCD_ALIGNED16(g) && CCD_ALIGNED16(gb), CCD_EINVAL);
+    if (M == 0) return CCD_OK;
+    CCD_CHECK(M > 0 && N > 0 && K > 0 && (!rowscale || rows_per_sample > 0), CCD_EINVAL);
+    CCD_CHECK(N <= ccd::GR_BN && N % 8 == 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldx % 4 == 0 && ldg % 4 == 0 &&
+              (!gb || ldgb % 4 == 0), CCD_ESHAPE);
+    CCD_CHECK(((long)M * lda + K) * 2 < CCD_MAX_OPERAND_BYTES && ((long)N * ldb + K) * 2 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
+    ccd::GemmParams p = ccd::GemmParams();
+    p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.C = g; p.ldc = ldg; p.resid = x; p.ldr = ldx;
+    p.rowscale = gb ? rowscale : nullptr; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; p.alpha = 1.0f;
+    p.rows_mul = 1; p.k_per_split = K;
+    p.rps_shift = -1;
+    for (int sft = 0; sft < 31; ++sft) if ((1 << sft) == p.rows_per_sample) p.rps_shift = sft;
+    p.ln_gamma = gamma; p.ln_mean = const_cast<float*>(mean); p.ln_rstd = const_cast<float*>(rstd);
+    p.lnb_accumulate = accumulate; p.lnb_gb = gb; p.ld_gb = ldgb; p.lnb_dgamma = dgamma; p.lnb_dbeta = dbeta; p.lnb_dbias = dbias;
+    return ccd_launch_gemm_row384(p, 8 /* EPI_LNBWD */, stream);
 }
 
 int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, const float* b1, const ccd_bf16* w2, long ld2,

@@ -22,7 +22,8 @@ enum GemmEpilogue {
     EPI_ATOMIC = 4,     // C(f32) += acc                       (split-K partial sums)
     EPI_DGELU = 5,      // C(bf16) = acc * gelu'(aux) ; optional C2(bf16) = gelu(aux)   (aux = saved pre-activation u, bf16)
     EPI_BF16_ADDF32 = 6, // C(bf16) = acc + bias ; C2(f32) += acc (unused hook kept for head experiments)
-    EPI_RESID_LN = 7     // EPI_RESID + LayerNorm of the finished rows (gemm_row384.h only)
+    EPI_RESID_LN = 7,    // EPI_RESID + LayerNorm of the finished rows (gemm_row384.h only)
+    EPI_LNBWD = 8        // the product IS dy of a LayerNorm: its backward (g (+)= dx, dgamma, dbeta, optional bf16 tail) in the epilogue
 };
 
 struct GemmParams {
@@ -65,6 +66,15 @@ struct GemmParams {
     float* ln_mean;
     float* ln_rstd;
     float ln_eps;
+    // ---- LayerNorm BACKWARD folded into the epilogue (EPI_LNBWD, gemm_row384.h): acc = dy; x = resid (ldr), statistics
+    // ln_mean / ln_rstd (inputs), ln_gamma; C = g (fp32, += dx when lnb_accumulate); optional tail gb = bf16(g_new *
+    // rowscale) with lnb_dbias += column sums of gb; lnb_dgamma / lnb_dbeta += column sums
+    int lnb_accumulate;
+    bf16_t* lnb_gb;
+    long ld_gb;
+    float* lnb_dgamma;
+    float* lnb_dbeta;
+    float* lnb_dbias;
     const int* d_rows;      // optional device-side row count: NT rows M / TN contraction length K become
     int rows_mul;           //   min(static value, d_rows[0] * rows_mul); the grid is sized for the static value
 };

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
     float* vbeta = vgamma + GR_BN;
     for (int i = t; i < GR_BN; i += GR_THREADS) {
         vbias[i] = (p.bias && i < p.N) ? p.bias[i] : 0.f;
-        vgamma[i] = (EPI == EPI_RESID_LN && i < p.N) ? p.ln_gamma[i] : 0.f;
+        vgamma[i] = ((EPI == EPI_RESID_LN || EPI == EPI_LNBWD) && i < p.N) ? p.ln_gamma[i] : 0.f;
         vbeta[i] = (EPI == EPI_RESID_LN && i < p.N) ? p.ln_beta[i] : 0.f;
     }
     __syncthreads();
@@ -124,6 +124,10 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
         }
     };
 
+    // EPI_LNBWD: per-lane column sums (this lane's 3 x 4 columns) over every row the workgroup finishes
+    f32x4v cs_dg[3], cs_db[3], cs_dbi[3];
+#pragma unroll
+    for (int c3 = 0; c3 < 3; ++c3) cs_dg[c3] = cs_db[c3] = cs_dbi[c3] = f32x4v{0.f, 0.f, 0.f, 0.f};
     unsigned item = slot;
     setup(item);
     load(0, ra0, rb0);
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
         const bool has_next = next < cnt_x;
         if (has_next) {                                      // next tile's first two k-tiles fly under the epilogue
             setup(next);
-            if (EPI != EPI_RESID_LN) {                       // (the fused-LayerNorm epilogue requests them itself, below)
+            if (EPI != EPI_RESID_LN && EPI != EPI_LNBWD) {   // (the row-wise epilogues request them themselves, below)
                 load(0, ra0, rb0);
                 load(1, ra1, rb1);
             }
@@ -193,6 +197,25 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
                     // the residual rows of this pass are requested before the staging writes and the barrier, so their
                     // latency is not paid serially inside the row sweep
                     f32x4v rpre[2][3];
+                    f32x4v gpre[2][3];                       // EPI_LNBWD: the rows of g that dx is added to
+                    float mu_pre[2] = {0.f, 0.f}, rs_pre[2] = {0.f, 0.f};
+                    if (EPI == EPI_LNBWD) {
+#pragma unroll
+                        for (int step = 0; step < 2; ++step) {
+                            const int gm = em0 + 64 * h + 32 * q + 16 * step + 2 * w + hf;
+                            if (gm < p.M) { mu_pre[step] = p.ln_mean[gm]; rs_pre[step] = p.ln_rstd[gm]; }
+#pragma unroll
+                            for (int c3 = 0; c3 < 3; ++c3) {
+                                const int gnc = 4 * ((lane & 31) + 32 * c3);
+                                rpre[step][c3] = gpre[step][c3] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                                if (gm < p.M && gnc < p.N) {
+                                    rpre[step][c3] = *reinterpret_cast<const f32x4v*>(p.resid + (long)gm * p.ldr + gnc);
+                                    if (p.lnb_accumulate)
+                                        gpre[step][c3] = *reinterpret_cast<const f32x4v*>(reinterpret_cast<const float*>(p.C) + (long)gm * p.ldc + gnc);
+                                }
+                            }
+                        }
+                    }
                     if (EPI == EPI_RESID_LN) {
 #pragma unroll
                         for (int step = 0; step < 2; ++step) {
@@ -232,10 +255,64 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
                     }
                     constexpr bool fuse_ln = EPI == EPI_RESID_LN;
                     lds_barrier();
-                    if (fuse_ln && q == 1 && h == 1 && has_next) {       // every accumulator has been staged
+                    if ((fuse_ln || EPI == EPI_LNBWD) && q == 1 && h == 1 && has_next) {       // every accumulator has been staged
                         load(0, ra0, rb0);
                         prefetched = true;
                     }
+                    if (EPI == EPI_LNBWD) {
+                        // LayerNorm backward of the finished rows (layernorm.h: ln_bwd_kernel, same arithmetic): half a wave
+                        // owns one row, the two row means by shuffles, column sums kept per lane until the kernel ends
+                        const int L = lane & 31;
+                        const float inv_n = 1.0f / (float)p.N;
+#pragma unroll
+                        for (int step = 0; step < 2; ++step) {
+                            const int s2 = 16 * step + 2 * w + hf;
+                            const int gm = em0 + 64 * h + 32 * q + s2;
+                            const bool row_ok = gm < p.M;
+                            const float mu = mu_pre[step], rs = rs_pre[step];
+                            f32x4v xh[3], d[3];
+                            float s1 = 0.f, sq = 0.f;
+#pragma unroll
+                            for (int c3 = 0; c3 < 3; ++c3) {
+                                const int chunk = L + 32 * c3, gnc = 4 * chunk;
+                                xh[c3] = d[c3] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                                if (row_ok && gnc < p.N) {
+                                    const f32x4v dyv = *reinterpret_cast<const f32x4v*>(stg + s2 * ROWB + ((chunk ^ (s2 & 15)) * 16));
+                                    const f32x4v ga = *reinterpret_cast<const f32x4v*>(vgamma + gnc);
+                                    xh[c3] = (rpre[step][c3] - mu) * rs;
+                                    d[c3] = dyv * ga;
+                                    cs_dg[c3] += dyv * xh[c3];
+                                    cs_db[c3] += dyv;
+                                    s1 += (d[c3].x + d[c3].y) + (d[c3].z + d[c3].w);
+                                    const f32x4v e = d[c3] * xh[c3];
+                                    sq += (e.x + e.y) + (e.z + e.w);
+                                }
+                            }
+#pragma unroll
+                            for (int msk = 16; msk >= 1; msk >>= 1) { s1 += shfl_xor(s1, msk); sq += shfl_xor(sq, msk); }
+                            s1 *= inv_n;
+                            sq *= inv_n;
+                            const float sc = (row_ok && p.lnb_gb && p.rowscale)
+                                                 ? p.rowscale[p.rps_shift >= 0 ? gm >> p.rps_shift : gm / p.rows_per_sample] : 1.0f;
+#pragma unroll
+                            for (int c3 = 0; c3 < 3; ++c3) {
+                                const int gnc = 4 * (L + 32 * c3);
+                                if (row_ok && gnc < p.N) {
+                                    const f32x4v dx = (d[c3] - s1 - xh[c3] * sq) * rs + gpre[step][c3];
+                                    *reinterpret_cast<f32x4v*>(reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gnc) = dx;
+                                    if (p.lnb_gb) {
+                                        const f32x4v o = dx * sc;
+                                        u32x2 pk;
+                                        pk.x = pack_bf2(o.x, o.y);
+                                        pk.y = pack_bf2(o.z, o.w);
+                                        *reinterpret_cast<u32x2*>(p.lnb_gb + (long)gm * p.ld_gb + gnc) = pk;
+                                        // sum what the GEMMs will actually read (the bf16-rounded values)
+                                        cs_dbi[c3] += f32x4v{bf_lo(pk.x), bf_hi(pk.x), bf_lo(pk.y), bf_hi(pk.y)};
+                                    }
+                                }
+                            }
+                        }
+                    } else
                     if (fuse_ln) {
                         // residual epilogue + LayerNorm of the finished rows.  Half a wave owns one row (32 lanes x three
                         // 16-byte chunks = 384 columns): the row sums are five shuffles, no LDS traffic, one sweep.
@@ -330,11 +407,37 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
             }
         }
         if (!has_next) break;
-        if (EPI == EPI_RESID_LN) {
+        if (EPI == EPI_RESID_LN || EPI == EPI_LNBWD) {
             if (!prefetched) load(0, ra0, rb0);              // tile without work: nothing was requested in its epilogue
             load(1, ra1, rb1);
         }
         item = next;
+    }
+    if (EPI == EPI_LNBWD) {
+        // column sums: 16 half-waves hold partial sums of the same 384 columns -> LDS -> one atomic per column and sum
+        float* red = reinterpret_cast<float*>(smem);                  // [3][16][GR_BN] fp32 = 72 KiB of the idle stages
+        const int L = lane & 31, hw = 2 * w + hf;
+        lds_barrier();
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) {
+            const int gnc = 4 * (L + 32 * c3);
+            *reinterpret_cast<f32x4v*>(red + (0 * 16 + hw) * GR_BN + gnc) = cs_dg[c3];
+            *reinterpret_cast<f32x4v*>(red + (1 * 16 + hw) * GR_BN + gnc) = cs_db[c3];
+            *reinterpret_cast<f32x4v*>(red + (2 * 16 + hw) * GR_BN + gnc) = cs_dbi[c3];
+        }
+        lds_barrier();
+        for (int c = t; c < p.N; c += GR_THREADS) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                a0 += red[(0 * 16 + r) * GR_BN + c];
+                a1 += red[(1 * 16 + r) * GR_BN + c];
+                a2 += red[(2 * 16 + r) * GR_BN + c];
+            }
+            atomicAdd(p.lnb_dgamma + c, a0);
+            atomicAdd(p.lnb_dbeta + c, a1);
+            if (p.lnb_gb && p.lnb_dbias) atomicAdd(p.lnb_dbias + c, a2);
+        }
     }
 }
 

@@ -237,6 +237,8 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
     def mlp_tail(i):            # what the MLP branch of block i wants from the writer in front of it
         return dict(gb=gb, rowscale=ctxs[i].ds2, rows_per_sample=256, dbias=arena.g(f"{pre}blocks.{i}.mlp.fc2.bias"))
 
+    # LayerNorm backward folded into the epilogue of the data-gradient product in front of it (ccd_gemm_nt_lnbwd, N <= 384)
+    fuse_lnbwd = E <= 384 and E % 8 == 0 and os.environ.get("CCD_FUSE_LNBWD", "1") != "0"
     side = _SideStream(dev)
     gb_reader = None            # event of the last side-stream product that reads gb (the next writer of gb waits for it)
     have_gb = False
@@ -273,12 +275,17 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
             du = ops.gemm_nt(gb, arena.wbt(b + "mlp.fc2.weight"), epilogue=ops.EPI_DGELU, aux=c.u,
                              colsum=arena.g(b + "mlp.fc1.bias"))
         side.run(lambda du=du: ops.gemm_tn(du, y2, arena.g(b + "mlp.fc1.weight")), du, y2)
-        dy2 = ops.gemm_nt(du, arena.wbt(b + "mlp.fc1.weight"))
-        del du
         side.wait(gb_reader)                                 # norm2's backward rewrites gb
-        ops.ln_bwd(dy2, c.x_mid, c.mean2, c.rstd2, arena.w(b + "norm2.weight"), g, arena.g(b + "norm2.weight"),
-                   arena.g(b + "norm2.bias"), accumulate=True, gb=gb, rowscale=c.ds1, rows_per_sample=256,
-                   dbias=arena.g(b + "attn.proj.bias"))
+        if fuse_lnbwd:           # dy2 = du . W1 never leaves the chip: LayerNorm-2's backward is the product's epilogue
+            ops.gemm_nt_lnbwd(du, arena.wbt(b + "mlp.fc1.weight"), c.x_mid, c.mean2, c.rstd2, arena.w(b + "norm2.weight"), g,
+                              arena.g(b + "norm2.weight"), arena.g(b + "norm2.bias"), accumulate=True, gb=gb, rowscale=c.ds1,
+                              rows_per_sample=256, dbias=arena.g(b + "attn.proj.bias"))
+        else:
+            dy2 = ops.gemm_nt(du, arena.wbt(b + "mlp.fc1.weight"))
+            ops.ln_bwd(dy2, c.x_mid, c.mean2, c.rstd2, arena.w(b + "norm2.weight"), g, arena.g(b + "norm2.weight"),
+                       arena.g(b + "norm2.bias"), accumulate=True, gb=gb, rowscale=c.ds1, rows_per_sample=256,
+                       dbias=arena.g(b + "attn.proj.bias"))
+        del du
         # ---- attention branch: x_mid = x_in + ds1 * proj(attn(qkv(LN1(x_in))))
         gb_reader = side.run(lambda: ops.gemm_tn(gb, att.view(R, E), arena.g(b + "attn.proj.weight")), gb, att)
         d_att = ops.gemm_nt(gb, arena.wbt(b + "attn.proj.weight"))
@@ -289,12 +296,16 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
             ops.gemm_tn(d_qkv, y1, arena.g(b + "attn.qkv.weight"))
             ops.colsum_bf16(d_qkv, arena.g(b + "attn.qkv.bias"))
         side.run(qkv_grads, d_qkv, y1)
-        dy1 = ops.gemm_nt(d_qkv, arena.wbt(b + "attn.qkv.weight"))
         tail = mlp_tail(i - 1) if (i > 0 and (i - 1) not in tap_at) else {}
         if tail:
             side.wait(gb_reader)                             # this LayerNorm backward rewrites gb for the next block
-        ops.ln_bwd(dy1, c.x_in, c.mean1, c.rstd1, arena.w(b + "norm1.weight"), g, arena.g(b + "norm1.weight"),
-                   arena.g(b + "norm1.bias"), accumulate=True, **tail)
+        if fuse_lnbwd:
+            ops.gemm_nt_lnbwd(d_qkv, arena.wbt(b + "attn.qkv.weight"), c.x_in, c.mean1, c.rstd1, arena.w(b + "norm1.weight"), g,
+                              arena.g(b + "norm1.weight"), arena.g(b + "norm1.bias"), accumulate=True, **tail)
+        else:
+            dy1 = ops.gemm_nt(d_qkv, arena.wbt(b + "attn.qkv.weight"))
+            ops.ln_bwd(dy1, c.x_in, c.mean1, c.rstd1, arena.w(b + "norm1.weight"), g, arena.g(b + "norm1.weight"),
+                       arena.g(b + "norm1.bias"), accumulate=True, **tail)
         have_gb = bool(tail)
         ctxs[i] = None
         if on_block_done is not None:

@@ -139,6 +139,27 @@ def gemm_nt_resid_ln(a, b, *, bias, resid, rowscale, rows_per_sample, gamma, bet
     return out, y, mean, rstd
 
 
+def gemm_nt_lnbwd(a, b, x, mean, rstd, gamma, g, dgamma, dbeta, accumulate=True, gb=None, rowscale=None, rows_per_sample=1,
+                  dbias=None):
+    """dy = a @ b^T is the gradient of a LayerNorm output: g (+)= LN'(dy) with dgamma / dbeta (+ the bf16 tail of ln_bwd) in
+    the epilogue of the product - dy never reaches HBM (ccd_gemm_nt + ccd_ln_bwd in one launch; N <= 384)."""
+    _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(x, F32, "x"); _chk(g, F32, "g"); _chk(gb, BF16, "gb")
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and tuple(x.shape) == (M, N) and tuple(g.shape) == (M, N) and N <= 384
+    span = TIMER.span("gemm_nt_lnbwd", 2.0 * M * N * K, 2.0 * (M * K + N * K) + M * N * (12.0 if accumulate else 8.0)
+                      + (2.0 * M * N if gb is not None else 0.0)) if TIMER is not None else None
+    if span:
+        span[0].record()
+    _call("ccd_gemm_nt_lnbwd", _lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0), M, N, K, _lib.ptr(x), x.stride(0),
+          _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(g), g.stride(0), 1 if accumulate else 0, _lib.ptr(dgamma),
+          _lib.ptr(dbeta), _lib.ptr(gb), 0 if gb is None else gb.stride(0), _lib.ptr(rowscale), int(rows_per_sample),
+          _lib.ptr(dbias))
+    if span:
+        span[1].record()
+    return g
+
+
 def mlp_fused(y, w1, b1, w2, b2, *, resid, rowscale, rows_per_sample, gamma, beta, eps, store_u=False, out=None):
     """out (fp32) = resid + (gelu(y @ w1^T + b1) @ w2^T + b2) * rowscale[row // rows_per_sample];
     y_next = LayerNorm(out) * gamma + beta  ->  (out, y_next bf16, mean, rstd, u bf16 | None).

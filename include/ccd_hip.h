@@ -63,6 +63,16 @@ int ccd_gemm_nt_resid_ln(const ccd_bf16* A, long lda, const ccd_bf16* B, long ld
                          const float* bias, const float* resid, long ldr, const float* rowscale, int rows_per_sample,
                          const float* ln_gamma, const float* ln_beta, float ln_eps, ccd_bf16* y, long ldy, float* mean,
                          float* rstd, void* stream);
+/* A data-gradient product whose result IS the gradient of a LayerNorm output, with that LayerNorm's backward pass in the
+ * epilogue (autograd of nn.LayerNorm(eps=1e-6) in Block.forward, vision_transformer.py:99,103,107-113):
+ *   dy = A . B^T  (never written);  xhat = (x - mean) * rstd;  dx = rstd * (dy*gamma - mean_row(dy*gamma) - xhat * mean_row(dy*gamma*xhat))
+ *   g (f32) = (accumulate ? g : 0) + dx;  dgamma += colsum(dy * xhat);  dbeta += colsum(dy)
+ *   optional tail: gb (bf16) = g_new * rowscale[row / rows_per_sample], dbias += colsum(gb)
+ * N <= 384, N % 8 == 0, K % 64 == 0.  Replaces ccd_gemm_nt(EPI_BF16) + ccd_ln_bwd. */
+int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, const float* x, long ldx,
+                      const float* mean, const float* rstd, const float* gamma, float* g, long ldg, int accumulate,
+                      float* dgamma, float* dbeta, ccd_bf16* gb, long ldgb, const float* rowscale, int rows_per_sample,
+                      float* dbias, void* stream);
 /* The whole MLP branch of a transformer block in one launch (Mlp.forward + the residual of Block.forward,
  * Dino/modules/vision_transformer.py:59-65,107-113, and the LayerNorm that consumes the stream next, :99/:156):
  *   h = gelu(bf16(y . W1^T + b1)) ;  out (f32) = resid + (h . W2^T + b2) * rowscale[row / rows_per_sample]

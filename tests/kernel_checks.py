@@ -748,6 +748,41 @@ def check_mlp_fused(dev, M, E, H, rps=128, seed=31, store_u=True):
             assert torch.equal(out[lo:hi].cpu(), resid[lo:hi]), "dropped sample: the stream must pass through unchanged"
 
 
+def check_gemm_lnbwd(dev, M, N, K, seed=33):
+    """Data-gradient product with the LayerNorm backward in its epilogue == gemm_nt followed by ln_bwd, and both == autograd."""
+    g = torch.Generator().manual_seed(seed)
+    a = rnd((M, K), g).to(BF); b = rnd((N, K), g, 0.2).to(BF)
+    x = rnd((M, N), g) * 2 + 0.3
+    gamma = 1 + 0.1 * rnd((N,), g)
+    mean, var = x.mean(1), x.var(1, unbiased=False)
+    rstd = (var + 1e-6).rsqrt()
+    g0 = rnd((M, N), g)
+    rps = 16
+    rowscale = (torch.rand((M + rps - 1) // rps, generator=g) > 0.3).float() * 1.25
+    dy = a.float() @ b.float().t()
+    xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = torch.zeros(N, requires_grad=True)
+    F.layer_norm(xr, (N,), gr, br, 1e-6).backward(dy)
+    scale_dy = float(dy.pow(2).mean().sqrt())
+    for acc in (True, False):
+        for tail in (True, False):
+            gbuf = g0.clone().to(dev)
+            dgam = torch.full((N,), 0.5).to(dev); dbet = torch.full((N,), -0.25).to(dev)
+            gb = torch.zeros(M, N, dtype=BF).to(dev) if tail else None
+            dbias = torch.full((N,), 0.25).to(dev)
+            ops.gemm_nt_lnbwd(a.to(dev), b.to(dev), x.to(dev), mean.to(dev), rstd.to(dev), gamma.to(dev), gbuf, dgam, dbet,
+                              accumulate=acc, gb=gb, rowscale=rowscale.to(dev) if tail else None, rows_per_sample=rps,
+                              dbias=dbias if tail else None)
+            want_g = xr.grad + (g0 if acc else 0)
+            tag = f"lnbwd acc={acc} tail={tail}"
+            close(gbuf, want_g, 2e-3, 2e-3 * scale_dy, tag + "/g")
+            close(dgam, gr.grad + 0.5, 2e-3, 2e-3 * scale_dy * M ** 0.5, tag + "/dgamma")
+            close(dbet, br.grad - 0.25, 2e-3, 2e-3 * scale_dy * M ** 0.5, tag + "/dbeta")
+            if tail:
+                want_gb = (want_g * rowscale.repeat_interleave(rps)[:M, None])
+                close(gb, want_gb, 1e-2, 1e-2 * scale_dy, tag + "/gb")
+                close(dbias, want_gb.to(BF).float().sum(0) + 0.25, 5e-3, 2e-2 * scale_dy * M ** 0.5, tag + "/dbias")
+
+
 # ------------------------------------------------------------------------------------------------ finetune path
 def drop_keep_ref(seed, n, p):
     """Python mirror of decoder.h: drop_keep (splitmix64 finaliser on seed + index)."""

@@ -143,6 +143,11 @@ def test_gemm_row384(hip, M, N, K):
         kc.check_gemm_dynamic_rows(hip.device, M=max(M, 600), N=N, K=K, live=75)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 384, 128), (4096, 384, 1536), (40000, 384, 1152), (2048, 192, 768)])
+def test_gemm_lnbwd(hip, M, N, K):
+    kc.check_gemm_lnbwd(hip.device, M=M, N=N, K=K)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 384, 128), (4096, 384, 1536), (2048, 192, 768)])
 def test_gemm_resid_ln(hip, M, N, K):
     kc.check_gemm_resid_ln(hip.device, M=M, N=N, K=K)

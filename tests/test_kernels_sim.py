@@ -138,6 +138,11 @@ def test_policy_table_sim(sim):
         ops.policy_set("no_such_key", 1)
 
 
+def test_gemm_lnbwd_sim(sim):
+    kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=128)
+    kc.check_gemm_lnbwd(sim.device, M=140, N=192, K=64)
+
+
 def test_gemm_resid_ln_sim(sim):
     kc.check_gemm_resid_ln(sim.device, M=300, N=384, K=128)
     kc.check_gemm_resid_ln(sim.device, M=140, N=192, K=64)
