@@ -21,7 +21,7 @@ constexpr int GR_BM = 128, GR_BN = 384, GR_BK = 64, GR_THREADS = 512;
 constexpr int GR_A_BYTES = GR_BM * GR_BK * 2, GR_B_BYTES = GR_BN * GR_BK * 2;   // 16 KiB + 48 KiB per stage
 constexpr int GR_STAGE_BYTES = GR_A_BYTES + GR_B_BYTES;                          // 64 KiB
 constexpr int GR_VEC_BYTES = 3 * GR_BN * 4;                                      // bias, LayerNorm gamma / beta (fp32)
-constexpr int GR_SMEM_BYTES = 2 * GR_STAGE_BYTES + GR_VEC_BYTES;                 // 128 KiB + 4.5 KiB
+constexpr int GR_SMEM_BYTES = 2 * GR_STAGE_BYTES + 2 * GR_VEC_BYTES;             // 128 KiB + vectors + EPI_LNBWD column sums
 
 template <int EPI>
 __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p) {
@@ -47,6 +47,8 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
     float* vbias = reinterpret_cast<float*>(smem + 2 * GR_STAGE_BYTES);
     float* vgamma = vbias + GR_BN;
     float* vbeta = vgamma + GR_BN;
+    float* csum = vbeta + GR_BN;                          // EPI_LNBWD: [3][GR_BN] column sums of the whole workgroup
+    for (int i = t; i < 3 * GR_BN; i += GR_THREADS) csum[i] = 0.f;
     for (int i = t; i < GR_BN; i += GR_THREADS) {
         vbias[i] = (p.bias && i < p.N) ? p.bias[i] : 0.f;
         vgamma[i] = ((EPI == EPI_RESID_LN || EPI == EPI_LNBWD) && i < p.N) ? p.ln_gamma[i] : 0.f;
@@ -124,10 +126,6 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
         }
     };
 
-    // EPI_LNBWD: per-lane column sums (this lane's 3 x 4 columns) over every row the workgroup finishes
-    f32x4v cs_dg[3], cs_db[3], cs_dbi[3];
-#pragma unroll
-    for (int c3 = 0; c3 < 3; ++c3) cs_dg[c3] = cs_db[c3] = cs_dbi[c3] = f32x4v{0.f, 0.f, 0.f, 0.f};
     unsigned item = slot;
     setup(item);
     load(0, ra0, rb0);
@@ -181,6 +179,11 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[i][j][r] *= p.alpha;
             }
+            // EPI_LNBWD: per-lane column sums (this lane's 3 x 4 columns) of this tile's rows; added to the workgroup's LDS
+            // sums when the tile is done (live across the main loop they pushed the kernel over its 256 registers)
+            f32x4v cs_dg[3], cs_db[3], cs_dbi[3];
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) cs_dg[c3] = cs_db[c3] = cs_dbi[c3] = f32x4v{0.f, 0.f, 0.f, 0.f};
             const bool want_stats = EPI == EPI_BF16 && p.colsum != nullptr;
             float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const int ct = t % CT, rr = t / CT;
@@ -255,7 +258,8 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
                     }
                     constexpr bool fuse_ln = EPI == EPI_RESID_LN;
                     lds_barrier();
-                    if ((fuse_ln || EPI == EPI_LNBWD) && q == 1 && h == 1 && has_next) {       // every accumulator has been staged
+                    // (EPI_LNBWD requests nothing here: its row sweep needs the registers the next tile's k-tiles would occupy)
+                    if (fuse_ln && q == 1 && h == 1 && has_next) {       // every accumulator has been staged
                         load(0, ra0, rb0);
                         prefetched = true;
                     }
@@ -270,21 +274,21 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
                             const int gm = em0 + 64 * h + 32 * q + s2;
                             const bool row_ok = gm < p.M;
                             const float mu = mu_pre[step], rs = rs_pre[step];
-                            f32x4v xh[3], d[3];
+                            f32x4v d[3];                 // (xhat is recomputed in the second sweep: 12 registers matter here)
                             float s1 = 0.f, sq = 0.f;
 #pragma unroll
                             for (int c3 = 0; c3 < 3; ++c3) {
                                 const int chunk = L + 32 * c3, gnc = 4 * chunk;
-                                xh[c3] = d[c3] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                                d[c3] = f32x4v{0.f, 0.f, 0.f, 0.f};
                                 if (row_ok && gnc < p.N) {
                                     const f32x4v dyv = *reinterpret_cast<const f32x4v*>(stg + s2 * ROWB + ((chunk ^ (s2 & 15)) * 16));
                                     const f32x4v ga = *reinterpret_cast<const f32x4v*>(vgamma + gnc);
-                                    xh[c3] = (rpre[step][c3] - mu) * rs;
+                                    const f32x4v xh = (rpre[step][c3] - mu) * rs;
                                     d[c3] = dyv * ga;
-                                    cs_dg[c3] += dyv * xh[c3];
+                                    cs_dg[c3] += dyv * xh;
                                     cs_db[c3] += dyv;
                                     s1 += (d[c3].x + d[c3].y) + (d[c3].z + d[c3].w);
-                                    const f32x4v e = d[c3] * xh[c3];
+                                    const f32x4v e = d[c3] * xh;
                                     sq += (e.x + e.y) + (e.z + e.w);
                                 }
                             }
@@ -298,7 +302,8 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
                             for (int c3 = 0; c3 < 3; ++c3) {
                                 const int gnc = 4 * (L + 32 * c3);
                                 if (row_ok && gnc < p.N) {
-                                    const f32x4v dx = (d[c3] - s1 - xh[c3] * sq) * rs + gpre[step][c3];
+                                    const f32x4v xh = (rpre[step][c3] - mu) * rs;
+                                    const f32x4v dx = (d[c3] - s1 - xh * sq) * rs + gpre[step][c3];
                                     *reinterpret_cast<f32x4v*>(reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gnc) = dx;
                                     if (p.lnb_gb) {
                                         const f32x4v o = dx * sc;
@@ -390,6 +395,19 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
                     lds_barrier();
                 }
             }
+            if (EPI == EPI_LNBWD) {
+                const int L = lane & 31;
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) {
+                    const int gnc = 4 * (L + 32 * c3);
+                    if (gnc < p.N) {
+                        const float a[12] = {cs_dg[c3].x, cs_dg[c3].y, cs_dg[c3].z, cs_dg[c3].w, cs_db[c3].x, cs_db[c3].y,
+                                             cs_db[c3].z, cs_db[c3].w, cs_dbi[c3].x, cs_dbi[c3].y, cs_dbi[c3].z, cs_dbi[c3].w};
+#pragma unroll
+                        for (int e = 0; e < 12; ++e) atomicAdd(csum + (e >> 2) * GR_BN + gnc + (e & 3), a[e]);     // ds_add_f32
+                    }
+                }
+            }
             if (want_stats) {
                 float* red = reinterpret_cast<float*>(stg);
                 if (rr < RSTEP) {
@@ -414,29 +432,11 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
         item = next;
     }
     if (EPI == EPI_LNBWD) {
-        // column sums: 16 half-waves hold partial sums of the same 384 columns -> LDS -> one atomic per column and sum
-        float* red = reinterpret_cast<float*>(smem);                  // [3][16][GR_BN] fp32 = 72 KiB of the idle stages
-        const int L = lane & 31, hw = 2 * w + hf;
-        lds_barrier();
-#pragma unroll
-        for (int c3 = 0; c3 < 3; ++c3) {
-            const int gnc = 4 * (L + 32 * c3);
-            *reinterpret_cast<f32x4v*>(red + (0 * 16 + hw) * GR_BN + gnc) = cs_dg[c3];
-            *reinterpret_cast<f32x4v*>(red + (1 * 16 + hw) * GR_BN + gnc) = cs_db[c3];
-            *reinterpret_cast<f32x4v*>(red + (2 * 16 + hw) * GR_BN + gnc) = cs_dbi[c3];
-        }
-        lds_barrier();
+        lds_barrier();                                       // every wave's LDS additions are in
         for (int c = t; c < p.N; c += GR_THREADS) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                a0 += red[(0 * 16 + r) * GR_BN + c];
-                a1 += red[(1 * 16 + r) * GR_BN + c];
-                a2 += red[(2 * 16 + r) * GR_BN + c];
-            }
-            atomicAdd(p.lnb_dgamma + c, a0);
-            atomicAdd(p.lnb_dbeta + c, a1);
-            if (p.lnb_gb && p.lnb_dbias) atomicAdd(p.lnb_dbias + c, a2);
+            atomicAdd(p.lnb_dgamma + c, csum[c]);
+            atomicAdd(p.lnb_dbeta + c, csum[GR_BN + c]);
+            if (p.lnb_gb && p.lnb_dbias) atomicAdd(p.lnb_dbias + c, csum[2 * GR_BN + c]);
         }
     }
 }
