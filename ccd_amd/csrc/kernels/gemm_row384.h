@@ -47,8 +47,8 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
     float* vbias = reinterpret_cast<float*>(smem + 2 * GR_STAGE_BYTES);
     float* vgamma = vbias + GR_BN;
     float* vbeta = vgamma + GR_BN;
-    float* csum = vbeta + GR_BN;                          // EPI_LNBWD: [3][GR_BN] column sums of the whole workgroup
-    for (int i = t; i < 3 * GR_BN; i += GR_THREADS) csum[i] = 0.f;
+    float* lds_colsum = vbeta + GR_BN;                    // EPI_LNBWD: [3][GR_BN] column sums of the whole workgroup
+    for (int i = t; i < 3 * GR_BN; i += GR_THREADS) lds_colsum[i] = 0.f;
     for (int i = t; i < GR_BN; i += GR_THREADS) {
         vbias[i] = (p.bias && i < p.N) ? p.bias[i] : 0.f;
         vgamma[i] = ((EPI == EPI_RESID_LN || EPI == EPI_LNBWD) && i < p.N) ? p.ln_gamma[i] : 0.f;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
                         const float a[12] = {cs_dg[c3].x, cs_dg[c3].y, cs_dg[c3].z, cs_dg[c3].w, cs_db[c3].x, cs_db[c3].y,
                                              cs_db[c3].z, cs_db[c3].w, cs_dbi[c3].x, cs_dbi[c3].y, cs_dbi[c3].z, cs_dbi[c3].w};
 #pragma unroll
-                        for (int e = 0; e < 12; ++e) atomicAdd(csum + (e >> 2) * GR_BN + gnc + (e & 3), a[e]);     // ds_add_f32
+                        for (int e = 0; e < 12; ++e) atomicAdd(lds_colsum + (e >> 2) * GR_BN + gnc + (e & 3), a[e]);     // ds_add_f32
                     }
                 }
             }
@@ -434,9 +434,9 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
     if (EPI == EPI_LNBWD) {
         lds_barrier();                                       // every wave's LDS additions are in
         for (int c = t; c < p.N; c += GR_THREADS) {
-            atomicAdd(p.lnb_dgamma + c, csum[c]);
-            atomicAdd(p.lnb_dbeta + c, csum[GR_BN + c]);
-            if (p.lnb_gb && p.lnb_dbias) atomicAdd(p.lnb_dbias + c, csum[2 * GR_BN + c]);
+            atomicAdd(p.lnb_dgamma + c, lds_colsum[c]);
+            atomicAdd(p.lnb_dbeta + c, lds_colsum[GR_BN + c]);
+            if (p.lnb_gb && p.lnb_dbias) atomicAdd(p.lnb_dbias + c, lds_colsum[2 * GR_BN + c]);
         }
     }
 }
