@@ -9,6 +9,7 @@
 #include "kernels/gemm256.h"
 #include "kernels/gemm_row384.h"
 #include "kernels/mlp_fused.h"
+#include "kernels/rowgemm.h"
 #include "kernels/layernorm.h"
 #include "kernels/attention_fwd.h"
 #include "kernels/attention_bwd.h"
@@ -79,6 +80,7 @@ struct CcdPolicy {
     int gemm_256_f32 = 0;       // 256-row kernels also for the fp32 / residual epilogues
     int gemm_256_deep = 0;      // BK = 32 x 4 buffers (three k-steps of DMA in flight) instead of BK = 64 x 2
     int gemm_row384 = 0;        // 1 = full-row kernel for N <= 384 residual / fp32 epilogues, 2 = bf16 too
+    int rowgemm = 1;            // row-owner kernels (rowgemm.h) for the N in {128, 256, 384} row-wise epilogues; 0 = gemm_row384.h
     int ln_bwd_bpc = 5;         // LayerNorm backward: blocks per CU (one resident wave; more blocks = more dgamma/dbeta atomics)
     int dec_attn_simt = 0;      // decoder attention: force the general SIMT kernels
     int cu_reserve = 0;         // compute units the persistent grids leave free (set while an RCCL gradient reducer is attached)
@@ -89,7 +91,7 @@ static const CcdPolicyKey ccd_policy_keys[] = {
     {"gemm_256", &CcdPolicy::gemm_256}, {"gemm_256_min_m", &CcdPolicy::gemm_256_min_m},
     {"gemm_256_min_n", &CcdPolicy::gemm_256_min_n}, {"gemm_256_f32", &CcdPolicy::gemm_256_f32},
     {"gemm_256_deep", &CcdPolicy::gemm_256_deep}, {"gemm_row384", &CcdPolicy::gemm_row384},
-    {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"lab", &CcdPolicy::lab}};
+    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"lab", &CcdPolicy::lab}};
 static CcdPolicy& ccd_policy() {
     static CcdPolicy pol = [] {
         CcdPolicy q;
@@ -233,6 +235,23 @@ int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, 
     CCD_CHECK(N <= ccd::GR_BN && N % 8 == 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldx % 4 == 0 && ldg % 4 == 0 &&
               (!gb || ldgb % 4 == 0), CCD_ESHAPE);
     CCD_CHECK(((long)M * lda + K) * 2 < CCD_MAX_OPERAND_BYTES && ((long)N * ldb + K) * 2 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
+    const int cus = ccd_grid_cus();
+    if (ccd_policy().rowgemm && (N == 128 || N == 256 || N == 384) && K % (64 * ccd::rg_ring(N)) == 0 && ldg % 4 == 0 &&
+        ((long)M + (long)cus * ccd::RG_BM) * lda * 2 < CCD_MAX_OPERAND_BYTES && (long)M * ldx * 4 < CCD_MAX_OPERAND_BYTES &&
+        (long)M * ldg * 4 < CCD_MAX_OPERAND_BYTES) {
+        ccd::RowGemmParams q;
+        q.A = A; q.lda = lda; q.W = B; q.ldw = ldb; q.M = M; q.K = K; q.x = x; q.ldx = ldx; q.mean = mean; q.rstd = rstd;
+        q.gamma = gamma; q.g = g; q.ldg = ldg; q.accumulate = accumulate; q.dgamma = dgamma; q.dbeta = dbeta; q.gb = gb;
+        q.ld_gb = ldgb; q.rowscale = gb ? rowscale : nullptr; q.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
+        q.dbias = gb ? dbias : nullptr; q.lab = ccd_policy().lab;
+        const int tiles = (M + ccd::RG_BM - 1) / ccd::RG_BM, smem = ccd::rg_smem_bytes(N);
+        const dim3 grid(tiles < cus ? tiles : cus), block(ccd::RG_THREADS);
+        if (N == 384 && ccd_policy().rowgemm == 2 && K % 384 == 0) CCD_LAUNCH((ccd::rowgemm_lnbwd_kernel<384, 6>), grid, block, smem, stream, q);
+        else if (N == 384) CCD_LAUNCH((ccd::rowgemm_lnbwd_kernel<384, ccd::rg_ring(384)>), grid, block, smem, stream, q);
+        else if (N == 256) CCD_LAUNCH((ccd::rowgemm_lnbwd_kernel<256, ccd::rg_ring(256)>), grid, block, smem, stream, q);
+        else CCD_LAUNCH((ccd::rowgemm_lnbwd_kernel<128, ccd::rg_ring(128)>), grid, block, smem, stream, q);
+        return ccd_rt_last_error();
+    }
     ccd::GemmParams p = ccd::GemmParams();
     p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.C = g; p.ldc = ldg; p.resid = x; p.ldr = ldx;
     p.rowscale = gb ? rowscale : nullptr; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; p.alpha = 1.0f;

@@ -1,0 +1,358 @@
+// rowgemm.h - data-gradient products whose output row (E = 128 / 256 / 384 columns) fits ONE wave's accumulators, with the
+// LayerNorm backward pass of those rows as the epilogue (autograd of nn.LayerNorm in Block.forward,
+// vision_transformer.py:99,103,107-113):
+//     dy = A . W^T  (never written);  xhat = (x - mean) * rstd
+//     dx = rstd * (dy*gamma - mean_row(dy*gamma) - xhat * mean_row(dy*gamma*xhat));   g = (accumulate ? g : 0) + dx
+//     dgamma += colsum(dy * xhat);  dbeta += colsum(dy);  optional: gb (bf16) = g * rowscale[sample], dbias += colsum(gb)
+// Same "row owner" structure as mlp_fused.h (whose second product this is, with the activations coming from HBM instead of
+// from the GELU): one workgroup = 4 waves = 128 rows, a wave owns 32 rows and all E columns of them (E/2 accumulator
+// registers), the weights stream through the 5-slot LDS ring in pieces of [E/2 output columns][64 k] that all four waves
+// consume in lock step, and every lane reads ITS row of A straight into MFMA operand registers (128 contiguous bytes per
+// row and 64-wide k-block, R - 1 blocks ahead of their use, across tile boundaries).  Compared with gemm_row384.h
+// (one 128 x 384 tile per 8 waves, both operands through LDS) the LDS carries the weights only, the row statistics need
+// one shuffle, and the epilogue runs on accumulators that never left their registers.
+//
+// VMEM bookkeeping (vmcnt counts every VMEM instruction of the wave, in issue order for loads): every piece "window"
+// issues exactly KT ring requests (MFMA steps 1, 5, 9, ...) and 2 activation loads (steps 0 and 2), so "my quarter of piece q
+// has landed" is vmcnt <= 3 * (KT + 2): at least that many instructions are younger than the last request of piece q, and
+// whatever the epilogue adds in between only makes the wait conservative.
+#pragma once
+
+namespace ccd {
+
+struct RowGemmParams {
+    const bf16_t* A;        // [M, K] bf16 activations (the upstream gradient)
+    long lda;
+    const bf16_t* W;        // [E, K] bf16: out = A . W^T
+    long ldw;
+    int M, K;
+    const float* x;         // [M, E] fp32: the LayerNorm's input
+    long ldx;
+    const float* mean;      // [M]
+    const float* rstd;
+    const float* gamma;     // [E]
+    float* g;               // [M, E] fp32 gradient of the residual stream (in / out)
+    long ldg;
+    int accumulate;
+    float* dgamma;          // [E] +=
+    float* dbeta;
+    bf16_t* gb;             // optional [M, E] bf16 = g_new * rowscale
+    long ld_gb;
+    const float* rowscale;
+    int rows_per_sample;
+    float* dbias;           // optional [E] += colsum(gb)
+    int lab;                // experiment switch (policy key "lab"): n > 0 delays odd workgroups by ~n * 8 k cycles
+};
+
+constexpr int RG_NSLOT = 5, RG_SCRATCH = 4096, RG_THREADS = 256, RG_BM = 128;
+__host__ __device__ inline int rg_smem_bytes(int E) {
+    return RG_NSLOT * mlp_piece_bytes(E) + 4 * RG_SCRATCH + 4 * E * 4;      // ring, scratch, gamma, 3 column-sum vectors
+}
+
+// activation k-blocks a lane holds (the newest arrives R - 1 blocks = 2 (R - 1) pieces ahead of its use): 48 registers at
+// E = 384 - with 96 the epilogue (accumulators + the next tile's blocks + its own streams) spills.  K / 64 % R == 0.
+__host__ __device__ constexpr int rg_ring(int E) { return E == 384 ? 3 : 2; }
+// (dy * gamma, xhat) in one register between the two epilogue passes
+__device__ __forceinline__ unsigned rg_pack(float dg, float xh) {
+    const unsigned hi = (__builtin_bit_cast(unsigned, dg) + 0x800u) & 0xFFFFF000u;
+    float q = fmaf(xh, 102.4f, 2048.5f);
+    q = q < 0.f ? 0.f : (q > 4095.f ? 4095.f : q);
+    return hi | (unsigned)q;
+}
+__device__ __forceinline__ float rg_unpack_dg(unsigned pk) { return __builtin_bit_cast(float, pk & 0xFFFFF000u); }
+__device__ __forceinline__ float rg_unpack_xh(unsigned pk) { return ((float)(int)(pk & 0xFFFu) - 2048.f) * (1.0f / 102.4f); }
+// one halving step of a sum over lanes: every lane keeps one of (a, b) - the one its bit MASK of the lane id selects - and
+// adds the partner lane's copy of it.  16 values -> 8 -> 4 -> 2 -> 1 sums 16 values over 16 lanes in 15 such steps.
+template <int MASK>
+__device__ __forceinline__ float rg_fold(float a, float b, bool up) {
+    const float keep = up ? b : a, send = up ? a : b;
+    return keep + lane_xor<MASK>(send);
+}
+// v[4 g + e] = this lane's row, column 8 g + 4 hf + e of a 32-column tile: column sums over the 32 rows of the wave, added
+// to dst[32 columns] (LDS; the 16 low lanes of each half wave own one column each)
+__device__ __forceinline__ void rg_colsum16(const float (&v)[16], float* dst, int lq, int hf) {
+    float a8[8], a4[4], a2[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a8[j] = rg_fold<1>(v[2 * j], v[2 * j + 1], (lq & 1) != 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a4[j] = rg_fold<2>(a8[2 * j], a8[2 * j + 1], (lq & 2) != 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) a2[j] = rg_fold<4>(a4[2 * j], a4[2 * j + 1], (lq & 4) != 0);
+    float tot = rg_fold<8>(a2[0], a2[1], (lq & 8) != 0);
+    atomicAdd(dst + 8 * ((lq >> 2) & 3) + 4 * hf + (lq & 3), tot);
+}
+
+template <int E, int R>
+__global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_lnbwd_kernel(RowGemmParams p) {
+    constexpr int KT = E / 64;             // ring requests (1 KiB wave instructions) per wave and piece
+    constexpr int NT = E / 32, NTH = NT / 2;
+    constexpr int PIECE = mlp_piece_bytes(E);
+    constexpr int AHEAD = RG_NSLOT - 1;
+    constexpr int DEPTH = 6;               // fragment reads in flight ahead of their MFMA
+    constexpr int NSTEP = 4 * NTH;         // MFMAs per piece
+    constexpr int WIN_VM = KT + 2;         // VMEM instructions per window
+    static_assert(E % 128 == 0 && NSTEP == 4 * KT && AHEAD == 4, "ring bookkeeping");
+    char* smem = dynamic_smem();
+    const int t = threadIdx.x, lane = t & 63, hf = lane >> 5, lq = lane & 31;
+    const int w = uniform_i32(t >> 6);
+    char* scratch = smem + RG_NSLOT * PIECE + w * RG_SCRATCH;
+    float* vga = reinterpret_cast<float*>(smem + RG_NSLOT * PIECE + 4 * RG_SCRATCH);
+    float* cs = vga + E;                   // [3][E]: dgamma, dbeta, dbias of this workgroup
+    for (int i = t; i < E; i += RG_THREADS) { vga[i] = p.gamma[i]; cs[i] = 0.f; cs[E + i] = 0.f; cs[2 * E + i] = 0.f; }
+    __syncthreads();
+
+    const int NB = p.K / 64, NP = 2 * NB;  // k-blocks, pieces per row tile (NB % R == 0)
+#ifdef CCD_MLP_LAB      // lab build only: cycle totals of wave 0 per phase -> first 64 bytes per workgroup of g (destroyed)
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#define RG_STAMP(i) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph[i] += tn_ - tprev; tprev = tn_; }
+#else
+#define RG_STAMP(i)
+#endif
+    const int tiles = (p.M + RG_BM - 1) / RG_BM, G = gridDim.x;
+
+    // ---- weight ring (mlp_fused.h: W2-type pieces): piece (blk, half) = rows half * E/2 + 32 i + 8 w + (0..7), k = 64 blk ..
+    const int dr = lane >> 3, dp = lane & 7, drow = 8 * w + dr;
+    const unsigned req_lane = (unsigned)(2 * drow) * (unsigned)p.ldw + (unsigned)((dp ^ mlp_swz(drow)) * 16);
+    const long req_step_a = 64 * p.ldw, req_step_b = 128 * p.ldw;
+    int slot_i = 0, slot_c = 0, pos_i = 0;
+    const char* req_base = nullptr;
+    char* req_lds = nullptr;
+    auto issue_prepare = [&]() {
+        const int blk = pos_i >> 1, half = pos_i & 1;
+        req_base = reinterpret_cast<const char*>(p.W) + ((long)(half * (E / 2)) * p.ldw + 64 * blk) * 2;
+        req_lds = smem + slot_i * PIECE + w * 1024;
+        slot_i = slot_i + 1 == RG_NSLOT ? 0 : slot_i + 1;
+        pos_i = pos_i + 1 == NP ? 0 : pos_i + 1;
+    };
+    auto issue_one = [&](int i) {
+        glds16(req_base + ((i & 1) * req_step_a + (i >> 1) * req_step_b) + req_lane, req_lds + 4096 * i);
+    };
+    const unsigned smem_addr = lds_addr_of(smem);
+    auto acquire = [&]() -> unsigned {
+        glds_wait<(AHEAD - 1) * WIN_VM>();
+        RG_STAMP(1)
+        lds_barrier();
+        RG_STAMP(2)
+        issue_prepare();
+        const unsigned sb = smem_addr + (unsigned)(slot_c * PIECE);
+        slot_c = slot_c + 1 == RG_NSLOT ? 0 : slot_c + 1;
+        return sb;
+    };
+#pragma unroll
+    for (int j = 0; j < AHEAD; ++j) {
+        issue_prepare();
+#pragma unroll
+        for (int i = 0; i < KT; ++i) issue_one(i);
+    }
+    unsigned off2[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) off2[kk] = (unsigned)(lq * 128 + (((2 * kk + hf) ^ mlp_swz(lq)) * 16));
+
+    const buf_rsrc rs_a = make_rsrc(p.A, (unsigned)((((long)p.M - 1) * p.lda + p.K) * 2));
+    const buf_rsrc rs_x = make_rsrc(p.x, (unsigned)((((long)p.M - 1) * p.ldx + E) * 4));
+    const buf_rsrc rs_g = make_rsrc(p.g, (unsigned)((((long)p.M - 1) * p.ldg + E) * 4));
+    const buf_rsrc rs_b = make_rsrc(p.gb, p.gb ? (unsigned)((((long)p.M - 1) * p.ld_gb + E) * 2) : 0u);
+    struct LaneOff {
+        int lane, hf, lq, dr, dp;
+        __device__ __forceinline__ explicit LaneOff(int t) {
+            lane = opaque_vgpr(t) & 63; hf = lane >> 5; lq = lane & 31; dr = lane >> 3; dp = lane & 7;
+        }
+        __device__ __forceinline__ unsigned frag(long ld, int elt, int per_hf) const { return (unsigned)((lq * ld + per_hf * hf) * elt); }
+        __device__ __forceinline__ unsigned rows8(long ld, int elt) const { return (unsigned)(dr * ld * elt + dp * 16); }
+        __device__ __forceinline__ unsigned scr_rd(int i) const { return (unsigned)((dr + 8 * i) * 128 + ((dp ^ dr) * 16)); }
+        __device__ __forceinline__ unsigned scr_wr(int slot16) const { return (unsigned)(lq * 128 + ((slot16 ^ (lq & 7)) * 16)); }
+    };
+    // this lane's row of A: k-block b of row tile tt, quarter j = the B operand of k-step j (k = 64 b + 16 j + 8 hf .. + 7)
+    const unsigned lo_a = (unsigned)((lq * p.lda + 8 * hf) * 2);
+    u32x4 ab[R][4];
+    auto load_a = [&](u32x4& dst, int tt, int b, int j) {
+        dst = buf_load16(rs_a, lo_a, (unsigned)(tt * RG_BM + 32 * w) * (unsigned)(p.lda * 2) + (unsigned)(128 * b + 32 * j));
+    };
+    if ((int)blockIdx.x < tiles) {
+#pragma unroll
+        for (int b = 0; b < R - 1; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_a(ab[b][j], blockIdx.x, b, j);
+    }
+    // the first acquires count on 3 * WIN_VM instructions younger than the ring requests of the prologue: true when the
+    // activation loads above are that many, else (E = 128) start from a drained queue
+    if constexpr (4 * (R - 1) + 2 < KT + 6) glds_wait_all();
+    const float inv_e = 1.0f / (float)E;
+    if (p.lab > 0 && (blockIdx.x & 1)) wave_sleep(p.lab);
+
+    for (int tile = blockIdx.x; tile < tiles; tile += G) {
+        const int m0 = tile * RG_BM, r0 = m0 + 32 * w;
+        const int row = r0 + lq, grow = row < p.M ? row : p.M - 1;
+        const float mu = p.mean[grow], rs = p.rstd[grow];
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        RG_STAMP(0)
+#pragma unroll 1
+        for (int grp = 0; grp < NB / R; ++grp) {
+            mlp_static_for<0, R>([&](auto I) {
+                constexpr int i = decltype(I)::value, sp = (i + R - 1) % R;
+                // the block that slot sp receives while block (grp, i) is multiplied: R - 1 blocks ahead, maybe of the next tile
+                int tb = grp * R + i + R - 1, tt = tile;
+                if (tb >= NB) { tb -= NB; tt += G; }
+                mlp_static_for<0, 2>([&](auto HH) {
+                    constexpr int hh = decltype(HH)::value;
+                    const unsigned sb = acquire();
+                    const unsigned areg[4] = {sb + off2[0], sb + off2[1], sb + off2[2], sb + off2[3]};
+                    mlp_product<NSTEP, DEPTH, MlpMapP2<NTH>, MlpNoExtra>(
+                        areg,
+                        [&](auto K, const bf16x8& a) {
+                            constexpr int k = decltype(K)::value;
+                            acc[NTH * hh + k % NTH] = mfma_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, ab[i][k / NTH]), acc[NTH * hh + k % NTH]);
+                        },
+                        [&](auto K) {
+                            constexpr int k = decltype(K)::value;
+                            if constexpr (k % 4 == 1) issue_one(k / 4);
+                            if constexpr (k == 0) load_a(ab[sp][2 * hh], tt, tb, 2 * hh);
+                            if constexpr (k == 2) load_a(ab[sp][2 * hh + 1], tt, tb, 2 * hh + 1);
+                        });
+                    RG_STAMP(3)
+                });
+            });
+        }
+        // ---- epilogue: a row is complete inside its two lanes (lane, lane ^ 32); acc[nt][4 g + e] = column 32 nt + 8 g + 4 hf + e.
+        // Pass A: the two row means and the column sums of dy * xhat and dy (x streams in two tiles ahead of its use).
+        const unsigned so_x = (unsigned)r0 * (unsigned)(p.ldx * 4);
+        float s1 = 0.f, sq = 0.f;
+        {
+            const unsigned lo_x = LaneOff(t).frag(p.ldx, 4, 4);
+            constexpr int PA = 4;          // tiles of x in flight (HBM latency x 14 GB/s per CU and tile in flight)
+            u32x4 xb[PA][4];
+            auto load_x = [&](int nt) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xb[nt % PA][g] = buf_load16(rs_x, lo_x, so_x + (32 * nt + 8 * g) * 4);
+            };
+#pragma unroll
+            for (int nt = 0; nt < PA - 1 && nt < NT; ++nt) load_x(nt);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (nt + PA - 1 < NT) load_x(nt + PA - 1);
+                float vg[16], vb[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4v x = __builtin_bit_cast(f32x4v, xb[nt % PA][g]);
+                    const f32x4v ga = *reinterpret_cast<const f32x4v*>(vga + 32 * nt + 8 * g + 4 * hf);
+                    const float xx[4] = {x.x, x.y, x.z, x.w}, gg[4] = {ga.x, ga.y, ga.z, ga.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float dy = acc[nt][4 * g + e], xh = (xx[e] - mu) * rs, dg = dy * gg[e];
+                        // what pass B needs, in the accumulator's own register, so that x is read once: dy * gamma rounded to 12
+                        // mantissa bits (the unfused pair rounds dy to 8) above xhat in 12-bit fixed point (|xhat| < 20, steps of 0.01;
+                        // it only scales the small second-moment correction)
+                        // (opaque: the optimiser sinks the packing into pass B otherwise, and carries BOTH values there)
+                        acc[nt][4 * g + e] = opaque_f32(__builtin_bit_cast(float, rg_pack(dg, xh)));
+                        s1 += dg;
+                        sq = fmaf(dg, xh, sq);
+                        vg[4 * g + e] = dy * xh;
+                        vb[4 * g + e] = dy;
+                    }
+                }
+                rg_colsum16(vg, cs + 32 * nt, lq, hf);
+                rg_colsum16(vb, cs + E + 32 * nt, lq, hf);
+                CCD_SCHED_FENCE();             // one tile at a time: interleaved tiles (and every load of the pass hoisted to
+                asm volatile("" ::: "memory");   // its top) cost more registers than there are
+            }
+        }
+        RG_STAMP(4)
+        s1 += shfl_xor(s1, 32);
+        sq += shfl_xor(sq, 32);
+        const float c1 = rs * s1 * inv_e, c2 = rs * sq * inv_e;
+        float sc = 1.0f;
+        if (p.gb && p.rowscale) sc = p.rowscale[grow / p.rows_per_sample];
+        // Pass B: dx, g and gb per 32-column tile, leaving through the wave's scratch image as 128-byte row segments
+        {
+            const LaneOff lo(t);
+            const unsigned lo_gl = lo.frag(p.ldg, 4, 4), so_g = (unsigned)r0 * (unsigned)(p.ldg * 4);
+            const unsigned lo_o = lo.rows8(p.ldg, 4), lo_n = lo.rows8(p.ld_gb, 2);
+            constexpr int PB = 3;
+            u32x4 gbuf[PB][4];
+            auto load_xg = [&](int nt) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    gbuf[nt % PB][g] = u32x4{0u, 0u, 0u, 0u};
+                    if (p.accumulate) gbuf[nt % PB][g] = buf_load16(rs_g, lo_gl, so_g + (32 * nt + 8 * g) * 4);
+                }
+            };
+#pragma unroll
+            for (int nt = 0; nt < PB - 1 && nt < NT; ++nt) load_xg(nt);
+#pragma unroll
+            for (int np = 0; np < NT / 2; ++np) {
+                u32x2 ypk[2][4];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int nt = 2 * np + tt;
+                    if (nt + PB - 1 < NT) load_xg(nt + PB - 1);
+                    float vbi[16];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4v go = __builtin_bit_cast(f32x4v, gbuf[nt % PB][g]);
+                        const float oo[4] = {go.x, go.y, go.z, go.w};
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float pf = acc[nt][4 * g + e];      // (bit_cast applied to the element lvalue itself reads the wrong lane)
+                            const unsigned pk = __builtin_bit_cast(unsigned, pf);
+                            const float dx = fmaf(-c2, rg_unpack_xh(pk), fmaf(rg_unpack_dg(pk), rs, -c1));
+                            v[e] = oo[e] + dx;
+                        }
+                        *reinterpret_cast<f32x4v*>(scratch + lo.scr_wr(2 * g + lo.hf)) = f32x4v{v[0], v[1], v[2], v[3]};
+                        if (p.gb) {
+                            ypk[tt][g].x = pack_bf2(v[0] * sc, v[1] * sc);
+                            ypk[tt][g].y = pack_bf2(v[2] * sc, v[3] * sc);
+                            // sum what the GEMMs will read: the bf16-rounded values
+                            vbi[4 * g] = bf_lo(ypk[tt][g].x); vbi[4 * g + 1] = bf_hi(ypk[tt][g].x);
+                            vbi[4 * g + 2] = bf_lo(ypk[tt][g].y); vbi[4 * g + 3] = bf_hi(ypk[tt][g].y);
+                        }
+                    }
+                    if (p.gb && p.dbias) rg_colsum16(vbi, cs + 2 * E + 32 * nt, lq, hf);
+                    wave_lds_fence();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u32x4 o = *reinterpret_cast<const u32x4*>(scratch + lo.scr_rd(i));
+                        buf_store16(rs_g, lo_o, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldg * 4) + 128 * nt, o);
+                    }
+                    wave_lds_fence();
+                    CCD_SCHED_FENCE();
+                    asm volatile("" ::: "memory");
+                }
+                if (p.gb) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<u32x2*>(scratch + lo.scr_wr(4 * tt + g) + 8 * lo.hf) = ypk[tt][g];
+                    wave_lds_fence();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u32x4 o = *reinterpret_cast<const u32x4*>(scratch + lo.scr_rd(i));
+                        buf_store16(rs_b, lo_n, (unsigned)(r0 + 8 * i) * (unsigned)(p.ld_gb * 2) + 128 * np, o);
+                    }
+                    wave_lds_fence();
+                }
+            }
+        }
+        RG_STAMP(5)
+    }
+    glds_wait_all();                       // requested pieces that no tile consumed must not outlive the workgroup's LDS
+    __syncthreads();
+    for (int i = t; i < E; i += RG_THREADS) {
+        atomicAdd(p.dgamma + i, cs[i]);
+        atomicAdd(p.dbeta + i, cs[E + i]);
+        if (p.dbias) atomicAdd(p.dbias + i, cs[2 * E + i]);
+    }
+#ifdef CCD_MLP_LAB
+    RG_STAMP(6)
+    if (t == 0)
+        for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(p.g)[blockIdx.x * 8 + i] = ph[i];
+#endif
+}
+
+}  // namespace ccd

@@ -106,6 +106,17 @@ __device__ __forceinline__ void lds_gather_f32(float& dst, unsigned lds_addr) {
 }
 __device__ __forceinline__ void lds_landed(float& a, float& b) { asm volatile("" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// the value lane (l ^ M) holds, M in {1, 2, 4, 8, 16}: DPP where gfx950 has a pattern for it (no LDS crossbar traffic), the
+// swizzle unit otherwise
+template <int M>
+__device__ __forceinline__ float lane_xor(float v) {
+    int x = __builtin_bit_cast(int, v);
+    if constexpr (M == 1) x = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);          // quad_perm:[1,0,3,2]
+    else if constexpr (M == 2) x = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);     // quad_perm:[2,3,0,1]
+    else if constexpr (M == 8) x = __builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false);    // row_ror:8
+    else x = __builtin_amdgcn_ds_swizzle(x, (M << 10) | 0x1F);                                    // swizzle(SWAP, M)
+    return __builtin_bit_cast(float, x);
+}
 // static wave priority (guide T5): 0..3, arbitration between the waves sharing a SIMD
 template <int P>
 __device__ __forceinline__ void wave_prio() { __builtin_amdgcn_s_setprio(P); }
@@ -115,6 +126,7 @@ __device__ __forceinline__ unsigned opaque_u32(unsigned x) { asm volatile("" : "
 // the same for a per-lane value, and NOT hoistable out of a loop: address arithmetic derived from it is redone where it is
 // used instead of living in a register (or, worse, in scratch) across a register-starved main loop
 __device__ __forceinline__ int opaque_vgpr(int x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ float opaque_f32(float x) { asm volatile("" : "+v"(x)); return x; }
 // hardware float -> bf16 (RNE): clang lowers the __bf16 casts to v_cvt_pk_bf16_f32 on gfx950
 typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {

@@ -142,6 +142,7 @@ template <int N>
 inline void glds_wait() {}
 inline unsigned opaque_u32(unsigned x) { return x; }
 inline int opaque_vgpr(int x) { return x; }
+inline float opaque_f32(float x) { return x; }
 // hand-issued LDS fragment reads (prelude_hip.h): synchronous here; LDS "addresses" are offsets from the block's dynamic LDS
 inline unsigned lds_addr_of(const void* p) { return (unsigned)(reinterpret_cast<const char*>(p) - sim::curblk->dyn_smem); }
 template <int OFF>
@@ -193,6 +194,8 @@ inline T shfl(T v, int src_lane) {
 }
 template <typename T>
 inline T shfl_xor(T v, int mask) { return shfl(v, sim::cur->lane ^ mask); }
+template <int M>
+inline float lane_xor(float v) { return shfl(v, sim::cur->lane ^ M); }
 template <typename T>
 inline T shfl_down(T v, int d) { int s = sim::cur->lane + d; return shfl(v, s > 63 ? sim::cur->lane : s); }
 inline unsigned long long ballot(bool p) {

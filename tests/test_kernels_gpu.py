@@ -143,9 +143,16 @@ def test_gemm_row384(hip, M, N, K):
         kc.check_gemm_dynamic_rows(hip.device, M=max(M, 600), N=N, K=K, live=75)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 384, 128), (4096, 384, 1536), (40000, 384, 1152), (2048, 192, 768)])
+@pytest.mark.parametrize("M,N,K", [(300, 384, 128), (300, 384, 384), (4096, 384, 1536), (40000, 384, 1152), (2048, 192, 768),
+                                   (5000, 128, 512), (33000, 256, 768)])
 def test_gemm_lnbwd(hip, M, N, K):
-    kc.check_gemm_lnbwd(hip.device, M=M, N=N, K=K)
+    kc.check_gemm_lnbwd(hip.device, M=M, N=N, K=K)            # rowgemm.h where K % N == 0 and N in {128, 256, 384}
+
+
+def test_gemm_lnbwd_row384_kernel(hip):
+    from ccd_amd import ops
+    with ops.policy(rowgemm=0):
+        kc.check_gemm_lnbwd(hip.device, M=4096, N=384, K=1536)
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 384, 128), (4096, 384, 1536), (2048, 192, 768)])

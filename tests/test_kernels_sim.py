@@ -139,7 +139,10 @@ def test_policy_table_sim(sim):
 
 
 def test_gemm_lnbwd_sim(sim):
-    kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=128)
+    kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=384)      # rowgemm.h (K % N == 0, N in {128, 256, 384})
+    kc.check_gemm_lnbwd(sim.device, M=200, N=128, K=256)
+    kc.check_gemm_lnbwd(sim.device, M=260, N=256, K=256)
+    kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=128)      # gemm_row384.h
     kc.check_gemm_lnbwd(sim.device, M=140, N=192, K=64)
 
 
