@@ -14,6 +14,7 @@
 #include "kernels/attention_fwd.h"
 #include "kernels/attention_bwd.h"
 #include "kernels/charmap.h"
+#include "kernels/datapipe.h"
 #include "kernels/embed.h"
 #include "kernels/head.h"
 #include "kernels/loss.h"
@@ -476,6 +477,22 @@ int ccd_seg_to_mask(const float* seg_logits, float* mask, int images, void* stre
     if (images == 0) return CCD_OK;
     const long n = (long)images * ccd::CM_PIX;
     CCD_LAUNCH(ccd::seg_to_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, seg_logits, mask, images);
+    return ccd_rt_last_error();
+}
+int ccd_kmeans2_mask(const uint8_t* gray, const long* offsets, const int* hw, uint8_t* mask, int images, void* stream) {
+    CCD_CHECK(gray && offsets && hw && mask && images >= 0, CCD_EINVAL);
+    if (images == 0) return CCD_OK;
+    CCD_LAUNCH(ccd::kmeans2_mask_kernel, dim3(images), dim3(ccd::KM_THREADS), 0, stream, gray, offsets, hw, mask);
+    return ccd_rt_last_error();
+}
+int ccd_augment_views(const uint8_t* img, const float* params, const float* theta, float* out, int batch, int height, int width,
+                      const float* mean3, const float* std3, void* stream) {
+    CCD_CHECK(img && params && theta && out && mean3 && std3 && batch >= 0, CCD_EINVAL);
+    CCD_CHECK(height >= 2 && width >= 2 && (long)height * width < (1L << 24), CCD_ESHAPE);
+    CCD_CHECK(std3[0] > 0.f && std3[1] > 0.f && std3[2] > 0.f, CCD_EINVAL);
+    if (batch == 0) return CCD_OK;
+    CCD_LAUNCH(ccd::augment_views_kernel, dim3((height * width + 255) / 256, batch), dim3(256), 0, stream, img, params, theta, out,
+               batch, height, width, mean3[0], mean3[1], mean3[2], 1.0f / std3[0], 1.0f / std3[1], 1.0f / std3[2]);
     return ccd_rt_last_error();
 }
 int ccd_warp_idmap(const uint8_t* src, const float* theta, int theta_stride, uint8_t* dst, int images, void* stream) {

@@ -335,6 +335,43 @@ def seg_to_mask(seg_logits, images):
     return out
 
 
+def kmeans2_mask(grays, device=None):
+    """Text masks of word images (clusterpixels(im, 2), mask_create/generate_mask.py:13-29) for a list of uint8 [h, w] gray
+    images of any sizes -> list of uint8 [h, w] 0/1 arrays (numpy).  One workgroup per image of the ragged batch."""
+    import numpy as np
+    if not grays:
+        return []
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    arrs = [np.ascontiguousarray(np.asarray(g, dtype=np.uint8)) for g in grays]
+    for a in arrs:
+        assert a.ndim == 2 and a.size > 0, "kmeans2_mask expects non-empty [h, w] gray images"
+    sizes = np.array([a.size for a in arrs], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    hw = np.array([a.shape for a in arrs], dtype=np.int32).reshape(-1)
+    flat = torch.from_numpy(np.concatenate([a.reshape(-1) for a in arrs])).to(dev)
+    d_offs, d_hw = torch.from_numpy(offs).to(dev), torch.from_numpy(hw).to(dev)
+    out = torch.empty_like(flat)
+    _call("ccd_kmeans2_mask", _lib.ptr(flat), _lib.ptr(d_offs), _lib.ptr(d_hw), _lib.ptr(out), len(arrs))
+    host = out.cpu().numpy()
+    return [host[offs[i]:offs[i + 1]].reshape(arrs[i].shape) for i in range(len(arrs))]
+
+
+def augment_views(img, params, theta, mean, std):
+    """img uint8 [B,H,W,3] (resized samples), params fp32 [B,2,16], theta fp32 [B,3,3] -> image_tensors fp32 [B,3,3,H,W]:
+    (plain, colour-augmented, colour-augmented + warped by theta), normalised - the dataset's batch contract
+    (datasetsupervised_kmeans.py:48-87)."""
+    import ctypes as C
+    assert img.dtype == U8 and img.is_contiguous() and img.dim() == 4 and img.shape[3] == 3
+    _chk(params, F32, "params"); _chk(theta, F32, "theta")
+    B, H, W, _ = img.shape
+    assert tuple(params.shape) == (B, 2, 16) and tuple(theta.shape) == (B, 3, 3)
+    out = torch.empty((B, 3, 3, H, W), dtype=F32, device=img.device)
+    m3, s3 = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
+    _call("ccd_augment_views", _lib.ptr(img), _lib.ptr(params), _lib.ptr(theta), _lib.ptr(out), B, H, W,
+          C.cast(m3, C.c_void_p), C.cast(s3, C.c_void_p))
+    return out
+
+
 def warp_idmap(src, theta):
     """src uint8 [B,32,128], theta fp32 [B,3,3] (or [B,2,3]) -> warped id map (view 2)."""
     assert src.dtype == U8 and src.is_contiguous() and theta.dtype == F32 and theta.is_contiguous()

@@ -146,6 +146,18 @@ int ccd_ccl_label(const float* mask, uint8_t* idmap, int images, void* stream);
 int ccd_mask_to_idmap(const float* mask, uint8_t* idmap, int images, void* stream);
 /* softmax(seg)[:,1] > 0.5 of the first `images` images (dino_vision.py:65-66); seg [>=images,2,32,128] fp32 */
 int ccd_seg_to_mask(const float* seg_logits, float* mask, int images, void* stream);
+/* ---------------------------------------------------------------- data pipeline
+ * clusterpixels(im, 2), mask_create/generate_mask.py:13-29 (= Dino/utils/kmeans.py:7-23): 2-means of the gray values of a
+ * word image + "the cluster that owns the border is background".  A RAGGED batch: image i is gray[offsets[i] ..
+ * offsets[i+1]) with hw[2i] rows x hw[2i+1] columns (device arrays; offsets has images + 1 entries); mask gets 0 / 1
+ * at the same offsets.  Integer / fp64 arithmetic with a fixed operation order: bit-exact against oracle/datapipe_np.py. */
+int ccd_kmeans2_mask(const uint8_t* gray, const long* offsets, const int* hw, uint8_t* mask, int images, void* stream);
+/* The three views of ImageDatasetSelfSupervisedKmeans._process_training (datasetsupervised_kmeans.py:48-87) from resized
+ * uint8 images img [B,H,W,3]: out fp32 [B,3,3,H,W] = (plain, colour(params[b,0]), warp_theta(colour(params[b,1]))),
+ * each normalised with mean3 / std3 (HOST arrays of 3 floats; dataset.py:79-80).  params fp32 [B,2,16] (layout in
+ * kernels/datapipe.h), theta fp32 [B,3,3] = the `metrics` tensor the model receives (identity = no warp). */
+int ccd_augment_views(const uint8_t* img, const float* params, const float* theta, float* out, int batch, int height, int width,
+                      const float* mean3, const float* std3, void* stream);
 /* affine_grid(theta[:, :2]) + grid_sample(bilinear) > 0.1, dino_vision.py:72-77 / train.py:234-236; theta row stride in floats */
 int ccd_warp_idmap(const uint8_t* src, const float* theta, int theta_stride, uint8_t* dst, int images, void* stream);
 /* ABIDINOModel.attention, dino_vision.py:38-49, in sparse form: per token up to 4 (plane, normalised weight) pairs -

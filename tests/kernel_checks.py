@@ -208,6 +208,81 @@ def check_warp(dev):
     np.testing.assert_array_equal(got, ids[B:])
 
 
+def _golden_kmeans():
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kmeans_masks.npz"))
+    grays, masks, off = [], [], 0
+    for h, w in z["hw"]:
+        grays.append(z["gray"][off:off + h * w].reshape(h, w)); masks.append(z["mask"][off:off + h * w].reshape(h, w))
+        off += h * w
+    return grays, masks
+
+
+def check_kmeans2_mask(dev, seed=51, extra=12):
+    """clusterpixels(im, 2) on the device (mask_create/generate_mask.py:13-29): bit-equal to the REAL function's outputs on
+    the committed word images, and to the oracle on ragged random batches incl. the degenerate cases."""
+    from oracle import datapipe_np as D
+    grays, masks = _golden_kmeans()
+    got = ops.kmeans2_mask(grays, device=dev)
+    for i, (g, m) in enumerate(zip(got, masks)):
+        np.testing.assert_array_equal(g, m, err_msg=f"fixture image {i}")
+    rs = np.random.RandomState(seed)
+    batch = [np.full((5, 7), 93, np.uint8),                                   # one gray level: no clustering, all zero
+             np.array([[0, 255]], np.uint8),                                  # 1 x 2
+             (np.arange(6 * 300) % 251).astype(np.uint8).reshape(6, 300),      # flat histogram
+             np.pad(np.full((10, 20), 200, np.uint8), 6, constant_values=30),  # bright blob on dark: no flip
+             np.pad(np.full((10, 20), 30, np.uint8), 6, constant_values=200)]  # dark blob on bright: flip
+    for _ in range(extra):
+        h, w = rs.randint(1, 70), rs.randint(1, 300)
+        a = rs.normal(rs.choice([60, 180]), 25, size=(h, w))
+        a[rs.uniform(size=(h, w)) < 0.3] += rs.choice([-90, 90])
+        batch.append(np.clip(np.rint(a), 0, 255).astype(np.uint8))
+    got = ops.kmeans2_mask(batch, device=dev)
+    for i, (g, a) in enumerate(zip(got, batch)):
+        np.testing.assert_array_equal(g, D.kmeans2_mask(a), err_msg=f"random image {i} {a.shape}")
+    assert got[3][8, 10] == 1 and got[3][0, 0] == 0 and got[4][8, 10] == 1 and got[4][0, 0] == 0
+    assert ops.kmeans2_mask([], device=dev) == []
+
+
+def check_augment_views(dev, B=5, H=32, W=128, seed=52):
+    """The three views of a sample (datasetsupervised_kmeans.py:48-87) vs the numpy restatement, every colour member
+    exercised; geometry: view 2 of an un-coloured sample == F.grid_sample of view 0's pixels in the dataset's
+    (size-1)-normalised convention, and identity theta reproduces view 1's colour on view 2."""
+    from oracle import datapipe_np as D
+    from ccd_amd.dataset.augment import IDENTITY_PARAMS, sample_colour_params, sample_theta
+    rs = np.random.RandomState(seed)
+    img = rs.randint(0, 256, size=(B, H, W, 3)).astype(np.uint8)
+    img[0, 8:24, 20:60] = (250, 30, 90)
+    params = sample_colour_params(rs, B, 5)
+    # make sure every member is exercised at least once
+    params[0, 0] = IDENTITY_PARAMS; params[0, 1] = IDENTITY_PARAMS
+    params[1, 0] = [1, 0.4, 3, 1.7, 1.2, 0.8, 1.1, 0.7, 12, 9.0, 0.3, 0.05, 100, 77, 0, 0]
+    params[1, 1] = [0, 1.0, 5, 0.6, 1, 1, 1, 1, -20, 0, 0, 0.1, 256, 123456, 0, 0]
+    theta = sample_theta(rs, B, H, W, p_warp=1.0)
+    theta[2] = np.eye(3)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    got = ops.augment_views(torch.from_numpy(img).to(dev), torch.from_numpy(params).to(dev), torch.from_numpy(theta).to(dev),
+                            mean, std).cpu().numpy()
+    want = D.augment_views(img, params, theta, mean, std)
+    assert got.shape == (B, 3, 3, H, W)
+    err = np.abs(got - want)
+    # powf / logf / cosf differ by ulps between libm and the device; impulse / solarize decisions can flip on a tie
+    assert np.quantile(err, 0.999) < 2e-3 and (err > 0.05).mean() < 1e-4, (err.max(), np.quantile(err, 0.999))
+    # view 0 is the plain normalised image, exactly
+    v0 = ((img.astype(np.float32) * np.float32(1 / 255.0) - np.float32(mean)) * (np.float32(1) / np.float32(std))).transpose(0, 3, 1, 2)
+    np.testing.assert_allclose(got[:, 0], v0, rtol=0, atol=1e-6)
+    # sample 0: no colour change -> view 1 == view 0, and view 2 == bilinear warp of view 0's raw pixels (zeros outside)
+    np.testing.assert_allclose(got[0, 1], got[0, 0], rtol=0, atol=1e-5)
+    raw = torch.from_numpy(img[0].astype(np.float32)).permute(2, 0, 1)[None]
+    th = torch.from_numpy(theta[0])[None, :2, :]
+    grid = F.affine_grid(th, size=(1, 3, H, W), align_corners=True)         # (size-1) normalisation == align_corners=True
+    warped = F.grid_sample(raw, grid, mode="bilinear", padding_mode="zeros", align_corners=True)[0].numpy()
+    want2 = (warped * np.float32(1 / 255.0) - np.float32(mean)[:, None, None]) / np.float32(std)[:, None, None]
+    np.testing.assert_allclose(got[0, 2], want2, rtol=0, atol=2e-4)
+    # sample 2: identity theta -> view 2 is a pure colour view of the same pixels (same family as view 1)
+    np.testing.assert_allclose(got[2, 2], D.augment_views(img[2:3], params[2:3], theta[2:3], mean, std)[0, 2], rtol=0, atol=2e-3)
+
+
 def check_seg_to_mask(dev, seed=23):
     """Predicted-mask branch (dino_vision.py:64-66): softmax(seg, dim=1)[:, 1] > 0.5 on fp32 logits - random values,
     exact ties, huge magnitudes, infinities / NaNs (the reference's softmax turns those into NaN -> False)."""

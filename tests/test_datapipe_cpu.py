@@ -1,0 +1,183 @@
+"""Host side of the data pipeline: the LMDB file format, the dataset's record handling and resize,
+theta's composition, and the k-means oracle against the fixtures the REAL reference function wrote."""
+import io
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ccd_amd.dataset import lmdb_file
+from ccd_amd.dataset.augment import affine_pixel_matrix, sample_colour_params, sample_theta, theta_from_pixel_matrix
+from ccd_amd.dataset.datasetsupervised_kmeans import ImageDatasetSelfSupervisedKmeans, collate_uint8, resize_bilinear
+from oracle import datapipe_np as D
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _png(arr, mode=None):
+    from PIL import Image
+    out = io.BytesIO()
+    Image.fromarray(arr, mode=mode).save(out, format="PNG")
+    return out.getvalue()
+
+
+@pytest.mark.parametrize("psize,count", [(4096, 3000), (512, 900)])
+def test_lmdb_roundtrip(tmp_path, psize, count):
+    rs = np.random.RandomState(1)
+    items = {b"num-samples": str(count).encode()}
+    for i in range(1, count + 1):
+        items[b"image-%09d" % i] = rs.bytes(int(rs.choice([1, 17, 200, psize // 2 - 30, psize // 2, 3 * psize + 5])))
+        items[b"label-%09d" % i] = b"w%d" % i
+    stat = lmdb_file.write_lmdb(str(tmp_path / "db"), items, psize=psize)
+    assert stat["entries"] == len(items) and stat["overflow_pages"] > 0
+    assert stat["depth"] >= (3 if psize == 512 else 2)
+    with lmdb_file.LmdbReader(str(tmp_path / "db")) as env:
+        assert env.stat()["entries"] == len(items) and env.psize == psize and env.depth == stat["depth"]
+        for k, v in items.items():
+            assert env.get(k) == v, k
+        for missing in (b"a", b"image-000000000", b"image-%09d" % (count + 1), b"zzzz", b"label", b"num-sample", b"num-samples0"):
+            assert env.get(missing) is None
+        assert [k for k, _ in env.items()] == sorted(items)
+        with env.begin(write=False) as txn:                        # the reference's access pattern, dataset.py:65-66
+            assert int(txn.get("num-samples".encode())) == count
+    # the same through the lmdb.open(...) spelling
+    env = lmdb_file.open(str(tmp_path / "db"), readonly=True, lock=False, readahead=False, meminit=False)
+    assert env.get("label-000000007") == b"w7"
+    env.close()
+
+
+def test_lmdb_page_structure(tmp_path):
+    """What liblmdb checks when it opens a file: magic / version / page size in meta 0, the newer meta wins, page numbers
+    stored in the pages, branch page first key empty, leaf nodes sorted."""
+    items = {b"k%05d" % i: b"v" * (i % 50) for i in range(2000)}
+    lmdb_file.write_lmdb(str(tmp_path / "db"), items, psize=512)
+    raw = open(tmp_path / "db" / "data.mdb", "rb").read()
+    assert len(raw) % 512 == 0
+    for pg in range(len(raw) // 512):
+        pgno, _pad, flags = struct.unpack_from("<QHH", raw, pg * 512)
+        if flags & lmdb_file.P_OVERFLOW and pgno != pg:
+            continue                                               # inside an overflow run: data, not a header
+        assert pgno == pg
+    magic, version = struct.unpack_from("<II", raw, 16)
+    assert magic == 0xBEEFC0DE and version == 1
+    assert struct.unpack_from("<I", raw, 16 + 24)[0] == 512        # mm_dbs[FREE].md_pad = page size
+    tx0 = struct.unpack_from("<Q", raw, 16 + 24 + 96 + 8)[0]
+    tx1 = struct.unpack_from("<Q", raw, 512 + 16 + 24 + 96 + 8)[0]
+    assert (tx0, tx1) == (0, 1)
+    env = lmdb_file.LmdbReader(str(tmp_path / "db"))
+    off, flags, lower, _ = env._page(env.root)
+    assert flags & lmdb_file.P_BRANCH
+    assert env._node(off, 0)[3] == 0                               # implicit lowest key
+    env.close()
+
+
+def test_lmdb_errors(tmp_path):
+    with pytest.raises(lmdb_file.LmdbError):
+        lmdb_file.LmdbReader(str(tmp_path / "nope"))
+    os.makedirs(tmp_path / "bad")
+    (tmp_path / "bad" / "data.mdb").write_bytes(b"\0" * 8192)
+    with pytest.raises(lmdb_file.LmdbError, match="magic"):
+        lmdb_file.LmdbReader(str(tmp_path / "bad"))
+    with pytest.raises(ValueError):
+        lmdb_file.write_lmdb(str(tmp_path / "dup"), [(b"a", b"1"), (b"a", b"2")])
+    empty = lmdb_file.write_lmdb(str(tmp_path / "empty"), {})
+    assert empty["entries"] == 0 and lmdb_file.LmdbReader(str(tmp_path / "empty")).get(b"x") is None
+
+
+def test_kmeans_oracle_is_the_reference_function():
+    """oracle/datapipe_np.kmeans2_mask == the outputs Dino/utils/kmeans.py::clusterpixels wrote (tools/gen_golden.py)."""
+    z = np.load(os.path.join(HERE, "golden", "kmeans_masks.npz"))
+    off = 0
+    assert len(z["hw"]) >= 40
+    for h, w in z["hw"]:
+        g, m = z["gray"][off:off + h * w].reshape(h, w), z["mask"][off:off + h * w].reshape(h, w)
+        off += h * w
+        np.testing.assert_array_equal(D.kmeans2_mask(g), m)
+    # PIL's "L" conversion (generate_mask.py:69)
+    from PIL import Image
+    rgb = np.random.RandomState(0).randint(0, 256, size=(9, 13, 3)).astype(np.uint8)
+    np.testing.assert_array_equal(D.gray_from_rgb(rgb), np.asarray(Image.fromarray(rgb).convert("L")))
+
+
+def test_theta_is_the_datasets_composition():
+    """datasetsupervised_kmeans.py:63-70 with an original image of another size: metric = W_inv . M_orig^-1 . W,
+    theta = W_ . metric . W_^-1.  The device augmenter draws M at network resolution; both must give the same theta for
+    the same warp."""
+    rs = np.random.RandomState(3)
+    img_h, img_w, oh, ow = 32, 128, 47, 211
+    for _ in range(20):
+        m_net = affine_pixel_matrix(rs, img_h, img_w)
+        w_scale, h_scale = ow / img_w, oh / img_h
+        Wm = np.array([[w_scale, 0, 0], [0, h_scale, 0], [0, 0, 1]])
+        W_inv = np.array([[1 / w_scale, 0, 0], [0, 1 / h_scale, 0], [0, 0, 1]])
+        m_orig = Wm @ m_net @ W_inv                                 # the same warp expressed at the original resolution
+        metric = W_inv @ np.linalg.inv(m_orig) @ Wm
+        W_ = np.array([[2 / (img_w - 1), 0, -1], [0, 2 / (img_h - 1), -1], [0, 0, 1]])
+        want = np.array(W_ @ metric @ np.linalg.inv(W_), dtype=np.float32)
+        np.testing.assert_allclose(theta_from_pixel_matrix(m_net, img_h, img_w), want, rtol=1e-5, atol=1e-6)
+    th = sample_theta(np.random.RandomState(0), 2000, img_h, img_w)
+    ident = (th == np.eye(3, dtype=np.float32)).all(axis=(1, 2)).mean()
+    assert 0.26 < ident < 0.34                                      # `random.random() > 0.3` -> warp
+    assert np.allclose(th[:, 2], [0, 0, 1])
+    p = sample_colour_params(np.random.RandomState(0), 500, 5)
+    assert p.shape == (500, 2, 16) and np.isfinite(p).all() and (p[..., 3] > 0).all() and (p[..., 2] < 6).all()
+    from ccd_amd.dataset.augment import IDENTITY_PARAMS
+    assert (sample_colour_params(np.random.RandomState(0), 4, 0)[..., :13] == IDENTITY_PARAMS[:13]).all()   # severity 0: no colour change
+
+
+def test_resize_is_cv2_inter_linear_geometry():
+    """Half-pixel centres, no antialiasing: torch's bilinear (align_corners=False) is the same map."""
+    rs = np.random.RandomState(0)
+    for (h, w) in [(47, 211), (20, 64), (32, 128), (64, 300), (9, 31)]:
+        img = rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+        got = resize_bilinear(img, 32, 128)
+        want = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None].double(), size=(32, 128), mode="bilinear",
+                             align_corners=False)[0].permute(1, 2, 0).numpy()
+        assert got.dtype == np.uint8 and np.abs(got.astype(np.float64) - want).max() <= 0.5 + 1e-9
+
+
+def _make_lmdbs(tmp_path, n=12):
+    rs = np.random.RandomState(5)
+    root = tmp_path / "data" / "training" / "label" / "Synth" / "MJ"
+    mask_root = tmp_path / "Mask"
+    imgs, recs, mrecs = [], {}, {}
+    for i in range(1, n + 1):
+        h, w = int(rs.randint(16, 60)), int(rs.randint(40, 220))
+        img = rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+        imgs.append(img)
+        recs[b"image-%09d" % i] = _png(img)
+        recs[b"label-%09d" % i] = b"word"
+        mrecs[b"mask-%09d" % i] = _png(D.kmeans2_mask(D.gray_from_rgb(img)), mode="L")
+    recs[b"image-%09d" % 3] = b"not a png"                          # corrupted record -> another sample is drawn
+    del mrecs[b"mask-%09d" % 5]                                      # missing mask -> zeros
+    recs[b"num-samples"] = str(n).encode(); mrecs[b"num-samples"] = str(n).encode()
+    lmdb_file.write_lmdb(str(root), recs)
+    lmdb_file.write_lmdb(str(mask_root) + "/label/Synth/MJ", mrecs)
+    return str(root), str(mask_root), imgs
+
+
+def test_dataset_records_and_collate(tmp_path):
+    root, mask_root, imgs = _make_lmdbs(tmp_path)
+    ds = ImageDatasetSelfSupervisedKmeans(path=root, mask_path=mask_root, img_h=32, img_w=128, is_training=True,
+                                          data_aug=True, augmentation_severity=5, charset_path="ignored", max_length=25)
+    assert len(ds) == 12
+    image, mask = ds[0]
+    assert image.dtype == torch.uint8 and tuple(image.shape) == (32, 128, 3) and tuple(mask.shape) == (32, 128)
+    np.testing.assert_array_equal(image.numpy(), resize_bilinear(imgs[0], 32, 128))
+    want_mask = (resize_bilinear(D.kmeans2_mask(D.gray_from_rgb(imgs[0])).astype(np.float32), 32, 128) >= 0.5)
+    np.testing.assert_array_equal(mask.numpy(), want_mask.astype(np.float32))
+    assert set(np.unique(mask.numpy())) <= {0.0, 1.0}
+    assert ds[2] is not None and tuple(ds[2][0].shape) == (32, 128, 3)        # corrupted -> replacement sample
+    assert float(ds[4][1].abs().sum()) == 0.0                                 # no mask record -> zero mask
+    loader = torch.utils.data.DataLoader(ds, batch_size=4, collate_fn=collate_uint8, num_workers=2, shuffle=False)
+    batches = list(loader)
+    assert len(batches) == 3 and tuple(batches[0][0].shape) == (4, 32, 128, 3) and batches[0][1].dtype == torch.float32
+    ds_eval = ImageDatasetSelfSupervisedKmeans(path=root, mask_path=mask_root, img_h=32, img_w=128, is_training=False)
+    assert ds_eval[2] is None and collate_uint8([ds_eval[1], ds_eval[2]])[0].shape[0] == 1
+    half = ImageDatasetSelfSupervisedKmeans(path=root, mask_path=mask_root, img_w=128, data_portion=0.5)
+    assert len(half) == 6
+    with pytest.raises(AssertionError):
+        ImageDatasetSelfSupervisedKmeans(path=root + "_missing", mask_path=mask_root)

@@ -188,3 +188,11 @@ def test_mlp_fused_repeatable(hip):
             ref = cur
         else:
             assert all(torch.equal(a, b) for a, b in zip(ref, cur)), "mlp_fused is not run-to-run deterministic"
+
+
+def test_kmeans2_mask(hip):
+    kc.check_kmeans2_mask(hip.device)
+
+
+def test_augment_views(hip):
+    kc.check_augment_views(hip.device)

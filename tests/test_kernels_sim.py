@@ -184,3 +184,11 @@ def test_mlp_fused_sim(sim):
     """Ragged last tile, several tiles per workgroup (1 CU), a dropped sample, both instantiations of E."""
     kc.check_mlp_fused(sim.device, M=300, E=128, H=256, rps=128)
     kc.check_mlp_fused(sim.device, M=200, E=384, H=128, rps=8, store_u=False)     # per-row DropPath scales
+
+
+def test_kmeans2_mask_sim(sim):
+    kc.check_kmeans2_mask(sim.device, extra=4)
+
+
+def test_augment_views_sim(sim):
+    kc.check_augment_views(sim.device, B=3, H=16, W=40)

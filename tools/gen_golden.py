@@ -510,6 +510,53 @@ def gen_finetune():
     print("finetune_step.npz written")
 
 
+def word_image(rs, h, w, n_chars, fg, bg, noise, blur=True):
+    """A synthetic gray word image: n_chars blocky glyphs of gray level fg on bg, box-blurred edges + gaussian noise."""
+    img = np.full((h, w), float(bg))
+    cw = max(2, (w - 4) // max(n_chars, 1))
+    for c in range(n_chars):
+        x0 = 2 + c * cw + rs.randint(0, max(1, cw // 4))
+        gw = max(1, int(cw * rs.uniform(0.4, 0.8)))
+        y0 = rs.randint(1, max(2, h // 4))
+        gh = max(1, int(h * rs.uniform(0.5, 0.75)))
+        img[y0:y0 + gh, x0:x0 + gw] = fg
+        if gw > 3 and gh > 4 and rs.uniform() < 0.5:          # a hole, so that glyphs are not convex
+            img[y0 + gh // 3:y0 + 2 * gh // 3, x0 + 1:x0 + gw - 1] = bg
+    if blur:
+        pad = np.pad(img, 1, mode="edge")
+        img = sum(pad[dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3)) / 9.0
+    img = img + rs.normal(0, noise, size=img.shape)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def gen_kmeans():
+    """Fixtures of `clusterpixels(im, 2)` (Dino/utils/kmeans.py:7-23 = mask_create/generate_mask.py:13-29): the REAL function
+    (scipy.cluster.vq.kmeans with its own random restarts) on synthetic word images, run 3 times per image with different
+    numpy seeds - an image is kept only when the three runs agree (the reference itself is deterministic there)."""
+    np.float = float                       # the reference was written for numpy < 1.24 (`im.astype(np.float)`)
+    from Dino.utils.kmeans import clusterpixels
+    rs = np.random.RandomState(7)
+    imgs, masks, dropped = [], [], 0
+    shapes = [(32, 100), (31, 97), (48, 160), (20, 64), (64, 256), (17, 33), (40, 40), (7, 9)]
+    for i in range(48):
+        h, w = shapes[i % len(shapes)]
+        dark_text = rs.uniform() < 0.5
+        fg, bg = (rs.randint(10, 90), rs.randint(150, 245)) if dark_text else (rs.randint(160, 250), rs.randint(5, 100))
+        img = word_image(rs, h, w, rs.randint(1, 9), fg, bg, noise=rs.uniform(0, 12))
+        outs = []
+        for seed in (0, 1, 2):
+            np.random.seed(seed)
+            outs.append(np.asarray(clusterpixels(img, 2)).astype(np.uint8))
+        if not all((o == outs[0]).all() for o in outs[1:]):
+            dropped += 1
+            continue
+        imgs.append(img); masks.append(outs[0])
+    flat_i = np.concatenate([a.reshape(-1) for a in imgs]); flat_m = np.concatenate([a.reshape(-1) for a in masks])
+    np.savez_compressed(os.path.join(GOLD, "kmeans_masks.npz"), gray=flat_i, mask=flat_m,
+                        hw=np.array([a.shape for a in imgs], dtype=np.int32))
+    print(f"kmeans_masks.npz written: {len(imgs)} images ({dropped} dropped: reference output depends on its random restarts)")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -517,7 +564,7 @@ if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     os.chdir("/root/reference")  # Config() and friends use relative paths; we never write here
     torch.set_num_threads(8)
-    todo = [a.only] if a.only else ["sched", "ccl", "tiny", "small", "small3", "keys", "finetune"]
+    todo = [a.only] if a.only else ["sched", "ccl", "tiny", "small", "small3", "keys", "finetune", "kmeans"]
     for t in todo:
         {"sched": gen_sched, "ccl": gen_ccl, "tiny": gen_tiny, "small": gen_small, "small3": gen_small3, "keys": gen_keys,
-         "finetune": gen_finetune}[t]()
+         "finetune": gen_finetune, "kmeans": gen_kmeans}[t]()

@@ -72,23 +72,61 @@ class _ScalarLog:
             self.fh.flush()
 
 
+def _lmdb_dirs(paths):
+    """The reference's `_get_dataset` walk (train.py:414-421): a root either IS an LMDB environment or holds sub-trees of them."""
+    out = []
+    for p in paths:
+        p = str(p)
+        if os.path.isfile(os.path.join(p, "data.mdb")):
+            out.append(p)
+            continue
+        if not os.path.isdir(p):
+            raise FileNotFoundError(f"dataset root {p} does not exist")
+        subs = sorted(f.path for f in os.scandir(p) if f.is_dir())
+        if not subs:
+            raise FileNotFoundError(f"dataset root {p} holds no LMDB environment")
+        out.extend(_lmdb_dirs(subs))
+    return out
+
+
 def _get_databaunch(config):
-    if config.dataset_scheme != "synthetic":
-        raise NotImplementedError(
-            "LMDB datasets (ImageDatasetSelfSupervisedKmeans) are not part of this implementation; set "
-            "`dataset: {scheme: synthetic}` to train on seeded synthetic batches with the same tensor contract")
-    n = int(config.dataset_synthetic_samples or 64 * config.batch_size_per_gpu * utils.get_world_size())
-    ds = SyntheticPretrainSet(n, seed=int(config.seed or 0))
+    """-> (loader, view_maker): `view_maker` (device augmentation, ccd_amd/dataset) is None for synthetic batches, which already
+    are (image_tensors, masks, metrics)."""
+    world, rank = utils.get_world_size(), utils.get_rank()
+    if config.dataset_scheme == "synthetic":
+        n = int(config.dataset_synthetic_samples or 64 * config.batch_size_per_gpu * world)
+        ds = SyntheticPretrainSet(n, seed=int(config.seed or 0))
+        sampler = torch.utils.data.DistributedSampler(ds, shuffle=True)
+        return torch.utils.data.DataLoader(ds, sampler=sampler, batch_size=config.batch_size_per_gpu, num_workers=0,
+                                           pin_memory=bool(config.dataset_pin_memory), drop_last=True), None
+    if config.dataset_scheme != "selfsupervised_kmeans":
+        raise NotImplementedError(f"dataset.scheme {config.dataset_scheme!r}: pretraining reads `selfsupervised_kmeans` LMDB "
+                                  "datasets (or `synthetic` batches)")
+    from ccd_amd.dataset import DeviceViewMaker, ImageDatasetSelfSupervisedKmeans, collate_uint8
+    h, w = int(config.dataset_image_height or 32), int(config.dataset_image_width or 128)
+    if (h, w) != (32, 128):
+        raise ValueError(f"the character-region kernels are built for 32 x 128 inputs, not {h} x {w}")
+    kwargs = dict(img_h=h, img_w=w, is_training=True, data_aug=bool(config.dataset_data_aug),
+                  multiscales=bool(config.dataset_multiscales), data_portion=float(config.dataset_portion or 1.0),
+                  mask=True, mask_path=config.dataset_mask_path or "",
+                  augmentation_severity=int(config.dataset_augmentation_severity or 1))
+    parts = [ImageDatasetSelfSupervisedKmeans(path=p, **kwargs) for p in _lmdb_dirs(config.dataset_train_roots)]
+    ds = parts[0] if len(parts) == 1 else torch.utils.data.ConcatDataset(parts)
     sampler = torch.utils.data.DistributedSampler(ds, shuffle=True)
-    return torch.utils.data.DataLoader(ds, sampler=sampler, batch_size=config.batch_size_per_gpu, num_workers=0,
-                                       pin_memory=bool(config.dataset_pin_memory), drop_last=True)
+    workers = int(config.dataset_num_workers or 0)
+    loader = torch.utils.data.DataLoader(ds, sampler=sampler, batch_size=config.batch_size_per_gpu, num_workers=workers,
+                                         collate_fn=collate_uint8, pin_memory=bool(config.dataset_pin_memory), drop_last=True,
+                                         persistent_workers=workers > 0)
+    views = DeviceViewMaker(img_h=h, img_w=w, severity=kwargs["augmentation_severity"], data_aug=kwargs["data_aug"],
+                            seed=int(config.seed or 0) * 1000 + rank)
+    return loader, views
 
 
 def train(config):
     utils.init_distributed_mode(config)
     utils.fix_random_seeds(config.seed)
     logging.info("Construct dataset.")
-    loader = _get_databaunch(config)
+    loader, view_maker = _get_databaunch(config)
     config.iter_num = len(loader)
     world = utils.get_world_size()
 
@@ -152,9 +190,11 @@ def train(config):
         loader.sampler.set_epoch(train_epoch)
         metric_logger = utils.MetricLogger(delimiter="  ")
         header = "Epoch: [{}/{}]".format(train_epoch, config.training_epochs)
-        for image_tensors, masks, metrics in metric_logger.log_every(loader, 10, header):
+        for batch in metric_logger.log_every(loader, 10, header):
             if iteration >= niter:
                 break
+            # LMDB batches arrive as uint8 samples + masks: the three views and theta are made on the device
+            image_tensors, masks, metrics = batch if view_maker is None else view_maker(*batch)
             epoch = int((iteration + 1) * global_bs / config.imgnet_based)
             if epoch != global_epoch:          # pseudo-epoch boundary: sync meters, checkpoint, log.txt
                 global_epoch = epoch
