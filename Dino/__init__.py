@@ -20,6 +20,11 @@ _ALIASES = {
     "Dino.decoder.nrtr_decoder": "ccd_amd.decoder.nrtr_decoder",
     "Dino.convertor": "ccd_amd.convertor",
     "Dino.convertor.attn": "ccd_amd.convertor.attn",
+    "Dino.metric": "ccd_amd.metric",
+    "Dino.metric.eval_acc": "ccd_amd.metric.eval_acc",
+    "Dino.dataset": "ccd_amd.dataset",
+    "Dino.dataset.dataset_pretrain": "ccd_amd.dataset.dataset_pretrain",
+    "Dino.dataset.datasetsupervised_kmeans": "ccd_amd.dataset.datasetsupervised_kmeans",
     "Dino.utils": "ccd_amd.utils",
     "Dino.utils.utils": "ccd_amd.utils.utils",
 }

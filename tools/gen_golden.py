@@ -510,6 +510,62 @@ def gen_finetune():
     print("finetune_step.npz written")
 
 
+def gen_eval():
+    """eval_acc.npz: the REAL `TextAccuracy.compute` (Dino/metric/eval_acc.py:27-64, as test.py:198-203 drives it) on the
+    seeded vit_tiny recogniser: predictions of three batches, ground truths derived from them (exact, case / punctuation
+    variants, edits, unrelated words), and the metric dictionary."""
+    from Dino.metric.eval_acc import TextAccuracy
+    model = build_reference_finetune("vit_tiny", 2, seed=0)
+    model.eval()
+    g = torch.Generator().manual_seed(4321)
+    batches = [torch.randn(6, 3, 32, 128, generator=g) for _ in range(3)]
+    with torch.no_grad():
+        preds = []
+        for img in batches:
+            idx, _ = model.label_convertor.tensor2idx(model(img, None, return_loss=False))
+            preds.append(model.label_convertor.idx2str(idx))
+
+    def variant(k, p):
+        if k % 6 == 0:
+            return p                                              # exact
+        if k % 6 == 1:
+            return p.swapcase()                                   # case differs only
+        if k % 6 == 2:
+            return (p[:2] + "-" + p[2:] + "!") if p else "!"       # punctuation the normalisation removes
+        if k % 6 == 3:
+            return (p[:-1] + "x") if p else "x"                   # one substitution
+        if k % 6 == 4:
+            return "unrelated" + str(k)
+        return p[1:] if len(p) > 1 else p + "q"                   # one deletion
+    gts = [[variant(6 * b + i, p) for i, p in enumerate(ps)] for b, ps in enumerate(preds)]
+
+    class It:
+        def __init__(self):
+            self.k = 0
+
+        def __len__(self):
+            return len(batches)
+
+        def next(self):                                           # the reference calls iterator.next() (eval_acc.py:30)
+            self.k += 1
+            return batches[self.k - 1], [tuple(gts[self.k - 1])]
+
+        __next__ = next
+
+    class Loader:
+        def __iter__(self):
+            return It()
+
+    metric = TextAccuracy(charset_path=None, case_sensitive=False, model_eval="vision")
+    with torch.no_grad():
+        res = metric.compute(torch.nn.DataParallel(model), Loader())
+    out = {"pred": np.array([p for ps in preds for p in ps]), "gt": np.array([t for ts in gts for t in ts]),
+           "names": np.array(list(res.keys())), "values": np.array([float(v) for v in res.values()]),
+           "image_stat": np.stack([stat(b) for b in batches])}
+    np.savez_compressed(os.path.join(GOLD, "eval_acc.npz"), **out)
+    print("eval_acc.npz written:", {k: round(float(v), 4) for k, v in res.items() if k != "time"}, out["pred"][:4], out["gt"][:4])
+
+
 def word_image(rs, h, w, n_chars, fg, bg, noise, blur=True):
     """A synthetic gray word image: n_chars blocky glyphs of gray level fg on bg, box-blurred edges + gaussian noise."""
     img = np.full((h, w), float(bg))
@@ -564,7 +620,7 @@ if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     os.chdir("/root/reference")  # Config() and friends use relative paths; we never write here
     torch.set_num_threads(8)
-    todo = [a.only] if a.only else ["sched", "ccl", "tiny", "small", "small3", "keys", "finetune", "kmeans"]
+    todo = [a.only] if a.only else ["sched", "ccl", "tiny", "small", "small3", "keys", "finetune", "kmeans", "eval"]
     for t in todo:
         {"sched": gen_sched, "ccl": gen_ccl, "tiny": gen_tiny, "small": gen_small, "small3": gen_small3, "keys": gen_keys,
-         "finetune": gen_finetune, "kmeans": gen_kmeans}[t]()
+         "finetune": gen_finetune, "kmeans": gen_kmeans, "eval": gen_eval}[t]()

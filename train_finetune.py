@@ -8,8 +8,8 @@ The reference wraps the model in nn.DataParallel (one process, train_finetune.py
 with gradient averaging over RCCL (ccd_amd.parallel.DataParallel) - state-dict keys keep the
 `module.` prefix either way, so `pretrain_checkpoint` (the teacher of a pretraining run, :190-198) and `checkpoint`
 ({net, optimizer, iteration}, :199-207, 382-388) load and save in the reference's layout.
-Data: `dataset.scheme: synthetic` gives seeded labelled batches; the LMDB pipeline (Dino/dataset/*) and the benchmark
-evaluation (eval_acc.py) are outside this implementation's scope.
+Data: `dataset.scheme: supervised` reads the labelled LMDB datasets (ccd_amd/dataset/dataset_pretrain.py), `synthetic` gives
+seeded labelled batches; benchmark evaluation is test.py (TextAccuracy, ccd_amd/metric/eval_acc.py).
 """
 import argparse
 import logging
@@ -45,10 +45,23 @@ class SyntheticLabelledSet(torch.utils.data.Dataset):
 
 
 def _loader(config, convertor, world, rank):
-    if config.dataset_scheme != "synthetic":
-        raise NotImplementedError("LMDB datasets are not part of this implementation; set `dataset: {scheme: synthetic}` "
-                                  "to train on seeded synthetic labelled batches with the same tensor contract")
     bs = int(config.dataset_train_batch_size)
+    if config.dataset_scheme == "supervised":
+        # labelled LMDB datasets (Dino/dataset/dataset_pretrain.py:18-277; roots walked like train_finetune.py:96-121)
+        from ccd_amd.dataset.dataset_pretrain import ImageDataset, collate_fn_filter_none
+        from train import _lmdb_dirs
+        kw = dict(img_h=int(config.dataset_image_height or 32), img_w=int(config.dataset_image_width or 128),
+                  max_length=int(config.decoder_max_seq_len or 25), type=config.dataset_charset_type or "DICT90",
+                  data_portion=float(config.dataset_portion or 1.0), is_training=True)
+        parts = [ImageDataset(path=p, **kw) for p in _lmdb_dirs(config.dataset_train_roots)]
+        ds = parts[0] if len(parts) == 1 else torch.utils.data.ConcatDataset(parts)
+        sampler = torch.utils.data.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True) if world > 1 else None
+        return torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=sampler is None, sampler=sampler,
+                                           num_workers=int(config.dataset_num_workers or 0), collate_fn=collate_fn_filter_none,
+                                           pin_memory=bool(config.dataset_pin_memory), drop_last=True)
+    if config.dataset_scheme != "synthetic":
+        raise NotImplementedError(f"dataset.scheme {config.dataset_scheme!r}: finetuning reads `supervised` LMDB datasets "
+                                  "(or `synthetic` labelled batches)")
     n = int(config.dataset_synthetic_samples or 32 * bs * world)
     ds = SyntheticLabelledSet(n, convertor, seed=int(config.seed or 0))
     sampler = torch.utils.data.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True) if world > 1 else None
