@@ -212,9 +212,30 @@ int ccd_gemm_nt_resid_ln(const ccd_bf16* A, long lda, const ccd_bf16* B, long ld
     CCD_CHECK(CCD_ALIGNED16(A) && CCD_ALIGNED16(B) && CCD_ALIGNED16(C) && CCD_ALIGNED16(resid) && CCD_ALIGNED16(y), CCD_EINVAL);
     if (M == 0) return CCD_OK;
     CCD_CHECK(M > 0 && N > 0 && K > 0 && rows_per_sample > 0, CCD_EINVAL);
-    CCD_CHECK(N <= ccd::GR_BN && N % 8 == 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && ldr % 4 == 0 &&
+    CCD_CHECK(N <= 512 && N % 8 == 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && ldr % 4 == 0 &&
               ldy % 8 == 0, CCD_ESHAPE);
     CCD_CHECK(((long)M * lda + K) * 2 < CCD_MAX_OPERAND_BYTES && ((long)N * ldb + K) * 2 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
+    const int cus = ccd_grid_cus();
+    // (measured at N = 384: 0.131 ms with gemm_row384.h's 8-wave tile - whose residual rows stream in under the staging
+    // barrier - against 0.198 ms here, where the epilogue starts after the last MFMA: the row-owner kernel is the default
+    // only where the other does not exist, N = 512; policy rowgemm = 2 forces it)
+    if (ccd_policy().rowgemm && (N == 512 || ccd_policy().rowgemm == 2) && (N == 128 || N == 256 || N == 384 || N == 512) &&
+        K % (64 * ccd::rg_ring(N)) == 0 &&
+        ((long)M + (long)cus * ccd::RG_BM) * lda * 2 < CCD_MAX_OPERAND_BYTES && (long)M * ldr * 4 < CCD_MAX_OPERAND_BYTES &&
+        (long)M * ldc * 4 < CCD_MAX_OPERAND_BYTES) {
+        ccd::RowGemmParams q = ccd::RowGemmParams();
+        q.A = A; q.lda = lda; q.W = B; q.ldw = ldb; q.M = M; q.K = K; q.gamma = ln_gamma; q.ln_beta = ln_beta; q.ln_eps = ln_eps;
+        q.bias = bias; q.resid = resid; q.ldr = ldr; q.out = C; q.ldc = ldc; q.ln_y = y; q.ld_y = ldy; q.ln_mean = mean;
+        q.ln_rstd = rstd; q.rowscale = rowscale; q.rows_per_sample = rows_per_sample; q.lab = ccd_policy().lab;
+        const int tiles = (M + ccd::RG_BM - 1) / ccd::RG_BM, smem = ccd::rg_smem_bytes(N);
+        const dim3 grid(tiles < cus ? tiles : cus), block(ccd::RG_THREADS);
+        if (N == 512) CCD_LAUNCH((ccd::rowgemm_kernel<512, ccd::rg_ring(512), ccd::RG_RESID_LN>), grid, block, smem, stream, q);
+        else if (N == 384) CCD_LAUNCH((ccd::rowgemm_kernel<384, ccd::rg_ring(384), ccd::RG_RESID_LN>), grid, block, smem, stream, q);
+        else if (N == 256) CCD_LAUNCH((ccd::rowgemm_kernel<256, ccd::rg_ring(256), ccd::RG_RESID_LN>), grid, block, smem, stream, q);
+        else CCD_LAUNCH((ccd::rowgemm_kernel<128, ccd::rg_ring(128), ccd::RG_RESID_LN>), grid, block, smem, stream, q);
+        return ccd_rt_last_error();
+    }
+    CCD_CHECK(N <= ccd::GR_BN, CCD_ESHAPE);
     ccd::GemmParams p = ccd::GemmParams();
     p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.C = C; p.ldc = ldc; p.bias = bias;
     p.resid = resid; p.ldr = ldr; p.rowscale = rowscale; p.rows_per_sample = rows_per_sample; p.alpha = 1.0f; p.rows_mul = 1;
@@ -233,11 +254,11 @@ int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, 
     CCD_CHECK(CCD_ALIGNED16(A) && CCD_ALIGNED16(B) && CCD_ALIGNED16(x) && CCD_ALIGNED16(g) && CCD_ALIGNED16(gb), CCD_EINVAL);
     if (M == 0) return CCD_OK;
     CCD_CHECK(M > 0 && N > 0 && K > 0 && (!rowscale || rows_per_sample > 0), CCD_EINVAL);
-    CCD_CHECK(N <= ccd::GR_BN && N % 8 == 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldx % 4 == 0 && ldg % 4 == 0 &&
+    CCD_CHECK(N <= 512 && N % 8 == 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldx % 4 == 0 && ldg % 4 == 0 &&
               (!gb || ldgb % 4 == 0), CCD_ESHAPE);
     CCD_CHECK(((long)M * lda + K) * 2 < CCD_MAX_OPERAND_BYTES && ((long)N * ldb + K) * 2 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
     const int cus = ccd_grid_cus();
-    if (ccd_policy().rowgemm && (N == 128 || N == 256 || N == 384) && K % (64 * ccd::rg_ring(N)) == 0 && ldg % 4 == 0 &&
+    if (ccd_policy().rowgemm && (N == 128 || N == 256 || N == 384 || N == 512) && K % (64 * ccd::rg_ring(N)) == 0 && ldg % 4 == 0 &&
         ((long)M + (long)cus * ccd::RG_BM) * lda * 2 < CCD_MAX_OPERAND_BYTES && (long)M * ldx * 4 < CCD_MAX_OPERAND_BYTES &&
         (long)M * ldg * 4 < CCD_MAX_OPERAND_BYTES) {
         ccd::RowGemmParams q;
@@ -245,14 +266,17 @@ int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, 
         q.gamma = gamma; q.g = g; q.ldg = ldg; q.accumulate = accumulate; q.dgamma = dgamma; q.dbeta = dbeta; q.gb = gb;
         q.ld_gb = ldgb; q.rowscale = gb ? rowscale : nullptr; q.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
         q.dbias = gb ? dbias : nullptr; q.lab = ccd_policy().lab;
+        q.bias = nullptr; q.resid = nullptr; q.out = nullptr; q.ln_beta = nullptr; q.ln_y = nullptr; q.ln_mean = q.ln_rstd = nullptr;
+        q.ldr = q.ldc = q.ld_y = 0; q.ln_eps = 0.f;
         const int tiles = (M + ccd::RG_BM - 1) / ccd::RG_BM, smem = ccd::rg_smem_bytes(N);
         const dim3 grid(tiles < cus ? tiles : cus), block(ccd::RG_THREADS);
-        if (N == 384 && ccd_policy().rowgemm == 2 && K % 384 == 0) CCD_LAUNCH((ccd::rowgemm_lnbwd_kernel<384, 6>), grid, block, smem, stream, q);
-        else if (N == 384) CCD_LAUNCH((ccd::rowgemm_lnbwd_kernel<384, ccd::rg_ring(384)>), grid, block, smem, stream, q);
-        else if (N == 256) CCD_LAUNCH((ccd::rowgemm_lnbwd_kernel<256, ccd::rg_ring(256)>), grid, block, smem, stream, q);
-        else CCD_LAUNCH((ccd::rowgemm_lnbwd_kernel<128, ccd::rg_ring(128)>), grid, block, smem, stream, q);
+        if (N == 512) CCD_LAUNCH((ccd::rowgemm_kernel<512, ccd::rg_ring(512), ccd::RG_LNBWD>), grid, block, smem, stream, q);
+        else if (N == 384) CCD_LAUNCH((ccd::rowgemm_kernel<384, ccd::rg_ring(384), ccd::RG_LNBWD>), grid, block, smem, stream, q);
+        else if (N == 256) CCD_LAUNCH((ccd::rowgemm_kernel<256, ccd::rg_ring(256), ccd::RG_LNBWD>), grid, block, smem, stream, q);
+        else CCD_LAUNCH((ccd::rowgemm_kernel<128, ccd::rg_ring(128), ccd::RG_LNBWD>), grid, block, smem, stream, q);
         return ccd_rt_last_error();
     }
+    CCD_CHECK(N <= ccd::GR_BN, CCD_ESHAPE);
     ccd::GemmParams p = ccd::GemmParams();
     p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.C = g; p.ldc = ldg; p.resid = x; p.ldr = ldx;
     p.rowscale = gb ? rowscale : nullptr; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; p.alpha = 1.0f;
@@ -273,7 +297,7 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
               CCD_ALIGNED16(ln_y) && CCD_ALIGNED16(u), CCD_EINVAL);
     if (M == 0) return CCD_OK;
     CCD_CHECK(M > 0 && H > 0 && (!rowscale || rows_per_sample > 0), CCD_EINVAL);
-    CCD_CHECK((E == 128 || E == 256 || E == 384) && H % 64 == 0 && ldy % 8 == 0 && ld1 % 8 == 0 && ld2 % 8 == 0 && ldr % 4 == 0 &&
+    CCD_CHECK((E == 128 || E == 256 || E == 384 || E == 512) && H % 64 == 0 && ldy % 8 == 0 && ld1 % 8 == 0 && ld2 % 8 == 0 && ldr % 4 == 0 &&
               ldc % 4 == 0 && ld_y % 8 == 0 && (!u || ldu % 8 == 0), CCD_ESHAPE);
     CCD_CHECK((long)H * ld1 * 2 < CCD_MAX_OPERAND_BYTES && (long)E * ld2 * 2 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
     const int smem = ccd::mlp_smem_bytes(E, H);
@@ -285,7 +309,10 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
     p.ln_rstd = ln_rstd; p.u = u; p.ldu = ldu; p.M = M; p.H = H; p.lab = ccd_policy().lab;
     const int tiles = (M + ccd::MLP_BM - 1) / ccd::MLP_BM, cus = ccd_grid_cus();
     const dim3 grid(tiles < cus ? tiles : cus), block(ccd::MLP_THREADS);
-    if (E == 384) {
+    if (E == 512) {
+        if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<512, true>), grid, block, smem, stream, p);
+        else CCD_LAUNCH((ccd::mlp_fused_kernel<512, false>), grid, block, smem, stream, p);
+    } else if (E == 384) {
         if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<384, true>), grid, block, smem, stream, p);
         else CCD_LAUNCH((ccd::mlp_fused_kernel<384, false>), grid, block, smem, stream, p);
     } else if (E == 256) {

@@ -61,10 +61,12 @@ struct MlpParams {
     int lab;                // experiment switch (policy key "lab"): n > 0 delays odd workgroups by ~n * 8 k cycles
 };
 
-constexpr int MLP_NSLOT = 5, MLP_SCRATCH = 4096, MLP_THREADS = 256, MLP_BM = 128;
+constexpr int MLP_SCRATCH = 4096, MLP_THREADS = 256, MLP_BM = 128;
+// ring slots: 5 (four pieces ahead) where 160 KiB allow it; 3 at E = 512 (32-KiB pieces, H = 2048 vectors)
+__host__ __device__ constexpr int mlp_slots(int E) { return E <= 384 ? 5 : 3; }
 __host__ __device__ constexpr int mlp_piece_bytes(int E) { return 32 * E * 2; }
 __host__ __device__ inline int mlp_smem_bytes(int E, int H) {
-    return MLP_NSLOT * mlp_piece_bytes(E) + 4 * MLP_SCRATCH + (1536 + H + 3 * E) * 4;    // ring, scratch, Phi table, vectors
+    return mlp_slots(E) * mlp_piece_bytes(E) + 4 * MLP_SCRATCH + (1536 + H + 3 * E) * 4;    // ring, scratch, Phi table, vectors
 }
 // 16-byte slot swizzle of a 128-byte image row (rows taken modulo 32: a piece is a stack of 32-row blocks)
 __device__ __forceinline__ int mlp_swz(int row) { return (((row & 31) >> 1) ^ ((row & 31) >> 4)) & 7; }
@@ -136,9 +138,10 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
     constexpr int NT = E / 32;             // 32-column output tiles of a row
     constexpr int NTH = NT / 2;            // ... per W2 piece
     constexpr int PIECE = mlp_piece_bytes(E);
+    constexpr int MLP_NSLOT = mlp_slots(E);
     constexpr int AHEAD = MLP_NSLOT - 1;   // pieces issued ahead of the one being consumed
     constexpr int DEPTH = 6;               // fragment reads in flight ahead of their MFMA
-    static_assert(E % 128 == 0 && AHEAD == 4, "ring bookkeeping; a W1 piece is one K half in whole 64-wide k-tiles");
+    static_assert(E % 128 == 0 && AHEAD >= 2, "ring bookkeeping; a W1 piece is one K half in whole 64-wide k-tiles");
     char* smem = dynamic_smem();
     const int t = threadIdx.x, lane = t & 63, hf = lane >> 5, lq = lane & 31;
     const int w = uniform_i32(t >> 6);     // wave index as a scalar: everything derived from it stays in SGPRs

@@ -1,4 +1,6 @@
-// rowgemm.h - data-gradient products whose output row (E = 128 / 256 / 384 columns) fits ONE wave's accumulators, with the
+// rowgemm.h - products whose output row (E = 128 / 256 / 384 / 512 columns) fits ONE wave's accumulators, with a ROW-WISE
+// epilogue: RG_RESID_LN = bias + DropPath + fp32 residual + the next LayerNorm (Block.forward, vision_transformer.py:107-113:
+// attn.proj; replaces gemm_row384.h's EPI_RESID_LN), and RG_LNBWD = the data gradient of qkv / fc1 with the
 // LayerNorm backward pass of those rows as the epilogue (autograd of nn.LayerNorm in Block.forward,
 // vision_transformer.py:99,103,107-113):
 //     dy = A . W^T  (never written);  xhat = (x - mean) * rstd
@@ -41,12 +43,27 @@ struct RowGemmParams {
     const float* rowscale;
     int rows_per_sample;
     float* dbias;           // optional [E] += colsum(gb)
+    // EPI RG_RESID_LN:  out (f32) = resid + (A . W^T + bias) * rowscale[sample];  ln_y (bf16) = LayerNorm(out), mean / rstd saved
+    const float* bias;      // [E] or null
+    const float* resid;     // [M, E] fp32
+    long ldr;
+    float* out;             // [M, E] fp32
+    long ldc;
+    const float* ln_beta;   // (ln gamma = `gamma`)
+    float ln_eps;
+    bf16_t* ln_y;
+    long ld_y;
+    float* ln_mean;
+    float* ln_rstd;
     int lab;                // experiment switch (policy key "lab"): n > 0 delays odd workgroups by ~n * 8 k cycles
 };
 
-constexpr int RG_NSLOT = 5, RG_SCRATCH = 4096, RG_THREADS = 256, RG_BM = 128;
+constexpr int RG_SCRATCH = 4096, RG_THREADS = 256, RG_BM = 128;
+constexpr int RG_LNBWD = 0, RG_RESID_LN = 1;
+// ring slots: 5 (four pieces ahead) where 160 KiB allow it, 4 at E = 512 (32-KiB pieces)
+__host__ __device__ constexpr int rg_slots(int E) { return E <= 384 ? 5 : 4; }
 __host__ __device__ inline int rg_smem_bytes(int E) {
-    return RG_NSLOT * mlp_piece_bytes(E) + 4 * RG_SCRATCH + 4 * E * 4;      // ring, scratch, gamma, 3 column-sum vectors
+    return rg_slots(E) * mlp_piece_bytes(E) + 4 * RG_SCRATCH + 4 * E * 4;   // ring, scratch, gamma + 3 vectors (sums | beta, bias)
 }
 
 // activation k-blocks a lane holds (the newest arrives R - 1 blocks = 2 (R - 1) pieces ahead of its use): 48 registers at
@@ -82,8 +99,9 @@ __device__ __forceinline__ void rg_colsum16(const float (&v)[16], float* dst, in
     atomicAdd(dst + 8 * ((lq >> 2) & 3) + 4 * hf + (lq & 3), tot);
 }
 
-template <int E, int R>
-__global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_lnbwd_kernel(RowGemmParams p) {
+template <int E, int R, int EPI>
+__global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p) {
+    constexpr int RG_NSLOT = rg_slots(E);
     constexpr int KT = E / 64;             // ring requests (1 KiB wave instructions) per wave and piece
     constexpr int NT = E / 32, NTH = NT / 2;
     constexpr int PIECE = mlp_piece_bytes(E);
@@ -91,14 +109,20 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_lnbwd_kernel(RowGemmPar
     constexpr int DEPTH = 6;               // fragment reads in flight ahead of their MFMA
     constexpr int NSTEP = 4 * NTH;         // MFMAs per piece
     constexpr int WIN_VM = KT + 2;         // VMEM instructions per window
-    static_assert(E % 128 == 0 && NSTEP == 4 * KT && AHEAD == 4, "ring bookkeeping");
+    static_assert(E % 128 == 0 && NSTEP == 4 * KT && AHEAD >= 2, "ring bookkeeping");
     char* smem = dynamic_smem();
     const int t = threadIdx.x, lane = t & 63, hf = lane >> 5, lq = lane & 31;
     const int w = uniform_i32(t >> 6);
     char* scratch = smem + RG_NSLOT * PIECE + w * RG_SCRATCH;
     float* vga = reinterpret_cast<float*>(smem + RG_NSLOT * PIECE + 4 * RG_SCRATCH);
-    float* cs = vga + E;                   // [3][E]: dgamma, dbeta, dbias of this workgroup
-    for (int i = t; i < E; i += RG_THREADS) { vga[i] = p.gamma[i]; cs[i] = 0.f; cs[E + i] = 0.f; cs[2 * E + i] = 0.f; }
+    float* cs = vga + E;                   // RG_LNBWD: [3][E] dgamma, dbeta, dbias of this workgroup
+    float* vbe = vga + E;                  // RG_RESID_LN: beta, bias
+    float* vbi = vbe + E;
+    for (int i = t; i < E; i += RG_THREADS) {
+        vga[i] = p.gamma[i];
+        if (EPI == RG_LNBWD) { cs[i] = 0.f; cs[E + i] = 0.f; cs[2 * E + i] = 0.f; }
+        else { vbe[i] = p.ln_beta[i]; vbi[i] = p.bias ? p.bias[i] : 0.f; }
+    }
     __syncthreads();
 
     const int NB = p.K / 64, NP = 2 * NB;  // k-blocks, pieces per row tile (NB % R == 0)
@@ -150,9 +174,13 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_lnbwd_kernel(RowGemmPar
     for (int kk = 0; kk < 4; ++kk) off2[kk] = (unsigned)(lq * 128 + (((2 * kk + hf) ^ mlp_swz(lq)) * 16));
 
     const buf_rsrc rs_a = make_rsrc(p.A, (unsigned)((((long)p.M - 1) * p.lda + p.K) * 2));
-    const buf_rsrc rs_x = make_rsrc(p.x, (unsigned)((((long)p.M - 1) * p.ldx + E) * 4));
-    const buf_rsrc rs_g = make_rsrc(p.g, (unsigned)((((long)p.M - 1) * p.ldg + E) * 4));
-    const buf_rsrc rs_b = make_rsrc(p.gb, p.gb ? (unsigned)((((long)p.M - 1) * p.ld_gb + E) * 2) : 0u);
+    // the row-wise streams of the epilogue: (x, g, gb) for the LayerNorm backward, (resid, out, ln_y) for residual + LayerNorm
+    const buf_rsrc rs_x = EPI == RG_LNBWD ? make_rsrc(p.x, (unsigned)((((long)p.M - 1) * p.ldx + E) * 4))
+                                          : make_rsrc(p.resid, (unsigned)((((long)p.M - 1) * p.ldr + E) * 4));
+    const buf_rsrc rs_g = EPI == RG_LNBWD ? make_rsrc(p.g, (unsigned)((((long)p.M - 1) * p.ldg + E) * 4))
+                                          : make_rsrc(p.out, (unsigned)((((long)p.M - 1) * p.ldc + E) * 4));
+    const buf_rsrc rs_b = EPI == RG_LNBWD ? make_rsrc(p.gb, p.gb ? (unsigned)((((long)p.M - 1) * p.ld_gb + E) * 2) : 0u)
+                                          : make_rsrc(p.ln_y, (unsigned)((((long)p.M - 1) * p.ld_y + E) * 2));
     struct LaneOff {
         int lane, hf, lq, dr, dp;
         __device__ __forceinline__ explicit LaneOff(int t) {
@@ -175,16 +203,17 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_lnbwd_kernel(RowGemmPar
 #pragma unroll
             for (int j = 0; j < 4; ++j) load_a(ab[b][j], blockIdx.x, b, j);
     }
-    // the first acquires count on 3 * WIN_VM instructions younger than the ring requests of the prologue: true when the
-    // activation loads above are that many, else (E = 128) start from a drained queue
-    if constexpr (4 * (R - 1) + 2 < KT + 6) glds_wait_all();
+    // the first acquire counts on (AHEAD - 1) * WIN_VM instructions younger than piece 0's requests: the prologue's other
+    // pieces + the activation loads above.  Where they are fewer (R = 2) start from a drained queue.
+    if constexpr (4 * (R - 1) < 2 * (AHEAD - 1)) glds_wait_all();
     const float inv_e = 1.0f / (float)E;
     if (p.lab > 0 && (blockIdx.x & 1)) wave_sleep(p.lab);
 
     for (int tile = blockIdx.x; tile < tiles; tile += G) {
         const int m0 = tile * RG_BM, r0 = m0 + 32 * w;
         const int row = r0 + lq, grow = row < p.M ? row : p.M - 1;
-        const float mu = p.mean[grow], rs = p.rstd[grow];
+        float mu = 0.f, rs = 0.f;
+        if (EPI == RG_LNBWD) { mu = p.mean[grow]; rs = p.rstd[grow]; }
         f32x16 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -219,6 +248,90 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_lnbwd_kernel(RowGemmPar
             });
         }
         // ---- epilogue: a row is complete inside its two lanes (lane, lane ^ 32); acc[nt][4 g + e] = column 32 nt + 8 g + 4 hf + e.
+        if constexpr (EPI == RG_RESID_LN) {
+            // (mlp_fused.h's epilogue)  Pass A: out = x + (acc + bias) * sc back into the accumulators, LayerNorm statistics
+            float sc = 1.0f;
+            if (p.rowscale) sc = p.rowscale[grow / p.rows_per_sample];
+            float s1 = 0.f, s2 = 0.f;
+            {
+                const unsigned so = (unsigned)r0 * (unsigned)(p.ldr * 4), lo_x = LaneOff(t).frag(p.ldr, 4, 4);
+                constexpr int PA = 4;
+                u32x4 xb[PA][4];
+                auto load_x = [&](int nt) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) xb[nt % PA][g] = buf_load16(rs_x, lo_x, so + (32 * nt + 8 * g) * 4);
+                };
+#pragma unroll
+                for (int nt = 0; nt < PA - 1 && nt < NT; ++nt) load_x(nt);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (nt + PA - 1 < NT) load_x(nt + PA - 1);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4v x = __builtin_bit_cast(f32x4v, xb[nt % PA][g]);
+                        const f32x4v b = *reinterpret_cast<const f32x4v*>(vbi + 32 * nt + 8 * g + 4 * hf);
+                        const float xx[4] = {x.x, x.y, x.z, x.w}, bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = xx[e] + (acc[nt][4 * g + e] + bb[e]) * sc;
+                            acc[nt][4 * g + e] = v;
+                            s1 += v;
+                            s2 = fmaf(v, v, s2);
+                        }
+                    }
+                    CCD_SCHED_FENCE();
+                    asm volatile("" ::: "memory");
+                }
+            }
+            s1 += shfl_xor(s1, 32);
+            s2 += shfl_xor(s2, 32);
+            const float mean = s1 * inv_e;
+            float var = s2 * inv_e - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            const float rstd = 1.0f / sqrtf(var + p.ln_eps);
+            if (hf == 0 && row < p.M) { p.ln_mean[row] = mean; p.ln_rstd[row] = rstd; }
+            const LaneOff lo(t);
+            const unsigned lo_o = lo.rows8(p.ldc, 4), lo_n = lo.rows8(p.ld_y, 2);
+            // Pass B: out (fp32, one 32-column tile at a time) and ln_y (bf16, two tiles) through the scratch image
+#pragma unroll
+            for (int np = 0; np < NT / 2; ++np) {
+                u32x2 ypk[2][4];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int nt = 2 * np + tt;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float v[4] = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
+                        *reinterpret_cast<f32x4v*>(scratch + lo.scr_wr(2 * g + lo.hf)) = f32x4v{v[0], v[1], v[2], v[3]};
+                        const int n = 32 * nt + 8 * g + 4 * hf;
+                        const f32x4v ga = *reinterpret_cast<const f32x4v*>(vga + n), be = *reinterpret_cast<const f32x4v*>(vbe + n);
+                        ypk[tt][g].x = pack_bf2((v[0] - mean) * rstd * ga.x + be.x, (v[1] - mean) * rstd * ga.y + be.y);
+                        ypk[tt][g].y = pack_bf2((v[2] - mean) * rstd * ga.z + be.z, (v[3] - mean) * rstd * ga.w + be.w);
+                    }
+                    wave_lds_fence();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u32x4 o = *reinterpret_cast<const u32x4*>(scratch + lo.scr_rd(i));
+                        buf_store16(rs_g, lo_o, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldc * 4) + 128 * nt, o);
+                    }
+                    wave_lds_fence();
+                    CCD_SCHED_FENCE();
+                    asm volatile("" ::: "memory");
+                }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<u32x2*>(scratch + lo.scr_wr(4 * tt + g) + 8 * lo.hf) = ypk[tt][g];
+                wave_lds_fence();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32x4 o = *reinterpret_cast<const u32x4*>(scratch + lo.scr_rd(i));
+                    buf_store16(rs_b, lo_n, (unsigned)(r0 + 8 * i) * (unsigned)(p.ld_y * 2) + 128 * np, o);
+                }
+                wave_lds_fence();
+            }
+        } else {
         // Pass A: the two row means and the column sums of dy * xhat and dy (x streams in two tiles ahead of its use).
         const unsigned so_x = (unsigned)r0 * (unsigned)(p.ldx * 4);
         float s1 = 0.f, sq = 0.f;
@@ -339,19 +452,22 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_lnbwd_kernel(RowGemmPar
                 }
             }
         }
+        }
         RG_STAMP(5)
     }
     glds_wait_all();                       // requested pieces that no tile consumed must not outlive the workgroup's LDS
     __syncthreads();
-    for (int i = t; i < E; i += RG_THREADS) {
-        atomicAdd(p.dgamma + i, cs[i]);
-        atomicAdd(p.dbeta + i, cs[E + i]);
-        if (p.dbias) atomicAdd(p.dbias + i, cs[2 * E + i]);
+    if (EPI == RG_LNBWD) {
+        for (int i = t; i < E; i += RG_THREADS) {
+            atomicAdd(p.dgamma + i, cs[i]);
+            atomicAdd(p.dbeta + i, cs[E + i]);
+            if (p.dbias) atomicAdd(p.dbias + i, cs[2 * E + i]);
+        }
     }
 #ifdef CCD_MLP_LAB
     RG_STAMP(6)
     if (t == 0)
-        for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(p.g)[blockIdx.x * 8 + i] = ph[i];
+        for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(EPI == RG_LNBWD ? p.g : p.out)[blockIdx.x * 8 + i] = ph[i];
 #endif
 }
 

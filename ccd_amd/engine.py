@@ -100,8 +100,11 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
     ctxs, taps, tap_ctx = [], [], []
     scale = (E // spec.heads) ** -0.5
     # LayerNorm folded into the epilogue of the residual product that finishes its input rows (full-row kernel,
-    # E <= 384): proj -> norm2 of the same block, fc2 -> norm1 of the next block / the final norm
-    fuse_ln = E <= 384 and os.environ.get("CCD_FUSE_LN", "1") != "0"
+    # E <= 384 or 512): proj -> norm2 of the same block, fc2 -> norm1 of the next block / the final norm
+    # (E = 512 - vit_base: the row-owner kernels exist (`CCD_FUSE_LN=1` forces them) but lose there - 256 accumulator registers
+    # per lane leave a 3-slot weight ring and spills: 51.9 ms per step against 47.0 with only the LayerNorm-backward product
+    # fused, 47.3 unfused; B = 128, one MI355X)
+    fuse_ln = os.environ.get("CCD_FUSE_LN", "1" if E <= 384 else "0") != "0" and (E <= 384 or E == 512)
     # the whole MLP branch in one kernel (csrc/kernels/mlp_fused.h): the hidden activation never reaches HBM; when
     # activations are saved only the bf16 pre-activation u is stored and backward re-derives gelu(u) in the epilogue
     # that already reads u (ccd_gemm_nt, EPI_DGELU with a second output)
@@ -237,8 +240,8 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
     def mlp_tail(i):            # what the MLP branch of block i wants from the writer in front of it
         return dict(gb=gb, rowscale=ctxs[i].ds2, rows_per_sample=256, dbias=arena.g(f"{pre}blocks.{i}.mlp.fc2.bias"))
 
-    # LayerNorm backward folded into the epilogue of the data-gradient product in front of it (ccd_gemm_nt_lnbwd, N <= 384)
-    fuse_lnbwd = E <= 384 and E % 8 == 0 and os.environ.get("CCD_FUSE_LNBWD", "1") != "0"
+    # LayerNorm backward folded into the epilogue of the data-gradient product in front of it (ccd_gemm_nt_lnbwd, N <= 384 or 512)
+    fuse_lnbwd = (E <= 384 or E == 512) and E % 8 == 0 and os.environ.get("CCD_FUSE_LNBWD", "1") != "0"
     side = _SideStream(dev)
     gb_reader = None            # event of the last side-stream product that reads gb (the next writer of gb waits for it)
     have_gb = False

@@ -122,7 +122,7 @@ def gemm_nt_resid_ln(a, b, *, bias, resid, rowscale, rows_per_sample, gamma, bet
     _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(bias, F32, "bias"); _chk(resid, F32, "resid"); _chk(rowscale, F32, "rowscale")
     M, K = a.shape
     N = b.shape[0]
-    assert b.shape[1] == K and N <= 384
+    assert b.shape[1] == K and N <= 512
     if out is None:
         out = torch.empty((M, N), dtype=F32, device=a.device)
     y = torch.empty((M, N), dtype=BF16, device=a.device)
@@ -142,11 +142,11 @@ def gemm_nt_resid_ln(a, b, *, bias, resid, rowscale, rows_per_sample, gamma, bet
 def gemm_nt_lnbwd(a, b, x, mean, rstd, gamma, g, dgamma, dbeta, accumulate=True, gb=None, rowscale=None, rows_per_sample=1,
                   dbias=None):
     """dy = a @ b^T is the gradient of a LayerNorm output: g (+)= LN'(dy) with dgamma / dbeta (+ the bf16 tail of ln_bwd) in
-    the epilogue of the product - dy never reaches HBM (ccd_gemm_nt + ccd_ln_bwd in one launch; N <= 384)."""
+    the epilogue of the product - dy never reaches HBM (ccd_gemm_nt + ccd_ln_bwd in one launch; N <= 384 or N = 512)."""
     _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(x, F32, "x"); _chk(g, F32, "g"); _chk(gb, BF16, "gb")
     M, K = a.shape
     N = b.shape[0]
-    assert b.shape[1] == K and tuple(x.shape) == (M, N) and tuple(g.shape) == (M, N) and N <= 384
+    assert b.shape[1] == K and tuple(x.shape) == (M, N) and tuple(g.shape) == (M, N) and N <= 512
     span = TIMER.span("gemm_nt_lnbwd", 2.0 * M * N * K, 2.0 * (M * K + N * K) + M * N * (12.0 if accumulate else 8.0)
                       + (2.0 * M * N if gb is not None else 0.0)) if TIMER is not None else None
     if span:

@@ -58,7 +58,9 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
  * x = x + drop_path(f(...)); the following norm1 / norm2 / norm of the stream):
  *   C[M,N] (f32) = resid + (A . B^T + bias) * rowscale[row / rows_per_sample]
  *   y[M,N] (bf16) = (C - mean) * rstd * ln_gamma + ln_beta,  mean / rstd [M] saved for ccd_ln_bwd
- * One workgroup owns whole rows (N <= 384, N % 8 == 0, K % 64 == 0); replaces ccd_gemm_nt(EPI_RESID) + ccd_ln_fwd. */
+ * One workgroup owns whole rows: N in {128, 256, 384, 512} with K % 128 == 0 (K % 192 at N = 384) runs the row-owner
+ * kernel (rowgemm.h), any other N <= 384 (N % 8 == 0, K % 64 == 0) the 128 x 384 tile of gemm_row384.h;
+ * replaces ccd_gemm_nt(EPI_RESID) + ccd_ln_fwd. */
 int ccd_gemm_nt_resid_ln(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, float* C, long ldc,
                          const float* bias, const float* resid, long ldr, const float* rowscale, int rows_per_sample,
                          const float* ln_gamma, const float* ln_beta, float ln_eps, ccd_bf16* y, long ldy, float* mean,
@@ -68,7 +70,7 @@ int ccd_gemm_nt_resid_ln(const ccd_bf16* A, long lda, const ccd_bf16* B, long ld
  *   dy = A . B^T  (never written);  xhat = (x - mean) * rstd;  dx = rstd * (dy*gamma - mean_row(dy*gamma) - xhat * mean_row(dy*gamma*xhat))
  *   g (f32) = (accumulate ? g : 0) + dx;  dgamma += colsum(dy * xhat);  dbeta += colsum(dy)
  *   optional tail: gb (bf16) = g_new * rowscale[row / rows_per_sample], dbias += colsum(gb)
- * N <= 384, N % 8 == 0, K % 64 == 0.  Replaces ccd_gemm_nt(EPI_BF16) + ccd_ln_bwd. */
+ * Same shape rules as ccd_gemm_nt_resid_ln.  Replaces ccd_gemm_nt(EPI_BF16) + ccd_ln_bwd. */
 int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, const float* x, long ldx,
                       const float* mean, const float* rstd, const float* gamma, float* g, long ldg, int accumulate,
                       float* dgamma, float* dbeta, ccd_bf16* gb, long ldgb, const float* rowscale, int rows_per_sample,
@@ -78,7 +80,7 @@ int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, 
  *   h = gelu(bf16(y . W1^T + b1)) ;  out (f32) = resid + (h . W2^T + b2) * rowscale[row / rows_per_sample]
  *   ln_y (bf16) = (out - mean) * rstd * ln_gamma + ln_beta ;  ln_mean / ln_rstd [M] saved for ccd_ln_bwd
  * The [M, H] hidden activation stays on chip; `u` (optional, [M, H] bf16) receives the pre-activation the backward
- * pass needs.  W1 = fc1.weight [H, E], W2 = fc2.weight [E, H] (bf16).  E in {128, 256, 384}, H % 64 == 0.
+ * pass needs.  W1 = fc1.weight [H, E], W2 = fc2.weight [E, H] (bf16).  E in {128, 256, 384, 512}, H % 64 == 0.
  * Replaces ccd_gemm_nt(EPI_GELU) + ccd_gemm_nt_resid_ln. */
 int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, const float* b1, const ccd_bf16* w2, long ld2,
                   const float* b2, const float* resid, long ldr, const float* rowscale, int rows_per_sample, float* out,

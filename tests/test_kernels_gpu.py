@@ -144,7 +144,7 @@ def test_gemm_row384(hip, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 384, 128), (300, 384, 384), (4096, 384, 1536), (40000, 384, 1152), (2048, 192, 768),
-                                   (5000, 128, 512), (33000, 256, 768)])
+                                   (5000, 128, 512), (33000, 256, 768), (20000, 512, 1536), (4100, 512, 2048)])
 def test_gemm_lnbwd(hip, M, N, K):
     kc.check_gemm_lnbwd(hip.device, M=M, N=N, K=K)            # rowgemm.h where K % N == 0 and N in {128, 256, 384}
 
@@ -155,12 +155,26 @@ def test_gemm_lnbwd_row384_kernel(hip):
         kc.check_gemm_lnbwd(hip.device, M=4096, N=384, K=1536)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 384, 128), (4096, 384, 1536), (2048, 192, 768)])
+@pytest.mark.parametrize("M,N,K", [(300, 384, 128), (4096, 384, 1536), (2048, 192, 768), (40000, 384, 384), (5000, 128, 512),
+                                   (33000, 256, 768), (20000, 512, 512), (4100, 512, 2048)])
 def test_gemm_resid_ln(hip, M, N, K):
-    kc.check_gemm_resid_ln(hip.device, M=M, N=N, K=K)
+    from ccd_amd import ops
+    kc.check_gemm_resid_ln(hip.device, M=M, N=N, K=K)          # gemm_row384.h for N <= 384, rowgemm.h at N = 512
+    if N in (128, 256, 384):
+        with ops.policy(rowgemm=2):                            # the row-owner kernel forced
+            kc.check_gemm_resid_ln(hip.device, M=M, N=N, K=K)
 
 
-@pytest.mark.parametrize("M,E,H,rps", [(300, 128, 256, 128), (200, 384, 128, 8), (40000, 384, 1536, 256), (4096, 256, 1024, 256)])
+def test_gemm_resid_ln_policy_off_rejects_n512(hip):
+    from ccd_amd import ops
+    with ops.policy(rowgemm=0):
+        kc.check_gemm_resid_ln(hip.device, M=4096, N=384, K=1536)
+        with pytest.raises(RuntimeError):
+            kc.check_gemm_resid_ln(hip.device, M=256, N=512, K=512)
+
+
+@pytest.mark.parametrize("M,E,H,rps", [(300, 128, 256, 128), (200, 384, 128, 8), (40000, 384, 1536, 256), (4096, 256, 1024, 256),
+                                       (33000, 512, 2048, 256)])
 def test_mlp_fused(hip, M, E, H, rps):
     """fc1 + GELU + fc2 + residual + LayerNorm in one launch: ragged tiles, many tiles per workgroup (the ring of weight
     pieces runs across them), dropped samples, with and without the stored pre-activation."""

@@ -142,12 +142,18 @@ def test_gemm_lnbwd_sim(sim):
     kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=384)      # rowgemm.h (K % N == 0, N in {128, 256, 384})
     kc.check_gemm_lnbwd(sim.device, M=200, N=128, K=256)
     kc.check_gemm_lnbwd(sim.device, M=260, N=256, K=256)
+    kc.check_gemm_lnbwd(sim.device, M=130, N=512, K=128)
     kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=128)      # gemm_row384.h
     kc.check_gemm_lnbwd(sim.device, M=140, N=192, K=64)
 
 
 def test_gemm_resid_ln_sim(sim):
-    kc.check_gemm_resid_ln(sim.device, M=300, N=384, K=128)
+    from ccd_amd import ops
+    with ops.policy(rowgemm=2):                                   # rowgemm.h forced (default only at N = 512)
+        kc.check_gemm_resid_ln(sim.device, M=300, N=384, K=192)
+        kc.check_gemm_resid_ln(sim.device, M=200, N=128, K=256)
+    kc.check_gemm_resid_ln(sim.device, M=130, N=512, K=128)
+    kc.check_gemm_resid_ln(sim.device, M=300, N=384, K=128)      # gemm_row384.h
     kc.check_gemm_resid_ln(sim.device, M=140, N=192, K=64)
 
 
@@ -184,6 +190,7 @@ def test_mlp_fused_sim(sim):
     """Ragged last tile, several tiles per workgroup (1 CU), a dropped sample, both instantiations of E."""
     kc.check_mlp_fused(sim.device, M=300, E=128, H=256, rps=128)
     kc.check_mlp_fused(sim.device, M=200, E=384, H=128, rps=8, store_u=False)     # per-row DropPath scales
+    kc.check_mlp_fused(sim.device, M=130, E=512, H=128, rps=8)                     # 3-slot ring (vit_base)
 
 
 def test_kmeans2_mask_sim(sim):
