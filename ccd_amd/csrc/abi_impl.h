@@ -195,7 +195,10 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
         (epilogue == CCD_EPI_RESID || epilogue == CCD_EPI_F32 || (epilogue == CCD_EPI_BF16 && pol.gemm_row384 >= 2)))
         return ccd_launch_gemm_row384(p, epilogue, stream);
     const bool bf16_out = epilogue == CCD_EPI_BF16 || epilogue == CCD_EPI_GELU || epilogue == CCD_EPI_DGELU;
-    if (pol.gemm_256 >= 1 && (bf16_out || (pol.gemm_256_f32 && epilogue != CCD_EPI_ATOMIC)) && M >= pol.gemm_256_min_m &&
+    // fp32 / residual epilogues take the 256-row tile where the columns fill whole tiles (vit_base, N = 512: 6.6 vs 7.6 ms per
+    // step); at N = 384 (one and a half tiles) the 128-row kernels are faster
+    const bool f32_256 = epilogue != CCD_EPI_ATOMIC && (pol.gemm_256_f32 || N % 256 == 0);
+    if (pol.gemm_256 >= 1 && (bf16_out || f32_256) && M >= pol.gemm_256_min_m &&
         N >= pol.gemm_256_min_n) {
         if (pol.gemm_256_deep) return ccd_launch_gemm256<256, true>(p, epilogue, stream);
         return ccd_launch_gemm256<256>(p, epilogue, stream);
