@@ -335,7 +335,9 @@ def check_dist_world1(device, port=29611):
     # key bias of qkv) the SIGN is rounding noise of fp32 atomics, different from run to run.  Compare the update as a whole.
     update = w0 - tiny_networks(device)[0].arena.flat
     rel = ((w0 - w1).double().norm() / update.double().norm()).item()
-    assert rel < 0.05, f"the distributed iteration updated the weights differently (relative difference {rel})"
+    # (a flipped sign moves an element by 2 lr: rel = 0.1 <=> 0.25 % of the elements flipped; measured 0.03 - 0.06 between two
+    # runs whose atomics sum in another order - the reserved CUs change every persistent grid; a wrong reduction gives >= 0.5)
+    assert rel < 0.1, f"the distributed iteration updated the weights differently (relative difference {rel})"
     assert (c0 - c1).abs().max().item() < 1e-6
     return {"loss_plain": l0, "loss_dist": l1, "collectives": len(calls)}
 
