@@ -204,7 +204,12 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
         return ccd_launch_gemm256<256>(p, epilogue, stream);
     }
     if (pol.gemm_256 >= 2 && epilogue != CCD_EPI_ATOMIC && M >= pol.gemm_256_min_m) return ccd_launch_gemm256<128>(p, epilogue, stream);
-    return ccd_launch_gemm<false>(p, epilogue, 1, stream);
+    int splits = 1;
+    if (epilogue == CCD_EPI_ATOMIC && K >= 16384) {      // few output tiles, long contraction (the head's data gradient,
+        p.k_per_split = 8192;                            // K = 65536: 52 live tiles): slices of 8192 accumulate by fp32 atomics
+        splits = (K + 8191) / 8192;
+    }
+    return ccd_launch_gemm<false>(p, epilogue, splits, stream);
 }
 
 int ccd_gemm_nt_resid_ln(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, float* C, long ldc,
@@ -406,8 +411,8 @@ int ccd_attention_bwd(const ccd_bf16* qkv, const ccd_bf16* out, const ccd_bf16* 
     const int cus = ccd_rt_num_cus();
     CCD_LAUNCH(ccd::attention_bwd_dq_kernel, dim3(nblocks < cus ? nblocks : cus), dim3(512), ccd::ATTB_DQ_SMEM, stream, qkv,
                out, d_out, lse, delta_ws, d_qkv, heads, scale, nblocks);
-    CCD_LAUNCH(ccd::attention_bwd_dkv_kernel, dim3(views * heads), dim3(512), ccd::ATTB_DKV_SMEM, stream, qkv, d_out, lse,
-               delta_ws, d_qkv, heads, scale);
+    CCD_LAUNCH(ccd::attention_bwd_dkv_kernel, dim3(nblocks < cus ? nblocks : cus), dim3(512), ccd::ATTB_DKV_SMEM, stream, qkv,
+               d_out, lse, delta_ws, d_qkv, heads, scale, nblocks);
     return ccd_rt_last_error();
 }
 

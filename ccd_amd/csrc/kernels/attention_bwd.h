@@ -1,6 +1,6 @@
 // attention_bwd.h - backward of the T=256, d=64 attention of attention_fwd.h, as two kernels per layer:
 //   attention_bwd_dq_kernel   one WG (8 waves x 32 queries) per (view, head): D = rowsum(dO*O), dQ
-//   attention_bwd_dkv_kernel  one WG (8 waves x 32 keys)    per (view, head): dK, dV
+//   attention_bwd_dkv_kernel  one WG (8 waves x 32 keys)    per (view, head): dK, dV   (both persistent: one WG per CU)
 // P is recomputed from the saved LSE (never stored).  Both kernels use the transposed-product trick of the
 // forward: the probability / dS tile that comes out of one MFMA is directly the B operand of the next one,
 // and the LDS-resident A operands (K^T, Q^T, dO^T images) carry the matching key/query permutation.
@@ -113,6 +113,19 @@ __device__ __forceinline__ void attb_store_transposed(const AttbRows& x, char* i
     }
 }
 
+// the row image written from the registers of the TRANSPOSED loader (a thread holds rows 4 kb .. 4 kb + 3, columns 8 db .. + 7):
+// one set of loads feeds both images of an operand
+__device__ __forceinline__ void attb_store_rows_of_transposed(const AttbRows& x, char* img) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int kb = 16 * (w & 3) + (lane & 15);
+    const int db = (lane >> 4) + 4 * (w >> 2);
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+        const int row = 4 * kb + kq;
+        *reinterpret_cast<u32x4*>(img + row * 128 + ((db ^ ((row >> 1) & 7)) * 16)) = x.r[kq];
+    }
+}
+
 __global__ __launch_bounds__(512) void attention_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
                                                                const bf16_t* __restrict__ o,
                                                                const bf16_t* __restrict__ d_o,
@@ -127,13 +140,12 @@ __global__ __launch_bounds__(512) void attention_bwd_dq_kernel(const bf16_t* __r
     const int E = heads * ATT_D;
     const long rs3 = 3L * E;
     const int q = 32 * w + lq;
-    AttbRows kr, vr, ktr;
+    AttbRows vr, ktr;                                         // (K: one load set feeds the row and the transposed image)
     u32x4 qw[4], dw[4], ow[4];
     float lse_n = 0.f;
     auto request = [&](int blk) {                             // everything this thread needs of block `blk`
         const int view = blk / heads, head = blk % heads;
         const bf16_t* q_base = qkv + (long)view * ATT_T * rs3 + head * ATT_D;
-        attb_load_rows(q_base + E, rs3, kr);
         attb_load_rows(q_base + 2 * E, rs3, vr);
         attb_load_transposed(q_base + E, rs3, ktr);
         const long orow = ((long)view * ATT_T + q) * E + head * ATT_D;
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(512) void attention_bwd_dq_kernel(const bf16_t* __r
     if (blk < nblocks) request(blk);
     for (; blk < nblocks; blk += gridDim.x) {
         const int view = blk / heads, head = blk % heads;
-        attb_store_rows(kr, k_img);
+        attb_store_rows_of_transposed(ktr, k_img);
         attb_store_rows(vr, v_img);
         attb_store_transposed(ktr, kt_img);
         bf16x8 qf[4], dof[4];
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(512) void attention_bwd_dkv_kernel(const bf16_t* __
                                                                 const bf16_t* __restrict__ d_o,
                                                                 const float* __restrict__ lse,
                                                                 const float* __restrict__ delta,
-                                                                bf16_t* __restrict__ dqkv, int heads, float scale) {
+                                                                bf16_t* __restrict__ dqkv, int heads, float scale, int nblocks) {
     char* smem = dynamic_smem();
     char* q_img = smem;
     char* do_img = smem + ATTB_IMG;
@@ -220,70 +232,93 @@ __global__ __launch_bounds__(512) void attention_bwd_dkv_kernel(const bf16_t* __
     float* lse_s = reinterpret_cast<float*>(smem + 4 * ATTB_IMG);
     float* del_s = lse_s + ATT_T;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hf = lane >> 5, lq = lane & 31;
-    const int view = blockIdx.x / heads, head = blockIdx.x % heads;
     const int E = heads * ATT_D;
     const long rs3 = 3L * E;
-    const bf16_t* q_base = qkv + (long)view * ATT_T * rs3 + head * ATT_D;
-    const bf16_t* do_base = d_o + (long)view * ATT_T * E + head * ATT_D;
-    attb_stage_rows(q_base, rs3, q_img);
-    attb_stage_rows(do_base, E, do_img);
-    attb_stage_transposed(q_base, rs3, qt_img);
-    attb_stage_transposed(do_base, E, dot_img);
-    if (threadIdx.x < ATT_T) {
-        const long stat = ((long)view * heads + head) * ATT_T + threadIdx.x;
-        lse_s[threadIdx.x] = lse[stat];
-        del_s[threadIdx.x] = delta[stat];
-    }
     const int key = 32 * w + lq;
-    bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        kf[kk] = *reinterpret_cast<const bf16x8*>(q_base + E + (long)key * rs3 + 16 * kk + 8 * hf);
-        vf[kk] = *reinterpret_cast<const bf16x8*>(q_base + 2 * E + (long)key * rs3 + 16 * kk + 8 * hf);
-    }
-    __syncthreads();
-
-    f32x16 dk[2], dv[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
-#pragma unroll 1
-    for (int qt = 0; qt < 8; ++qt) {
-        f32x16 s, dp;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-        const int row = 32 * qt + lq;
+    // persistent like the dQ kernel: everything a thread needs of block b + gridDim.x is requested right after block b's
+    // pieces have been written to LDS (measured: 214 -> ... us per launch; the staging latency of 128 KiB per block used to
+    // sit in front of every block's ~5 us of MFMA work)
+    AttbRows qtr, dotr;                                       // (one load set per operand feeds its row AND its transposed image)
+    u32x4 kw[4], vw[4];
+    float lse_r = 0.f, del_r = 0.f;
+    auto request = [&](int blk) {
+        const int view = blk / heads, head = blk % heads;
+        const bf16_t* q_base = qkv + (long)view * ATT_T * rs3 + head * ATT_D;
+        const bf16_t* do_base = d_o + (long)view * ATT_T * E + head * ATT_D;
+        attb_load_transposed(q_base, rs3, qtr);
+        attb_load_transposed(do_base, E, dotr);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            s = mfma_32x32x16_bf16(attb_row_frag(q_img, row, kk, hf), kf[kk], s);      // S[q][key]
-            dp = mfma_32x32x16_bf16(attb_row_frag(do_img, row, kk, hf), vf[kk], dp);   // dP[q][key]
+            kw[kk] = *reinterpret_cast<const u32x4*>(q_base + E + (long)key * rs3 + 16 * kk + 8 * hf);
+            vw[kk] = *reinterpret_cast<const u32x4*>(q_base + 2 * E + (long)key * rs3 + 16 * kk + 8 * hf);
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qq = 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * hf;
-            const float p = fast_exp2(fmaf(s[r], scale * 1.4426950408889634f, -lse_s[qq] * 1.4426950408889634f));
-            s[r] = p;
-            dp[r] = p * (dp[r] - del_s[qq]) * scale;
+        if (threadIdx.x < ATT_T) {
+            const long stat = ((long)view * heads + head) * ATT_T + threadIdx.x;
+            lse_r = lse[stat];
+            del_r = delta[stat];
         }
+    };
+    int blk = blockIdx.x;
+    if (blk < nblocks) request(blk);
+    for (; blk < nblocks; blk += gridDim.x) {
+        const int view = blk / heads, head = blk % heads;
+        attb_store_rows_of_transposed(qtr, q_img);
+        attb_store_rows_of_transposed(dotr, do_img);
+        attb_store_transposed(qtr, qt_img);
+        attb_store_transposed(dotr, dot_img);
+        if (threadIdx.x < ATT_T) { lse_s[threadIdx.x] = lse_r; del_s[threadIdx.x] = del_r; }
+        bf16x8 kf[4], vf[4];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 pf, dsf;
+        for (int kk = 0; kk < 4; ++kk) {
+            kf[kk] = __builtin_bit_cast(bf16x8, kw[kk]);
+            vf[kk] = __builtin_bit_cast(bf16x8, vw[kk]);
+        }
+        __syncthreads();
+        if (blk + (int)gridDim.x < nblocks) request(blk + gridDim.x);      // flies under this block's MFMAs
+
+        f32x16 dk[2], dv[2];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                pf[e] = (short)f2bf(s[8 * s2 + e]);
-                dsf[e] = (short)f2bf(dp[8 * s2 + e]);
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+#pragma unroll 1
+        for (int qt = 0; qt < 8; ++qt) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            const int row = 32 * qt + lq;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                s = mfma_32x32x16_bf16(attb_row_frag(q_img, row, kk, hf), kf[kk], s);      // S[q][key]
+                dp = mfma_32x32x16_bf16(attb_row_frag(do_img, row, kk, hf), vf[kk], dp);   // dP[q][key]
             }
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                dv[dt] = mfma_32x32x16_bf16(attb_tr_frag(dot_img, 32 * dt + lq, 2 * qt + s2, hf), pf, dv[dt]);
-                dk[dt] = mfma_32x32x16_bf16(attb_tr_frag(qt_img, 32 * dt + lq, 2 * qt + s2, hf), dsf, dk[dt]);
+            for (int r = 0; r < 16; ++r) {
+                const int qq = 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                const float p = fast_exp2(fmaf(s[r], scale * 1.4426950408889634f, -lse_s[qq] * 1.4426950408889634f));
+                s[r] = p;
+                dp[r] = p * (dp[r] - del_s[qq]) * scale;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pf, dsf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    pf[e] = (short)f2bf(s[8 * s2 + e]);
+                    dsf[e] = (short)f2bf(dp[8 * s2 + e]);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dv[dt] = mfma_32x32x16_bf16(attb_tr_frag(dot_img, 32 * dt + lq, 2 * qt + s2, hf), pf, dv[dt]);
+                    dk[dt] = mfma_32x32x16_bf16(attb_tr_frag(qt_img, 32 * dt + lq, 2 * qt + s2, hf), dsf, dk[dt]);
+                }
             }
         }
+        bf16_t* drow = dqkv + ((long)view * ATT_T + key) * rs3 + head * ATT_D;
+        attb_store_t(drow + E, dk, hf);
+        attb_store_t(drow + 2 * E, dv, hf);
+        __syncthreads();                                     // the images are rewritten by the next block
     }
-    bf16_t* drow = dqkv + ((long)view * ATT_T + key) * rs3 + head * ATT_D;
-    attb_store_t(drow + E, dk, hf);
-    attb_store_t(drow + 2 * E, dv, hf);
 }
 
 }  // namespace ccd

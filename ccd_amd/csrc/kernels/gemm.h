@@ -296,7 +296,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     // hardware sends workgroup b to XCD b % 8) owns one contiguous range of ids, its workgroups take them round-robin,
     // so neighbours run at the same time on the same L2 and the re-reads are L2 hits instead of HBM traffic.
     const unsigned ntile = (unsigned)(tiles_m * tiles_n);
-    const unsigned total = TN ? (unsigned)p.work_items : ntile, G = gridDim.x;
+    // (NT: the contraction is cut too when k_per_split < K - EPI_ATOMIC products with few output tiles and a long K)
+    const unsigned nt_splits = TN ? 1u : (unsigned)((p.K + p.k_per_split - 1) / p.k_per_split);
+    const unsigned total = TN ? (unsigned)p.work_items : ntile * nt_splits, G = gridDim.x;
     const unsigned ng = G < 8u ? G : 8u;                                       // XCDs that received workgroups
     const unsigned xcd = blockIdx.x % ng, slot = blockIdx.x / ng;
     const unsigned nx = G / ng + (xcd < G % ng ? 1u : 0u);                     // workgroups on this XCD
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         n0 = tn * GEMM_BN;
         k_begin = 0;
         k_end = p.K;
-        if (TN) {
+        if (TN || nt_splits > 1) {
             k_begin = split * p.k_per_split;
             k_end = k_begin + p.k_per_split < p.K ? k_begin + p.k_per_split : p.K;
         }

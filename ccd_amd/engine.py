@@ -420,7 +420,11 @@ def head_backward(arena, pre, saved, d_logits, d_total, last_layer_trainable_g, 
     ops.gemm_tn(d_logits, zn, dw, accumulate=False, **dyn)                       # dW_eff = d_logits^T . zn
     ops.weightnorm_bwd(v, gw, winv, dw, arena.g(pre + "last_layer.weight_v"),
                        arena.g(pre + "last_layer.weight_g") if last_layer_trainable_g else None)
-    dzn = ops.gemm_nt(d_logits, w_t, m_fastest=0, **dyn)                          # [rows, D]
+    # [rows, D] = d_logits . W: two column tiles x ~26 live row tiles and a 65536-long contraction - cut into slices that add
+    # up in fp32 (ccd_gemm_nt, EPI_ATOMIC: 611 -> ~100 us)
+    dzn32 = torch.zeros((d_logits.shape[0], D), dtype=F32, device=dev)
+    ops.gemm_nt(d_logits, w_t, epilogue=ops.EPI_ATOMIC, out=dzn32, m_fastest=0, **dyn)
+    dzn = dzn32.to(BF16)
     dz = torch.zeros_like(z)
     ops.l2norm_bwd(z, inv, dzn, dz, **dyn)
     ops.gemm_tn(dz, a1, arena.g(pre + "mlp.4.weight"), **dyn)

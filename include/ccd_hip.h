@@ -45,7 +45,7 @@ int ccd_policy_get(const char* key, int* value);
 #define CCD_EPI_GELU 1     /* C(bf16) = u = acc + bias, C2(bf16) = gelu(u)   Mlp.fc1+act, vit.py:59-61    */
 #define CCD_EPI_RESID 2    /* C(f32) = resid + (acc + bias) * rowscale[row / rows_per_sample]  Block :109 */
 #define CCD_EPI_F32 3      /* C(f32) = acc + bias                                                        */
-#define CCD_EPI_ATOMIC 4   /* C(f32) += acc   (split-K partial sums)                                     */
+#define CCD_EPI_ATOMIC 4   /* C(f32) += acc   (split-K partial sums; NT: K >= 16384 is cut into slices of 8192)   */
 #define CCD_EPI_DGELU 5    /* C(bf16) = acc * gelu'(aux); C2 (optional, bf16) = gelu(aux)                */
 
 /* C[M,N] = A[M,K] . B[N,K]^T   (F.linear(x, W): Dino/modules/vision_transformer.py:60,63,82,90,325-327)

@@ -85,6 +85,18 @@ def check_gemm_dynamic_rows(dev, M, N, K, live, seed=5):
     assert bool((outb[2 * live:].float() == 7.0).all()), "rows past the device-side count were written (bf16)"
 
 
+def check_gemm_nt_split_k(dev, M=200, N=72, K=16384 + 8192 + 64, seed=9):
+    """EPI_ATOMIC on the NT product: C += A . B^T with the contraction cut into slices of 8192 (the head's data gradient,
+    K = 65536), ragged last slice, accumulation onto existing values."""
+    g = torch.Generator().manual_seed(seed)
+    a = rnd((M, K), g, 0.05).to(BF); b = rnd((N, K), g, 0.05).to(BF)
+    base = rnd((M, N), g)
+    out = base.clone().to(dev)
+    ops.gemm_nt(a.to(dev), b.to(dev), epilogue=ops.EPI_ATOMIC, out=out)
+    want = base + a.float() @ b.float().t()
+    close(out, want, 2e-3, 2e-3 * float(want.abs().max()), "gemm_nt split-K atomic")
+
+
 def check_gemm_tn(dev, Mc, P, Q, seed=1, splits=0):
     g = torch.Generator().manual_seed(seed)
     a = rnd((Mc, P), g).to(BF); b = rnd((Mc, Q), g).to(BF)

@@ -22,6 +22,11 @@ def test_gemm_nt(hip, M, N, K):
     kc.check_gemm_nt(hip.device, M, N, K)
 
 
+def test_gemm_nt_split_k(hip):
+    kc.check_gemm_nt_split_k(hip.device)
+    kc.check_gemm_nt_split_k(hip.device, M=3000, N=256, K=65536)
+
+
 @pytest.mark.parametrize("Mc,P,Q,splits", [(300, 136, 72, 3), (4096, 1152, 384, 0), (8192, 384, 1536, 0),
                                            (96, 65536, 256, 1), (64, 8, 264, 0)])
 def test_gemm_tn(hip, Mc, P, Q, splits):
