@@ -48,12 +48,9 @@ __device__ __forceinline__ void att_stage_transposed(const bf16_t* __restrict__ 
         for (int j = 0; j < 8; ++j) {
             const int d = 8 * db + j;
             const unsigned w0 = r[0][j >> 1], w1 = r[1][j >> 1], w2 = r[2][j >> 1], w3 = r[3][j >> 1];
-            unsigned e0, e1, e2, e3;
-            if (j & 1) { e0 = w0 >> 16; e1 = w1 >> 16; e2 = w2 >> 16; e3 = w3 >> 16; }
-            else { e0 = w0 & 0xffffu; e1 = w1 & 0xffffu; e2 = w2 & 0xffffu; e3 = w3 & 0xffffu; }
             u32x2 o;
-            o.x = e0 | (e1 << 16);
-            o.y = e2 | (e3 << 16);
+            o.x = perm_b32(w1, w0, (j & 1) ? 0x07060302u : 0x05040100u);
+            o.y = perm_b32(w3, w2, (j & 1) ? 0x07060302u : 0x05040100u);
             const int slot = (chunk >> 1) ^ (d & 15);
             *reinterpret_cast<u32x2*>(img + d * 512 + slot * 16 + (chunk & 1) * 8) = o;
         }

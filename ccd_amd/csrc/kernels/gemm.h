@@ -212,13 +212,13 @@ __device__ __forceinline__ void gemm_store_tn(char* tile, const u32x4 (&r)[4]) {
     for (int j = 0; j < 8; ++j) {
         const int row = 8 * cb + j;                         // tile row = output row/column index
         const unsigned w0 = r[0][j >> 1], w1 = r[1][j >> 1], w2 = r[2][j >> 1], w3 = r[3][j >> 1];
-        u32x2 o;
+        u32x2 o;                                            // one v_perm_b32 per dword (shift + and + or were three)
         if (j & 1) {                                        // high halves of the four m rows
-            o.x = (w0 >> 16) | (w1 & 0xffff0000u);
-            o.y = (w2 >> 16) | (w3 & 0xffff0000u);
+            o.x = perm_b32(w1, w0, 0x07060302u);
+            o.y = perm_b32(w3, w2, 0x07060302u);
         } else {
-            o.x = (w0 & 0xffffu) | (w1 << 16);
-            o.y = (w2 & 0xffffu) | (w3 << 16);
+            o.x = perm_b32(w1, w0, 0x05040100u);
+            o.y = perm_b32(w3, w2, 0x05040100u);
         }
         *reinterpret_cast<u32x2*>(tile + row * 128 + gemm_swz(row, mb >> 1) * 16 + (mb & 1) * 8) = o;
     }

@@ -126,6 +126,8 @@ __device__ __forceinline__ unsigned opaque_u32(unsigned x) { asm volatile("" : "
 // the same for a per-lane value, and NOT hoistable out of a loop: address arithmetic derived from it is redone where it is
 // used instead of living in a register (or, worse, in scratch) across a register-starved main loop
 __device__ __forceinline__ int opaque_vgpr(int x) { asm volatile("" : "+v"(x)); return x; }
+// v_perm_b32: result byte i = byte sel.byte[i] of the 8-byte value {hi : lo} (0..3 = lo's bytes, 4..7 = hi's bytes)
+__device__ __forceinline__ unsigned perm_b32(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 __device__ __forceinline__ float opaque_f32(float x) { asm volatile("" : "+v"(x)); return x; }
 // hardware float -> bf16 (RNE): clang lowers the __bf16 casts to v_cvt_pk_bf16_f32 on gfx950
 typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;

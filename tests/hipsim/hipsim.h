@@ -143,6 +143,12 @@ inline void glds_wait() {}
 inline unsigned opaque_u32(unsigned x) { return x; }
 inline int opaque_vgpr(int x) { return x; }
 inline float opaque_f32(float x) { return x; }
+inline unsigned perm_b32(unsigned hi, unsigned lo, unsigned sel) {
+    const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+    unsigned r = 0;
+    for (int i = 0; i < 4; ++i) r |= (unsigned)((v >> (8 * ((sel >> (8 * i)) & 7))) & 0xffu) << (8 * i);
+    return r;
+}
 // hand-issued LDS fragment reads (prelude_hip.h): synchronous here; LDS "addresses" are offsets from the block's dynamic LDS
 inline unsigned lds_addr_of(const void* p) { return (unsigned)(reinterpret_cast<const char*>(p) - sim::curblk->dyn_smem); }
 template <int OFF>
