@@ -10,6 +10,7 @@
 #include "kernels/gemm_row384.h"
 #include "kernels/mlp_fused.h"
 #include "kernels/rowgemm.h"
+#include "kernels/rowgemm16.h"
 #include "kernels/layernorm.h"
 #include "kernels/attention_fwd.h"
 #include "kernels/attention_bwd.h"
@@ -278,6 +279,26 @@ int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, 
         q.ldr = q.ldc = q.ld_y = 0; q.ln_eps = 0.f;
         const int tiles = (M + ccd::RG_BM - 1) / ccd::RG_BM, smem = ccd::rg_smem_bytes(N);
         const dim3 grid(tiles < cus ? tiles : cus), block(ccd::RG_THREADS);
+        // N = 384: two independent 64-row workgroups per CU (rowgemm16.h: 0.309 / 0.273 ms against 0.345 / 0.291 of the 128-row
+        // kernel at K = 1536 / 1152, 131072 rows); policy rowgemm = 2 keeps the 128-row kernel, 3 = the 6-block ring (lab)
+        if (ccd_policy().rowgemm == 1 && N == 384 && K % 192 == 0) {
+            const int tiles16 = (M + ccd::RG16_BM - 1) / ccd::RG16_BM;
+            const dim3 grid16(tiles16 < 2 * cus ? tiles16 : 2 * cus), block16(ccd::RG16_THREADS);
+            q.lab = 0;
+            CCD_LAUNCH((ccd::rowgemm16_lnbwd_kernel<384, 3, 6>), grid16, block16, ccd::rg16_smem_bytes(384), stream, q);
+            return ccd_rt_last_error();
+        }
+        if (ccd_policy().rowgemm == 3 && N == 384 && K % 384 == 0) {
+            const int tiles16 = (M + ccd::RG16_BM - 1) / ccd::RG16_BM;
+            const dim3 grid16(tiles16 < 2 * cus ? tiles16 : 2 * cus), block16(ccd::RG16_THREADS);
+            const int lab = ccd_policy().lab;
+            q.lab = 0;
+            if (lab == 4) CCD_LAUNCH((ccd::rowgemm16_lnbwd_kernel<384, 6, 4>), grid16, block16, ccd::rg16_smem_bytes(384), stream, q);
+            else if (lab == 8) CCD_LAUNCH((ccd::rowgemm16_lnbwd_kernel<384, 6, 8>), grid16, block16, ccd::rg16_smem_bytes(384), stream, q);
+            else if (lab == 3) CCD_LAUNCH((ccd::rowgemm16_lnbwd_kernel<384, 3, 6>), grid16, block16, ccd::rg16_smem_bytes(384), stream, q);
+            else CCD_LAUNCH((ccd::rowgemm16_lnbwd_kernel<384, 6>), grid16, block16, ccd::rg16_smem_bytes(384), stream, q);
+            return ccd_rt_last_error();
+        }
         if (N == 512) CCD_LAUNCH((ccd::rowgemm_kernel<512, ccd::rg_ring(512), ccd::RG_LNBWD>), grid, block, smem, stream, q);
         else if (N == 384) CCD_LAUNCH((ccd::rowgemm_kernel<384, ccd::rg_ring(384), ccd::RG_LNBWD>), grid, block, smem, stream, q);
         else if (N == 256) CCD_LAUNCH((ccd::rowgemm_kernel<256, ccd::rg_ring(256), ccd::RG_LNBWD>), grid, block, smem, stream, q);

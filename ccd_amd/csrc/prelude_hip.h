@@ -126,6 +126,13 @@ __device__ __forceinline__ unsigned opaque_u32(unsigned x) { asm volatile("" : "
 // the same for a per-lane value, and NOT hoistable out of a loop: address arithmetic derived from it is redone where it is
 // used instead of living in a register (or, worse, in scratch) across a register-starved main loop
 __device__ __forceinline__ int opaque_vgpr(int x) { asm volatile("" : "+v"(x)); return x; }
+// A VMEM load that moves nothing (empty descriptor: every offset is out of range, no memory access) but occupies a slot
+// of the wave's vmcnt queue - keeps "VMEM instructions per window" a compile-time constant for counted waits.  The zero it
+// returns lands in `sink` whenever the load retires: `sink` must stay a live, otherwise unused register.
+__device__ __forceinline__ void vmem_pad_load(unsigned& sink) {
+    const buf_u32x4 none = {0u, 0u, 0u, 0x00020000u};
+    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(sink) : "v"(BUF_OOB), "s"(none));
+}
 // v_perm_b32: result byte i = byte sel.byte[i] of the 8-byte value {hi : lo} (0..3 = lo's bytes, 4..7 = hi's bytes)
 __device__ __forceinline__ unsigned perm_b32(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 __device__ __forceinline__ float opaque_f32(float x) { asm volatile("" : "+v"(x)); return x; }

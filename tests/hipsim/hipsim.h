@@ -143,6 +143,7 @@ inline void glds_wait() {}
 inline unsigned opaque_u32(unsigned x) { return x; }
 inline int opaque_vgpr(int x) { return x; }
 inline float opaque_f32(float x) { return x; }
+inline void vmem_pad_load(unsigned& sink) { (void)sink; }
 inline unsigned perm_b32(unsigned hi, unsigned lo, unsigned sel) {
     const unsigned long long v = ((unsigned long long)hi << 32) | lo;
     unsigned r = 0;

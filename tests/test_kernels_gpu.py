@@ -151,7 +151,19 @@ def test_gemm_row384(hip, M, N, K):
 @pytest.mark.parametrize("M,N,K", [(300, 384, 128), (300, 384, 384), (4096, 384, 1536), (40000, 384, 1152), (2048, 192, 768),
                                    (5000, 128, 512), (33000, 256, 768), (20000, 512, 1536), (4100, 512, 2048)])
 def test_gemm_lnbwd(hip, M, N, K):
-    kc.check_gemm_lnbwd(hip.device, M=M, N=N, K=K)            # rowgemm.h where K % N == 0 and N in {128, 256, 384}
+    from ccd_amd import ops
+    kc.check_gemm_lnbwd(hip.device, M=M, N=N, K=K)            # rowgemm16.h at N = 384, rowgemm.h at N in {128, 256, 512}
+    if N == 384:
+        with ops.policy(rowgemm=2):                           # the 128-row kernel
+            kc.check_gemm_lnbwd(hip.device, M=M, N=N, K=K)
+
+
+@pytest.mark.parametrize("M,K", [(300, 384), (40000, 1152), (4100, 1536)])
+def test_gemm_lnbwd_rowgemm16(hip, M, K):
+    """rowgemm16.h: 16-row waves, two independent 64-row workgroups per CU."""
+    from ccd_amd import ops
+    with ops.policy(rowgemm=3):
+        kc.check_gemm_lnbwd(hip.device, M=M, N=384, K=K)
 
 
 def test_gemm_lnbwd_row384_kernel(hip):

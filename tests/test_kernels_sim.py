@@ -143,10 +143,17 @@ def test_policy_table_sim(sim):
 
 
 def test_gemm_lnbwd_sim(sim):
-    kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=384)      # rowgemm.h (K % N == 0, N in {128, 256, 384})
+    from ccd_amd import ops
+    kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=384)      # rowgemm16.h (N = 384), rowgemm.h (N in {128, 256, 512})
+    with ops.policy(rowgemm=2):
+        kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=384)  # the 128-row kernel at N = 384
     kc.check_gemm_lnbwd(sim.device, M=200, N=128, K=256)
     kc.check_gemm_lnbwd(sim.device, M=260, N=256, K=256)
     kc.check_gemm_lnbwd(sim.device, M=130, N=512, K=128)
+    from ccd_amd import ops
+    with ops.policy(rowgemm=3):                               # rowgemm16.h: 16-row waves, two workgroups per CU
+        kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=384)
+        kc.check_gemm_lnbwd(sim.device, M=70, N=384, K=768)
     kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=128)      # gemm_row384.h
     kc.check_gemm_lnbwd(sim.device, M=140, N=192, K=64)
 
