@@ -120,12 +120,19 @@ __device__ __forceinline__ void attb_store_rows_of_transposed(const AttbRows& x,
     }
 }
 
+// The two waves of a SIMD (w and w + 4) run the same MFMA / softmax / MFMA phases in lock step after every block barrier -
+// the matrix pipe, the VALU and the LDS take turns instead of overlapping.  Holding waves 4..7 back by about one MFMA phase
+// (skew x 64 cycles) makes the pairs alternate.
+__device__ __forceinline__ void attb_skew(int w, int skew) {
+    if (w >= 4) wave_nap(skew);
+}
+
 __global__ __launch_bounds__(512) void attention_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
                                                                const bf16_t* __restrict__ o,
                                                                const bf16_t* __restrict__ d_o,
                                                                const float* __restrict__ lse,
                                                                float* __restrict__ delta, bf16_t* __restrict__ dqkv,
-                                                               int heads, float scale, int nblocks) {
+                                                               int heads, float scale, int nblocks, int skew) {
     char* smem = dynamic_smem();
     char* k_img = smem;
     char* v_img = smem + ATTB_IMG;
@@ -176,6 +183,7 @@ __global__ __launch_bounds__(512) void attention_bwd_dq_kernel(const bf16_t* __r
         if (hf == 0) delta[stat] = dsum;
         __syncthreads();
         if (blk + (int)gridDim.x < nblocks) request(blk + gridDim.x);      // flies under this block's MFMAs
+        attb_skew(w, skew);
 
         f32x16 dq[2];
 #pragma unroll
@@ -217,7 +225,8 @@ __global__ __launch_bounds__(512) void attention_bwd_dkv_kernel(const bf16_t* __
                                                                 const bf16_t* __restrict__ d_o,
                                                                 const float* __restrict__ lse,
                                                                 const float* __restrict__ delta,
-                                                                bf16_t* __restrict__ dqkv, int heads, float scale, int nblocks) {
+                                                                bf16_t* __restrict__ dqkv, int heads, float scale, int nblocks,
+                                                                int skew) {
     char* smem = dynamic_smem();
     char* q_img = smem;
     char* do_img = smem + ATTB_IMG;
@@ -269,6 +278,7 @@ __global__ __launch_bounds__(512) void attention_bwd_dkv_kernel(const bf16_t* __
         }
         __syncthreads();
         if (blk + (int)gridDim.x < nblocks) request(blk + gridDim.x);      // flies under this block's MFMAs
+        attb_skew(w, skew);
 
         f32x16 dk[2], dv[2];
 #pragma unroll

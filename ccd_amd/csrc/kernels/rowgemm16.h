@@ -132,6 +132,8 @@ __global__ __launch_bounds__(RG16_THREADS, 2) void rowgemm16_lnbwd_kernel(RowGem
     }
     if constexpr (2 * (R - 1) < 2 * (AHEAD - 1)) glds_wait_all();
     const float inv_e = 1.0f / (float)E;
+    // (lab: the second workgroup of every CU starts late - two workgroups launched together run the same phase at the same time)
+    if (p.lab > 0 && blockIdx.x >= gridDim.x / 2) wave_sleep(p.lab);
 
     for (int tile = blockIdx.x; tile < tiles; tile += G) {
         const int m0 = tile * RG16_BM, r0 = m0 + 16 * w;

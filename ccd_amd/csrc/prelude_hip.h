@@ -65,6 +65,7 @@ __device__ __forceinline__ buf_u32x4 buf_load16_nt(buf_rsrc r, unsigned lane_off
 __device__ __forceinline__ void buf_store16_nt(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset, buf_u32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)lane_offset, (int)uniform_offset, 2);
 }
+__device__ __forceinline__ void wave_nap(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); }        // ~n * 64 cycles
 __device__ __forceinline__ void wave_sleep(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127); }   // ~n * 8 k cycles
 // LDS-DMA: one wave instruction copies 64 x 16 B from per-lane global addresses straight into LDS at
 // (wave-uniform lds_base) + lane * 16 - no VGPR round trip, counted on vmcnt like any VMEM load.

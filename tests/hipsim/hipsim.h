@@ -185,6 +185,7 @@ inline void buf_store16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offse
 inline buf_u32x4 buf_load16_nt(buf_rsrc r, unsigned a, unsigned b) { return buf_load16(r, a, b); }
 inline void buf_store16_nt(buf_rsrc r, unsigned a, unsigned b, buf_u32x4 v) { buf_store16(r, a, b, v); }
 inline void wave_sleep(int) {}
+inline void wave_nap(int) {}
 inline int lane_id() { return sim::cur->lane; }
 inline int wave_id() { return sim::cur->wave; }
 
