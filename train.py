@@ -183,7 +183,7 @@ def train(config):
     iteration, epoch = int(to_restore["iteration"]), to_restore["epoch"]
     print(f"continue to train:{iteration}:{epoch}")
     start_time, global_epoch = time.time(), 0
-    pending_loss = None
+    pending_loss, loss_sum, loss_n = None, None, 0
 
     print("Starting DINO training !")
     for train_epoch in range(config.training_epochs):
@@ -198,6 +198,13 @@ def train(config):
             epoch = int((iteration + 1) * global_bs / config.imgnet_based)
             if epoch != global_epoch:          # pseudo-epoch boundary: sync meters, checkpoint, log.txt
                 global_epoch = epoch
+                # the loss of the last enqueued step is still unverified: never persist weights a NaN step has touched
+                if pending_loss is not None and not math.isfinite(pending_loss.item()):
+                    print("Loss is {}, stopping training".format(pending_loss.item()), force=True)
+                    sys.exit(1)
+                if loss_sum is not None:       # the meters see EVERY iteration's loss (summed on the device, read here)
+                    metric_logger.update(loss=(loss_sum / loss_n).item())
+                    loss_sum, loss_n = None, 0
                 metric_logger.synchronize_between_processes()
                 print("Averaged stats:", metric_logger)
                 stats = {k: m.global_avg for k, m in metric_logger.meters.items()}
@@ -223,8 +230,11 @@ def train(config):
                 print("Loss is {}, stopping training".format(pending_loss.item()), force=True)
                 sys.exit(1)
             pending_loss = loss
-            if iteration % 10 == 0:
-                metric_logger.update(loss=loss.item())
+            loss_sum = loss.detach() if loss_sum is None else loss_sum + loss.detach()
+            loss_n += 1
+            if iteration % 10 == 0:            # one host read per print interval: the mean of the iterations since the last one
+                metric_logger.update(loss=(loss_sum / loss_n).item())
+                loss_sum, loss_n = None, 0
                 metric_logger.update(lr=optimizer.param_groups[0]["lr"])
                 metric_logger.update(wd=optimizer.param_groups[0]["weight_decay"])
             if iteration % config.training_show_iters == 0 and config.writer is not None:
