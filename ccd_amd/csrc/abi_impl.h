@@ -355,8 +355,19 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
     return ccd_rt_last_error();
 }
 
+static int ccd_gemm_tn_impl(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P, int Q, int Mc, int epilogue, float* C,
+                            long ldc, float alpha, int splits, const int* d_rows, int rows_mul, float* colsum_a, void* stream);
 int ccd_gemm_tn(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P, int Q, int Mc, int epilogue, float* C,
                 long ldc, float alpha, int splits, const int* d_rows, int rows_mul, void* stream) {
+    return ccd_gemm_tn_impl(A, lda, B, ldb, P, Q, Mc, epilogue, C, ldc, alpha, splits, d_rows, rows_mul, nullptr, stream);
+}
+int ccd_gemm_tn_colsum(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P, int Q, int Mc, float* C, long ldc,
+                       float* colsum_a, int splits, void* stream) {
+    CCD_CHECK(colsum_a, CCD_EINVAL);
+    return ccd_gemm_tn_impl(A, lda, B, ldb, P, Q, Mc, CCD_EPI_ATOMIC, C, ldc, 1.0f, splits, nullptr, 1, colsum_a, stream);
+}
+static int ccd_gemm_tn_impl(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P, int Q, int Mc, int epilogue, float* C,
+                            long ldc, float alpha, int splits, const int* d_rows, int rows_mul, float* colsum_a, void* stream) {
     CCD_CHECK(A && B && C, CCD_EINVAL);
     CCD_CHECK(CCD_ALIGNED16(A) && CCD_ALIGNED16(B) && CCD_ALIGNED16(C), CCD_EINVAL);
     if (P == 0 || Q == 0 || Mc == 0) return CCD_OK;
@@ -378,7 +389,7 @@ int ccd_gemm_tn(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P,
     p.C = C; p.ldc = ldc; p.C2 = nullptr; p.ldc2 = 0; p.bias = nullptr; p.resid = nullptr; p.ldr = 0;
     p.rowscale = nullptr; p.rows_per_sample = 1; p.rps_shift = 0; p.aux = nullptr; p.ldaux = 0;
     p.k_per_split = per; p.m_fastest = 0; p.alpha = alpha; p.d_rows = d_rows; p.rows_mul = rows_mul;
-    p.colsum = nullptr;
+    p.colsum = nullptr; p.colsum_a = colsum_a;
     return ccd_launch_gemm<true>(p, epilogue, splits, stream);
 }
 

@@ -49,6 +49,7 @@ struct GemmParams {
     int work_items;         // tiles x splits (the persistent grid may be smaller)
     float alpha;            // scales acc before the epilogue
     float* colsum;          // optional [N] fp32: += column sums of the (final) output tile, e.g. the bias gradient
+    float* colsum_a;        // TN only, optional [P] fp32: += column sums of operand A (the bias gradient that belongs to dW = dY^T X)
     float* colsumsq;        // optional [N] fp32: += column sums of squares (BatchNorm batch statistics), EPI_BF16 only
     // ---- implicit-GEMM convolution (NT, GATHER instantiation): A row r is pixel (n, oy, ox) of a 2^gh x 2^gw grid,
     // contraction index k = tap * cin + c reads source pixel (oy*s_mul + dy(tap), ox*s_mul + dx(tap)) of an s_h x s_w
@@ -357,11 +358,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
             ntb.load(make_rsrc(p.B + k_begin + kt * GEMM_BK, whole), rb);
         }
     };
+    // operand-A column sums (TN): kept per thread while the work item's k-tiles pass through the staging registers; only the
+    // items of the first column tile (n0 == 0) carry them, so every row of A is summed exactly once
+    float asum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool want_asum = false;
     auto store = [&](int stage, const u32x4 (&ra)[4], const u32x4 (&rb)[4]) {
         char* as = smem + stage * 2 * GEMM_STAGE_BYTES;
         char* bs = as + GEMM_STAGE_BYTES;
         if (TN) { gemm_store_tn(as, ra); gemm_store_tn(bs, rb); }
         else { gemm_store_nt(as, ra); gemm_store_nt(bs, rb); }
+        if (TN && !GATHER && want_asum) {                    // this thread's 4 contraction rows x 8 columns of dY
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    asum[2 * jj] += bf_lo(ra[i][jj]);
+                    asum[2 * jj + 1] += bf_hi(ra[i][jj]);
+                }
+        }
     };
     f32x16 acc[2][2];
     auto compute = [&](int stage) {
@@ -408,6 +422,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     float csq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     unsigned item = slot;
     decode(item);
+    want_asum = TN && p.colsum_a != nullptr && n0 == 0;
     init_loaders();
     load(0, ra0, rb0);
     load(1, ra1, rb1);
@@ -444,12 +459,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
             __syncthreads();
             LAB_STAMP(1)
         }
+        if (TN && !GATHER && want_asum) {                    // (wave-uniform) 16 contraction blocks x 128 columns -> one atomic per column
+            float* red = reinterpret_cast<float*>(smem);
+            const int cb = t & 15, mb = t >> 4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { red[mb * 128 + 8 * cb + j] = asum[j]; asum[j] = 0.f; }
+            __syncthreads();
+            if (t < 128 && m0 + t < p.M) {
+                float a = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) a += red[q * 128 + t];
+                atomicAdd(p.colsum_a + m0 + t, a);
+            }
+            __syncthreads();
+        }
         // ---- next work item: its first two k-tiles fly while this tile's accumulators are written out
         const int em0 = m0, en0 = n0;
         const unsigned next = item + nx;
         const bool has_next = next < cnt_x;
         if (has_next) {
             decode(next);
+            want_asum = TN && p.colsum_a != nullptr && n0 == 0;
             init_loaders();
             load(0, ra0, rb0);
             load(1, ra1, rb1);

@@ -190,6 +190,23 @@ def mlp_fused(y, w1, b1, w2, b2, *, resid, rowscale, rows_per_sample, gamma, bet
     return out, yn, mean, rstd, u
 
 
+def gemm_tn_colsum(a, b, out, colsum, *, splits=0):
+    """out[P,Q] += a[Mc,P]^T @ b[Mc,Q] and colsum[P] += a.sum(0): the weight and the bias gradient of a Linear in one pass
+    over dY (fp32 atomics)."""
+    _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(out, F32, "out"); _chk(colsum, F32, "colsum")
+    Mc, Pd = a.shape
+    Q = b.shape[1]
+    assert b.shape[0] == Mc and tuple(out.shape) == (Pd, Q) and colsum.numel() == Pd
+    span = TIMER.span("gemm_tn_atomic", 2.0 * Mc * Pd * Q, 2.0 * Mc * (Pd + Q) + 4.0 * Pd * Q) if TIMER is not None else None
+    if span:
+        span[0].record()
+    _call("ccd_gemm_tn_colsum", _lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0), Pd, Q, Mc, _lib.ptr(out), out.stride(0),
+          _lib.ptr(colsum), int(splits))
+    if span:
+        span[1].record()
+    return out
+
+
 def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, splits=0, d_rows=None, rows_mul=1):
     """out[P,Q] (+)= a[Mc,P]^T @ b[Mc,Q]  (fp32 out; accumulate=True adds with fp32 atomics, split over Mc)."""
     _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(out, F32, "out")

@@ -92,6 +92,11 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
  * P % 8 == 0, Q % 8 == 0; epilogue CCD_EPI_ATOMIC accumulates into fp32 C (split over m), CCD_EPI_F32 stores. */
 int ccd_gemm_tn(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P, int Q, int Mc, int epilogue,
                 float* C, long ldc, float alpha, int splits, const int* d_rows, int rows_mul, void* stream);
+/* The same weight-gradient product with the BIAS gradient of the same Linear in one pass over dY:
+ * C[P,Q] += A^T . B (fp32 atomics, split over m) and colsum_a[P] += column sums of A - the rows of dY are summed while they
+ * pass through the loader's registers (replaces ccd_gemm_tn + ccd_colsum_bf16: one read of dY less). */
+int ccd_gemm_tn_colsum(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P, int Q, int Mc, float* C, long ldc,
+                       float* colsum_a, int splits, void* stream);
 /* d_rows (optional, both GEMMs): device int; the effective row count (NT: M, TN: Mc) is
  * min(static value, d_rows[0] * rows_mul) so data-dependent row counts never reach the host. */
 

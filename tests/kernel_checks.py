@@ -85,6 +85,18 @@ def check_gemm_dynamic_rows(dev, M, N, K, live, seed=5):
     assert bool((outb[2 * live:].float() == 7.0).all()), "rows past the device-side count were written (bf16)"
 
 
+def check_gemm_tn_colsum(dev, Mc=300, P=264, Q=72, splits=3, seed=12):
+    """Weight + bias gradient in one pass: C += A^T B and colsum += A.sum(0), several column tiles (only the first carries the
+    sums), ragged contraction slices, accumulation onto existing values."""
+    g = torch.Generator().manual_seed(seed)
+    a = rnd((Mc, P), g).to(BF); b = rnd((Mc, Q), g).to(BF)
+    c0 = rnd((P, Q), g); s0 = rnd((P,), g)
+    out, cs = c0.clone().to(dev), s0.clone().to(dev)
+    ops.gemm_tn_colsum(a.to(dev), b.to(dev), out, cs, splits=splits)
+    close(out, c0 + a.float().t() @ b.float(), 2e-3, 2e-3 * Mc ** 0.5, "gemm_tn_colsum/C")
+    close(cs, s0 + a.float().sum(0), 1e-4, 1e-4 * Mc ** 0.5, "gemm_tn_colsum/colsum")
+
+
 def check_gemm_nt_split_k(dev, M=200, N=72, K=16384 + 8192 + 64, seed=9):
     """EPI_ATOMIC on the NT product: C += A . B^T with the contraction cut into slices of 8192 (the head's data gradient,
     K = 65536), ragged last slice, accumulation onto existing values."""

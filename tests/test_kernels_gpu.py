@@ -22,6 +22,11 @@ def test_gemm_nt(hip, M, N, K):
     kc.check_gemm_nt(hip.device, M, N, K)
 
 
+@pytest.mark.parametrize("Mc,P,Q,splits", [(300, 264, 72, 3), (131072, 1152, 384, 0), (4096, 384, 384, 0)])
+def test_gemm_tn_colsum(hip, Mc, P, Q, splits):
+    kc.check_gemm_tn_colsum(hip.device, Mc, P, Q, splits)
+
+
 def test_gemm_nt_split_k(hip):
     kc.check_gemm_nt_split_k(hip.device)
     kc.check_gemm_nt_split_k(hip.device, M=3000, N=256, K=65536)

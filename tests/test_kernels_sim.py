@@ -26,6 +26,11 @@ def test_gemm_nt_split_k_sim(sim):
     kc.check_gemm_nt_split_k(sim.device, M=70, N=40)
 
 
+def test_gemm_tn_colsum_sim(sim):
+    kc.check_gemm_tn_colsum(sim.device)
+    kc.check_gemm_tn_colsum(sim.device, Mc=64, P=8, Q=264, splits=0)
+
+
 def test_gemm_tn_sim(sim):
     kc.check_gemm_tn(sim.device, Mc=300, P=136, Q=72, splits=3)
     kc.check_gemm_tn(sim.device, Mc=64, P=8, Q=264)
