@@ -17,7 +17,7 @@ def hip():
 
 
 @pytest.mark.parametrize("M,N,K", [(200, 136, 128), (1024, 1152, 384), (4096, 384, 1536), (96, 65536, 256),
-                                   (1000, 192, 192), (40000, 264, 192), (33000, 1536, 384), (131072, 384, 384)])
+                                   (1000, 192, 192), (40000, 264, 192), (33000, 1536, 384), (131072, 384, 384), (33000, 1152, 384)])
 def test_gemm_nt(hip, M, N, K):
     kc.check_gemm_nt(hip.device, M, N, K)
 
