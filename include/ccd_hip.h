@@ -33,9 +33,16 @@ const char* ccd_build_info(void);
 
 /* Kernel-selection policy.  Which tile shape serves a product is decided by a small table of integers that is read ONCE
  * from the environment (CCD_GEMM_256, CCD_GEMM_256_MIN_M, CCD_GEMM_256_MIN_N, CCD_GEMM_256_F32, CCD_GEMM_256_DEEP,
- * CCD_GEMM_ROW384, CCD_LN_BWD_BPC, CCD_DEC_ATTN_SIMT, CCD_CU_RESERVE) and can be changed at run time by key (lower case,
- * without the prefix) - the launch path never calls getenv.  Unknown key: CCD_EINVAL.  No reference counterpart: the
- * reference leaves kernel selection to ATen / cuDNN heuristics. */
+ * CCD_GEMM_ROW384, CCD_ROWGEMM, CCD_LN_BWD_BPC, CCD_DEC_ATTN_SIMT, CCD_ATTN_SKEW, CCD_CU_RESERVE, CCD_LAB) and can be
+ * changed at run time by key (lower case, without the prefix) - the launch path never calls getenv.  Unknown key:
+ * CCD_EINVAL.  No reference counterpart: the reference leaves kernel selection to ATen / cuDNN heuristics.
+ *   rowgemm    0: the row-wise epilogues (ccd_gemm_nt_resid_ln / _lnbwd) on gemm_row384.h's tile (N <= 384 only)
+ *              1 (default): LayerNorm-backward product on rowgemm16.h (N = 384) / rowgemm.h (N = 128, 256, 512);
+ *                 residual + LayerNorm on gemm_row384.h (N <= 384) / rowgemm.h (N = 512)
+ *              2: rowgemm.h wherever its shapes allow (tests), 3: rowgemm16.h with the 6-block ring (lab)
+ *   attn_skew  cycles / 64 by which waves 4..7 of the attention-backward kernels trail waves 0..3 (default 8)
+ *   cu_reserve compute units the persistent grids leave free (set while an RCCL gradient reducer is attached)
+ *   lab        scratch switch of the lab harnesses under tools/ (0 in production) */
 int ccd_policy_set(const char* key, int value);
 int ccd_policy_get(const char* key, int* value);
 
