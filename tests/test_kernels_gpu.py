@@ -45,7 +45,10 @@ def test_layernorm(hip, rows, E):
 
 @pytest.mark.parametrize("views,heads,spike", [(1, 2, False), (16, 6, False), (3, 8, True)])
 def test_attention(hip, views, heads, spike):
+    from ccd_amd import ops
     kc.check_attention(hip.device, views, heads, spike=spike)
+    with ops.policy(attn_fused=1):                            # the backward pass as ONE kernel (q, k, v, dO, O read once)
+        kc.check_attention(hip.device, views, heads, spike=spike)
 
 
 def test_gemm_dynamic_rows(hip):

@@ -42,7 +42,10 @@ def test_layernorm_sim(sim):
 
 
 def test_attention_sim(sim):
+    from ccd_amd import ops
     kc.check_attention(sim.device, views=1, heads=2)
+    with ops.policy(attn_fused=1):                           # backward as ONE kernel
+        kc.check_attention(sim.device, views=1, heads=2)
 
 
 def test_gemm_dynamic_rows_sim(sim):

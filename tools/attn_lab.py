@@ -29,10 +29,12 @@ def main():
     out, lse = ops.attention_fwd(qkv, heads, scale)
     ms = timeit(lambda: ops.attention_fwd(qkv, heads, scale))
     print(json.dumps({"kernel": "attention_fwd", "views": a.views, "ms": round(ms, 4)}), flush=True)
-    for skew in a.skews:
-        with ops.policy(attn_skew=skew):
-            ms = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, scale))
-        print(json.dumps({"kernel": "attention_bwd (dq + dkv)", "views": a.views, "skew": skew, "ms": round(ms, 4)}), flush=True)
+    for fused in (1, 0):
+        for skew in a.skews:
+            with ops.policy(attn_skew=skew, attn_fused=fused):
+                ms = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, scale))
+            print(json.dumps({"kernel": "attention_bwd " + ("fused" if fused else "(dq + dkv)"), "views": a.views, "skew": skew,
+                              "ms": round(ms, 4)}), flush=True)
 
 
 if __name__ == "__main__":
