@@ -13,7 +13,7 @@
 //     colour-augmented, view 2 colour-augmented + affine-warped; ImageNet mean/std normalisation (dataset.py:79-80,
 //     TF.normalize :80).  The colour stage is the pointwise family of the reference's imgaug pipelines (invert, grayscale
 //     blend, channel shuffle, gamma / linear contrast, brightness and per-channel gains, solarize, additive / multiplicative
-//     / impulse noise); the warp samples the colour-augmented source with bilinear weights and zero fill, at
+//     / impulse noise) behind one optional 3x3 filter (blur / sharpen / emboss / edge members); the warp samples the colour-augmented source with bilinear weights and zero fill, at
 //     src = W_^-1 theta W_ (x, y, 1) - the exact inverse of how the dataset derives theta from the pixel matrix (:65-71).
 #pragma once
 
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(KM_THREADS) void kmeans2_mask_kernel(const unsigned
 }
 
 // ---- augmentation ---------------------------------------------------------------------------------------------------
-constexpr int AUG_NP = 16;        // floats per (sample, view 1 | view 2): see ccd_amd/dataset/augment.py for the sampler
+constexpr int AUG_NP = 32;        // floats per (sample, view 1 | view 2): see ccd_amd/dataset/augment.py for the sampler
 // p[0] invert (0/1)  p[1] gray alpha  p[2] channel permutation id 0..5  p[3] gamma  p[4..6] per-channel gain
 // p[7] contrast alpha (around 128)  p[8] add  p[9] gaussian sigma  p[10] multiplicative noise half range
 // p[11] impulse probability  p[12] solarize threshold (>= 256: off)  p[13] noise seed (integer valued)
@@ -146,6 +146,28 @@ __device__ __forceinline__ void aug_colour(const float* __restrict__ p, float r,
     }
 }
 
+// the (optionally 3x3-filtered) source pixel
+__device__ __forceinline__ void aug_source(const unsigned char* __restrict__ src, int H, int W, int y, int x,
+                                           const float* __restrict__ p, float* rgb) {
+    if (p[14] == 0.f) {
+        const int sp = (y * W + x) * 3;
+        rgb[0] = src[sp]; rgb[1] = src[sp + 1]; rgb[2] = src[sp + 2];
+        return;
+    }
+    rgb[0] = rgb[1] = rgb[2] = 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            int yy = y + dy, xx = x + dx;
+            yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+            xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+            const float wgt = p[16 + 3 * (dy + 1) + (dx + 1)];
+            const int sp = (yy * W + xx) * 3;
+            rgb[0] += wgt * src[sp]; rgb[1] += wgt * src[sp + 1]; rgb[2] += wgt * src[sp + 2];
+        }
+}
+
 // img uint8 [B, H, W, 3]; params fp32 [B, 2, AUG_NP] (view 1, view 2); theta fp32 [B, 3, 3]; out fp32 [B, 3 views, 3, H, W]
 __global__ __launch_bounds__(256) void augment_views_kernel(const unsigned char* __restrict__ img, const float* __restrict__ params,
                                                             const float* __restrict__ theta, float* __restrict__ out,
@@ -166,8 +188,9 @@ __global__ __launch_bounds__(256) void augment_views_kernel(const unsigned char*
         for (int k = 0; k < 3; ++k) o[k * plane] = (c[k] * (1.0f / 255.f) - mean[k]) * istd[k];
     }
     {
-        float c[3];
-        aug_colour(params + (long)b * 2 * AUG_NP, r, g, bl, (unsigned)pix, c);
+        float c[3], f[3];
+        aug_source(src, H, W, y, x, params + (long)b * 2 * AUG_NP, f);
+        aug_colour(params + (long)b * 2 * AUG_NP, f[0], f[1], f[2], (unsigned)pix, c);
 #pragma unroll
         for (int k = 0; k < 3; ++k) o[(3 + k) * plane] = (c[k] * (1.0f / 255.f) - mean[k]) * istd[k];
     }
@@ -189,8 +212,9 @@ __global__ __launch_bounds__(256) void augment_views_kernel(const unsigned char*
                 const float wgt = (dx ? ax : 1.0f - ax) * (dy ? ay : 1.0f - ay);
                 if (xx >= 0 && xx < W && yy >= 0 && yy < H && wgt != 0.f) {
                     const int sp = yy * W + xx;
-                    float c[3];
-                    aug_colour(p2, src[sp * 3], src[sp * 3 + 1], src[sp * 3 + 2], (unsigned)sp, c);
+                    float c[3], f[3];
+                    aug_source(src, H, W, yy, xx, p2, f);
+                    aug_colour(p2, f[0], f[1], f[2], (unsigned)sp, c);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) acc[k] += wgt * c[k];
                 }

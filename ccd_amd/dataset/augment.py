@@ -8,7 +8,9 @@ Colour = the POINTWISE members of the imgaug pipelines the configs select (augme
 `augment_tfs`, 6 for `augment_color`): invert, grayscale blend, channel shuffle, gamma / linear contrast, brightness and
 per-channel gains (MultiplyBrightness, ChangeColorTemperature), solarize, additive gaussian / multiplicative / impulse
 noise, with the reference's ranges and its "identity with probability 0.2 / each group with probability 0.7" structure.
-The spatial members (blur, emboss, edge filters, weather, JPEG, elastic) are not reproduced.
+The 3x3-support SPATIAL members are reproduced as one 3x3 filter in front of the pointwise chain (GaussianBlur / AverageBlur as
+their 3x3 truncation, Sharpen, Emboss, EdgeDetect with imgaug's effect matrices); median / motion / bilateral blur, weather,
+JPEG and elastic members are not.
 """
 from __future__ import annotations
 
@@ -16,8 +18,20 @@ import math
 
 import numpy as np
 
-AUG_NP = 16
-IDENTITY_PARAMS = np.array([0, 0, 0, 1, 1, 1, 1, 1, 0, 0, 0, 0, 256, 0, 0, 0], dtype=np.float32)
+AUG_NP = 32
+IDENTITY_PARAMS = np.array([0, 0, 0, 1, 1, 1, 1, 1, 0, 0, 0, 0, 256, 0, 0, 0] + [0, 0, 0, 0, 1, 0, 0, 0, 0] + [0] * 7,
+                           dtype=np.float32)            # [16:25] = the 3x3 filter (identity), [14] = filter on
+_NOCHANGE = np.array([[0, 0, 0], [0, 1, 0], [0, 0, 0]], dtype=np.float64)
+
+
+def _set_filter(p, kernel):
+    p[14] = 1.0
+    p[16:25] = np.asarray(kernel, dtype=np.float32).reshape(-1)
+
+
+def _blend(alpha, effect):
+    """imgaug's convolutional augmenters: (1 - alpha) * identity + alpha * effect matrix."""
+    return (1.0 - alpha) * _NOCHANGE + alpha * np.asarray(effect, dtype=np.float64)
 
 
 def affine_pixel_matrix(rs: np.random.RandomState, h: int, w: int) -> np.ndarray:
@@ -78,7 +92,13 @@ def _colour_params(rs: np.random.RandomState, severity: int) -> np.ndarray:
         elif k == 6:
             if rs.uniform() < 0.5:
                 p[12] = rs.uniform(32, 128)
-        # k == 7: a spatial member (emboss / edge / jpeg / dropout2d) was drawn: nothing pointwise to do
+        elif k == 7:                              # Emboss(alpha 0-1, strength 0.5-1.5) / EdgeDetect(alpha 0-1)
+            a = rs.uniform(0.0, 1.0)
+            if rs.uniform() < 0.5:
+                st = rs.uniform(0.5, 1.5)
+                _set_filter(p, _blend(a, [[-1 - st, 0 - st, 0], [0 - st, 1, 0 + st], [0, 0 + st, 1 + st]]))
+            else:
+                _set_filter(p, _blend(a, [[0, 1, 0], [1, -4, 1], [0, 1, 0]]))
     if groups["color"] is not None and rs.uniform() < groups["color"]:
         k = rs.randint(0, 5)
         if k == 0:
@@ -95,6 +115,17 @@ def _colour_params(rs: np.random.RandomState, severity: int) -> np.ndarray:
             p[6] *= 1.0 - 0.25 * t
         elif k == 4:
             p[3] = rs.uniform(0.5, 2.0)           # GammaContrast
+    if severity == 5 and p[14] == 0 and rs.uniform() < 0.7:            # `Blur`: Sharpen | one of the blurs
+        if rs.uniform() < 0.5:
+            a, light = rs.uniform(0.0, 0.5), rs.uniform(0.0, 0.5)
+            _set_filter(p, _blend(a, [[-1, -1, -1], [-1, 8 + light, -1], [-1, -1, -1]]))
+        elif rs.uniform() < 0.5:                  # GaussianBlur(sigma 0.5 - 1.5), truncated to 3 x 3
+            sg = rs.uniform(0.5, 1.5)
+            g1 = np.array([math.exp(-0.5 / sg ** 2), 1.0, math.exp(-0.5 / sg ** 2)])
+            g1 /= g1.sum()
+            _set_filter(p, np.outer(g1, g1))
+        else:                                     # AverageBlur, 3 x 3
+            _set_filter(p, np.full((3, 3), 1.0 / 9.0))
     if groups["contrast"] is not None and rs.uniform() < groups["contrast"]:
         k = rs.randint(0, 3)
         if k == 0:
@@ -106,7 +137,7 @@ def _colour_params(rs: np.random.RandomState, severity: int) -> np.ndarray:
 
 
 def sample_colour_params(rs: np.random.RandomState, batch: int, severity: int = 5) -> np.ndarray:
-    """fp32 [batch, 2, 16]: view 1 from pipeline `severity`, view 2 from the same pipeline (both come from `augment_tfs`,
+    """fp32 [batch, 2, 32]: view 1 from pipeline `severity`, view 2 from the same pipeline (both come from `augment_tfs`,
     datasetsupervised_kmeans.py:57)."""
     out = np.empty((batch, 2, AUG_NP), dtype=np.float32)
     for b in range(batch):

@@ -374,14 +374,14 @@ def kmeans2_mask(grays, device=None):
 
 
 def augment_views(img, params, theta, mean, std):
-    """img uint8 [B,H,W,3] (resized samples), params fp32 [B,2,16], theta fp32 [B,3,3] -> image_tensors fp32 [B,3,3,H,W]:
+    """img uint8 [B,H,W,3] (resized samples), params fp32 [B,2,32], theta fp32 [B,3,3] -> image_tensors fp32 [B,3,3,H,W]:
     (plain, colour-augmented, colour-augmented + warped by theta), normalised - the dataset's batch contract
     (datasetsupervised_kmeans.py:48-87)."""
     import ctypes as C
     assert img.dtype == U8 and img.is_contiguous() and img.dim() == 4 and img.shape[3] == 3
     _chk(params, F32, "params"); _chk(theta, F32, "theta")
     B, H, W, _ = img.shape
-    assert tuple(params.shape) == (B, 2, 16) and tuple(theta.shape) == (B, 3, 3)
+    assert tuple(params.shape) == (B, 2, 32) and tuple(theta.shape) == (B, 3, 3)
     out = torch.empty((B, 3, 3, H, W), dtype=F32, device=img.device)
     m3, s3 = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
     _call("ccd_augment_views", _lib.ptr(img), _lib.ptr(params), _lib.ptr(theta), _lib.ptr(out), B, H, W,

@@ -168,7 +168,7 @@ int ccd_seg_to_mask(const float* seg_logits, float* mask, int images, void* stre
 int ccd_kmeans2_mask(const uint8_t* gray, const long* offsets, const int* hw, uint8_t* mask, int images, void* stream);
 /* The three views of ImageDatasetSelfSupervisedKmeans._process_training (datasetsupervised_kmeans.py:48-87) from resized
  * uint8 images img [B,H,W,3]: out fp32 [B,3,3,H,W] = (plain, colour(params[b,0]), warp_theta(colour(params[b,1]))),
- * each normalised with mean3 / std3 (HOST arrays of 3 floats; dataset.py:79-80).  params fp32 [B,2,16] (layout in
+ * each normalised with mean3 / std3 (HOST arrays of 3 floats; dataset.py:79-80).  params fp32 [B,2,32] (layout in
  * kernels/datapipe.h), theta fp32 [B,3,3] = the `metrics` tensor the model receives (identity = no warp). */
 int ccd_augment_views(const uint8_t* img, const float* params, const float* theta, float* out, int batch, int height, int width,
                       const float* mean3, const float* std3, void* stream);

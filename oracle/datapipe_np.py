@@ -59,7 +59,7 @@ def kmeans2_mask(gray):
 
 
 # ---------------------------------------------------------------------------------------------------- augmentation
-AUG_NP = 16
+AUG_NP = 32
 
 
 def _hash(a, b):
@@ -110,8 +110,23 @@ def colour(p, rgb, pix_id):
     return out.astype(f)
 
 
+def source(p, src):
+    """the optionally 3x3-filtered image (borders replicate): src [H,W,3] fp32 -> [H,W,3] fp32."""
+    f = np.float32
+    if p[14] == 0:
+        return src
+    H, W, _ = src.shape
+    out = np.zeros_like(src)
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            yy = np.clip(np.arange(H) + dy, 0, H - 1)
+            xx = np.clip(np.arange(W) + dx, 0, W - 1)
+            out = out + f(p[16 + 3 * (dy + 1) + (dx + 1)]) * src[yy][:, xx]
+    return out.astype(f)
+
+
 def augment_views(img, params, theta, mean, std):
-    """img uint8 [B,H,W,3], params [B,2,16], theta [B,3,3] -> fp32 [B,3,3,H,W]."""
+    """img uint8 [B,H,W,3], params [B,2,32], theta [B,3,3] -> fp32 [B,3,3,H,W]."""
     f = np.float32
     img = np.asarray(img)
     B, H, W, _ = img.shape
@@ -126,7 +141,7 @@ def augment_views(img, params, theta, mean, std):
     for b in range(B):
         src = img[b].astype(f)
         out[b, 0] = norm(src)
-        out[b, 1] = norm(colour(params[b, 0], src, pid))
+        out[b, 1] = norm(colour(params[b, 0], source(params[b, 0], src), pid))
         th = theta[b].astype(f)
         xn = f(2) * xs.astype(f) / f(W - 1) - f(1)
         yn = f(2) * ys.astype(f) / f(H - 1) - f(1)
@@ -135,7 +150,7 @@ def augment_views(img, params, theta, mean, std):
         x0, y0 = np.floor(sx), np.floor(sy)
         ax, ay = (sx - x0).astype(f), (sy - y0).astype(f)
         x0, y0 = x0.astype(np.int64), y0.astype(np.int64)
-        col2 = colour(params[b, 1], src, pid)                     # colour of every source pixel once
+        col2 = colour(params[b, 1], source(params[b, 1], src), pid)   # colour of every source pixel once
         acc = np.zeros((H, W, 3), f)
         for dy in (0, 1):
             for dx in (0, 1):

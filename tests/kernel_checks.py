@@ -280,8 +280,8 @@ def check_augment_views(dev, B=5, H=32, W=128, seed=52):
     params = sample_colour_params(rs, B, 5)
     # make sure every member is exercised at least once
     params[0, 0] = IDENTITY_PARAMS; params[0, 1] = IDENTITY_PARAMS
-    params[1, 0] = [1, 0.4, 3, 1.7, 1.2, 0.8, 1.1, 0.7, 12, 9.0, 0.3, 0.05, 100, 77, 0, 0]
-    params[1, 1] = [0, 1.0, 5, 0.6, 1, 1, 1, 1, -20, 0, 0, 0.1, 256, 123456, 0, 0]
+    params[1, 0] = [1, 0.4, 3, 1.7, 1.2, 0.8, 1.1, 0.7, 12, 9.0, 0.3, 0.05, 100, 77, 1, 0] + [0.05, 0.1, 0.05, 0.1, 0.4, 0.1, 0.05, 0.1, 0.05] + [0] * 7
+    params[1, 1] = [0, 1.0, 5, 0.6, 1, 1, 1, 1, -20, 0, 0, 0.1, 256, 123456, 1, 0] + [-0.3, -0.3, -0.3, -0.3, 3.5, -0.3, -0.3, -0.3, -0.3] + [0] * 7
     theta = sample_theta(rs, B, H, W, p_warp=1.0)
     theta[2] = np.eye(3)
     mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)

@@ -123,9 +123,12 @@ def test_theta_is_the_datasets_composition():
     assert 0.26 < ident < 0.34                                      # `random.random() > 0.3` -> warp
     assert np.allclose(th[:, 2], [0, 0, 1])
     p = sample_colour_params(np.random.RandomState(0), 500, 5)
-    assert p.shape == (500, 2, 16) and np.isfinite(p).all() and (p[..., 3] > 0).all() and (p[..., 2] < 6).all()
+    assert p.shape == (500, 2, 32) and np.isfinite(p).all() and (p[..., 3] > 0).all() and (p[..., 2] < 6).all()
     from ccd_amd.dataset.augment import IDENTITY_PARAMS
-    assert (sample_colour_params(np.random.RandomState(0), 4, 0)[..., :13] == IDENTITY_PARAMS[:13]).all()   # severity 0: no colour change
+    ident = sample_colour_params(np.random.RandomState(0), 4, 0)
+    assert (ident[..., :13] == IDENTITY_PARAMS[:13]).all() and (ident[..., 14:] == IDENTITY_PARAMS[14:]).all()   # severity 0
+    filt = p[p[..., 14] == 1][:, 16:25]
+    assert 0.2 < (p[..., 14] == 1).mean() < 0.9 and np.abs(filt.sum(1)).max() < 3.0        # 3x3 members are drawn and bounded
 
 
 def test_resize_is_cv2_inter_linear_geometry():
