@@ -15,9 +15,14 @@ BF = torch.bfloat16
 PEAK_TF, PEAK_GBS = 2500.0, 8000.0
 
 
-def timeit(fn, iters=20, warm=3):
-    for _ in range(warm):
+def timeit(fn, iters=20, warm=3, warm_seconds=0.5):
+    import time
+    t0, n = time.time(), 0
+    while n < warm or time.time() - t0 < warm_seconds:      # clock ramp: see tools/mlp_lab.py
         fn()
+        n += 1
+        if n % 8 == 0:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -14,9 +14,17 @@ from ccd_amd import ops
 BF = torch.bfloat16
 
 
-def timeit(fn, iters=20, warm=3):
-    for _ in range(warm):
+def timeit(fn, iters=20, warm=3, warm_seconds=0.5):
+    """Mean ms per call.  Warm-up runs until `warm_seconds` of GPU work have passed: the first configuration of a lab loop
+    measured 8 - 15 % slow with three warm-up calls (clock ramp) - an artefact that once read as a gain of whatever came second."""
+    import time
+    t0 = time.time()
+    n = 0
+    while n < warm or time.time() - t0 < warm_seconds:
         fn()
+        n += 1
+        if n % 8 == 0:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
