@@ -86,7 +86,7 @@ struct CcdPolicy {
     int ln_bwd_bpc = 5;         // LayerNorm backward: blocks per CU (one resident wave; more blocks = more dgamma/dbeta atomics)
     int dec_attn_simt = 0;      // decoder attention: force the general SIMT kernels
     int attn_fused = 0;         // attention backward: 1 = dQ and dK/dV in one kernel (reads q, k, v, dO, O once; measured 0.407 vs 0.377 ms)
-    int attn_skew = 8;          // attention backward: waves 4..7 start each block ~skew * 64 cycles late (0.412 -> 0.373 ms per layer)
+    int attn_skew = 0;          // attention backward: waves 4..7 start each block ~skew * 64 cycles late (lab; no effect once clocks are warm)
     int cu_reserve = 0;         // compute units the persistent grids leave free (set while an RCCL gradient reducer is attached)
     int lab = 0;                // scratch switch for kernel experiments (tools/*_lab.py); 0 in production
 };
@@ -281,9 +281,10 @@ int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, 
         q.ldr = q.ldc = q.ld_y = 0; q.ln_eps = 0.f;
         const int tiles = (M + ccd::RG_BM - 1) / ccd::RG_BM, smem = ccd::rg_smem_bytes(N);
         const dim3 grid(tiles < cus ? tiles : cus), block(ccd::RG_THREADS);
-        // N = 384: two independent 64-row workgroups per CU (rowgemm16.h: 0.309 / 0.273 ms against 0.345 / 0.291 of the 128-row
-        // kernel at K = 1536 / 1152, 131072 rows); policy rowgemm = 2 keeps the 128-row kernel, 3 = the 6-block ring (lab)
-        if (ccd_policy().rowgemm == 1 && N == 384 && K % 192 == 0) {
+        // N = 384, policy rowgemm = 4: two independent 64-row workgroups per CU (rowgemm16.h).  With warmed-up clocks it is 3 %
+        // SLOWER than the 128-row kernel (0.306 / 0.272 vs 0.297 / 0.266 ms at K = 1536 / 1152, 131072 rows; gemm_row384.h:
+        // 0.324 / 0.314) - it is kept as the tested record of that experiment, not as the default
+        if (ccd_policy().rowgemm == 4 && N == 384 && K % 192 == 0) {
             const int tiles16 = (M + ccd::RG16_BM - 1) / ccd::RG16_BM;
             const dim3 grid16(tiles16 < 2 * cus ? tiles16 : 2 * cus), block16(ccd::RG16_THREADS);
             q.lab = ccd_policy().lab;

@@ -37,10 +37,12 @@ const char* ccd_build_info(void);
  * changed at run time by key (lower case, without the prefix) - the launch path never calls getenv.  Unknown key:
  * CCD_EINVAL.  No reference counterpart: the reference leaves kernel selection to ATen / cuDNN heuristics.
  *   rowgemm    0: the row-wise epilogues (ccd_gemm_nt_resid_ln / _lnbwd) on gemm_row384.h's tile (N <= 384 only)
- *              1 (default): LayerNorm-backward product on rowgemm16.h (N = 384) / rowgemm.h (N = 128, 256, 512);
+ *              1 (default): LayerNorm-backward product on rowgemm.h (N = 128, 256, 384, 512);
  *                 residual + LayerNorm on gemm_row384.h (N <= 384) / rowgemm.h (N = 512)
- *              2: rowgemm.h wherever its shapes allow (tests), 3: rowgemm16.h with the 6-block ring (lab)
- *   attn_skew  cycles / 64 by which waves 4..7 of the attention-backward kernels trail waves 0..3 (default 8)
+ *              2: rowgemm.h for both epilogues wherever its shapes allow (tests)
+ *              3 / 4: rowgemm16.h (two 64-row workgroups per CU) with the 6- / 3-block ring (lab, N = 384)
+ *   attn_fused 1: attention backward as one kernel (default 0: dQ kernel + dK/dV kernel)
+ *   attn_skew  cycles / 64 by which waves 4..7 of the attention-backward kernels trail waves 0..3 (lab, default 0)
  *   cu_reserve compute units the persistent grids leave free (set while an RCCL gradient reducer is attached)
  *   lab        scratch switch of the lab harnesses under tools/ (0 in production) */
 int ccd_policy_set(const char* key, int value);

@@ -160,9 +160,9 @@ def test_gemm_row384(hip, M, N, K):
                                    (5000, 128, 512), (33000, 256, 768), (20000, 512, 1536), (4100, 512, 2048)])
 def test_gemm_lnbwd(hip, M, N, K):
     from ccd_amd import ops
-    kc.check_gemm_lnbwd(hip.device, M=M, N=N, K=K)            # rowgemm16.h at N = 384, rowgemm.h at N in {128, 256, 512}
-    if N == 384:
-        with ops.policy(rowgemm=2):                           # the 128-row kernel
+    kc.check_gemm_lnbwd(hip.device, M=M, N=N, K=K)            # rowgemm.h where K % (64 R) == 0 and N in {128, 256, 384, 512}
+    if N == 384 and K % 192 == 0:
+        with ops.policy(rowgemm=4):                           # rowgemm16.h, 3-block ring
             kc.check_gemm_lnbwd(hip.device, M=M, N=N, K=K)
 
 

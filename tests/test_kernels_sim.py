@@ -152,9 +152,9 @@ def test_policy_table_sim(sim):
 
 def test_gemm_lnbwd_sim(sim):
     from ccd_amd import ops
-    kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=384)      # rowgemm16.h (N = 384), rowgemm.h (N in {128, 256, 512})
-    with ops.policy(rowgemm=2):
-        kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=384)  # the 128-row kernel at N = 384
+    kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=384)      # rowgemm.h (N in {128, 256, 384, 512})
+    with ops.policy(rowgemm=4):
+        kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=384)  # rowgemm16.h, 3-block ring
     kc.check_gemm_lnbwd(sim.device, M=200, N=128, K=256)
     kc.check_gemm_lnbwd(sim.device, M=260, N=256, K=256)
     kc.check_gemm_lnbwd(sim.device, M=130, N=512, K=128)

@@ -47,7 +47,7 @@ def main():
         for K in (384, 1152, 1536):
             aa = torch.randn(M, K, generator=g).to(BF).to(dev)
             w = (torch.randn(E, K, generator=g) * 0.05).to(BF).to(dev)
-            for rowgemm, lab in [(1, 0), (1, 2), (1, 4), (1, 8), (1, 12)] + [(1, int(v)) for v in os.environ.get("RG_LAB", "").split(",") if v]:
+            for rowgemm, lab in [(1, 0), (2, 0), (0, 0)] + [(1, int(v)) for v in os.environ.get("RG_LAB", "").split(",") if v]:
                 for tail in (False, True):
                     for acc in (True,) if os.environ.get("RG_QUICK") else (True, False):
                         with ops.policy(rowgemm=rowgemm, lab=lab):
