@@ -261,10 +261,10 @@ __global__ __launch_bounds__(512) void attention_bwd_dkv_kernel(const bf16_t* __
             del_r = delta[stat];
         }
     };
-    int blk = blockIdx.x;
-    if (blk < nblocks) request(blk);
-    for (; blk < nblocks; blk += gridDim.x) {
+    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
         const int view = blk / heads, head = blk % heads;
+        request(blk);                                        // (no cross-block prefetch: its 64 registers are worth more as the
+                                                             // second score tile of the software pipeline below)
         attb_store_rows_of_transposed(qtr, q_img);
         attb_store_rows_of_transposed(dotr, do_img);
         attb_store_transposed(qtr, qt_img);
@@ -277,7 +277,6 @@ __global__ __launch_bounds__(512) void attention_bwd_dkv_kernel(const bf16_t* __
             vf[kk] = __builtin_bit_cast(bf16x8, vw[kk]);
         }
         __syncthreads();
-        if (blk + (int)gridDim.x < nblocks) request(blk + gridDim.x);      // flies under this block's MFMAs
         attb_skew(w, skew);
 
         f32x16 dk[2], dv[2];
@@ -285,9 +284,9 @@ __global__ __launch_bounds__(512) void attention_bwd_dkv_kernel(const bf16_t* __
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
-#pragma unroll 1
-        for (int qt = 0; qt < 8; ++qt) {
-            f32x16 s, dp;
+        // software pipeline: the score products of tile qt + 1 are issued BEFORE the softmax arithmetic of tile qt, so the
+        // matrix pipe works under the VALU block instead of waiting for it
+        auto scores = [&](int qt, f32x16& s, f32x16& dp) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
             const int row = 32 * qt + lq;
@@ -296,6 +295,13 @@ __global__ __launch_bounds__(512) void attention_bwd_dkv_kernel(const bf16_t* __
                 s = mfma_32x32x16_bf16(attb_row_frag(q_img, row, kk, hf), kf[kk], s);      // S[q][key]
                 dp = mfma_32x32x16_bf16(attb_row_frag(do_img, row, kk, hf), vf[kk], dp);   // dP[q][key]
             }
+        };
+        f32x16 s, dp;
+        scores(0, s, dp);
+#pragma unroll 1
+        for (int qt = 0; qt < 8; ++qt) {
+            f32x16 sn, dpn;
+            scores(qt + 1 < 8 ? qt + 1 : 7, sn, dpn);        // (the last iteration recomputes tile 7: branch-free)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qq = 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * hf;
@@ -317,6 +323,8 @@ __global__ __launch_bounds__(512) void attention_bwd_dkv_kernel(const bf16_t* __
                     dk[dt] = mfma_32x32x16_bf16(attb_tr_frag(qt_img, 32 * dt + lq, 2 * qt + s2, hf), dsf, dk[dt]);
                 }
             }
+            s = sn;
+            dp = dpn;
         }
         bf16_t* drow = dqkv + ((long)view * ATT_T + key) * rs3 + head * ATT_D;
         attb_store_t(drow + E, dk, hf);
