@@ -50,6 +50,12 @@ struct GemmParams {
     float alpha;            // scales acc before the epilogue
     float* colsum;          // optional [N] fp32: += column sums of the (final) output tile, e.g. the bias gradient
     float* colsum_a;        // TN only, optional [P] fp32: += column sums of operand A (the bias gradient that belongs to dW = dY^T X)
+    // ---- gemm_tn384.h only: an optional SECOND weight-gradient problem over the same contraction rows, C2[M2,N2] += A2^T . B2
+    // (C2 / ldc2 above), sharing the launch - and the contraction slices - with the first
+    const bf16_t* A2;
+    const bf16_t* B2;
+    long lda2, ldb2;
+    int M2, N2;
     float* colsumsq;        // optional [N] fp32: += column sums of squares (BatchNorm batch statistics), EPI_BF16 only
     // ---- implicit-GEMM convolution (NT, GATHER instantiation): A row r is pixel (n, oy, ox) of a 2^gh x 2^gw grid,
     // contraction index k = tap * cin + c reads source pixel (oy*s_mul + dy(tap), ox*s_mul + dx(tap)) of an s_h x s_w

@@ -134,6 +134,26 @@ __device__ __forceinline__ void vmem_pad_load(unsigned& sink) {
     const buf_u32x4 none = {0u, 0u, 0u, 0x00020000u};
     asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(sink) : "v"(BUF_OOB), "s"(none));
 }
+// ds_read_b64_tr_b16 (gfx950): within each group of 16 lanes, lane j addresses 4 contiguous bf16 D[j][0..3]; lane i receives
+// {D[i / 4][i % 4], D[4 + i / 4][i % 4], D[8 + i / 4][i % 4], D[12 + i / 4][i % 4]} - with lane j pointing at (row j / 4, columns
+// 4 (j % 4) ..) of a row-major 4 x 16 block that is column i of the four rows (tools/probe/tr_probe.hip).  The compiler
+// counts it in lgkmcnt like any LDS read.
+typedef __attribute__((ext_vector_type(4))) short tr_v4s;
+typedef __attribute__((ext_vector_type(2))) unsigned tr_u32x2;
+__device__ __forceinline__ tr_u32x2 lds_read_tr16(const char* p) {
+    const tr_v4s v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)p);
+    return __builtin_bit_cast(tr_u32x2, v);
+}
+// hand-issued form (same in-order queue and counted waits as lds_read_frag): the builtin's LDS memory operand makes the compiler
+// put `s_waitcnt vmcnt(0)` in front of it whenever an LDS-DMA is in flight (it cannot tell the DMA's buffer from the one being read)
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr(tr_u32x2& dst, unsigned lds_addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFF));
+}
+__device__ __forceinline__ bf16x8 frag_from_tr(tr_u32x2 lo, tr_u32x2 hi) {
+    const buf_u32x4 v = {lo.x, lo.y, hi.x, hi.y};
+    return __builtin_bit_cast(bf16x8, v);
+}
 // v_perm_b32: result byte i = byte sel.byte[i] of the 8-byte value {hi : lo} (0..3 = lo's bytes, 4..7 = hi's bytes)
 __device__ __forceinline__ unsigned perm_b32(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 __device__ __forceinline__ float opaque_f32(float x) { asm volatile("" : "+v"(x)); return x; }

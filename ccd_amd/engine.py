@@ -272,12 +272,12 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
             gact = torch.empty_like(c.u)
             du = ops.gemm_nt(gb, arena.wbt(b + "mlp.fc2.weight"), epilogue=ops.EPI_DGELU, aux=c.u, out2=gact,
                              colsum=arena.g(b + "mlp.fc1.bias"))
-            gb_reader = side.run(lambda: ops.gemm_tn(gb, gact, arena.g(b + "mlp.fc2.weight")), gb, gact)
         else:
-            gb_reader = side.run(lambda: ops.gemm_tn(gb, gact, arena.g(b + "mlp.fc2.weight")), gb, gact)
             du = ops.gemm_nt(gb, arena.wbt(b + "mlp.fc2.weight"), epilogue=ops.EPI_DGELU, aux=c.u,
                              colsum=arena.g(b + "mlp.fc1.bias"))
-        side.run(lambda du=du: ops.gemm_tn(du, y2, arena.g(b + "mlp.fc1.weight")), du, y2)
+        # both weight gradients of the MLP in ONE launch (ccd_gemm_tn_pair: the same rows, one atomic epilogue per workgroup)
+        gb_reader = side.run(lambda du=du, gact=gact: ops.gemm_tn_pair(gb, gact, arena.g(b + "mlp.fc2.weight"), du, y2,
+                                                                       arena.g(b + "mlp.fc1.weight")), gb, gact, du, y2)
         side.wait(gb_reader)                                 # norm2's backward rewrites gb
         if fuse_lnbwd:           # dy2 = du . W1 never leaves the chip: LayerNorm-2's backward is the product's epilogue
             ops.gemm_nt_lnbwd(du, arena.wbt(b + "mlp.fc1.weight"), c.x_mid, c.mean2, c.rstd2, arena.w(b + "norm2.weight"), g,
@@ -290,7 +290,6 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
                        dbias=arena.g(b + "attn.proj.bias"))
         del du
         # ---- attention branch: x_mid = x_in + ds1 * proj(attn(qkv(LN1(x_in))))
-        gb_reader = side.run(lambda: ops.gemm_tn(gb, att.view(R, E), arena.g(b + "attn.proj.weight")), gb, att)
         d_att = ops.gemm_nt(gb, arena.wbt(b + "attn.proj.weight"))
         d_qkv = ops.attention_bwd(c.qkv.view(N, 256, 3 * E), c.att, d_att.view(N, 256, E), c.lse, spec.heads, scale)
         d_qkv = d_qkv.view(R, 3 * E)
@@ -298,9 +297,10 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
         def qkv_grads(d_qkv=d_qkv):
             # (ops.gemm_tn_colsum does both in one pass over d_qkv - measured 56.4 vs 56.1 ms per step: the 64 extra VALU
             # operations per k-tile in the TN loader cost more than the second 302-MB read they save)
-            ops.gemm_tn(d_qkv, y1, arena.g(b + "attn.qkv.weight"))
+            # proj.weight's gradient waits for qkv.weight's: one launch for both (gb is not rewritten before norm1's backward)
+            ops.gemm_tn_pair(gb, att.view(R, E), arena.g(b + "attn.proj.weight"), d_qkv, y1, arena.g(b + "attn.qkv.weight"))
             ops.colsum_bf16(d_qkv, arena.g(b + "attn.qkv.bias"))
-        side.run(qkv_grads, d_qkv, y1)
+        gb_reader = side.run(qkv_grads, gb, att, d_qkv, y1)
         tail = mlp_tail(i - 1) if (i > 0 and (i - 1) not in tap_at) else {}
         if tail:
             side.wait(gb_reader)                             # this LayerNorm backward rewrites gb for the next block

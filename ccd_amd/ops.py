@@ -207,6 +207,27 @@ def gemm_tn_colsum(a, b, out, colsum, *, splits=0):
     return out
 
 
+def gemm_tn_pair(a1, b1, out1, a2, b2, out2):
+    """out1 += a1^T @ b1 and out2 += a2^T @ b2 (same number of contraction rows) in one launch where the shapes allow it
+    (ccd_gemm_tn_pair); equal to two gemm_tn calls up to fp32 summation order."""
+    for t, n in ((a1, "a1"), (b1, "b1"), (a2, "a2"), (b2, "b2")):
+        _chk(t, BF16, n)
+    _chk(out1, F32, "out1"); _chk(out2, F32, "out2")
+    Mc = a1.shape[0]
+    assert b1.shape[0] == Mc and a2.shape[0] == Mc and b2.shape[0] == Mc
+    assert tuple(out1.shape) == (a1.shape[1], b1.shape[1]) and tuple(out2.shape) == (a2.shape[1], b2.shape[1])
+    flops = 2.0 * Mc * (a1.shape[1] * b1.shape[1] + a2.shape[1] * b2.shape[1])
+    nbytes = 2.0 * Mc * (a1.shape[1] + b1.shape[1] + a2.shape[1] + b2.shape[1]) + 4.0 * (out1.numel() + out2.numel())
+    span = TIMER.span("gemm_tn_atomic", flops, nbytes) if TIMER is not None else None
+    if span:
+        span[0].record()
+    _call("ccd_gemm_tn_pair", _lib.ptr(a1), a1.stride(0), _lib.ptr(b1), b1.stride(0), a1.shape[1], b1.shape[1], _lib.ptr(out1),
+          out1.stride(0), _lib.ptr(a2), a2.stride(0), _lib.ptr(b2), b2.stride(0), a2.shape[1], b2.shape[1], _lib.ptr(out2),
+          out2.stride(0), Mc)
+    if span:
+        span[1].record()
+
+
 def gemm_tn(a, b, out, *, accumulate=True, alpha=1.0, splits=0, d_rows=None, rows_mul=1):
     """out[P,Q] (+)= a[Mc,P]^T @ b[Mc,Q]  (fp32 out; accumulate=True adds with fp32 atomics, split over Mc)."""
     _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(out, F32, "out")

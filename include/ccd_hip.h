@@ -106,6 +106,14 @@ int ccd_gemm_tn(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P,
  * pass through the loader's registers (replaces ccd_gemm_tn + ccd_colsum_bf16: one read of dY less). */
 int ccd_gemm_tn_colsum(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P, int Q, int Mc, float* C, long ldc,
                        float* colsum_a, int splits, void* stream);
+/* Two weight-gradient products over the SAME contraction rows in one launch: C1[P1,Q1] += A1^T . B1 and C2[P2,Q2] += A2^T . B2
+ * (fp32 atomics) - the pairs autograd produces together: {fc2.weight, fc1.weight} once gelu'(u) is applied, {proj.weight,
+ * qkv.weight} once the attention backward has run (Dino/modules/svtr.py:92-145).  With P % 384 == 0, Q % 192 == 0 and
+ * Mc % 32 == 0 both run in gemm_tn384.h's XCD-grouped launch and share ONE atomic epilogue per workgroup; any other shape
+ * falls back to two ccd_gemm_tn calls.  Results are those of the two separate calls up to fp32 summation order. */
+int ccd_gemm_tn_pair(const ccd_bf16* A1, long lda1, const ccd_bf16* B1, long ldb1, int P1, int Q1, float* C1, long ldc1,
+                     const ccd_bf16* A2, long lda2, const ccd_bf16* B2, long ldb2, int P2, int Q2, float* C2, long ldc2, int Mc,
+                     void* stream);
 /* d_rows (optional, both GEMMs): device int; the effective row count (NT: M, TN: Mc) is
  * min(static value, d_rows[0] * rows_mul) so data-dependent row counts never reach the host. */
 

@@ -144,6 +144,22 @@ inline unsigned opaque_u32(unsigned x) { return x; }
 inline int opaque_vgpr(int x) { return x; }
 inline float opaque_f32(float x) { return x; }
 inline void vmem_pad_load(unsigned& sink) { (void)sink; }
+// ds_read_b64_tr_b16 (prelude_hip.h): every lane deposits the 4 bf16 it addresses, lane i of a 16-lane group collects element
+// i % 4 of lanes i / 4, 4 + i / 4, 8 + i / 4, 12 + i / 4
+typedef __attribute__((ext_vector_type(2))) unsigned tr_u32x2;
+inline tr_u32x2 lds_read_tr16(const char* p) {
+    sim::WaveState& w = sim::curblk->waves[sim::cur->wave];
+    const int lane = sim::cur->lane, grp = lane & ~15, i = lane & 15;
+    std::memcpy(w.xchg[lane], p, 8);
+    sim::wave_sync();
+    unsigned short e[4];
+    for (int r = 0; r < 4; ++r) std::memcpy(&e[r], w.xchg[grp + 4 * r + (i >> 2)] + 2 * (i & 3), 2);
+    sim::wave_sync();
+    tr_u32x2 out;
+    out.x = (unsigned)e[0] | ((unsigned)e[1] << 16);
+    out.y = (unsigned)e[2] | ((unsigned)e[3] << 16);
+    return out;
+}
 inline unsigned perm_b32(unsigned hi, unsigned lo, unsigned sel) {
     const unsigned long long v = ((unsigned long long)hi << 32) | lo;
     unsigned r = 0;
@@ -164,6 +180,14 @@ inline void wave_prio() {}
 inline void lds_barrier() { __syncthreads(); }
 // buffer addressing: out-of-range lanes read zeros (prelude_hip.h)
 typedef __attribute__((ext_vector_type(4))) unsigned buf_u32x4;
+template <int OFF>
+inline void lds_read_tr(tr_u32x2& dst, unsigned lds_addr) { dst = lds_read_tr16(sim::curblk->dyn_smem + lds_addr + OFF); }
+inline bf16x8 frag_from_tr(tr_u32x2 lo, tr_u32x2 hi) {
+    const buf_u32x4 v = {lo.x, lo.y, hi.x, hi.y};
+    bf16x8 r;
+    std::memcpy(&r, &v, 16);
+    return r;
+}
 struct buf_rsrc { const char* base; unsigned bytes; };
 constexpr unsigned BUF_OOB = 0x80000000u;
 inline buf_rsrc make_rsrc(const void* base, unsigned bytes) { return buf_rsrc{reinterpret_cast<const char*>(base), bytes}; }

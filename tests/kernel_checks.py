@@ -122,6 +122,20 @@ def check_gemm_tn(dev, Mc, P, Q, seed=1, splits=0):
     close(out2, 2 * ref, 1e-4, 2 * tol, "tn/store")
 
 
+def check_gemm_tn_pair(dev, Mc, shape1, shape2, seed=5):
+    """Two weight-gradient products over the same rows in one call (ccd_gemm_tn_pair): accumulation onto existing values."""
+    g = torch.Generator().manual_seed(seed)
+    outs, wants, args = [], [], []
+    for P, Q in (shape1, shape2):
+        a = rnd((Mc, P), g).to(BF); b = rnd((Mc, Q), g).to(BF)
+        base = rnd((P, Q), g)
+        outs.append(base.clone().to(dev)); wants.append(base + a.float().t() @ b.float()); args.append((a.to(dev), b.to(dev)))
+    ops.gemm_tn_pair(args[0][0], args[0][1], outs[0], args[1][0], args[1][1], outs[1])
+    tol = 1e-3 * math.sqrt(Mc)
+    close(outs[0], wants[0], 1e-4, tol, "tn_pair/first")
+    close(outs[1], wants[1], 1e-4, tol, "tn_pair/second")
+
+
 def check_layernorm(dev, rows, E, seed=2):
     g = torch.Generator().manual_seed(seed)
     x = rnd((rows, E), g) * 2 + 0.3

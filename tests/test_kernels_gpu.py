@@ -38,6 +38,24 @@ def test_gemm_tn(hip, Mc, P, Q, splits):
     kc.check_gemm_tn(hip.device, Mc, P, Q, splits=splits)
 
 
+@pytest.mark.parametrize("Mc,shape1,shape2", [(8192, (384, 1536), (1536, 384)), (4096 + 64, (384, 384), (1152, 384)),
+                                              (131072, (384, 384), (1152, 384)), (600, (136, 72), (384, 192))])
+def test_gemm_tn_pair(hip, Mc, shape1, shape2):
+    """ccd_gemm_tn_pair: the MLP pair and the attention pair in gemm_tn384.h's grouped launch (16 / 8 tiles per contraction slice,
+    ragged slices, the full 131072 rows of the benchmark batch), and the two-call fallback."""
+    kc.check_gemm_tn_pair(hip.device, Mc, shape1, shape2)
+
+
+@pytest.mark.parametrize("policy", [dict(gemm_tn384=0), dict(gemm_tn384_min_tiles=1)])
+def test_gemm_tn_policies(hip, policy):
+    """Single weight-gradient products on the kernel that is not the default for their shape: the 128-square kernel for the
+    fc shapes, gemm_tn384.h for proj (2 tiles, 128 slices)."""
+    from ccd_amd import ops
+    with ops.policy(**policy):
+        kc.check_gemm_tn(hip.device, 8192, 384, 384)
+        kc.check_gemm_tn(hip.device, 4096, 1536, 384, seed=7)
+
+
 @pytest.mark.parametrize("rows,E", [(37, 192), (4096, 384), (1001, 512)])
 def test_layernorm(hip, rows, E):
     kc.check_layernorm(hip.device, rows, E)

@@ -36,6 +36,25 @@ def test_gemm_tn_sim(sim):
     kc.check_gemm_tn(sim.device, Mc=64, P=8, Q=264)
 
 
+def test_gemm_tn_pair_sim(sim, monkeypatch):
+    """ccd_gemm_tn_pair: both products in gemm_tn384.h's launch (3 tiles per group on a 4-CU chip: 1 + 2), and the fallback to
+    two separate products for shapes that kernel does not take."""
+    monkeypatch.setenv("CCD_SIM_CUS", "4")
+    kc.check_gemm_tn_pair(sim.device, 2048, (384, 192), (384, 384))
+    kc.check_gemm_tn_pair(sim.device, 320, (136, 72), (8, 264), seed=6)
+
+
+def test_gemm_tn384_sim(sim, monkeypatch):
+    """gemm_tn384.h (LDS-DMA image + transposing LDS reads): one workgroup with 67 stages; 4 ragged slices of 17 / 16 stages;
+    two tiles per group and two groups; 16 workgroups spread over 8 'XCDs' (2 groups of one tile each, 4 stages)."""
+    kc.check_gemm_tn(sim.device, Mc=2048 + 96, P=384, Q=192)
+    monkeypatch.setenv("CCD_SIM_CUS", "4")
+    kc.check_gemm_tn(sim.device, Mc=2048 + 96, P=384, Q=192, seed=2)
+    kc.check_gemm_tn(sim.device, Mc=2048, P=384, Q=384, seed=3)
+    monkeypatch.setenv("CCD_SIM_CUS", "16")
+    kc.check_gemm_tn(sim.device, Mc=2048, P=384, Q=192, seed=4)
+
+
 def test_layernorm_sim(sim):
     kc.check_layernorm(sim.device, rows=37, E=192)
     kc.check_layernorm(sim.device, rows=9, E=384)
