@@ -89,6 +89,7 @@ struct CcdPolicy {
     int attn_fused = 0;         // attention backward: 1 = dQ and dK/dV in one kernel (reads q, k, v, dO, O once; measured 0.407 vs 0.377 ms)
     int attn_skew = 0;          // attention backward: waves 4..7 start each block ~skew * 64 cycles late (lab; no effect once clocks are warm)
     int gemm_tn384 = 1;         // weight gradients with P % 384 == 0, Q % 192 == 0: XCD-grouped 384x192 LDS-DMA kernel (gemm_tn384.h); 0 = 128-square kernel, 2 = never as a pair
+    int gemm_tn384_geom = 0;    // its workgroup: 0 = 384x192 tile, 8 waves, one per CU; 1 = 192x192 tile, 4 waves, two per CU
     int gemm_tn384_min_tiles = 6;   // ... for a SINGLE product only from this many tiles on (proj, 2 tiles = 128 slices: the atomic epilogue dominates)
     int cu_reserve = 0;         // compute units the persistent grids leave free (set while an RCCL gradient reducer is attached)
     int lab = 0;                // scratch switch for kernel experiments (tools/*_lab.py); 0 in production
@@ -98,7 +99,7 @@ static const CcdPolicyKey ccd_policy_keys[] = {
     {"gemm_256", &CcdPolicy::gemm_256}, {"gemm_256_min_m", &CcdPolicy::gemm_256_min_m},
     {"gemm_256_min_n", &CcdPolicy::gemm_256_min_n}, {"gemm_256_f32", &CcdPolicy::gemm_256_f32},
     {"gemm_256_deep", &CcdPolicy::gemm_256_deep}, {"gemm_row384", &CcdPolicy::gemm_row384},
-    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_fused", &CcdPolicy::attn_fused}, {"attn_skew", &CcdPolicy::attn_skew}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"lab", &CcdPolicy::lab}};
+    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_fused", &CcdPolicy::attn_fused}, {"attn_skew", &CcdPolicy::attn_skew}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"lab", &CcdPolicy::lab}};
 static CcdPolicy& ccd_policy() {
     static CcdPolicy pol = [] {
         CcdPolicy q;
@@ -149,6 +150,24 @@ static int ccd_launch_gemm_row384(const ccd::GemmParams& p, int epilogue, void* 
         case 8: CCD_LAUNCH((ccd::gemm_row384_kernel<ccd::EPI_LNBWD>), grid, block, smem, stream, p); break;
         default: return CCD_EINVAL;
     }
+    return ccd_rt_last_error();
+}
+
+// gemm_tn384.h launch for one workgroup geometry (see ccd_launch_tn384 below)
+template <int WM, int WN, int STAGES>
+static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, void* stream) {
+    using G = ccd::Tn3Geom<WM, WN, STAGES>;
+    const int per_cu = 8 / G::WAVES;
+    const int tiles = (p.M / G::TP) * (p.N / G::TQ) + (p.M2 / G::TP) * (p.N2 / G::TQ), slots = per_cu * ccd_grid_cus();
+    const int xcds = slots >= 8 * tiles ? 8 : 1;
+    const int spx = slots / xcds, gpx = spx / tiles;
+    if (gpx < 1) return CCD_ESHAPE;
+    int slices = xcds * gpx;
+    int per = (Mc + slices - 1) / slices;
+    per = ((per + ccd::TN3_BK - 1) / ccd::TN3_BK) * ccd::TN3_BK;
+    slices = (Mc + per - 1) / per;
+    p.k_per_split = per; p.work_items = slices; p.m_fastest = xcds;
+    CCD_LAUNCH((ccd::gemm_tn384_kernel<WM, WN, STAGES>), dim3(xcds * spx), dim3(G::THREADS), G::SMEM_BYTES, stream, p);
     return ccd_rt_last_error();
 }
 
@@ -362,28 +381,24 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
 
 static int ccd_gemm_tn_impl(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P, int Q, int Mc, int epilogue, float* C,
                             long ldc, float alpha, int splits, const int* d_rows, int rows_mul, float* colsum_a, void* stream);
-// gemm_tn384.h: one group of (P / 384) (Q / 192) [+ the second problem's] workgroups per contraction slice, whole groups per XCD
+// gemm_tn384.h: one group of (P / TP) (Q / TQ) [+ the second problem's] workgroups per contraction slice, whole groups per XCD
 // (workgroup b runs on XCD b % 8).  CCD_ESHAPE: the tiles of one slice do not fit the grid - the caller takes another kernel.
 static bool ccd_tn384_fits(int P, int Q, int Mc) {
-    return P % ccd::TN3_TP == 0 && Q % ccd::TN3_TQ == 0 && Mc % ccd::TN3_BK == 0 && Mc >= 2048;
+    const int tp = ccd_policy().gemm_tn384_geom == 1 ? 192 : 384;
+    return P % tp == 0 && Q % 192 == 0 && Mc % ccd::TN3_BK == 0 && Mc >= 2048;
+}
+static int ccd_tn384_tiles(int P, int Q) {
+    return (P / (ccd_policy().gemm_tn384_geom == 1 ? 192 : 384)) * (Q / 192);
 }
 static int ccd_launch_tn384(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P, int Q, float* C, long ldc,
                             const ccd_bf16* A2, long lda2, const ccd_bf16* B2, long ldb2, int P2, int Q2, float* C2, long ldc2,
                             int Mc, float alpha, float* lab_out, void* stream) {
-    const int tiles = (P / ccd::TN3_TP) * (Q / ccd::TN3_TQ) + (P2 / ccd::TN3_TP) * (Q2 / ccd::TN3_TQ), cus = ccd_grid_cus();
-    const int xcds = cus >= 8 * tiles ? 8 : 1;
-    const int spx = cus / xcds, gpx = spx / tiles;
-    if (gpx < 1) return CCD_ESHAPE;
-    int slices = xcds * gpx;
-    int per = (Mc + slices - 1) / slices;
-    per = ((per + ccd::TN3_BK - 1) / ccd::TN3_BK) * ccd::TN3_BK;
-    slices = (Mc + per - 1) / per;
     ccd::GemmParams p = ccd::GemmParams();
     p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.M = P; p.N = Q; p.K = Mc; p.C = C; p.ldc = ldc;
     p.A2 = A2; p.B2 = B2; p.lda2 = lda2; p.ldb2 = ldb2; p.M2 = P2; p.N2 = Q2; p.C2 = C2; p.ldc2 = ldc2;
-    p.k_per_split = per; p.work_items = slices; p.m_fastest = xcds; p.alpha = alpha; p.rps_shift = ccd_policy().lab; p.colsum_a = lab_out;
-    CCD_LAUNCH(ccd::gemm_tn384_kernel, dim3(xcds * spx), dim3(ccd::TN3_THREADS), ccd::TN3_SMEM_BYTES, stream, p);
-    return ccd_rt_last_error();
+    p.alpha = alpha; p.rps_shift = ccd_policy().lab; p.colsum_a = lab_out;
+    if (ccd_policy().gemm_tn384_geom == 1) return ccd_launch_tn384_geom<2, 2, 3>(p, Mc, stream);
+    return ccd_launch_tn384_geom<4, 2, 4>(p, Mc, stream);
 }
 int ccd_gemm_tn_pair(const ccd_bf16* A1, long lda1, const ccd_bf16* B1, long ldb1, int P1, int Q1, float* C1, long ldc1,
                      const ccd_bf16* A2, long lda2, const ccd_bf16* B2, long ldb2, int P2, int Q2, float* C2, long ldc2, int Mc,
@@ -420,7 +435,7 @@ static int ccd_gemm_tn_impl(const ccd_bf16* A, long lda, const ccd_bf16* B, long
     CCD_CHECK(P % 8 == 0 && Q % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, CCD_ESHAPE);
     CCD_CHECK(epilogue == CCD_EPI_ATOMIC || epilogue == CCD_EPI_F32, CCD_EINVAL);
     if (ccd_policy().gemm_tn384 && epilogue == CCD_EPI_ATOMIC && !d_rows && (!colsum_a || (ccd_policy().lab & 4)) &&
-        ccd_tn384_fits(P, Q, Mc) && (P / ccd::TN3_TP) * (Q / ccd::TN3_TQ) >= ccd_policy().gemm_tn384_min_tiles) {
+        ccd_tn384_fits(P, Q, Mc) && ccd_tn384_tiles(P, Q) >= ccd_policy().gemm_tn384_min_tiles * (ccd_policy().gemm_tn384_geom == 1 ? 2 : 1)) {
         const int rc = ccd_launch_tn384(A, lda, B, ldb, P, Q, C, ldc, nullptr, 0, nullptr, 0, 0, 0, nullptr, 0, Mc, alpha, colsum_a, stream);
         if (rc != CCD_ESHAPE) return rc;
     }

@@ -46,7 +46,7 @@ def test_gemm_tn_pair(hip, Mc, shape1, shape2):
     kc.check_gemm_tn_pair(hip.device, Mc, shape1, shape2)
 
 
-@pytest.mark.parametrize("policy", [dict(gemm_tn384=0), dict(gemm_tn384_min_tiles=1)])
+@pytest.mark.parametrize("policy", [dict(gemm_tn384=0), dict(gemm_tn384_min_tiles=1), dict(gemm_tn384_geom=1)])
 def test_gemm_tn_policies(hip, policy):
     """Single weight-gradient products on the kernel that is not the default for their shape: the 128-square kernel for the
     fc shapes, gemm_tn384.h for proj (2 tiles, 128 slices)."""
@@ -54,6 +54,7 @@ def test_gemm_tn_policies(hip, policy):
     with ops.policy(**policy):
         kc.check_gemm_tn(hip.device, 8192, 384, 384)
         kc.check_gemm_tn(hip.device, 4096, 1536, 384, seed=7)
+        kc.check_gemm_tn_pair(hip.device, 8192 + 32, (384, 1536), (1536, 384), seed=8)
 
 
 @pytest.mark.parametrize("rows,E", [(37, 192), (4096, 384), (1001, 512)])

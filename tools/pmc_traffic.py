@@ -39,6 +39,8 @@ def collect(path, counter):
                 m = re.search(r"gemm_row384_kernel<(\d+)", name)
                 key = {"0": "gemm_nt_bf16", "2": "gemm_nt_resid", "3": "gemm_nt_f32", "7": "gemm_nt_resid"}.get(
                     m.group(1), "gemm_row384?") if m else "gemm_row384?"
+            elif "gemm_tn384_kernel" in name:                # weight-gradient products (single or paired) of the ViT blocks
+                key = "gemm_tn_atomic"
             elif "mlp_fused_kernel" in name:                 # fc1 + GELU + fc2 + residual + LayerNorm in one launch
                 key = "mlp_fused"
             elif "ln_fwd_kernel" in name:
