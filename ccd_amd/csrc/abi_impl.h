@@ -87,6 +87,7 @@ struct CcdPolicy {
     int ln_bwd_bpc = 5;         // LayerNorm backward: blocks per CU (one resident wave; more blocks = more dgamma/dbeta atomics)
     int dec_attn_simt = 0;      // decoder attention: force the general SIMT kernels
     int attn_fused = 0;         // attention backward: 1 = dQ and dK/dV in one kernel (reads q, k, v, dO, O once; measured 0.407 vs 0.377 ms)
+    int attn_tr = 1;            // attention backward dK/dV: double-buffered LDS-DMA row images + ds_read_b64_tr_b16 (0 = four register-staged images)
     int attn_skew = 0;          // attention backward: waves 4..7 start each block ~skew * 64 cycles late (lab; no effect once clocks are warm)
     int gemm_tn384 = 1;         // weight gradients with P % 384 == 0, Q % 192 == 0: XCD-grouped 384x192 LDS-DMA kernel (gemm_tn384.h); 0 = 128-square kernel, 2 = never as a pair
     int gemm_tn384_geom = 0;    // its workgroup: 0 = 384x192 tile, 8 waves, one per CU; 1 = 192x192 tile, 4 waves, two per CU
@@ -99,7 +100,7 @@ static const CcdPolicyKey ccd_policy_keys[] = {
     {"gemm_256", &CcdPolicy::gemm_256}, {"gemm_256_min_m", &CcdPolicy::gemm_256_min_m},
     {"gemm_256_min_n", &CcdPolicy::gemm_256_min_n}, {"gemm_256_f32", &CcdPolicy::gemm_256_f32},
     {"gemm_256_deep", &CcdPolicy::gemm_256_deep}, {"gemm_row384", &CcdPolicy::gemm_row384},
-    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_fused", &CcdPolicy::attn_fused}, {"attn_skew", &CcdPolicy::attn_skew}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"lab", &CcdPolicy::lab}};
+    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_fused", &CcdPolicy::attn_fused}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"lab", &CcdPolicy::lab}};
 static CcdPolicy& ccd_policy() {
     static CcdPolicy pol = [] {
         CcdPolicy q;
@@ -158,15 +159,36 @@ template <int WM, int WN, int STAGES>
 static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, void* stream) {
     using G = ccd::Tn3Geom<WM, WN, STAGES>;
     const int per_cu = 8 / G::WAVES;
-    const int tiles = (p.M / G::TP) * (p.N / G::TQ) + (p.M2 / G::TP) * (p.N2 / G::TQ), slots = per_cu * ccd_grid_cus();
-    const int xcds = slots >= 8 * tiles ? 8 : 1;
-    const int spx = slots / xcds, gpx = spx / tiles;
-    if (gpx < 1) return CCD_ESHAPE;
-    int slices = xcds * gpx;
-    int per = (Mc + slices - 1) / slices;
-    per = ((per + ccd::TN3_BK - 1) / ccd::TN3_BK) * ccd::TN3_BK;
-    slices = (Mc + per - 1) / per;
-    p.k_per_split = per; p.work_items = slices; p.m_fastest = xcds;
+    const int t1 = (p.M / G::TP) * (p.N / G::TQ), t2 = (p.M2 / G::TP) * (p.N2 / G::TQ), slots = per_cu * ccd_grid_cus();
+    const int xcds = slots >= 8 * (t1 > t2 ? t1 : t2) ? 8 : 1;
+    const int spx = slots / xcds;
+    // groups per XCD: always the problem with fewer groups so far (ties: the larger group first) while it fits - both problems
+    // end up with (nearly) the same number of slices, i.e. rows per workgroup, whatever is left of an XCD's slots
+    int s1 = 0, s2 = 0;
+    unsigned long long units1 = 0, units2 = 0;
+    for (int x = 0; x < xcds; ++x) {
+        int rem = spx, u1 = 0, u2 = 0;
+        while (true) {
+            const bool first = t2 == 0 || s1 < s2 || (s1 == s2 && t1 >= t2);
+            if (first && t1 <= rem && u1 < 255) { ++u1; ++s1; rem -= t1; }
+            else if (!first && t2 <= rem && u2 < 255) { ++u2; ++s2; rem -= t2; }
+            else if (first && t2 > 0 && s2 <= s1 && t2 <= rem && u2 < 255) { ++u2; ++s2; rem -= t2; }
+            else if (!first && s1 <= s2 && t1 <= rem && u1 < 255) { ++u1; ++s1; rem -= t1; }
+            else break;
+        }
+        units1 |= (unsigned long long)u1 << (8 * x);
+        units2 |= (unsigned long long)u2 << (8 * x);
+    }
+    if (s1 < 1 || (t2 > 0 && s2 < 1)) return CCD_ESHAPE;
+    auto rows_per = [&](int& slices) {
+        int per = (Mc + slices - 1) / slices;
+        per = ((per + ccd::TN3_BK - 1) / ccd::TN3_BK) * ccd::TN3_BK;
+        slices = (Mc + per - 1) / per;
+        return per;
+    };
+    p.k_per_split = rows_per(s1); p.work_items = s1;
+    if (t2 > 0) { p.per2 = rows_per(s2); p.slices2 = s2; }
+    p.units1 = units1; p.units2 = units2; p.m_fastest = xcds;
     CCD_LAUNCH((ccd::gemm_tn384_kernel<WM, WN, STAGES>), dim3(xcds * spx), dim3(G::THREADS), G::SMEM_BYTES, stream, p);
     return ccd_rt_last_error();
 }
@@ -514,6 +536,10 @@ int ccd_attention_bwd(const ccd_bf16* qkv, const ccd_bf16* out, const ccd_bf16* 
     }
     CCD_LAUNCH(ccd::attention_bwd_dq_kernel, dim3(nblocks < cus ? nblocks : cus), dim3(512), ccd::ATTB_DQ_SMEM, stream, qkv,
                out, d_out, lse, delta_ws, d_qkv, heads, scale, nblocks, ccd_policy().attn_skew);
+    if (ccd_policy().attn_tr)               // dK / dV on the double-buffered LDS-DMA image with transposing LDS reads
+        CCD_LAUNCH(ccd::attention_bwd_dkv_tr_kernel, dim3(nblocks < cus ? nblocks : cus), dim3(512), ccd::ATTB_DKV_TR_SMEM, stream,
+                   qkv, d_out, lse, delta_ws, d_qkv, heads, scale, nblocks, ccd_policy().lab);
+    else
     CCD_LAUNCH(ccd::attention_bwd_dkv_kernel, dim3(nblocks < cus ? nblocks : cus), dim3(512), ccd::ATTB_DKV_SMEM, stream, qkv,
                d_out, lse, delta_ws, d_qkv, heads, scale, nblocks, ccd_policy().attn_skew);
     return ccd_rt_last_error();

@@ -333,6 +333,202 @@ __global__ __launch_bounds__(512) void attention_bwd_dkv_kernel(const bf16_t* __
     }
 }
 
+// ---- dK / dV on a double-buffered LDS-DMA image with transposing LDS reads (round 2).  The kernel above spends two thirds of a
+// block outside its MFMA loop (phase profile of wave 0: issuing + waiting for the block's global loads 20 %, writing the four
+// LDS images 9 %, the two block barriers 28 %, stores 8 %).  Here
+//   * the transposed images are gone: the dV / dK products take their dO^T / Q^T fragments out of the ROW images with
+//     ds_read_b64_tr_b16 - the MFMA's contraction order (e & 3) + 8 (e >> 2) + 4 hf over a 16-query step is exactly two such
+//     reads of 4 query rows each (rows 4 hf .. + 3 and 8 + 4 hf .. + 3),
+//   * the two remaining images (Q, dO rows: 64 KiB + lse / delta) fit twice: block b + 1's are written by LDS-DMA (no VGPRs, no
+//     ds_write pass) into the other buffer while block b is multiplied; k / v fragments of block b + 1 wait in registers,
+//   * one barrier per block (behind the drain of the DMA), no barrier after the stores.
+// Row image swizzle: slot ^ f(row), f = x ^ ((x & 1) << 2), x = (row >> 1) & 7 - a bijection of the forward kernel's x (the
+// ds_read_b128 row fragments stay conflict-free) whose bit 2 alternates every two rows, which puts the 4 rows x 64 B of a
+// transposing half-wave read on four different 64-byte bank groups (brute-force checked: 1-way for both read kinds).
+constexpr int ATTB_TR_BUF = 2 * ATTB_IMG + 2 * ATT_T * 4;      // Q rows, dO rows, lse, delta
+constexpr int ATTB_DKV_TR_SMEM = 2 * ATTB_TR_BUF;              // 132 KiB
+__device__ __forceinline__ int attb_swz2(int row) {
+    const int x = (row >> 1) & 7;
+    return x ^ ((x & 1) << 2);
+}
+__global__ __launch_bounds__(512) void attention_bwd_dkv_tr_kernel(const bf16_t* __restrict__ qkv,
+                                                                   const bf16_t* __restrict__ d_o,
+                                                                   const float* __restrict__ lse,
+                                                                   const float* __restrict__ delta,
+                                                                   bf16_t* __restrict__ dqkv, int heads, float scale, int nblocks, int lab) {
+    char* smem = dynamic_smem();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hf = lane >> 5, lq = lane & 31;
+    const int E = heads * ATT_D;
+    const long rs3 = 3L * E;
+    const int key = 32 * w + lq;
+    // DMA: a 1-KiB piece = 8 image rows; lane L writes row 8 n + L / 8, slot L % 8 and fetches the slot the swizzle puts there.
+    // Wave w moves pieces 4 w .. 4 w + 3 of both images and 64 of the 512 statistics.
+    unsigned qoff[4], dooff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * (4 * w + i) + (lane >> 3), src = (lane & 7) ^ attb_swz2(row);
+        qoff[i] = (unsigned)(row * (int)rs3 + src * 8);
+        dooff[i] = (unsigned)(row * E + src * 8);
+    }
+    auto dma_block = [&](int blk, int buf) {
+        const int view = blk / heads, head = blk % heads;
+        const bf16_t* q_base = qkv + (long)view * ATT_T * rs3 + head * ATT_D;
+        const bf16_t* do_base = d_o + (long)view * ATT_T * E + head * ATT_D;
+        char* base = smem + buf * ATTB_TR_BUF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(q_base + qoff[i], base + (4 * w + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(do_base + dooff[i], base + ATTB_IMG + (4 * w + i) * 1024);
+        const float* stat = (w < 4 ? lse : delta) + ((long)view * heads + head) * ATT_T + 64 * (w & 3) + lane;
+        glds4(stat, base + 2 * ATTB_IMG + 256 * w);          // lse_s = floats 0-255, del_s = floats 256-511
+    };
+    u32x4 kw[4], vw[4];
+    auto request_kv = [&](int blk) {
+        const int view = blk / heads, head = blk % heads;
+        const bf16_t* krow = qkv + ((long)view * ATT_T + key) * rs3 + head * ATT_D + E;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            kw[kk] = *reinterpret_cast<const u32x4*>(krow + 16 * kk + 8 * hf);
+            vw[kk] = *reinterpret_cast<const u32x4*>(krow + E + 16 * kk + 8 * hf);
+        }
+    };
+    // transposing reads: lane (j = lane & 15: row j / 4, 4 columns at 4 (j % 4); lanes 16-31: columns + 16; hf: rows + 4)
+    unsigned troff[2][2];                                     // [d tile][rows 0-3 / 8-11 of the 16-query step]
+    {
+        const int j = lane & 15, g16 = (lane >> 4) & 1, r4 = j >> 2, c = j & 3;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rsel = 0; rsel < 2; ++rsel) {
+                const int row = 8 * rsel + 4 * hf + r4, d0 = 32 * dt + 16 * g16 + 4 * c;
+                troff[dt][rsel] = (unsigned)(row * 128 + (((d0 >> 3) ^ attb_swz2(row)) << 4) + (d0 & 7) * 2);
+            }
+    }
+    const unsigned smem_addr = lds_addr_of(smem);
+
+    int blk = blockIdx.x;
+    if (blk >= nblocks) return;
+    dma_block(blk, 0);
+    request_kv(blk);
+    glds_wait_all();
+    for (int it = 0; blk < nblocks; blk += gridDim.x, ++it) {
+        const int view = blk / heads, head = blk % heads, buf = it & 1;
+        const char* q_img = smem + buf * ATTB_TR_BUF;
+        const char* do_img = q_img + ATTB_IMG;
+        const float* lse_s = reinterpret_cast<const float*>(q_img + 2 * ATTB_IMG);
+        const float* del_s = lse_s + ATT_T;
+        // Every wave drained its requests for this block (DMA pieces, k / v rows) BEFORE it stored the previous block's results
+        // (below): the barrier publishes the images and says that every wave has left the previous block, whose buffer the next
+        // block's DMA overwrites - and the stores drain under this block's products instead of in front of a `vmcnt(0)`.
+        // (A full drain, not a counted wait: counted waits must not span LDS-DMA and register loads, see gemm_tn384.h.)
+        __syncthreads();
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            kf[kk] = __builtin_bit_cast(bf16x8, kw[kk]);
+            vf[kk] = __builtin_bit_cast(bf16x8, vw[kk]);
+        }
+        if (blk + (int)gridDim.x < nblocks && !(lab & 2)) {     // (lab bit 2: no loads after the first block)
+            dma_block(blk + gridDim.x, buf ^ 1);
+            request_kv(blk + gridDim.x);
+        }
+
+        f32x16 dk[2], dv[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+        auto scores = [&](int qt, f32x16& s, f32x16& dp) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            const int row = 32 * qt + lq;
+            const int f = attb_swz2(row);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int off = row * 128 + (((2 * kk + hf) ^ f) << 4);
+                s = mfma_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(q_img + off), kf[kk], s);       // S[q][key]
+                dp = mfma_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(do_img + off), vf[kk], dp);    // dP[q][key]
+            }
+        };
+        f32x16 s, dp;
+        scores(0, s, dp);
+        const unsigned q_addr = smem_addr + (unsigned)(buf * ATTB_TR_BUF), do_addr = q_addr + ATTB_IMG;
+        // dO^T / Q^T fragments of a 16-query step, both d tiles: 8 transposing reads (prelude: lds_read_tr), retired in issue
+        // order.  Step 0's are requested in front of the bf16 packing of the tile's P / dS, step 1's behind step 0's products.
+#define ATTB_TR_READS(x, OFF)                                                                                         \
+        lds_read_tr<OFF>(x[0][0], do_addr + tile + troff[0][0]); lds_read_tr<OFF>(x[0][1], do_addr + tile + troff[0][1]);   \
+        lds_read_tr<OFF>(x[1][0], q_addr + tile + troff[0][0]);  lds_read_tr<OFF>(x[1][1], q_addr + tile + troff[0][1]);    \
+        lds_read_tr<OFF>(x[2][0], do_addr + tile + troff[1][0]); lds_read_tr<OFF>(x[2][1], do_addr + tile + troff[1][1]);   \
+        lds_read_tr<OFF>(x[3][0], q_addr + tile + troff[1][0]);  lds_read_tr<OFF>(x[3][1], q_addr + tile + troff[1][1]);
+#pragma unroll 1
+        for (int qt = 0; qt < 8; ++qt) {
+            f32x16 sn, dpn;
+            scores(qt + 1 < 8 ? qt + 1 : 7, sn, dpn);        // (the last iteration recomputes tile 7: branch-free)
+            const unsigned tile = (unsigned)(qt * 32 * 128);
+            tr_u32x2 x0[4][2], x1[4][2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qq = 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                const float p = fast_exp2(fmaf(s[r], scale * 1.4426950408889634f, -lse_s[qq] * 1.4426950408889634f));
+                s[r] = p;
+                dp[r] = p * (dp[r] - del_s[qq]) * scale;
+            }
+            CCD_SCHED_FENCE();
+            ATTB_TR_READS(x0, 0)                             // (land under the packing below)
+            bf16x8 pf, dsf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pf[e] = (short)f2bf(s[e]);
+                dsf[e] = (short)f2bf(dp[e]);
+            }
+            {
+                bf16x8 a = frag_from_tr(x0[0][0], x0[0][1]), b = frag_from_tr(x0[1][0], x0[1][1]);
+                bf16x8 c = frag_from_tr(x0[2][0], x0[2][1]), d = frag_from_tr(x0[3][0], x0[3][1]);
+                // (every fragment goes through a wait of its own: a product whose operands do not depend on the wait would be
+                // free to move above it)
+                lds_wait_frag<6>(a);
+                dv[0] = mfma_32x32x16_bf16(a, pf, dv[0]);
+                lds_wait_frag<4>(b);
+                dk[0] = mfma_32x32x16_bf16(b, dsf, dk[0]);
+                lds_wait_frag<2>(c);
+                dv[1] = mfma_32x32x16_bf16(c, pf, dv[1]);
+                lds_wait_frag<0>(d);
+                dk[1] = mfma_32x32x16_bf16(d, dsf, dk[1]);
+            }
+            CCD_SCHED_FENCE();
+            ATTB_TR_READS(x1, 2048)                          // (step 1's land under step 0's four MFMAs and step 1's packing)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pf[e] = (short)f2bf(s[8 + e]);
+                dsf[e] = (short)f2bf(dp[8 + e]);
+            }
+            {
+                bf16x8 a = frag_from_tr(x1[0][0], x1[0][1]), b = frag_from_tr(x1[1][0], x1[1][1]);
+                bf16x8 c = frag_from_tr(x1[2][0], x1[2][1]), d = frag_from_tr(x1[3][0], x1[3][1]);
+                // (every fragment goes through a wait of its own: a product whose operands do not depend on the wait would be
+                // free to move above it)
+                lds_wait_frag<6>(a);
+                dv[0] = mfma_32x32x16_bf16(a, pf, dv[0]);
+                lds_wait_frag<4>(b);
+                dk[0] = mfma_32x32x16_bf16(b, dsf, dk[0]);
+                lds_wait_frag<2>(c);
+                dv[1] = mfma_32x32x16_bf16(c, pf, dv[1]);
+                lds_wait_frag<0>(d);
+                dk[1] = mfma_32x32x16_bf16(d, dsf, dk[1]);
+            }
+            s = sn;
+            dp = dpn;
+        }
+#undef ATTB_TR_READS
+        glds_wait_all();                                     // the next block's requests (issued a whole block ago)
+        bf16_t* drow = dqkv + ((long)view * ATT_T + key) * rs3 + head * ATT_D;
+        if (!(lab & 1) || blk == (int)blockIdx.x) {          // (lab bit 1: stores of the first block only)
+            attb_store_t(drow + E, dk, hf);
+            attb_store_t(drow + 2 * E, dv, hf);
+        }
+    }
+}
+
 // ---- both passes in ONE kernel: q, k, v, dO, O of a block are read once (0.8 GB per layer instead of 1.2).  Pass A is the dQ
 // kernel's body (K, V, K^T images; a lane owns a query); its lanes then keep their q / dO rows and lse / delta, write them
 // to LDS as the Q / dO row images of pass B (whose transposed images are rebuilt from those, LDS to LDS), the key / value

@@ -56,6 +56,10 @@ struct GemmParams {
     const bf16_t* B2;
     long lda2, ldb2;
     int M2, N2;
+    // the workgroups of XCD x are units1[x] groups of the first problem's tiles, then units2[x] groups of the second's (one byte
+    // per XCD); a group works on one contraction slice of ITS problem: slices2 slices of per2 rows for the second problem
+    unsigned long long units1, units2;
+    int slices2, per2;
     float* colsumsq;        // optional [N] fp32: += column sums of squares (BatchNorm batch statistics), EPI_BF16 only
     // ---- implicit-GEMM convolution (NT, GATHER instantiation): A row r is pixel (n, oy, ox) of a 2^gh x 2^gw grid,
     // contraction index k = tap * cin + c reads source pixel (oy*s_mul + dy(tap), ox*s_mul + dx(tap)) of an s_h x s_w

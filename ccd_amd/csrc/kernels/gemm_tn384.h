@@ -60,9 +60,12 @@ __device__ __forceinline__ int tn3_swz(int row) {
 
 // p.M = P, p.N = Q, p.K = contraction length, p.k_per_split = rows per slice (multiple of 32), p.work_items = number of slices,
 // p.m_fastest = XCDs the grid is spread over (8, or 1: every workgroup is its own group member in launch order).
-// p.M2 > 0: a second problem (A2, B2, C2; same K) whose tiles follow the first one's inside every group - the launch then pays
-// ONE atomic epilogue per workgroup for two products (the epilogue, ~55 us, is a third of a single product's time).
-// Grid: xcds * slots; workgroup b -> xcd b % xcds, slot b / xcds; slot -> (group, tile); slice = xcd * groups_per_xcd + group.
+// p.M2 > 0: a second problem (A2, B2, C2; same K; slices2 slices of per2 rows) in the same launch - which then pays ONE atomic
+// epilogue per workgroup for two products (the epilogue, ~55 us, is a third of a single product's time).
+// Grid: xcds * slots; workgroup b -> xcd b % xcds, slot b / xcds.  The slots of XCD x: units1[x] groups of the first problem's
+// tiles, then units2[x] groups of the second's; the k-th group of a problem (counted over the XCDs) works on its slice k.  The two
+// problems' groups are placed independently, so an XCD with 31 usable slots (one CU reserved for the collectives) still holds
+// three groups of 8 (the host alternates 2 + 1 and 1 + 2) instead of one pair of 16.
 template <int WM, int WN, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN, 8 / (WM * WN)) void gemm_tn384_kernel(GemmParams p) {
     using G = Tn3Geom<WM, WN, STAGES>;
@@ -70,17 +73,27 @@ __global__ __launch_bounds__(64 * WM * WN, 8 / (WM * WN)) void gemm_tn384_kernel
     char* smem = dynamic_smem();
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, hf = lane >> 5, lq = lane & 31;
     const int wm = w % WM, wn = w / WM;
-    const int tiles1 = (p.M / G::TP) * (p.N / G::TQ), tiles = tiles1 + (p.M2 / G::TP) * (p.N2 / G::TQ);
-    const int xcds = p.m_fastest, spx = (int)gridDim.x / xcds, gpx = spx / tiles;
-    const int xcd = (int)blockIdx.x % xcds, slot = (int)blockIdx.x / xcds;
-    const int group = slot / tiles;
-    int tile = slot % tiles;
-    const int slice = xcd * gpx + group;
-    if (group >= gpx || slice >= p.work_items) return;
-    if (tile >= tiles1) {                                    // a tile of the second problem (wave-uniform)
-        tile -= tiles1;
-        p.A = p.A2; p.B = p.B2; p.lda = p.lda2; p.ldb = p.ldb2; p.N = p.N2; p.C = p.C2; p.ldc = p.ldc2;
+    const int tiles1 = (p.M / G::TP) * (p.N / G::TQ), tiles2 = (p.M2 / G::TP) * (p.N2 / G::TQ);
+    const int xcds = p.m_fastest, xcd = (int)blockIdx.x % xcds, slot = (int)blockIdx.x / xcds;
+    const int u1 = (int)((p.units1 >> (8 * xcd)) & 255ull), u2 = (int)((p.units2 >> (8 * xcd)) & 255ull);
+    int base1 = 0, base2 = 0;                                // groups of the XCDs in front of this one
+    for (int y = 0; y < xcd; ++y) {
+        base1 += (int)((p.units1 >> (8 * y)) & 255ull);
+        base2 += (int)((p.units2 >> (8 * y)) & 255ull);
     }
+    int tile, slice;
+    if (slot < u1 * tiles1) {
+        tile = slot % tiles1;
+        slice = base1 + slot / tiles1;
+    } else {                                                 // a tile of the second problem (wave-uniform)
+        const int s2 = slot - u1 * tiles1;
+        if (s2 >= u2 * tiles2) return;
+        tile = s2 % tiles2;
+        slice = base2 + s2 / tiles2;
+        p.A = p.A2; p.B = p.B2; p.lda = p.lda2; p.ldb = p.ldb2; p.N = p.N2; p.C = p.C2; p.ldc = p.ldc2;
+        p.k_per_split = p.per2; p.work_items = p.slices2;
+    }
+    if (slice >= p.work_items) return;
     const int tiles_q = p.N / G::TQ;
     const int p0 = (tile / tiles_q) * G::TP, q0 = (tile % tiles_q) * G::TQ;
     const int k_begin = slice * p.k_per_split;

@@ -73,6 +73,11 @@ __device__ __forceinline__ void glds16(const void* gptr, char* lds_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
                                      (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
+// 4-byte form: lane l's dword lands at lds_base + 4 l
+__device__ __forceinline__ void glds4(const void* gptr, char* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_base, 4, 0, 0);
+}
 __device__ __forceinline__ void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <int N>
 __device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }   // <= N VMEM ops outstanding

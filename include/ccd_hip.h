@@ -43,6 +43,10 @@ const char* ccd_build_info(void);
  *              3 / 4: rowgemm16.h (two 64-row workgroups per CU) with the 6- / 3-block ring (lab, N = 384)
  *   attn_fused 1: attention backward as one kernel (default 0: dQ kernel + dK/dV kernel)
  *   attn_skew  cycles / 64 by which waves 4..7 of the attention-backward kernels trail waves 0..3 (lab, default 0)
+ *   attn_tr    1 (default): dK / dV kernel on double-buffered LDS-DMA row images with transposing LDS reads; 0: four register-staged images
+ *   gemm_tn384 1 (default): ViT weight gradients (P % 384 == 0, Q % 192 == 0) on the XCD-grouped kernel of gemm_tn384.h, 0: 128-square
+ *              kernel, 2: never as a pair;  gemm_tn384_min_tiles (6): smallest single product it takes;  gemm_tn384_geom 1: 192x192 tiles,
+ *              two 4-wave workgroups per CU (tested, slower)
  *   cu_reserve compute units the persistent grids leave free (set while an RCCL gradient reducer is attached)
  *   lab        scratch switch of the lab harnesses under tools/ (0 in production) */
 int ccd_policy_set(const char* key, int value);

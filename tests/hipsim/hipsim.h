@@ -137,6 +137,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 inline char* dynamic_smem() { return sim::curblk->dyn_smem; }
 // LDS-DMA (prelude_hip.h): the executor copies synchronously, lane by lane
 inline void glds16(const void* gptr, char* lds_base) { std::memcpy(lds_base + 16 * sim::cur->lane, gptr, 16); }
+inline void glds4(const void* gptr, char* lds_base) { std::memcpy(lds_base + 4 * sim::cur->lane, gptr, 4); }
 inline void glds_wait_all() {}
 template <int N>
 inline void glds_wait() {}

@@ -46,6 +46,18 @@ def test_gemm_tn_pair(hip, Mc, shape1, shape2):
     kc.check_gemm_tn_pair(hip.device, Mc, shape1, shape2)
 
 
+def test_gemm_tn_pair_reserved_cus(hip):
+    """The grouped launch with compute units held back for the collectives (the N > 1 engine sets cu_reserve = 8: 31 slots per
+    XCD): the two problems' groups are placed independently - 2 + 1 / 1 + 2 groups of 8 for the MLP pair, 3-5 + 3-4 for the
+    attention pair - with different slice counts per problem; an odd reserve leaves XCDs with different slot counts."""
+    from ccd_amd import ops
+    for reserve in (8, 13):
+        with ops.policy(cu_reserve=reserve):
+            kc.check_gemm_tn_pair(hip.device, 16384 + 96, (384, 1536), (1536, 384), seed=11)
+            kc.check_gemm_tn_pair(hip.device, 16384, (384, 384), (1152, 384), seed=12)
+            kc.check_gemm_tn(hip.device, 8192, 1536, 384, seed=13)
+
+
 @pytest.mark.parametrize("policy", [dict(gemm_tn384=0), dict(gemm_tn384_min_tiles=1), dict(gemm_tn384_geom=1)])
 def test_gemm_tn_policies(hip, policy):
     """Single weight-gradient products on the kernel that is not the default for their shape: the 128-square kernel for the
@@ -67,6 +79,10 @@ def test_attention(hip, views, heads, spike):
     from ccd_amd import ops
     kc.check_attention(hip.device, views, heads, spike=spike)
     with ops.policy(attn_fused=1):                            # the backward pass as ONE kernel (q, k, v, dO, O read once)
+        kc.check_attention(hip.device, views, heads, spike=spike)
+    with ops.policy(attn_tr=0):                               # dK / dV on the four register-staged images
+        kc.check_attention(hip.device, views, heads, spike=spike)
+    with ops.policy(cu_reserve=248):                          # 8 workgroups walk the blocks: the double-buffered images turn over
         kc.check_attention(hip.device, views, heads, spike=spike)
 
 

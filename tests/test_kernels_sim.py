@@ -69,6 +69,8 @@ def test_attention_sim(sim):
     kc.check_attention(sim.device, views=1, heads=2)
     with ops.policy(attn_fused=1):                           # backward as ONE kernel
         kc.check_attention(sim.device, views=1, heads=2)
+    with ops.policy(attn_tr=0):                              # dK / dV on the four register-staged images
+        kc.check_attention(sim.device, views=1, heads=2)
 
 
 def test_gemm_dynamic_rows_sim(sim):
