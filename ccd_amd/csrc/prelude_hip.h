@@ -159,6 +159,13 @@ __device__ __forceinline__ bf16x8 frag_from_tr(tr_u32x2 lo, tr_u32x2 hi) {
     const buf_u32x4 v = {lo.x, lo.y, hi.x, hi.y};
     return __builtin_bit_cast(bf16x8, v);
 }
+// v_permlane32_swap (gfx950): lanes l < 32 keep a and receive lane l + 32's a in b; lanes l >= 32 keep b and receive lane
+// l - 32's b in a - two half-wave exchanges in one instruction
+__device__ __forceinline__ void lane32_swap(unsigned& a, unsigned& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
 // v_perm_b32: result byte i = byte sel.byte[i] of the 8-byte value {hi : lo} (0..3 = lo's bytes, 4..7 = hi's bytes)
 __device__ __forceinline__ unsigned perm_b32(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 __device__ __forceinline__ float opaque_f32(float x) { asm volatile("" : "+v"(x)); return x; }

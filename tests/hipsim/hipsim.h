@@ -225,6 +225,11 @@ inline T shfl(T v, int src_lane) {
     sim::wave_sync();
     return r;
 }
+inline void lane32_swap(unsigned& a, unsigned& b) {           // prelude_hip.h: v_permlane32_swap
+    const int lane = sim::cur->lane;
+    const unsigned pa = shfl(a, lane ^ 32), pb = shfl(b, lane ^ 32);
+    if (lane < 32) b = pa; else a = pb;
+}
 template <typename T>
 inline T shfl_xor(T v, int mask) { return shfl(v, sim::cur->lane ^ mask); }
 template <int M>
