@@ -49,24 +49,8 @@ __device__ __forceinline__ bf16x8 attb_row_frag(const char* img, int row, int kk
 __device__ __forceinline__ bf16x8 attb_tr_frag(const char* img, int d, int ks, int hf) {
     return *reinterpret_cast<const bf16x8*>(img + d * 512 + (((2 * ks + hf) ^ (d & 15)) * 16));
 }
-// a lane's 16 + 16 values of its row (columns 8 g + 4 hf .. + 3 of each 32-column tile) as 16-byte stores: the two half-waves
-// exchange quads (v_permlane32_swap) so that lanes < 32 own columns 8 g .. + 7 for even g and lanes >= 32 for odd g - half the
-// store instructions and half the cache-line requests of the 8-byte form (a wave store touches 32 rows either way)
 __device__ __forceinline__ void attb_store_t(bf16_t* row_ptr, const f32x16 (&acc)[2], int hf) {
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-            const int ge = 8 * gp, go = 8 * gp + 4;          // accumulator registers of the even / odd 8-column group
-            unsigned ex = pack_bf2(acc[dt][ge + 0], acc[dt][ge + 1]), ey = pack_bf2(acc[dt][ge + 2], acc[dt][ge + 3]);
-            unsigned ox = pack_bf2(acc[dt][go + 0], acc[dt][go + 1]), oy = pack_bf2(acc[dt][go + 2], acc[dt][go + 3]);
-            lane32_swap(ex, ox);
-            lane32_swap(ey, oy);
-            // lanes < 32: (ex, ey) own quad, (ox, oy) the partner's quad of the SAME even group; lanes >= 32: (ex, ey) the
-            // partner's quad of the odd group, (ox, oy) own
-            const u32x4 v = {ex, ey, ox, oy};
-            *reinterpret_cast<u32x4*>(row_ptr + 32 * dt + 8 * (2 * gp + hf)) = v;
-        }
+    att_store_row16(row_ptr, acc, hf, 1.0f);                 // (attention_fwd.h: 16-byte stores after a half-wave exchange)
 }
 
 // Register images of one (view, head) block's operands: what a thread moves to LDS / consumes itself.  The kernels are

@@ -57,6 +57,27 @@ __device__ __forceinline__ void att_stage_transposed(const bf16_t* __restrict__ 
     }
 }
 
+// A lane's 16 + 16 values of its output row (columns 8 g + 4 hf .. + 3 of each 32-column tile of the transposed product) as
+// 16-byte stores: the two half-waves exchange quads (v_permlane32_swap) so that lanes < 32 own columns 8 g .. + 7 for even g and
+// lanes >= 32 for odd g - half the store instructions and cache-line requests of the 8-byte form (a wave store touches 32 rows
+// either way).  Measured on the backward kernels: 0.36 -> 0.345 ms per layer pair.
+__device__ __forceinline__ void att_store_row16(bf16_t* row_ptr, const f32x16 (&acc)[2], int hf, float mul) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+            const int ge = 8 * gp, go = 8 * gp + 4;          // accumulator registers of the even / odd 8-column group
+            unsigned ex = pack_bf2(acc[dt][ge + 0] * mul, acc[dt][ge + 1] * mul), ey = pack_bf2(acc[dt][ge + 2] * mul, acc[dt][ge + 3] * mul);
+            unsigned ox = pack_bf2(acc[dt][go + 0] * mul, acc[dt][go + 1] * mul), oy = pack_bf2(acc[dt][go + 2] * mul, acc[dt][go + 3] * mul);
+            lane32_swap(ex, ox);
+            lane32_swap(ey, oy);
+            // lanes < 32: (ex, ey) own quad, (ox, oy) the partner's quad of the SAME even group; lanes >= 32: (ex, ey) the
+            // partner's quad of the odd group, (ox, oy) own
+            const u32x4 v = {ex, ey, ox, oy};
+            *reinterpret_cast<u32x4*>(row_ptr + 32 * dt + 8 * (2 * gp + hf)) = v;
+        }
+}
+
 __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, int heads, float scale) {
     char* smem = dynamic_smem();
@@ -151,15 +172,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const bf16_t* __r
         }
         const float inv = 1.0f / sum;
         bf16_t* orow = out + ((long)view * ATT_T + q) * E + head * ATT_D;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2 pk;
-                pk.x = pack_bf2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
-                pk.y = pack_bf2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
-                *reinterpret_cast<u32x2*>(orow + 32 * dt + 8 * g + 4 * hf) = pk;
-            }
+        att_store_row16(orow, o, hf, inv);
         if (hf == 0) lse[((long)view * heads + head) * ATT_T + q] = mx * scale + logf(sum);
     }
 }
