@@ -93,6 +93,8 @@ struct CcdPolicy {
     int gemm_tn384_geom = 0;    // its workgroup: 0 = 384x192 tile, 8 waves, one per CU; 1 = 192x192 tile, 4 waves, two per CU
     int gemm_tn384_min_tiles = 6;   // ... for a SINGLE product only from this many tiles on (proj, 2 tiles = 128 slices: the atomic epilogue dominates)
     int cu_reserve = 0;         // compute units the persistent grids leave free (set while an RCCL gradient reducer is attached)
+    int cu_reserve_window = -1; // -1: every launch leaves them free; N >= 0: only the next `cu_reserve_left` launches do (the reducer
+    int cu_reserve_left = 0;    // re-arms it with N whenever it starts a bucket's all-reduce: the kernels that run beside the collective)
     int lab = 0;                // scratch switch for kernel experiments (tools/*_lab.py); 0 in production
 };
 struct CcdPolicyKey { const char* name; int CcdPolicy::*field; };
@@ -100,7 +102,7 @@ static const CcdPolicyKey ccd_policy_keys[] = {
     {"gemm_256", &CcdPolicy::gemm_256}, {"gemm_256_min_m", &CcdPolicy::gemm_256_min_m},
     {"gemm_256_min_n", &CcdPolicy::gemm_256_min_n}, {"gemm_256_f32", &CcdPolicy::gemm_256_f32},
     {"gemm_256_deep", &CcdPolicy::gemm_256_deep}, {"gemm_row384", &CcdPolicy::gemm_row384},
-    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_fused", &CcdPolicy::attn_fused}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"lab", &CcdPolicy::lab}};
+    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_fused", &CcdPolicy::attn_fused}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"lab", &CcdPolicy::lab}};
 static CcdPolicy& ccd_policy() {
     static CcdPolicy pol = [] {
         CcdPolicy q;
@@ -116,8 +118,17 @@ static CcdPolicy& ccd_policy() {
     return pol;
 }
 // compute units a persistent grid may occupy: all of them, minus the ones reserved for concurrently running RCCL kernels
+// Reserving CUs is expensive for the row-owner kernels (131072 rows = 512 tiles of 256 rows: 2 rounds on 256 CUs, 3 on 248 - the
+// fused MLP, the residual + LayerNorm product and the LayerNorm-backward product ran 16-20 % longer), and a bucket's all-reduce is in
+// flight for well under a millisecond: with cu_reserve_window >= 0 only the launches right behind a bucket launch leave CUs free.
 static int ccd_grid_cus() {
-    const int cus = ccd_rt_num_cus() - ccd_policy().cu_reserve;
+    CcdPolicy& pol = ccd_policy();
+    int reserve = pol.cu_reserve;
+    if (reserve > 0 && pol.cu_reserve_window >= 0) {
+        if (pol.cu_reserve_left > 0) --pol.cu_reserve_left;
+        else reserve = 0;
+    }
+    const int cus = ccd_rt_num_cus() - reserve;
     return cus > 1 ? cus : 1;
 }
 // 256x256-tile LDS-DMA kernel for the large-M products (gemm256.h): one workgroup per CU

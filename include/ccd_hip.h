@@ -48,6 +48,8 @@ const char* ccd_build_info(void);
  *              kernel, 2: never as a pair;  gemm_tn384_min_tiles (6): smallest single product it takes;  gemm_tn384_geom 1: 192x192 tiles,
  *              two 4-wave workgroups per CU (tested, slower)
  *   cu_reserve compute units the persistent grids leave free (set while an RCCL gradient reducer is attached)
+ *   cu_reserve_window -1 (default): every launch leaves them free; N >= 0: only the next cu_reserve_left launches do - the
+ *              gradient reducer sets cu_reserve_left = N whenever it starts a bucket's all-reduce (ccd_amd/parallel.py)
  *   lab        scratch switch of the lab harnesses under tools/ (0 in production) */
 int ccd_policy_set(const char* key, int value);
 int ccd_policy_get(const char* key, int* value);

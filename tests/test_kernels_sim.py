@@ -243,3 +243,17 @@ def test_kmeans2_mask_sim(sim):
 
 def test_augment_views_sim(sim):
     kc.check_augment_views(sim.device, B=3, H=16, W=40)
+
+
+def test_cu_reserve_window_sim(sim, monkeypatch):
+    """cu_reserve_window >= 0: only the launches right behind a bucket launch (cu_reserve_left, re-armed by the gradient reducer)
+    leave compute units free; results do not depend on the grid either way."""
+    from ccd_amd import ops
+    monkeypatch.setenv("CCD_SIM_CUS", "4")
+    with ops.policy(cu_reserve=2, cu_reserve_window=3, cu_reserve_left=2):
+        kc.check_gemm_nt(sim.device, M=200, N=136, K=128)          # several persistent-grid launches: the counter runs out
+        assert ops.policy_get("cu_reserve_left") == 0
+        kc.check_gemm_tn(sim.device, Mc=300, P=136, Q=72, splits=3)
+        ops.policy_set("cu_reserve_left", 1)
+        kc.check_gemm_tn(sim.device, Mc=2048, P=384, Q=192, seed=9)   # one gemm_tn384 launch on 2 of the 4 CUs, then the rest on 4
+        assert ops.policy_get("cu_reserve_left") == 0
