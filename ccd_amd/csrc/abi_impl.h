@@ -1094,7 +1094,7 @@ int ccd_dec_attn_fwd(const ccd_bf16* q, long ldq, const ccd_bf16* k, long ldk, c
     const int rc = ccd_dec_attn_check(a);
     if (rc != CCD_OK) return rc;
     if (B == 0) return CCD_OK;
-    if (ccd_sattn_mfma(a) && ldo % 4 == 0) {                             // short key sequences: one wave per (sample, head)
+    if (ccd_sattn_mfma(a) && ldo % 8 == 0 && CCD_ALIGNED16(out)) {       // short key sequences: one wave per (sample, head); 16-byte row stores
         CCD_LAUNCH(ccd::sattn_fwd_kernel, dim3((B * H + 3) / 4), dim3(256), (size_t)ccd::SA_FWD_SMEM, stream, a);
         return ccd_rt_last_error();
     }
@@ -1123,7 +1123,7 @@ int ccd_dec_attn_bwd(const ccd_bf16* q, long ldq, const ccd_bf16* k, long ldk, c
     CCD_CHECK(lddk % 8 == 0 && lddv % 8 == 0 && CCD_ALIGNED16(dk) && CCD_ALIGNED16(dv) && CCD_ALIGNED16(d_out) && ldo % 8 == 0,
               CCD_ESHAPE);
     if (B == 0) return CCD_OK;
-    if (ccd_sattn_mfma(a) && lddq % 4 == 0 && CCD_ALIGNED16(out)) {
+    if (ccd_sattn_mfma(a) && lddq % 8 == 0 && CCD_ALIGNED16(dq) && CCD_ALIGNED16(out)) {
         CCD_LAUNCH(ccd::sattn_bwd_kernel, dim3((B * H + 3) / 4), dim3(256), (size_t)ccd::SA_BWD_SMEM, stream, a);
         return ccd_rt_last_error();
     }

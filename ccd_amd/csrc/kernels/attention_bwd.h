@@ -49,8 +49,8 @@ __device__ __forceinline__ bf16x8 attb_row_frag(const char* img, int row, int kk
 __device__ __forceinline__ bf16x8 attb_tr_frag(const char* img, int d, int ks, int hf) {
     return *reinterpret_cast<const bf16x8*>(img + d * 512 + (((2 * ks + hf) ^ (d & 15)) * 16));
 }
-__device__ __forceinline__ void attb_store_t(bf16_t* row_ptr, const f32x16 (&acc)[2], int hf) {
-    att_store_row16(row_ptr, acc, hf, 1.0f);                 // (attention_fwd.h: 16-byte stores after a half-wave exchange)
+__device__ __forceinline__ void attb_store_t(bf16_t* row_ptr, const f32x16 (&acc)[2], int hf, bool live = true) {
+    att_store_row16(row_ptr, acc, hf, 1.0f, live);           // (attention_fwd.h: 16-byte stores after a half-wave exchange)
 }
 
 // Register images of one (view, head) block's operands: what a thread moves to LDS / consumes itself.  The kernels are

@@ -61,7 +61,8 @@ __device__ __forceinline__ void att_stage_transposed(const bf16_t* __restrict__ 
 // 16-byte stores: the two half-waves exchange quads (v_permlane32_swap) so that lanes < 32 own columns 8 g .. + 7 for even g and
 // lanes >= 32 for odd g - half the store instructions and cache-line requests of the 8-byte form (a wave store touches 32 rows
 // either way).  Measured on the backward kernels: 0.36 -> 0.345 ms per layer pair.
-__device__ __forceinline__ void att_store_row16(bf16_t* row_ptr, const f32x16 (&acc)[2], int hf, float mul) {
+// `live`: rows beyond the matrix take part in the exchange (both lanes of a row share the predicate) but store nothing.
+__device__ __forceinline__ void att_store_row16(bf16_t* row_ptr, const f32x16 (&acc)[2], int hf, float mul, bool live = true) {
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -74,7 +75,7 @@ __device__ __forceinline__ void att_store_row16(bf16_t* row_ptr, const f32x16 (&
             // lanes < 32: (ex, ey) own quad, (ox, oy) the partner's quad of the SAME even group; lanes >= 32: (ex, ey) the
             // partner's quad of the odd group, (ox, oy) own
             const u32x4 v = {ex, ey, ox, oy};
-            *reinterpret_cast<u32x4*>(row_ptr + 32 * dt + 8 * (2 * gp + hf)) = v;
+            if (live) *reinterpret_cast<u32x4*>(row_ptr + 32 * dt + 8 * (2 * gp + hf)) = v;
         }
 }
 

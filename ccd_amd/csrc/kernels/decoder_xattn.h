@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(DecAttnParams p) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) o[dt] = mfma_32x32x16_bf16(xa_qt_frag(vt_img, 32 * dt + lq, s2, hf), pf, o[dt]);
     }
-    if (lq < Tq) attb_store_t(p.out + ((long)b * Tq + lq) * p.ldo + h * XA_D, o, hf);
+    attb_store_t(p.out + ((long)b * Tq + lq) * p.ldo + h * XA_D, o, hf, lq < Tq);     // (every lane takes part in the exchange)
 }
 
 __global__ __launch_bounds__(256) void sattn_bwd_kernel(DecAttnParams p) {
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void sattn_bwd_kernel(DecAttnParams p) {
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma_32x32x16_bf16(xa_qt_frag(kt_img, 32 * dt + lq, s2, hf), dsf, dq[dt]);
         }
-        if (lq < Tq) attb_store_t(p.dq + ((long)b * Tq + lq) * p.lddq + h * XA_D, dq, hf);
+        attb_store_t(p.dq + ((long)b * Tq + lq) * p.lddq + h * XA_D, dq, hf, lq < Tq);
     }
     {   // orientation 2: lane = key -> dK, dV
         f32x16 s, dp;
@@ -551,10 +551,8 @@ __global__ __launch_bounds__(256) void sattn_bwd_kernel(DecAttnParams p) {
                 dk[dt] = mfma_32x32x16_bf16(xa_qt_frag(qt_img, 32 * dt + lq, s2, hf), dsf, dk[dt]);
             }
         }
-        if (lq < Tk) {
-            attb_store_t(p.dk + ((long)b * Tk + lq) * p.lddk + h * XA_D, dk, hf);
-            attb_store_t(p.dv + ((long)b * Tk + lq) * p.lddv + h * XA_D, dv, hf);
-        }
+        attb_store_t(p.dk + ((long)b * Tk + lq) * p.lddk + h * XA_D, dk, hf, lq < Tk);
+        attb_store_t(p.dv + ((long)b * Tk + lq) * p.lddv + h * XA_D, dv, hf, lq < Tk);
     }
 }
 
