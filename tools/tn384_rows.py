@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""gemm_tn384.h main loop (policy lab = 1) against the size of the operands - L2-, MALL- and HBM-resident: the time per 32-row
+stage does not depend on it (profiles/r02_tn384_lab.jsonl).  usage (GPU box): python tools/tn384_rows.py"""
 import sys, json, torch
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tools')
 from ccd_amd import ops
