@@ -90,7 +90,7 @@ struct CcdPolicy {
     int attn_tr = 1;            // attention backward dK/dV: double-buffered LDS-DMA row images + ds_read_b64_tr_b16 (0 = four register-staged images)
     int attn_skew = 0;          // attention backward: waves 4..7 start each block ~skew * 64 cycles late (lab; no effect once clocks are warm)
     int gemm_tn384 = 1;         // weight gradients with P % 384 == 0, Q % 192 == 0: XCD-grouped 384x192 LDS-DMA kernel (gemm_tn384.h); 0 = 128-square kernel, 2 = never as a pair
-    int gemm_tn384_geom = 0;    // its workgroup: 0 = 384x192 tile, 8 waves, one per CU; 1 = 192x192 tile, 4 waves, two per CU
+    int gemm_tn384_geom = 0;    // its workgroup: 0 = 384x192 tile, 8 waves, one per CU; 1 = 192x192 tile, 4 waves, two per CU; 2 = 0 + 512x128 tiles for the shapes 384x192 does not divide (E = 512)
     int gemm_tn384_min_tiles = 6;   // ... for a SINGLE product only from this many tiles on (proj, 2 tiles = 128 slices: the atomic epilogue dominates)
     int cu_reserve = 0;         // compute units the persistent grids leave free (set while an RCCL gradient reducer is attached)
     int cu_reserve_window = -1; // -1: every launch leaves them free; N >= 0: only the next `cu_reserve_left` launches do (the reducer
@@ -166,9 +166,9 @@ static int ccd_launch_gemm_row384(const ccd::GemmParams& p, int epilogue, void* 
 }
 
 // gemm_tn384.h launch for one workgroup geometry (see ccd_launch_tn384 below)
-template <int WM, int WN, int STAGES>
+template <int WM, int WN, int STAGES, int TI, int TJ>
 static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, void* stream) {
-    using G = ccd::Tn3Geom<WM, WN, STAGES>;
+    using G = ccd::Tn3Geom<WM, WN, STAGES, TI, TJ>;
     const int per_cu = 8 / G::WAVES;
     const int t1 = (p.M / G::TP) * (p.N / G::TQ), t2 = (p.M2 / G::TP) * (p.N2 / G::TQ), slots = per_cu * ccd_grid_cus();
     const int xcds = slots >= 8 * (t1 > t2 ? t1 : t2) ? 8 : 1;
@@ -200,7 +200,7 @@ static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, void* stream) {
     p.k_per_split = rows_per(s1); p.work_items = s1;
     if (t2 > 0) { p.per2 = rows_per(s2); p.slices2 = s2; }
     p.units1 = units1; p.units2 = units2; p.m_fastest = xcds;
-    CCD_LAUNCH((ccd::gemm_tn384_kernel<WM, WN, STAGES>), dim3(xcds * spx), dim3(G::THREADS), G::SMEM_BYTES, stream, p);
+    CCD_LAUNCH((ccd::gemm_tn384_kernel<WM, WN, STAGES, TI, TJ>), dim3(xcds * spx), dim3(G::THREADS), G::SMEM_BYTES, stream, p);
     return ccd_rt_last_error();
 }
 
@@ -416,12 +416,17 @@ static int ccd_gemm_tn_impl(const ccd_bf16* A, long lda, const ccd_bf16* B, long
                             long ldc, float alpha, int splits, const int* d_rows, int rows_mul, float* colsum_a, void* stream);
 // gemm_tn384.h: one group of (P / TP) (Q / TQ) [+ the second problem's] workgroups per contraction slice, whole groups per XCD
 // (workgroup b runs on XCD b % 8).  CCD_ESHAPE: the tiles of one slice do not fit the grid - the caller takes another kernel.
-static bool ccd_tn384_fits(int P, int Q, int Mc) {
-    const int tp = ccd_policy().gemm_tn384_geom == 1 ? 192 : 384;
-    return P % tp == 0 && Q % 192 == 0 && Mc % ccd::TN3_BK == 0 && Mc >= 2048;
+// workgroup geometry for a P x Q product: 0 = 384 x 192 tiles, 2 = 512 x 128 (the E = 512 shapes), 1 = 192 x 192 x two per CU (policy
+// gemm_tn384_geom = 1 only); -1 = none of them divides the shape
+static int ccd_tn384_geom(int P, int Q, int Mc) {
+    if (Mc % ccd::TN3_BK != 0 || Mc < 2048) return -1;
+    if (ccd_policy().gemm_tn384_geom == 1) return P % 192 == 0 && Q % 192 == 0 ? 1 : -1;
+    if (P % 384 == 0 && Q % 192 == 0) return 0;
+    if (ccd_policy().gemm_tn384_geom == 2 && P % 512 == 0 && Q % 128 == 0) return 2;    // (measured on vit_base: 44.6 vs 44.3 ms - opt-in)
+    return -1;
 }
-static int ccd_tn384_tiles(int P, int Q) {
-    return (P / (ccd_policy().gemm_tn384_geom == 1 ? 192 : 384)) * (Q / 192);
+static int ccd_tn384_tiles(int geom, int P, int Q) {
+    return geom == 0 ? (P / 384) * (Q / 192) : geom == 2 ? (P / 512) * (Q / 128) : (P / 192) * (Q / 192);
 }
 static int ccd_launch_tn384(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P, int Q, float* C, long ldc,
                             const ccd_bf16* A2, long lda2, const ccd_bf16* B2, long ldb2, int P2, int Q2, float* C2, long ldc2,
@@ -430,8 +435,11 @@ static int ccd_launch_tn384(const ccd_bf16* A, long lda, const ccd_bf16* B, long
     p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.M = P; p.N = Q; p.K = Mc; p.C = C; p.ldc = ldc;
     p.A2 = A2; p.B2 = B2; p.lda2 = lda2; p.ldb2 = ldb2; p.M2 = P2; p.N2 = Q2; p.C2 = C2; p.ldc2 = ldc2;
     p.alpha = alpha; p.rps_shift = ccd_policy().lab; p.colsum_a = lab_out;
-    if (ccd_policy().gemm_tn384_geom == 1) return ccd_launch_tn384_geom<2, 2, 3>(p, Mc, stream);
-    return ccd_launch_tn384_geom<4, 2, 4>(p, Mc, stream);
+    const int geom = ccd_tn384_geom(P, Q, Mc);
+    if (geom < 0 || (P2 > 0 && ccd_tn384_geom(P2, Q2, Mc) != geom)) return CCD_ESHAPE;
+    if (geom == 1) return ccd_launch_tn384_geom<2, 2, 3, 3, 3>(p, Mc, stream);
+    if (geom == 2) return ccd_launch_tn384_geom<4, 2, 3, 4, 2>(p, Mc, stream);
+    return ccd_launch_tn384_geom<4, 2, 4, 3, 3>(p, Mc, stream);
 }
 int ccd_gemm_tn_pair(const ccd_bf16* A1, long lda1, const ccd_bf16* B1, long ldb1, int P1, int Q1, float* C1, long ldc1,
                      const ccd_bf16* A2, long lda2, const ccd_bf16* B2, long ldb2, int P2, int Q2, float* C2, long ldc2, int Mc,
@@ -442,7 +450,8 @@ int ccd_gemm_tn_pair(const ccd_bf16* A1, long lda1, const ccd_bf16* B1, long ldb
     CCD_CHECK(P1 > 0 && Q1 > 0 && P2 > 0 && Q2 > 0 && Mc >= 0, CCD_EINVAL);
     if (Mc == 0) return CCD_OK;
     CCD_CHECK(lda1 % 8 == 0 && ldb1 % 8 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && ldc1 % 4 == 0 && ldc2 % 4 == 0, CCD_ESHAPE);
-    if (ccd_policy().gemm_tn384 && ccd_policy().gemm_tn384 != 2 && ccd_tn384_fits(P1, Q1, Mc) && ccd_tn384_fits(P2, Q2, Mc)) {
+    if (ccd_policy().gemm_tn384 && ccd_policy().gemm_tn384 != 2 && ccd_tn384_geom(P1, Q1, Mc) >= 0 &&
+        ccd_tn384_geom(P1, Q1, Mc) == ccd_tn384_geom(P2, Q2, Mc)) {
         const int rc = ccd_launch_tn384(A1, lda1, B1, ldb1, P1, Q1, C1, ldc1, A2, lda2, B2, ldb2, P2, Q2, C2, ldc2, Mc, 1.0f, nullptr, stream);
         if (rc != CCD_ESHAPE) return rc;
     }
@@ -468,7 +477,8 @@ static int ccd_gemm_tn_impl(const ccd_bf16* A, long lda, const ccd_bf16* B, long
     CCD_CHECK(P % 8 == 0 && Q % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, CCD_ESHAPE);
     CCD_CHECK(epilogue == CCD_EPI_ATOMIC || epilogue == CCD_EPI_F32, CCD_EINVAL);
     if (ccd_policy().gemm_tn384 && epilogue == CCD_EPI_ATOMIC && !d_rows && (!colsum_a || (ccd_policy().lab & 4)) &&
-        ccd_tn384_fits(P, Q, Mc) && ccd_tn384_tiles(P, Q) >= ccd_policy().gemm_tn384_min_tiles * (ccd_policy().gemm_tn384_geom == 1 ? 2 : 1)) {
+        ccd_tn384_geom(P, Q, Mc) >= 0 &&
+        ccd_tn384_tiles(ccd_tn384_geom(P, Q, Mc), P, Q) >= ccd_policy().gemm_tn384_min_tiles * (ccd_policy().gemm_tn384_geom == 1 ? 2 : 1)) {
         const int rc = ccd_launch_tn384(A, lda, B, ldb, P, Q, C, ldc, nullptr, 0, nullptr, 0, 0, 0, nullptr, 0, Mc, alpha, colsum_a, stream);
         if (rc != CCD_ESHAPE) return rc;
     }

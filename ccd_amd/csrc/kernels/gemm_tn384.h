@@ -31,24 +31,28 @@ namespace ccd {
 constexpr int TN3_BK = 32;                                   // contraction rows per stage
 // Geometry of a workgroup: WM x WN waves of 96 x 96 outputs, STAGES LDS buffers (STAGES - 1 stages of DMA in flight).
 //   <4, 2, 4>: 384 x 192 tile, 8 waves, 4 x 36 KiB, one workgroup per CU
+//   <4, 2, 3, 4, 2>: 512 x 128 tile (128 x 64 per wave), 8 waves, 3 x 40 KiB: the E = 512 shapes (vit_base: 1536 / 512 / 2048 x 512,
+//              512 x 2048), which 384 x 192 tiles do not divide.  MEASURED on vit_base (B = 128, 65536 rows): 44.6 against 44.3 ms per step
+//              with the 128-square kernel - opt-in (policy gemm_tn384_geom = 2), tested
 //   <2, 2, 3>: 192 x 192 tile, 4 waves, 3 x 24 KiB, TWO workgroups per CU: the waves of one workgroup run in lockstep (one
 //              barrier per stage: ~950 of a stage's 2.4 k cycles are barrier skew, the cold LDS reads behind it and the DMA wait),
 //              a second, independent workgroup could fill those gaps - for 33 % more DMA bytes per flop.  MEASURED: no gain
 //              (MLP pair 0.333 vs 0.327 ms, attention pair 0.188 vs 0.190; 56.7 vs 54.3 ms per step): kept as policy
 //              gemm_tn384_geom = 1, tested, not the default
-template <int WM, int WN, int STAGES_>
+template <int WM, int WN, int STAGES_, int TI_ = 3, int TJ_ = 3>
 struct Tn3Geom {
-    static constexpr int WAVES = WM * WN, THREADS = 64 * WAVES, STAGES = STAGES_;
-    static constexpr int TP = 96 * WM, TQ = 96 * WN;
+    static constexpr int WAVES = WM * WN, THREADS = 64 * WAVES, STAGES = STAGES_, TI = TI_, TJ = TJ_;   // TI x TJ MFMA tiles per wave
+    static constexpr int TP = 32 * TI * WM, TQ = 32 * TJ * WN;
     static constexpr int A_ROWB = TP * 2, B_ROWB = TQ * 2;
     static constexpr int A_BYTES = TN3_BK * A_ROWB, B_BYTES = TN3_BK * B_ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int SMEM_BYTES = STAGES * STAGE_BYTES;
-    static constexpr int A_PIECES = A_BYTES / 1024 / WAVES;                  // 1-KiB DMA pieces per wave and stage (3)
-    static constexpr int B_TOTAL = B_BYTES / 1024;                          // B pieces per stage: 12
-    static constexpr int B_PIECES = (B_TOTAL + WAVES - 1) / WAVES;          // per wave: 2 (the second only in waves 0-3) or 3
+    static constexpr int A_PIECES = A_BYTES / 1024 / WAVES;                  // 1-KiB DMA pieces per wave and stage (3 or 4)
+    static constexpr int B_TOTAL = B_BYTES / 1024;                          // B pieces per stage: 12 (8)
+    static constexpr int B_PIECES = (B_TOTAL + WAVES - 1) / WAVES;          // per wave: 2 (the second only in waves 0-3), 3 or 1
     static constexpr int B_FULL = B_TOTAL - (B_PIECES - 1) * WAVES;         // waves that own a last B piece
     static constexpr int PER_STAGE = A_PIECES + B_PIECES;
-    static_assert(A_BYTES % (1024 * WAVES) == 0 && A_PIECES + B_PIECES == 5 + (WAVES == 4 ? 1 : 0), "piece schedule below");
+    static_assert((TI == 3 && TJ == 3) || (TI == 4 && TJ == 2), "the two hand-scheduled stage bodies below");
+    static_assert(A_BYTES % (1024 * WAVES) == 0 && (PER_STAGE == 5 || PER_STAGE == 6), "piece schedule below");
 };
 // 16-byte chunk swizzle of an image whose rows are ROWB bytes: the four rows of one transposing read must fall on four
 // different 64-byte bank groups (rows 0 mod 256 apart: all four collide; 128 mod 256: rows r and r + 2 collide)
@@ -66,9 +70,9 @@ __device__ __forceinline__ int tn3_swz(int row) {
 // tiles, then units2[x] groups of the second's; the k-th group of a problem (counted over the XCDs) works on its slice k.  The two
 // problems' groups are placed independently, so an XCD with 31 usable slots (one CU reserved for the collectives) still holds
 // three groups of 8 (the host alternates 2 + 1 and 1 + 2) instead of one pair of 16.
-template <int WM, int WN, int STAGES>
+template <int WM, int WN, int STAGES, int TI = 3, int TJ = 3>
 __global__ __launch_bounds__(64 * WM * WN, 8 / (WM * WN)) void gemm_tn384_kernel(GemmParams p) {
-    using G = Tn3Geom<WM, WN, STAGES>;
+    using G = Tn3Geom<WM, WN, STAGES, TI, TJ>;
     constexpr int AHEAD = STAGES - 1;                        // stages of DMA in flight
     char* smem = dynamic_smem();
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, hf = lane >> 5, lq = lane & 31;
@@ -160,22 +164,27 @@ __global__ __launch_bounds__(64 * WM * WN, 8 / (WM * WN)) void gemm_tn384_kernel
 
     // ---- fragment addresses (see the header): lane (j = lane & 15, half-row group g16, hf)
     const int j = lane & 15, g16 = (lane >> 4) & 1, r4 = j >> 2, c4 = j & 3;
-    unsigned base_a[3], base_b[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    unsigned base_a[TI], base_b[TJ];
+    {
         const int row = 8 * hf + r4;
-        const int chunk_a = 12 * wm + 4 * i + 2 * g16 + (c4 >> 1);
-        base_a[i] = (unsigned)(row * G::A_ROWB + ((chunk_a ^ tn3_swz<G::A_ROWB>(row)) << 4) + (c4 & 1) * 8);
-        const int chunk_b = 12 * wn + 4 * i + 2 * g16 + (c4 >> 1);
-        base_b[i] = (unsigned)(G::A_BYTES + row * G::B_ROWB + ((chunk_b ^ tn3_swz<G::B_ROWB>(row)) << 4) + (c4 & 1) * 8);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int chunk_a = 4 * TI * wm + 4 * i + 2 * g16 + (c4 >> 1);
+            base_a[i] = (unsigned)(row * G::A_ROWB + ((chunk_a ^ tn3_swz<G::A_ROWB>(row)) << 4) + (c4 & 1) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < TJ; ++i) {
+            const int chunk_b = 4 * TJ * wn + 4 * i + 2 * g16 + (c4 >> 1);
+            base_b[i] = (unsigned)(G::A_BYTES + row * G::B_ROWB + ((chunk_b ^ tn3_swz<G::B_ROWB>(row)) << 4) + (c4 & 1) * 8);
+        }
     }
 
     const unsigned smem_addr = lds_addr_of(smem);
-    f32x16 acc[3][3];
+    f32x16 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 3; ++jj)
+        for (int jj = 0; jj < TJ; ++jj)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
@@ -199,8 +208,8 @@ __global__ __launch_bounds__(64 * WM * WN, 8 / (WM * WN)) void gemm_tn384_kernel
         // k-step 0, then the same of k-step 1 issued between the MFMA rows of k-step 0; every wait names the youngest fragment
         // its MFMAs need and the number of reads issued behind it.
         const unsigned sb = smem_addr + (unsigned)((kt % STAGES) * G::STAGE_BYTES);
-        const unsigned aa0 = sb + base_a[0], aa1 = sb + base_a[1], aa2 = sb + base_a[2];
-        const unsigned ab0 = sb + base_b[0], ab1 = sb + base_b[1], ab2 = sb + base_b[2];
+        const unsigned aa0 = sb + base_a[0], aa1 = sb + base_a[1], aa2 = sb + base_a[2], aa3 = sb + base_a[TI - 1];
+        const unsigned ab0 = sb + base_b[0], ab1 = sb + base_b[1], ab2 = sb + base_b[TJ - 1];
         tr_u32x2 x[2][6][2];                                  // [k-step][a0 b0 b1 b2 a1 a2][rows 0-3 / 4-7]
 #define TN3_RD_A(ks, slot, addr)                                                     \
         lds_read_tr<(16 * ks) * G::A_ROWB>(x[ks][slot][0], addr);                       \
@@ -209,6 +218,7 @@ __global__ __launch_bounds__(64 * WM * WN, 8 / (WM * WN)) void gemm_tn384_kernel
         lds_read_tr<(16 * ks) * G::B_ROWB>(x[ks][slot][0], addr);                       \
         lds_read_tr<(16 * ks + 4) * G::B_ROWB>(x[ks][slot][1], addr);
 #define TN3_FRAG(ks, slot) frag_from_tr(x[ks][slot][0], x[ks][slot][1])
+        if constexpr (TI == 3) {
         TN3_RD_A(0, 0, aa0) TN3_RD_B(0, 1, ab0) TN3_RD_B(0, 2, ab1) TN3_RD_B(0, 3, ab2) TN3_RD_A(0, 4, aa1) TN3_RD_A(0, 5, aa2)
         bf16x8 a0 = TN3_FRAG(0, 0), b0 = TN3_FRAG(0, 1), b1 = TN3_FRAG(0, 2), b2 = TN3_FRAG(0, 3), a1 = TN3_FRAG(0, 4), a2 = TN3_FRAG(0, 5);
         lds_wait_frag<8>(b0);
@@ -259,6 +269,57 @@ __global__ __launch_bounds__(64 * WM * WN, 8 / (WM * WN)) void gemm_tn384_kernel
         acc[2][0] = mfma_32x32x16_bf16(a2, b0, acc[2][0]);
         acc[2][1] = mfma_32x32x16_bf16(a2, b1, acc[2][1]);
         acc[2][2] = mfma_32x32x16_bf16(a2, b2, acc[2][2]);
+        } else {
+        // 4 x 2 tiles per wave: group order a0 b0 | b1 a1 | a2 a3
+        TN3_RD_A(0, 0, aa0) TN3_RD_B(0, 1, ab0) TN3_RD_B(0, 2, ab1) TN3_RD_A(0, 3, aa1) TN3_RD_A(0, 4, aa2) TN3_RD_A(0, 5, aa3)
+        bf16x8 a0 = TN3_FRAG(0, 0), b0 = TN3_FRAG(0, 1), b1 = TN3_FRAG(0, 2), a1 = TN3_FRAG(0, 3), a2 = TN3_FRAG(0, 4), a3 = TN3_FRAG(0, 5);
+        lds_wait_frag<8>(b0);
+        TN3_STAMP(1)
+        acc[0][0] = mfma_32x32x16_bf16(a0, b0, acc[0][0]);
+        lds_wait_frag<6>(b1);
+        acc[0][1] = mfma_32x32x16_bf16(a0, b1, acc[0][1]);
+        CCD_SCHED_FENCE();
+        if (more) dma_piece(kt + AHEAD, 0);
+        CCD_SCHED_FENCE();
+        TN3_RD_A(1, 0, aa0) TN3_RD_B(1, 1, ab0)
+        lds_wait_frag<8>(a1);                                // (4 of k-step 0 + 4 of k-step 1 behind it)
+        acc[1][0] = mfma_32x32x16_bf16(a1, b0, acc[1][0]);
+        acc[1][1] = mfma_32x32x16_bf16(a1, b1, acc[1][1]);
+        CCD_SCHED_FENCE();
+        if (more) dma_piece(kt + AHEAD, 1);
+        CCD_SCHED_FENCE();
+        TN3_RD_B(1, 2, ab1) TN3_RD_A(1, 3, aa1)
+        lds_wait_frag<10>(a2);
+        acc[2][0] = mfma_32x32x16_bf16(a2, b0, acc[2][0]);
+        acc[2][1] = mfma_32x32x16_bf16(a2, b1, acc[2][1]);
+        CCD_SCHED_FENCE();
+        if (more) dma_piece(kt + AHEAD, 2);
+        CCD_SCHED_FENCE();
+        TN3_RD_A(1, 4, aa2) TN3_RD_A(1, 5, aa3)
+        lds_wait_frag<12>(a3);
+        acc[3][0] = mfma_32x32x16_bf16(a3, b0, acc[3][0]);
+        acc[3][1] = mfma_32x32x16_bf16(a3, b1, acc[3][1]);
+        a0 = TN3_FRAG(1, 0); b0 = TN3_FRAG(1, 1); b1 = TN3_FRAG(1, 2); a1 = TN3_FRAG(1, 3); a2 = TN3_FRAG(1, 4); a3 = TN3_FRAG(1, 5);
+        lds_wait_frag<8>(b0);
+        acc[0][0] = mfma_32x32x16_bf16(a0, b0, acc[0][0]);
+        lds_wait_frag<6>(b1);
+        acc[0][1] = mfma_32x32x16_bf16(a0, b1, acc[0][1]);
+        CCD_SCHED_FENCE();
+        if (more) dma_piece(kt + AHEAD, 3);
+        CCD_SCHED_FENCE();
+        lds_wait_frag<4>(a1);
+        acc[1][0] = mfma_32x32x16_bf16(a1, b0, acc[1][0]);
+        acc[1][1] = mfma_32x32x16_bf16(a1, b1, acc[1][1]);
+        CCD_SCHED_FENCE();
+        if (more) dma_piece(kt + AHEAD, 4);
+        CCD_SCHED_FENCE();
+        lds_wait_frag<2>(a2);
+        acc[2][0] = mfma_32x32x16_bf16(a2, b0, acc[2][0]);
+        acc[2][1] = mfma_32x32x16_bf16(a2, b1, acc[2][1]);
+        lds_wait_frag<0>(a3);
+        acc[3][0] = mfma_32x32x16_bf16(a3, b0, acc[3][0]);
+        acc[3][1] = mfma_32x32x16_bf16(a3, b1, acc[3][1]);
+        }
 #undef TN3_RD_A
 #undef TN3_RD_B
 #undef TN3_FRAG
@@ -287,10 +348,10 @@ __global__ __launch_bounds__(64 * WM * WN, 8 / (WM * WN)) void gemm_tn384_kernel
     // (Rotating the order of the 3 x 3 sub-tiles by the slice number, so that concurrent slices add onto different cache lines,
     // changed nothing - 0.1914 vs 0.1905 ms: the epilogue is bound by the L2's atomic throughput, not by same-line contention.)
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 3; ++jj) {
-            float* cp = C + (long)(p0 + 96 * wm + 32 * i + 4 * hf) * p.ldc + (q0 + 96 * wn + 32 * jj + lq);
+        for (int jj = 0; jj < TJ; ++jj) {
+            float* cp = C + (long)(p0 + 32 * TI * wm + 32 * i + 4 * hf) * p.ldc + (q0 + 32 * TJ * wn + 32 * jj + lq);
 #pragma unroll
             for (int r = 0; r < 16; ++r) atomicAdd(cp + (long)((r & 3) + 8 * (r >> 2)) * p.ldc, acc[i][jj][r] * p.alpha);
         }

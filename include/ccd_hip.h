@@ -46,7 +46,7 @@ const char* ccd_build_info(void);
  *   attn_tr    1 (default): dK / dV kernel on double-buffered LDS-DMA row images with transposing LDS reads; 0: four register-staged images
  *   gemm_tn384 1 (default): ViT weight gradients (P % 384 == 0, Q % 192 == 0) on the XCD-grouped kernel of gemm_tn384.h, 0: 128-square
  *              kernel, 2: never as a pair;  gemm_tn384_min_tiles (6): smallest single product it takes;  gemm_tn384_geom 1: 192x192 tiles,
- *              two 4-wave workgroups per CU (tested, slower)
+ *              two 4-wave workgroups per CU (tested, slower), 2: also 512x128 tiles for the E = 512 shapes (tested, no gain)
  *   cu_reserve compute units the persistent grids leave free (set while an RCCL gradient reducer is attached)
  *   cu_reserve_window -1 (default): every launch leaves them free; N >= 0: only the next cu_reserve_left launches do - the
  *              gradient reducer sets cu_reserve_left = N whenever it starts a bucket's all-reduce (ccd_amd/parallel.py)

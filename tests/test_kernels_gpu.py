@@ -39,11 +39,16 @@ def test_gemm_tn(hip, Mc, P, Q, splits):
 
 
 @pytest.mark.parametrize("Mc,shape1,shape2", [(8192, (384, 1536), (1536, 384)), (4096 + 64, (384, 384), (1152, 384)),
+                                              (8192 + 32, (512, 2048), (2048, 512)), (65536, (512, 512), (1536, 512)),
                                               (131072, (384, 384), (1152, 384)), (600, (136, 72), (384, 192))])
 def test_gemm_tn_pair(hip, Mc, shape1, shape2):
     """ccd_gemm_tn_pair: the MLP pair and the attention pair in gemm_tn384.h's grouped launch (16 / 8 tiles per contraction slice,
-    ragged slices, the full 131072 rows of the benchmark batch), and the two-call fallback."""
+    ragged slices, the full 131072 rows of the benchmark batch), the E = 512 pairs (two-call fallback by default, 512 x 128 tiles
+    with gemm_tn384_geom = 2), and the two-call fallback for other shapes."""
+    from ccd_amd import ops
     kc.check_gemm_tn_pair(hip.device, Mc, shape1, shape2)
+    with ops.policy(gemm_tn384_geom=2):
+        kc.check_gemm_tn_pair(hip.device, Mc, shape1, shape2, seed=15)
 
 
 def test_gemm_tn_pair_reserved_cus(hip):

@@ -48,6 +48,18 @@ def test_gemm_tn_pair_sim(sim, monkeypatch):
         kc.check_gemm_tn(sim.device, Mc=2048, P=192, Q=192, seed=8)
 
 
+def test_gemm_tn512_sim(sim, monkeypatch):
+    """gemm_tn384.h with 512 x 128 tiles (4 x 2 MFMA tiles per wave, 3 LDS buffers): the shapes 384 x 192 tiles do not divide
+    (vit_base, E = 512) - one tile; a pair of 1 + 2 tiles; 2 x 2 tiles with ragged slices."""
+    from ccd_amd import ops
+    with ops.policy(gemm_tn384_geom=2, gemm_tn384_min_tiles=1):
+        monkeypatch.setenv("CCD_SIM_CUS", "4")
+        kc.check_gemm_tn(sim.device, Mc=2048 + 64, P=512, Q=128, seed=21)
+        kc.check_gemm_tn_pair(sim.device, 2048, (512, 128), (512, 256), seed=22)
+        monkeypatch.setenv("CCD_SIM_CUS", "8")
+        kc.check_gemm_tn(sim.device, Mc=2048 + 32, P=1024, Q=256, seed=23)
+
+
 def test_gemm_tn384_sim(sim, monkeypatch):
     """gemm_tn384.h (LDS-DMA image + transposing LDS reads): one workgroup with 67 stages; 4 ragged slices of 17 / 16 stages;
     two tiles per group and two groups; 16 workgroups spread over 8 'XCDs' (2 groups of one tile each, 4 stages)."""
