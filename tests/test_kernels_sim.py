@@ -42,6 +42,9 @@ def test_gemm_tn_pair_sim(sim, monkeypatch):
     monkeypatch.setenv("CCD_SIM_CUS", "4")
     kc.check_gemm_tn_pair(sim.device, 2048, (384, 192), (384, 384))
     kc.check_gemm_tn_pair(sim.device, 320, (136, 72), (8, 264), seed=6)
+    monkeypatch.setenv("CCD_SIM_CUS", "16")    # 8 "XCDs" x 2 slots: the XCDs hold different numbers of groups of either problem
+    kc.check_gemm_tn_pair(sim.device, 2048 + 32, (384, 192), (384, 384), seed=16)
+    monkeypatch.setenv("CCD_SIM_CUS", "4")
     from ccd_amd import ops
     with ops.policy(gemm_tn384_geom=1):     # 192 x 192 tiles, 4 waves, two workgroups per CU: 2 + 4 tiles on 8 slots; 3 LDS buffers
         kc.check_gemm_tn_pair(sim.device, 2048 + 64, (384, 192), (384, 384), seed=7)
