@@ -33,8 +33,11 @@ class GradReducer:
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         self._works.append((dist.all_reduce(buf, op=op, group=self.pg, async_op=True), lo, hi))
         if self.reserve_window > 0 and buf.device.type == "cuda":
+            # the kernels launched next run beside this collective: they leave `cu_reserve` CUs free - `reserve_window` launches
+            # per bucket-size worth of gradients (the 16.8 M-element head range is one 67-MB all-reduce: three windows)
             from . import ops
-            ops.policy_set("cu_reserve_left", self.reserve_window)
+            scale = max(1, -(-(hi - lo) // self.bucket_elems))
+            ops.policy_set("cu_reserve_left", self.reserve_window * scale)
 
     def mark_ready(self, prefix):
         """All gradients of parameters named `prefix`* are final: reduce the range (merged into buckets)."""
