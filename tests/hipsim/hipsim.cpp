@@ -57,6 +57,9 @@ static void stack_put(std::vector<void*>& v) {
 static void lane_entry() {
     Lane* l = cur;
     (*l->blk->body)();
+    for (const Lane::PendingDma& d : l->dma)         // (late-DMA mode: whatever a kernel left in flight)
+        if (d.bytes) std::memcpy(d.dst, d.src, (size_t)d.bytes);
+    l->dma.clear();
     l->done = true;
     Block* b = l->blk;
     WaveState& w = b->waves[l->wave];

@@ -50,6 +50,9 @@ struct Lane {
     unsigned wait_gen = 0;
     Block* blk = nullptr;
     void* stack = nullptr;
+    // LDS-DMA requests of this lane that have not been retired by a counted wait yet (late mode, see glds16 below)
+    struct PendingDma { char* dst; const void* src; int bytes; };
+    std::vector<PendingDma> dma;
 };
 struct WaveState {
     int alive = 0, arrived = 0;
@@ -102,7 +105,18 @@ void launch(dim3 grid, dim3 block, size_t dyn_smem, const std::function<void()>&
 #define blockIdx (sim::curblk->bid)
 #define blockDim (sim::curblk->bdim)
 #define gridDim (sim::curblk->gdim)
-inline void __syncthreads() { sim::block_sync(); }
+inline bool sim_dma_late() {
+    static const bool late = [] { const char* v = getenv("CCD_SIM_DMA"); return v && v[0] == 'l'; }();
+    return late;
+}
+inline void sim_dma_retire(size_t leave) {
+    auto& q = sim::cur->dma;
+    const size_t n = q.size() > leave ? q.size() - leave : 0;
+    for (size_t i = 0; i < n; ++i)
+        if (q[i].bytes) std::memcpy(q[i].dst, q[i].src, (size_t)q[i].bytes);
+    q.erase(q.begin(), q.begin() + (long)n);
+}
+inline void __syncthreads() { sim_dma_retire(0); sim::block_sync(); }      // (the compiler drains vmcnt in front of s_barrier)
 
 // ------------------------------------------------------------------------------------------- atomics
 template <typename T>
@@ -136,11 +150,27 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 inline char* dynamic_smem() { return sim::curblk->dyn_smem; }
 // LDS-DMA (prelude_hip.h): the executor copies synchronously, lane by lane
-inline void glds16(const void* gptr, char* lds_base) { std::memcpy(lds_base + 16 * sim::cur->lane, gptr, 16); }
-inline void glds4(const void* gptr, char* lds_base) { std::memcpy(lds_base + 4 * sim::cur->lane, gptr, 4); }
-inline void glds_wait_all() {}
+// LDS-DMA (prelude_hip.h).  Two models of WHEN the bytes land, selected by CCD_SIM_DMA:
+//   early (default): at issue, lane by lane - the earliest the hardware could deliver them: a DMA into a buffer that other waves
+//                    still read shows up as wrong results;
+//   late:            only when a counted wait of the issuing lane retires the request (`glds_wait<N>` leaves the N youngest in
+//                    flight, in issue order; every lane runs the same instruction stream, so the per-lane queue is the wave's
+//                    vmcnt) - the latest the hardware may deliver them: a fragment read in front of a sufficient wait sees stale
+//                    LDS.  Loads that return to registers (vmem_pad_load) are NOT counted, i.e. they are modelled as returning at
+//                    once: a wait window that relies on such loads to keep its count is too lax here, as it was on the GPU.
+inline void glds16(const void* gptr, char* lds_base) {
+    char* dst = lds_base + 16 * sim::cur->lane;
+    if (::sim_dma_late()) sim::cur->dma.push_back({dst, gptr, 16});
+    else std::memcpy(dst, gptr, 16);
+}
+inline void glds4(const void* gptr, char* lds_base) {
+    char* dst = lds_base + 4 * sim::cur->lane;
+    if (::sim_dma_late()) sim::cur->dma.push_back({dst, gptr, 4});
+    else std::memcpy(dst, gptr, 4);
+}
+inline void glds_wait_all() { ::sim_dma_retire(0); }
 template <int N>
-inline void glds_wait() {}
+inline void glds_wait() { ::sim_dma_retire((size_t)N); }
 inline unsigned opaque_u32(unsigned x) { return x; }
 inline int opaque_vgpr(int x) { return x; }
 inline float opaque_f32(float x) { return x; }
@@ -178,7 +208,7 @@ inline void lds_landed(float&, float&) {}
 inline void lds_drain() {}
 template <int P>
 inline void wave_prio() {}
-inline void lds_barrier() { __syncthreads(); }
+inline void lds_barrier() { sim::block_sync(); }                           // LDS-only barrier: an LDS-DMA in flight spans it
 // buffer addressing: out-of-range lanes read zeros (prelude_hip.h)
 typedef __attribute__((ext_vector_type(4))) unsigned buf_u32x4;
 template <int OFF>
@@ -192,12 +222,17 @@ inline bf16x8 frag_from_tr(tr_u32x2 lo, tr_u32x2 hi) {
 struct buf_rsrc { const char* base; unsigned bytes; };
 constexpr unsigned BUF_OOB = 0x80000000u;
 inline buf_rsrc make_rsrc(const void* base, unsigned bytes) { return buf_rsrc{reinterpret_cast<const char*>(base), bytes}; }
+// (late-DMA mode: a buffer load of real data keeps its place in the lane's in-order queue - its data is here at once, but a
+// counted wait still has to get past it - while vmem_pad_load, out of range by construction, holds no place: see glds16)
+inline void sim_vmem_slot() { if (::sim_dma_late()) sim::cur->dma.push_back({nullptr, nullptr, 0}); }
 inline buf_u32x4 buf_load16(buf_rsrc r, unsigned byte_offset) {
+    sim_vmem_slot();
     buf_u32x4 v = {0u, 0u, 0u, 0u};
     if ((unsigned long long)byte_offset + 16ull <= (unsigned long long)r.bytes) std::memcpy(&v, r.base + byte_offset, 16);
     return v;
 }
 inline buf_u32x4 buf_load16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset) {
+    sim_vmem_slot();
     const unsigned long long o = (unsigned long long)lane_offset + uniform_offset;
     buf_u32x4 v = {0u, 0u, 0u, 0u};
     if (o + 16ull <= (unsigned long long)r.bytes) std::memcpy(&v, r.base + o, 16);
