@@ -48,3 +48,19 @@ def test_finetune_fused_mlp_sim(sim, monkeypatch):
 def _run_fused(sim):
     mc.check_finetune_against_oracle(sim.device, arch="vit_test128", vit_kw=dict(embed_dim=128, depth=2, heads=2), B=2,
                                      max_seq_len=25, steps=2, decode=False)
+
+
+def test_training_iterations_under_late_dma_model():
+    """One pretraining and one finetune iteration with the executor delivering LDS-DMA data as late as the hardware may
+    (CCD_SIM_DMA=late, see tests/test_kernels_sim.py::test_kernels_under_late_dma_model): every default kernel's counted waits
+    inside whole forward / backward passes."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("CCD_SIM_DMA", "").startswith("l"):
+        return
+    env = dict(os.environ, CCD_SIM_DMA="late")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider", "-k",
+                        "tiny_training_iteration or finetune_against_oracle"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
