@@ -65,6 +65,27 @@ def test_gemm_tn512_sim(sim, monkeypatch):
         kc.check_gemm_tn(sim.device, Mc=2048 + 32, P=1024, Q=256, seed=23)
 
 
+def test_gemm_tn_pair_placements_sim(sim, monkeypatch):
+    """Seeded sweep over the grouped launch's host-side placement: chip sizes that do / do not split into 8 'XCDs', reserved
+    compute units, one or two problems of 1-3 x 1-2 tiles, ragged contraction lengths - every (problem, tile, slice) must be
+    covered exactly once whatever is left of an XCD's slots."""
+    import random
+    from ccd_amd import ops
+    rng = random.Random(7)
+    for case in range(8):
+        cus = rng.choice([1, 3, 4, 8, 9, 16, 17, 24])
+        reserve = rng.choice([0, 0, 1])
+        monkeypatch.setenv("CCD_SIM_CUS", str(cus))
+        shape1 = (384 * rng.choice([1, 2, 3]), 192 * rng.choice([1, 2]))
+        shape2 = (384 * rng.choice([1, 2]), 192 * rng.choice([1, 2]))
+        mc = 2048 + 32 * rng.randrange(0, 8)
+        with ops.policy(cu_reserve=min(reserve, cus - 1), gemm_tn384_min_tiles=1):
+            if rng.random() < 0.7:
+                kc.check_gemm_tn_pair(sim.device, mc, shape1, shape2, seed=30 + case)
+            else:
+                kc.check_gemm_tn(sim.device, Mc=mc, P=shape1[0], Q=shape1[1], seed=30 + case)
+
+
 def test_gemm_tn384_sim(sim, monkeypatch):
     """gemm_tn384.h (LDS-DMA image + transposing LDS reads): one workgroup with 67 stages; 4 ragged slices of 17 / 16 stages;
     two tiles per group and two groups; 16 workgroups spread over 8 'XCDs' (2 groups of one tile each, 4 stages)."""
