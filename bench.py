@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """bench.py - images/sec of the CCD-ViT-Small pretraining step (BASELINE.json metric) on N MI355X of one node.
 
-    python bench.py --gpus 1 --steps K --warmup W                      (single GPU)
+    python bench.py --gpus N --steps K --warmup W       (N > 1 without a launcher: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+The line carries `rccl_ranks` (the size of the group RCCL formed), the RCCL version and every rank's device / row count M,
+gathered through the communicator: proof of how many ranks really ran.
 
 One "step" = the full iteration of train.py:221-272 on a resident synthetic batch: student fwd
 (2 views), teacher fwd, seg + DINO loss, centre update, backward, per-tensor clip, AdamW, teacher EMA.  bf16 MFMA
@@ -25,6 +27,29 @@ PEAK_BF16_TF = 2500.0       # MI355X dense bf16 MFMA peak (guide: MI355X_MICROAR
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (~6.3 TB/s achievable)
 GF_PER_IMAGE = {"vit_small": (96.7 + 8.7, 44.56e-3 * 4), "vit_base": (167.6 + 10.1, 45.09e-3 * 4),
                 "vit_tiny": (25.6 + 6.6, 43.9e-3 * 4)}   # (backbone+seg GF/img, head GF per selected row pair) SURVEY 8d
+
+
+# timer kind (ccd_amd/ops.py spans) -> the kernel(s) of ccd_amd/csrc/kernels that the launches of that kind run at the default policy
+KIND_KERNEL = {
+    "mlp_fused": "ccd::mlp_fused_kernel<E, store_u> (mlp_fused.h)",
+    "gemm_nt_lnbwd": "ccd::rowgemm_kernel<E, ring, RG_LNBWD> (rowgemm.h)",
+    "gemm_nt_resid": "ccd::gemm_row384_kernel<EPI_RESID_LN> (gemm_row384.h) / gemm_bf16_kernel<NT, EPI_RESID> (gemm.h)",
+    "gemm_nt_bf16": "ccd::gemm256_kernel<EPI_BF16> (gemm256.h) / gemm_bf16_kernel<NT, EPI_BF16> (gemm.h)",
+    "gemm_nt_gelu": "ccd::gemm256_kernel<EPI_GELU> (gemm256.h)",
+    "gemm_nt_dgelu": "ccd::gemm256_kernel<EPI_DGELU> (gemm256.h)",
+    "gemm_nt_f32": "ccd::gemm256_kernel<EPI_F32> (gemm256.h) / gemm_bf16_kernel<NT, EPI_F32> (gemm.h)",
+    "gemm_nt_atomic": "ccd::gemm_bf16_kernel<NT, EPI_ATOMIC> (gemm.h)",
+    "gemm_tn_atomic": "ccd::gemm_tn384_kernel<4, 2, 4> (gemm_tn384.h) / gemm_bf16_kernel<TN, EPI_ATOMIC> (gemm.h)",
+    "gemm_tn_f32": "ccd::gemm_bf16_kernel<TN, EPI_F32> (gemm.h)",
+    "conv_gemm": "ccd::gemm_bf16_kernel<NT, epi, GATHER> (gemm.h, implicit-GEMM convolutions)",
+    "conv_wgrad": "ccd::gemm_bf16_kernel<TN, EPI_ATOMIC, GATHER> (gemm.h)",
+    "attention_fwd": "ccd::attention_fwd_kernel (attention_fwd.h)",
+    "attention_bwd": "ccd::attention_bwd_dq_kernel + ccd::attention_bwd_dkv_tr_kernel (attention_bwd.h)",
+    "layernorm_fwd": "ccd::ln_fwd_kernel (layernorm.h)",
+    "layernorm_bwd": "ccd::ln_bwd_kernel (layernorm.h)",
+    "dino_loss_fwd": "ccd::dino_loss_fwd_kernel (loss.h)",
+    "dino_loss_bwd": "ccd::dino_loss_bwd_kernel (loss.h)",
+}
 
 
 def cpu_baseline(arch, steps=2):
@@ -159,6 +184,7 @@ def main_finetune(a, world, rank, dev, use_dist):
     elapsed = t.item()
     final_loss = loss.item()
     assert final_loss == final_loss and abs(final_loss) < 1e4, f"non-finite loss {final_loss}"
+    census = rank_census(world, rank, dev, 25 * B)
     if rank == 0:
         ms = elapsed / a.steps * 1e3
         ips = B * world * a.steps / elapsed
@@ -178,6 +204,7 @@ def main_finetune(a, world, rank, dev, use_dist):
                            "global_batch": B * world, "parallelism": f"dp{world}", "gflop_per_image": round(gf_img, 1),
                            "step_frac_of_mfma_peak": round(ips / world * gf_img / 1e3 / PEAK_BF16_TF, 4),
                            "final_loss": round(final_loss, 4)}}
+        line.update(census)
         if timer is not None:
             summ = timer.summary()
             key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
@@ -186,7 +213,7 @@ def main_finetune(a, world, rank, dev, use_dist):
             gbs = d["bytes"] / d["launches"] / avg_ms / 1e6
             intensity = d["flops"] / max(d["bytes"], 1.0)
             hbm_bound = intensity < PEAK_BF16_TF * 1e12 / (PEAK_HBM_GBS * 1e9)
-            line["roofline"] = {"bound": "hbm" if hbm_bound else "mfma", "kernel": f"GEMM kind {key}",
+            line["roofline"] = {"bound": "hbm" if hbm_bound else "mfma", "kernel": KIND_KERNEL.get(key, key), "kind": key,
                                 "achieved": round(gbs if hbm_bound else tflops, 1),
                                 "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TF,
                                 "unit": "GB/s" if hbm_bound else "TFLOP/s",
@@ -238,6 +265,7 @@ def main_recognize(a, world, rank, dev, use_dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
     assert tuple(probs.shape) == (B, 25, 92) and bool(torch.isfinite(probs).all())
+    census = rank_census(world, rank, dev, 25 * B)
     if rank == 0:
         line = {"metric": "images/sec (32x128 crops) CCD text recognition, greedy decoding (25 steps)",
                 "value": round(B * world * a.steps / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
@@ -246,10 +274,63 @@ def main_recognize(a, world, rank, dev, use_dist):
                 "config": {"workload": f"DINO_Finetune.forward_test {a.arch} bf16, bs={B}/GPU, 6-layer NRTR decoder, 25 greedy "
                                        f"steps, HIP graph {'on' if os.environ.get('CCD_DECODE_GRAPH', '1') != '0' else 'off'}",
                            "global_batch": B * world, "parallelism": f"replicas x{world}"}}
+        line.update(census)
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
         emit(line)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-execute this command under torch.distributed.run with one rank per GPU
+    (what README.md:33 of the reference does with `torch.distributed.launch`), rendezvous on 127.0.0.1 and an OS-chosen port.
+    The JSON line is printed by rank 0 of the child job; this process only forwards the exit code."""
+    import socket
+    import subprocess
+    if os.environ.get("BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < n:
+        sys.exit(f"bench.py: --gpus {n} but this node exposes {torch.cuda.device_count()} GPU(s)")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def rank_census(world, rank, dev, rows):
+    """What the collective library itself saw: the size of the group, its version, and every rank's (device, selected rows M)
+    gathered THROUGH it - evidence in the JSON line that N ranks really joined one RCCL communicator."""
+    info = {"rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1}
+    if dist.is_initialized():
+        mine = torch.tensor([rank, dev.index if dev.type == "cuda" else -1, int(rows)], dtype=torch.int64, device=dev)
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        info["ranks"] = [{"rank": int(t[0]), "device": int(t[1]), "rows_M": int(t[2])} for t in got]
+        if dist.get_backend() == "nccl":
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    return info
+
+
+def rendezvous_dry_run(a, world, rank):
+    """BENCH_BACKEND=gloo: no GPU work - the ranks the launcher started join ONE process group, run the barrier / max-over-ranks
+    timing skeleton of the real bench and rank 0 prints the census.  Exists so that the N-rank launch path of this file is
+    exercised in the GPU-less build container (tests/test_bench_cli.py); it never produces a throughput number."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    dist.barrier()
+    t0 = time.perf_counter()
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    census = rank_census(world, rank, dev, rows=100 + rank)
+    dist.destroy_process_group()
+    if rank == 0:
+        emit({"dry_run": True, "backend": "gloo", "n_gpus": world, "gpus_arg": a.gpus, **census})
 
 
 def main():
@@ -269,13 +350,22 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(a.gpus)               # `python bench.py --gpus N`: become the launcher of N ranks of this command
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = os.environ.get("BENCH_BACKEND", "nccl")       # "gloo": rendezvous dry run without GPUs (tests/test_bench_cli.py)
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"      # the latter: 1-rank RCCL smoke of the N>1 path
+    if backend == "gloo":
+        return rendezvous_dry_run(a, world, rank)
+    if torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: --gpus {world} but this node exposes {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"      # the latter: 1-rank RCCL smoke of the N>1 path
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -344,13 +434,16 @@ def main():
     final_loss = loss.item()
     assert final_loss == final_loss and abs(final_loss) < 1e4, f"non-finite loss {final_loss}"
 
+    # every rank: its selected-row count M (ranks hold different batches, so M differs), gathered through the collective library
+    from ccd_amd import engine
+    ids = ops.ccl_label(masks)
+    m_local = int(engine.Selection(torch.cat([ids, ops.warp_idmap(ids, metrics)]), B).M)
+    census = rank_census(world, rank, dev, m_local)
     if rank == 0:
         ms = elapsed / a.steps * 1e3
         ips = B * world * a.steps / elapsed
         # whole-step MFMA fraction: SURVEY 8(d) FLOP table with the measured rows-per-image of this batch
-        from ccd_amd import engine
-        ids = ops.ccl_label(masks)
-        m_rows = engine.Selection(torch.cat([ids, ops.warp_idmap(ids, metrics)]), B).M / B
+        m_rows = m_local / B
         body, per_row = GF_PER_IMAGE.get(a.arch, GF_PER_IMAGE["vit_small"])
         gf_img = body + per_row * 2 * m_rows
         arch_name = {"vit_small": "CCD-ViT-Small", "vit_base": "CCD-ViT-Base", "vit_tiny": "CCD-ViT-Tiny"}.get(a.arch, a.arch)
@@ -366,6 +459,7 @@ def main():
                            "rows_per_image_per_view": round(m_rows, 3), "gflop_per_image": round(gf_img, 1),
                            "step_frac_of_mfma_peak": round(ips / world * gf_img / 1e3 / PEAK_BF16_TF, 4),
                            "final_loss": round(final_loss, 4)}}
+        line.update(census)
         if timer is not None:
             summ = timer.summary()
             key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])          # the GEMM kind with the largest total time
@@ -377,7 +471,7 @@ def main():
             intensity = d["flops"] / max(d["bytes"], 1.0)
             hbm_bound = intensity < ridge
             line["roofline"] = {"bound": "hbm" if hbm_bound else "mfma",
-                                "kernel": f"ccd::gemm_bf16_kernel / gemm256_kernel / gemm_row384_kernel ({key})",
+                                "kernel": KIND_KERNEL.get(key, key), "kind": key,
                                 "achieved": round(gbs if hbm_bound else tflops, 1),
                                 "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TF,
                                 "unit": "GB/s" if hbm_bound else "TFLOP/s",
@@ -391,11 +485,17 @@ def main():
                                 "avg_launch_ms": round(avg_ms, 4), "launches_per_step": d["launches"] // a.steps,
                                 }
             table, per = (warm_summary, 1) if warm_summary else (summ, a.steps)
+            for k, v in table.items():      # the loss kernels are launched for the worst case 2 * 26 * B rows and read M on the device
+                if k.startswith("dino_loss"):
+                    live = 2.0 * m_local / (2 * 26 * B)
+                    v["flops"], v["bytes"] = v["flops"] * live, v["bytes"] * live
             line["roofline"].update({
-                "by_kind_source": "last warm-up step (every GEMM launch timed)" if warm_summary else "timed region",
-                "gemm_ms_per_step": round(sum(v["ms"] for v in table.values()) / per, 3),
+                "by_kind_source": "last warm-up step (every GEMM / attention / LayerNorm / loss launch timed)" if warm_summary else "timed region",
+                "timed_ms_per_step": round(sum(v["ms"] for v in table.values()) / per, 3),
+                "gemm_ms_per_step": round(sum(v["ms"] for k, v in table.items() if k.startswith(("gemm", "mlp", "conv"))) / per, 3),
                 "by_kind_ms_per_step": {k: round(v["ms"] / per, 3) for k, v in sorted(table.items())},
-                "by_kind_tflops": {k: round(v["flops"] / v["ms"] / 1e9, 1) for k, v in sorted(table.items())}})
+                "by_kind_tflops": {k: round(v["flops"] / v["ms"] / 1e9, 1) for k, v in sorted(table.items())},
+                "by_kind_algorithmic_gbs": {k: round(v["bytes"] / v["ms"] / 1e6, 1) for k, v in sorted(table.items())}})
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.arch)
     if use_dist:

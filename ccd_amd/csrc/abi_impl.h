@@ -11,7 +11,6 @@
 #include "kernels/mlp_fused.h"
 #include "kernels/rowgemm.h"
 #include "kernels/gemm_tn384.h"
-#include "kernels/rowgemm16.h"
 #include "kernels/layernorm.h"
 #include "kernels/attention_fwd.h"
 #include "kernels/attention_bwd.h"
@@ -86,11 +85,10 @@ struct CcdPolicy {
     int rowgemm = 1;            // row-owner kernels (rowgemm.h) for the N in {128, 256, 384} row-wise epilogues; 0 = gemm_row384.h
     int ln_bwd_bpc = 5;         // LayerNorm backward: blocks per CU (one resident wave; more blocks = more dgamma/dbeta atomics)
     int dec_attn_simt = 0;      // decoder attention: force the general SIMT kernels
-    int attn_fused = 0;         // attention backward: 1 = dQ and dK/dV in one kernel (reads q, k, v, dO, O once; measured 0.407 vs 0.377 ms)
     int attn_tr = 1;            // attention backward dK/dV: double-buffered LDS-DMA row images + ds_read_b64_tr_b16 (0 = four register-staged images)
     int attn_skew = 0;          // attention backward: waves 4..7 start each block ~skew * 64 cycles late (lab; no effect once clocks are warm)
     int gemm_tn384 = 1;         // weight gradients with P % 384 == 0, Q % 192 == 0: XCD-grouped 384x192 LDS-DMA kernel (gemm_tn384.h); 0 = 128-square kernel, 2 = never as a pair
-    int gemm_tn384_geom = 0;    // its workgroup: 0 = 384x192 tile, 8 waves, one per CU; 1 = 192x192 tile, 4 waves, two per CU; 2 = 0 + 512x128 tiles for the shapes 384x192 does not divide (E = 512)
+    int gemm_tn384_geom = 0;    // its workgroup: 0 = 384x192 tile, 8 waves, one per CU; 2 = 0 + 512x128 tiles for the shapes 384x192 does not divide (E = 512)
     int gemm_tn384_min_tiles = 6;   // ... for a SINGLE product only from this many tiles on (proj, 2 tiles = 128 slices: the atomic epilogue dominates)
     int cu_reserve = 0;         // compute units the persistent grids leave free (set while an RCCL gradient reducer is attached)
     int cu_reserve_window = -1; // -1: every launch leaves them free; N >= 0: only the next `cu_reserve_left` launches do (the reducer
@@ -102,7 +100,7 @@ static const CcdPolicyKey ccd_policy_keys[] = {
     {"gemm_256", &CcdPolicy::gemm_256}, {"gemm_256_min_m", &CcdPolicy::gemm_256_min_m},
     {"gemm_256_min_n", &CcdPolicy::gemm_256_min_n}, {"gemm_256_f32", &CcdPolicy::gemm_256_f32},
     {"gemm_256_deep", &CcdPolicy::gemm_256_deep}, {"gemm_row384", &CcdPolicy::gemm_row384},
-    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_fused", &CcdPolicy::attn_fused}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"lab", &CcdPolicy::lab}};
+    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"lab", &CcdPolicy::lab}};
 static CcdPolicy& ccd_policy() {
     static CcdPolicy pol = [] {
         CcdPolicy q;
@@ -149,9 +147,10 @@ static int ccd_launch_gemm256(const ccd::GemmParams& p, int epilogue, void* stre
     return ccd_rt_last_error();
 }
 // full-row kernel for N <= 384 (gemm_row384.h): one workgroup per CU
-static int ccd_launch_gemm_row384(const ccd::GemmParams& p, int epilogue, void* stream) {
+// `cus`: the caller's ccd_grid_cus() when it already asked (one launch consumes ONE slot of the cu_reserve window), -1 otherwise
+static int ccd_launch_gemm_row384(const ccd::GemmParams& p, int epilogue, void* stream, int cus = -1) {
     const int tiles = (p.M + ccd::GR_BM - 1) / ccd::GR_BM;
-    const int cus = ccd_grid_cus();
+    if (cus < 0) cus = ccd_grid_cus();
     const dim3 grid(tiles < cus ? tiles : cus), block(ccd::GR_THREADS);
     const size_t smem = ccd::GR_SMEM_BYTES;
     switch (epilogue) {
@@ -309,7 +308,7 @@ int ccd_gemm_nt_resid_ln(const ccd_bf16* A, long lda, const ccd_bf16* B, long ld
     p.rps_shift = -1;
     for (int sft = 0; sft < 31; ++sft) if ((1 << sft) == rows_per_sample) p.rps_shift = sft;
     p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_eps = ln_eps; p.ln_y = y; p.ld_y = ldy; p.ln_mean = mean; p.ln_rstd = rstd;
-    return ccd_launch_gemm_row384(p, 7 /* EPI_RESID_LN */, stream);
+    return ccd_launch_gemm_row384(p, 7 /* EPI_RESID_LN */, stream, cus);
 }
 
 int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, const float* x, long ldx,
@@ -336,27 +335,6 @@ int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, 
         q.ldr = q.ldc = q.ld_y = 0; q.ln_eps = 0.f;
         const int tiles = (M + ccd::RG_BM - 1) / ccd::RG_BM, smem = ccd::rg_smem_bytes(N);
         const dim3 grid(tiles < cus ? tiles : cus), block(ccd::RG_THREADS);
-        // N = 384, policy rowgemm = 4: two independent 64-row workgroups per CU (rowgemm16.h).  With warmed-up clocks it is 3 %
-        // SLOWER than the 128-row kernel (0.306 / 0.272 vs 0.297 / 0.266 ms at K = 1536 / 1152, 131072 rows; gemm_row384.h:
-        // 0.324 / 0.314) - it is kept as the tested record of that experiment, not as the default
-        if (ccd_policy().rowgemm == 4 && N == 384 && K % 192 == 0) {
-            const int tiles16 = (M + ccd::RG16_BM - 1) / ccd::RG16_BM;
-            const dim3 grid16(tiles16 < 2 * cus ? tiles16 : 2 * cus), block16(ccd::RG16_THREADS);
-            q.lab = ccd_policy().lab;
-            CCD_LAUNCH((ccd::rowgemm16_lnbwd_kernel<384, 3, 6>), grid16, block16, ccd::rg16_smem_bytes(384), stream, q);
-            return ccd_rt_last_error();
-        }
-        if (ccd_policy().rowgemm == 3 && N == 384 && K % 384 == 0) {
-            const int tiles16 = (M + ccd::RG16_BM - 1) / ccd::RG16_BM;
-            const dim3 grid16(tiles16 < 2 * cus ? tiles16 : 2 * cus), block16(ccd::RG16_THREADS);
-            const int lab = ccd_policy().lab;
-            q.lab = 0;
-            if (lab == 4) CCD_LAUNCH((ccd::rowgemm16_lnbwd_kernel<384, 6, 4>), grid16, block16, ccd::rg16_smem_bytes(384), stream, q);
-            else if (lab == 8) CCD_LAUNCH((ccd::rowgemm16_lnbwd_kernel<384, 6, 8>), grid16, block16, ccd::rg16_smem_bytes(384), stream, q);
-            else if (lab == 3) CCD_LAUNCH((ccd::rowgemm16_lnbwd_kernel<384, 3, 6>), grid16, block16, ccd::rg16_smem_bytes(384), stream, q);
-            else CCD_LAUNCH((ccd::rowgemm16_lnbwd_kernel<384, 6>), grid16, block16, ccd::rg16_smem_bytes(384), stream, q);
-            return ccd_rt_last_error();
-        }
         if (N == 512) CCD_LAUNCH((ccd::rowgemm_kernel<512, ccd::rg_ring(512), ccd::RG_LNBWD>), grid, block, smem, stream, q);
         else if (N == 384) CCD_LAUNCH((ccd::rowgemm_kernel<384, ccd::rg_ring(384), ccd::RG_LNBWD>), grid, block, smem, stream, q);
         else if (N == 256) CCD_LAUNCH((ccd::rowgemm_kernel<256, ccd::rg_ring(256), ccd::RG_LNBWD>), grid, block, smem, stream, q);
@@ -372,7 +350,7 @@ int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, 
     for (int sft = 0; sft < 31; ++sft) if ((1 << sft) == p.rows_per_sample) p.rps_shift = sft;
     p.ln_gamma = gamma; p.ln_mean = const_cast<float*>(mean); p.ln_rstd = const_cast<float*>(rstd);
     p.lnb_accumulate = accumulate; p.lnb_gb = gb; p.ld_gb = ldgb; p.lnb_dgamma = dgamma; p.lnb_dbeta = dbeta; p.lnb_dbias = dbias;
-    return ccd_launch_gemm_row384(p, 8 /* EPI_LNBWD */, stream);
+    return ccd_launch_gemm_row384(p, 8 /* EPI_LNBWD */, stream, cus);
 }
 
 int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, const float* b1, const ccd_bf16* w2, long ld2,
@@ -416,17 +394,16 @@ static int ccd_gemm_tn_impl(const ccd_bf16* A, long lda, const ccd_bf16* B, long
                             long ldc, float alpha, int splits, const int* d_rows, int rows_mul, float* colsum_a, void* stream);
 // gemm_tn384.h: one group of (P / TP) (Q / TQ) [+ the second problem's] workgroups per contraction slice, whole groups per XCD
 // (workgroup b runs on XCD b % 8).  CCD_ESHAPE: the tiles of one slice do not fit the grid - the caller takes another kernel.
-// workgroup geometry for a P x Q product: 0 = 384 x 192 tiles, 2 = 512 x 128 (the E = 512 shapes), 1 = 192 x 192 x two per CU (policy
-// gemm_tn384_geom = 1 only); -1 = none of them divides the shape
+// workgroup geometry for a P x Q product: 0 = 384 x 192 tiles, 2 = 512 x 128 (the E = 512 shapes, policy gemm_tn384_geom = 2);
+// -1 = neither divides the shape
 static int ccd_tn384_geom(int P, int Q, int Mc) {
     if (Mc % ccd::TN3_BK != 0 || Mc < 2048) return -1;
-    if (ccd_policy().gemm_tn384_geom == 1) return P % 192 == 0 && Q % 192 == 0 ? 1 : -1;
     if (P % 384 == 0 && Q % 192 == 0) return 0;
     if (ccd_policy().gemm_tn384_geom == 2 && P % 512 == 0 && Q % 128 == 0) return 2;    // (measured on vit_base: 44.6 vs 44.3 ms - opt-in)
     return -1;
 }
 static int ccd_tn384_tiles(int geom, int P, int Q) {
-    return geom == 0 ? (P / 384) * (Q / 192) : geom == 2 ? (P / 512) * (Q / 128) : (P / 192) * (Q / 192);
+    return geom == 0 ? (P / 384) * (Q / 192) : (P / 512) * (Q / 128);
 }
 static int ccd_launch_tn384(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P, int Q, float* C, long ldc,
                             const ccd_bf16* A2, long lda2, const ccd_bf16* B2, long ldb2, int P2, int Q2, float* C2, long ldc2,
@@ -437,7 +414,6 @@ static int ccd_launch_tn384(const ccd_bf16* A, long lda, const ccd_bf16* B, long
     p.alpha = alpha; p.rps_shift = ccd_policy().lab; p.colsum_a = lab_out;
     const int geom = ccd_tn384_geom(P, Q, Mc);
     if (geom < 0 || (P2 > 0 && ccd_tn384_geom(P2, Q2, Mc) != geom)) return CCD_ESHAPE;
-    if (geom == 1) return ccd_launch_tn384_geom<2, 2, 3, 3, 3>(p, Mc, stream);
     if (geom == 2) return ccd_launch_tn384_geom<4, 2, 3, 4, 2>(p, Mc, stream);
     return ccd_launch_tn384_geom<4, 2, 4, 3, 3>(p, Mc, stream);
 }
@@ -478,7 +454,7 @@ static int ccd_gemm_tn_impl(const ccd_bf16* A, long lda, const ccd_bf16* B, long
     CCD_CHECK(epilogue == CCD_EPI_ATOMIC || epilogue == CCD_EPI_F32, CCD_EINVAL);
     if (ccd_policy().gemm_tn384 && epilogue == CCD_EPI_ATOMIC && !d_rows && (!colsum_a || (ccd_policy().lab & 4)) &&
         ccd_tn384_geom(P, Q, Mc) >= 0 &&
-        ccd_tn384_tiles(ccd_tn384_geom(P, Q, Mc), P, Q) >= ccd_policy().gemm_tn384_min_tiles * (ccd_policy().gemm_tn384_geom == 1 ? 2 : 1)) {
+        ccd_tn384_tiles(ccd_tn384_geom(P, Q, Mc), P, Q) >= ccd_policy().gemm_tn384_min_tiles) {
         const int rc = ccd_launch_tn384(A, lda, B, ldb, P, Q, C, ldc, nullptr, 0, nullptr, 0, 0, 0, nullptr, 0, Mc, alpha, colsum_a, stream);
         if (rc != CCD_ESHAPE) return rc;
     }
@@ -550,11 +526,6 @@ int ccd_attention_bwd(const ccd_bf16* qkv, const ccd_bf16* out, const ccd_bf16* 
     CCD_CHECK(views > 0 && heads > 0, CCD_EINVAL);
     const int nblocks = views * heads;                      // persistent: one workgroup per CU walks the (view, head) blocks
     const int cus = ccd_rt_num_cus();
-    if (ccd_policy().attn_fused) {          // both passes in one kernel: q, k, v, dO, O read once (attention_bwd.h)
-        CCD_LAUNCH(ccd::attention_bwd_fused_kernel, dim3(nblocks < cus ? nblocks : cus), dim3(512), ccd::ATTB_DKV_SMEM, stream,
-                   qkv, out, d_out, lse, d_qkv, heads, scale, nblocks, ccd_policy().attn_skew);
-        return ccd_rt_last_error();
-    }
     CCD_LAUNCH(ccd::attention_bwd_dq_kernel, dim3(nblocks < cus ? nblocks : cus), dim3(512), ccd::ATTB_DQ_SMEM, stream, qkv,
                out, d_out, lse, delta_ws, d_qkv, heads, scale, nblocks, ccd_policy().attn_skew);
     if (ccd_policy().attn_tr)               // dK / dV on the double-buffered LDS-DMA image with transposing LDS reads

@@ -521,176 +521,5 @@ __global__ __launch_bounds__(512) void attention_bwd_dkv_tr_kernel(const bf16_t*
     }
 }
 
-// ---- both passes in ONE kernel: q, k, v, dO, O of a block are read once (0.8 GB per layer instead of 1.2).  Pass A is the dQ
-// kernel's body (K, V, K^T images; a lane owns a query); its lanes then keep their q / dO rows and lse / delta, write them
-// to LDS as the Q / dO row images of pass B (whose transposed images are rebuilt from those, LDS to LDS), the key / value
-// operands of pass B are read out of pass A's K / V images before they are overwritten.  Pass B is the dK/dV kernel's body.
-__global__ __launch_bounds__(512) void attention_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
-                                                                  const bf16_t* __restrict__ d_o,
-                                                                  const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
-                                                                  int heads, float scale, int nblocks, int skew) {
-    char* smem = dynamic_smem();
-    char* img0 = smem;                       // pass A: K rows    pass B: Q rows
-    char* img1 = smem + ATTB_IMG;            //         V rows            dO rows
-    char* img2 = smem + 2 * ATTB_IMG;        //         K^T               Q^T
-    char* img3 = smem + 3 * ATTB_IMG;        //         -                 dO^T
-    float* lse_s = reinterpret_cast<float*>(smem + 4 * ATTB_IMG);
-    float* del_s = lse_s + ATT_T;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hf = lane >> 5, lq = lane & 31;
-    const int E = heads * ATT_D;
-    const long rs3 = 3L * E;
-    const int q = 32 * w + lq;               // this lane's query in pass A and its key in pass B
-    AttbRows vr, ktr;
-    u32x4 qw[4], dw[4], ow[4];
-    float lse_n = 0.f;
-    auto request = [&](int blk) {
-        const int view = blk / heads, head = blk % heads;
-        const bf16_t* q_base = qkv + (long)view * ATT_T * rs3 + head * ATT_D;
-        attb_load_rows(q_base + 2 * E, rs3, vr);
-        attb_load_transposed(q_base + E, rs3, ktr);
-        const long orow = ((long)view * ATT_T + q) * E + head * ATT_D;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            qw[kk] = *reinterpret_cast<const u32x4*>(q_base + (long)q * rs3 + 16 * kk + 8 * hf);
-            dw[kk] = *reinterpret_cast<const u32x4*>(d_o + orow + 16 * kk + 8 * hf);
-            ow[kk] = *reinterpret_cast<const u32x4*>(o + orow + 16 * kk + 8 * hf);
-        }
-        lse_n = lse[((long)view * heads + head) * ATT_T + q];
-    };
-    int blk = blockIdx.x;
-    if (blk < nblocks) request(blk);
-    for (; blk < nblocks; blk += gridDim.x) {
-        const int view = blk / heads, head = blk % heads;
-        // ------------------------------------------------------------------ pass A: dQ
-        attb_store_rows_of_transposed(ktr, img0);
-        attb_store_rows(vr, img1);
-        attb_store_transposed(ktr, img2);
-        bf16x8 qf[4], dof[4];
-        float dsum = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            qf[kk] = __builtin_bit_cast(bf16x8, qw[kk]);
-            dof[kk] = __builtin_bit_cast(bf16x8, dw[kk]);
-            float a[8], b[8];
-            unpack8(dw[kk], a);
-            unpack8(ow[kk], b);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dsum += a[e] * b[e];
-        }
-        dsum += shfl_xor(dsum, 32);
-        const float my_lse = lse_n;
-        if (hf == 0) { lse_s[q] = my_lse; del_s[q] = dsum; }
-        __syncthreads();
-        attb_skew(w, skew);
-        {
-            f32x16 dq[2];
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
-#pragma unroll 1
-            for (int kt = 0; kt < 8; ++kt) {
-                f32x16 s, dp;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-                const int row = 32 * kt + lq;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    s = mfma_32x32x16_bf16(attb_row_frag(img0, row, kk, hf), qf[kk], s);
-                    dp = mfma_32x32x16_bf16(attb_row_frag(img1, row, kk, hf), dof[kk], dp);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pr = fast_exp2(fmaf(s[r], scale * 1.4426950408889634f, -my_lse * 1.4426950408889634f));
-                    s[r] = pr * (dp[r] - dsum) * scale;
-                }
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    bf16x8 dsf;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) dsf[e] = (short)f2bf(s[8 * s2 + e]);
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt)
-                        dq[dt] = mfma_32x32x16_bf16(attb_tr_frag(img2, 32 * dt + lq, 2 * kt + s2, hf), dsf, dq[dt]);
-                }
-            }
-            attb_store_t(dqkv + ((long)view * ATT_T + q) * rs3 + head * ATT_D, dq, hf);
-        }
-        // ------------------------------------------------------------------ hand-over: pass B's operands
-        bf16x8 kf[4], vf[4];                 // this lane's KEY row and VALUE row (key index = q), out of pass A's images
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            kf[kk] = attb_row_frag(img0, q, kk, hf);
-            vf[kk] = attb_row_frag(img1, q, kk, hf);
-        }
-        __syncthreads();                     // every wave is done with K / V / K^T
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {     // the Q / dO row images from the rows the lanes hold
-            *reinterpret_cast<bf16x8*>(img0 + q * 128 + (((2 * kk + hf) ^ ((q >> 1) & 7)) * 16)) = qf[kk];
-            *reinterpret_cast<bf16x8*>(img1 + q * 128 + (((2 * kk + hf) ^ ((q >> 1) & 7)) * 16)) = dof[kk];
-        }
-        __syncthreads();
-        {                                    // transposed images, LDS to LDS (the loader's 4 rows x 8 columns per thread)
-            const int kb = 16 * (w & 3) + (lane & 15), db = (lane >> 4) + 4 * (w >> 2);
-            AttbRows tq, td;
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq) {
-                const int row = 4 * kb + kq;
-                tq.r[kq] = *reinterpret_cast<const u32x4*>(img0 + row * 128 + ((db ^ ((row >> 1) & 7)) * 16));
-                td.r[kq] = *reinterpret_cast<const u32x4*>(img1 + row * 128 + ((db ^ ((row >> 1) & 7)) * 16));
-            }
-            attb_store_transposed(tq, img2);
-            attb_store_transposed(td, img3);
-        }
-        __syncthreads();
-        if (blk + (int)gridDim.x < nblocks) request(blk + gridDim.x);      // flies under pass B
-        attb_skew(w, skew);
-        // ------------------------------------------------------------------ pass B: dK, dV
-        {
-            f32x16 dk[2], dv[2];
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
-#pragma unroll 1
-            for (int qt = 0; qt < 8; ++qt) {
-                f32x16 s, dp;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-                const int row = 32 * qt + lq;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    s = mfma_32x32x16_bf16(attb_row_frag(img0, row, kk, hf), kf[kk], s);
-                    dp = mfma_32x32x16_bf16(attb_row_frag(img1, row, kk, hf), vf[kk], dp);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int qq = 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                    const float pr = fast_exp2(fmaf(s[r], scale * 1.4426950408889634f, -lse_s[qq] * 1.4426950408889634f));
-                    s[r] = pr;
-                    dp[r] = pr * (dp[r] - del_s[qq]) * scale;
-                }
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    bf16x8 pf, dsf;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        pf[e] = (short)f2bf(s[8 * s2 + e]);
-                        dsf[e] = (short)f2bf(dp[8 * s2 + e]);
-                    }
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        dv[dt] = mfma_32x32x16_bf16(attb_tr_frag(img3, 32 * dt + lq, 2 * qt + s2, hf), pf, dv[dt]);
-                        dk[dt] = mfma_32x32x16_bf16(attb_tr_frag(img2, 32 * dt + lq, 2 * qt + s2, hf), dsf, dk[dt]);
-                    }
-                }
-            }
-            bf16_t* drow = dqkv + ((long)view * ATT_T + q) * rs3 + head * ATT_D;
-            attb_store_t(drow + E, dk, hf);
-            attb_store_t(drow + 2 * E, dv, hf);
-        }
-        __syncthreads();                     // the images are rewritten by the next block
-    }
-}
 
 }  // namespace ccd

@@ -34,11 +34,8 @@ constexpr int TN3_BK = 32;                                   // contraction rows
 //   <4, 2, 3, 4, 2>: 512 x 128 tile (128 x 64 per wave), 8 waves, 3 x 40 KiB: the E = 512 shapes (vit_base: 1536 / 512 / 2048 x 512,
 //              512 x 2048), which 384 x 192 tiles do not divide.  MEASURED on vit_base (B = 128, 65536 rows): 44.6 against 44.3 ms per step
 //              with the 128-square kernel - opt-in (policy gemm_tn384_geom = 2), tested
-//   <2, 2, 3>: 192 x 192 tile, 4 waves, 3 x 24 KiB, TWO workgroups per CU: the waves of one workgroup run in lockstep (one
-//              barrier per stage: ~950 of a stage's 2.4 k cycles are barrier skew, the cold LDS reads behind it and the DMA wait),
-//              a second, independent workgroup could fill those gaps - for 33 % more DMA bytes per flop.  MEASURED: no gain
-//              (MLP pair 0.333 vs 0.327 ms, attention pair 0.188 vs 0.190; 56.7 vs 54.3 ms per step): kept as policy
-//              gemm_tn384_geom = 1, tested, not the default
+//   (a 192 x 192 tile with two 4-wave workgroups per CU was measured in round 2 - MLP pair 0.333 vs 0.327 ms, 56.7 vs 54.3 ms per
+//   step - and removed from the product in round 3)
 template <int WM, int WN, int STAGES_, int TI_ = 3, int TJ_ = 3>
 struct Tn3Geom {
     static constexpr int WAVES = WM * WN, THREADS = 64 * WAVES, STAGES = STAGES_, TI = TI_, TJ = TJ_;   // TI x TJ MFMA tiles per wave

@@ -34,6 +34,27 @@ class VitSpec:
         return self._keep[device]
 
 
+def _env_switch(key):
+    return None if os.environ.get(key) is None else os.environ[key] != "0"
+
+
+class Fusion:
+    """Which fused row-owner kernels the backbone uses.  Read ONCE at import from CCD_FUSE_LN / CCD_FUSE_MLP / CCD_FUSE_LNBWD /
+    CCD_SIDE_STREAM (lab switches; None = the measured default for the embedding width); tests and lab scripts may assign the
+    attributes.  Nothing on the forward / backward path reads the environment."""
+    ln = _env_switch("CCD_FUSE_LN")                # LayerNorm in the epilogue of proj / fc2   (default: E <= 384)
+    mlp = _env_switch("CCD_FUSE_MLP")              # fc1 -> GELU -> fc2 -> residual -> LayerNorm in one launch (default: with `ln`)
+    lnbwd = _env_switch("CCD_FUSE_LNBWD")          # LayerNorm backward in the epilogue of the data-gradient product (default: on)
+    side_stream = bool(_env_switch("CCD_SIDE_STREAM"))
+
+    @classmethod
+    def resolve(cls, E):
+        ln = (cls.ln if cls.ln is not None else E <= 384) and (E <= 384 or E == 512)
+        mlp = ln and E % 128 == 0 and (cls.mlp if cls.mlp is not None else True)
+        lnbwd = (E <= 384 or E == 512) and E % 8 == 0 and (cls.lnbwd if cls.lnbwd is not None else True)
+        return ln, mlp, lnbwd
+
+
 _DROPPATH_SEED = {"base": None, "calls": 0}
 
 
@@ -104,11 +125,10 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
     # (E = 512 - vit_base: the row-owner kernels exist (`CCD_FUSE_LN=1` forces them) but lose there - 256 accumulator registers
     # per lane leave a 3-slot weight ring and spills: 51.9 ms per step against 47.0 with only the LayerNorm-backward product
     # fused, 47.3 unfused; B = 128, one MI355X)
-    fuse_ln = os.environ.get("CCD_FUSE_LN", "1" if E <= 384 else "0") != "0" and (E <= 384 or E == 512)
+    fuse_ln, fuse_mlp, _ = Fusion.resolve(E)
     # the whole MLP branch in one kernel (csrc/kernels/mlp_fused.h): the hidden activation never reaches HBM; when
     # activations are saved only the bf16 pre-activation u is stored and backward re-derives gelu(u) in the epilogue
     # that already reads u (ccd_gemm_nt, EPI_DGELU with a second output)
-    fuse_mlp = fuse_ln and E % 128 == 0 and os.environ.get("CCD_FUSE_MLP", "1") != "0"
     pending = None                               # (y, mean, rstd) of the coming norm1, made by the previous fc2
     # DropPath: per-(block, branch, sample) keep mask / keep_prob (vision_transformer.py:27-35), one kernel per pass
     scales = ops.droppath_scales(spec.keep_probs(dev), N, _next_droppath_seed()) if training and max(spec.dpr) > 0.0 else None
@@ -182,8 +202,7 @@ class _SideStream:
     _streams = {}
 
     def __init__(self, device):
-        import os
-        self.on = device.type == "cuda" and os.environ.get("CCD_SIDE_STREAM", "0") == "1"
+        self.on = device.type == "cuda" and Fusion.side_stream
         if self.on:
             key = device.index if device.index is not None else torch.cuda.current_device()
             if key not in _SideStream._streams:
@@ -241,7 +260,7 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
         return dict(gb=gb, rowscale=ctxs[i].ds2, rows_per_sample=256, dbias=arena.g(f"{pre}blocks.{i}.mlp.fc2.bias"))
 
     # LayerNorm backward folded into the epilogue of the data-gradient product in front of it (ccd_gemm_nt_lnbwd, N <= 384 or 512)
-    fuse_lnbwd = (E <= 384 or E == 512) and E % 8 == 0 and os.environ.get("CCD_FUSE_LNBWD", "1") != "0"
+    fuse_lnbwd = Fusion.resolve(E)[2]
     side = _SideStream(dev)
     gb_reader = None            # event of the last side-stream product that reads gb (the next writer of gb waits for it)
     have_gb = False

@@ -39,7 +39,22 @@ class KernelTimer:
         return out
 
 
-TIMER = None     # set to a KernelTimer to time every GEMM launch
+TIMER = None     # set to a KernelTimer to time every GEMM / attention / LayerNorm / loss launch
+
+
+class _Span:
+    """with _Span(key, flops, algorithmic bytes): the launches inside are bracketed by HIP events when a KernelTimer is attached."""
+
+    def __init__(self, key, flops, nbytes):
+        self.ev = TIMER.span(key, flops, nbytes) if TIMER is not None else None
+
+    def __enter__(self):
+        if self.ev:
+            self.ev[0].record()
+
+    def __exit__(self, *a):
+        if self.ev:
+            self.ev[1].record()
 
 
 def policy_set(key, value):
@@ -256,8 +271,9 @@ def ln_fwd(x, gamma, beta, eps=1e-6):
     y = torch.empty((rows, E), dtype=BF16, device=x.device)
     mean = torch.empty(rows, dtype=F32, device=x.device)
     rstd = torch.empty(rows, dtype=F32, device=x.device)
-    _lib.check(_lib.get().ccd_ln_fwd(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y), _lib.ptr(mean),
-                                     _lib.ptr(rstd), rows, E, float(eps), _lib.stream()), "ln_fwd")
+    with _Span("layernorm_fwd", 8.0 * rows * E, 6.0 * rows * E):
+        _lib.check(_lib.get().ccd_ln_fwd(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y), _lib.ptr(mean),
+                                         _lib.ptr(rstd), rows, E, float(eps), _lib.stream()), "ln_fwd")
     return y, mean, rstd
 
 
@@ -266,10 +282,11 @@ def ln_bwd(dy, x, mean, rstd, gamma, g, dgamma, dbeta, accumulate=True, gb=None,
     """g (+)= LN'(dy); dgamma += , dbeta += (in place).  Optional fused tail: gb = bf16(g * rowscale), dbias += colsum(gb)."""
     _chk(dy, BF16, "dy"); _chk(x, F32, "x"); _chk(g, F32, "g"); _chk(gb, BF16, "gb")
     rows, E = x.shape
-    _lib.check(_lib.get().ccd_ln_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma),
-                                     _lib.ptr(g), 1 if accumulate else 0, _lib.ptr(dgamma), _lib.ptr(dbeta),
-                                     _lib.ptr(gb), _lib.ptr(rowscale), int(rows_per_sample), _lib.ptr(dbias), rows, E,
-                                     _lib.stream()), "ln_bwd")
+    with _Span("layernorm_bwd", 16.0 * rows * E, rows * E * ((14.0 if accumulate else 10.0) + (2.0 if gb is not None else 0.0))):
+        _lib.check(_lib.get().ccd_ln_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma),
+                                         _lib.ptr(g), 1 if accumulate else 0, _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                         _lib.ptr(gb), _lib.ptr(rowscale), int(rows_per_sample), _lib.ptr(dbias), rows, E,
+                                         _lib.stream()), "ln_bwd")
     return g
 
 
@@ -280,8 +297,10 @@ def attention_fwd(qkv, heads, scale):
     assert T == 256 and E3 == 3 * heads * 64 and qkv.is_contiguous()
     out = torch.empty((views, T, E3 // 3), dtype=BF16, device=qkv.device)
     lse = torch.empty((views, heads, T), dtype=F32, device=qkv.device)
-    _lib.check(_lib.get().ccd_attention_fwd(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(lse), views, heads, float(scale),
-                                            _lib.stream()), "attention_fwd")
+    # per (view, head): S = Q K^T and O = P V, 2 * 256 * 256 * 64 flop each; q, k, v read and o written once
+    with _Span("attention_fwd", views * heads * 4.0 * T * T * 64, views * heads * (4.0 * T * 64 * 2 + 4.0 * T)):
+        _lib.check(_lib.get().ccd_attention_fwd(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(lse), views, heads, float(scale),
+                                                _lib.stream()), "attention_fwd")
     return out, lse
 
 
@@ -291,9 +310,11 @@ def attention_bwd(qkv, out, d_out, lse, heads, scale):
     views = qkv.shape[0]
     d_qkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
-    _lib.check(_lib.get().ccd_attention_bwd(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(d_out), _lib.ptr(lse),
-                                            _lib.ptr(delta), _lib.ptr(d_qkv), views, heads, float(scale),
-                                            _lib.stream()), "attention_bwd")
+    # five products (S, dP, dV, dK, dQ) of 2 * 256 * 256 * 64 flop per (view, head); q, k, v, o, dO read and dq, dk, dv written once
+    with _Span("attention_bwd", views * heads * 10.0 * 256 * 256 * 64, views * heads * (8.0 * 256 * 64 * 2 + 8.0 * 256)):
+        _lib.check(_lib.get().ccd_attention_bwd(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(d_out), _lib.ptr(lse),
+                                                _lib.ptr(delta), _lib.ptr(d_qkv), views, heads, float(scale),
+                                                _lib.stream()), "attention_bwd")
     return d_qkv
 
 
@@ -489,16 +510,19 @@ def weightnorm_bwd(v, g, inv, dw, dv, dg):
 # ------------------------------------------------------------------------------------------ losses
 def dino_loss_fwd(s_logits, t_logits, center, d_m, student_temp, teacher_temp, stats, loss_out):
     max_rows, K = s_logits.shape
-    _call("ccd_dino_loss_fwd", _lib.ptr(s_logits), _lib.ptr(t_logits), _lib.ptr(center), K, _lib.ptr(d_m), max_rows,
-          float(student_temp), float(teacher_temp), _lib.ptr(stats), _lib.ptr(loss_out))
+    # (the kernels read the device-side row count M <= max_rows / 2; bytes are the worst case the launch is sized for)
+    with _Span("dino_loss_fwd", 12.0 * max_rows * K, 8.0 * max_rows * K):
+        _call("ccd_dino_loss_fwd", _lib.ptr(s_logits), _lib.ptr(t_logits), _lib.ptr(center), K, _lib.ptr(d_m), max_rows,
+              float(student_temp), float(teacher_temp), _lib.ptr(stats), _lib.ptr(loss_out))
 
 
 def dino_loss_bwd(s_logits, t_logits, center, d_m, student_temp, teacher_temp, stats, grad_scale, d_logits,
                   d_grad_scale=None):
     max_rows, K = s_logits.shape
-    _call("ccd_dino_loss_bwd", _lib.ptr(s_logits), _lib.ptr(t_logits), _lib.ptr(center), K, _lib.ptr(d_m), max_rows,
-          float(student_temp), float(teacher_temp), _lib.ptr(stats), float(grad_scale), _lib.ptr(d_grad_scale),
-          _lib.ptr(d_logits))
+    with _Span("dino_loss_bwd", 12.0 * max_rows * K, 10.0 * max_rows * K):
+        _call("ccd_dino_loss_bwd", _lib.ptr(s_logits), _lib.ptr(t_logits), _lib.ptr(center), K, _lib.ptr(d_m), max_rows,
+              float(student_temp), float(teacher_temp), _lib.ptr(stats), float(grad_scale), _lib.ptr(d_grad_scale),
+              _lib.ptr(d_logits))
 
 
 def colsum_f32(x, out, d_rows=None, rows_mul=1):

@@ -40,13 +40,11 @@ const char* ccd_build_info(void);
  *              1 (default): LayerNorm-backward product on rowgemm.h (N = 128, 256, 384, 512);
  *                 residual + LayerNorm on gemm_row384.h (N <= 384) / rowgemm.h (N = 512)
  *              2: rowgemm.h for both epilogues wherever its shapes allow (tests)
- *              3 / 4: rowgemm16.h (two 64-row workgroups per CU) with the 6- / 3-block ring (lab, N = 384)
- *   attn_fused 1: attention backward as one kernel (default 0: dQ kernel + dK/dV kernel)
  *   attn_skew  cycles / 64 by which waves 4..7 of the attention-backward kernels trail waves 0..3 (lab, default 0)
  *   attn_tr    1 (default): dK / dV kernel on double-buffered LDS-DMA row images with transposing LDS reads; 0: four register-staged images
  *   gemm_tn384 1 (default): ViT weight gradients (P % 384 == 0, Q % 192 == 0) on the XCD-grouped kernel of gemm_tn384.h, 0: 128-square
- *              kernel, 2: never as a pair;  gemm_tn384_min_tiles (6): smallest single product it takes;  gemm_tn384_geom 1: 192x192 tiles,
- *              two 4-wave workgroups per CU (tested, slower), 2: also 512x128 tiles for the E = 512 shapes (tested, no gain)
+ *              kernel, 2: never as a pair;  gemm_tn384_min_tiles (6): smallest single product it takes;  gemm_tn384_geom 2: also
+ *              512x128 tiles for the E = 512 shapes (tested, no gain)
  *   cu_reserve compute units the persistent grids leave free (set while an RCCL gradient reducer is attached)
  *   cu_reserve_window -1 (default): every launch leaves them free; N >= 0: only the next cu_reserve_left launches do - the
  *              gradient reducer sets cu_reserve_left = N whenever it starts a bucket's all-reduce (ccd_amd/parallel.py)

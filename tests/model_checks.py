@@ -218,75 +218,96 @@ def check_small_steps(device, loss_tol=1e-3):
 def check_small3_steps(device, loss_tol=1e-3):
     """Multi-iteration parity against the REAL reference (tests/golden/small3_step.npz): CCD_pretrain_ViT_small, B=8,
     head biases perturbed to non-zero values before the first step - so no pooled row enters F.normalize as an exact zero
-    vector and none of the reference's gradients is rounding residue times 1/eps - three consecutive iterations on the
-    dataset-mask branch and a fourth on the predicted-mask branch (epoch 30).  Distillation loss within 1e-3 at EVERY
-    iteration, index maps bit-exact, every gradient norm, no tensor excluded."""
+    vector and none of the reference's gradients is rounding residue times 1/eps - and the last layer of the segmentation
+    head fitted to the text masks (recorded in the fixture), so that the predicted-mask branch thresholds logits with real
+    margins.  One iteration on the predicted-mask branch (epoch 30, dino_vision.py:64-70) followed by three consecutive
+    iterations on the dataset-mask branch.  At EVERY iteration: distillation / mask / total loss within `loss_tol` (1e-3, the
+    north star's tolerance), the character-mask index map and `new_index` BIT-EXACT, every gradient norm within 8 %, no
+    tensor excluded.  On the predicted-mask branch the model's own bf16-path prediction must equal the reference's fp32
+    prediction pixel for pixel (flips would only be tolerated where the reference's margin is inside the measured logit
+    error - with this fixture there is no such pixel); the same iteration is also run with the reference's prediction
+    injected, which isolates everything behind the threshold."""
+    from ccd_amd import ops
     from ccd_amd.synthetic import make_text_like_batch
     g = np.load(os.path.join(GOLD, "small3_step.npz"))
-    torch.manual_seed(0)
-    np.random.seed(0)
-    student, teacher = pretrain.build_networks(arch="vit_small", out_dim=65536, drop_path_rate=0.0,
-                                               norm_last_layer=False, device=device)
-    gen = torch.Generator().manual_seed(int(g["perturb"][0]))
-    tsd = teacher.state_dict()
-    with torch.no_grad():
-        for k, v in student.state_dict().items():
-            if k.startswith("head.") and k.endswith(".bias"):
-                v.add_((float(g["perturb"][1]) * torch.randn(v.shape, generator=gen)).to(v.device))
-                tsd[k].copy_(v)
-    sd = student.state_dict()
-    for n, row in zip(g["init_names"], g["init_stats"]):
-        assert_init_stat(stat(sd[str(n)]), row, n)
-    dino_loss = DINOLoss(65536, 2, 0.04, 0.04, 0, 40).to(device)
-    opt = pretrain.make_optimizer(student, clip_grad=3.0)
-    report = {}
-    for step in range(4):
+
+    def build():
+        torch.manual_seed(0)
+        np.random.seed(0)
+        student, teacher = pretrain.build_networks(arch="vit_small", out_dim=65536, drop_path_rate=0.0,
+                                                   norm_last_layer=False, device=device)
+        gen = torch.Generator().manual_seed(int(g["perturb"][0]))
+        tsd = teacher.state_dict()
+        with torch.no_grad():
+            for k, v in student.state_dict().items():
+                if k.startswith("head.") and k.endswith(".bias"):
+                    v.add_((float(g["perturb"][1]) * torch.randn(v.shape, generator=gen)).to(v.device))
+                    tsd[k].copy_(v)
+        sd = student.state_dict()
+        for n, row in zip(g["init_names"], g["init_stats"]):
+            assert_init_stat(stat(sd[str(n)]), row, n)
+        with torch.no_grad():
+            sd["segmentation.cls.weight"].copy_(torch.from_numpy(g["cls_weight"]).to(device))
+            sd["segmentation.cls.bias"].copy_(torch.from_numpy(g["cls_bias"]).to(device))
+        if getattr(student, "arena", None) is not None:
+            student.arena.refresh_mirrors()
+        return student, teacher, DINOLoss(65536, 2, 0.04, 0.04, 0, 40).to(device), pretrain.make_optimizer(student, clip_grad=3.0)
+
+    def iteration(nets, step, inject_reference_prediction=False):
+        student, teacher, dino_loss, opt = nets
         p = f"s{step}/"
         epoch, lr, wd, mom, clip, freeze, seed = g[p + "hyper"]
         images, masks, metrics = (make_text_like_batch if epoch >= 30 else make_batch)(8, seed=int(seed), device=device)
         captured = {}
         orig = student.forward
         student.forward = lambda *a, **k: captured.setdefault("out", orig(*a, **k))
-        loss = pretrain.training_iteration(student, teacher, dino_loss, opt, images, masks, metrics, int(epoch), lr, wd,
-                                           mom, freeze_last_layer=int(freeze))
-        student.forward = orig
+        real_seg_to_mask = ops.seg_to_mask
+        if inject_reference_prediction:
+            ref_pred = torch.from_numpy(g[p + "pred_mask"].astype(np.float32)).to(device)
+            ops.seg_to_mask = lambda seg, B: ref_pred.clone()
+        try:
+            loss = pretrain.training_iteration(student, teacher, dino_loss, opt, images, masks, metrics, int(epoch), lr, wd,
+                                               mom, freeze_last_layer=int(freeze))
+        finally:
+            student.forward = orig
+            ops.seg_to_mask = real_seg_to_mask
         out = captured["out"]
         losses = np.array([loss.item(), dino_loss.last_losses["mask_loss"].item(), dino_loss.last_losses["Dino_loss"].item()])
-        rep = {"epoch": int(epoch), "hip": losses.tolist(), "reference": g[p + "losses"].tolist()}
+        rep = {"epoch": int(epoch), "hip": losses.tolist(), "reference": g[p + "losses"].tolist(),
+               "abs_diff": np.abs(losses - g[p + "losses"]).tolist()}
         idmap = out.raw("selection").idmap.cpu().numpy()
-        if epoch >= 30:
-            # the branch thresholds the model's OWN bf16-path segmentation: a pixel may only differ from the reference's
-            # prediction where the reference's fp32 margin |l1 - l0| is within the bf16 error of the logits
+        if epoch >= 30 and not inject_reference_prediction:
             seg_ref = g[p + "seg_logits_view1"]
             margin = np.abs(seg_ref[:, 1] - seg_ref[:, 0])
             seg = out["mask"].detach().float()[:8].cpu().numpy()
-            pred = (seg[:, 1] > seg[:, 0]).astype(np.uint8)
-            flips = pred != g[p + "pred_mask"]
+            flips = (seg[:, 1] > seg[:, 0]).astype(np.uint8) != g[p + "pred_mask"]
             rep["pred_mask_flipped_pixels"] = int(flips.sum())
             rep["seg_logit_max_abs_err"] = float(np.abs(seg - seg_ref).max())
-            assert rep["seg_logit_max_abs_err"] < 5e-2
+            rep["reference_margin_min"] = float(margin.min())
+            print(f"small3 step {step} (epoch {int(epoch)}): {rep['pred_mask_flipped_pixels']} of {flips.size} predicted-mask pixels "
+                  f"flipped, max logit error {rep['seg_logit_max_abs_err']:.4f}, smallest reference margin {margin.min():.4f}")
             assert not (flips & (margin > 2.0 * rep["seg_logit_max_abs_err"])).any(), "prediction differs beyond the logit error"
-            if not flips.any():
-                np.testing.assert_array_equal(idmap, g[p + "zero_idmap"])
-                np.testing.assert_array_equal(out["index"].cpu().numpy(), g[p + "new_index"])
-        else:
-            np.testing.assert_array_equal(idmap, g[p + "zero_idmap"])                          # bit-exact index map
-            np.testing.assert_array_equal(out["index"].cpu().numpy(), g[p + "new_index"])
-        report[f"step{step}"] = rep
-        same_rows = np.array_equal(out["index"].cpu().numpy(), g[p + "new_index"]) and np.array_equal(idmap, g[p + "zero_idmap"])
-        if same_rows:
-            np.testing.assert_allclose(losses, g[p + "losses"], atol=loss_tol, rtol=0, err_msg=f"losses vs reference, step {step}")
-            r, c = g[p + "rows"], g[p + "cols"]
-            sl = out["instances_view"].detach().float()[torch.as_tensor(r)][:, torch.as_tensor(c)].cpu().numpy()
-            assert np.abs(sl - g[p + "student_logits_sample"]).max() < 4e-2
-            arena = student.arena
-            for n, row in zip(g[p + "grad_names"], g[p + "grad_stats"]):
-                got_l2 = arena.g(str(n)).double().pow(2).sum().sqrt().item()
-                if row[2] > 1e-5:
-                    assert abs(got_l2 - row[2]) <= 8e-2 * row[2], f"step {step} grad norm {n}: {got_l2} vs reference {row[2]}"
-        else:
-            assert epoch >= 30, "index maps of the dataset-mask branch must be bit-exact"
-            np.testing.assert_allclose(losses, g[p + "losses"], atol=5e-2, rtol=0)
+            assert rep["pred_mask_flipped_pixels"] == 0, "the fixture has margins: the bf16 path must reproduce the prediction"
+        np.testing.assert_array_equal(idmap, g[p + "zero_idmap"])                              # bit-exact index map
+        np.testing.assert_array_equal(out["index"].cpu().numpy(), g[p + "new_index"])
+        np.testing.assert_allclose(losses, g[p + "losses"], atol=loss_tol, rtol=0, err_msg=f"losses vs reference, step {step}")
+        r, c = g[p + "rows"], g[p + "cols"]
+        sl = out["instances_view"].detach().float()[torch.as_tensor(r)][:, torch.as_tensor(c)].cpu().numpy()
+        assert np.abs(sl - g[p + "student_logits_sample"]).max() < 4e-2
+        arena = student.arena
+        for n, row in zip(g[p + "grad_names"], g[p + "grad_stats"]):
+            got_l2 = arena.g(str(n)).double().pow(2).sum().sqrt().item()
+            if row[2] > 1e-5:
+                assert abs(got_l2 - row[2]) <= 8e-2 * row[2], f"step {step} grad norm {n}: {got_l2} vs reference {row[2]}"
+        return rep
+
+    report = {}
+    nets = build()
+    for step in range(4):
+        report[f"step{step}"] = iteration(nets, step)
+    # the predicted-mask iteration once more on fresh networks with the REFERENCE's thresholded prediction handed to the branch:
+    # connected components, warp, pooling, head, both losses and every gradient behind the threshold, at the same tolerances
+    report["step0_reference_prediction_injected"] = iteration(build(), 0, inject_reference_prediction=True)
     return report
 
 

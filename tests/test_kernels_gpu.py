@@ -63,7 +63,7 @@ def test_gemm_tn_pair_reserved_cus(hip):
             kc.check_gemm_tn(hip.device, 8192, 1536, 384, seed=13)
 
 
-@pytest.mark.parametrize("policy", [dict(gemm_tn384=0), dict(gemm_tn384_min_tiles=1), dict(gemm_tn384_geom=1)])
+@pytest.mark.parametrize("policy", [dict(gemm_tn384=0), dict(gemm_tn384_min_tiles=1)])
 def test_gemm_tn_policies(hip, policy):
     """Single weight-gradient products on the kernel that is not the default for their shape: the 128-square kernel for the
     fc shapes, gemm_tn384.h for proj (2 tiles, 128 slices)."""
@@ -83,8 +83,6 @@ def test_layernorm(hip, rows, E):
 def test_attention(hip, views, heads, spike):
     from ccd_amd import ops
     kc.check_attention(hip.device, views, heads, spike=spike)
-    with ops.policy(attn_fused=1):                            # the backward pass as ONE kernel (q, k, v, dO, O read once)
-        kc.check_attention(hip.device, views, heads, spike=spike)
     with ops.policy(attn_tr=0):                               # dK / dV on the four register-staged images
         kc.check_attention(hip.device, views, heads, spike=spike)
     with ops.policy(cu_reserve=248):                          # 8 workgroups walk the blocks: the double-buffered images turn over
@@ -201,17 +199,6 @@ def test_gemm_row384(hip, M, N, K):
 def test_gemm_lnbwd(hip, M, N, K):
     from ccd_amd import ops
     kc.check_gemm_lnbwd(hip.device, M=M, N=N, K=K)            # rowgemm.h where K % (64 R) == 0 and N in {128, 256, 384, 512}
-    if N == 384 and K % 192 == 0:
-        with ops.policy(rowgemm=4):                           # rowgemm16.h, 3-block ring
-            kc.check_gemm_lnbwd(hip.device, M=M, N=N, K=K)
-
-
-@pytest.mark.parametrize("M,K", [(300, 384), (40000, 1152), (4100, 1536)])
-def test_gemm_lnbwd_rowgemm16(hip, M, K):
-    """rowgemm16.h: 16-row waves, two independent 64-row workgroups per CU."""
-    from ccd_amd import ops
-    with ops.policy(rowgemm=3):
-        kc.check_gemm_lnbwd(hip.device, M=M, N=384, K=K)
 
 
 def test_gemm_lnbwd_row384_kernel(hip):

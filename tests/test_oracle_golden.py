@@ -155,6 +155,9 @@ def test_small3_steps(golden_dir):
         if k.startswith("head."):
             teacher.P[k] = student.P[k].detach().clone()
     _check_stats(g["init_names"], g["init_stats"], student.P, rtol=0, atol=0, what="init")
+    with torch.no_grad():       # the fixture's fitted last layer of the segmentation head (tools/gen_golden.py: fit_seg_classifier)
+        student.P["segmentation.cls.weight"].copy_(torch.from_numpy(g["cls_weight"]))
+        student.P["segmentation.cls.bias"].copy_(torch.from_numpy(g["cls_bias"]))
     center, opt = torch.zeros(1, spec.out_dim), O.AdamWState()
     for step in range(4):
         p = f"s{step}/"
@@ -170,11 +173,14 @@ def test_small3_steps(golden_dir):
             np.testing.assert_allclose(seg1.numpy(), g[p + "seg_logits_view1"], rtol=1e-3, atol=2e-5)
             np.testing.assert_array_equal((F.softmax(seg1, 1)[:, 1] > 0.5).numpy().astype(np.uint8), g[p + "pred_mask"])
             assert len(np.unique(g[p + "zero_idmap"])) > 3, "fixture: the predicted masks must hold components"
+            assert float(g[p + "pred_margin_min"][0]) > 1.0, "fixture: the prediction must have real margins"
         np.testing.assert_array_equal(s["idmap"], g[p + "zero_idmap"])
         np.testing.assert_array_equal(s["index"].numpy(), g[p + "new_index"])
         np.testing.assert_allclose([rec["loss"], rec["mask_loss"], rec["dino_loss"]], g[p + "losses"], rtol=5e-6)
         _check_stats(g[p + "grad_names"], g[p + "grad_stats"], rec["grads_raw"], rtol=2e-3, atol=5e-7, what="grad")
-        _check_stats(g[p + "post_names"], g[p + "post_stats"], student.P, rtol=1e-4, atol=1e-6, what="post")
+        # (atol: Adam moves an element whose gradient is ~0 by +-lr whichever way rounding tips it - with the fitted classifier
+        # the mask loss is small and a few BatchNorm biases of the segmentation head see such gradients: 2e-6 on an abs-sum of 3e-3)
+        _check_stats(g[p + "post_names"], g[p + "post_stats"], student.P, rtol=1e-4, atol=5e-6, what="post")
         _check_stats(g[p + "teacher_post_names"], g[p + "teacher_post_stats"], teacher.P, rtol=1e-5, atol=1e-6, what="ema")
 
 

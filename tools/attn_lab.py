@@ -30,21 +30,19 @@ def main():
     ms = timeit(lambda: ops.attention_fwd(qkv, heads, scale))
     print(json.dumps({"kernel": "attention_fwd", "views": a.views, "ms": round(ms, 4)}), flush=True)
     for tr in (1, 0):
-        with ops.policy(attn_tr=tr, attn_fused=0, attn_skew=0):
+        with ops.policy(attn_tr=tr, attn_skew=0):
             ms = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, scale))
         print(json.dumps({"kernel": "attention_bwd (dq + dkv)", "attn_tr": tr, "views": a.views, "ms": round(ms, 4)}), flush=True)
     for lab, what in ((1, "no stores"), (2, "no loads"), (3, "no loads, no stores")):
-        with ops.policy(attn_tr=1, attn_fused=0, attn_skew=0, lab=lab):
+        with ops.policy(attn_tr=1, attn_skew=0, lab=lab):
             ms = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, scale))
         print(json.dumps({"kernel": "attention_bwd (dq + dkv_tr)", "lab": what, "ms": round(ms, 4)}), flush=True)
     if os.environ.get("ATTN_LAB_SHORT"):
         return
-    for fused in (1, 0):
-        for skew in a.skews:
-            with ops.policy(attn_skew=skew, attn_fused=fused):
-                ms = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, scale))
-            print(json.dumps({"kernel": "attention_bwd " + ("fused" if fused else "(dq + dkv)"), "views": a.views, "skew": skew,
-                              "ms": round(ms, 4)}), flush=True)
+    for skew in a.skews:
+        with ops.policy(attn_skew=skew):
+            ms = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, scale))
+        print(json.dumps({"kernel": "attention_bwd (dq + dkv)", "views": a.views, "skew": skew, "ms": round(ms, 4)}), flush=True)
 
 
 if __name__ == "__main__":

@@ -300,6 +300,12 @@ def gen_small():
                                             drop_path_rate=0.0, tiny=False)
     out = {}
     out["init_names"], out["init_stats"] = state_stats(student.state_dict().items())
+    # A segmentation head WITH margins.  Straight from its random init the head's two logits differ by ~0 at every pixel, so the
+    # thresholded prediction is decided by rounding noise and no reduced-precision implementation can reproduce it.  The state
+    # the fixture starts from is therefore a head whose last layer (segmentation.cls, 2 x 128 x 3 x 3 + 2 numbers - small
+    # enough to record) has been fitted to the text masks of the epoch-30 batch on the head's own features: the prediction
+    # then has real foreground / background margins, as a head that has trained for 30 epochs would.
+    out["cls_weight"], out["cls_bias"] = fit_seg_classifier(student, make_text_like_batch(B, seed=13))
     dino_loss = DINOLoss(K, 2, 0.04, 0.04, 0, 40)
     optimizer = torch.optim.AdamW(rutils.get_params_groups(student))
     lr_s = rutils.cosine_iter_scheduler(0.0005 * B / 256.0, 1e-6, 50, warmup_iters=10)
@@ -365,6 +371,47 @@ def perturb_head_biases(named_parameters):
                 p.add_(HEAD_BIAS_PERTURB["scale"] * torch.randn(p.shape, generator=g))
 
 
+def fit_seg_classifier(student, batch, steps=400):
+    """Fit ONLY student.segmentation.cls (in place) so that softmax(cls(features))[:, 1] predicts the text masks of view 1 of
+    `batch`: features = the input of `cls` in a training-mode forward (BatchNorm batch statistics - what the recorded
+    iteration will see); plain logistic regression with L-BFGS in this script (not reference code).  Buffers touched by
+    the extra forward (BatchNorm running statistics) are restored.  Returns the fitted (weight, bias) as numpy arrays."""
+    images, masks, metrics = batch
+    B = images.shape[0]
+    buffers = {k: v.clone() for k, v in student.state_dict().items()}
+    feats = {}
+    hook = student.segmentation.cls.register_forward_hook(lambda m, i, o: feats.__setitem__("x", i[0].detach()))
+    student.train()
+    with torch.no_grad():
+        student(images, metrics, masks, 0, clusters=None)
+    hook.remove()
+    student.load_state_dict(buffers)
+    x = feats["x"][:B]                                           # the branch thresholds the first B images (view 1)
+    target = masks.long()
+    cls = student.segmentation.cls
+    w = cls.weight.detach().clone().requires_grad_(True)
+    b = cls.bias.detach().clone().requires_grad_(True)
+    opt = torch.optim.LBFGS([w, b], lr=1.0, max_iter=steps, history_size=20, line_search_fn="strong_wolfe")
+
+    def closure():
+        opt.zero_grad()
+        loss = F.cross_entropy(F.conv2d(x, w, b, padding=1), target) + 1e-4 * (w * w).sum()
+        loss.backward()
+        return loss
+
+    opt.step(closure)
+    with torch.no_grad():
+        cls.weight.copy_(w)
+        cls.bias.copy_(b)
+        logit = F.conv2d(x, w, b, padding=1)
+        margin = (logit[:, 1] - logit[:, 0])
+        acc = ((margin > 0) == (target > 0)).float().mean().item()
+        q = torch.quantile(margin.abs().flatten(), torch.tensor([0.001, 0.01, 0.1, 0.5]))
+        print(f"fit_seg_classifier: pixel accuracy {acc:.4f}, |margin| quantiles 0.1% / 1% / 10% / 50%: {q.tolist()}, "
+              f"pixels with |margin| < 0.05: {int((margin.abs() < 0.05).sum())} of {margin.numel()}")
+    return cls.weight.detach().numpy().copy(), cls.bias.detach().numpy().copy()
+
+
 def gen_small3():
     """CCD_pretrain_ViT_small, B=8, head biases perturbed before the first step: one iteration at epoch 30 (predicted-mask
     branch, dino_vision.py:64-70, on images that carry the characters) followed by THREE consecutive iterations on the
@@ -379,6 +426,12 @@ def gen_small3():
     teacher.head.load_state_dict(student.head.state_dict())
     out = {"perturb": np.array([HEAD_BIAS_PERTURB["seed"], HEAD_BIAS_PERTURB["scale"]])}
     out["init_names"], out["init_stats"] = state_stats(student.state_dict().items())
+    # A segmentation head WITH margins.  Straight from its random init the head's two logits differ by ~0 at every pixel, so the
+    # thresholded prediction is decided by rounding noise and no reduced-precision implementation can reproduce it.  The state
+    # the fixture starts from is therefore a head whose last layer (segmentation.cls, 2 x 128 x 3 x 3 + 2 numbers - small
+    # enough to record) has been fitted to the text masks of the epoch-30 batch on the head's own features: the prediction
+    # then has real foreground / background margins, as a head that has trained for 30 epochs would.
+    out["cls_weight"], out["cls_bias"] = fit_seg_classifier(student, make_text_like_batch(B, seed=13))
     dino_loss = DINOLoss(K, 2, 0.04, 0.04, 0, 40)
     optimizer = torch.optim.AdamW(rutils.get_params_groups(student))
     lr_s = rutils.cosine_iter_scheduler(0.0005 * B / 256.0, 1e-6, 50, warmup_iters=10)

@@ -46,8 +46,6 @@ def pairs(dev, R=131072, E=384):
             ms1 = timeit(lambda: ops.gemm_tn_pair(a1, b1, c1, a2, b2, c2), iters=20)
         print(json.dumps({"pair": name, "main_loop_ms": round(ms1, 4)}), flush=True)
         for what, fn, pol in (("pair", lambda: ops.gemm_tn_pair(a1, b1, c1, a2, b2, c2), {}),
-                              ("pair, 192x192 x 2 per CU", lambda: ops.gemm_tn_pair(a1, b1, c1, a2, b2, c2), dict(gemm_tn384_geom=1)),
-                              ("pair, 192x192 x 2 per CU, main loop only", lambda: ops.gemm_tn_pair(a1, b1, c1, a2, b2, c2), dict(gemm_tn384_geom=1, lab=1)),
                               ("two calls, defaults", lambda: (ops.gemm_tn(a1, b1, c1), ops.gemm_tn(a2, b2, c2)), {}),
                               ("two calls, 128-square", lambda: (ops.gemm_tn(a1, b1, c1), ops.gemm_tn(a2, b2, c2)), dict(gemm_tn384=0))):
             with ops.policy(**pol):
