@@ -38,7 +38,8 @@ SIGNATURES = {
     "ccd_ln_fwd": [P, P, P, P, P, P, I, I, F, P],
     "ccd_ln_bwd": [P, P, P, P, P, P, I, P, P, P, P, I, P, I, I, P],
     "ccd_attention_fwd": [P, P, P, I, I, F, P],
-    "ccd_attention_bwd": [P, P, P, P, P, P, I, I, F, P],
+    "ccd_attention_bwd": [P, P, P, P, P, P, I, I, F, P, P, P],
+    "ccd_attention_bwd_ws_floats": [I, I],
     "ccd_patch_embed_fwd": [P, P, P, P, P, I, I, P],
     "ccd_patch_embed_bwd": [P, P, P, P, P, P, P, I, I, P],
     "ccd_small_matmul_f32": [P, P, P, I, I, I, I, I, P],
@@ -91,7 +92,7 @@ SIGNATURES = {
     "ccd_tf_loss_bwd": [P, L, I, P, I, I, I, P, P, P, P, L, P],
     "ccd_greedy_step": [P, L, I, I, P, I, I, P, I, P],
 }
-_RESTYPES = {"ccd_build_info": C.c_char_p}
+_RESTYPES = {"ccd_build_info": C.c_char_p, "ccd_attention_bwd_ws_floats": L}
 
 
 def bind(lib: C.CDLL) -> C.CDLL:

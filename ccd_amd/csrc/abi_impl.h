@@ -10,6 +10,7 @@
 #include "kernels/gemm_row384.h"
 #include "kernels/mlp_fused.h"
 #include "kernels/rowgemm.h"
+#include "kernels/rowproj.h"
 #include "kernels/gemm_tn384.h"
 #include "kernels/layernorm.h"
 #include "kernels/attention_fwd.h"
@@ -82,6 +83,9 @@ struct CcdPolicy {
     int gemm_256_f32 = 0;       // 256-row kernels also for the fp32 / residual epilogues
     int gemm_256_deep = 0;      // BK = 32 x 4 buffers (three k-steps of DMA in flight) instead of BK = 64 x 2
     int gemm_row384 = 0;        // 1 = full-row kernel for N <= 384 residual / fp32 epilogues, 2 = bf16 too
+    int rowproj = 1;            // K = 384 / 512 bf16 projections (qkv, proj data gradient) with the activation rows resident in registers (rowproj.h); 0 = gemm256.h / gemm.h
+    int rowproj_min_m = 16384;  // ... from this many rows on (a workgroup tile is 256 rows: below ~64 tiles the 128-row kernels fill the chip better)
+    int mlp_gelu_poly = 0;      // fused MLP (E = 384): GELU by the packed-VALU polynomial of common.h instead of the LDS table of Phi
     int rowgemm = 1;            // row-owner kernels (rowgemm.h) for the N in {128, 256, 384} row-wise epilogues; 0 = gemm_row384.h
     int ln_bwd_bpc = 5;         // LayerNorm backward: blocks per CU (one resident wave; more blocks = more dgamma/dbeta atomics)
     int dec_attn_simt = 0;      // decoder attention: force the general SIMT kernels
@@ -100,7 +104,8 @@ static const CcdPolicyKey ccd_policy_keys[] = {
     {"gemm_256", &CcdPolicy::gemm_256}, {"gemm_256_min_m", &CcdPolicy::gemm_256_min_m},
     {"gemm_256_min_n", &CcdPolicy::gemm_256_min_n}, {"gemm_256_f32", &CcdPolicy::gemm_256_f32},
     {"gemm_256_deep", &CcdPolicy::gemm_256_deep}, {"gemm_row384", &CcdPolicy::gemm_row384},
-    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"lab", &CcdPolicy::lab}};
+    {"rowproj", &CcdPolicy::rowproj}, {"rowproj_min_m", &CcdPolicy::rowproj_min_m},
+    {"mlp_gelu_poly", &CcdPolicy::mlp_gelu_poly}, {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"lab", &CcdPolicy::lab}};
 static CcdPolicy& ccd_policy() {
     static CcdPolicy pol = [] {
         CcdPolicy q;
@@ -128,6 +133,28 @@ static int ccd_grid_cus() {
     }
     const int cus = ccd_rt_num_cus() - reserve;
     return cus > 1 ? cus : 1;
+}
+// row-owner projection (rowproj.h): out bf16 = A . B^T + bias, K in {384, 512}, N % 64 == 0
+static bool ccd_rowproj_takes(const ccd::GemmParams& p, int epilogue) {
+    const CcdPolicy& pol = ccd_policy();
+    return pol.rowproj && epilogue == CCD_EPI_BF16 && (p.K == 384 || p.K == 512) && p.N % 64 == 0 && p.N <= 4096 &&
+           p.M >= pol.rowproj_min_m && !p.d_rows && !p.colsum && p.alpha == 1.0f && p.ldc % 8 == 0 &&
+           ccd::rp_smem_bytes(p.K, p.N) <= 160 * 1024 &&
+           ((long)p.M + 512) * p.lda * 2 < CCD_MAX_OPERAND_BYTES && ((long)p.M + 512) * p.ldc * 2 < CCD_MAX_OPERAND_BYTES;
+}
+static int ccd_launch_rowproj(const ccd::GemmParams& p, void* stream) {
+    ccd::RowProjParams q;
+    q.a = reinterpret_cast<const ccd::bf16_t*>(p.A); q.lda = p.lda; q.w = reinterpret_cast<const ccd::bf16_t*>(p.B); q.ldw = p.ldb;
+    q.bias = p.bias; q.out = reinterpret_cast<ccd::bf16_t*>(p.C); q.ldc = p.ldc; q.M = p.M; q.N = p.N;
+    const int cus = ccd_grid_cus(), smem = ccd::rp_smem_bytes(p.K, p.N);
+    if (p.K == 384) {
+        const int tiles = (p.M + ccd::rp_rows(2) - 1) / ccd::rp_rows(2);
+        CCD_LAUNCH((ccd::rowproj_kernel<384, 2>), dim3(tiles < cus ? tiles : cus), dim3(ccd::RP_THREADS), smem, stream, q);
+    } else {
+        const int tiles = (p.M + ccd::rp_rows(1) - 1) / ccd::rp_rows(1);
+        CCD_LAUNCH((ccd::rowproj_kernel<512, 1>), dim3(tiles < cus ? tiles : cus), dim3(ccd::RP_THREADS), smem, stream, q);
+    }
+    return ccd_rt_last_error();
 }
 // 256x256-tile LDS-DMA kernel for the large-M products (gemm256.h): one workgroup per CU
 template <int BN, bool DEEP = false>
@@ -205,8 +232,8 @@ static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, void* stream) {
 
 extern "C" {
 
-int ccd_abi_version(void) { return 3; }   // 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
-const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi3"; }
+int ccd_abi_version(void) { return 4; }   // 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
+const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi4"; }
 int ccd_policy_set(const char* key, int value) {
     CCD_CHECK(key, CCD_EINVAL);
     for (const CcdPolicyKey& k : ccd_policy_keys)
@@ -248,6 +275,7 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
     // kernel choice by the policy table (defaults measured in DESIGN.md section 3; the tests change it through
     // ccd_policy_set to force small problems through the 256-row kernels)
     const CcdPolicy& pol = ccd_policy();
+    if (ccd_rowproj_takes(p, epilogue)) return ccd_launch_rowproj(p, stream);
     if (pol.gemm_row384 >= 1 && N <= ccd::GR_BN && M >= pol.gemm_256_min_m &&
         (epilogue == CCD_EPI_RESID || epilogue == CCD_EPI_F32 || (epilogue == CCD_EPI_BF16 && pol.gemm_row384 >= 2)))
         return ccd_launch_gemm_row384(p, epilogue, stream);
@@ -377,6 +405,9 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
     if (E == 512) {
         if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<512, true>), grid, block, smem, stream, p);
         else CCD_LAUNCH((ccd::mlp_fused_kernel<512, false>), grid, block, smem, stream, p);
+    } else if (E == 384 && ccd_policy().mlp_gelu_poly) {
+        if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<384, true, true>), grid, block, smem, stream, p);
+        else CCD_LAUNCH((ccd::mlp_fused_kernel<384, false, true>), grid, block, smem, stream, p);
     } else if (E == 384) {
         if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<384, true>), grid, block, smem, stream, p);
         else CCD_LAUNCH((ccd::mlp_fused_kernel<384, false>), grid, block, smem, stream, p);
@@ -519,21 +550,32 @@ int ccd_attention_fwd(const ccd_bf16* qkv, ccd_bf16* out, float* lse, int views,
     return ccd_rt_last_error();
 }
 
+long ccd_attention_bwd_ws_floats(int views, int heads) {
+    const long nblocks = (long)views * heads, cus = ccd_rt_num_cus();
+    return (nblocks < cus ? nblocks : cus) * 3L * heads * ccd::ATT_D;
+}
 int ccd_attention_bwd(const ccd_bf16* qkv, const ccd_bf16* out, const ccd_bf16* d_out, const float* lse,
-                      float* delta_ws, ccd_bf16* d_qkv, int views, int heads, float scale, void* stream) {
-    CCD_CHECK(qkv && out && d_out && lse && delta_ws && d_qkv, CCD_EINVAL);
+                      float* delta_ws, ccd_bf16* d_qkv, int views, int heads, float scale, float* d_qkv_bias, float* bias_ws,
+                      void* stream) {
+    CCD_CHECK(qkv && out && d_out && lse && delta_ws && d_qkv && (!d_qkv_bias || bias_ws), CCD_EINVAL);
     if (views == 0) return CCD_OK;
-    CCD_CHECK(views > 0 && heads > 0, CCD_EINVAL);
+    CCD_CHECK(views > 0 && heads > 0 && heads <= ccd::ATTB_MAX_HEADS, CCD_EINVAL);
     const int nblocks = views * heads;                      // persistent: one workgroup per CU walks the (view, head) blocks
     const int cus = ccd_rt_num_cus();
-    CCD_LAUNCH(ccd::attention_bwd_dq_kernel, dim3(nblocks < cus ? nblocks : cus), dim3(512), ccd::ATTB_DQ_SMEM, stream, qkv,
-               out, d_out, lse, delta_ws, d_qkv, heads, scale, nblocks, ccd_policy().attn_skew);
+    const int grid = nblocks < cus ? nblocks : cus;
+    float* ws = d_qkv_bias ? bias_ws : nullptr;             // [grid][3 E] partial column sums: dQ | dK | dV
+    CCD_LAUNCH(ccd::attention_bwd_dq_kernel, dim3(grid), dim3(512), ccd::ATTB_DQ_SMEM, stream, qkv,
+               out, d_out, lse, delta_ws, d_qkv, ws, heads, scale, nblocks, ccd_policy().attn_skew);
     if (ccd_policy().attn_tr)               // dK / dV on the double-buffered LDS-DMA image with transposing LDS reads
-        CCD_LAUNCH(ccd::attention_bwd_dkv_tr_kernel, dim3(nblocks < cus ? nblocks : cus), dim3(512), ccd::ATTB_DKV_TR_SMEM, stream,
-                   qkv, d_out, lse, delta_ws, d_qkv, heads, scale, nblocks, ccd_policy().lab);
+        CCD_LAUNCH(ccd::attention_bwd_dkv_tr_kernel, dim3(grid), dim3(512), ccd::ATTB_DKV_TR_SMEM, stream,
+                   qkv, d_out, lse, delta_ws, d_qkv, ws, heads, scale, nblocks, ccd_policy().lab);
     else
-    CCD_LAUNCH(ccd::attention_bwd_dkv_kernel, dim3(nblocks < cus ? nblocks : cus), dim3(512), ccd::ATTB_DKV_SMEM, stream, qkv,
-               d_out, lse, delta_ws, d_qkv, heads, scale, nblocks, ccd_policy().attn_skew);
+        CCD_LAUNCH(ccd::attention_bwd_dkv_kernel, dim3(grid), dim3(512), ccd::ATTB_DKV_SMEM, stream, qkv,
+                   d_out, lse, delta_ws, d_qkv, ws, heads, scale, nblocks, ccd_policy().attn_skew);
+    if (ws) {
+        const int N = 3 * heads * ccd::ATT_D;
+        CCD_LAUNCH(ccd::colsum_partials_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, ws, grid, N, d_qkv_bias);
+    }
     return ccd_rt_last_error();
 }
 

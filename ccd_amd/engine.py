@@ -310,15 +310,15 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
         del du
         # ---- attention branch: x_mid = x_in + ds1 * proj(attn(qkv(LN1(x_in))))
         d_att = ops.gemm_nt(gb, arena.wbt(b + "attn.proj.weight"))
-        d_qkv = ops.attention_bwd(c.qkv.view(N, 256, 3 * E), c.att, d_att.view(N, 256, E), c.lse, spec.heads, scale)
+        # (the qkv-bias gradient = column sums of d_qkv comes out of the attention-backward kernels' fp32 result tiles:
+        # round 2 ran a separate colsum pass over the 302 MB of d_qkv per block, 0.95 ms per step)
+        d_qkv = ops.attention_bwd(c.qkv.view(N, 256, 3 * E), c.att, d_att.view(N, 256, E), c.lse, spec.heads, scale,
+                                  d_bias=arena.g(b + "attn.qkv.bias"))
         d_qkv = d_qkv.view(R, 3 * E)
 
         def qkv_grads(d_qkv=d_qkv):
-            # (ops.gemm_tn_colsum does both in one pass over d_qkv - measured 56.4 vs 56.1 ms per step: the 64 extra VALU
-            # operations per k-tile in the TN loader cost more than the second 302-MB read they save)
             # proj.weight's gradient waits for qkv.weight's: one launch for both (gb is not rewritten before norm1's backward)
             ops.gemm_tn_pair(gb, att.view(R, E), arena.g(b + "attn.proj.weight"), d_qkv, y1, arena.g(b + "attn.qkv.weight"))
-            ops.colsum_bf16(d_qkv, arena.g(b + "attn.qkv.bias"))
         gb_reader = side.run(qkv_grads, gb, att, d_qkv, y1)
         tail = mlp_tail(i - 1) if (i > 0 and (i - 1) not in tap_at) else {}
         if tail:

@@ -304,17 +304,23 @@ def attention_fwd(qkv, heads, scale):
     return out, lse
 
 
-def attention_bwd(qkv, out, d_out, lse, heads, scale):
-    _chk(qkv, BF16, "qkv"); _chk(out, BF16, "out"); _chk(d_out, BF16, "d_out")
+def attention_bwd(qkv, out, d_out, lse, heads, scale, d_bias=None):
+    """-> d_qkv bf16 [views,256,3E].  d_bias (fp32 [3E], optional): += column sums of d_qkv over all rows (the qkv-bias
+    gradient), taken from the fp32 result tiles inside the kernels."""
+    _chk(qkv, BF16, "qkv"); _chk(out, BF16, "out"); _chk(d_out, BF16, "d_out"); _chk(d_bias, F32, "d_bias")
     assert qkv.is_contiguous() and out.is_contiguous() and d_out.is_contiguous()
     views = qkv.shape[0]
     d_qkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
+    ws = None
+    if d_bias is not None:
+        assert d_bias.numel() == qkv.shape[2] and d_bias.is_contiguous()
+        ws = torch.empty(int(_lib.get().ccd_attention_bwd_ws_floats(views, heads)), dtype=F32, device=qkv.device)
     # five products (S, dP, dV, dK, dQ) of 2 * 256 * 256 * 64 flop per (view, head); q, k, v, o, dO read and dq, dk, dv written once
     with _Span("attention_bwd", views * heads * 10.0 * 256 * 256 * 64, views * heads * (8.0 * 256 * 64 * 2 + 8.0 * 256)):
         _lib.check(_lib.get().ccd_attention_bwd(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(d_out), _lib.ptr(lse),
                                                 _lib.ptr(delta), _lib.ptr(d_qkv), views, heads, float(scale),
-                                                _lib.stream()), "attention_bwd")
+                                                _lib.ptr(d_bias), _lib.ptr(ws), _lib.stream()), "attention_bwd")
     return d_qkv
 
 

@@ -97,6 +97,33 @@ def check_gemm_tn_colsum(dev, Mc=300, P=264, Q=72, splits=3, seed=12):
     close(cs, s0 + a.float().sum(0), 1e-4, 1e-4 * Mc ** 0.5, "gemm_tn_colsum/colsum")
 
 
+def check_rowproj(dev, M, N, K, seed=0, strided=True):
+    """rowproj.h through ccd_gemm_nt (EPI_BF16, K in {384, 512}, N % 64 == 0, policy rowproj): activation rows resident in
+    registers, weights through the LDS ring.  Ragged last tile, strided A / out (the qkv buffer's column slices), with and
+    without bias; the result must equal the tiled kernels' to bf16 rounding and rows beyond M must stay untouched."""
+    g = torch.Generator().manual_seed(seed)
+    a_full = rnd((M, K + 64), g).to(BF)
+    a = a_full[:, 8:8 + K] if strided else a_full[:, :K].contiguous()
+    b = rnd((N, K), g, 0.2).to(BF)
+    bias = rnd((N,), g)
+    ref = a.float() @ b.float().t()
+    A = a_full.to(dev)[:, 8:8 + K] if strided else a.to(dev)
+    B_ = b.to(dev)
+    with ops.policy(rowproj=1, rowproj_min_m=1):
+        got = ops.gemm_nt(A, B_, epilogue=ops.EPI_BF16, bias=bias.to(dev))
+        close(got, ref + bias, 1e-2, 2e-2, "rowproj/bias")
+        big = torch.full((M + 3, N + 64), 7.0, dtype=BF).to(dev)
+        out = big[:M, 32:32 + N]
+        ops.gemm_nt(A, B_, epilogue=ops.EPI_BF16, out=out)
+        close(out, ref, 1e-2, 2e-2, "rowproj/nobias-strided-out")
+        untouched = big.clone()
+        untouched[:M, 32:32 + N] = 7.0
+        assert bool((untouched == 7.0).all()), "rowproj wrote outside its [M, N] block"
+    with ops.policy(rowproj=0):
+        tiled = ops.gemm_nt(A, B_, epilogue=ops.EPI_BF16, bias=bias.to(dev))
+    close(got, tiled.float(), 1e-2, 1e-2, "rowproj vs tiled kernel")
+
+
 def check_gemm_nt_split_k(dev, M=200, N=72, K=16384 + 8192 + 64, seed=9):
     """EPI_ATOMIC on the NT product: C += A . B^T with the contraction cut into slices of 8192 (the head's data gradient,
     K = 65536), ragged last slice, accumulation onto existing values."""
@@ -191,8 +218,15 @@ def check_attention(dev, views, heads, seed=3, spike=False):
     close(lse, torch.logsumexp((q @ k.transpose(-2, -1)) * scale, dim=-1), 1e-3, 2e-3, "attn/lse")
     d_out = rnd((views, 256, E), g).to(BF)
     ref.backward(d_out.float())
-    d_qkv = ops.attention_bwd(qkv.to(dev), out, d_out.to(dev), lse, heads, scale)
+    d_bias = torch.full((3 * E,), 0.5, dtype=torch.float32, device=dev)          # accumulated into, not overwritten
+    d_qkv = ops.attention_bwd(qkv.to(dev), out, d_out.to(dev), lse, heads, scale, d_bias=d_bias)
     want = qf.grad
+    # the qkv-bias gradient: column sums over all rows (fp32 tiles inside the kernels; the stored d_qkv is their bf16 rounding)
+    want_b = want.reshape(-1, 3 * E).double().sum(0)
+    # (rounding errors of the bf16 operands add up like a random walk over the rows: measured 0.02 at 768 rows, |element| < 1)
+    close(d_bias - 0.5, want_b.float(), 1e-2, 4e-3 * (views * 256) ** 0.5 * want.abs().max().item(), "attn/d_qkv_bias")
+    d_plain = ops.attention_bwd(qkv.to(dev), out, d_out.to(dev), lse, heads, scale)      # without the bias gradient: same d_qkv
+    assert torch.equal(d_plain, d_qkv)
     for i, nm in enumerate("qkv"):
         close(d_qkv[..., i * E:(i + 1) * E], want[..., i * E:(i + 1) * E], 4e-2, 4e-2 * want.abs().max().item(),
               f"attn/d{nm}")

@@ -74,6 +74,32 @@ def test_gemm_tn_policies(hip, policy):
         kc.check_gemm_tn_pair(hip.device, 8192 + 32, (384, 1536), (1536, 384), seed=8)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 128, 384), (40000, 1152, 384), (131072, 384, 384), (70000 + 17, 1536, 512),
+                                   (16384, 64, 384)])
+def test_rowproj(hip, M, N, K):
+    """rowproj.h: the K = 384 / 512 bf16 projections with the activation rows resident in registers (qkv, proj data gradient),
+    ragged last tiles, strided operands, several tiles per workgroup; against fp32 torch and against the tiled kernels."""
+    kc.check_rowproj(hip.device, M=M, N=N, K=K, seed=M % 7)
+
+
+def test_rowproj_is_the_default_for_the_vit_projections(hip):
+    """At the benchmark shapes ccd_gemm_nt (EPI_BF16, K = 384, 131072 rows) runs rowproj.h: 20 launches must be bit-identical
+    (a row-owner kernel has no split-K atomics) and equal the tiled kernel to bf16 rounding."""
+    import torch
+    from ccd_amd import ops
+    g = torch.Generator().manual_seed(3)
+    a = kc.rnd((131072, 384), g).to(kc.BF).to(hip.device)
+    w = kc.rnd((1152, 384), g, 0.2).to(kc.BF).to(hip.device)
+    bias = kc.rnd((1152,), g).to(hip.device)
+    assert ops.policy_get("rowproj") == 1 and ops.policy_get("rowproj_min_m") <= 131072
+    first = ops.gemm_nt(a, w, bias=bias)
+    for _ in range(20):
+        assert torch.equal(ops.gemm_nt(a, w, bias=bias), first)
+    with ops.policy(rowproj=0):
+        tiled = ops.gemm_nt(a, w, bias=bias)
+    kc.close(first, tiled.float(), 1e-2, 1e-2, "rowproj vs gemm256 at the qkv shape")
+
+
 @pytest.mark.parametrize("rows,E", [(37, 192), (4096, 384), (1001, 512)])
 def test_layernorm(hip, rows, E):
     kc.check_layernorm(hip.device, rows, E)
@@ -230,8 +256,12 @@ def test_gemm_resid_ln_policy_off_rejects_n512(hip):
 def test_mlp_fused(hip, M, E, H, rps):
     """fc1 + GELU + fc2 + residual + LayerNorm in one launch: ragged tiles, many tiles per workgroup (the ring of weight
     pieces runs across them), dropped samples, with and without the stored pre-activation."""
+    from ccd_amd import ops
     for store_u in (True, False):
         kc.check_mlp_fused(hip.device, M=M, E=E, H=H, rps=rps, store_u=store_u)
+        if E == 384:
+            with ops.policy(mlp_gelu_poly=1 - ops.policy_get("mlp_gelu_poly")):      # the other GELU (LDS table <-> packed polynomial)
+                kc.check_mlp_fused(hip.device, M=M, E=E, H=H, rps=rps, store_u=store_u)
 
 
 def test_mlp_fused_repeatable(hip):

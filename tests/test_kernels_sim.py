@@ -92,6 +92,15 @@ def test_gemm_tn384_sim(sim, monkeypatch):
     kc.check_gemm_tn(sim.device, Mc=2048, P=384, Q=192, seed=4)
 
 
+def test_rowproj_sim(sim, monkeypatch):
+    """rowproj.h on the CPU executor: one and several tiles per workgroup (the weight ring runs across tiles), ragged rows,
+    K = 384 with two row blocks per wave and K = 512 with one."""
+    monkeypatch.setenv("CCD_SIM_CUS", "2")
+    kc.check_rowproj(sim.device, M=300, N=128, K=384)            # 2 tiles of 256 rows on 2 workgroups
+    kc.check_rowproj(sim.device, M=256 * 3 + 40, N=192, K=384, seed=3)   # 4 tiles on 2 workgroups: 2 each
+    kc.check_rowproj(sim.device, M=200, N=64, K=512, seed=4, strided=False)
+
+
 def test_layernorm_sim(sim):
     kc.check_layernorm(sim.device, rows=37, E=192)
     kc.check_layernorm(sim.device, rows=9, E=384)
@@ -264,6 +273,10 @@ def test_mlp_fused_sim(sim):
     """Ragged last tile, several tiles per workgroup (1 CU), a dropped sample, both instantiations of E."""
     kc.check_mlp_fused(sim.device, M=300, E=128, H=256, rps=128)
     kc.check_mlp_fused(sim.device, M=200, E=384, H=128, rps=8, store_u=False)     # per-row DropPath scales
+    from ccd_amd import ops
+    with ops.policy(mlp_gelu_poly=1):                                              # GELU by the packed polynomial, no LDS table
+        kc.check_mlp_fused(sim.device, M=200, E=384, H=128, rps=8, store_u=False)
+        kc.check_mlp_fused(sim.device, M=140, E=384, H=192, rps=128, seed=5)
     kc.check_mlp_fused(sim.device, M=130, E=512, H=128, rps=8)                     # 3-slot ring (vit_base)
 
 
