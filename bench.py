@@ -349,6 +349,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     a = ap.parse_args()
+    if os.environ.get("BENCH_NOTIMER") == "1":
+        a.no_kernel_timer = True
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(a.gpus)               # `python bench.py --gpus N`: become the launcher of N ranks of this command

@@ -38,7 +38,7 @@ SIGNATURES = {
     "ccd_ln_fwd": [P, P, P, P, P, P, I, I, F, P],
     "ccd_ln_bwd": [P, P, P, P, P, P, I, P, P, P, P, I, P, I, I, P],
     "ccd_attention_fwd": [P, P, P, I, I, F, P],
-    "ccd_attention_bwd": [P, P, P, P, P, P, I, I, F, P, P, P],
+    "ccd_attention_bwd": [P, P, P, P, P, P, I, I, F, P, P, P, P, L, P],
     "ccd_attention_bwd_ws_floats": [I, I],
     "ccd_patch_embed_fwd": [P, P, P, P, P, I, I, P],
     "ccd_patch_embed_bwd": [P, P, P, P, P, P, P, I, I, P],

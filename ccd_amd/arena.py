@@ -136,6 +136,9 @@ class ParamArena:
     def zero_grad(self):
         if self.grad is not None:
             self.grad.zero_()
+            # a backward pass that starts from zeroed gradients may read a slot it has just completed as "this pass's sum"
+            # (engine.backbone_backward: colsum(gb) = proj.bias's gradient); cleared by the first backward pass that runs
+            self.grad_fresh = True
 
     # -------------------------------------------------------------------------------- optimizer tables
     def opt_tables(self):

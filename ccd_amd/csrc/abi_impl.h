@@ -85,7 +85,6 @@ struct CcdPolicy {
     int gemm_row384 = 0;        // 1 = full-row kernel for N <= 384 residual / fp32 epilogues, 2 = bf16 too
     int rowproj = 1;            // K = 384 / 512 bf16 projections (qkv, proj data gradient) with the activation rows resident in registers (rowproj.h); 0 = gemm256.h / gemm.h
     int rowproj_min_m = 16384;  // ... from this many rows on (a workgroup tile is 256 rows: below ~64 tiles the 128-row kernels fill the chip better)
-    int mlp_gelu_poly = 0;      // fused MLP (E = 384): GELU by the packed-VALU polynomial of common.h instead of the LDS table of Phi
     int rowgemm = 1;            // row-owner kernels (rowgemm.h) for the N in {128, 256, 384} row-wise epilogues; 0 = gemm_row384.h
     int ln_bwd_bpc = 5;         // LayerNorm backward: blocks per CU (one resident wave; more blocks = more dgamma/dbeta atomics)
     int dec_attn_simt = 0;      // decoder attention: force the general SIMT kernels
@@ -105,7 +104,7 @@ static const CcdPolicyKey ccd_policy_keys[] = {
     {"gemm_256_min_n", &CcdPolicy::gemm_256_min_n}, {"gemm_256_f32", &CcdPolicy::gemm_256_f32},
     {"gemm_256_deep", &CcdPolicy::gemm_256_deep}, {"gemm_row384", &CcdPolicy::gemm_row384},
     {"rowproj", &CcdPolicy::rowproj}, {"rowproj_min_m", &CcdPolicy::rowproj_min_m},
-    {"mlp_gelu_poly", &CcdPolicy::mlp_gelu_poly}, {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"lab", &CcdPolicy::lab}};
+    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"lab", &CcdPolicy::lab}};
 static CcdPolicy& ccd_policy() {
     static CcdPolicy pol = [] {
         CcdPolicy q;
@@ -405,9 +404,6 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
     if (E == 512) {
         if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<512, true>), grid, block, smem, stream, p);
         else CCD_LAUNCH((ccd::mlp_fused_kernel<512, false>), grid, block, smem, stream, p);
-    } else if (E == 384 && ccd_policy().mlp_gelu_poly) {
-        if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<384, true, true>), grid, block, smem, stream, p);
-        else CCD_LAUNCH((ccd::mlp_fused_kernel<384, false, true>), grid, block, smem, stream, p);
     } else if (E == 384) {
         if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<384, true>), grid, block, smem, stream, p);
         else CCD_LAUNCH((ccd::mlp_fused_kernel<384, false>), grid, block, smem, stream, p);
@@ -552,29 +548,30 @@ int ccd_attention_fwd(const ccd_bf16* qkv, ccd_bf16* out, float* lse, int views,
 
 long ccd_attention_bwd_ws_floats(int views, int heads) {
     const long nblocks = (long)views * heads, cus = ccd_rt_num_cus();
-    return (nblocks < cus ? nblocks : cus) * 3L * heads * ccd::ATT_D;
+    return (nblocks < cus ? nblocks : cus) * (long)heads * ccd::ATT_D;
 }
 int ccd_attention_bwd(const ccd_bf16* qkv, const ccd_bf16* out, const ccd_bf16* d_out, const float* lse,
                       float* delta_ws, ccd_bf16* d_qkv, int views, int heads, float scale, float* d_qkv_bias, float* bias_ws,
-                      void* stream) {
-    CCD_CHECK(qkv && out && d_out && lse && delta_ws && d_qkv && (!d_qkv_bias || bias_ws), CCD_EINVAL);
+                      const float* dout_colsum_vec, const float* dout_colsum_mat, long ld_mat, void* stream) {
+    CCD_CHECK(qkv && out && d_out && lse && delta_ws && d_qkv && (!d_qkv_bias || (bias_ws && dout_colsum_vec)), CCD_EINVAL);
     if (views == 0) return CCD_OK;
     CCD_CHECK(views > 0 && heads > 0 && heads <= ccd::ATTB_MAX_HEADS, CCD_EINVAL);
     const int nblocks = views * heads;                      // persistent: one workgroup per CU walks the (view, head) blocks
     const int cus = ccd_rt_num_cus();
     const int grid = nblocks < cus ? nblocks : cus;
-    float* ws = d_qkv_bias ? bias_ws : nullptr;             // [grid][3 E] partial column sums: dQ | dK | dV
+    float* ws = d_qkv_bias ? bias_ws : nullptr;             // [grid][E] partial column sums of dQ
     CCD_LAUNCH(ccd::attention_bwd_dq_kernel, dim3(grid), dim3(512), ccd::ATTB_DQ_SMEM, stream, qkv,
                out, d_out, lse, delta_ws, d_qkv, ws, heads, scale, nblocks, ccd_policy().attn_skew);
     if (ccd_policy().attn_tr)               // dK / dV on the double-buffered LDS-DMA image with transposing LDS reads
         CCD_LAUNCH(ccd::attention_bwd_dkv_tr_kernel, dim3(grid), dim3(512), ccd::ATTB_DKV_TR_SMEM, stream,
-                   qkv, d_out, lse, delta_ws, d_qkv, ws, heads, scale, nblocks, ccd_policy().lab);
+                   qkv, d_out, lse, delta_ws, d_qkv, heads, scale, nblocks, ccd_policy().lab);
     else
         CCD_LAUNCH(ccd::attention_bwd_dkv_kernel, dim3(grid), dim3(512), ccd::ATTB_DKV_SMEM, stream, qkv,
-                   d_out, lse, delta_ws, d_qkv, ws, heads, scale, nblocks, ccd_policy().attn_skew);
+                   d_out, lse, delta_ws, d_qkv, heads, scale, nblocks, ccd_policy().attn_skew);
     if (ws) {
-        const int N = 3 * heads * ccd::ATT_D;
-        CCD_LAUNCH(ccd::colsum_partials_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, ws, grid, N, d_qkv_bias);
+        const int E = heads * ccd::ATT_D;
+        CCD_LAUNCH(ccd::qkv_bias_finish_kernel, dim3((E + 63) / 64, 2), dim3(1024), 0, stream, ws, grid, dout_colsum_vec,
+                   dout_colsum_mat, ld_mat, E, d_qkv_bias);
     }
     return ccd_rt_last_error();
 }

@@ -14,14 +14,22 @@ constexpr int ATTB_IMG = ATT_T * ATT_D * 2;                    // 32 KiB per ope
 constexpr int ATTB_MAX_HEADS = 16;
 constexpr int ATTB_CS_BYTES = ATTB_MAX_HEADS * ATT_D * 4;      // per-head column sums of one gradient (qkv-bias gradient)
 constexpr int ATTB_DQ_SMEM = 3 * ATTB_IMG + ATTB_CS_BYTES;     // K, V, K^T, column sums of dQ
-constexpr int ATTB_DKV_SMEM = 4 * ATTB_IMG + 2 * ATT_T * 4 + 2 * ATTB_CS_BYTES;    // Q, dO, Q^T, dO^T, lse, D, column sums of dK / dV
+constexpr int ATTB_DKV_SMEM = 4 * ATTB_IMG + 2 * ATT_T * 4;    // Q, dO, Q^T, dO^T, lse, D
 
-// The qkv-bias gradient (column sums of d_qkv over all token rows, vision_transformer.py:75 `qkv_bias`) comes out of these
-// kernels instead of a separate pass over d_qkv (19 colsum_bf16 launches, 0.95 ms per step in round 2): the fp32 result tiles
-// are summed over their 32 rows by the DPP halving tree of rowgemm.h (rg_colsum16: 31 exchanges per tile), added to a per-head
-// LDS accumulator of the (persistent) workgroup, and written ONCE per workgroup as a row of partial sums
-// bias_ws[workgroup][3 E] (plain stores: same-address fp32 atomics from 256 workgroups cost more than the pass they replace);
-// colsum_partials_kernel adds the <= 256 rows up.
+// The qkv-bias gradient (column sums of d_qkv over all token rows; vision_transformer.py:75 `qkv_bias`, autograd's
+// grad_output.sum(0) of the qkv Linear) without a pass over d_qkv (round 2: 12 colsum_bf16 launches over 302 MB each):
+//   k part: sum_key dK[key][:] = sum_q (sum_key dS[q][key]) Q[q][:] and sum_key dS[q][key] = scale (sum_key P dP - D sum_key P)
+//           = scale (D - D) = 0: the softmax is shift invariant, the key bias has NO gradient.  Nothing is added (the reference's
+//           fp32 sum is rounding residue of the order 1e-7 there).
+//   v part: sum_key dV[key][:] = sum_q (sum_key P[q][key]) dO[q][:] = column sums of dO, which the caller knows without
+//           touching dO: dO = gb . Wproj, so colsum(dO) = colsum(gb) . Wproj = (proj.bias gradient) . Wproj - a 384 x 384 matvec.
+//   q part: has no closed form: the dQ kernel sums its fp32 result tiles over their 32 rows with the DPP halving tree of
+//           rowgemm.h (rg_colsum16), adds them to a per-head LDS accumulator of the (persistent) workgroup and writes ONE row of
+//           partial sums bias_ws[workgroup][E] at its end (plain stores: same-address fp32 atomics from 256 workgroups cost more
+//           than the pass they replace).
+// qkv_bias_finish_kernel adds the <= 256 partial rows up and forms the matvec.  (Fusing the k / v sums into the dK / dV kernel
+// as well was measured first: + 69 us per layer for both kernels - that kernel already spills at 256 registers - against 56 us
+// for the separate pass.)
 __device__ __forceinline__ void attb_colsum_tiles(const f32x16 (&acc)[2], float* cs_head, int lq, int hf) {
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
@@ -31,18 +39,33 @@ __device__ __forceinline__ void attb_colsum_tiles(const f32x16 (&acc)[2], float*
         rg_colsum16(v, cs_head + 32 * dt, lq, hf);
     }
 }
-// dst[c] (+)= sum over `rows` of src[r][c]: one workgroup per 64 columns, 4 row groups
-__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ src, int rows, int N, float* __restrict__ dst) {
-    __shared__ float part[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+// blockIdx.y = 0: d_bias[c] += sum_r ws[r][c] (r < rows: the dQ kernel's partial rows), c < E
+// blockIdx.y = 1: d_bias[2 E + c] += vec[c] (mat == null) or sum_i vec[i] mat[i][c] (colsum(dO) = proj.bias gradient . Wproj)
+// 64 columns x 16 row groups per workgroup
+__global__ __launch_bounds__(1024) void qkv_bias_finish_kernel(const float* __restrict__ ws, int rows, const float* __restrict__ vec,
+                                                              const float* __restrict__ mat, long ld_mat, int E,
+                                                              float* __restrict__ d_bias) {
+    __shared__ float part[16][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     float a = 0.f;
-    if (c < N)
-        for (int r = rg; r < rows; r += 4) a += src[(long)r * N + c];
-    part[rg][threadIdx.x & 63] = a;
+    if (c < E) {
+        if (blockIdx.y == 0) {
+            for (int r = rg; r < rows; r += 16) a += ws[(long)r * E + c];
+        } else if (mat) {
+            for (int i = rg; i < E; i += 16) a = fmaf(vec[i], mat[(long)i * ld_mat + c], a);
+        } else if (rg == 0) {
+            a = vec[c];
+        }
+    }
+    part[rg][cl] = a;
     __syncthreads();
-    if (rg == 0 && c < N) dst[c] += (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (rg == 0 && c < E) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += part[i][cl];
+        d_bias[(blockIdx.y ? 2 * E : 0) + c] += t;
+    }
 }
-
 __device__ __forceinline__ void attb_stage_rows(const bf16_t* __restrict__ src, long row_stride, char* img) {
     const int t = threadIdx.x;
 #pragma unroll
@@ -246,15 +269,15 @@ __global__ __launch_bounds__(512) void attention_bwd_dq_kernel(const bf16_t* __r
         __syncthreads();                                     // the images are rewritten by the next block
     }
     if (bias_ws)                                             // (the loop's last barrier published every wave's sums)
-        for (int i = threadIdx.x; i < E; i += ATTB_THREADS) bias_ws[(long)blockIdx.x * 3 * E + i] = cs[i];
+        for (int i = threadIdx.x; i < E; i += ATTB_THREADS) bias_ws[(long)blockIdx.x * E + i] = cs[i];
 }
 
 __global__ __launch_bounds__(512) void attention_bwd_dkv_kernel(const bf16_t* __restrict__ qkv,
                                                                 const bf16_t* __restrict__ d_o,
                                                                 const float* __restrict__ lse,
                                                                 const float* __restrict__ delta,
-                                                                bf16_t* __restrict__ dqkv, float* __restrict__ bias_ws, int heads,
-                                                                float scale, int nblocks, int skew) {
+                                                                bf16_t* __restrict__ dqkv, int heads, float scale, int nblocks,
+                                                                int skew) {
     char* smem = dynamic_smem();
     char* q_img = smem;
     char* do_img = smem + ATTB_IMG;
@@ -262,9 +285,7 @@ __global__ __launch_bounds__(512) void attention_bwd_dkv_kernel(const bf16_t* __
     char* dot_img = smem + 3 * ATTB_IMG;
     float* lse_s = reinterpret_cast<float*>(smem + 4 * ATTB_IMG);
     float* del_s = lse_s + ATT_T;
-    float* cs = del_s + ATT_T;                               // [2][heads][64]: column sums of dK, dV over this workgroup's blocks
-    if (bias_ws)
-        for (int i = threadIdx.x; i < 2 * heads * ATT_D; i += ATTB_THREADS) cs[i] = 0.f;
+
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hf = lane >> 5, lq = lane & 31;
     const int E = heads * ATT_D;
     const long rs3 = 3L * E;
@@ -360,15 +381,8 @@ __global__ __launch_bounds__(512) void attention_bwd_dkv_kernel(const bf16_t* __
         bf16_t* drow = dqkv + ((long)view * ATT_T + key) * rs3 + head * ATT_D;
         attb_store_t(drow + E, dk, hf);
         attb_store_t(drow + 2 * E, dv, hf);
-        if (bias_ws) {
-            attb_colsum_tiles(dk, cs + head * ATT_D, lane & 31, hf);
-            attb_colsum_tiles(dv, cs + (heads + head) * ATT_D, lane & 31, hf);
-        }
         __syncthreads();                                     // the images are rewritten by the next block
     }
-    if (bias_ws)
-        for (int i = threadIdx.x; i < 2 * heads * ATT_D; i += ATTB_THREADS)
-            bias_ws[(long)blockIdx.x * 3 * heads * ATT_D + heads * ATT_D + i] = cs[i];
 }
 
 // ---- dK / dV on a double-buffered LDS-DMA image with transposing LDS reads (round 2).  The kernel above spends two thirds of a
@@ -384,7 +398,7 @@ __global__ __launch_bounds__(512) void attention_bwd_dkv_kernel(const bf16_t* __
 // ds_read_b128 row fragments stay conflict-free) whose bit 2 alternates every two rows, which puts the 4 rows x 64 B of a
 // transposing half-wave read on four different 64-byte bank groups (brute-force checked: 1-way for both read kinds).
 constexpr int ATTB_TR_BUF = 2 * ATTB_IMG + 2 * ATT_T * 4;      // Q rows, dO rows, lse, delta
-constexpr int ATTB_DKV_TR_SMEM = 2 * ATTB_TR_BUF + 2 * ATTB_CS_BYTES;      // 132 KiB + column sums of dK / dV
+constexpr int ATTB_DKV_TR_SMEM = 2 * ATTB_TR_BUF;              // 132 KiB
 __device__ __forceinline__ int attb_swz2(int row) {
     const int x = (row >> 1) & 7;
     return x ^ ((x & 1) << 2);
@@ -393,14 +407,10 @@ __global__ __launch_bounds__(512) void attention_bwd_dkv_tr_kernel(const bf16_t*
                                                                    const bf16_t* __restrict__ d_o,
                                                                    const float* __restrict__ lse,
                                                                    const float* __restrict__ delta,
-                                                                   bf16_t* __restrict__ dqkv, float* __restrict__ bias_ws, int heads,
-                                                                   float scale, int nblocks, int lab) {
+                                                                   bf16_t* __restrict__ dqkv, int heads, float scale, int nblocks, int lab) {
     char* smem = dynamic_smem();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hf = lane >> 5, lq = lane & 31;
     const int E = heads * ATT_D;
-    float* cs = reinterpret_cast<float*>(smem + 2 * ATTB_TR_BUF);    // [2][heads][64]: column sums of dK, dV (LDS atomics, no barrier)
-    if (bias_ws)
-        for (int i = threadIdx.x; i < 2 * E; i += ATTB_THREADS) cs[i] = 0.f;     // (published by the first block's barrier)
     const long rs3 = 3L * E;
     const int key = 32 * w + lq;
     // DMA: a 1-KiB piece = 8 image rows; lane L writes row 8 n + L / 8, slot L % 8 and fetches the slot the swizzle puts there.
@@ -568,14 +578,6 @@ __global__ __launch_bounds__(512) void attention_bwd_dkv_tr_kernel(const bf16_t*
             attb_store_t(drow + E, dk, hf);
             attb_store_t(drow + 2 * E, dv, hf);
         }
-        if (bias_ws) {
-            attb_colsum_tiles(dk, cs + head * ATT_D, lq, hf);
-            attb_colsum_tiles(dv, cs + E + head * ATT_D, lq, hf);
-        }
-    }
-    if (bias_ws) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < 2 * E; i += ATTB_THREADS) bias_ws[(long)blockIdx.x * 3 * E + E + i] = cs[i];
     }
 }
 

@@ -70,8 +70,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      bf16_t* __restrict__ gb, const float* __restrict__ rowscale,
                                                      int rows_per_sample, float* __restrict__ dbias, int rows, int E,
                                                      int rows_per_block) {
-    __shared__ float red[3][4][64 * LN_VEC * LN_STEPS];
+    // column sums of the four waves meet in 6 KiB of LDS by ds_add_f32 (every lane its own columns: conflict-free) - small
+    // enough that two blocks fit NEXT to a 144-KiB weight-gradient workgroup on the same CU (engine.py runs this HBM-bound
+    // kernel beside the MFMA-bound gemm_tn384 kernel of the other stream when the LayerNorm backward is not fused)
+    __shared__ float red[3][64 * LN_VEC * LN_STEPS];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < 3 * 64 * LN_VEC * LN_STEPS; c += 256) (&red[0][0])[c] = 0.f;
+    __syncthreads();
     const int row_begin = blockIdx.x * rows_per_block;
     const int row_end = row_begin + rows_per_block < rows ? row_begin + rows_per_block : rows;
     f32x4v gam[LN_STEPS], dg[LN_STEPS], db[LN_STEPS], dbi[LN_STEPS];
@@ -135,15 +140,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
     for (int i = 0; i < LN_STEPS; ++i) {
         const int c = LN_VEC * (lane + 64 * i);
-        *reinterpret_cast<f32x4v*>(&red[0][w][c]) = dg[i];
-        *reinterpret_cast<f32x4v*>(&red[1][w][c]) = db[i];
-        *reinterpret_cast<f32x4v*>(&red[2][w][c]) = dbi[i];
+        const float vg[4] = {dg[i].x, dg[i].y, dg[i].z, dg[i].w}, vb[4] = {db[i].x, db[i].y, db[i].z, db[i].w};
+        const float vi[4] = {dbi[i].x, dbi[i].y, dbi[i].z, dbi[i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(&red[0][c + e], vg[e]);
+            atomicAdd(&red[1][c + e], vb[e]);
+            if (gb && dbias) atomicAdd(&red[2][c + e], vi[e]);
+        }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < E; c += 256) {
-        atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-        atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
-        if (gb && dbias) atomicAdd(dbias + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
+        atomicAdd(dgamma + c, red[0][c]);
+        atomicAdd(dbeta + c, red[1][c]);
+        if (gb && dbias) atomicAdd(dbias + c, red[2][c]);
     }
 }
 

@@ -131,8 +131,7 @@ struct MlpGeluSchedule {
 };
 constexpr unsigned MLP_LUT_LO = 0x3B80u, MLP_LUT_HI = 0x4180u;      // bf16 magnitudes 2^-8 .. 16: 1536 table entries
 
-// GELU_POLY: gelu by gelu_pair_poly (common.h: packed VALU, no LDS) instead of the LDS table of Phi
-template <int E, bool STORE_U, bool GELU_POLY = false>
+template <int E, bool STORE_U>
 __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) {
     constexpr int KT = E / 64;             // 64-wide k-tiles of a W1 piece = DMA instructions per wave and piece
     constexpr int KJ = E / 16;             // MFMA k-steps of the first product
@@ -154,8 +153,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
     float* vbe = vga + E;
     for (int i = t; i < p.H; i += MLP_THREADS) vb1[i] = p.b1[i];
     for (int i = t; i < E; i += MLP_THREADS) { vb2[i] = p.b2[i]; vga[i] = p.ln_gamma[i]; vbe[i] = p.ln_beta[i]; }
-    if (!GELU_POLY)
-        for (unsigned i = t; i < MLP_LUT_HI - MLP_LUT_LO; i += MLP_THREADS) lut[i] = gelu_terms(bf2f((bf16_t)(MLP_LUT_LO + i))).cdf;
+    for (unsigned i = t; i < MLP_LUT_HI - MLP_LUT_LO; i += MLP_THREADS) lut[i] = gelu_terms(bf2f((bf16_t)(MLP_LUT_LO + i))).cdf;
     __syncthreads();                       // (plain loads only so far: nothing in flight that a drain would hurt)
     const float* lut_biased = lut - MLP_LUT_LO;
 
@@ -405,26 +403,19 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                 auto pair_issue = [&](auto PI) {
                     constexpr int pi = decltype(PI)::value, k4 = pi >> 2, e = pi & 3, r = 8 * (k4 & 1) + 2 * e, sl = pi & 7;
                     upk[sl] = pack_bf2(hv[k4 >> 1][r], hv[k4 >> 1][r + 1]);
-                    if constexpr (!GELU_POLY) {
-                        unsigned m0_ = upk[sl] & 0x7fffu, m1_ = (upk[sl] >> 16) & 0x7fffu;
-                        m0_ = m0_ < MLP_LUT_LO ? MLP_LUT_LO : (m0_ > MLP_LUT_HI - 1u ? MLP_LUT_HI - 1u : m0_);
-                        m1_ = m1_ < MLP_LUT_LO ? MLP_LUT_LO : (m1_ > MLP_LUT_HI - 1u ? MLP_LUT_HI - 1u : m1_);
-                        lds_gather_f32(f0[sl], lut_addr + 4u * m0_);
-                        lds_gather_f32(f1[sl], lut_addr + 4u * m1_);
-                    }
+                    unsigned m0_ = upk[sl] & 0x7fffu, m1_ = (upk[sl] >> 16) & 0x7fffu;
+                    m0_ = m0_ < MLP_LUT_LO ? MLP_LUT_LO : (m0_ > MLP_LUT_HI - 1u ? MLP_LUT_HI - 1u : m0_);
+                    m1_ = m1_ < MLP_LUT_LO ? MLP_LUT_LO : (m1_ > MLP_LUT_HI - 1u ? MLP_LUT_HI - 1u : m1_);
+                    lds_gather_f32(f0[sl], lut_addr + 4u * m0_);
+                    lds_gather_f32(f1[sl], lut_addr + 4u * m1_);
                 };
                 auto pair_finish = [&](auto PI) {
                     constexpr int pi = decltype(PI)::value, k4 = pi >> 2, e = pi & 3, sl = pi & 7;
+                    lds_landed(f0[sl], f1[sl]);
                     const float u0 = bf_lo(upk[sl]), u1 = bf_hi(upk[sl]);
-                    if constexpr (GELU_POLY) {
-                        const f32x2v g = gelu_pair_poly(u0, u1);
-                        hbw[k4][e] = pack_bf2(g.x, g.y);
-                    } else {
-                        lds_landed(f0[sl], f1[sl]);
-                        const float g0 = fmaf(fabsf(u0), f0[sl], fminf(u0, 0.f));
-                        const float g1 = fmaf(fabsf(u1), f1[sl], fminf(u1, 0.f));
-                        hbw[k4][e] = pack_bf2(g0, g1);
-                    }
+                    const float g0 = fmaf(fabsf(u0), f0[sl], fminf(u0, 0.f));
+                    const float g1 = fmaf(fabsf(u1), f1[sl], fminf(u1, 0.f));
+                    hbw[k4][e] = pack_bf2(g0, g1);
                     if (STORE_U) {
                         uw[e] = upk[sl];
                         if (e == 3) {      // [32 rows][64 hidden] bf16 image in the wave's scratch
@@ -438,19 +429,6 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                     // issued at step q * S and finished at step q * S + DEPTH + 1 when that step exists, else after the piece
                     auto piece_with_gelu = [&](auto KH) {
                         constexpr int kh = decltype(KH)::value;
-                        if constexpr (GELU_POLY) {
-                            // no LDS operation of its own: pair q of the piece is packed at step q * S and finished (polynomial,
-                            // exp2, pack) two steps later - the MFMAs in between cover the latency of its v_exp_f32
-                            constexpr int S = (KJ - 4) / 8 > 0 ? (KJ - 4) / 8 : 1;
-                            p1_piece(KH, c + 1, MlpNoExtra{}, [&](auto K) {
-                                constexpr int k = decltype(K)::value;
-                                if constexpr (k >= 2 && (k - 2) % S == 0 && (k - 2) / S < 8)
-                                    pair_finish(std::integral_constant<int, 8 * kh + (k - 2) / S>{});
-                                if constexpr (k % S == 0 && k / S < 8) pair_issue(std::integral_constant<int, 8 * kh + k / S>{});
-                            });
-                            constexpr int first_late = (KJ - 1 - 2) / S + 1;
-                            if constexpr (first_late < 8) mlp_static_for<8 * kh + first_late, 8 * kh + 8>(pair_finish);
-                        } else {
                         p1_piece(KH, c + 1, MlpGeluSchedule<KJ, DEPTH>{}, [&](auto K) {
                             constexpr int k = decltype(K)::value;
                             using Sch = MlpGeluSchedule<KJ, DEPTH>;
@@ -463,7 +441,6 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                             lds_drain();
                             mlp_static_for<8 * kh + (first_late < 0 ? 0 : first_late), 8 * kh + 8>(pair_finish);
                         }
-                        }
                     };
                     piece_with_gelu(I0{});
                     MLP_STAMP(4)
@@ -473,7 +450,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                     mlp_static_for<0, 4>([&](auto Gq) {
                         constexpr int gq = decltype(Gq)::value;
                         mlp_static_for<4 * gq, 4 * gq + 4>(pair_issue);
-                        if constexpr (!GELU_POLY) lds_drain();
+                        lds_drain();
                         mlp_static_for<4 * gq, 4 * gq + 4>(pair_finish);
                     });
                 }

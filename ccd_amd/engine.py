@@ -46,6 +46,7 @@ class Fusion:
     mlp = _env_switch("CCD_FUSE_MLP")              # fc1 -> GELU -> fc2 -> residual -> LayerNorm in one launch (default: with `ln`)
     lnbwd = _env_switch("CCD_FUSE_LNBWD")          # LayerNorm backward in the epilogue of the data-gradient product (default: on)
     side_stream = bool(_env_switch("CCD_SIDE_STREAM"))
+    double_gb = False                       # tests: rotate the two gb buffers of the side-stream mode also without a side stream
 
     @classmethod
     def resolve(cls, E):
@@ -206,7 +207,9 @@ class _SideStream:
         if self.on:
             key = device.index if device.index is not None else torch.cuda.current_device()
             if key not in _SideStream._streams:
-                _SideStream._streams[key] = torch.cuda.Stream(device=device)
+                # high priority: when both streams have workgroups waiting, the 144-KiB weight-gradient workgroups go first and
+                # the small LayerNorm-backward blocks fill in beside them (the other order leaves no room for the big ones)
+                _SideStream._streams[key] = torch.cuda.Stream(device=device, priority=-1)
             self.side = _SideStream._streams[key]
             self.main = torch.cuda.current_stream(device)
         self.pending = []                      # events of side work since the last join
@@ -251,18 +254,33 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
     R = N * 256
     dev = img.device
     g = torch.empty((R, E), dtype=F32, device=dev)
-    gb = torch.empty((R, E), dtype=BF16, device=dev)
     tap_at = {i: (j, x, m, r) for j, (i, x, m, r) in enumerate(tap_ctx) if d_taps[j] is not None}
     scale = (E // spec.heads) ** -0.5
     top = spec.depth - 1
-
-    def mlp_tail(i):            # what the MLP branch of block i wants from the writer in front of it
-        return dict(gb=gb, rowscale=ctxs[i].ds2, rows_per_sample=256, dbias=arena.g(f"{pre}blocks.{i}.mlp.fc2.bias"))
-
     # LayerNorm backward folded into the epilogue of the data-gradient product in front of it (ccd_gemm_nt_lnbwd, N <= 384 or 512)
     fuse_lnbwd = Fusion.resolve(E)[2]
     side = _SideStream(dev)
-    gb_reader = None            # event of the last side-stream product that reads gb (the next writer of gb waits for it)
+    grad_fresh = getattr(arena, "grad_fresh", False)     # the gradient arena was zeroed since the last backward pass
+    arena.grad_fresh = False
+    # gb = bf16(g * DropPath scale), the gradient that enters a residual branch.  With the side stream on it lives in TWO
+    # buffers used in turn: a LayerNorm backward writes the next branch's gb while the weight-gradient launch of the
+    # previous branch (side stream) still reads the old one.
+    gbuf = [torch.empty((R, E), dtype=BF16, device=dev) for _ in range(2 if (side.on or Fusion.double_gb) else 1)]
+    readers = [None] * len(gbuf)      # event of the last side-stream launch that reads each buffer
+    cur = [0]
+
+    def gb_read():
+        return gbuf[cur[0]]
+
+    def gb_write():                   # the buffer the next writer fills (it becomes the current one)
+        cur[0] = (cur[0] + 1) % len(gbuf)
+        side.wait(readers[cur[0]])
+        readers[cur[0]] = None
+        return gbuf[cur[0]]
+
+    def mlp_tail(i):            # what the MLP branch of block i wants from the writer in front of it
+        return dict(gb=gb_write(), rowscale=ctxs[i].ds2, rows_per_sample=256, dbias=arena.g(f"{pre}blocks.{i}.mlp.fc2.bias"))
+
     have_gb = False
     if d_tokens is not None:
         tail = mlp_tail(top) if top not in tap_at else {}
@@ -276,17 +294,17 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
         c = ctxs[i]
         if i in tap_at:
             j, xt, m, r = tap_at[i]
-            side.wait(gb_reader)
             ops.ln_bwd(d_taps[j].reshape(R, E), xt, m, r, arena.w(f"{pre}norm_seg.{j}.weight"), g,
                        arena.g(f"{pre}norm_seg.{j}.weight"), arena.g(f"{pre}norm_seg.{j}.bias"), accumulate=True,
                        **mlp_tail(i))
             have_gb = True
         if not have_gb:          # only when no gradient reached the final norm: plain cast + column sum
-            side.wait(gb_reader)
-            ops.scale_cast_rows(g, gb, c.ds2, 256)
-            ops.colsum_bf16(gb, arena.g(b + "mlp.fc2.bias"))
+            gbw = gb_write()
+            ops.scale_cast_rows(g, gbw, c.ds2, 256)
+            ops.colsum_bf16(gbw, arena.g(b + "mlp.fc2.bias"))
         # ---- MLP branch: x_out = x_mid + ds2 * fc2(gelu(fc1(LN2(x_mid))))
         gact, y2, att, y1 = c.gact, c.y2, c.att, c.y1
+        gb = gb_read()
         if gact is None:            # fused-MLP forward kept only u: gelu(u) comes out of the gelu'(u) epilogue below
             gact = torch.empty_like(c.u)
             du = ops.gemm_nt(gb, arena.wbt(b + "mlp.fc2.weight"), epilogue=ops.EPI_DGELU, aux=c.u, out2=gact,
@@ -294,40 +312,52 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
         else:
             du = ops.gemm_nt(gb, arena.wbt(b + "mlp.fc2.weight"), epilogue=ops.EPI_DGELU, aux=c.u,
                              colsum=arena.g(b + "mlp.fc1.bias"))
+
         # both weight gradients of the MLP in ONE launch (ccd_gemm_tn_pair: the same rows, one atomic epilogue per workgroup)
-        gb_reader = side.run(lambda du=du, gact=gact: ops.gemm_tn_pair(gb, gact, arena.g(b + "mlp.fc2.weight"), du, y2,
-                                                                       arena.g(b + "mlp.fc1.weight")), gb, gact, du, y2)
-        side.wait(gb_reader)                                 # norm2's backward rewrites gb
+        def mlp_grads(gb=gb, du=du, gact=gact):
+            ops.gemm_tn_pair(gb, gact, arena.g(b + "mlp.fc2.weight"), du, y2, arena.g(b + "mlp.fc1.weight"))
         if fuse_lnbwd:           # dy2 = du . W1 never leaves the chip: LayerNorm-2's backward is the product's epilogue
+            readers[cur[0]] = side.run(mlp_grads, gb, gact, du, y2)
             ops.gemm_nt_lnbwd(du, arena.wbt(b + "mlp.fc1.weight"), c.x_mid, c.mean2, c.rstd2, arena.w(b + "norm2.weight"), g,
-                              arena.g(b + "norm2.weight"), arena.g(b + "norm2.bias"), accumulate=True, gb=gb, rowscale=c.ds1,
+                              arena.g(b + "norm2.weight"), arena.g(b + "norm2.bias"), accumulate=True, gb=gb_write(), rowscale=c.ds1,
                               rows_per_sample=256, dbias=arena.g(b + "attn.proj.bias"))
         else:
+            # unfused: the product first, THEN the weight-gradient launch (side stream: it starts once the product is done) and
+            # the HBM-bound LayerNorm backward beside it - ln_bwd_kernel's 6 KiB of LDS and 44 registers fit next to a 144-KiB
+            # gemm_tn384 workgroup, so the two share the CUs instead of taking turns
             dy2 = ops.gemm_nt(du, arena.wbt(b + "mlp.fc1.weight"))
+            readers[cur[0]] = side.run(mlp_grads, gb, gact, du, y2)
             ops.ln_bwd(dy2, c.x_mid, c.mean2, c.rstd2, arena.w(b + "norm2.weight"), g, arena.g(b + "norm2.weight"),
-                       arena.g(b + "norm2.bias"), accumulate=True, gb=gb, rowscale=c.ds1, rows_per_sample=256,
+                       arena.g(b + "norm2.bias"), accumulate=True, gb=gb_write(), rowscale=c.ds1, rows_per_sample=256,
                        dbias=arena.g(b + "attn.proj.bias"))
         del du
         # ---- attention branch: x_mid = x_in + ds1 * proj(attn(qkv(LN1(x_in))))
+        gb = gb_read()
         d_att = ops.gemm_nt(gb, arena.wbt(b + "attn.proj.weight"))
-        # (the qkv-bias gradient = column sums of d_qkv comes out of the attention-backward kernels' fp32 result tiles:
-        # round 2 ran a separate colsum pass over the 302 MB of d_qkv per block, 0.95 ms per step)
+        # the qkv-bias gradient = column sums of d_qkv without a pass over d_qkv (round 2: 0.95 ms per step of colsum launches):
+        # q part from the dQ kernel's fp32 tiles, k part identically zero, v part = colsum(d_att) = colsum(gb) . Wproj, and
+        # colsum(gb) is proj.bias's gradient, final since the LayerNorm-2 backward above (ops.attention_bwd, include/ccd_hip.h)
+        if grad_fresh:
+            dcs, dcs_mat = arena.g(b + "attn.proj.bias"), arena.w(b + "attn.proj.weight")
+        else:       # gradients are being accumulated over several backward passes: the slot holds more than this pass's sum
+            dcs, dcs_mat = ops.colsum_bf16(d_att, torch.zeros(E, dtype=F32, device=dev)), None
         d_qkv = ops.attention_bwd(c.qkv.view(N, 256, 3 * E), c.att, d_att.view(N, 256, E), c.lse, spec.heads, scale,
-                                  d_bias=arena.g(b + "attn.qkv.bias"))
+                                  d_bias=arena.g(b + "attn.qkv.bias"), dout_colsum=dcs, dout_colsum_mat=dcs_mat)
         d_qkv = d_qkv.view(R, 3 * E)
 
-        def qkv_grads(d_qkv=d_qkv):
-            # proj.weight's gradient waits for qkv.weight's: one launch for both (gb is not rewritten before norm1's backward)
+        def qkv_grads(gb=gb, d_qkv=d_qkv):
+            # proj.weight's gradient waits for qkv.weight's: one launch for both
             ops.gemm_tn_pair(gb, att.view(R, E), arena.g(b + "attn.proj.weight"), d_qkv, y1, arena.g(b + "attn.qkv.weight"))
-        gb_reader = side.run(qkv_grads, gb, att, d_qkv, y1)
-        tail = mlp_tail(i - 1) if (i > 0 and (i - 1) not in tap_at) else {}
-        if tail:
-            side.wait(gb_reader)                             # this LayerNorm backward rewrites gb for the next block
+        want_tail = i > 0 and (i - 1) not in tap_at
         if fuse_lnbwd:
+            readers[cur[0]] = side.run(qkv_grads, gb, att, d_qkv, y1)
+            tail = mlp_tail(i - 1) if want_tail else {}
             ops.gemm_nt_lnbwd(d_qkv, arena.wbt(b + "attn.qkv.weight"), c.x_in, c.mean1, c.rstd1, arena.w(b + "norm1.weight"), g,
                               arena.g(b + "norm1.weight"), arena.g(b + "norm1.bias"), accumulate=True, **tail)
         else:
             dy1 = ops.gemm_nt(d_qkv, arena.wbt(b + "attn.qkv.weight"))
+            readers[cur[0]] = side.run(qkv_grads, gb, att, d_qkv, y1)
+            tail = mlp_tail(i - 1) if want_tail else {}
             ops.ln_bwd(dy1, c.x_in, c.mean1, c.rstd1, arena.w(b + "norm1.weight"), g, arena.g(b + "norm1.weight"),
                        arena.g(b + "norm1.bias"), accumulate=True, **tail)
         have_gb = bool(tail)

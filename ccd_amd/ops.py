@@ -304,23 +304,28 @@ def attention_fwd(qkv, heads, scale):
     return out, lse
 
 
-def attention_bwd(qkv, out, d_out, lse, heads, scale, d_bias=None):
-    """-> d_qkv bf16 [views,256,3E].  d_bias (fp32 [3E], optional): += column sums of d_qkv over all rows (the qkv-bias
-    gradient), taken from the fp32 result tiles inside the kernels."""
+def attention_bwd(qkv, out, d_out, lse, heads, scale, d_bias=None, dout_colsum=None, dout_colsum_mat=None):
+    """-> d_qkv bf16 [views,256,3E].  d_bias (fp32 [3E], optional): += the qkv-bias gradient (column sums of d_qkv) without a
+    pass over d_qkv - q part inside the dQ kernel, k part identically 0, v part = colsum(d_out) = `dout_colsum` [E], or
+    `dout_colsum` [E] @ `dout_colsum_mat` [E, E] when the caller knows d_out = gb @ mat (see include/ccd_hip.h)."""
     _chk(qkv, BF16, "qkv"); _chk(out, BF16, "out"); _chk(d_out, BF16, "d_out"); _chk(d_bias, F32, "d_bias")
+    _chk(dout_colsum, F32, "dout_colsum"); _chk(dout_colsum_mat, F32, "dout_colsum_mat")
     assert qkv.is_contiguous() and out.is_contiguous() and d_out.is_contiguous()
     views = qkv.shape[0]
     d_qkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
     ws = None
     if d_bias is not None:
-        assert d_bias.numel() == qkv.shape[2] and d_bias.is_contiguous()
+        assert d_bias.numel() == qkv.shape[2] and d_bias.is_contiguous() and dout_colsum is not None
+        assert dout_colsum.numel() == qkv.shape[2] // 3 and dout_colsum.is_contiguous()
         ws = torch.empty(int(_lib.get().ccd_attention_bwd_ws_floats(views, heads)), dtype=F32, device=qkv.device)
     # five products (S, dP, dV, dK, dQ) of 2 * 256 * 256 * 64 flop per (view, head); q, k, v, o, dO read and dq, dk, dv written once
     with _Span("attention_bwd", views * heads * 10.0 * 256 * 256 * 64, views * heads * (8.0 * 256 * 64 * 2 + 8.0 * 256)):
         _lib.check(_lib.get().ccd_attention_bwd(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(d_out), _lib.ptr(lse),
                                                 _lib.ptr(delta), _lib.ptr(d_qkv), views, heads, float(scale),
-                                                _lib.ptr(d_bias), _lib.ptr(ws), _lib.stream()), "attention_bwd")
+                                                _lib.ptr(d_bias), _lib.ptr(ws), _lib.ptr(dout_colsum), _lib.ptr(dout_colsum_mat),
+                                                0 if dout_colsum_mat is None else dout_colsum_mat.stride(0), _lib.stream()),
+                   "attention_bwd")
     return d_qkv
 
 

@@ -135,14 +135,20 @@ int ccd_ln_bwd(const ccd_bf16* dy, const float* x, const float* mean, const floa
  * qkv [views, 256, 3, heads, 64] bf16 (the layout Attention.forward reshapes to), out [views, 256, heads*64]  */
 int ccd_attention_fwd(const ccd_bf16* qkv, ccd_bf16* out, float* lse, int views, int heads, float scale,
                       void* stream);
-/* d_qkv_bias (nullable, fp32 [3 * heads * 64], ACCUMULATED): column sums of d_qkv over all views * 256 rows - the gradient of the
- * qkv bias (vit.py:75 `qkv_bias`, what autograd's Linear backward computes as grad_output.sum(0)) - taken from the fp32 result
- * tiles inside the kernels.  It needs bias_ws: ccd_attention_bwd_ws_floats(views, heads) floats of scratch (per-workgroup
- * partial sums, plain stores) that a tiny third launch adds up. */
+/* d_qkv_bias (nullable, fp32 [3 * heads * 64], ACCUMULATED): the gradient of the qkv bias (vit.py:75 `qkv_bias`; what autograd's
+ * Linear backward computes as grad_output.sum(0) over d_qkv) without a pass over d_qkv:
+ *   q part  column sums of the fp32 dQ tiles, inside the dQ kernel; needs bias_ws = ccd_attention_bwd_ws_floats(views, heads)
+ *           floats of scratch (per-workgroup partial rows, plain stores)
+ *   k part  identically zero (the softmax is shift invariant): nothing is added
+ *   v part  = column sums of d_out (every softmax row sums to 1), which the caller supplies WITHOUT touching d_out:
+ *           dout_colsum_mat == null: dout_colsum_vec [E] IS colsum(d_out);
+ *           otherwise colsum(d_out) = dout_colsum_vec [E] . dout_colsum_mat [E, E] (row-major, ld_mat) - for d_out = gb . Wproj
+ *           (vit.py:90-91) that is (proj.bias gradient) . (proj.weight).
+ * A third, tiny launch adds the partial rows up and forms the matvec. */
 long ccd_attention_bwd_ws_floats(int views, int heads);
 int ccd_attention_bwd(const ccd_bf16* qkv, const ccd_bf16* out, const ccd_bf16* d_out, const float* lse,
                       float* delta_ws, ccd_bf16* d_qkv, int views, int heads, float scale, float* d_qkv_bias, float* bias_ws,
-                      void* stream);
+                      const float* dout_colsum_vec, const float* dout_colsum_mat, long ld_mat, void* stream);
 
 /* ---------------------------------------------------------------- patch embedding, vit.py:128-131,225-236
  * img [views,3,32,128] fp32 NCHW; w [E,3,4,4]; pos [256,E] = the bicubically resampled pos_embed; out fp32 [views*256,E] */

@@ -218,13 +218,25 @@ def check_attention(dev, views, heads, seed=3, spike=False):
     close(lse, torch.logsumexp((q @ k.transpose(-2, -1)) * scale, dim=-1), 1e-3, 2e-3, "attn/lse")
     d_out = rnd((views, 256, E), g).to(BF)
     ref.backward(d_out.float())
+    # the qkv-bias gradient without a pass over d_qkv: q part from the dQ kernel's fp32 tiles, k part identically zero (nothing
+    # added), v part = colsum(d_out) handed in - once as the vector itself, once factored as vec @ mat (d_out = gb @ mat)
     d_bias = torch.full((3 * E,), 0.5, dtype=torch.float32, device=dev)          # accumulated into, not overwritten
-    d_qkv = ops.attention_bwd(qkv.to(dev), out, d_out.to(dev), lse, heads, scale, d_bias=d_bias)
+    dcs = d_out.float().sum((0, 1)).to(dev)
+    d_qkv = ops.attention_bwd(qkv.to(dev), out, d_out.to(dev), lse, heads, scale, d_bias=d_bias, dout_colsum=dcs)
     want = qf.grad
-    # the qkv-bias gradient: column sums over all rows (fp32 tiles inside the kernels; the stored d_qkv is their bf16 rounding)
-    want_b = want.reshape(-1, 3 * E).double().sum(0)
+    want_b = want.reshape(-1, 3 * E).double().sum(0).float()
     # (rounding errors of the bf16 operands add up like a random walk over the rows: measured 0.02 at 768 rows, |element| < 1)
-    close(d_bias - 0.5, want_b.float(), 1e-2, 4e-3 * (views * 256) ** 0.5 * want.abs().max().item(), "attn/d_qkv_bias")
+    tol_b = 4e-3 * (views * 256) ** 0.5 * want.abs().max().item()
+    got_b = d_bias.cpu() - 0.5
+    close(got_b[:E], want_b[:E], 1e-2, tol_b, "attn/d_qkv_bias q")
+    close(got_b[2 * E:], want_b[2 * E:], 1e-2, tol_b, "attn/d_qkv_bias v")
+    assert bool((got_b[E:2 * E] == 0).all()) and want_b[E:2 * E].abs().max().item() < tol_b, "the key bias has no gradient"
+    vec = rnd((E,), g).to(dev)
+    mat = (torch.outer(vec.cpu(), dcs.cpu()) / vec.cpu().pow(2).sum() + 0.0).to(dev)      # vec @ mat == dcs
+    d_bias2 = torch.zeros(3 * E, dtype=torch.float32, device=dev)
+    ops.attention_bwd(qkv.to(dev), out, d_out.to(dev), lse, heads, scale, d_bias=d_bias2, dout_colsum=vec, dout_colsum_mat=mat)
+    close(d_bias2.cpu()[2 * E:], dcs.cpu(), 1e-4, 1e-4 * dcs.abs().max().item(), "attn/d_qkv_bias v (factored)")
+    close(d_bias2.cpu()[:E], got_b[:E], 1e-5, 1e-5 * tol_b, "attn/d_qkv_bias q (second launch)")
     d_plain = ops.attention_bwd(qkv.to(dev), out, d_out.to(dev), lse, heads, scale)      # without the bias gradient: same d_qkv
     assert torch.equal(d_plain, d_qkv)
     for i, nm in enumerate("qkv"):

@@ -273,10 +273,6 @@ def test_mlp_fused_sim(sim):
     """Ragged last tile, several tiles per workgroup (1 CU), a dropped sample, both instantiations of E."""
     kc.check_mlp_fused(sim.device, M=300, E=128, H=256, rps=128)
     kc.check_mlp_fused(sim.device, M=200, E=384, H=128, rps=8, store_u=False)     # per-row DropPath scales
-    from ccd_amd import ops
-    with ops.policy(mlp_gelu_poly=1):                                              # GELU by the packed polynomial, no LDS table
-        kc.check_mlp_fused(sim.device, M=200, E=384, H=128, rps=8, store_u=False)
-        kc.check_mlp_fused(sim.device, M=140, E=384, H=192, rps=128, seed=5)
     kc.check_mlp_fused(sim.device, M=130, E=512, H=128, rps=8)                     # 3-slot ring (vit_base)
 
 

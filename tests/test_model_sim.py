@@ -17,6 +17,19 @@ def test_tiny_training_iteration_sim(sim):
     mc.check_tiny_step(sim.device)
 
 
+@pytest.mark.parametrize("lnbwd", [True, False])
+def test_tiny_training_iteration_rotating_gb_buffers_sim(sim, lnbwd):
+    """The backward pass of the side-stream mode (two gb buffers used in turn; LayerNorm backward fused into the data-gradient
+    product or as its own launch behind it) must give the same iteration - here without a second stream, on the CPU executor."""
+    from ccd_amd import engine
+    saved = (engine.Fusion.double_gb, engine.Fusion.lnbwd)
+    engine.Fusion.double_gb, engine.Fusion.lnbwd = True, lnbwd
+    try:
+        mc.check_tiny_step(sim.device)
+    finally:
+        engine.Fusion.double_gb, engine.Fusion.lnbwd = saved
+
+
 def test_optimizer_steps_sim(sim):
     mc.check_optimizer_host_runs_ahead(sim.device, steps=3)
 
