@@ -26,7 +26,10 @@ import torch.distributed as dist
 PEAK_BF16_TF = 2500.0       # MI355X dense bf16 MFMA peak (guide: MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (~6.3 TB/s achievable)
 GF_PER_IMAGE = {"vit_small": (96.7 + 8.7, 44.56e-3 * 4), "vit_base": (167.6 + 10.1, 45.09e-3 * 4),
-                "vit_tiny": (25.6 + 6.6, 43.9e-3 * 4)}   # (backbone+seg GF/img, head GF per selected row pair) SURVEY 8d
+                "vit_tiny": (25.6 + 6.6, 43.9e-3 * 4),
+                # E = 768 / 12 heads: 12 (2 * 256 * 12 E^2 + 4 * 256^2 E) = 45.9 GF per view forward, x 8 (2 views: student fwd +
+                # 2 x bwd + teacher fwd); segmentation head 2.13 GF per view forward x 6; head 46.13 MF per row x 4
+                "vit_base_768": (367.2 + 12.8, 46.13e-3 * 4)}   # (backbone+seg GF/img, head GF per selected row pair) SURVEY 8d
 
 
 # timer kind (ccd_amd/ops.py spans) -> the kernel(s) of ccd_amd/csrc/kernels that the launches of that kind run at the default policy
@@ -448,7 +451,8 @@ def main():
         m_rows = m_local / B
         body, per_row = GF_PER_IMAGE.get(a.arch, GF_PER_IMAGE["vit_small"])
         gf_img = body + per_row * 2 * m_rows
-        arch_name = {"vit_small": "CCD-ViT-Small", "vit_base": "CCD-ViT-Base", "vit_tiny": "CCD-ViT-Tiny"}.get(a.arch, a.arch)
+        arch_name = {"vit_small": "CCD-ViT-Small", "vit_base": "CCD-ViT-Base", "vit_tiny": "CCD-ViT-Tiny",
+                     "vit_base_768": "CCD-ViT-Base (768/12)"}.get(a.arch, a.arch)
         line = {"metric": f"images/sec (32x128 crops, 2 views) {arch_name} pretrain step", "value": round(ips, 2),
                 "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

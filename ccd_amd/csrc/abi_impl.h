@@ -509,9 +509,11 @@ int ccd_ln_fwd(const float* x, const float* gamma, const float* beta, ccd_bf16* 
                int E, float eps, void* stream) {
     CCD_CHECK(x && gamma && beta && y && mean && rstd, CCD_EINVAL);
     if (rows == 0) return CCD_OK;
-    CCD_CHECK(rows > 0 && E > 0 && E % 4 == 0 && E <= 64 * ccd::LN_VEC * ccd::LN_STEPS, CCD_ESHAPE);
-    CCD_LAUNCH(ccd::ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, rows, E,
-               eps);
+    CCD_CHECK(rows > 0 && E > 0 && E % 4 == 0 && E <= 1024, CCD_ESHAPE);
+    if (ccd::ln_steps(E) == 2)
+        CCD_LAUNCH((ccd::ln_fwd_kernel<2>), dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, rows, E, eps);
+    else
+        CCD_LAUNCH((ccd::ln_fwd_kernel<4>), dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, rows, E, eps);
     return ccd_rt_last_error();
 }
 
@@ -520,18 +522,17 @@ int ccd_ln_bwd(const ccd_bf16* dy, const float* x, const float* mean, const floa
                float* dbias, int rows, int E, void* stream) {
     CCD_CHECK(dy && x && mean && rstd && gamma && g && dgamma && dbeta, CCD_EINVAL);
     if (rows == 0) return CCD_OK;
-    CCD_CHECK(rows > 0 && E > 0 && E % 4 == 0 && E <= 64 * ccd::LN_VEC * ccd::LN_STEPS, CCD_ESHAPE);
+    CCD_CHECK(rows > 0 && E > 0 && E % 4 == 0 && E <= 1024, CCD_ESHAPE);
     CCD_CHECK(!rowscale || rows_per_sample > 0, CCD_EINVAL);
     int blocks = ccd_policy().ln_bwd_bpc * ccd_rt_num_cus();   // one resident wave of blocks (measured 187 -> 165 us vs 8 / CU)
     int rpb = (rows + blocks - 1) / blocks;
     rpb = ((rpb + 3) / 4) * 4;
     blocks = (rows + rpb - 1) / rpb;
-    if (accumulate)
-        CCD_LAUNCH((ccd::ln_bwd_kernel<true>), dim3(blocks), dim3(256), 0, stream, dy, x, mean, rstd, gamma, g, dgamma,
-                   dbeta, gb, rowscale, rows_per_sample, dbias, rows, E, rpb);
-    else
-        CCD_LAUNCH((ccd::ln_bwd_kernel<false>), dim3(blocks), dim3(256), 0, stream, dy, x, mean, rstd, gamma, g, dgamma,
-                   dbeta, gb, rowscale, rows_per_sample, dbias, rows, E, rpb);
+#define CCD_LN_BWD(ACC, ST) CCD_LAUNCH((ccd::ln_bwd_kernel<ACC, ST>), dim3(blocks), dim3(256), 0, stream, dy, x, mean, rstd, gamma, g, \
+                                       dgamma, dbeta, gb, rowscale, rows_per_sample, dbias, rows, E, rpb)
+    if (ccd::ln_steps(E) == 2) { if (accumulate) CCD_LN_BWD(true, 2); else CCD_LN_BWD(false, 2); }
+    else { if (accumulate) CCD_LN_BWD(true, 4); else CCD_LN_BWD(false, 4); }
+#undef CCD_LN_BWD
     return ccd_rt_last_error();
 }
 
@@ -680,14 +681,17 @@ int ccd_kmeans2_mask(const uint8_t* gray, const long* offsets, const int* hw, ui
     CCD_LAUNCH(ccd::kmeans2_mask_kernel, dim3(images), dim3(ccd::KM_THREADS), 0, stream, gray, offsets, hw, mask);
     return ccd_rt_last_error();
 }
-int ccd_augment_views(const uint8_t* img, const float* params, const float* theta, float* out, int batch, int height, int width,
-                      const float* mean3, const float* std3, void* stream) {
-    CCD_CHECK(img && params && theta && out && mean3 && std3 && batch >= 0, CCD_EINVAL);
+int ccd_augment_views(const uint8_t* img, const float* params, const float* theta, float* out, uint8_t* staged_ws, int batch,
+                      int height, int width, const float* mean3, const float* std3, void* stream) {
+    CCD_CHECK(img && params && theta && out && staged_ws && mean3 && std3 && batch >= 0, CCD_EINVAL);
     CCD_CHECK(height >= 2 && width >= 2 && (long)height * width < (1L << 24), CCD_ESHAPE);
+    CCD_CHECK(ccd::aug_spatial_smem(height, width) <= 160 * 1024, CCD_ESHAPE);      // the pre-pass keeps a (sample, view) image in LDS
     CCD_CHECK(std3[0] > 0.f && std3[1] > 0.f && std3[2] > 0.f, CCD_EINVAL);
     if (batch == 0) return CCD_OK;
-    CCD_LAUNCH(ccd::augment_views_kernel, dim3((height * width + 255) / 256, batch), dim3(256), 0, stream, img, params, theta, out,
-               batch, height, width, mean3[0], mean3[1], mean3[2], 1.0f / std3[0], 1.0f / std3[1], 1.0f / std3[2]);
+    CCD_LAUNCH(ccd::augment_spatial_kernel, dim3(2 * batch), dim3(256), (int)ccd::aug_spatial_smem(height, width), stream, img, params,
+               staged_ws, height, width);
+    CCD_LAUNCH(ccd::augment_views_kernel, dim3((height * width + 255) / 256, batch), dim3(256), 0, stream, img, staged_ws, params, theta,
+               out, batch, height, width, mean3[0], mean3[1], mean3[2], 1.0f / std3[0], 1.0f / std3[1], 1.0f / std3[2]);
     return ccd_rt_last_error();
 }
 int ccd_warp_idmap(const uint8_t* src, const float* theta, int theta_stride, uint8_t* dst, int images, void* stream) {

@@ -1,13 +1,15 @@
 // layernorm.h - LayerNorm(eps) over the fp32 residual stream, bf16 out (vision_transformer.py:99,103,156,162).
-// One wave per token row, 16-byte fp32 / 8-byte bf16 accesses (4 elements per lane and step, E <= 512), statistics
+// One wave per token row, 16-byte fp32 / 8-byte bf16 accesses (4 elements per lane and step; STEPS = 2 for E <= 512, 4 for E <= 1024), statistics
 // by wave shuffles.  HBM-bound: algorithmic bytes per row = 4E (x) + 2E (y) forward;
 // backward 2E (dy) + 4E (x) + 8E (g read+write) [+ 2E for the fused bf16 copy of the updated gradient stream].
 #pragma once
 
 namespace ccd {
 
-constexpr int LN_VEC = 4, LN_STEPS = 2;          // lane l owns elements 4*(l + 64*s) .. +3, s < LN_STEPS  (E <= 512)
+constexpr int LN_VEC = 4;                        // lane l owns elements 4*(l + 64*s) .. +3, s < LN_STEPS (template parameter)
+__host__ __device__ constexpr int ln_steps(int E) { return E <= 512 ? 2 : 4; }       // E <= 1024 (vit_base_768: 3 live steps of 4)
 
+template <int LN_STEPS>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // Optional fused tail (gb != null): gb[row,:] = bf16(g_new[row,:] * rowscale[row / rows_per_sample]) - the gradient
 // entering the NEXT residual branch with that branch's DropPath scale - and dbias += column sums of gb (the bias
 // gradient of that branch's output projection).  Saves a pass over g and a pass over gb per branch.
-template <bool ACCUM>
+template <bool ACCUM, int LN_STEPS>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, float* __restrict__ g,

@@ -4,8 +4,10 @@ Drop-in for `Dino.dataset.dataset_pretrain.ImageDataset` (reference :18-277): re
 `num-samples`; training samples are (normalised image fp32 [3,h,w], target indices [max_length] from AttnConvertor.str2tensor,
 :215-222), evaluation samples are (image, [raw_label]) so that the default collate hands TextAccuracy a tuple of strings
 in `label_tensors[0]` (eval_acc.py:37).  Empty labels and labels that encode to nothing are skipped in training like the
-reference does (:213-221).  The finetuning-time imgaug pipeline (:70-158) is not reproduced here (finetuning in this
-implementation augments nothing on the host); resize + ToTensor + ImageNet normalisation are (:250-258)."""
+reference does (:213-221).  With `data_aug` (training only) a sample is the RESIZED UINT8 image and the finetuning-time imgaug
+pipeline (:70-158) runs per batch on the device: `DeviceImageAugmenter` below (sampler: augment.sample_finetune_params; kernels:
+csrc/kernels/datapipe.h) hands the model the normalised fp32 batch.  Without it: resize + ToTensor + ImageNet normalisation
+on the host (:250-258)."""
 from __future__ import annotations
 
 import io
@@ -32,6 +34,7 @@ class ImageDataset(Dataset):
         if multiscales:
             raise NotImplementedError("multiscales=True is not used by the CCD configs")
         self.is_training, self.img_h, self.img_w, self.convert_mode = bool(is_training), int(img_h), int(img_w), convert_mode
+        self.data_aug = bool(is_training) and bool(data_aug)                       # (:68 `if self.is_training and self.data_aug`)
         self.label_convertor = AttnConvertor(dict_type=type, max_seq_len=max_length, with_unknown=True)
         self._env = None
         with lmdb_file.LmdbReader(self.path) as env:
@@ -89,6 +92,8 @@ class ImageDataset(Dataset):
             return None
         image, text = datum
         arr = resize_bilinear(np.asarray(image), self.img_h, self.img_w)
+        if self.data_aug:                     # uint8 [h, w, 3]: augmented + normalised per batch by DeviceImageAugmenter
+            return torch.from_numpy(np.ascontiguousarray(arr)), text
         ten = torch.from_numpy(arr).permute(2, 0, 1).float().div(255.0)             # ToTensor
         return (ten - self._mean) / self._std, text
 
@@ -96,3 +101,24 @@ class ImageDataset(Dataset):
 def collate_fn_filter_none(batch):
     batch = [b for b in batch if b is not None]
     return default_collate(batch)
+
+
+class DeviceImageAugmenter:
+    """images uint8 [B,h,w,3] -> normalised fp32 [B,3,h,w] on the GPU: `_process_training` of the labelled dataset
+    (dataset_pretrain.py:250-253: augment_tfs, resize, ToTensor, normalize) with the augmentation after the resize, one
+    launch pair per batch (ops.augment_views: the colour + warp view)."""
+
+    def __init__(self, img_h=32, img_w=128, seed=0, device=None):
+        self.h, self.w, self.device = int(img_h), int(img_w), device
+        self.rs = np.random.RandomState(seed)
+
+    def __call__(self, images_u8):
+        from .. import ops
+        from .augment import sample_finetune_params
+        dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+        B = images_u8.shape[0]
+        assert tuple(images_u8.shape[1:]) == (self.h, self.w, 3) and images_u8.dtype == torch.uint8
+        params, theta = sample_finetune_params(self.rs, B, self.h, self.w)
+        out = ops.augment_views(images_u8.to(dev, non_blocking=True).contiguous(), torch.from_numpy(params).to(dev),
+                                torch.from_numpy(theta).to(dev), MEAN, STD)
+        return out[:, 2].contiguous()

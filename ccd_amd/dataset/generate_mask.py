@@ -32,35 +32,39 @@ def generate(root, out, batch=512, device=None, start=1, end=None):
     env = lmdb_file.LmdbReader(root)
     n = int(env.get(b"num-samples"))
     end = n if end is None else min(end, n)
-    records, cnt = {}, 0
-    pending, keys = [], []
+    cnt = 0
 
-    def flush():
-        nonlocal pending, keys, cnt
-        if not pending:
-            return
-        for k, m in zip(keys, ops.kmeans2_mask(pending, device=device)):
-            records[k] = _png(m)
-            cnt += 1
+    def records():
+        """(key, PNG) in key order - `mask-%09d` by increasing index, then `num-samples` - one device batch in memory at a time:
+        write_lmdb(presorted=True) streams them to disk (the reference's cached writer, generate_mask.py:48-58)."""
+        nonlocal cnt
         pending, keys = [], []
 
-    for index in range(start, end + 1):
-        buf = env.get(b"image-%09d" % index)
-        try:
-            g = _gray(buf)
-            if g.shape[0] < 2 and g.shape[1] < 2:                  # generate_mask.py:70-72
+        def flush():
+            nonlocal pending, keys, cnt
+            out_recs = [(k, _png(m)) for k, m in zip(keys, ops.kmeans2_mask(pending, device=device))] if pending else []
+            cnt += len(out_recs)
+            pending, keys = [], []
+            return out_recs
+
+        for index in range(start, end + 1):
+            buf = env.get(b"image-%09d" % index)
+            try:
+                g = _gray(buf)
+                if g.shape[0] < 2 and g.shape[1] < 2:                  # generate_mask.py:70-72
+                    continue
+            except Exception:
+                print(f"Corrupted image for {index}")
                 continue
-        except Exception:
-            print(f"Corrupted image for {index}")
-            continue
-        pending.append(g)
-        keys.append(b"mask-%09d" % index)
-        if len(pending) >= batch:
-            flush()
-    flush()
-    records[b"num-samples"] = str(cnt).encode()
+            pending.append(g)
+            keys.append(b"mask-%09d" % index)
+            if len(pending) >= batch:
+                yield from flush()
+        yield from flush()
+        yield b"num-samples", str(cnt).encode()
+
     os.makedirs(out, exist_ok=True)
-    stat = lmdb_file.write_lmdb(out, records)
+    stat = lmdb_file.write_lmdb(out, records(), presorted=True)
     print(f"Created dataset with {cnt} samples")
     return stat
 

@@ -218,27 +218,39 @@ def open(path, readonly=True, **_ignored):          # noqa: A001 - `lmdb.open(pa
 
 
 # ---------------------------------------------------------------------------------------------------- bulk writer
-def write_lmdb(path, items, psize=4096):
+def write_lmdb(path, items, psize=4096, presorted=False):
     """Create the environment `path` (a directory) holding `items` (mapping or iterable of (key, value) byte strings) in
     ONE committed transaction - what generate_mask.py / the dataset converters do with put() in a loop.  Produces the same
     structures liblmdb's append-mode load does: sorted leaves filled front to back, values larger than a quarter page
-    (liblmdb: node > (psize - 16) / 2 with its 2 minimum keys) on overflow runs, branch levels on top."""
-    pairs = sorted(((k.encode() if isinstance(k, str) else bytes(k), bytes(v)) for k, v in
-                    (items.items() if hasattr(items, "items") else items)), key=lambda kv: kv[0])
-    for (a, _), (b, _) in zip(pairs, pairs[1:]):
-        if a == b:
-            raise ValueError(f"duplicate key {a!r}")
+    (liblmdb: node > (psize - 16) / 2 with its 2 minimum keys) on overflow runs, branch levels on top.
+    `presorted=True`: `items` is an ITERATOR that yields strictly increasing keys (MDB_APPEND's contract); pages are written
+    to the file as they fill and only the (first key, page) index of each level stays in memory - the reference builds its
+    mask databases for multi-million-image datasets the same way, with a write cache flushed every 1000 records
+    (generate_mask.py:48-58)."""
+    def norm(kv):
+        k, v = kv
+        return (k.encode() if isinstance(k, str) else bytes(k)), bytes(v)
+    if presorted:
+        pairs = (norm(kv) for kv in items)
+    else:
+        pairs = sorted((norm(kv) for kv in (items.items() if hasattr(items, "items") else items)), key=lambda kv: kv[0])
     maxkey = 511
-    for k, _ in pairs:
-        if not 0 < len(k) <= maxkey:
-            raise ValueError(f"key length {len(k)} outside 1..{maxkey}")
     os.makedirs(path, exist_ok=True)
-    pages = {}                      # pgno -> bytes
-    next_pg = 2
     nodemax = (((psize - PAGEHDR) // 2) & ~1) - 2    # me_nodemax: larger leaf nodes put their data on overflow pages
-    n_leaf = n_branch = n_ovf = 0
+    counts = {"leaf": 0, "branch": 0, "ovf": 0, "entries": 0}
+    state = {"next_pg": 2}
+    f = builtins.open(os.path.join(path, "data.mdb"), "wb")
+    f.write(b"\0" * (2 * psize))                      # the two meta pages are written last
 
-    def new_page_image(pgno, flags, nodes):
+    def emit(image):
+        """Append page images (whole pages) at page number next_pg."""
+        assert f.tell() == state["next_pg"] * psize and len(image) % psize == 0
+        f.write(image)
+        first = state["next_pg"]
+        state["next_pg"] += len(image) // psize
+        return first
+
+    def page_image(pgno, flags, nodes):
         """nodes: list of encoded node byte strings (2-byte aligned); laid out from the page end downwards."""
         buf = bytearray(psize)
         upper = psize
@@ -257,93 +269,88 @@ def write_lmdb(path, items, psize=4096):
     def even(b):
         return b + b"\0" if len(b) & 1 else b
 
-    # ---- leaves
+    # ---- leaves (and the overflow runs of their big values), streamed
     level = []                      # (first key, pgno) of the pages of the level being built
-    cur, used = [], PAGEHDR
-    first_key = None
+    cur, used, first_key, prev_key = [], PAGEHDR, None, None
 
-    def flush_leaf():
-        nonlocal cur, used, first_key, next_pg, n_leaf
+    def flush(flags, kind):
+        nonlocal cur, used, first_key
         if not cur:
             return
-        pages[next_pg] = new_page_image(next_pg, P_LEAF, cur)
-        level.append((first_key, next_pg))
-        next_pg += 1
-        n_leaf += 1
+        pg = emit(page_image(state["next_pg"], flags, cur))
+        level.append((first_key, pg))
+        counts[kind] += 1
         cur, used, first_key = [], PAGEHDR, None
 
-    for k, v in pairs:
-        if NODEHDR + len(k) + len(v) > nodemax:
-            npages = (PAGEHDR + len(v) + psize - 1) // psize
-            ovf = next_pg
-            next_pg += npages
-            n_ovf += npages
-            img = bytearray(npages * psize)
-            struct.pack_into("<QHHI", img, 0, ovf, 0, P_OVERFLOW, npages)
-            img[PAGEHDR: PAGEHDR + len(v)] = v
-            for i in range(npages):
-                pages[ovf + i] = bytes(img[i * psize: (i + 1) * psize])
-            node = struct.pack("<HHHH", len(v) & 0xFFFF, len(v) >> 16, F_BIGDATA, len(k)) + k + struct.pack("<Q", ovf)
-        else:
-            node = struct.pack("<HHHH", len(v) & 0xFFFF, len(v) >> 16, 0, len(k)) + k + v
-        node = even(node)
-        if used + 2 + len(node) > psize:
-            flush_leaf()
-        if first_key is None:
-            first_key = k
-        cur.append(node)
-        used += 2 + len(node)
-    flush_leaf()
-
-    # ---- branch levels
-    depth = 1 if level else 0
-    while len(level) > 1:
-        upper_level = []
-        cur, used, first_key = [], PAGEHDR, None
-        for i, (k, child) in enumerate(level):
-            def enc(key):
-                return even(struct.pack("<HHHH", child & 0xFFFF, (child >> 16) & 0xFFFF, (child >> 32) & 0xFFFF, len(key)) + key)
-            node = enc(b"" if not cur else k)
+    try:
+        for k, v in pairs:
+            if not 0 < len(k) <= maxkey:
+                raise ValueError(f"key length {len(k)} outside 1..{maxkey}")
+            if prev_key is not None and k <= prev_key:
+                raise ValueError(f"duplicate key {k!r}" if k == prev_key else f"keys out of order: {prev_key!r} before {k!r}")
+            prev_key = k
+            counts["entries"] += 1
+            if NODEHDR + len(k) + len(v) > nodemax:
+                npages = (PAGEHDR + len(v) + psize - 1) // psize
+                img = bytearray(npages * psize)
+                struct.pack_into("<QHHI", img, 0, state["next_pg"], 0, P_OVERFLOW, npages)
+                img[PAGEHDR: PAGEHDR + len(v)] = v
+                ovf = emit(bytes(img))
+                counts["ovf"] += npages
+                node = struct.pack("<HHHH", len(v) & 0xFFFF, len(v) >> 16, F_BIGDATA, len(k)) + k + struct.pack("<Q", ovf)
+            else:
+                node = struct.pack("<HHHH", len(v) & 0xFFFF, len(v) >> 16, 0, len(k)) + k + v
+            node = even(node)
             if used + 2 + len(node) > psize:
-                pages[next_pg] = new_page_image(next_pg, P_BRANCH, cur)
-                upper_level.append((first_key, next_pg))
-                next_pg += 1
-                n_branch += 1
-                cur, used, first_key = [], PAGEHDR, None
-                node = enc(b"")
+                flush(P_LEAF, "leaf")
             if first_key is None:
                 first_key = k
             cur.append(node)
             used += 2 + len(node)
-        pages[next_pg] = new_page_image(next_pg, P_BRANCH, cur)
-        upper_level.append((first_key, next_pg))
-        next_pg += 1
-        n_branch += 1
-        level = upper_level
-        depth += 1
-    root = level[0][1] if level else P_INVALID
-    last_pg = next_pg - 1
+        flush(P_LEAF, "leaf")
 
-    def meta(pgno, txnid, with_tree):
-        buf = bytearray(psize)
-        struct.pack_into("<QHHHH", buf, 0, pgno, 0, P_META, 0, 0)
-        mapsize = max(10 << 20, next_pg * psize)
-        _META.pack_into(buf, PAGEHDR, MAGIC, VERSION, 0, mapsize)
-        _DB.pack_into(buf, PAGEHDR + _META.size, psize, 0, 0, 0, 0, 0, 0, P_INVALID)
-        if with_tree:
-            _DB.pack_into(buf, PAGEHDR + _META.size + _DB.size, 0, 0, depth, n_branch, n_leaf, n_ovf, len(pairs), root)
-            lp = last_pg
-        else:
-            _DB.pack_into(buf, PAGEHDR + _META.size + _DB.size, 0, 0, 0, 0, 0, 0, 0, P_INVALID)
-            lp = 1
-        struct.pack_into("<QQ", buf, PAGEHDR + _META.size + 2 * _DB.size, lp, txnid)
-        return bytes(buf)
+        # ---- branch levels
+        depth = 1 if level else 0
+        while len(level) > 1:
+            below, level = level, []
+            for k, child in below:
+                def enc(key):
+                    return even(struct.pack("<HHHH", child & 0xFFFF, (child >> 16) & 0xFFFF, (child >> 32) & 0xFFFF, len(key)) + key)
+                node = enc(b"" if not cur else k)
+                if used + 2 + len(node) > psize:
+                    flush(P_BRANCH, "branch")
+                    node = enc(b"")
+                if first_key is None:
+                    first_key = k
+                cur.append(node)
+                used += 2 + len(node)
+            flush(P_BRANCH, "branch")
+            depth += 1
+        root = level[0][1] if level else P_INVALID
+        last_pg = state["next_pg"] - 1
 
-    with builtins.open(os.path.join(path, "data.mdb"), "wb") as f:
+        def meta(pgno, txnid, with_tree):
+            buf = bytearray(psize)
+            struct.pack_into("<QHHHH", buf, 0, pgno, 0, P_META, 0, 0)
+            mapsize = max(10 << 20, state["next_pg"] * psize)
+            _META.pack_into(buf, PAGEHDR, MAGIC, VERSION, 0, mapsize)
+            _DB.pack_into(buf, PAGEHDR + _META.size, psize, 0, 0, 0, 0, 0, 0, P_INVALID)
+            if with_tree:
+                _DB.pack_into(buf, PAGEHDR + _META.size + _DB.size, 0, 0, depth, counts["branch"], counts["leaf"], counts["ovf"],
+                              counts["entries"], root)
+                lp = last_pg
+            else:
+                _DB.pack_into(buf, PAGEHDR + _META.size + _DB.size, 0, 0, 0, 0, 0, 0, 0, P_INVALID)
+                lp = 1
+            struct.pack_into("<QQ", buf, PAGEHDR + _META.size + 2 * _DB.size, lp, txnid)
+            return bytes(buf)
+
+        f.seek(0)
         f.write(meta(0, 0, False))          # the state before the load (txn 0), as mdb_env_init_meta leaves it
         f.write(meta(1, 1, True))           # the committed load (txn 1 -> meta page 1)
-        for pg in range(2, next_pg):
-            f.write(pages[pg])
-    with builtins.open(os.path.join(path, "lock.mdb"), "wb") as f:
-        f.write(b"\0" * 8192)
-    return {"entries": len(pairs), "depth": depth, "leaf_pages": n_leaf, "branch_pages": n_branch, "overflow_pages": n_ovf}
+    finally:
+        f.close()
+    with builtins.open(os.path.join(path, "lock.mdb"), "wb") as fl:
+        fl.write(b"\0" * 8192)
+    return {"entries": counts["entries"], "depth": depth, "leaf_pages": counts["leaf"], "branch_pages": counts["branch"],
+            "overflow_pages": counts["ovf"]}

@@ -139,6 +139,14 @@ def vit_base(patch_size=16, **kwargs):
                              norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
 
 
+def vit_base_768(patch_size=16, **kwargs):
+    """E = 768 / 12 heads: the shape BASELINE.json config #4 names for "ViT-Base".  The reference's own `vit_base` is 512 / 8
+    (above); 768 / 12 is what its VisionTransformer constructor defaults to (vision_transformer.py:117-120).  Unfused path
+    (the row-owner kernels stop at E = 512): tiled GEMMs, stand-alone LayerNorm kernels with 3 of 4 column steps live."""
+    return VisionTransformer(patch_size=patch_size, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
+                             norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
 class DINOHead(ArenaModule):
     """3-layer GELU MLP -> L2 normalise -> weight-normalised Linear(bottleneck, out_dim, bias=False)."""
 

@@ -427,17 +427,19 @@ def kmeans2_mask(grays, device=None):
 
 
 def augment_views(img, params, theta, mean, std):
-    """img uint8 [B,H,W,3] (resized samples), params fp32 [B,2,32], theta fp32 [B,3,3] -> image_tensors fp32 [B,3,3,H,W]:
+    """img uint8 [B,H,W,3] (resized samples), params fp32 [B,2,96], theta fp32 [B,3,3] -> image_tensors fp32 [B,3,3,H,W]:
     (plain, colour-augmented, colour-augmented + warped by theta), normalised - the dataset's batch contract
-    (datasetsupervised_kmeans.py:48-87)."""
+    (datasetsupervised_kmeans.py:48-87).  The neighbourhood members (JPEG, blurs, convolutions) run in a pre-pass that stages
+    one uint8 image per (sample, view)."""
     import ctypes as C
     assert img.dtype == U8 and img.is_contiguous() and img.dim() == 4 and img.shape[3] == 3
     _chk(params, F32, "params"); _chk(theta, F32, "theta")
     B, H, W, _ = img.shape
-    assert tuple(params.shape) == (B, 2, 32) and tuple(theta.shape) == (B, 3, 3)
+    assert tuple(params.shape) == (B, 2, 96) and tuple(theta.shape) == (B, 3, 3) and params.is_contiguous()
     out = torch.empty((B, 3, 3, H, W), dtype=F32, device=img.device)
+    staged = torch.empty((B, 2, H, W, 3), dtype=U8, device=img.device)
     m3, s3 = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
-    _call("ccd_augment_views", _lib.ptr(img), _lib.ptr(params), _lib.ptr(theta), _lib.ptr(out), B, H, W,
+    _call("ccd_augment_views", _lib.ptr(img), _lib.ptr(params), _lib.ptr(theta), _lib.ptr(out), _lib.ptr(staged), B, H, W,
           C.cast(m3, C.c_void_p), C.cast(s3, C.c_void_p))
     return out
 

@@ -55,6 +55,7 @@ ARCH = {  # vision_transformer.py:273-291
     "vit_tiny": dict(embed_dim=192, depth=12, heads=3),
     "vit_small": dict(embed_dim=384, depth=12, heads=6),
     "vit_base": dict(embed_dim=512, depth=12, heads=8),
+    "vit_base_768": dict(embed_dim=768, depth=12, heads=12),     # the constructor's defaults (vision_transformer.py:117-120); BASELINE config #4's shape
 }
 
 

@@ -59,7 +59,7 @@ def kmeans2_mask(gray):
 
 
 # ---------------------------------------------------------------------------------------------------- augmentation
-AUG_NP = 32
+AUG_NP = 96
 
 
 def _hash(a, b):
@@ -110,23 +110,25 @@ def colour(p, rgb, pix_id):
     return out.astype(f)
 
 
-def source(p, src):
-    """the optionally 3x3-filtered image (borders replicate): src [H,W,3] fp32 -> [H,W,3] fp32."""
-    f = np.float32
-    if p[14] == 0:
-        return src
-    H, W, _ = src.shape
-    out = np.zeros_like(src)
-    for dy in (-1, 0, 1):
-        for dx in (-1, 0, 1):
-            yy = np.clip(np.arange(H) + dy, 0, H - 1)
-            xx = np.clip(np.arange(W) + dx, 0, W - 1)
-            out = out + f(p[16 + 3 * (dy + 1) + (dx + 1)]) * src[yy][:, xx]
-    return out.astype(f)
+def staged_source(p, src_u8):
+    """augment_spatial_kernel: the neighbourhood members of one (sample, view): JPEG round trip first (p[25] = quality), then
+    the Blur-group member p[14] selects - 1: 7 x 7 correlation p[32:81], 2: median k = p[15], 3: bilateral (d = p[15],
+    sigma_color = p[26], sigma_space = p[27]).  uint8 [H,W,3] -> uint8 [H,W,3]."""
+    cur = np.asarray(src_u8, dtype=np.uint8)
+    if int(p[25]) > 0:
+        cur = jpeg_roundtrip(cur, int(p[25]))
+    mode = int(p[14])
+    if mode == 1:
+        cur = filter7(cur, np.asarray(p[32:81], dtype=np.float32).reshape(7, 7))
+    elif mode == 2:
+        cur = median_blur(cur, int(p[15]))
+    elif mode == 3:
+        cur = bilateral_blur(cur, int(p[15]), float(p[26]), float(p[27]))
+    return cur
 
 
 def augment_views(img, params, theta, mean, std):
-    """img uint8 [B,H,W,3], params [B,2,32], theta [B,3,3] -> fp32 [B,3,3,H,W]."""
+    """img uint8 [B,H,W,3], params [B,2,96], theta [B,3,3] -> fp32 [B,3,3,H,W]."""
     f = np.float32
     img = np.asarray(img)
     B, H, W, _ = img.shape
@@ -141,7 +143,7 @@ def augment_views(img, params, theta, mean, std):
     for b in range(B):
         src = img[b].astype(f)
         out[b, 0] = norm(src)
-        out[b, 1] = norm(colour(params[b, 0], source(params[b, 0], src), pid))
+        out[b, 1] = norm(colour(params[b, 0], staged_source(params[b, 0], img[b]).astype(f), pid))
         th = theta[b].astype(f)
         xn = f(2) * xs.astype(f) / f(W - 1) - f(1)
         yn = f(2) * ys.astype(f) / f(H - 1) - f(1)
@@ -150,7 +152,7 @@ def augment_views(img, params, theta, mean, std):
         x0, y0 = np.floor(sx), np.floor(sy)
         ax, ay = (sx - x0).astype(f), (sy - y0).astype(f)
         x0, y0 = x0.astype(np.int64), y0.astype(np.int64)
-        col2 = colour(params[b, 1], source(params[b, 1], src), pid)   # colour of every source pixel once
+        col2 = colour(params[b, 1], staged_source(params[b, 1], img[b]).astype(f), pid)   # colour of every source pixel once
         acc = np.zeros((H, W, 3), f)
         for dy in (0, 1):
             for dx in (0, 1):
@@ -161,3 +163,180 @@ def augment_views(img, params, theta, mean, std):
                 acc = acc + np.where(ok[..., None], wgt[..., None] * tap, f(0))
         out[b, 2] = norm(acc)
     return out
+
+
+# ------------------------------------------------------------------------------------- spatial members of the pipelines
+# Restatements of the DOCUMENTED algorithms behind the imgaug members that need a neighbourhood (augmentation_pipelines.py:
+# Blur group :165-176, JpegCompression :140): imgaug itself is absent here, so each function is pinned against the library
+# that imgaug delegates to where that library exists in this image (PIL / libjpeg for JPEG, scipy.ndimage for the median and
+# the correlation) - tests/test_datapipe_cpu.py - and restates OpenCV's documented behaviour where it does not (bilateral).
+
+def reflect101(idx, n):
+    """cv2.BORDER_REFLECT_101 (the default border of filter2D / blur / bilateralFilter): ... 2 1 | 0 1 2 ... n-1 | n-2 n-3 ..."""
+    idx = np.abs(np.asarray(idx))
+    period = 2 * (n - 1) if n > 1 else 1
+    idx = idx % period
+    return np.where(idx > n - 1, period - idx, idx)
+
+
+def filter7(img, kern):
+    """cv2.filter2D (correlation) with a 7 x 7 kernel [dy + 3][dx + 3], BORDER_REFLECT_101, rounded to uint8 (imgaug's
+    convolutional augmenters, GaussianBlur / AverageBlur / MotionBlur kernels embedded in the 7 x 7 grid)."""
+    img = np.asarray(img, dtype=np.float32)
+    H, W, _ = img.shape
+    out = np.zeros_like(img)
+    for dy in range(-3, 4):
+        for dx in range(-3, 4):
+            wgt = np.float32(kern[dy + 3][dx + 3])
+            if wgt == 0:
+                continue
+            out = out + wgt * img[reflect101(np.arange(H) + dy, H)][:, reflect101(np.arange(W) + dx, W)]
+    return np.clip(np.floor(out + np.float32(0.5)), 0, 255).astype(np.uint8)
+
+
+def median_blur(img, k):
+    """cv2.medianBlur(img, k) (iaa.MedianBlur): per channel median of the k x k window, BORDER_REPLICATE."""
+    img = np.asarray(img, dtype=np.uint8)
+    H, W, C = img.shape
+    r = k // 2
+    stack = []
+    for dy in range(-r, r + 1):
+        for dx in range(-r, r + 1):
+            stack.append(img[np.clip(np.arange(H) + dy, 0, H - 1)][:, np.clip(np.arange(W) + dx, 0, W - 1)])
+    return np.sort(np.stack(stack, 0), axis=0)[(k * k) // 2].astype(np.uint8)
+
+
+def bilateral_blur(img, d, sigma_color, sigma_space):
+    """cv2.bilateralFilter(img, d, sigmaColor, sigmaSpace) for 8-bit 3-channel images as OpenCV documents / implements it
+    (iaa.BilateralBlur): radius = d / 2, taps inside the circle r <= radius, weight = exp(-r^2 / (2 sigma_space^2)) *
+    exp(-(|db| + |dg| + |dr|)^2 / (2 sigma_color^2)) - ONE weight for the three channels from the L1 colour distance -
+    BORDER_REFLECT_101, result rounded."""
+    img = np.asarray(img, dtype=np.uint8)
+    H, W, _ = img.shape
+    f = np.float32
+    radius = int(d) // 2
+    gc = f(-0.5) / (f(sigma_color) * f(sigma_color))
+    gs = f(-0.5) / (f(sigma_space) * f(sigma_space))
+    src = img.astype(f)
+    num = np.zeros((H, W, 3), f)
+    den = np.zeros((H, W), f)
+    for dy in range(-radius, radius + 1):
+        for dx in range(-radius, radius + 1):
+            rr = dy * dy + dx * dx
+            if rr > radius * radius:
+                continue
+            tap = src[reflect101(np.arange(H) + dy, H)][:, reflect101(np.arange(W) + dx, W)]
+            dist = np.abs(tap - src).sum(-1)
+            w = (np.exp(f(rr) * gs) * np.exp(dist * dist * gc)).astype(f)
+            num += w[..., None] * tap
+            den += w
+    return np.clip(np.floor(num / den[..., None] + f(0.5)), 0, 255).astype(np.uint8)
+
+
+def motion_blur_kernel(k, angle_deg, direction):
+    """iaa.MotionBlur(k, angle, direction, order=1): a k x k matrix whose middle COLUMN holds linspace(d, 1 - d) with
+    d = (clip(direction, -1, 1) + 1) / 2, quantised to uint8, rotated by `angle` about the matrix centre with bilinear
+    sampling and zero padding (iaa.Affine(rotate=angle, order=1) on the uint8 matrix), divided by its sum."""
+    k = k if k % 2 else k + 1
+    d = (min(max(float(direction), -1.0), 1.0) + 1.0) / 2.0
+    m = np.zeros((k, k), np.float64)
+    m[:, k // 2] = np.linspace(d, 1.0 - d, num=k)
+    m8 = np.floor(m * 255.0).astype(np.float64)                   # (matrix * 255).astype(np.uint8) truncates
+    c = (k - 1) / 2.0
+    a = np.deg2rad(angle_deg)
+    out = np.zeros((k, k), np.float64)
+    for y in range(k):
+        for x in range(k):
+            # inverse map of a rotation by +angle (image coordinates, y down) about the centre
+            xs = np.cos(a) * (x - c) + np.sin(a) * (y - c) + c
+            ys = -np.sin(a) * (x - c) + np.cos(a) * (y - c) + c
+            x0, y0 = int(np.floor(xs)), int(np.floor(ys))
+            ax, ay = xs - x0, ys - y0
+            v = 0.0
+            for yy, wy in ((y0, 1 - ay), (y0 + 1, ay)):
+                for xx, wx in ((x0, 1 - ax), (x0 + 1, ax)):
+                    if 0 <= yy < k and 0 <= xx < k:
+                        v += wy * wx * m8[yy, xx]
+            out[y, x] = np.floor(v + 0.5)
+    s = out.sum()
+    return (out / s if s > 0 else m / m.sum()).astype(np.float32)
+
+
+JPEG_LUMA = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29,
+                      51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121,
+                      120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.int64).reshape(8, 8)
+JPEG_CHROMA = np.array([17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99,
+                        99, 99, 99, 99] + [99] * 32, dtype=np.int64).reshape(8, 8)
+
+
+def jpeg_quant_table(base, quality):
+    """libjpeg's jpeg_quality_scaling + jpeg_add_quant_table (baseline: entries clamped to 1..255)."""
+    q = min(max(int(quality), 1), 100)
+    scale = 5000 // q if q < 50 else 200 - 2 * q
+    return np.clip((np.asarray(base, np.int64) * scale + 50) // 100, 1, 255)
+
+
+_DCT = np.array([[(np.sqrt(0.125) if u == 0 else 0.5) * np.cos((2 * x + 1) * u * np.pi / 16.0) for x in range(8)]
+                 for u in range(8)], dtype=np.float64)          # F = D f D^T
+
+
+def jpeg_roundtrip(rgb, quality):
+    """PIL's Image.save(format='JPEG', quality=q) -> Image.open() as baseline JFIF does it (iaa.JpegCompression goes through
+    exactly that): RGB -> YCbCr (libjpeg's 16-bit fixed point), 4:2:0 chroma (h2v2 averages with the alternating 1 / 2 bias,
+    edges replicated up to whole 16 x 16 MCUs), 8 x 8 DCT of the level-shifted samples, quantisation by the quality-scaled
+    Annex-K tables (round half away from zero), dequantisation, inverse DCT, clamp, "fancy" triangle up-sampling of the chroma
+    planes, YCbCr -> RGB.  The DCTs are floating point here; libjpeg's default is the 13-bit integer "islow" pair, which
+    lands within one level of it except where a coefficient sits on a rounding boundary."""
+    rgb = np.asarray(rgb, dtype=np.int64)
+    H, W, _ = rgb.shape
+    Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
+    pad = rgb[np.minimum(np.arange(Hp), H - 1)][:, np.minimum(np.arange(Wp), W - 1)]
+    R, G, B = pad[..., 0], pad[..., 1], pad[..., 2]
+    fix = lambda x: int(x * 65536 + 0.5)
+    half = 1 << 15
+    Y = (fix(0.29900) * R + fix(0.58700) * G + fix(0.11400) * B + half) >> 16
+    cbias = (128 << 16) + half - 1
+    Cb = (-fix(0.16874) * R - fix(0.33126) * G + fix(0.50000) * B + cbias) >> 16
+    Cr = (fix(0.50000) * R - fix(0.41869) * G - fix(0.08131) * B + cbias) >> 16
+
+    def down(P):           # h2v2_downsample: bias 1, 2, 1, 2 ... along a row
+        s = P[0::2, 0::2] + P[0::2, 1::2] + P[1::2, 0::2] + P[1::2, 1::2]
+        bias = np.where(np.arange(s.shape[1]) % 2 == 0, 1, 2)[None, :]
+        return (s + bias) >> 2
+
+    def codec(P, table):
+        h, w = P.shape
+        blocks = (P.astype(np.float64) - 128.0).reshape(h // 8, 8, w // 8, 8).transpose(0, 2, 1, 3)
+        F = np.einsum("ux,abxy,vy->abuv", _DCT, blocks, _DCT)
+        t = table.astype(np.float64)
+        q = np.sign(F) * np.floor(np.abs(F) / t + 0.5)             # round half away from zero (jcdctmgr's DIVIDE_BY)
+        rec = np.einsum("ux,abuv,vy->abxy", _DCT, q * t, _DCT)
+        pix = np.clip(np.floor(rec + 128.0 + 0.5), 0, 255).astype(np.int64)
+        return pix.transpose(0, 2, 1, 3).reshape(h, w)
+
+    Yd = codec(Y, jpeg_quant_table(JPEG_LUMA, quality))
+    tc = jpeg_quant_table(JPEG_CHROMA, quality)
+    Cbd, Crd = codec(down(Cb), tc), codec(down(Cr), tc)
+
+    def up(P):             # h2v2_fancy_upsample (jdsample.c): 3/4 nearer + 1/4 further in each direction, edges replicated
+        h, w = P.shape
+        above, below = P[np.maximum(np.arange(h) - 1, 0)], P[np.minimum(np.arange(h) + 1, h - 1)]
+        out = np.zeros((2 * h, 2 * w), np.int64)
+        for v, far in ((0, above), (1, below)):
+            col = 3 * P + far                                        # "thiscolsum"
+            last = col[:, np.maximum(np.arange(w) - 1, 0)]
+            nxt = col[:, np.minimum(np.arange(w) + 1, w - 1)]
+            out[v::2, 0::2] = (3 * col + last + 8) >> 4
+            out[v::2, 1::2] = (3 * col + nxt + 7) >> 4
+        return out
+
+    Cbu, Cru = up(Cbd) - 128, up(Crd) - 128
+    r = Yd + ((fix(1.40200) * Cru + half) >> 16)
+    g = Yd + ((-fix(0.34414) * Cbu - fix(0.71414) * Cru + half) >> 16)
+    b = Yd + ((fix(1.77200) * Cbu + half) >> 16)
+    return np.clip(np.stack([r, g, b], -1), 0, 255)[:H, :W].astype(np.uint8)
+
+
+def jpeg_quality_from_compression(compression):
+    """iaa.JpegCompression: compression 0 .. 100 -> PIL quality 100 .. 1 (linear, rounded, clipped)."""
+    return int(np.clip(np.round(1 + (100 - 1) * (1.0 - compression / 100.0)), 1, 100))

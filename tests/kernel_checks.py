@@ -328,21 +328,51 @@ def check_kmeans2_mask(dev, seed=51, extra=12):
     assert ops.kmeans2_mask([], device=dev) == []
 
 
-def check_augment_views(dev, B=5, H=32, W=128, seed=52):
-    """The three views of a sample (datasetsupervised_kmeans.py:48-87) vs the numpy restatement, every colour member
-    exercised; geometry: view 2 of an un-coloured sample == F.grid_sample of view 0's pixels in the dataset's
-    (size-1)-normalised convention, and identity theta reproduces view 1's colour on view 2."""
+def _aug_params(**kw):
+    """One parameter row (kernels/datapipe.h layout) from named fields; `kern` = a correlation kernel embedded in the 7 x 7 grid."""
+    from ccd_amd.dataset import augment as A
+    p = A.IDENTITY_PARAMS.copy()
+    kern = kw.pop("kern", None)
+    for k, v in kw.items():
+        p[{"invert": 0, "gray": 1, "perm": 2, "gamma": 3, "contrast": 7, "add": 8, "sigma": 9, "mulnoise": 10, "impulse": 11,
+           "solarize": 12, "seed": 13, "mode": 14, "k": 15, "jpeg": 25, "sigc": 26, "sigs": 27}[k]] = v
+    if kern is not None:
+        A._set_filter(p, kern)
+    return p
+
+
+def check_augment_views(dev, B=9, H=32, W=128, seed=52):
+    """The three views of a sample (datasetsupervised_kmeans.py:48-87) vs the numpy restatement, every member exercised -
+    pointwise chain, JPEG round trip, 7 x 7 correlations (Gaussian 5 x 5, even-sized average with cv2's anchor, motion blur,
+    sharpen), median 3 / 5 / 7, bilateral; geometry: view 2 of an un-coloured sample == F.grid_sample of view 0's pixels in the
+    dataset's (size-1)-normalised convention, and identity theta reproduces the colour view on view 2."""
     from oracle import datapipe_np as D
-    from ccd_amd.dataset.augment import IDENTITY_PARAMS, sample_colour_params, sample_theta
+    from ccd_amd.dataset import augment as A
     rs = np.random.RandomState(seed)
     img = rs.randint(0, 256, size=(B, H, W, 3)).astype(np.uint8)
-    img[0, 8:24, 20:60] = (250, 30, 90)
-    params = sample_colour_params(rs, B, 5)
-    # make sure every member is exercised at least once
-    params[0, 0] = IDENTITY_PARAMS; params[0, 1] = IDENTITY_PARAMS
-    params[1, 0] = [1, 0.4, 3, 1.7, 1.2, 0.8, 1.1, 0.7, 12, 9.0, 0.3, 0.05, 100, 77, 1, 0] + [0.05, 0.1, 0.05, 0.1, 0.4, 0.1, 0.05, 0.1, 0.05] + [0] * 7
-    params[1, 1] = [0, 1.0, 5, 0.6, 1, 1, 1, 1, -20, 0, 0, 0.1, 256, 123456, 1, 0] + [-0.3, -0.3, -0.3, -0.3, 3.5, -0.3, -0.3, -0.3, -0.3] + [0] * 7
-    theta = sample_theta(rs, B, H, W, p_warp=1.0)
+    for b in range(B):                                                 # text-like structure under the noise: blocks of colour
+        img[b] = (0.35 * img[b] + 0.65 * np.array(rs.randint(0, 256, 3))).astype(np.uint8)
+        for _ in range(5):
+            y0, x0 = rs.randint(0, H - 6), rs.randint(0, W - 10)
+            img[b, y0:y0 + rs.randint(3, H // 2), x0:x0 + rs.randint(3, 12)] = rs.randint(0, 256, 3)
+    theta, warped = A.sample_theta(rs, B, H, W, p_warp=1.0, return_warped=True)
+    params = A.sample_colour_params(rs, B, 5, warped=warped)
+    params[0, 0] = A.IDENTITY_PARAMS; params[0, 1] = A.IDENTITY_PARAMS
+    params[1, 0] = _aug_params(invert=1, gray=0.4, perm=3, gamma=1.7, contrast=0.7, add=12, sigma=9.0, mulnoise=0.3, impulse=0.05,
+                               solarize=100, seed=77, kern=np.full((3, 3), 1 / 9.0))
+    params[1, 0, 4:7] = (1.2, 0.8, 1.1)
+    params[1, 1] = _aug_params(gray=1.0, perm=5, gamma=0.6, add=-20, impulse=0.1, seed=123456,
+                               kern=A._blend(0.4, [[-1, -1, -1], [-1, 8.3, -1], [-1, -1, -1]]))
+    params[2, 0] = _aug_params(jpeg=2, seed=5)
+    params[2, 1] = _aug_params(jpeg=17, kern=A.gaussian_kernel5(0.8))                      # JPEG, then the blur on its output
+    params[3, 0] = _aug_params(mode=2, k=3)
+    params[3, 1] = _aug_params(mode=2, k=7, jpeg=31)
+    params[4, 0] = _aug_params(mode=2, k=5, add=9)
+    params[4, 1] = _aug_params(mode=3, k=9, sigc=60.0, sigs=120.0)
+    params[5, 0] = _aug_params(mode=3, k=4, sigc=15.0, sigs=10.0, gamma=1.3)
+    params[5, 1] = _aug_params(kern=A.motion_kernel(5, 37.0, -0.4))
+    params[6, 0] = _aug_params(kern=np.full((6, 6), 1 / 36.0))                               # AverageBlur k = 6: offsets -3 .. 2
+    params[6, 1] = _aug_params(kern=np.full((2, 2), 0.25))
     theta[2] = np.eye(3)
     mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
     got = ops.augment_views(torch.from_numpy(img).to(dev), torch.from_numpy(params).to(dev), torch.from_numpy(theta).to(dev),
@@ -350,21 +380,30 @@ def check_augment_views(dev, B=5, H=32, W=128, seed=52):
     want = D.augment_views(img, params, theta, mean, std)
     assert got.shape == (B, 3, 3, H, W)
     err = np.abs(got - want)
-    # powf / logf / cosf differ by ulps between libm and the device; impulse / solarize decisions can flip on a tie
-    assert np.quantile(err, 0.999) < 2e-3 and (err > 0.05).mean() < 1e-4, (err.max(), np.quantile(err, 0.999))
+    # powf / logf / cosf / expf differ by ulps between libm and the device; impulse / solarize decisions, a uint8 rounding of the
+    # staged image or a DCT coefficient on a quantisation boundary can flip on a tie: a staged pixel that is one level off moves the
+    # normalised value by 1 / (255 * 0.22) = 0.018
+    assert np.quantile(err, 0.995) < 2e-3 and (err > 0.04).mean() < 3e-4, (err.max(), np.quantile(err, 0.995), (err > 0.04).mean())
     # view 0 is the plain normalised image, exactly
     v0 = ((img.astype(np.float32) * np.float32(1 / 255.0) - np.float32(mean)) * (np.float32(1) / np.float32(std))).transpose(0, 3, 1, 2)
     np.testing.assert_allclose(got[:, 0], v0, rtol=0, atol=1e-6)
+    # the staged members alone (no pointwise change): view 1 of samples 2, 3, 6 is the restated member, to the level
+    for b in (2, 3, 6):
+        stg = D.staged_source(params[b, 0], img[b]).astype(np.float32)
+        w1 = ((stg * np.float32(1 / 255.0) - np.float32(mean)) / np.float32(std)).transpose(2, 0, 1)
+        lvl = np.abs(got[b, 1] - w1) * 255.0 * np.float32(std)[:, None, None]
+        assert (lvl > 0.5).mean() < 6e-3 and lvl.max() < (40.0 if b == 2 else 1.5), (b, lvl.max(), (lvl > 0.5).mean())   # (x.5 ties round either way)
     # sample 0: no colour change -> view 1 == view 0, and view 2 == bilinear warp of view 0's raw pixels (zeros outside)
     np.testing.assert_allclose(got[0, 1], got[0, 0], rtol=0, atol=1e-5)
     raw = torch.from_numpy(img[0].astype(np.float32)).permute(2, 0, 1)[None]
     th = torch.from_numpy(theta[0])[None, :2, :]
     grid = F.affine_grid(th, size=(1, 3, H, W), align_corners=True)         # (size-1) normalisation == align_corners=True
-    warped = F.grid_sample(raw, grid, mode="bilinear", padding_mode="zeros", align_corners=True)[0].numpy()
-    want2 = (warped * np.float32(1 / 255.0) - np.float32(mean)[:, None, None]) / np.float32(std)[:, None, None]
+    warped_ref = F.grid_sample(raw, grid, mode="bilinear", padding_mode="zeros", align_corners=True)[0].numpy()
+    want2 = (warped_ref * np.float32(1 / 255.0) - np.float32(mean)[:, None, None]) / np.float32(std)[:, None, None]
     np.testing.assert_allclose(got[0, 2], want2, rtol=0, atol=2e-4)
-    # sample 2: identity theta -> view 2 is a pure colour view of the same pixels (same family as view 1)
-    np.testing.assert_allclose(got[2, 2], D.augment_views(img[2:3], params[2:3], theta[2:3], mean, std)[0, 2], rtol=0, atol=2e-3)
+    # sample 2: identity theta -> view 2 is a pure colour view of the same pixels
+    e2 = np.abs(got[2, 2] - D.augment_views(img[2:3], params[2:3], theta[2:3], mean, std)[0, 2])
+    assert np.quantile(e2, 0.995) < 2e-3, np.quantile(e2, 0.995)
 
 
 def check_seg_to_mask(dev, seed=23):

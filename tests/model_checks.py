@@ -732,16 +732,24 @@ def check_finetune_golden(device, tag="tiny", loss_tol=2e-3):
     assert compared >= 4 * B, compared
 
 
-def check_pretrain_arch_vs_oracle(device, arch="vit_base", B=4, out_dim=4096, loss_tol=2e-3):
+def check_pretrain_arch_vs_oracle(device, arch="vit_base", B=4, out_dim=4096, loss_tol=2e-3, dims=None):
     """One pretraining iteration of another shipped architecture (BASELINE config #4: vit_base = E 512 / 8 heads, which
-    takes the non-fused residual / LayerNorm kernels) against the pinned CPU oracle: index maps bit-exact, losses,
-    every gradient norm, centre."""
+    takes the non-fused residual / LayerNorm kernels; vit_base_768 = the 768 / 12 shape that config names) against the
+    pinned CPU oracle: index maps bit-exact, losses, every gradient norm, centre.  `dims` = (embed_dim, depth, heads, taps):
+    an explicit shallow model of the same width (the CPU executor's version of the wide architectures)."""
     from oracle import ccd_oracle as O
     torch.manual_seed(0)
     np.random.seed(0)
-    student, teacher = pretrain.build_networks(arch=arch, out_dim=out_dim, drop_path_rate=0.0, norm_last_layer=False,
-                                               device=device)
-    spec = O.Spec(norm_last_layer=False, out_dim=out_dim, seg_in=O.ARCH[arch]["embed_dim"], **O.ARCH[arch])
+    if dims is None:
+        student, teacher = pretrain.build_networks(arch=arch, out_dim=out_dim, drop_path_rate=0.0, norm_last_layer=False,
+                                                   device=device)
+        spec = O.Spec(norm_last_layer=False, out_dim=out_dim, seg_in=O.ARCH[arch]["embed_dim"], **O.ARCH[arch])
+    else:
+        E, depth, heads, taps = dims
+        student, teacher = pretrain.build_networks(
+            arch=None, out_dim=out_dim, drop_path_rate=0.0, norm_last_layer=False, seg_channel=E,
+            backbone_kwargs=dict(embed_dim=E, depth=depth, num_heads=heads, out_indices=list(taps)), device=device)
+        spec = O.Spec(embed_dim=E, depth=depth, heads=heads, taps=tuple(taps), out_dim=out_dim, norm_last_layer=False, seg_in=E)
     o_student, o_teacher = O.build_pair(spec, seed=0)
     sd = student.state_dict()
     for k in o_student.trainable:

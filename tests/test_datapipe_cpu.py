@@ -122,13 +122,112 @@ def test_theta_is_the_datasets_composition():
     ident = (th == np.eye(3, dtype=np.float32)).all(axis=(1, 2)).mean()
     assert 0.26 < ident < 0.34                                      # `random.random() > 0.3` -> warp
     assert np.allclose(th[:, 2], [0, 0, 1])
-    p = sample_colour_params(np.random.RandomState(0), 500, 5)
-    assert p.shape == (500, 2, 32) and np.isfinite(p).all() and (p[..., 3] > 0).all() and (p[..., 2] < 6).all()
+    th, warped = sample_theta(np.random.RandomState(3), 800, img_h, img_w, return_warped=True)
+    p = sample_colour_params(np.random.RandomState(0), 800, 5, warped=warped)
+    assert p.shape == (800, 2, 96) and np.isfinite(p).all() and (p[..., 3] > 0).all() and (p[..., 2] < 6).all()
     from ccd_amd.dataset.augment import IDENTITY_PARAMS
     ident = sample_colour_params(np.random.RandomState(0), 4, 0)
     assert (ident[..., :13] == IDENTITY_PARAMS[:13]).all() and (ident[..., 14:] == IDENTITY_PARAMS[14:]).all()   # severity 0
-    filt = p[p[..., 14] == 1][:, 16:25]
-    assert 0.2 < (p[..., 14] == 1).mean() < 0.9 and np.abs(filt.sum(1)).max() < 3.0        # 3x3 members are drawn and bounded
+    # a sample whose warp draw failed gets the plain image as view 2 (datasetsupervised_kmeans.py:72-74)
+    assert (p[~warped, 1, :13] == IDENTITY_PARAMS[:13]).all() and (p[~warped, 1, 14:] == 0).all()
+    assert (p[warped, 1] != IDENTITY_PARAMS).any()
+    v1 = p[:, 0]
+    mode = v1[:, 14]
+    assert 0.2 < (mode == 1).mean() < 0.7 and (mode == 2).sum() > 5 and (mode == 3).sum() > 5        # every Blur member is drawn
+    assert set(np.unique(v1[mode == 2, 15])) == {3.0, 5.0, 7.0} and v1[mode == 3, 15].min() >= 3 and v1[mode == 3, 15].max() <= 10
+    kern = v1[mode == 1][:, 32:81]
+    assert np.abs(kern.sum(1)).max() < 3.0 and (np.abs(kern) > 0).sum(1).max() <= 49
+    jq = v1[:, 25]
+    assert 0.02 < (jq > 0).mean() < 0.2 and jq[jq > 0].min() >= 2 and jq[jq > 0].max() <= 31        # compression 70-99 -> quality 31 .. 2
+
+
+def test_spatial_member_restatements_are_pinned():
+    """oracle/datapipe_np.py's neighbourhood members against the libraries imgaug delegates to, where this image has them:
+    jpeg_roundtrip vs PIL / libjpeg's real encode + decode (iaa.JpegCompression IS PIL's JPEG), median_blur and filter7 vs
+    scipy.ndimage; the motion-blur kernel of the sampler vs the restatement; reflect-101 borders."""
+    import io
+    from PIL import Image
+    from scipy import ndimage
+    from ccd_amd.dataset import augment as A
+    rs = np.random.RandomState(7)
+
+    def textlike(h, w):
+        img = np.zeros((h, w, 3)) + rs.uniform(30, 220, 3)
+        for _ in range(6):
+            y0, x0 = rs.randint(0, h - 8), rs.randint(0, w - 8)
+            img[y0:y0 + rs.randint(4, h // 2), x0:x0 + rs.randint(3, 12)] = rs.uniform(0, 255, 3)
+        return np.clip(img + rs.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+
+    for (h, w) in ((32, 128), (16, 40), (37, 101)):                   # whole MCUs, and sizes libjpeg pads by edge replication
+        for q in (2, 5, 11, 20, 31):                                  # the qualities JpegCompression(70-99) maps to
+            img = textlike(h, w)
+            buf = io.BytesIO()
+            Image.fromarray(img).save(buf, format="JPEG", quality=q)
+            ref = np.array(Image.open(io.BytesIO(buf.getvalue()))).astype(int)
+            d = np.abs(D.jpeg_roundtrip(img, q).astype(int) - ref)
+            # floating-point DCT here, libjpeg's 13-bit integer DCT there: a level or two, and rarely a coefficient that falls on
+            # the other side of a quantisation boundary (one 8 x 8 block)
+            assert d.mean() < 0.3 and (d > 2).mean() < 0.05, (h, w, q, d.max(), d.mean())
+    assert D.jpeg_quality_from_compression(70) == 31 and D.jpeg_quality_from_compression(99) == 2
+    img = textlike(32, 128)
+    for k in (3, 5, 7):
+        want = np.stack([ndimage.median_filter(img[..., c], size=k, mode="nearest") for c in range(3)], -1)
+        np.testing.assert_array_equal(D.median_blur(img, k), want)
+    kern = rs.rand(7, 7).astype(np.float32)
+    kern /= kern.sum()
+    want = np.stack([ndimage.correlate(img[..., c].astype(np.float32), kern, mode="mirror") for c in range(3)], -1)
+    assert np.abs(D.filter7(img, kern).astype(int) - np.clip(np.floor(want + 0.5), 0, 255)).max() <= 1
+    np.testing.assert_array_equal(D.reflect101(np.arange(-3, 8), 5), [3, 2, 1, 0, 1, 2, 3, 4, 3, 2, 1])
+    for ang, dirn in ((0, 0), (45, 0.5), (133, -0.7), (270, 1.0)):
+        np.testing.assert_allclose(A.motion_kernel(5, ang, dirn), D.motion_blur_kernel(5, ang, dirn), atol=1e-6)
+    np.testing.assert_allclose(A.motion_kernel(5, 0, 0.0)[:, 2], 0.2, atol=1e-6)          # direction 0: a uniform vertical line
+    # bilateral: a flat image is a fixed point; a hard edge with a small colour sigma stays an edge, with a large one it blurs
+    flat = np.full((8, 8, 3), 77, np.uint8)
+    np.testing.assert_array_equal(D.bilateral_blur(flat, 5, 30, 30), flat)
+    edge = np.zeros((8, 16, 3), np.uint8)
+    edge[:, 8:] = 200
+    np.testing.assert_array_equal(D.bilateral_blur(edge, 5, 10, 50), edge)
+    assert 0 < D.bilateral_blur(edge, 5, 250, 50)[4, 7, 0] < 200
+
+
+def test_reader_on_a_hand_assembled_environment():
+    """tests/golden/lmdb_handmade/data.mdb was assembled page by page by tools/make_lmdb_fixture.py - an independent code path
+    from write_lmdb: nodes in insertion (not key) order from the page end downwards, an overflow run, a branch root whose first
+    key is empty, the NEWER transaction on meta page 1 with a stale older tree and a garbage page left in the file.  (Still not
+    a file liblmdb itself wrote: py-lmdb is not part of this image.)"""
+    import hashlib
+    import json
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lmdb_handmade")
+    exp = json.load(open(os.path.join(root, "expected.json")))
+    with lmdb_file.LmdbReader(root) as env:
+        assert (env.txnid, env.depth, env.entries, env.psize) == (exp["txnid"], exp["depth"], exp["entries"], exp["psize"])
+        assert env.overflow_pages == 3 and env.branch_pages == 1 and env.leaf_pages == 2
+        for k, v in exp["records"].items():
+            got = env.get(k.encode())
+            assert got is not None and len(got) == v["len"] and hashlib.sha256(got).hexdigest() == v["sha256"], k
+        assert [k.decode() for k, _ in env.items()] == sorted(exp["records"])
+        assert env.get(b"num-samples") == b"3"                          # not the stale transaction's b"1"
+        assert env.get(b"label-000000002").decode("utf-8") == "na\u00efve" and env.get(b"label-000000003") == b""
+        for missing in (b"a", b"image-000000004", b"label-0000000015", b"zzz"):
+            assert env.get(missing) is None
+        from PIL import Image
+        assert Image.open(io.BytesIO(env.get(b"image-000000002"))).size == (200, 48)
+
+
+def test_streaming_writer_equals_the_bulk_load(tmp_path):
+    """write_lmdb(presorted=True) consumes an iterator, writes pages as they fill (overflow runs in front of the leaf that
+    points at them) and produces the same environment as the in-memory load; keys out of order are refused."""
+    rs = np.random.RandomState(1)
+    recs = {b"mask-%09d" % i: bytes(rs.randint(0, 256, size=int(rs.choice([40, 300, 2100, 9000]))).astype(np.uint8)) for i in range(1, 400)}
+    recs[b"num-samples"] = b"399"
+    a = lmdb_file.write_lmdb(str(tmp_path / "bulk"), recs)
+    b = lmdb_file.write_lmdb(str(tmp_path / "stream"), iter(sorted(recs.items())), presorted=True)
+    assert a == b and a["depth"] >= 2 and a["overflow_pages"] > 0
+    assert open(tmp_path / "bulk" / "data.mdb", "rb").read() == open(tmp_path / "stream" / "data.mdb", "rb").read()
+    with lmdb_file.LmdbReader(str(tmp_path / "stream")) as env:
+        assert env.entries == 400 and all(env.get(k) == v for k, v in recs.items())
+    with pytest.raises(ValueError):
+        lmdb_file.write_lmdb(str(tmp_path / "bad"), iter([(b"b", b"1"), (b"a", b"2")]), presorted=True)
 
 
 def test_resize_is_cv2_inter_linear_geometry():

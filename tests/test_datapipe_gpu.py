@@ -85,6 +85,47 @@ def test_lmdb_to_batch_contract(hip, tmp_path):
     assert seen_warp and seen_id
 
 
+def test_finetune_dataset_augments_on_the_device(hip, tmp_path):
+    """dataset.data_aug of the finetuning configs (CCD_vision_model_ARD.yaml:34; reference dataset_pretrain.py:68-158, 250-253):
+    the labelled dataset hands out resized uint8 samples and DeviceImageAugmenter runs the pipeline per batch; without data_aug
+    (and in evaluation) the host path returns the normalised tensor.  The two agree wherever the draw is the identity."""
+    from ccd_amd.dataset import augment as A
+    from ccd_amd.dataset.dataset_pretrain import DeviceImageAugmenter, ImageDataset, collate_fn_filter_none
+    root = str(tmp_path / "labelled")
+    build_image_lmdb(root, 24, seed=5)
+    aug_ds = ImageDataset(path=root, is_training=True, data_aug=True)
+    plain_ds = ImageDataset(path=root, is_training=True, data_aug=False)
+    eval_ds = ImageDataset(path=root, is_training=False, data_aug=True)
+    assert aug_ds.data_aug and not plain_ds.data_aug and not eval_ds.data_aug         # (:68 `is_training and data_aug`)
+    u8, target = aug_ds[3]
+    ref, _ = plain_ds[3]
+    assert u8.dtype == torch.uint8 and tuple(u8.shape) == (32, 128, 3) and ref.dtype == torch.float32 and tuple(target.shape) == (1, 26)
+    assert eval_ds[3][0].dtype == torch.float32
+    loader = torch.utils.data.DataLoader(aug_ds, batch_size=8, collate_fn=collate_fn_filter_none, num_workers=2, drop_last=True)
+    augment = DeviceImageAugmenter(32, 128, seed=11, device=hip.device)
+    changed = 0
+    for images_u8, labels in loader:
+        out = augment(images_u8)
+        assert out.is_cuda and tuple(out.shape) == (8, 3, 32, 128) and out.dtype == torch.float32 and bool(torch.isfinite(out).all())
+        host = (images_u8.float() / 255.0 - torch.tensor(A_MEAN)) / torch.tensor(A_STD)
+        changed += int(((out.cpu() - host.permute(0, 3, 1, 2)).abs().amax(dim=(1, 2, 3)) > 1e-3).sum())
+    assert 8 <= changed <= 24                                         # most samples are augmented, some draws are the identity
+    # an identity draw reproduces the host path exactly
+    ident = np.tile(A.IDENTITY_PARAMS, (1, 2, 1)).astype(np.float32)
+    from ccd_amd import ops
+    got = ops.augment_views(u8[None].to(hip.device), torch.from_numpy(ident).to(hip.device),
+                            torch.eye(3, device=hip.device)[None].contiguous(), A_MEAN, A_STD)[0, 2]
+    torch.testing.assert_close(got.cpu(), ref, rtol=0, atol=1e-5)
+    p, th = A.sample_finetune_params(np.random.RandomState(0), 600, 32, 128)
+    assert p.shape == (600, 2, 96) and (p[:, 0] == A.IDENTITY_PARAMS).all() and np.isfinite(p).all()
+    warped = ~(th == np.eye(3, dtype=np.float32)).all(axis=(1, 2))
+    assert 0.3 < warped.mean() < 0.5                                  # 0.6 x (Affine | Rotate) of three geometric members
+    assert (p[:, 1, 14] == 2).any() and (p[:, 1, 25] > 0).any() and (p[:, 1, 14] != 3).all()        # no bilateral member here
+
+
+A_MEAN, A_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
 def test_train_cli_on_lmdb_dataset(tmp_path):
     """The reference-shaped experiment file with its own `scheme: selfsupervised_kmeans`: only the paths are filled in."""
     if not torch.cuda.is_available():

@@ -105,10 +105,11 @@ def test_greedy_decoding_hip_graph_matches_eager(hip, monkeypatch):
     assert len(model.decoder._graphs) == 2
 
 
-@pytest.mark.parametrize("arch", ["vit_base", "vit_tiny"])
+@pytest.mark.parametrize("arch", ["vit_base", "vit_tiny", "vit_base_768"])
 def test_other_archs_pretrain_iteration_vs_oracle(hip, arch):
-    """BASELINE config #4's architecture (vit_base: E 512 / 8 heads, unfused residual + LayerNorm path) and vit_tiny."""
-    rep = mc.check_pretrain_arch_vs_oracle(hip.device, arch)
+    """BASELINE config #4's architecture (vit_base: E 512 / 8 heads, unfused residual + LayerNorm path; vit_base_768: the
+    768 / 12 shape that config's text names) and vit_tiny."""
+    rep = mc.check_pretrain_arch_vs_oracle(hip.device, arch, B=2 if arch == "vit_base_768" else 4)
     print(arch, rep)
 
 

@@ -30,6 +30,12 @@ def test_tiny_training_iteration_rotating_gb_buffers_sim(sim, lnbwd):
         engine.Fusion.double_gb, engine.Fusion.lnbwd = saved
 
 
+def test_wide_768_model_iteration_sim(sim):
+    """E = 768 / 12 heads (BASELINE config #4's shape) on the CPU executor: a 3-block model of that width, one full pretraining
+    iteration against the CPU oracle - the unfused GEMM path, LayerNorm kernels beyond 512 columns, 12-head attention."""
+    mc.check_pretrain_arch_vs_oracle(sim.device, arch=None, B=1, out_dim=256, dims=(768, 3, 12, (1, 2, 3)))
+
+
 def test_optimizer_steps_sim(sim):
     mc.check_optimizer_host_runs_ahead(sim.device, steps=3)
 

@@ -52,7 +52,8 @@ def _loader(config, convertor, world, rank):
         from train import _lmdb_dirs
         kw = dict(img_h=int(config.dataset_image_height or 32), img_w=int(config.dataset_image_width or 128),
                   max_length=int(config.decoder_max_seq_len or 25), type=config.dataset_charset_type or "DICT90",
-                  data_portion=float(config.dataset_portion or 1.0), is_training=True)
+                  data_portion=float(config.dataset_portion or 1.0), is_training=True,
+                  data_aug=bool(config.dataset_data_aug))             # the YAML's `data_aug` (dataset_pretrain.py:68-158)
         parts = [ImageDataset(path=p, **kw) for p in _lmdb_dirs(config.dataset_train_roots)]
         ds = parts[0] if len(parts) == 1 else torch.utils.data.ConcatDataset(parts)
         sampler = torch.utils.data.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True) if world > 1 else None
@@ -124,6 +125,7 @@ def main(config):
     out_dir = os.path.join(config.output_dir or "./saved_models/", config.global_name)
     os.makedirs(out_dir, exist_ok=True)
     total, it, t0, running, nrun = int(config.training_epochs * len(loader)), iter(loader), time.time(), None, 0
+    augmenter = None
     while iteration < total:
         try:
             images, labels = next(it)
@@ -132,7 +134,13 @@ def main(config):
                 loader.sampler.set_epoch(iteration // len(loader))
             it = iter(loader)
             images, labels = next(it)
-        images = images.to(device, non_blocking=True)
+        if images.dtype == torch.uint8:         # dataset.data_aug: resized uint8 samples, the imgaug-shaped pipeline runs on the device
+            if augmenter is None:
+                from ccd_amd.dataset.dataset_pretrain import DeviceImageAugmenter
+                augmenter = DeviceImageAugmenter(images.shape[1], images.shape[2], seed=int(config.seed or 0) + rank, device=device)
+            images = augmenter(images)
+        else:
+            images = images.to(device, non_blocking=True)
         labels = labels.squeeze(1).to(device, non_blocking=True)
         loss, attn = ft.training_iteration(model, optimizer, images, labels, lr_schedule[iteration])
         running = loss if running is None else running + loss
