@@ -88,6 +88,7 @@ struct CcdPolicy {
     int rowgemm = 1;            // row-owner kernels (rowgemm.h) for the N in {128, 256, 384} row-wise epilogues; 0 = gemm_row384.h
     int ln_bwd_bpc = 5;         // LayerNorm backward: blocks per CU (one resident wave; more blocks = more dgamma/dbeta atomics)
     int dec_attn_simt = 0;      // decoder attention: force the general SIMT kernels
+    int attn_chunks = 1;        // attention backward: the views in this many chunks, dQ and dK/dV launched per chunk, so that the second kernel's re-reads of q / k / v / dO come from the 256-MiB MALL instead of HBM
     int attn_tr = 1;            // attention backward dK/dV: double-buffered LDS-DMA row images + ds_read_b64_tr_b16 (0 = four register-staged images)
     int attn_skew = 0;          // attention backward: waves 4..7 start each block ~skew * 64 cycles late (lab; no effect once clocks are warm)
     int gemm_tn384 = 1;         // weight gradients with P % 384 == 0, Q % 192 == 0: XCD-grouped 384x192 LDS-DMA kernel (gemm_tn384.h); 0 = 128-square kernel, 2 = never as a pair
@@ -104,7 +105,7 @@ static const CcdPolicyKey ccd_policy_keys[] = {
     {"gemm_256_min_n", &CcdPolicy::gemm_256_min_n}, {"gemm_256_f32", &CcdPolicy::gemm_256_f32},
     {"gemm_256_deep", &CcdPolicy::gemm_256_deep}, {"gemm_row384", &CcdPolicy::gemm_row384},
     {"rowproj", &CcdPolicy::rowproj}, {"rowproj_min_m", &CcdPolicy::rowproj_min_m},
-    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"lab", &CcdPolicy::lab}};
+    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"attn_chunks", &CcdPolicy::attn_chunks}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"lab", &CcdPolicy::lab}};
 static CcdPolicy& ccd_policy() {
     static CcdPolicy pol = [] {
         CcdPolicy q;
@@ -547,9 +548,14 @@ int ccd_attention_fwd(const ccd_bf16* qkv, ccd_bf16* out, float* lse, int views,
     return ccd_rt_last_error();
 }
 
+static int ccd_attn_chunks(int views) {
+    const int c = ccd_policy().attn_chunks;
+    return c < 1 || views < 2 * c ? 1 : c;
+}
 long ccd_attention_bwd_ws_floats(int views, int heads) {
-    const long nblocks = (long)views * heads, cus = ccd_rt_num_cus();
-    return (nblocks < cus ? nblocks : cus) * (long)heads * ccd::ATT_D;
+    const long cus = ccd_rt_num_cus(), chunks = ccd_attn_chunks(views);
+    const long per_chunk = ((long)views + chunks - 1) / chunks * heads;
+    return chunks * (per_chunk < cus ? per_chunk : cus) * (long)heads * ccd::ATT_D;
 }
 int ccd_attention_bwd(const ccd_bf16* qkv, const ccd_bf16* out, const ccd_bf16* d_out, const float* lse,
                       float* delta_ws, ccd_bf16* d_qkv, int views, int heads, float scale, float* d_qkv_bias, float* bias_ws,
@@ -557,21 +563,33 @@ int ccd_attention_bwd(const ccd_bf16* qkv, const ccd_bf16* out, const ccd_bf16* 
     CCD_CHECK(qkv && out && d_out && lse && delta_ws && d_qkv && (!d_qkv_bias || (bias_ws && dout_colsum_vec)), CCD_EINVAL);
     if (views == 0) return CCD_OK;
     CCD_CHECK(views > 0 && heads > 0 && heads <= ccd::ATTB_MAX_HEADS, CCD_EINVAL);
-    const int nblocks = views * heads;                      // persistent: one workgroup per CU walks the (view, head) blocks
     const int cus = ccd_rt_num_cus();
-    const int grid = nblocks < cus ? nblocks : cus;
-    float* ws = d_qkv_bias ? bias_ws : nullptr;             // [grid][E] partial column sums of dQ
-    CCD_LAUNCH(ccd::attention_bwd_dq_kernel, dim3(grid), dim3(512), ccd::ATTB_DQ_SMEM, stream, qkv,
-               out, d_out, lse, delta_ws, d_qkv, ws, heads, scale, nblocks, ccd_policy().attn_skew);
-    if (ccd_policy().attn_tr)               // dK / dV on the double-buffered LDS-DMA image with transposing LDS reads
-        CCD_LAUNCH(ccd::attention_bwd_dkv_tr_kernel, dim3(grid), dim3(512), ccd::ATTB_DKV_TR_SMEM, stream,
-                   qkv, d_out, lse, delta_ws, d_qkv, heads, scale, nblocks, ccd_policy().lab);
-    else
-        CCD_LAUNCH(ccd::attention_bwd_dkv_kernel, dim3(grid), dim3(512), ccd::ATTB_DKV_SMEM, stream, qkv,
-                   d_out, lse, delta_ws, d_qkv, heads, scale, nblocks, ccd_policy().attn_skew);
+    const int chunks = ccd_attn_chunks(views);
+    float* ws = d_qkv_bias ? bias_ws : nullptr;             // [workgroups of all chunks][E] partial column sums of dQ
+    const int E3 = 3 * heads * ccd::ATT_D, E1 = heads * ccd::ATT_D;
+    int ws_rows = 0;
+    for (int c = 0; c < chunks; ++c) {                      // persistent kernels: one workgroup per CU walks the (view, head) blocks
+        const int v0 = (int)((long)views * c / chunks), v1 = (int)((long)views * (c + 1) / chunks), nb = (v1 - v0) * heads;
+        const int g = nb < cus ? nb : cus;
+        const ccd_bf16* qkv_c = qkv + (long)v0 * ccd::ATT_T * E3;
+        const ccd_bf16* out_c = out + (long)v0 * ccd::ATT_T * E1;
+        const ccd_bf16* dout_c = d_out + (long)v0 * ccd::ATT_T * E1;
+        const float* lse_c = lse + (long)v0 * heads * ccd::ATT_T;
+        float* delta_c = delta_ws + (long)v0 * heads * ccd::ATT_T;
+        ccd_bf16* dqkv_c = d_qkv + (long)v0 * ccd::ATT_T * E3;
+        CCD_LAUNCH(ccd::attention_bwd_dq_kernel, dim3(g), dim3(512), ccd::ATTB_DQ_SMEM, stream, qkv_c, out_c, dout_c, lse_c, delta_c,
+                   dqkv_c, ws ? ws + (long)ws_rows * E1 : nullptr, heads, scale, nb, ccd_policy().attn_skew);
+        ws_rows += g;
+        if (ccd_policy().attn_tr)           // dK / dV on the double-buffered LDS-DMA image with transposing LDS reads
+            CCD_LAUNCH(ccd::attention_bwd_dkv_tr_kernel, dim3(g), dim3(512), ccd::ATTB_DKV_TR_SMEM, stream, qkv_c, dout_c, lse_c,
+                       delta_c, dqkv_c, heads, scale, nb, ccd_policy().lab);
+        else
+            CCD_LAUNCH(ccd::attention_bwd_dkv_kernel, dim3(g), dim3(512), ccd::ATTB_DKV_SMEM, stream, qkv_c, dout_c, lse_c, delta_c,
+                       dqkv_c, heads, scale, nb, ccd_policy().attn_skew);
+    }
     if (ws) {
         const int E = heads * ccd::ATT_D;
-        CCD_LAUNCH(ccd::qkv_bias_finish_kernel, dim3((E + 63) / 64, 2), dim3(1024), 0, stream, ws, grid, dout_colsum_vec,
+        CCD_LAUNCH(ccd::qkv_bias_finish_kernel, dim3((E + 63) / 64, 2), dim3(1024), 0, stream, ws, ws_rows, dout_colsum_vec,
                    dout_colsum_mat, ld_mat, E, d_qkv_bias);
     }
     return ccd_rt_last_error();

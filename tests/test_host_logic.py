@@ -17,7 +17,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 def test_c_abi_library_exports_every_declared_symbol():
     from ccd_amd import _lib
     header = open(os.path.join(ROOT, "include", "ccd_hip.h")).read()
-    declared = sorted(set(re.findall(r"\b(?:int|const char\*)\s+(ccd_\w+)\s*\(", header)))
+    declared = sorted(set(re.findall(r"\b(?:int|long|const char\*)\s+(ccd_\w+)\s*\(", header)))
     assert len(declared) >= 35, declared
     assert os.path.isfile(_lib.LIB_PATH), "run __graft_entry__.build() first"
     lib = ctypes.CDLL(_lib.LIB_PATH)            # loads without a GPU; no compute call is made here
@@ -25,7 +25,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert not missing, missing
     assert sorted(_lib.SIGNATURES) == declared, "ccd_amd/_lib.py signature table out of sync with include/ccd_hip.h"
     _lib.bind(lib)
-    assert lib.ccd_abi_version() == 3
+    assert lib.ccd_abi_version() == 4
 
 
 def test_product_has_no_cpu_fallback():

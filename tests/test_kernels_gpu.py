@@ -113,6 +113,8 @@ def test_attention(hip, views, heads, spike):
         kc.check_attention(hip.device, views, heads, spike=spike)
     with ops.policy(cu_reserve=248):                          # 8 workgroups walk the blocks: the double-buffered images turn over
         kc.check_attention(hip.device, views, heads, spike=spike)
+    with ops.policy(attn_chunks=1 if ops.policy_get("attn_chunks") > 1 else 2):      # the other chunking of the launches
+        kc.check_attention(hip.device, views, heads, spike=spike)
 
 
 def test_gemm_dynamic_rows(hip):

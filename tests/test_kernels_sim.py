@@ -111,6 +111,8 @@ def test_attention_sim(sim):
     kc.check_attention(sim.device, views=1, heads=2)
     with ops.policy(attn_tr=0):                              # dK / dV on the four register-staged images
         kc.check_attention(sim.device, views=1, heads=2)
+    with ops.policy(attn_chunks=2):                          # the views in two chunks of launches (3 views: 1 + 2)
+        kc.check_attention(sim.device, views=3, heads=1, seed=4)
 
 
 def test_gemm_dynamic_rows_sim(sim):

@@ -478,11 +478,17 @@ def gen_keys():
     """State-dict key names + shapes of student/teacher for the three shipped archs."""
     import json
     table = {}
-    for arch in ["vit_tiny", "vit_small", "vit_base"]:
+    for arch in ["vit_tiny", "vit_small", "vit_base", "vit_base_768"]:
         from Dino.modules import vision_transformer as vits
-        e = {"vit_tiny": 192, "vit_small": 384, "vit_base": 512}[arch]
-        student, teacher = build_reference_pair(dict(arch=arch), dict(out_dim=1024), e, seed=0, drop_path_rate=0.1,
-                                                tiny=False)
+        e = {"vit_tiny": 192, "vit_small": 384, "vit_base": 512, "vit_base_768": 768}[arch]
+        if arch == "vit_base_768":
+            # BASELINE config #4's shape: not a factory of the reference, but what its VisionTransformer constructor builds by
+            # default (embed_dim=768, depth=12, num_heads=12, vision_transformer.py:117-120) - with qkv_bias / eps as the factories set them
+            student, teacher = build_reference_pair(dict(embed_dim=768, depth=12, num_heads=12, patch_size=4), dict(out_dim=1024), e,
+                                                    seed=0, drop_path_rate=0.1, tiny=True)
+        else:
+            student, teacher = build_reference_pair(dict(arch=arch), dict(out_dim=1024), e, seed=0, drop_path_rate=0.1,
+                                                    tiny=False)
         table[arch] = {
             "student": [[k, list(v.shape), str(v.dtype)] for k, v in student.state_dict().items()],
             "teacher": [[k, list(v.shape), str(v.dtype)] for k, v in teacher.state_dict().items()],

@@ -41,14 +41,16 @@ def main():
     d_out = torch.randn(views, 256, E, generator=g).to(BF).to(dev)
     out, lse = ops.attention_fwd(qkv, heads, 0.125)
     db = torch.zeros(3 * E, device=dev)
-    ms0 = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, 0.125))
-    dcs = torch.zeros(E, device=dev)
-    ms1 = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, 0.125, d_bias=db, dout_colsum=dcs, dout_colsum_mat=torch.eye(E, device=dev)))
+    dcs, eye = torch.zeros(E, device=dev), torch.eye(E, device=dev)
     dq = ops.attention_bwd(qkv, out, d_out, lse, heads, 0.125).view(-1, 3 * E)
     cs = torch.zeros(3 * E, device=dev)
     ms2 = timeit(lambda: ops.colsum_bf16(dq, cs))
-    print(json.dumps({"kernel": "attention_bwd", "views": views, "ms_plain": round(ms0, 4), "ms_with_qkv_bias_gradient": round(ms1, 4),
-                      "ms_separate_colsum_bf16": round(ms2, 4)}), flush=True)
+    for chunks in (1, 2, 4, 8):
+        with ops.policy(attn_chunks=chunks):
+            ms0 = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, 0.125))
+            ms1 = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, 0.125, d_bias=db, dout_colsum=dcs, dout_colsum_mat=eye))
+        print(json.dumps({"kernel": "attention_bwd", "views": views, "attn_chunks": chunks, "ms_plain": round(ms0, 4),
+                          "ms_with_qkv_bias_gradient": round(ms1, 4), "ms_separate_colsum_bf16": round(ms2, 4)}), flush=True)
 
 
 if __name__ == "__main__":
