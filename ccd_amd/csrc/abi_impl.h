@@ -11,10 +11,11 @@
 #include "kernels/mlp_fused.h"
 #include "kernels/rowgemm.h"
 #include "kernels/rowproj.h"
-#include "kernels/gemm_tn384.h"
-#include "kernels/layernorm.h"
 #include "kernels/attention_fwd.h"
 #include "kernels/attention_bwd.h"
+#include "kernels/mlp_bwd.h"
+#include "kernels/gemm_tn384.h"
+#include "kernels/layernorm.h"
 #include "kernels/charmap.h"
 #include "kernels/datapipe.h"
 #include "kernels/embed.h"
@@ -88,7 +89,6 @@ struct CcdPolicy {
     int rowgemm = 1;            // row-owner kernels (rowgemm.h) for the N in {128, 256, 384} row-wise epilogues; 0 = gemm_row384.h
     int ln_bwd_bpc = 5;         // LayerNorm backward: blocks per CU (one resident wave; more blocks = more dgamma/dbeta atomics)
     int dec_attn_simt = 0;      // decoder attention: force the general SIMT kernels
-    int attn_chunks = 1;        // attention backward: the views in this many chunks, dQ and dK/dV launched per chunk, so that the second kernel's re-reads of q / k / v / dO come from the 256-MiB MALL instead of HBM
     int attn_tr = 1;            // attention backward dK/dV: double-buffered LDS-DMA row images + ds_read_b64_tr_b16 (0 = four register-staged images)
     int attn_skew = 0;          // attention backward: waves 4..7 start each block ~skew * 64 cycles late (lab; no effect once clocks are warm)
     int gemm_tn384 = 1;         // weight gradients with P % 384 == 0, Q % 192 == 0: XCD-grouped 384x192 LDS-DMA kernel (gemm_tn384.h); 0 = 128-square kernel, 2 = never as a pair
@@ -105,7 +105,7 @@ static const CcdPolicyKey ccd_policy_keys[] = {
     {"gemm_256_min_n", &CcdPolicy::gemm_256_min_n}, {"gemm_256_f32", &CcdPolicy::gemm_256_f32},
     {"gemm_256_deep", &CcdPolicy::gemm_256_deep}, {"gemm_row384", &CcdPolicy::gemm_row384},
     {"rowproj", &CcdPolicy::rowproj}, {"rowproj_min_m", &CcdPolicy::rowproj_min_m},
-    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"attn_chunks", &CcdPolicy::attn_chunks}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"lab", &CcdPolicy::lab}};
+    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"lab", &CcdPolicy::lab}};
 static CcdPolicy& ccd_policy() {
     static CcdPolicy pol = [] {
         CcdPolicy q;
@@ -232,8 +232,8 @@ static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, void* stream) {
 
 extern "C" {
 
-int ccd_abi_version(void) { return 4; }   // 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
-const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi4"; }
+int ccd_abi_version(void) { return 5; }   // 5: ccd_mlp_bwd_fused; 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
+const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi5"; }
 int ccd_policy_set(const char* key, int value) {
     CCD_CHECK(key, CCD_EINVAL);
     for (const CcdPolicyKey& k : ccd_policy_keys)
@@ -418,6 +418,43 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
     return ccd_rt_last_error();
 }
 
+long ccd_mlp_bwd_ws_floats(int M, int H) {
+    const long tiles = ((long)M + ccd::MB_BM - 1) / ccd::MB_BM, cus = ccd_rt_num_cus();
+    return (tiles < cus ? tiles : cus) * (long)H;
+}
+int ccd_mlp_bwd_fused(const ccd_bf16* gb, long ldgb, const ccd_bf16* w2t, long ld2, const ccd_bf16* w1t, long ld1, const ccd_bf16* u,
+                      long ldu, ccd_bf16* du, long lddu, ccd_bf16* gact, long ldga, float* db1, float* db1_ws, const float* x, long ldx,
+                      const float* mean, const float* rstd, const float* gamma, float* g, long ldg, int accumulate, float* dgamma,
+                      float* dbeta, ccd_bf16* gb_out, long ld_gbo, const float* rowscale, int rows_per_sample, float* dbias, int M,
+                      int E, int H, void* stream) {
+    CCD_CHECK(gb && w2t && w1t && u && du && gact && db1 && db1_ws && x && mean && rstd && gamma && g && dgamma && dbeta, CCD_EINVAL);
+    CCD_CHECK(CCD_ALIGNED16(gb) && CCD_ALIGNED16(w2t) && CCD_ALIGNED16(w1t) && CCD_ALIGNED16(u) && CCD_ALIGNED16(du) &&
+              CCD_ALIGNED16(gact) && CCD_ALIGNED16(x) && CCD_ALIGNED16(g) && CCD_ALIGNED16(gb_out) && CCD_ALIGNED16(gamma), CCD_EINVAL);
+    CCD_CHECK(gb_out != gb, CCD_EINVAL);                    // the weight-gradient launch that follows still reads gb
+    if (M == 0) return CCD_OK;
+    CCD_CHECK(M > 0 && H > 0 && (!rowscale || rows_per_sample > 0), CCD_EINVAL);
+    CCD_CHECK((E == 128 || E == 256 || E == 384) && H % 64 == 0 && ldgb % 8 == 0 && ld2 % 8 == 0 && ld1 % 8 == 0 && ldu % 8 == 0 &&
+              lddu % 8 == 0 && ldga % 8 == 0 && ldx % 4 == 0 && ldg % 4 == 0 && (!gb_out || ld_gbo % 8 == 0), CCD_ESHAPE);
+    CCD_CHECK((long)H * ld2 * 2 < CCD_MAX_OPERAND_BYTES && (long)E * ld1 * 2 < CCD_MAX_OPERAND_BYTES &&
+              ((long)M + 128) * ldu * 2 < CCD_MAX_OPERAND_BYTES && ((long)M + 128) * ldg * 4 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
+    const int smem = ccd::mb_smem_bytes(E, H);
+    CCD_CHECK(smem <= 160 * 1024, CCD_ESHAPE);
+    ccd::MlpBwdParams p;
+    p.gb = gb; p.ld_gb_in = ldgb; p.w2t = w2t; p.ld2 = ld2; p.w1t = w1t; p.ld1 = ld1; p.u = u; p.ldu = ldu; p.du = du; p.lddu = lddu;
+    p.gact = gact; p.ldga = ldga; p.db1_ws = db1_ws; p.x = x; p.ldx = ldx; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.g = g;
+    p.ldg = ldg; p.accumulate = accumulate; p.dgamma = dgamma; p.dbeta = dbeta; p.gb_out = gb_out; p.ld_gbo = ld_gbo;
+    p.rowscale = gb_out ? rowscale : nullptr; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
+    p.dbias = gb_out ? dbias : nullptr; p.M = M; p.H = H;
+    const int tiles = (M + ccd::MB_BM - 1) / ccd::MB_BM, cus = ccd_rt_num_cus();      // (not ccd_grid_cus(): the row count of db1_ws is fixed)
+    const int grid = tiles < cus ? tiles : cus;
+    if (E == 384) CCD_LAUNCH((ccd::mlp_bwd_fused_kernel<384>), dim3(grid), dim3(ccd::MB_THREADS), smem, stream, p);
+    else if (E == 256) CCD_LAUNCH((ccd::mlp_bwd_fused_kernel<256>), dim3(grid), dim3(ccd::MB_THREADS), smem, stream, p);
+    else CCD_LAUNCH((ccd::mlp_bwd_fused_kernel<128>), dim3(grid), dim3(ccd::MB_THREADS), smem, stream, p);
+    // db1 += sum of the workgroups' partial rows (attention_bwd.h's row-sum kernel, its matvec branch unused)
+    CCD_LAUNCH(ccd::qkv_bias_finish_kernel, dim3((H + 63) / 64, 1), dim3(1024), 0, stream, db1_ws, grid, nullptr, nullptr, 0L, H, db1);
+    return ccd_rt_last_error();
+}
+
 static int ccd_gemm_tn_impl(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P, int Q, int Mc, int epilogue, float* C,
                             long ldc, float alpha, int splits, const int* d_rows, int rows_mul, float* colsum_a, void* stream);
 // gemm_tn384.h: one group of (P / TP) (Q / TQ) [+ the second problem's] workgroups per contraction slice, whole groups per XCD
@@ -548,48 +585,34 @@ int ccd_attention_fwd(const ccd_bf16* qkv, ccd_bf16* out, float* lse, int views,
     return ccd_rt_last_error();
 }
 
-static int ccd_attn_chunks(int views) {
-    const int c = ccd_policy().attn_chunks;
-    return c < 1 || views < 2 * c ? 1 : c;
-}
 long ccd_attention_bwd_ws_floats(int views, int heads) {
-    const long cus = ccd_rt_num_cus(), chunks = ccd_attn_chunks(views);
-    const long per_chunk = ((long)views + chunks - 1) / chunks * heads;
-    return chunks * (per_chunk < cus ? per_chunk : cus) * (long)heads * ccd::ATT_D;
+    const long nblocks = (long)views * heads, cus = ccd_rt_num_cus();
+    return (nblocks < cus ? nblocks : cus) * (long)heads * ccd::ATT_D;
 }
+// (Measured in round 3 and dropped: the views in 2 / 4 / 8 chunks of launches, so that the dK / dV kernel's re-reads of q, k, v, dO
+// would come from the 256-MiB MALL right after the dQ kernel touched them - 0.377 / 0.397 / 0.493 ms per layer against 0.353 in
+// one go (profiles/r03_attn_bwd_lab.jsonl): the re-reads are not what bounds the pair, the extra launch tails are pure cost.)
 int ccd_attention_bwd(const ccd_bf16* qkv, const ccd_bf16* out, const ccd_bf16* d_out, const float* lse,
                       float* delta_ws, ccd_bf16* d_qkv, int views, int heads, float scale, float* d_qkv_bias, float* bias_ws,
                       const float* dout_colsum_vec, const float* dout_colsum_mat, long ld_mat, void* stream) {
     CCD_CHECK(qkv && out && d_out && lse && delta_ws && d_qkv && (!d_qkv_bias || (bias_ws && dout_colsum_vec)), CCD_EINVAL);
     if (views == 0) return CCD_OK;
     CCD_CHECK(views > 0 && heads > 0 && heads <= ccd::ATTB_MAX_HEADS, CCD_EINVAL);
+    const int nblocks = views * heads;                      // persistent: one workgroup per CU walks the (view, head) blocks
     const int cus = ccd_rt_num_cus();
-    const int chunks = ccd_attn_chunks(views);
-    float* ws = d_qkv_bias ? bias_ws : nullptr;             // [workgroups of all chunks][E] partial column sums of dQ
-    const int E3 = 3 * heads * ccd::ATT_D, E1 = heads * ccd::ATT_D;
-    int ws_rows = 0;
-    for (int c = 0; c < chunks; ++c) {                      // persistent kernels: one workgroup per CU walks the (view, head) blocks
-        const int v0 = (int)((long)views * c / chunks), v1 = (int)((long)views * (c + 1) / chunks), nb = (v1 - v0) * heads;
-        const int g = nb < cus ? nb : cus;
-        const ccd_bf16* qkv_c = qkv + (long)v0 * ccd::ATT_T * E3;
-        const ccd_bf16* out_c = out + (long)v0 * ccd::ATT_T * E1;
-        const ccd_bf16* dout_c = d_out + (long)v0 * ccd::ATT_T * E1;
-        const float* lse_c = lse + (long)v0 * heads * ccd::ATT_T;
-        float* delta_c = delta_ws + (long)v0 * heads * ccd::ATT_T;
-        ccd_bf16* dqkv_c = d_qkv + (long)v0 * ccd::ATT_T * E3;
-        CCD_LAUNCH(ccd::attention_bwd_dq_kernel, dim3(g), dim3(512), ccd::ATTB_DQ_SMEM, stream, qkv_c, out_c, dout_c, lse_c, delta_c,
-                   dqkv_c, ws ? ws + (long)ws_rows * E1 : nullptr, heads, scale, nb, ccd_policy().attn_skew);
-        ws_rows += g;
-        if (ccd_policy().attn_tr)           // dK / dV on the double-buffered LDS-DMA image with transposing LDS reads
-            CCD_LAUNCH(ccd::attention_bwd_dkv_tr_kernel, dim3(g), dim3(512), ccd::ATTB_DKV_TR_SMEM, stream, qkv_c, dout_c, lse_c,
-                       delta_c, dqkv_c, heads, scale, nb, ccd_policy().lab);
-        else
-            CCD_LAUNCH(ccd::attention_bwd_dkv_kernel, dim3(g), dim3(512), ccd::ATTB_DKV_SMEM, stream, qkv_c, dout_c, lse_c, delta_c,
-                       dqkv_c, heads, scale, nb, ccd_policy().attn_skew);
-    }
+    const int grid = nblocks < cus ? nblocks : cus;
+    float* ws = d_qkv_bias ? bias_ws : nullptr;             // [grid][E] partial column sums of dQ
+    CCD_LAUNCH(ccd::attention_bwd_dq_kernel, dim3(grid), dim3(512), ccd::ATTB_DQ_SMEM, stream, qkv,
+               out, d_out, lse, delta_ws, d_qkv, ws, heads, scale, nblocks, ccd_policy().attn_skew);
+    if (ccd_policy().attn_tr)               // dK / dV on the double-buffered LDS-DMA image with transposing LDS reads
+        CCD_LAUNCH(ccd::attention_bwd_dkv_tr_kernel, dim3(grid), dim3(512), ccd::ATTB_DKV_TR_SMEM, stream,
+                   qkv, d_out, lse, delta_ws, d_qkv, heads, scale, nblocks, ccd_policy().lab);
+    else
+        CCD_LAUNCH(ccd::attention_bwd_dkv_kernel, dim3(grid), dim3(512), ccd::ATTB_DKV_SMEM, stream, qkv,
+                   d_out, lse, delta_ws, d_qkv, heads, scale, nblocks, ccd_policy().attn_skew);
     if (ws) {
         const int E = heads * ccd::ATT_D;
-        CCD_LAUNCH(ccd::qkv_bias_finish_kernel, dim3((E + 63) / 64, 2), dim3(1024), 0, stream, ws, ws_rows, dout_colsum_vec,
+        CCD_LAUNCH(ccd::qkv_bias_finish_kernel, dim3((E + 63) / 64, 2), dim3(1024), 0, stream, ws, grid, dout_colsum_vec,
                    dout_colsum_mat, ld_mat, E, d_qkv_bias);
     }
     return ccd_rt_last_error();

@@ -85,9 +85,8 @@ __device__ __forceinline__ float rg_fold(float a, float b, bool up) {
     const float keep = up ? b : a, send = up ? a : b;
     return keep + lane_xor<MASK>(send);
 }
-// v[4 g + e] = this lane's row, column 8 g + 4 hf + e of a 32-column tile: column sums over the 32 rows of the wave, added
-// to dst[32 columns] (LDS; the 16 low lanes of each half wave own one column each)
-__device__ __forceinline__ void rg_colsum16(const float (&v)[16], float* dst, int lq, int hf) {
+// 16 values per lane -> the sum over 16 lanes (those that differ in bits 0-3 of lq) of value number lq & 15, in every lane
+__device__ __forceinline__ float rg_fold16(const float (&v)[16], int lq) {
     float a8[8], a4[4], a2[2];
 #pragma unroll
     for (int j = 0; j < 8; ++j) a8[j] = rg_fold<1>(v[2 * j], v[2 * j + 1], (lq & 1) != 0);
@@ -95,8 +94,12 @@ __device__ __forceinline__ void rg_colsum16(const float (&v)[16], float* dst, in
     for (int j = 0; j < 4; ++j) a4[j] = rg_fold<2>(a8[2 * j], a8[2 * j + 1], (lq & 2) != 0);
 #pragma unroll
     for (int j = 0; j < 2; ++j) a2[j] = rg_fold<4>(a4[2 * j], a4[2 * j + 1], (lq & 4) != 0);
-    float tot = rg_fold<8>(a2[0], a2[1], (lq & 8) != 0);
-    atomicAdd(dst + 8 * ((lq >> 2) & 3) + 4 * hf + (lq & 3), tot);
+    return rg_fold<8>(a2[0], a2[1], (lq & 8) != 0);
+}
+// v[4 g + e] = this lane's row, column 8 g + 4 hf + e of a 32-column tile: column sums over the 32 rows of the wave, added
+// to dst[32 columns] (LDS; the 16 low lanes of each half wave own one column each)
+__device__ __forceinline__ void rg_colsum16(const float (&v)[16], float* dst, int lq, int hf) {
+    atomicAdd(dst + 8 * ((lq >> 2) & 3) + 4 * hf + (lq & 3), rg_fold16(v, lq));
 }
 
 template <int E, int R, int EPI>

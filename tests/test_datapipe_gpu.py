@@ -99,7 +99,7 @@ def test_finetune_dataset_augments_on_the_device(hip, tmp_path):
     assert aug_ds.data_aug and not plain_ds.data_aug and not eval_ds.data_aug         # (:68 `is_training and data_aug`)
     u8, target = aug_ds[3]
     ref, _ = plain_ds[3]
-    assert u8.dtype == torch.uint8 and tuple(u8.shape) == (32, 128, 3) and ref.dtype == torch.float32 and tuple(target.shape) == (1, 26)
+    assert u8.dtype == torch.uint8 and tuple(u8.shape) == (32, 128, 3) and ref.dtype == torch.float32 and tuple(target.shape) == (1, 25)
     assert eval_ds[3][0].dtype == torch.float32
     loader = torch.utils.data.DataLoader(aug_ds, batch_size=8, collate_fn=collate_fn_filter_none, num_workers=2, drop_last=True)
     augment = DeviceImageAugmenter(32, 128, seed=11, device=hip.device)

@@ -45,12 +45,10 @@ def main():
     dq = ops.attention_bwd(qkv, out, d_out, lse, heads, 0.125).view(-1, 3 * E)
     cs = torch.zeros(3 * E, device=dev)
     ms2 = timeit(lambda: ops.colsum_bf16(dq, cs))
-    for chunks in (1, 2, 4, 8):
-        with ops.policy(attn_chunks=chunks):
-            ms0 = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, 0.125))
-            ms1 = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, 0.125, d_bias=db, dout_colsum=dcs, dout_colsum_mat=eye))
-        print(json.dumps({"kernel": "attention_bwd", "views": views, "attn_chunks": chunks, "ms_plain": round(ms0, 4),
-                          "ms_with_qkv_bias_gradient": round(ms1, 4), "ms_separate_colsum_bf16": round(ms2, 4)}), flush=True)
+    ms0 = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, 0.125))
+    ms1 = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, 0.125, d_bias=db, dout_colsum=dcs, dout_colsum_mat=eye))
+    print(json.dumps({"kernel": "attention_bwd", "views": views, "ms_plain": round(ms0, 4),
+                      "ms_with_qkv_bias_gradient": round(ms1, 4), "ms_separate_colsum_bf16": round(ms2, 4)}), flush=True)
 
 
 if __name__ == "__main__":
