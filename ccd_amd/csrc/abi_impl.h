@@ -13,7 +13,6 @@
 #include "kernels/rowproj.h"
 #include "kernels/attention_fwd.h"
 #include "kernels/attention_bwd.h"
-#include "kernels/mlp_bwd.h"
 #include "kernels/gemm_tn384.h"
 #include "kernels/layernorm.h"
 #include "kernels/charmap.h"
@@ -232,8 +231,8 @@ static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, void* stream) {
 
 extern "C" {
 
-int ccd_abi_version(void) { return 5; }   // 5: ccd_mlp_bwd_fused; 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
-const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi5"; }
+int ccd_abi_version(void) { return 4; }   // 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
+const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi4"; }
 int ccd_policy_set(const char* key, int value) {
     CCD_CHECK(key, CCD_EINVAL);
     for (const CcdPolicyKey& k : ccd_policy_keys)
@@ -415,43 +414,6 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
         if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<128, true>), grid, block, smem, stream, p);
         else CCD_LAUNCH((ccd::mlp_fused_kernel<128, false>), grid, block, smem, stream, p);
     }
-    return ccd_rt_last_error();
-}
-
-long ccd_mlp_bwd_ws_floats(int M, int H) {
-    const long tiles = ((long)M + ccd::MB_BM - 1) / ccd::MB_BM, cus = ccd_rt_num_cus();
-    return (tiles < cus ? tiles : cus) * (long)H;
-}
-int ccd_mlp_bwd_fused(const ccd_bf16* gb, long ldgb, const ccd_bf16* w2t, long ld2, const ccd_bf16* w1t, long ld1, const ccd_bf16* u,
-                      long ldu, ccd_bf16* du, long lddu, ccd_bf16* gact, long ldga, float* db1, float* db1_ws, const float* x, long ldx,
-                      const float* mean, const float* rstd, const float* gamma, float* g, long ldg, int accumulate, float* dgamma,
-                      float* dbeta, ccd_bf16* gb_out, long ld_gbo, const float* rowscale, int rows_per_sample, float* dbias, int M,
-                      int E, int H, void* stream) {
-    CCD_CHECK(gb && w2t && w1t && u && du && gact && db1 && db1_ws && x && mean && rstd && gamma && g && dgamma && dbeta, CCD_EINVAL);
-    CCD_CHECK(CCD_ALIGNED16(gb) && CCD_ALIGNED16(w2t) && CCD_ALIGNED16(w1t) && CCD_ALIGNED16(u) && CCD_ALIGNED16(du) &&
-              CCD_ALIGNED16(gact) && CCD_ALIGNED16(x) && CCD_ALIGNED16(g) && CCD_ALIGNED16(gb_out) && CCD_ALIGNED16(gamma), CCD_EINVAL);
-    CCD_CHECK(gb_out != gb, CCD_EINVAL);                    // the weight-gradient launch that follows still reads gb
-    if (M == 0) return CCD_OK;
-    CCD_CHECK(M > 0 && H > 0 && (!rowscale || rows_per_sample > 0), CCD_EINVAL);
-    CCD_CHECK((E == 128 || E == 256 || E == 384) && H % 64 == 0 && ldgb % 8 == 0 && ld2 % 8 == 0 && ld1 % 8 == 0 && ldu % 8 == 0 &&
-              lddu % 8 == 0 && ldga % 8 == 0 && ldx % 4 == 0 && ldg % 4 == 0 && (!gb_out || ld_gbo % 8 == 0), CCD_ESHAPE);
-    CCD_CHECK((long)H * ld2 * 2 < CCD_MAX_OPERAND_BYTES && (long)E * ld1 * 2 < CCD_MAX_OPERAND_BYTES &&
-              ((long)M + 128) * ldu * 2 < CCD_MAX_OPERAND_BYTES && ((long)M + 128) * ldg * 4 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
-    const int smem = ccd::mb_smem_bytes(E, H);
-    CCD_CHECK(smem <= 160 * 1024, CCD_ESHAPE);
-    ccd::MlpBwdParams p;
-    p.gb = gb; p.ld_gb_in = ldgb; p.w2t = w2t; p.ld2 = ld2; p.w1t = w1t; p.ld1 = ld1; p.u = u; p.ldu = ldu; p.du = du; p.lddu = lddu;
-    p.gact = gact; p.ldga = ldga; p.db1_ws = db1_ws; p.x = x; p.ldx = ldx; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.g = g;
-    p.ldg = ldg; p.accumulate = accumulate; p.dgamma = dgamma; p.dbeta = dbeta; p.gb_out = gb_out; p.ld_gbo = ld_gbo;
-    p.rowscale = gb_out ? rowscale : nullptr; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
-    p.dbias = gb_out ? dbias : nullptr; p.M = M; p.H = H;
-    const int tiles = (M + ccd::MB_BM - 1) / ccd::MB_BM, cus = ccd_rt_num_cus();      // (not ccd_grid_cus(): the row count of db1_ws is fixed)
-    const int grid = tiles < cus ? tiles : cus;
-    if (E == 384) CCD_LAUNCH((ccd::mlp_bwd_fused_kernel<384>), dim3(grid), dim3(ccd::MB_THREADS), smem, stream, p);
-    else if (E == 256) CCD_LAUNCH((ccd::mlp_bwd_fused_kernel<256>), dim3(grid), dim3(ccd::MB_THREADS), smem, stream, p);
-    else CCD_LAUNCH((ccd::mlp_bwd_fused_kernel<128>), dim3(grid), dim3(ccd::MB_THREADS), smem, stream, p);
-    // db1 += sum of the workgroups' partial rows (attention_bwd.h's row-sum kernel, its matvec branch unused)
-    CCD_LAUNCH(ccd::qkv_bias_finish_kernel, dim3((H + 63) / 64, 1), dim3(1024), 0, stream, db1_ws, grid, nullptr, nullptr, 0L, H, db1);
     return ccd_rt_last_error();
 }
 

@@ -110,12 +110,6 @@ __device__ __forceinline__ void lds_wait_frag(bf16x8& frag) { asm volatile("s_wa
 __device__ __forceinline__ void lds_gather_f32(float& dst, unsigned lds_addr) {
     asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(lds_addr));
 }
-// 8-byte gather (two consecutive floats of a table of pairs): one LDS operation for two values
-typedef __attribute__((ext_vector_type(2))) float lds_f32x2;
-__device__ __forceinline__ void lds_gather_f32x2(lds_f32x2& dst, unsigned lds_addr) {
-    asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(lds_addr));
-}
-__device__ __forceinline__ void lds_landed(lds_f32x2& a, lds_f32x2& b) { asm volatile("" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void lds_landed(float& a, float& b) { asm volatile("" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // the value lane (l ^ M) holds, M in {1, 2, 4, 8, 16}: DPP where gfx950 has a pattern for it (no LDS crossbar traffic), the

@@ -45,7 +45,6 @@ class Fusion:
     ln = _env_switch("CCD_FUSE_LN")                # LayerNorm in the epilogue of proj / fc2   (default: E <= 384)
     mlp = _env_switch("CCD_FUSE_MLP")              # fc1 -> GELU -> fc2 -> residual -> LayerNorm in one launch (default: with `ln`)
     lnbwd = _env_switch("CCD_FUSE_LNBWD")          # LayerNorm backward in the epilogue of the data-gradient product (default: on)
-    mlp_bwd = _env_switch("CCD_FUSE_MLP_BWD")      # gelu'(u) product + fc1 data gradient + LayerNorm-2 backward in one launch (default: E <= 384)
     side_stream = bool(_env_switch("CCD_SIDE_STREAM"))
     double_gb = False                       # tests: rotate the two gb buffers of the side-stream mode also without a side stream
 
@@ -55,10 +54,6 @@ class Fusion:
         mlp = ln and E % 128 == 0 and (cls.mlp if cls.mlp is not None else True)
         lnbwd = (E <= 384 or E == 512) and E % 8 == 0 and (cls.lnbwd if cls.lnbwd is not None else True)
         return ln, mlp, lnbwd
-
-    @classmethod
-    def mlp_backward_fused(cls, E):
-        return E in (128, 256, 384) and cls.resolve(E)[2] and (cls.mlp_bwd if cls.mlp_bwd is not None else True)
 
 
 _DROPPATH_SEED = {"base": None, "calls": 0}
@@ -270,8 +265,7 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
     # gb = bf16(g * DropPath scale), the gradient that enters a residual branch.  With the side stream on it lives in TWO
     # buffers used in turn: a LayerNorm backward writes the next branch's gb while the weight-gradient launch of the
     # previous branch (side stream) still reads the old one.
-    fuse_mlp_bwd = Fusion.mlp_backward_fused(E)      # (its kernel writes the next gb while the weight-gradient launch reads this one)
-    gbuf = [torch.empty((R, E), dtype=BF16, device=dev) for _ in range(2 if (side.on or Fusion.double_gb or fuse_mlp_bwd) else 1)]
+    gbuf = [torch.empty((R, E), dtype=BF16, device=dev) for _ in range(2 if (side.on or Fusion.double_gb) else 1)]
     readers = [None] * len(gbuf)      # event of the last side-stream launch that reads each buffer
     cur = [0]
 
@@ -311,45 +305,36 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
         # ---- MLP branch: x_out = x_mid + ds2 * fc2(gelu(fc1(LN2(x_mid))))
         gact, y2, att, y1 = c.gact, c.y2, c.att, c.y1
         gb = gb_read()
-        if fuse_mlp_bwd and gact is None:
-            # gelu'(u) product, fc1 data gradient and LayerNorm-2's backward in ONE launch (csrc/kernels/mlp_bwd.h): du is consumed
-            # from the registers it is computed in; du and gelu(u) are written once for the weight-gradient launch behind it
-            src_idx = cur[0]
-            du, gact = ops.mlp_bwd_fused(gb, arena.wbt(b + "mlp.fc2.weight"), arena.wbt(b + "mlp.fc1.weight"), c.u,
-                                         db1=arena.g(b + "mlp.fc1.bias"), x=c.x_mid, mean=c.mean2, rstd=c.rstd2,
-                                         gamma=arena.w(b + "norm2.weight"), g=g, dgamma=arena.g(b + "norm2.weight"),
-                                         dbeta=arena.g(b + "norm2.bias"), gb_out=gb_write(), rowscale=c.ds1, rows_per_sample=256,
-                                         dbias=arena.g(b + "attn.proj.bias"))
-            readers[src_idx] = side.run(
-                lambda gb=gb, du=du, gact=gact: ops.gemm_tn_pair(gb, gact, arena.g(b + "mlp.fc2.weight"), du, y2,
-                                                                 arena.g(b + "mlp.fc1.weight")), gb, gact, du, y2)
+        # (Round 3 built the whole chain - gelu'(u) product, fc1 data gradient, LayerNorm-2 backward - as ONE row-owner kernel, the
+        # mirror of mlp_fused.h: correct (sim + GPU tests) and SLOWER, 836 us per block against 717 for the two launches below.  u has
+        # to stream in from HBM between the weight pieces of the LDS-DMA ring, and gfx950 counts loads, stores and DMA on one vmcnt:
+        # every ring wait behind a u request also waits for that request's HBM latency.  profiles/r03_mlp_bwd_fused_ab.jsonl.)
+        if gact is None:        # fused-MLP forward kept only u: gelu(u) comes out of the gelu'(u) epilogue below
+            gact = torch.empty_like(c.u)
+            du = ops.gemm_nt(gb, arena.wbt(b + "mlp.fc2.weight"), epilogue=ops.EPI_DGELU, aux=c.u, out2=gact,
+                             colsum=arena.g(b + "mlp.fc1.bias"))
         else:
-            if gact is None:        # fused-MLP forward kept only u: gelu(u) comes out of the gelu'(u) epilogue below
-                gact = torch.empty_like(c.u)
-                du = ops.gemm_nt(gb, arena.wbt(b + "mlp.fc2.weight"), epilogue=ops.EPI_DGELU, aux=c.u, out2=gact,
-                                 colsum=arena.g(b + "mlp.fc1.bias"))
-            else:
-                du = ops.gemm_nt(gb, arena.wbt(b + "mlp.fc2.weight"), epilogue=ops.EPI_DGELU, aux=c.u,
-                                 colsum=arena.g(b + "mlp.fc1.bias"))
+            du = ops.gemm_nt(gb, arena.wbt(b + "mlp.fc2.weight"), epilogue=ops.EPI_DGELU, aux=c.u,
+                             colsum=arena.g(b + "mlp.fc1.bias"))
 
-            # both weight gradients of the MLP in ONE launch (ccd_gemm_tn_pair: the same rows, one atomic epilogue per workgroup)
-            def mlp_grads(gb=gb, du=du, gact=gact):
-                ops.gemm_tn_pair(gb, gact, arena.g(b + "mlp.fc2.weight"), du, y2, arena.g(b + "mlp.fc1.weight"))
-            if fuse_lnbwd:       # dy2 = du . W1 never leaves the chip: LayerNorm-2's backward is the product's epilogue
-                readers[cur[0]] = side.run(mlp_grads, gb, gact, du, y2)
-                ops.gemm_nt_lnbwd(du, arena.wbt(b + "mlp.fc1.weight"), c.x_mid, c.mean2, c.rstd2, arena.w(b + "norm2.weight"), g,
-                                  arena.g(b + "norm2.weight"), arena.g(b + "norm2.bias"), accumulate=True, gb=gb_write(),
-                                  rowscale=c.ds1, rows_per_sample=256, dbias=arena.g(b + "attn.proj.bias"))
-            else:
-                # unfused: the product first, THEN the weight-gradient launch (side stream: it starts once the product is done)
-                # and the HBM-bound LayerNorm backward beside it - ln_bwd_kernel's 6 KiB of LDS and 44 registers fit next to a
-                # 144-KiB gemm_tn384 workgroup.  MEASURED (round 3, profiles/r03_side_stream_ab.jsonl): the two do run
-                # concurrently, and each takes as much longer as the other lasts - no gain; the fused path is the default.
-                dy2 = ops.gemm_nt(du, arena.wbt(b + "mlp.fc1.weight"))
-                readers[cur[0]] = side.run(mlp_grads, gb, gact, du, y2)
-                ops.ln_bwd(dy2, c.x_mid, c.mean2, c.rstd2, arena.w(b + "norm2.weight"), g, arena.g(b + "norm2.weight"),
-                           arena.g(b + "norm2.bias"), accumulate=True, gb=gb_write(), rowscale=c.ds1, rows_per_sample=256,
-                           dbias=arena.g(b + "attn.proj.bias"))
+        # both weight gradients of the MLP in ONE launch (ccd_gemm_tn_pair: the same rows, one atomic epilogue per workgroup)
+        def mlp_grads(gb=gb, du=du, gact=gact):
+            ops.gemm_tn_pair(gb, gact, arena.g(b + "mlp.fc2.weight"), du, y2, arena.g(b + "mlp.fc1.weight"))
+        if fuse_lnbwd:       # dy2 = du . W1 never leaves the chip: LayerNorm-2's backward is the product's epilogue
+            readers[cur[0]] = side.run(mlp_grads, gb, gact, du, y2)
+            ops.gemm_nt_lnbwd(du, arena.wbt(b + "mlp.fc1.weight"), c.x_mid, c.mean2, c.rstd2, arena.w(b + "norm2.weight"), g,
+                              arena.g(b + "norm2.weight"), arena.g(b + "norm2.bias"), accumulate=True, gb=gb_write(),
+                              rowscale=c.ds1, rows_per_sample=256, dbias=arena.g(b + "attn.proj.bias"))
+        else:
+            # unfused: the product first, THEN the weight-gradient launch (side stream: it starts once the product is done)
+            # and the HBM-bound LayerNorm backward beside it - ln_bwd_kernel's 6 KiB of LDS and 44 registers fit next to a
+            # 144-KiB gemm_tn384 workgroup.  MEASURED (round 3, profiles/r03_side_stream_ab.jsonl): the two do run
+            # concurrently, and each takes as much longer as the other lasts - no gain; the fused path is the default.
+            dy2 = ops.gemm_nt(du, arena.wbt(b + "mlp.fc1.weight"))
+            readers[cur[0]] = side.run(mlp_grads, gb, gact, du, y2)
+            ops.ln_bwd(dy2, c.x_mid, c.mean2, c.rstd2, arena.w(b + "norm2.weight"), g, arena.g(b + "norm2.weight"),
+                       arena.g(b + "norm2.bias"), accumulate=True, gb=gb_write(), rowscale=c.ds1, rows_per_sample=256,
+                       dbias=arena.g(b + "attn.proj.bias"))
         del du
         # ---- attention branch: x_mid = x_in + ds1 * proj(attn(qkv(LN1(x_in))))
         gb = gb_read()

@@ -175,31 +175,6 @@ def gemm_nt_lnbwd(a, b, x, mean, rstd, gamma, g, dgamma, dbeta, accumulate=True,
     return g
 
 
-def mlp_bwd_fused(gb, w2t, w1t, u, *, db1, x, mean, rstd, gamma, g, dgamma, dbeta, gb_out, rowscale=None, rows_per_sample=1,
-                  dbias=None, accumulate=True):
-    """The data-gradient chain of the MLP branch in one launch (include/ccd_hip.h: ccd_mlp_bwd_fused):
-    du = (gb @ w2t^T) * gelu'(u), gact = gelu(u), dy2 = du @ w1t^T, then LayerNorm-2's backward of dy2 as in gemm_nt_lnbwd.
-    w2t = fc2.weight^T [H, E], w1t = fc1.weight^T [E, H].  -> (du, gact) bf16 [M, H]; db1 += colsum(du)."""
-    _chk(gb, BF16, "gb"); _chk(w2t, BF16, "w2t"); _chk(w1t, BF16, "w1t"); _chk(u, BF16, "u"); _chk(x, F32, "x"); _chk(g, F32, "g")
-    _chk(gb_out, BF16, "gb_out"); _chk(db1, F32, "db1"); _chk(rowscale, F32, "rowscale")
-    M, E = gb.shape
-    H = w2t.shape[0]
-    assert tuple(w2t.shape) == (H, E) and tuple(w1t.shape) == (E, H) and tuple(u.shape) == (M, H) and tuple(x.shape) == (M, E)
-    assert gb_out is None or gb_out.data_ptr() != gb.data_ptr()
-    du = torch.empty((M, H), dtype=BF16, device=gb.device)
-    gact = torch.empty((M, H), dtype=BF16, device=gb.device)
-    ws = torch.empty(int(_lib.get().ccd_mlp_bwd_ws_floats(M, H)), dtype=F32, device=gb.device)
-    # algorithmic bytes: gb, u in; du, gact out; x in; g in + out; gb_out out; the weights once
-    nbytes = M * (2.0 * E + 6.0 * H + 4.0 * E + (8.0 if accumulate else 4.0) * E + (2.0 * E if gb_out is not None else 0.0)) + 4.0 * E * H
-    with _Span("mlp_bwd_fused", 4.0 * M * E * H, nbytes):
-        _call("ccd_mlp_bwd_fused", _lib.ptr(gb), gb.stride(0), _lib.ptr(w2t), w2t.stride(0), _lib.ptr(w1t), w1t.stride(0),
-              _lib.ptr(u), u.stride(0), _lib.ptr(du), du.stride(0), _lib.ptr(gact), gact.stride(0), _lib.ptr(db1), _lib.ptr(ws),
-              _lib.ptr(x), x.stride(0), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(g), g.stride(0),
-              1 if accumulate else 0, _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(gb_out), 0 if gb_out is None else gb_out.stride(0),
-              _lib.ptr(rowscale), int(rows_per_sample), _lib.ptr(dbias), M, E, H)
-    return du, gact
-
-
 def mlp_fused(y, w1, b1, w2, b2, *, resid, rowscale, rows_per_sample, gamma, beta, eps, store_u=False, out=None):
     """out (fp32) = resid + (gelu(y @ w1^T + b1) @ w2^T + b2) * rowscale[row // rows_per_sample];
     y_next = LayerNorm(out) * gamma + beta  ->  (out, y_next bf16, mean, rstd, u bf16 | None).

@@ -131,19 +131,6 @@ int ccd_ln_bwd(const ccd_bf16* dy, const float* x, const float* mean, const floa
                float* g, int accumulate, float* dgamma, float* dbeta, ccd_bf16* gb, const float* rowscale,
                int rows_per_sample, float* dbias, int rows, int E, void* stream);
 
-/* The data-gradient chain of the MLP branch in one launch - the backward of ccd_mlp_fused (vit.py:59-65 in Block.forward
- * :107-113): dh = gb . W2 ; du = dh * gelu'(u) ; gact = gelu(u) ; dy2 = du . W1 ; LayerNorm-2 backward of dy2 as in
- * ccd_gemm_nt_lnbwd (g (+)= dx, dgamma / dbeta += , gb_out = bf16(g * rowscale[row / rows_per_sample]), dbias += colsum(gb_out)).
- * w2t = fc2.weight^T [H, E], w1t = fc1.weight^T [E, H] (the transposed bf16 mirrors).  du and gact [M, H] are written for the
- * weight-gradient products (ccd_gemm_tn_pair) that follow; db1 += column sums of du (fc1.bias gradient) through db1_ws =
- * ccd_mlp_bwd_ws_floats(M, H) floats of scratch (per-workgroup partial rows).  gb_out must not alias gb.  E in {128, 256, 384}. */
-long ccd_mlp_bwd_ws_floats(int M, int H);
-int ccd_mlp_bwd_fused(const ccd_bf16* gb, long ldgb, const ccd_bf16* w2t, long ld2, const ccd_bf16* w1t, long ld1, const ccd_bf16* u,
-                      long ldu, ccd_bf16* du, long lddu, ccd_bf16* gact, long ldga, float* db1, float* db1_ws, const float* x, long ldx,
-                      const float* mean, const float* rstd, const float* gamma, float* g, long ldg, int accumulate, float* dgamma,
-                      float* dbeta, ccd_bf16* gb_out, long ld_gbo, const float* rowscale, int rows_per_sample, float* dbias, int M,
-                      int E, int H, void* stream);
-
 /* ---------------------------------------------------------------- attention, vit.py:80-92 (T = 256, head_dim = 64)
  * qkv [views, 256, 3, heads, 64] bf16 (the layout Attention.forward reshapes to), out [views, 256, heads*64]  */
 int ccd_attention_fwd(const ccd_bf16* qkv, ccd_bf16* out, float* lse, int views, int heads, float scale,

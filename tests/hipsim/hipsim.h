@@ -204,9 +204,6 @@ inline void lds_read_frag(bf16x8& dst, unsigned lds_addr) { std::memcpy(&dst, si
 template <int N>
 inline void lds_wait_frag(bf16x8&) {}
 inline void lds_gather_f32(float& dst, unsigned lds_addr) { std::memcpy(&dst, sim::curblk->dyn_smem + lds_addr, 4); }
-typedef __attribute__((ext_vector_type(2))) float lds_f32x2;
-inline void lds_gather_f32x2(lds_f32x2& dst, unsigned lds_addr) { std::memcpy(&dst, sim::curblk->dyn_smem + lds_addr, 8); }
-inline void lds_landed(lds_f32x2&, lds_f32x2&) {}
 inline void lds_landed(float&, float&) {}
 inline void lds_drain() {}
 template <int P>

@@ -114,14 +114,6 @@ def test_attention_sim(sim):
     kc.check_attention(sim.device, views=3, heads=1, seed=4)
 
 
-def test_mlp_bwd_fused_sim(sim, monkeypatch):
-    """mlp_bwd.h on the CPU executor: ragged tiles, several tiles per workgroup (the ring runs across them), every E."""
-    monkeypatch.setenv("CCD_SIM_CUS", "2")
-    kc.check_mlp_bwd_fused(sim.device, M=200, E=384, H=128, rps=8)
-    kc.check_mlp_bwd_fused(sim.device, M=128 * 4 + 40, E=128, H=256, rps=128, seed=5)      # 5 tiles on 2 workgroups
-    kc.check_mlp_bwd_fused(sim.device, M=130, E=256, H=192, rps=64, seed=6)
-
-
 def test_gemm_dynamic_rows_sim(sim):
     import torch
     from ccd_amd import ops
