@@ -231,8 +231,8 @@ static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, void* stream) {
 
 extern "C" {
 
-int ccd_abi_version(void) { return 4; }   // 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
-const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi4"; }
+int ccd_abi_version(void) { return 5; }   // 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
+const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi5"; }
 int ccd_policy_set(const char* key, int value) {
     CCD_CHECK(key, CCD_EINVAL);
     for (const CcdPolicyKey& k : ccd_policy_keys)
@@ -383,14 +383,14 @@ int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, 
 int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, const float* b1, const ccd_bf16* w2, long ld2,
                   const float* b2, const float* resid, long ldr, const float* rowscale, int rows_per_sample, float* out,
                   long ldc, const float* ln_gamma, const float* ln_beta, float ln_eps, ccd_bf16* ln_y, long ld_y,
-                  float* ln_mean, float* ln_rstd, ccd_bf16* u, long ldu, int M, int E, int H, void* stream) {
+                  float* ln_mean, float* ln_rstd, ccd_bf16* u, long ldu, ccd_bf16* gact, long ldga, int M, int E, int H, void* stream) {
     CCD_CHECK(y && w1 && b1 && w2 && b2 && resid && out && ln_gamma && ln_beta && ln_y && ln_mean && ln_rstd, CCD_EINVAL);
     CCD_CHECK(CCD_ALIGNED16(y) && CCD_ALIGNED16(w1) && CCD_ALIGNED16(w2) && CCD_ALIGNED16(resid) && CCD_ALIGNED16(out) &&
               CCD_ALIGNED16(ln_y) && CCD_ALIGNED16(u), CCD_EINVAL);
     if (M == 0) return CCD_OK;
     CCD_CHECK(M > 0 && H > 0 && (!rowscale || rows_per_sample > 0), CCD_EINVAL);
     CCD_CHECK((E == 128 || E == 256 || E == 384 || E == 512) && H % 64 == 0 && ldy % 8 == 0 && ld1 % 8 == 0 && ld2 % 8 == 0 && ldr % 4 == 0 &&
-              ldc % 4 == 0 && ld_y % 8 == 0 && (!u || ldu % 8 == 0), CCD_ESHAPE);
+              ldc % 4 == 0 && ld_y % 8 == 0 && (!u || ldu % 8 == 0) && (!gact || (u && ldga % 8 == 0 && CCD_ALIGNED16(gact))), CCD_ESHAPE);
     CCD_CHECK((long)H * ld1 * 2 < CCD_MAX_OPERAND_BYTES && (long)E * ld2 * 2 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
     const int smem = ccd::mlp_smem_bytes(E, H);
     CCD_CHECK(smem <= 160 * 1024, CCD_ESHAPE);
@@ -398,7 +398,7 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
     p.y = y; p.ldy_in = ldy; p.w1 = w1; p.ld1 = ld1; p.b1 = b1; p.w2 = w2; p.ld2 = ld2; p.b2 = b2; p.resid = resid; p.ldr = ldr;
     p.rowscale = rowscale; p.rows_per_sample = rowscale ? rows_per_sample : 1; p.out = out; p.ldc = ldc;
     p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_eps = ln_eps; p.ln_y = ln_y; p.ld_y = ld_y; p.ln_mean = ln_mean;
-    p.ln_rstd = ln_rstd; p.u = u; p.ldu = ldu; p.M = M; p.H = H; p.lab = ccd_policy().lab;
+    p.ln_rstd = ln_rstd; p.u = u; p.ldu = ldu; p.gact = gact; p.ldga = ldga; p.M = M; p.H = H; p.lab = ccd_policy().lab;
     const int tiles = (M + ccd::MLP_BM - 1) / ccd::MLP_BM, cus = ccd_grid_cus();
     const dim3 grid(tiles < cus ? tiles : cus), block(ccd::MLP_THREADS);
     if (E == 512) {

@@ -57,6 +57,8 @@ struct MlpParams {
     float* ln_rstd;
     bf16_t* u;              // optional [M, H] bf16 pre-activation (STORE_U)
     long ldu;
+    bf16_t* gact;           // optional (with u) [M, H] bf16 gelu(u): what the weight-gradient product dW2 = gb^T . gelu(u) reads.  Stored
+    long ldga;              // here, the gelu'(u) product of the backward pass neither gathers Phi a second time nor writes gelu(u)
     int M, H;
     int lab;                // experiment switch (policy key "lab"): n > 0 delays odd workgroups by ~n * 8 k cycles
 };
@@ -255,6 +257,8 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
     const buf_rsrc rs_o = make_rsrc(p.out, (unsigned)((((long)p.M - 1) * p.ldc + E) * 4));
     const buf_rsrc rs_n = make_rsrc(p.ln_y, (unsigned)((((long)p.M - 1) * p.ld_y + E) * 2));
     const buf_rsrc rs_u = make_rsrc(STORE_U ? p.u : nullptr, STORE_U ? (unsigned)((((long)p.M - 1) * p.ldu + p.H) * 2) : 0u);
+    const bool store_g = STORE_U && p.gact != nullptr;
+    const buf_rsrc rs_ga = make_rsrc(store_g ? p.gact : nullptr, store_g ? (unsigned)((((long)p.M - 1) * p.ldga + p.H) * 2) : 0u);
     // per-lane offsets of the row-tile traffic are recomputed from the lane id where they are used (LaneOff below): kept in
     // registers across the main loop they were the first values the allocator spilled, and a scratch reload in front of
     // every store (s_waitcnt vmcnt(0)!) serialised the whole epilogue
@@ -322,6 +326,14 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         buf_store16(rs_u, lo_u, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldu * 2) + 128 * cc, u32x4{0u, 0u, 0u, 0u});
+                if (store_g) {
+                    const unsigned lo_g = LaneOff(t).rows8(p.ldga, 2);
+#pragma unroll 1
+                    for (int cc = 0; cc < p.H / 64; ++cc)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            buf_store16(rs_ga, lo_g, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldga * 2) + 128 * cc, u32x4{0u, 0u, 0u, 0u});
+                }
             }
             continue;
         }
@@ -464,6 +476,18 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                         buf_store16(rs_u, lo_u, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldu * 2) + 128 * c, v);
                     }
                     wave_lds_fence();
+                    if (store_g) {         // gelu(u): the packed B operands of the second product ARE the image's 16-byte slots
+                        const unsigned lo_g = lo.rows8(p.ldga, 2);
+#pragma unroll
+                        for (int k4 = 0; k4 < 4; ++k4) *reinterpret_cast<u32x4*>(scratch + lo.scr_wr(2 * k4 + lo.hf)) = hbw[k4];
+                        wave_lds_fence();
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const u32x4 v = *reinterpret_cast<const u32x4*>(scratch + lo.scr_rd(i));
+                            buf_store16(rs_ga, lo_g, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldga * 2) + 128 * c, v);
+                        }
+                        wave_lds_fence();
+                    }
                 }
                 MLP_STAMP(5)
                 p2_piece(I0{});

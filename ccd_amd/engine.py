@@ -45,6 +45,7 @@ class Fusion:
     ln = _env_switch("CCD_FUSE_LN")                # LayerNorm in the epilogue of proj / fc2   (default: E <= 384)
     mlp = _env_switch("CCD_FUSE_MLP")              # fc1 -> GELU -> fc2 -> residual -> LayerNorm in one launch (default: with `ln`)
     lnbwd = _env_switch("CCD_FUSE_LNBWD")          # LayerNorm backward in the epilogue of the data-gradient product (default: on)
+    store_gact = _env_switch("CCD_STORE_GACT")     # the fused MLP forward also stores gelu(u) for the backward pass (default: see resolve_store_gact)
     side_stream = bool(_env_switch("CCD_SIDE_STREAM"))
     double_gb = False                       # tests: rotate the two gb buffers of the side-stream mode also without a side stream
 
@@ -157,12 +158,16 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
             c.y2, c.mean2, c.rstd2 = ops.ln_fwd(c.x_mid, arena.w(b + "norm2.weight"), arena.w(b + "norm2.bias"), spec.eps)
         if fuse_mlp:
             nxt = f"{pre}blocks.{i + 1}.norm1." if i + 1 < spec.depth else pre + "norm."
-            x, y_n, mean_n, rstd_n, c.u = ops.mlp_fused(
+            # (store_gact: gelu(u) leaves the forward kernel too - its packed second-product operands ARE that tensor - so the
+            # backward's gelu'(u) product gathers one table instead of two and writes du only)
+            keep_g = bool(save and Fusion.store_gact)
+            res = ops.mlp_fused(
                 c.y2, arena.wb(b + "mlp.fc1.weight"), arena.w(b + "mlp.fc1.bias"), arena.wb(b + "mlp.fc2.weight"),
                 arena.w(b + "mlp.fc2.bias"), resid=c.x_mid, rowscale=c.ds2, rows_per_sample=256,
-                gamma=arena.w(nxt + "weight"), beta=arena.w(nxt + "bias"), eps=spec.eps, store_u=save)
+                gamma=arena.w(nxt + "weight"), beta=arena.w(nxt + "bias"), eps=spec.eps, store_u=save, store_gact=keep_g)
+            x, y_n, mean_n, rstd_n, c.u = res[:5]
+            c.gact = res[5] if keep_g else None
             pending = [y_n, mean_n, rstd_n]
-            c.gact = None
         elif fuse_ln:
             c.u, c.gact = ops.gemm_nt(c.y2, arena.wb(b + "mlp.fc1.weight"), epilogue=ops.EPI_GELU,
                                       bias=arena.w(b + "mlp.fc1.bias"), store_u=save)   # u only feeds gelu' in backward

@@ -175,10 +175,11 @@ def gemm_nt_lnbwd(a, b, x, mean, rstd, gamma, g, dgamma, dbeta, accumulate=True,
     return g
 
 
-def mlp_fused(y, w1, b1, w2, b2, *, resid, rowscale, rows_per_sample, gamma, beta, eps, store_u=False, out=None):
+def mlp_fused(y, w1, b1, w2, b2, *, resid, rowscale, rows_per_sample, gamma, beta, eps, store_u=False, store_gact=False, out=None):
     """out (fp32) = resid + (gelu(y @ w1^T + b1) @ w2^T + b2) * rowscale[row // rows_per_sample];
-    y_next = LayerNorm(out) * gamma + beta  ->  (out, y_next bf16, mean, rstd, u bf16 | None).
-    The hidden activation never reaches HBM; `u` (the bf16 pre-activation) is written only when store_u."""
+    y_next = LayerNorm(out) * gamma + beta  ->  (out, y_next bf16, mean, rstd, u bf16 | None[, gelu(u) bf16 with store_gact]).
+    The hidden activation never reaches HBM; `u` (the bf16 pre-activation) is written only when store_u, gelu(u) only when
+    store_gact (the weight-gradient product of the backward pass reads it)."""
     _chk(y, BF16, "y"); _chk(w1, BF16, "w1"); _chk(w2, BF16, "w2"); _chk(b1, F32, "b1"); _chk(b2, F32, "b2")
     _chk(resid, F32, "resid"); _chk(rowscale, F32, "rowscale")
     M, E = y.shape
@@ -191,18 +192,20 @@ def mlp_fused(y, w1, b1, w2, b2, *, resid, rowscale, rows_per_sample, gamma, bet
     mean = torch.empty(M, dtype=F32, device=dev)
     rstd = torch.empty(M, dtype=F32, device=dev)
     u = torch.empty((M, H), dtype=BF16, device=dev) if store_u else None
-    # algorithmic bytes: y read, resid read, out + y_next written (+ u), weights once
-    nbytes = M * E * (2.0 + 4.0 + 4.0 + 2.0) + (2.0 * M * H if store_u else 0.0) + 4.0 * E * H
+    gact = torch.empty((M, H), dtype=BF16, device=dev) if (store_u and store_gact) else None
+    # algorithmic bytes: y read, resid read, out + y_next written (+ u, + gelu(u)), weights once
+    nbytes = M * E * (2.0 + 4.0 + 4.0 + 2.0) + (2.0 * M * H if store_u else 0.0) + (2.0 * M * H if gact is not None else 0.0) + 4.0 * E * H
     span = TIMER.span("mlp_fused", 4.0 * M * E * H, nbytes) if TIMER is not None else None
     if span:
         span[0].record()
     _call("ccd_mlp_fused", _lib.ptr(y), y.stride(0), _lib.ptr(w1), w1.stride(0), _lib.ptr(b1), _lib.ptr(w2), w2.stride(0),
           _lib.ptr(b2), _lib.ptr(resid), resid.stride(0), _lib.ptr(rowscale), int(rows_per_sample), _lib.ptr(out),
           out.stride(0), _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(yn), yn.stride(0), _lib.ptr(mean),
-          _lib.ptr(rstd), _lib.ptr(u), 0 if u is None else u.stride(0), M, E, H)
+          _lib.ptr(rstd), _lib.ptr(u), 0 if u is None else u.stride(0), _lib.ptr(gact), 0 if gact is None else gact.stride(0),
+          M, E, H)
     if span:
         span[1].record()
-    return out, yn, mean, rstd, u
+    return (out, yn, mean, rstd, u, gact) if store_gact else (out, yn, mean, rstd, u)
 
 
 def gemm_tn_colsum(a, b, out, colsum, *, splits=0):

@@ -93,12 +93,14 @@ int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, 
  *   h = gelu(bf16(y . W1^T + b1)) ;  out (f32) = resid + (h . W2^T + b2) * rowscale[row / rows_per_sample]
  *   ln_y (bf16) = (out - mean) * rstd * ln_gamma + ln_beta ;  ln_mean / ln_rstd [M] saved for ccd_ln_bwd
  * The [M, H] hidden activation stays on chip; `u` (optional, [M, H] bf16) receives the pre-activation the backward
- * pass needs.  W1 = fc1.weight [H, E], W2 = fc2.weight [E, H] (bf16).  E in {128, 256, 384, 512}, H % 64 == 0.
+ * pass needs, `gact` (optional, only with u) gelu(u) - the operand of the weight-gradient product dW2 = gb^T . gelu(u): stored
+ * here, the backward's gelu'(u) product (CCD_EPI_DGELU) neither looks Phi up a second time nor writes gelu(u).
+ * W1 = fc1.weight [H, E], W2 = fc2.weight [E, H] (bf16).  E in {128, 256, 384, 512}, H % 64 == 0.
  * Replaces ccd_gemm_nt(EPI_GELU) + ccd_gemm_nt_resid_ln. */
 int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, const float* b1, const ccd_bf16* w2, long ld2,
                   const float* b2, const float* resid, long ldr, const float* rowscale, int rows_per_sample, float* out,
                   long ldc, const float* ln_gamma, const float* ln_beta, float ln_eps, ccd_bf16* ln_y, long ld_y,
-                  float* ln_mean, float* ln_rstd, ccd_bf16* u, long ldu, int M, int E, int H, void* stream);
+                  float* ln_mean, float* ln_rstd, ccd_bf16* u, long ldu, ccd_bf16* gact, long ldga, int M, int E, int H, void* stream);
 /* colsum (optional, epilogues BF16 / DGELU): [N] fp32, += column sums of the output (bias gradient of the producer).
  * CCD_EPI_GELU accepts C == NULL (only gelu(u) is stored: forward passes that keep no activations). */
 /* C[P,Q] (+)= sum_m A[m,P] * B[m,Q]   (weight gradients dW = dY^T X of every Linear; autograd of the above)

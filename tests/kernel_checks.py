@@ -917,9 +917,11 @@ def check_mlp_fused(dev, M, E, H, rps=128, seed=31, store_u=True):
         rowscale[1] = 0.0                                  # a dropped sample is always present
     gamma, beta = rnd((E,), g).abs() + 0.5, rnd((E,), g) * 0.3
     for rs in (rowscale, None):
-        out, yn, mean, rstd, u = ops.mlp_fused(y.to(dev), w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), resid=resid.to(dev),
-                                               rowscale=None if rs is None else rs.to(dev), rows_per_sample=rps,
-                                               gamma=gamma.to(dev), beta=beta.to(dev), eps=1e-6, store_u=store_u)
+        out, yn, mean, rstd, u, gact = ops.mlp_fused(y.to(dev), w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), resid=resid.to(dev),
+                                                     rowscale=None if rs is None else rs.to(dev), rows_per_sample=rps,
+                                                     gamma=gamma.to(dev), beta=beta.to(dev), eps=1e-6, store_u=store_u,
+                                                     store_gact=True)
+        assert (gact is not None) == store_u
         u_ref = (y.float() @ w1.float().t() + b1).to(BF)
         h_ref = F.gelu(u_ref.float()).to(BF).float()
         scale = 1.0 if rs is None else rs.repeat_interleave(rps)[:M, None]
@@ -935,6 +937,12 @@ def check_mlp_fused(dev, M, E, H, rps=128, seed=31, store_u=True):
                     if rs[t0 // rps] == 0:
                         u_want[t0:t0 + 128] = 0
             close(u, u_want, 8e-3, 1e-3, tag + "/u")
+            # gelu(u) of the STORED u (what the backward's gelu'(u) product would derive from it), exactly the second product's operand
+            close(gact, F.gelu(u.float().cpu()), 8e-3, 1e-6, tag + "/gelu(u)")
+            plain = ops.mlp_fused(y.to(dev), w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), resid=resid.to(dev),
+                                  rowscale=None if rs is None else rs.to(dev), rows_per_sample=rps, gamma=gamma.to(dev),
+                                  beta=beta.to(dev), eps=1e-6, store_u=True)
+            assert len(plain) == 5 and torch.equal(plain[0], out) and torch.equal(plain[4], u)
         # bf16 roundings of u / gelu(u) that flip by one ulp move a row sum by ~2e-4 each: tolerance grows with sqrt(H)
         close(out, want, 2e-3, 3e-3 * max(1.0, (H / 128) ** 0.5), tag + "/out")
         mu, var = want.mean(1), want.var(1, unbiased=False)

@@ -11,6 +11,12 @@ import sqlite3
 
 
 def short(name):
+    name = name[:-3] if name.endswith(".kd") else name
+    try:
+        import subprocess
+        name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name
+    except OSError:
+        pass
     name = re.sub(r"\(.*", "", name).replace("void ", "")
     return name[:100]
 
@@ -20,6 +26,8 @@ def main():
     ap.add_argument("db")
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--marker", default="patch_embed_fwd")
+    ap.add_argument("--markers-per-step", type=int, default=1, help="launches of the marker kernel per training iteration "
+                    "(pretraining: 2 - the student's and the teacher's patch embedding)")
     a = ap.parse_args()
     cur = sqlite3.connect(a.db).cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
@@ -27,7 +35,7 @@ def main():
     ks = [t for t in tabs if "kernel_symbol" in t][0]
     names = {r[0]: r[1] for r in cur.execute(f"select id, kernel_name from {ks}")}
     rows = sorted((s, e, names[k]) for s, e, k in cur.execute(f"select start, end, kernel_id from {kd}"))
-    marks = [i for i, r in enumerate(rows) if a.marker in r[2]]
+    marks = [i for i, r in enumerate(rows) if a.marker in r[2]][::a.markers_per_step]
     assert len(marks) >= a.steps + 1, f"only {len(marks)} steps in the trace"
     lo, hi = marks[-a.steps - 1], marks[-1]
     sel = rows[lo:hi]
