@@ -92,7 +92,6 @@ struct CcdPolicy {
     int attn_skew = 0;          // attention backward: waves 4..7 start each block ~skew * 64 cycles late (lab; no effect once clocks are warm)
     int gemm_tn384 = 1;         // weight gradients with P % 384 == 0, Q % 192 == 0: XCD-grouped 384x192 LDS-DMA kernel (gemm_tn384.h); 0 = 128-square kernel, 2 = never as a pair
     int gemm_tn384_geom = 0;    // its workgroup: 0 = 384x192 tile, 8 waves, one per CU; 2 = 0 + 512x128 tiles for the shapes 384x192 does not divide (E = 512)
-    int gemm_tn384_skew = 0;    // per cent by which its first / last contraction slice is shorter / longer than the mean (0: equal slices)
     int gemm_tn384_min_tiles = 6;   // ... for a SINGLE product only from this many tiles on (proj, 2 tiles = 128 slices: the atomic epilogue dominates)
     int cu_reserve = 0;         // compute units the persistent grids leave free (set while an RCCL gradient reducer is attached)
     int cu_reserve_window = -1; // -1: every launch leaves them free; N >= 0: only the next `cu_reserve_left` launches do (the reducer
@@ -105,7 +104,7 @@ static const CcdPolicyKey ccd_policy_keys[] = {
     {"gemm_256_min_n", &CcdPolicy::gemm_256_min_n}, {"gemm_256_f32", &CcdPolicy::gemm_256_f32},
     {"gemm_256_deep", &CcdPolicy::gemm_256_deep}, {"gemm_row384", &CcdPolicy::gemm_row384},
     {"rowproj", &CcdPolicy::rowproj}, {"rowproj_min_m", &CcdPolicy::rowproj_min_m},
-    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_skew", &CcdPolicy::gemm_tn384_skew}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"lab", &CcdPolicy::lab}};
+    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"lab", &CcdPolicy::lab}};
 static CcdPolicy& ccd_policy() {
     static CcdPolicy pol = [] {
         CcdPolicy q;
@@ -225,15 +224,6 @@ static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, void* stream) {
     };
     p.k_per_split = rows_per(s1); p.work_items = s1;
     if (t2 > 0) { p.per2 = rows_per(s2); p.slices2 = s2; }
-    // unequal slices (policy gemm_tn384_skew = the first / last slice's deviation from the mean length, in per cent): the atomic
-    // epilogues of the early finishers run under the main loops of the late ones instead of all 256 workgroups queueing at once
-    auto skew = [&](int per, int slices) {
-        if (slices < 2) return 0;
-        const int d = (ccd_policy().gemm_tn384_skew * per / 100 / (slices - 1)) / ccd::TN3_BK * ccd::TN3_BK;
-        return per - d * (slices - 1) >= 4 * ccd::TN3_BK && (long)(slices - 1) * per - (long)d * (slices - 1) < Mc ? d : 0;
-    };
-    p.k_skew = skew(p.k_per_split, s1);
-    p.k_skew2 = t2 > 0 ? skew(p.per2, s2) : 0;
     p.units1 = units1; p.units2 = units2; p.m_fastest = xcds;
     CCD_LAUNCH((ccd::gemm_tn384_kernel<WM, WN, STAGES, TI, TJ>), dim3(xcds * spx), dim3(G::THREADS), G::SMEM_BYTES, stream, p);
     return ccd_rt_last_error();

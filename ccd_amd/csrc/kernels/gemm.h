@@ -60,9 +60,6 @@ struct GemmParams {
     // per XCD); a group works on one contraction slice of ITS problem: slices2 slices of per2 rows for the second problem
     unsigned long long units1, units2;
     int slices2, per2;
-    // gemm_tn384.h: slice s of a problem is k_per_split + k_skew (2 s - S + 1) rows long (S slices; k_skew a multiple of 32, 0 = equal
-    // slices): the workgroups then reach their fp32-atomic epilogues at different times instead of all at once
-    int k_skew, k_skew2;
     float* colsumsq;        // optional [N] fp32: += column sums of squares (BatchNorm batch statistics), EPI_BF16 only
     // ---- implicit-GEMM convolution (NT, GATHER instantiation): A row r is pixel (n, oy, ox) of a 2^gh x 2^gw grid,
     // contraction index k = tap * cin + c reads source pixel (oy*s_mul + dy(tap), ox*s_mul + dx(tap)) of an s_h x s_w

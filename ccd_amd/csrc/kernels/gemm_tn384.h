@@ -92,15 +92,16 @@ __global__ __launch_bounds__(64 * WM * WN, 8 / (WM * WN)) void gemm_tn384_kernel
         tile = s2 % tiles2;
         slice = base2 + s2 / tiles2;
         p.A = p.A2; p.B = p.B2; p.lda = p.lda2; p.ldb = p.ldb2; p.N = p.N2; p.C = p.C2; p.ldc = p.ldc2;
-        p.k_per_split = p.per2; p.work_items = p.slices2; p.k_skew = p.k_skew2;
+        p.k_per_split = p.per2; p.work_items = p.slices2;
     }
     if (slice >= p.work_items) return;
     const int tiles_q = p.N / G::TQ;
     const int p0 = (tile / tiles_q) * G::TP, q0 = (tile % tiles_q) * G::TQ;
-    // slice s covers rows [s per + d s (s - S), (s + 1) per + d (s + 1) (s + 1 - S)): lengths per + d (2 s - S + 1), the last one clamped
-    const int k_begin = slice * p.k_per_split + p.k_skew * slice * (slice - p.work_items);
-    const int k_stop = (slice + 1) * p.k_per_split + p.k_skew * (slice + 1) * (slice + 1 - p.work_items);
-    const int k_end = k_stop < p.K ? k_stop : p.K;
+    // (Unequal slices - lengths per + d (2 s - S + 1), so that the workgroups reach their fp32-atomic epilogues at different times - were
+    // measured in round 3: MLP pair 0.337 -> 0.327 ms at +- 8-14 %, worse beyond; attention pair 0.201 -> 0.182 at +- 36 %; nothing in the
+    // step.  profiles/r03_tn384_skew_lab.jsonl.)
+    const int k_begin = slice * p.k_per_split;
+    const int k_end = k_begin + p.k_per_split < p.K ? k_begin + p.k_per_split : p.K;
     const int nk = k_end > k_begin ? (k_end - k_begin) / TN3_BK : 0;
     if (nk == 0) return;
 

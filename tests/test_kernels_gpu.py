@@ -63,7 +63,7 @@ def test_gemm_tn_pair_reserved_cus(hip):
             kc.check_gemm_tn(hip.device, 8192, 1536, 384, seed=13)
 
 
-@pytest.mark.parametrize("policy", [dict(gemm_tn384=0), dict(gemm_tn384_min_tiles=1), dict(gemm_tn384_skew=20), dict(gemm_tn384_skew=0)])
+@pytest.mark.parametrize("policy", [dict(gemm_tn384=0), dict(gemm_tn384_min_tiles=1)])
 def test_gemm_tn_policies(hip, policy):
     """Single weight-gradient products on the kernel that is not the default for their shape: the 128-square kernel for the
     fc shapes, gemm_tn384.h for proj (2 tiles, 128 slices)."""

@@ -48,17 +48,6 @@ def test_gemm_tn_pair_sim(sim, monkeypatch):
     kc.check_gemm_tn_pair(sim.device, 2048 + 32, (384, 192), (384, 384), seed=16)
 
 
-def test_gemm_tn_skewed_slices_sim(sim, monkeypatch):
-    """gemm_tn384.h with unequal contraction slices (policy gemm_tn384_skew): every row still belongs to exactly one slice -
-    several slices per problem, ragged length, both problems of a pair with their own slice counts."""
-    from ccd_amd import ops
-    monkeypatch.setenv("CCD_SIM_CUS", "16")
-    for pct in (20, 45):
-        with ops.policy(gemm_tn384_skew=pct):
-            kc.check_gemm_tn_pair(sim.device, 4096 + 32, (384, 192), (384, 384), seed=30 + pct)
-            kc.check_gemm_tn(sim.device, Mc=4096, P=384, Q=192, seed=31 + pct)
-
-
 def test_gemm_tn512_sim(sim, monkeypatch):
     """gemm_tn384.h with 512 x 128 tiles (4 x 2 MFMA tiles per wave, 3 LDS buffers): the shapes 384 x 192 tiles do not divide
     (vit_base, E = 512) - one tile; a pair of 1 + 2 tiles; 2 x 2 tiles with ragged slices."""
