@@ -43,6 +43,17 @@ def collect(path, counter):
                 key = "gemm_tn_atomic"
             elif "mlp_fused_kernel" in name:                 # fc1 + GELU + fc2 + residual + LayerNorm in one launch
                 key = "mlp_fused"
+            elif "rowproj_kernel" in name:                   # K = E bf16 projections with resident activation rows (round 3)
+                key = "gemm_nt_bf16"
+            elif "rowgemm_kernel" in name:                   # row-owner products with a row-wise epilogue
+                m = re.search(r"rowgemm_kernel<\d+, \d+, (\d+)", name)
+                key = "gemm_nt_lnbwd" if (m and m.group(1) == "0") else "gemm_nt_resid"
+            elif "attention_fwd_kernel" in name:
+                key = "attention_fwd"
+            elif "attention_bwd_dq_kernel" in name:
+                key = "attention_bwd_dq"
+            elif "attention_bwd_dkv" in name:
+                key = "attention_bwd_dkv"
             elif "ln_fwd_kernel" in name:
                 key = "ln_fwd"
             else:
@@ -74,6 +85,10 @@ for k in sorted(fetch):
     fb = sum(fv) / len(fv) * 1024 * 2
     wb = sum(wv) / len(wv) * 1024 * wcal
     out[k] = {"launches": len(fv), "fetch_bytes": round(fb), "write_bytes": round(wb), "bytes_per_launch": round(fb + wb)}
+if "attention_bwd_dq" in out and "attention_bwd_dkv" in out:      # one ops.attention_bwd call = the two kernels (+ a tiny finish kernel)
+    a, b = out["attention_bwd_dq"], out["attention_bwd_dkv"]
+    out["attention_bwd"] = {"launches": a["launches"], "fetch_bytes": a["fetch_bytes"] + b["fetch_bytes"],
+                            "write_bytes": a["write_bytes"] + b["write_bytes"], "bytes_per_launch": a["bytes_per_launch"] + b["bytes_per_launch"]}
 # identify the kernels these passes were taken on: bench.py reports `traffic` only while the digest still matches
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
