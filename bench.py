@@ -208,6 +208,10 @@ def main_finetune(a, world, rank, dev, use_dist):
                            "step_frac_of_mfma_peak": round(ips / world * gf_img / 1e3 / PEAK_BF16_TF, 4),
                            "final_loss": round(final_loss, 4)}}
         line.update(census)
+        if graphed is not None:
+            line["config"]["workload"] += ", step replayed as one HIP graph"
+            line["hip_graph"] = {"captures": graphed.captures, "replays": graphed.replays,
+                                 "roofline_source": "eager warm-up step (HIP events cannot be read out of a graph replay)"}
         if timer is not None:
             summ = timer.summary()
             key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
@@ -349,6 +353,8 @@ def main():
                          "recognize = greedy-decoding inference of the finetuned model (forward_test)")
     ap.add_argument("--epoch", type=int, default=1, help="pseudo-epoch handed to the model: >= 30 takes the predicted-mask "
                     "branch (dino_vision.py:64-70; the batch then carries its characters in the images)")
+    ap.add_argument("--graph", action="store_true", help="pretrain, 1 GPU: replay the step as ONE HIP graph "
+                    "(pretrain.GraphedTrainingStep) - the small-batch regime, where the host's launches bound the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     a = ap.parse_args()
@@ -403,23 +409,36 @@ def main():
     images, masks, metrics = (make_text_like_batch if a.epoch >= 30 else make_batch)(B, seed=1000 + rank, device=dev)
     lr, wd, mom = 0.0005 * B * world / 256.0, 0.04, 0.9995
 
+    graphed = None
+    if a.graph:
+        if use_dist:
+            raise SystemExit("--graph captures a single-process step")
+        graphed = pretrain.GraphedTrainingStep(student, teacher, dino_loss, opt, eager_steps=2)
+        a.warmup = max(a.warmup, 3)          # two eager iterations, then the capturing call: all inside the warm-up
+
     def step():
+        if graphed is not None:
+            return graphed(images, masks, metrics, epoch=a.epoch, lr=lr, wd=wd, momentum=mom)
         return pretrain.training_iteration(model, teacher, dino_loss, opt, images, masks, metrics, epoch=a.epoch, lr=lr,
                                            wd=wd, momentum=mom)
 
     # Kernel timing (HIP events on the launching stream): the last warm-up step times EVERY GEMM launch - that picks the
     # dominant kind and fills the per-kind table; the timed region then only brackets the launches of that one kind
     # (two event records per launch on ~590 launches cost 1.3 ms of a 61 ms step; on ~48 launches 0.1 ms).
+    # (--graph: events cannot be read out of a replayed graph - the table comes from the second EAGER warm-up step, the timed
+    # region replays untimed and `roofline` says so)
     warm_summary = None
+    timed_warm = 1 if graphed is not None else a.warmup - 1
     for i in range(a.warmup):
-        if not a.no_kernel_timer and i == a.warmup - 1:
+        if not a.no_kernel_timer and i == timed_warm:
             ops.TIMER = ops.KernelTimer()
         loss = step()
-    if ops.TIMER is not None:
-        torch.cuda.synchronize()
-        warm_summary = ops.TIMER.summary()
+        if ops.TIMER is not None:
+            torch.cuda.synchronize()
+            warm_summary = ops.TIMER.summary()
+            ops.TIMER = None
     dominant = max(warm_summary.items(), key=lambda kv: kv[1]["ms"])[0] if warm_summary else None
-    timer = None if a.no_kernel_timer else ops.KernelTimer(only={dominant} if dominant else None)
+    timer = None if a.no_kernel_timer or graphed is not None else ops.KernelTimer(only={dominant} if dominant else None)
     ops.TIMER = timer
     if use_dist:
         dist.barrier()
@@ -432,6 +451,10 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
+    if graphed is not None and warm_summary:          # the per-kind table of the eager step stands in for the timed region
+        timer = ops.KernelTimer()
+        timer.summary = lambda: {k: dict(v, ms=v["ms"] * a.steps, launches=v["launches"] * a.steps, flops=v["flops"] * a.steps,
+                                         bytes=v["bytes"] * a.steps) for k, v in warm_summary.items()}
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -466,6 +489,10 @@ def main():
                            "step_frac_of_mfma_peak": round(ips / world * gf_img / 1e3 / PEAK_BF16_TF, 4),
                            "final_loss": round(final_loss, 4)}}
         line.update(census)
+        if graphed is not None:
+            line["config"]["workload"] += ", step replayed as one HIP graph"
+            line["hip_graph"] = {"captures": graphed.captures, "replays": graphed.replays,
+                                 "roofline_source": "eager warm-up step (HIP events cannot be read out of a graph replay)"}
         if timer is not None:
             summ = timer.summary()
             key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])          # the GEMM kind with the largest total time

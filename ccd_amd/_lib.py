@@ -71,7 +71,7 @@ SIGNATURES = {
     "ccd_seg_sumsq": [P, P, P, P, I, P, P],
     "ccd_adamw": [P, P, P, P, P, P, P, P, I, P, P, F, F, F, F, P],
     "ccd_clip_scale": [P, P, P, P, I, P, F, P],
-    "ccd_ema": [P, P, P, L, F, F, P],
+    "ccd_ema": [P, P, P, L, F, F, P, P],
     "ccd_conv_gemm": [P, L, P, P, L, I, I, P, L, P, P, P, P],
     "ccd_conv_wgrad": [P, L, I, P, L, P, L, P, L, P],
     "ccd_im2col": [P, L, P, L, P, P],
@@ -83,7 +83,7 @@ SIGNATURES = {
     "ccd_cls_grad_cols": [P, P, I, I, I, P],
     "ccd_permute4": [P, P, P, P, P, I, P],
     "ccd_dropout": [P, I, P, P, I, L, U64, F, P],
-    "ccd_droppath_scales": [P, P, I, I, U64, P],
+    "ccd_droppath_scales": [P, P, I, I, U64, P, P],
     "ccd_dec_embed_fwd": [P, P, P, P, I, I, I, I, U64, F, P],
     "ccd_dec_embed_bwd": [P, P, P, I, I, I, I, U64, F, P],
     "ccd_dec_attn_fwd": [P, L, P, L, P, L, P, L, P, P, P, P, I, I, I, I, I, I, F, U64, F, P],

@@ -231,8 +231,8 @@ static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, void* stream) {
 
 extern "C" {
 
-int ccd_abi_version(void) { return 5; }   // 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
-const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi5"; }
+int ccd_abi_version(void) { return 6; }   // 6: device-side momentum / DropPath seed (HIP graph of the training step); 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
+const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi6"; }
 int ccd_policy_set(const char* key, int value) {
     CCD_CHECK(key, CCD_EINVAL);
     for (const CcdPolicyKey& k : ccd_policy_keys)
@@ -858,11 +858,12 @@ int ccd_clip_scale(float* grad, const int* chunk_seg, const long* chunk_begin, c
                clip);
     return ccd_rt_last_error();
 }
-int ccd_ema(float* teacher, const float* student, ccd_bf16* mirror, long n, float m, float one_minus_m, void* stream) {
+int ccd_ema(float* teacher, const float* student, ccd_bf16* mirror, long n, float m, float one_minus_m, const float* d_m,
+            void* stream) {
     CCD_CHECK(teacher && student && n >= 0, CCD_EINVAL);
     if (n == 0) return CCD_OK;
     CCD_LAUNCH(ccd::ema_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, teacher, student, mirror, n, m,
-               one_minus_m);
+               one_minus_m, d_m);
     return ccd_rt_last_error();
 }
 
@@ -1058,13 +1059,14 @@ int ccd_dropout(const void* src, int src_bf16, const float* resid, void* dst, in
     else CCD_LAUNCH((ccd::dropout_kernel<false, false>), grid, block, 0, stream, src, resid, dst, n, sd, thr, scale);
     return ccd_rt_last_error();
 }
-int ccd_droppath_scales(const float* keep, float* out, int per_block, int nblocks, uint64_t seed, void* stream) {
+int ccd_droppath_scales(const float* keep, float* out, int per_block, int nblocks, uint64_t seed, const uint64_t* d_seed,
+                        void* stream) {
     CCD_CHECK(keep && out && per_block >= 0 && nblocks >= 0, CCD_EINVAL);
     const long n = (long)per_block * nblocks;
     if (n == 0) return CCD_OK;
     CCD_CHECK(n < (1L << 31), CCD_ESHAPE);
     CCD_LAUNCH(ccd::droppath_scales_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, keep, out, per_block, nblocks,
-               (unsigned long long)seed);
+               (unsigned long long)seed, reinterpret_cast<const unsigned long long*>(d_seed));
     return ccd_rt_last_error();
 }
 int ccd_dec_embed_fwd(const int64_t* tokens, const float* emb, const float* pos, float* x, int rows, int T, int D,

@@ -415,23 +415,25 @@ __global__ __launch_bounds__(512) void attention_bwd_dkv_tr_kernel(const bf16_t*
     const int key = 32 * w + lq;
     // DMA: a 1-KiB piece = 8 image rows; lane L writes row 8 n + L / 8, slot L % 8 and fetches the slot the swizzle puts there.
     // Wave w moves pieces 4 w .. 4 w + 3 of both images and 64 of the 512 statistics.
-    unsigned qoff[4], dooff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 8 * (4 * w + i) + (lane >> 3), src = (lane & 7) ^ attb_swz2(row);
-        qoff[i] = (unsigned)(row * (int)rs3 + src * 8);
-        dooff[i] = (unsigned)(row * E + src * 8);
-    }
+    // (the per-lane source offsets are re-derived per block from an opaque lane id: kept in registers across the block they are
+    // spilled, and every reload of a spilled register is a scratch load behind `s_waitcnt vmcnt(0)` in front of the requests)
     auto dma_block = [&](int blk, int buf) {
         const int view = blk / heads, head = blk % heads;
         const bf16_t* q_base = qkv + (long)view * ATT_T * rs3 + head * ATT_D;
         const bf16_t* do_base = d_o + (long)view * ATT_T * E + head * ATT_D;
         char* base = smem + buf * ATTB_TR_BUF;
+        const int ln = opaque_vgpr((int)threadIdx.x) & 63;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(q_base + qoff[i], base + (4 * w + i) * 1024);
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * (4 * w + i) + (ln >> 3), src = (ln & 7) ^ attb_swz2(row);
+            glds16(q_base + (unsigned)(row * (int)rs3 + src * 8), base + (4 * w + i) * 1024);
+        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(do_base + dooff[i], base + ATTB_IMG + (4 * w + i) * 1024);
-        const float* stat = (w < 4 ? lse : delta) + ((long)view * heads + head) * ATT_T + 64 * (w & 3) + lane;
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * (4 * w + i) + (ln >> 3), src = (ln & 7) ^ attb_swz2(row);
+            glds16(do_base + (unsigned)(row * E + src * 8), base + ATTB_IMG + (4 * w + i) * 1024);
+        }
+        const float* stat = (w < 4 ? lse : delta) + ((long)view * heads + head) * ATT_T + 64 * (w & 3) + ln;
         glds4(stat, base + 2 * ATTB_IMG + 256 * w);          // lse_s = floats 0-255, del_s = floats 256-511
     };
     u32x4 kw[4], vw[4];

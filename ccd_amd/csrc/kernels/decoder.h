@@ -59,8 +59,11 @@ __global__ __launch_bounds__(256) void dropout_kernel(const void* __restrict__ s
 
 // DropPath (vision_transformer.py:27-35) for a whole backbone pass: out[blk][j] = Bernoulli(keep[blk]) / keep[blk], one
 // value per (block, branch, sample); consumed as the GEMM epilogues' per-sample row scale.
+// d_seed (optional, device): added to `seed` at run time, so that a HIP graph of the step draws new masks at every replay
 __global__ __launch_bounds__(256) void droppath_scales_kernel(const float* __restrict__ keep, float* __restrict__ out,
-                                                              int per_block, int nblocks, unsigned long long seed) {
+                                                              int per_block, int nblocks, unsigned long long seed,
+                                                              const unsigned long long* __restrict__ d_seed) {
+    if (d_seed) seed += *d_seed;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= per_block * nblocks) return;
     const float k = keep[i / per_block];

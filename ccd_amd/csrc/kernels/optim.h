@@ -105,8 +105,12 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ gra
     for (int i = threadIdx.x; i < chunk_len[c]; i += 256) grad[base + i] *= cc;
 }
 
+// d_m (optional, device): {m, 1 - m} read at run time instead of the launch arguments - a HIP graph of the training step
+// replays with the momentum of ITS iteration (train.py:264: the schedule changes every iteration)
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ teacher, const float* __restrict__ student,
-                                                  bf16_t* __restrict__ mirror, long n, float m, float om) {
+                                                  bf16_t* __restrict__ mirror, long n, float m, float om,
+                                                  const float* __restrict__ d_m) {
+    if (d_m) { m = d_m[0]; om = d_m[1]; }
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i + 3 < n) {
         f32x4v t = *reinterpret_cast<f32x4v*>(teacher + i);

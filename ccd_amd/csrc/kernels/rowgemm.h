@@ -18,6 +18,10 @@
 // issues exactly KT ring requests (MFMA steps 1, 5, 9, ...) and 2 activation loads (steps 0 and 2), so "my quarter of piece q
 // has landed" is vmcnt <= 3 * (KT + 2): at least that many instructions are younger than the last request of piece q, and
 // whatever the epilogue adds in between only makes the wait conservative.
+// The ACTIVATION loads are hand-tracked too (round 3, prelude: buf_load16_late / vm_arrived): left to the compiler, each group
+// of R blocks carried two `s_waitcnt vmcnt(0)` - the ring and every block in flight drained twice per six windows, 4.9 us per
+// group where the MFMAs need 1.9.  Quarter j of a block is loaded R - 1 blocks ahead (window hh = j / 2, step 0 or 2) and
+// first used at step j * NTH of its block's first window; rg_younger() counts what is issued in between.
 #pragma once
 
 namespace ccd {
@@ -69,6 +73,16 @@ __host__ __device__ inline int rg_smem_bytes(int E) {
 // activation k-blocks a lane holds (the newest arrives R - 1 blocks = 2 (R - 1) pieces ahead of its use): 48 registers at
 // E = 384 - with 96 the epilogue (accumulators + the next tile's blocks + its own streams) spills.  K / 64 % R == 0.
 __host__ __device__ constexpr int rg_ring(int E) { return E == 384 ? 3 : 2; }
+// loads + ring requests issued after the load of quarter j (of the block R - 1 ahead) and before its first use.  A window issues,
+// in this order: load A (step 0), request 0 (step 1), load B (step 2), requests 1 .. KT - 1 (steps 5, 9, ...); an MFMA step's
+// own filler comes after its MFMA.
+__host__ __device__ constexpr int rg_younger(int j, int KT, int R) {
+    const int win = KT + 2, s = j * KT;                          // first use: step j * NTH (NTH == KT) of window (block, 0)
+    const int rest = (j & 1) ? KT - 1 : win - 1;                 // what the load's own window issues after it
+    const int between = 2 * (R - 1) - j / 2 - 1;                 // whole windows in between
+    const int req = (s + 2) / 4 < KT ? (s + 2) / 4 : KT;         // requests m with 4 m + 1 < s
+    return rest + between * win + (s > 0) + (s > 2) + (s > 0 ? req : 0);
+}
 // (dy * gamma, xhat) in one register between the two epilogue passes
 __device__ __forceinline__ unsigned rg_pack(float dg, float xh) {
     const unsigned hi = (__builtin_bit_cast(unsigned, dg) + 0x800u) & 0xFFFFF000u;
@@ -112,7 +126,11 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
     constexpr int DEPTH = 6;               // fragment reads in flight ahead of their MFMA
     constexpr int NSTEP = 4 * NTH;         // MFMAs per piece
     constexpr int WIN_VM = KT + 2;         // VMEM instructions per window
+    constexpr bool AB_LATE = E <= 384;     // hand-tracked activation loads into accumulator registers; at E = 512 the accumulators
+                                           // fill that file: the blocks stay compiler-managed loads there (with its drains)
     static_assert(E % 128 == 0 && NSTEP == 4 * KT && AHEAD >= 2, "ring bookkeeping");
+    static_assert(rg_younger(0, KT, R) <= 63 && rg_younger(1, KT, R) <= 63 && rg_younger(2, KT, R) >= 0 && rg_younger(3, KT, R) >= 0,
+                  "vmcnt is a 6-bit counter");
     char* smem = dynamic_smem();
     const int t = threadIdx.x, lane = t & 63, hf = lane >> 5, lq = lane & 31;
     const int w = uniform_i32(t >> 6);
@@ -133,8 +151,10 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #define RG_STAMP(i) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph[i] += tn_ - tprev; tprev = tn_; }
+#define RG_LAB_KEEP(bit) (!(p.lab & (bit)))   // lab switches of the main loop: 16 = no activation loads, 32 = no ring requests
 #else
 #define RG_STAMP(i)
+#define RG_LAB_KEEP(bit) true
 #endif
     const int tiles = (p.M + RG_BM - 1) / RG_BM, G = gridDim.x;
 
@@ -176,6 +196,7 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) off2[kk] = (unsigned)(lq * 128 + (((2 * kk + hf) ^ mlp_swz(lq)) * 16));
 
+    const buf_desc ds_a = make_desc(p.A, (unsigned)((((long)p.M - 1) * p.lda + p.K) * 2));
     const buf_rsrc rs_a = make_rsrc(p.A, (unsigned)((((long)p.M - 1) * p.lda + p.K) * 2));
     // the row-wise streams of the epilogue: (x, g, gb) for the LayerNorm backward, (resid, out, ln_y) for residual + LayerNorm
     const buf_rsrc rs_x = EPI == RG_LNBWD ? make_rsrc(p.x, (unsigned)((((long)p.M - 1) * p.ldx + E) * 4))
@@ -198,7 +219,9 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
     const unsigned lo_a = (unsigned)((lq * p.lda + 8 * hf) * 2);
     u32x4 ab[R][4];
     auto load_a = [&](u32x4& dst, int tt, int b, int j) {
-        dst = buf_load16(rs_a, lo_a, (unsigned)(tt * RG_BM + 32 * w) * (unsigned)(p.lda * 2) + (unsigned)(128 * b + 32 * j));
+        const unsigned so = (unsigned)(tt * RG_BM + 32 * w) * (unsigned)(p.lda * 2) + (unsigned)(128 * b + 32 * j);
+        if constexpr (AB_LATE) buf_load16_late(dst, ds_a, lo_a, so);
+        else dst = buf_load16(rs_a, lo_a, so);
     };
     if ((int)blockIdx.x < tiles) {
 #pragma unroll
@@ -206,11 +229,10 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
 #pragma unroll
             for (int j = 0; j < 4; ++j) load_a(ab[b][j], blockIdx.x, b, j);
     }
-    // the first acquire counts on (AHEAD - 1) * WIN_VM instructions younger than piece 0's requests: the prologue's other
-    // pieces + the activation loads above.  Where they are fewer (R = 2) start from a drained queue.
-    if constexpr (4 * (R - 1) < 2 * (AHEAD - 1)) glds_wait_all();
+    // the counted waits of the main loop assume a full pipeline behind them: start from a drained queue (once per workgroup)
+    glds_wait_all();
     const float inv_e = 1.0f / (float)E;
-    if (p.lab > 0 && (blockIdx.x & 1)) wave_sleep(p.lab);
+    if (p.lab > 0 && p.lab < 16 && (blockIdx.x & 1)) wave_sleep(p.lab);
 
     for (int tile = blockIdx.x; tile < tiles; tile += G) {
         const int m0 = tile * RG_BM, r0 = m0 + 32 * w;
@@ -230,6 +252,8 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
                 // the block that slot sp receives while block (grp, i) is multiplied: R - 1 blocks ahead, maybe of the next tile
                 int tb = grp * R + i + R - 1, tt = tile;
                 if (tb >= NB) { tb -= NB; tt += G; }
+                if (tt >= tiles) tt = tile;        // behind the last tile: re-read this one (an out-of-range load of the whole wave
+                                                   // need not keep its place in the return order)
                 mlp_static_for<0, 2>([&](auto HH) {
                     constexpr int hh = decltype(HH)::value;
                     const unsigned sb = acquire();
@@ -238,13 +262,14 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
                         areg,
                         [&](auto K, const bf16x8& a) {
                             constexpr int k = decltype(K)::value;
+                            if constexpr (AB_LATE && hh == 0 && k % NTH == 0) vm_arrived<rg_younger(k / NTH, KT, R)>(ab[i][k / NTH]);
                             acc[NTH * hh + k % NTH] = mfma_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, ab[i][k / NTH]), acc[NTH * hh + k % NTH]);
                         },
                         [&](auto K) {
                             constexpr int k = decltype(K)::value;
-                            if constexpr (k % 4 == 1) issue_one(k / 4);
-                            if constexpr (k == 0) load_a(ab[sp][2 * hh], tt, tb, 2 * hh);
-                            if constexpr (k == 2) load_a(ab[sp][2 * hh + 1], tt, tb, 2 * hh + 1);
+                            if constexpr (k % 4 == 1) { if (RG_LAB_KEEP(32)) issue_one(k / 4); }
+                            if constexpr (k == 0) { if (RG_LAB_KEEP(16)) load_a(ab[sp][2 * hh], tt, tb, 2 * hh); }
+                            if constexpr (k == 2) { if (RG_LAB_KEEP(16)) load_a(ab[sp][2 * hh + 1], tt, tb, 2 * hh + 1); }
                         });
                     RG_STAMP(3)
                 });
@@ -256,8 +281,15 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
             float sc = 1.0f;
             if (p.rowscale) sc = p.rowscale[grow / p.rows_per_sample];
             float s1 = 0.f, s2 = 0.f;
+            // (the vector tables are addressed from a per-tile opaque lane id: from the loop-invariant one the optimiser hoists
+            // one address register per (tile, group) out of the persistent loop - 80 spilled registers, and every reload of a
+            // spilled register is a scratch load behind `s_waitcnt vmcnt(0)`: a drain of the stores this epilogue streams)
+            const LaneOff lo(t);
+            const float* vbi_h = vbi + 4 * lo.hf;
+            const float* vga_h = vga + 4 * lo.hf;
+            const float* vbe_h = vbe + 4 * lo.hf;
             {
-                const unsigned so = (unsigned)r0 * (unsigned)(p.ldr * 4), lo_x = LaneOff(t).frag(p.ldr, 4, 4);
+                const unsigned so = (unsigned)r0 * (unsigned)(p.ldr * 4), lo_x = lo.frag(p.ldr, 4, 4);
                 constexpr int PA = 4;
                 u32x4 xb[PA][4];
                 auto load_x = [&](int nt) {
@@ -272,7 +304,7 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4v x = __builtin_bit_cast(f32x4v, xb[nt % PA][g]);
-                        const f32x4v b = *reinterpret_cast<const f32x4v*>(vbi + 32 * nt + 8 * g + 4 * hf);
+                        const f32x4v b = *reinterpret_cast<const f32x4v*>(vbi_h + 32 * nt + 8 * g);
                         const float xx[4] = {x.x, x.y, x.z, x.w}, bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -293,7 +325,6 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
             var = var > 0.f ? var : 0.f;
             const float rstd = 1.0f / sqrtf(var + p.ln_eps);
             if (hf == 0 && row < p.M) { p.ln_mean[row] = mean; p.ln_rstd[row] = rstd; }
-            const LaneOff lo(t);
             const unsigned lo_o = lo.rows8(p.ldc, 4), lo_n = lo.rows8(p.ld_y, 2);
             // Pass B: out (fp32, one 32-column tile at a time) and ln_y (bf16, two tiles) through the scratch image
 #pragma unroll
@@ -306,8 +337,8 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
                     for (int g = 0; g < 4; ++g) {
                         const float v[4] = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
                         *reinterpret_cast<f32x4v*>(scratch + lo.scr_wr(2 * g + lo.hf)) = f32x4v{v[0], v[1], v[2], v[3]};
-                        const int n = 32 * nt + 8 * g + 4 * hf;
-                        const f32x4v ga = *reinterpret_cast<const f32x4v*>(vga + n), be = *reinterpret_cast<const f32x4v*>(vbe + n);
+                        const int n = 32 * nt + 8 * g;
+                        const f32x4v ga = *reinterpret_cast<const f32x4v*>(vga_h + n), be = *reinterpret_cast<const f32x4v*>(vbe_h + n);
                         ypk[tt][g].x = pack_bf2((v[0] - mean) * rstd * ga.x + be.x, (v[1] - mean) * rstd * ga.y + be.y);
                         ypk[tt][g].y = pack_bf2((v[2] - mean) * rstd * ga.z + be.z, (v[3] - mean) * rstd * ga.w + be.w);
                     }

@@ -57,6 +57,24 @@ __device__ __forceinline__ buf_u32x4 buf_load16(buf_rsrc r, unsigned lane_offset
 __device__ __forceinline__ void buf_store16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset, buf_u32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)lane_offset, (int)uniform_offset, 0);
 }
+// Buffer loads whose ARRIVAL THE KERNEL TRACKS (rowgemm.h's activation blocks).  The compiler's own bookkeeping turns every
+// wait for a builtin load inside a loop that also carries LDS-DMA requests and (from the previous tile's epilogue) stores
+// into `s_waitcnt vmcnt(0)` - a full drain of the weight ring and of every prefetched block, twice per six windows in
+// rowgemm.h's main loop (found in the ISA; it was 2/3 of that loop's time).  These are issued by hand instead: the compiler
+// sees no VMEM operation (its own counted waits only get stricter), the destination is an ACCUMULATOR register quadruple (an
+// MFMA B operand can come from there: no copy that could run ahead of the data), and the value may only be used behind
+// vm_arrived<N>(dst), N = the number of loads / LDS-DMA requests issued after this one (loads return in issue order; stores
+// are counted by vmcnt too but can only make the wait longer).  Raw descriptor words: what make_rsrc builds.
+typedef buf_u32x4 buf_desc;
+__device__ __forceinline__ buf_desc make_desc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)(uintptr_t)base;
+    return buf_desc{(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ void buf_load16_late(buf_u32x4& dst, buf_desc r, unsigned lane_offset, unsigned uniform_offset) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(dst) : "v"(lane_offset), "s"(r), "s"(uniform_offset) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_arrived(buf_u32x4& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+a"(a) : "n"(N)); }
 // streaming variants: non-temporal cache policy (aux = 2, "nt"): data that is touched once must not push the L2-resident
 // operands (weights) of the same kernel out of the XCD's 4-MiB L2
 __device__ __forceinline__ buf_u32x4 buf_load16_nt(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset) {

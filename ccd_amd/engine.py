@@ -45,9 +45,9 @@ class Fusion:
     ln = _env_switch("CCD_FUSE_LN")                # LayerNorm in the epilogue of proj / fc2   (default: E <= 384)
     mlp = _env_switch("CCD_FUSE_MLP")              # fc1 -> GELU -> fc2 -> residual -> LayerNorm in one launch (default: with `ln`)
     lnbwd = _env_switch("CCD_FUSE_LNBWD")          # LayerNorm backward in the epilogue of the data-gradient product (default: on)
-    store_gact = _env_switch("CCD_STORE_GACT")     # the fused MLP forward also stores gelu(u) for the backward pass (default: on;
-    if store_gact is None:                         # measured 52.9 vs 53.0 ms per step: + 0.47 ms forward, - 0.75 ms gelu'(u) product)
-        store_gact = True
+    store_gact = _env_switch("CCD_STORE_GACT")     # the fused MLP forward also stores gelu(u) for the backward pass (default: off -
+    if store_gact is None:                         # a measured tie, 52.9 vs 53.0 ms per step: + 0.47 ms forward, - 0.75 ms gelu'(u)
+        store_gact = False                         # product, + 0.2 GB per block of saved activations at B = 256)
     side_stream = bool(_env_switch("CCD_SIDE_STREAM"))
     double_gb = False                       # tests: rotate the two gb buffers of the side-stream mode also without a side stream
 
@@ -59,7 +59,14 @@ class Fusion:
         return ln, mlp, lnbwd
 
 
-_DROPPATH_SEED = {"base": None, "calls": 0}
+_DROPPATH_SEED = {"base": None, "calls": 0, "device": None}
+DROPPATH_SEED_STRIDE = 0x632BE59BD9B4E019
+
+
+def set_device_droppath_seed(d_seed):
+    """d_seed: int64 [1] on the device (or None).  While set, the DropPath kernel adds *d_seed to its launch-time seed when it
+    RUNS: a captured step (pretrain.GraphedTrainingStep) draws new masks at every replay."""
+    _DROPPATH_SEED["device"] = d_seed
 
 
 def _next_droppath_seed():
@@ -67,7 +74,7 @@ def _next_droppath_seed():
     if _DROPPATH_SEED["base"] is None:
         _DROPPATH_SEED["base"] = int(torch.randint(0, 2 ** 62, (1,)).item())
     _DROPPATH_SEED["calls"] += 1
-    return _DROPPATH_SEED["base"] + _DROPPATH_SEED["calls"] * 0x632BE59BD9B4E019
+    return _DROPPATH_SEED["base"] + _DROPPATH_SEED["calls"] * DROPPATH_SEED_STRIDE
 
 
 # ------------------------------------------------------------------------------------------------ pos-embed resampling
@@ -135,7 +142,7 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
     # that already reads u (ccd_gemm_nt, EPI_DGELU with a second output)
     pending = None                               # (y, mean, rstd) of the coming norm1, made by the previous fc2
     # DropPath: per-(block, branch, sample) keep mask / keep_prob (vision_transformer.py:27-35), one kernel per pass
-    scales = ops.droppath_scales(spec.keep_probs(dev), N, _next_droppath_seed()) if training and max(spec.dpr) > 0.0 else None
+    scales = ops.droppath_scales(spec.keep_probs(dev), N, _next_droppath_seed(), _DROPPATH_SEED["device"]) if training and max(spec.dpr) > 0.0 else None
     for i in range(spec.depth):
         b = f"{pre}blocks.{i}."
         c = _BlockCtx()

@@ -576,8 +576,9 @@ def clip_scale(grad, chunk_seg, chunk_begin, chunk_len, norm2, clip):
           chunk_seg.numel(), _lib.ptr(norm2), float(clip))
 
 
-def ema(teacher, student, mirror, m):
-    _call("ccd_ema", _lib.ptr(teacher), _lib.ptr(student), _lib.ptr(mirror), teacher.numel(), float(m), float(1.0 - m))
+def ema(teacher, student, mirror, m, d_m=None):
+    """teacher = m teacher + (1 - m) student (+ bf16 mirror); d_m (fp32 [2] on the device: {m, 1 - m}) overrides m at run time."""
+    _call("ccd_ema", _lib.ptr(teacher), _lib.ptr(student), _lib.ptr(mirror), teacher.numel(), float(m), float(1.0 - m), _lib.ptr(d_m))
 
 
 # ------------------------------------------------------------------------------------------ segmentation head
@@ -726,11 +727,13 @@ def dropout(src, p, seed, *, resid=None, out=None, out_dtype=None):
     return out
 
 
-def droppath_scales(keep, samples, seed):
-    """keep fp32 [depth] (device) -> fp32 [depth, 2, samples]: per-(block, branch, sample) DropPath scale (0 or 1/keep)."""
+def droppath_scales(keep, samples, seed, d_seed=None):
+    """keep fp32 [depth] (device) -> fp32 [depth, 2, samples]: per-(block, branch, sample) DropPath scale (0 or 1/keep).
+    d_seed (int64 [1] on the device, optional) is added to `seed` when the kernel runs (HIP-graph replays)."""
     _chk(keep, F32, "keep")
     out = torch.empty((keep.shape[0], 2, samples), dtype=F32, device=keep.device)
-    _call("ccd_droppath_scales", _lib.ptr(keep), _lib.ptr(out), 2 * samples, keep.shape[0], int(seed) & 0xFFFFFFFFFFFFFFFF)
+    _call("ccd_droppath_scales", _lib.ptr(keep), _lib.ptr(out), 2 * samples, keep.shape[0], int(seed) & 0xFFFFFFFFFFFFFFFF,
+          _lib.ptr(d_seed))
     return out
 
 

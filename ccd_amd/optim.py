@@ -14,6 +14,37 @@ from . import ops
 from .arena import ParamArena
 
 
+class HostStaging:
+    """A small host table that travels to a device tensor once per step as one async copy.  The host runs ahead of the stream
+    (train.py reads the loss one iteration late), so a single pinned staging buffer would be overwritten by step N+1 before the
+    DMA of step N has read it: a ring of staging buffers, each guarded by the event recorded behind its copy (waited for -
+    normally long complete - before the buffer is refilled)."""
+
+    def __init__(self, shape, dtype, device, depth=4):
+        on_gpu = torch.device(device).type == "cuda"
+        self.ring = [torch.zeros(shape, dtype=dtype).pin_memory() if on_gpu else torch.zeros(shape, dtype=dtype)
+                     for _ in range(depth if on_gpu else 1)]
+        self.events = [None] * len(self.ring)
+        self.next = 0
+        self.dev = torch.zeros(shape, dtype=dtype, device=device)
+
+    def begin(self):
+        """-> the host buffer to fill for this step."""
+        self.slot = self.next
+        self.next = (self.slot + 1) % len(self.ring)
+        if self.events[self.slot] is not None:
+            self.events[self.slot].synchronize()            # the copy that last read this buffer has executed
+        return self.ring[self.slot]
+
+    def commit(self):
+        h = self.ring[self.slot]
+        self.dev.copy_(h, non_blocking=True)
+        if h.is_pinned():
+            self.events[self.slot] = torch.cuda.Event()
+            self.events[self.slot].record()
+        return self.dev
+
+
 class FusedClipAdamW:
     def __init__(self, arena: ParamArena, betas=(0.9, 0.999), eps=1e-8, clip_grad=0.0, lr=1e-3, weight_decay=1e-2,
                  global_norm=False):
@@ -35,16 +66,9 @@ class FusedClipAdamW:
         self.steps = {n: 0 for n in names}
         self.never_used = set()            # tensors that have never received a gradient (conv_mla.*, cls_token)
         self._norm2 = torch.zeros(len(names), dtype=torch.float32, device=arena.device)
-        # Per-tensor hyper-parameters travel host -> device as one small async copy per step.  The host runs ahead of the
-        # stream (train.py reads the loss one iteration late), so a single pinned staging buffer would be overwritten by
-        # step N+1 before the DMA of step N has read it: a ring of staging buffers, each guarded by the event recorded
-        # behind its copy (waited for - normally long complete - before the buffer is refilled).
-        on_gpu = arena.device.type == "cuda"
-        self._hyper_ring = [torch.zeros((len(names), 4), dtype=torch.float32).pin_memory() if on_gpu
-                            else torch.zeros((len(names), 4), dtype=torch.float32) for _ in range(4 if on_gpu else 1)]
-        self._hyper_events = [None] * len(self._hyper_ring)
-        self._hyper_next = 0
-        self._hyper_dev = torch.zeros((len(names), 4), dtype=torch.float32, device=arena.device)
+        # per-tensor hyper-parameters: host -> device as one small async copy per step
+        self._hyper = HostStaging((len(names), 4), torch.float32, arena.device)
+        self._hyper_dev = self._hyper.dev
 
     def zero_grad(self, set_to_none: bool = False):
         self.arena.zero_grad()
@@ -55,14 +79,17 @@ class FusedClipAdamW:
 
     @torch.no_grad()
     def step(self):
+        self.stage_hyper()
+        self.launch_step()
+
+    @torch.no_grad()
+    def stage_hyper(self):
+        """The host half of a step: step counters, bias corrections, lr / wd and the frozen-tensor switches of THIS iteration
+        go to the device table (an eager copy - a HIP graph of the step replays `launch_step` only)."""
         arena = self.arena
         b1, b2 = self.betas
         skip = arena.skip_substrings
-        slot = self._hyper_next
-        self._hyper_next = (slot + 1) % len(self._hyper_ring)
-        if self._hyper_events[slot] is not None:
-            self._hyper_events[slot].synchronize()          # the copy that last read this buffer has executed
-        h = self._hyper_ring[slot]
+        h = self._hyper.begin()
         for n, seg in arena.segments.items():
             gi = self._group_of.get(n)
             active = gi is not None and n not in self.never_used and not any(s in n for s in skip)
@@ -77,10 +104,13 @@ class FusedClipAdamW:
             h[seg.index, 2] = 1.0 / math.sqrt(1.0 - b2 ** t)
             h[seg.index, 3] = 1.0
         arena.skip_substrings = set()
-        self._hyper_dev.copy_(h, non_blocking=True)
-        if h.is_pinned():
-            self._hyper_events[slot] = torch.cuda.Event()
-            self._hyper_events[slot].record()
+        self._hyper.commit()
+
+    @torch.no_grad()
+    def launch_step(self):
+        """The device half: per-tensor (or global) clip + AdamW + mirror refresh; reads the staged table."""
+        arena = self.arena
+        b1, b2 = self.betas
         cs, cb, cl = arena.opt_tables()
         self._norm2.zero_()
         if self.clip_grad:
@@ -126,11 +156,12 @@ class FusedClipAdamW:
 
 @torch.no_grad()
 def ema_update(student_arena: ParamArena, teacher_arena: ParamArena, momentum: float,
-               prefixes=("backbone.", "head.")):
+               prefixes=("backbone.", "head."), d_m=None):
     """teacher = m*teacher + (1-m)*student over the backbone and head parameters (train.py:264-272).
-    Both arenas lay a prefix's tensors out identically, so each prefix is one contiguous range."""
+    Both arenas lay a prefix's tensors out identically, so each prefix is one contiguous range.
+    d_m (fp32 [2] on the device, {m, 1 - m}): the momentum is read when the kernel RUNS (replays of a graphed step)."""
     for pre in prefixes:
         slo, shi = student_arena.range_of(pre)
         tlo, thi = teacher_arena.range_of(pre)
         assert shi - slo == thi - tlo, pre
-        ops.ema(teacher_arena.flat[tlo:thi], student_arena.flat[slo:shi], teacher_arena.mirror[tlo:thi], momentum)
+        ops.ema(teacher_arena.flat[tlo:thi], student_arena.flat[slo:shi], teacher_arena.mirror[tlo:thi], momentum, d_m)

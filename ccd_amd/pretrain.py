@@ -49,15 +49,15 @@ def make_optimizer(student_module, clip_grad=3.0):
     return opt
 
 
-def training_iteration(student, teacher, dino_loss: DINOLoss, optimizer: FusedClipAdamW, images, masks, metrics,
-                       epoch, lr, wd, momentum, freeze_last_layer=1, check_finite=False):
-    """student / teacher may be wrapped (ccd_amd.parallel.DataParallel); returns the loss as a device tensor."""
-    s_mod = student.module if hasattr(student, "module") else student
-    t_mod = teacher.module if hasattr(teacher, "module") else teacher
+def _set_schedule(optimizer, lr, wd):
     for i, g in enumerate(optimizer.param_groups):
         g["lr"] = float(lr)
         if i == 0:
             g["weight_decay"] = float(wd)
+
+
+def _forward_backward(student, teacher, dino_loss, optimizer, images, masks, metrics, epoch, check_finite=False):
+    """train.py:221-246: both networks, the loss, zero_grad, backward (+ the gradient all-reduce of a wrapped student)."""
     metrics = metrics.float()
     s_out = student(images, metrics, masks, epoch, clusters=None)
     with torch.no_grad():
@@ -72,8 +72,114 @@ def training_iteration(student, teacher, dino_loss: DINOLoss, optimizer: FusedCl
     loss.backward()
     if hasattr(student, "finish_gradient_sync"):
         student.finish_gradient_sync()
+    return loss
+
+
+def training_iteration(student, teacher, dino_loss: DINOLoss, optimizer: FusedClipAdamW, images, masks, metrics,
+                       epoch, lr, wd, momentum, freeze_last_layer=1, check_finite=False):
+    """student / teacher may be wrapped (ccd_amd.parallel.DataParallel); returns the loss as a device tensor."""
+    s_mod = student.module if hasattr(student, "module") else student
+    t_mod = teacher.module if hasattr(teacher, "module") else teacher
+    _set_schedule(optimizer, lr, wd)
+    loss = _forward_backward(student, teacher, dino_loss, optimizer, images, masks, metrics, epoch, check_finite)
     if epoch < freeze_last_layer:
         s_mod.arena.skip_substrings.add("last_layer")        # cancel_gradients_last_layer (modules/utils.py:144-149)
     optimizer.step()                                         # per-tensor clip + AdamW, fused
     ema_update(s_mod.arena, t_mod.arena, float(momentum))
     return loss.detach()
+
+
+class GraphedTrainingStep:
+    """`training_iteration` captured ONCE into a HIP graph and replayed: one hipGraphLaunch per iteration instead of ~700
+    kernel launches driven from Python.  It is for the small-batch regime (64 images per GPU: the kernels of a step take less
+    time than the host needs to launch them); at the headline batch of 256 the host already runs ahead of the GPU.
+
+    What changes between iterations never enters the graph as a launch argument:
+      * the batch is copied into the graph's static input tensors;
+      * lr / weight decay / Adam bias corrections / frozen tensors: `FusedClipAdamW.stage_hyper` (an eager host -> device copy
+        of the per-tensor table the captured AdamW kernel reads);
+      * the EMA momentum and the DropPath seed: two device scalars the kernels read when they RUN (ccd_ema's d_m,
+        ccd_droppath_scales' d_seed), staged the same way.  The seed sequence is the eager one's, so a graphed run draws the
+        same masks as an eager run with the same torch seed;
+      * the teacher temperature and the epoch < 30 branch ARE launch-time constants: a change re-captures (once per epoch
+        during the temperature warm-up, once at epoch 30).
+    The first `eager_steps` calls run eagerly (they are real iterations): lazily built tables, MIOpen's algorithm search and
+    the allocator's pools settle before anything is captured.  Single process only - the gradient all-reduce of
+    parallel.DataParallel is launched from autograd hooks on a side stream and is not captured."""
+
+    def __init__(self, student, teacher, dino_loss: DINOLoss, optimizer: FusedClipAdamW, eager_steps=2):
+        if hasattr(student, "finish_gradient_sync"):
+            raise ValueError("GraphedTrainingStep captures a single-process step; run the data-parallel job eagerly")
+        from .optim import HostStaging
+        self.student, self.teacher, self.dino_loss, self.optimizer = student, teacher, dino_loss, optimizer
+        dev = student.arena.device
+        self._mom = HostStaging((2,), torch.float32, dev)
+        self._seed = HostStaging((1,), torch.int64, dev)
+        self.eager_left = int(eager_steps)
+        self.key = self.graph = None
+        self.captures = self.replays = 0
+
+    def _key(self, images, masks, metrics, epoch):
+        return (tuple(images.shape), images.dtype, tuple(masks.shape), masks.dtype, tuple(metrics.shape), metrics.dtype,
+                epoch < 30, float(self.dino_loss.teacher_temp_schedule[epoch]))
+
+    def _record(self, body):
+        """-> (something with .replay(), DropPath seeds drawn by one pass of `body`).  Capturing launches nothing."""
+        from . import engine
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        before = engine._DROPPATH_SEED["calls"]
+        with torch.cuda.graph(g):
+            body()
+        return g, engine._DROPPATH_SEED["calls"] - before
+
+    def _capture(self, images, masks, metrics, epoch):
+        from . import engine
+        self.graph = None                                    # the previous graph's pool goes back to the allocator first
+        self.images, self.masks, self.metrics = images.clone(), masks.clone(), metrics.clone()
+        seeds = engine._DROPPATH_SEED
+
+        def body():
+            loss = _forward_backward(self.student, self.teacher, self.dino_loss, self.optimizer, self.images, self.masks,
+                                     self.metrics, epoch)
+            self.optimizer.launch_step()
+            ema_update(self.student.arena, self.teacher.arena, 0.0, d_m=self._mom.dev)
+            self.loss = loss.detach()
+
+        self._calls0 = seeds["calls"]
+        engine.set_device_droppath_seed(self._seed.dev)
+        try:
+            self.graph, self._calls_per_step = self._record(body)
+        finally:
+            engine.set_device_droppath_seed(None)
+        seeds["calls"] = self._calls0                        # capturing drew nothing: the first replay uses these seeds
+        self.captures += 1
+
+    def __call__(self, images, masks, metrics, epoch, lr, wd, momentum, freeze_last_layer=1):
+        if self.eager_left > 0:
+            self.eager_left -= 1
+            return training_iteration(self.student, self.teacher, self.dino_loss, self.optimizer, images, masks, metrics,
+                                      epoch, lr, wd, momentum, freeze_last_layer)
+        from . import engine
+        key = self._key(images, masks, metrics, epoch)
+        if key != self.key:
+            self._capture(images, masks, metrics, epoch)
+            self.key = key
+        self.images.copy_(images, non_blocking=True)
+        self.masks.copy_(masks, non_blocking=True)
+        self.metrics.copy_(metrics, non_blocking=True)
+        h = self._mom.begin()
+        h[0], h[1] = float(momentum), 1.0 - float(momentum)
+        self._mom.commit()
+        seeds = engine._DROPPATH_SEED
+        delta = ((seeds["calls"] - self._calls0) * engine.DROPPATH_SEED_STRIDE) & 0xFFFFFFFFFFFFFFFF
+        self._seed.begin()[0] = delta - (1 << 64) if delta >= (1 << 63) else delta
+        self._seed.commit()
+        seeds["calls"] += self._calls_per_step
+        _set_schedule(self.optimizer, lr, wd)
+        if epoch < freeze_last_layer:
+            self.student.arena.skip_substrings.add("last_layer")
+        self.optimizer.stage_hyper()
+        self.graph.replay()
+        self.replays += 1
+        return self.loss.clone()

@@ -258,7 +258,9 @@ int ccd_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq
               void* stream);
 int ccd_clip_scale(float* grad, const int* chunk_seg, const long* chunk_begin, const int* chunk_len, int nchunks,
                    const float* norm2, float clip, void* stream);
-int ccd_ema(float* teacher, const float* student, ccd_bf16* mirror, long n, float m, float one_minus_m, void* stream);
+/* d_m (optional, device, 2 floats {m, 1 - m}): read at run time instead of the two launch arguments (HIP-graph replays of the step) */
+int ccd_ema(float* teacher, const float* student, ccd_bf16* mirror, long n, float m, float one_minus_m, const float* d_m,
+            void* stream);
 
 /* ---- segmentation head (Dino/modules/segmentor.py:38-95): channels-last bf16 activations [pixels, C] ----------- */
 /* Gather description of an implicit-GEMM convolution: output row r = (n, oy, ox) on a 2^g_h_log2 x 2^g_w_log2 grid;
@@ -321,7 +323,9 @@ int ccd_dropout(const void* src, int src_bf16, const float* resid, void* dst, in
                 void* stream);
 /* DropPath scales of one backbone pass (vision_transformer.py:27-35,107-113): out[blk*per_block + j] = keep_j / keep[blk]
  * with keep_j ~ Bernoulli(keep[blk]) from the same counter-based generator (keep: device array [nblocks]). */
-int ccd_droppath_scales(const float* keep, float* out, int per_block, int nblocks, uint64_t seed, void* stream);
+/* d_seed (optional, device): added to `seed` at run time (HIP-graph replays draw new masks) */
+int ccd_droppath_scales(const float* keep, float* out, int per_block, int nblocks, uint64_t seed, const uint64_t* d_seed,
+                        void* stream);
 /* x[r,:] = dropout(trg_word_emb[tokens[r]] + position_table[r % T])   (nrtr_decoder.py:93-95); D % 4 == 0 */
 int ccd_dec_embed_fwd(const int64_t* tokens, const float* emb, const float* pos, float* x, int rows, int T, int D,
                       int num_classes, uint64_t seed, float p, void* stream);

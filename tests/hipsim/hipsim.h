@@ -113,7 +113,10 @@ inline void sim_dma_retire(size_t leave) {
     auto& q = sim::cur->dma;
     const size_t n = q.size() > leave ? q.size() - leave : 0;
     for (size_t i = 0; i < n; ++i)
-        if (q[i].bytes) std::memcpy(q[i].dst, q[i].src, (size_t)q[i].bytes);
+        if (q[i].bytes) {
+            if (q[i].src) std::memcpy(q[i].dst, q[i].src, (size_t)q[i].bytes);
+            else std::memset(q[i].dst, 0, (size_t)q[i].bytes);      // a late register load of an out-of-range address
+        }
     q.erase(q.begin(), q.begin() + (long)n);
 }
 inline void __syncthreads() { sim_dma_retire(0); sim::block_sync(); }      // (the compiler drains vmcnt in front of s_barrier)
@@ -243,6 +246,24 @@ inline void buf_store16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offse
     if (o + 16ull <= (unsigned long long)r.bytes) std::memcpy(const_cast<char*>(r.base) + o, &v, 16);
 }
 inline buf_u32x4 buf_load16_nt(buf_rsrc r, unsigned a, unsigned b) { return buf_load16(r, a, b); }
+// hand-tracked buffer loads (prelude_hip.h: buf_load16_late / vm_arrived).  Late mode: the destination is poisoned (bf16 NaNs)
+// at issue and receives its data only when a counted wait of this lane retires the request - the latest the hardware may
+// deliver it, in the same in-order queue as the LDS-DMA requests: a use in front of a sufficient wait sees NaNs.
+typedef buf_rsrc buf_desc;
+inline buf_desc make_desc(const void* base, unsigned bytes) { return make_rsrc(base, bytes); }
+inline void buf_load16_late(buf_u32x4& dst, buf_desc r, unsigned lane_offset, unsigned uniform_offset) {
+    const unsigned long long o = (unsigned long long)lane_offset + uniform_offset;
+    const bool in_range = o + 16ull <= (unsigned long long)r.bytes;
+    if (::sim_dma_late()) {
+        dst = buf_u32x4{0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u};
+        sim::cur->dma.push_back({reinterpret_cast<char*>(&dst), in_range ? r.base + o : nullptr, 16});
+    } else {
+        dst = buf_u32x4{0u, 0u, 0u, 0u};
+        if (in_range) std::memcpy(&dst, r.base + o, 16);
+    }
+}
+template <int N>
+inline void vm_arrived(buf_u32x4&) { ::sim_dma_retire((size_t)N); }
 inline void buf_store16_nt(buf_rsrc r, unsigned a, unsigned b, buf_u32x4 v) { buf_store16(r, a, b, v); }
 inline void wave_sleep(int) {}
 inline void wave_nap(int) {}

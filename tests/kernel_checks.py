@@ -19,7 +19,7 @@ def close(got, want, rtol, atol, what):
     assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
     err = (got - want).abs()
     tol = atol + rtol * want.abs()
-    bad = err > tol
+    bad = ~(err <= tol)                     # (NaNs are bad: the executor poisons registers / LDS that are read too early)
     assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {err.max().item():.4g} "
                            f"(want max {want.abs().max().item():.4g})")
 
@@ -713,6 +713,10 @@ def check_optimizer(dev, seed=13):
     ops.ema(Td, student.to(dev), tm, 0.9995)
     close(Td, teacher * 0.9995 + (1 - 0.9995) * student, 1e-6, 1e-7, "opt/ema")
     close(tm, Td.to(BF), 0, 0, "opt/ema-mirror")
+    # the momentum read on the device when the kernel runs (replays of a graphed step): the launch arguments are ignored
+    Td2, tm2 = teacher.clone().to(dev), torch.zeros(total + 3, dtype=BF).to(dev)
+    ops.ema(Td2, student.to(dev), tm2, 0.0, d_m=torch.tensor([0.9995, 1 - 0.9995], dtype=torch.float32).to(dev))
+    assert torch.equal(Td2.cpu(), Td.cpu()) and torch.equal(tm2.cpu(), tm.cpu()), "opt/ema device momentum"
 
 
 def _cos(a, b):
@@ -1033,6 +1037,9 @@ def check_droppath(dev):
     ref = drop_keep_ref(99, 3 * 8000, 0.5).view(3, 2, 4000)
     assert torch.equal(out[2] > 0, ref[2])
     assert not torch.equal(out, ops.droppath_scales(keep.to(dev), 4000, 100).cpu())
+    # device-side seed offset (graph replays): seed 90 at launch + 9 on the device == seed 99; wraps modulo 2^64
+    assert torch.equal(out, ops.droppath_scales(keep.to(dev), 4000, 90, torch.tensor([9], dtype=torch.int64).to(dev)).cpu())
+    assert torch.equal(out, ops.droppath_scales(keep.to(dev), 4000, 100, torch.tensor([-1], dtype=torch.int64).to(dev)).cpu())
 
 
 def check_dec_embed(dev, B=5, T=25, D=128, C=93, seed=41):

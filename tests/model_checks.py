@@ -70,6 +70,54 @@ def check_optimizer_host_runs_ahead(device, steps=8):
     assert diff <= 1e-4 * move, f"optimizer steps saw another step's hyper-parameters (diff {diff}, update {move})"
 
 
+def check_graphed_step_matches_eager(device, steps=8, B=8, drop_path_rate=0.1):
+    """pretrain.GraphedTrainingStep (the iteration replayed as ONE HIP graph) against the eager iteration on the same batches
+    and schedules: lr / weight decay / momentum change every iteration, the last layer is frozen during pseudo-epoch 0
+    (train.py:247-248), the teacher temperature warms up over 3 epochs (=> re-captures) and DropPath is on (the graph's
+    device-side seed must follow the eager seed sequence).  Not bit-equal (fp32 atomics in the weight-gradient epilogues)."""
+    from ccd_amd import engine
+    from ccd_amd.synthetic import make_batch
+    out = []
+    for graphed in (False, True):
+        torch.manual_seed(3)
+        np.random.seed(3)
+        engine._DROPPATH_SEED.update(base=1234567, calls=0)
+        student, teacher = pretrain.build_networks(arch=None, out_dim=512, drop_path_rate=drop_path_rate,
+                                                   norm_last_layer=False, seg_channel=192,
+                                                   backbone_kwargs=dict(embed_dim=192, depth=3, num_heads=3, out_indices=[1, 2, 3]),
+                                                   head_kwargs=dict(hidden_dim=256, bottleneck_dim=64), device=device)
+        dino_loss = DINOLoss(512, 2, 0.04, 0.07, 3, 40).to(device)
+        opt = pretrain.make_optimizer(student, clip_grad=3.0)
+        run = pretrain.GraphedTrainingStep(student, teacher, dino_loss, opt, eager_steps=1) if graphed else None
+        losses = []
+        for i in range(steps):
+            images, masks, metrics = make_batch(B, seed=50 + i, device=device)
+            epoch = i // 2                                   # 0, 0, 1, 1, 2, 2, 3, 3: frozen last layer, three temperatures
+            kw = dict(epoch=epoch, lr=1e-3 * (1 + i % 3), wd=0.04 * (1 + i), momentum=0.99 - 0.01 * i)
+            if graphed:
+                losses.append(run(images, masks, metrics, **kw))
+            else:
+                losses.append(pretrain.training_iteration(student, teacher, dino_loss, opt, images, masks, metrics, **kw))
+        if device.type == "cuda":
+            torch.cuda.synchronize()
+        out.append(([float(l) for l in losses], student.arena.flat.clone(), teacher.arena.flat.clone(), dino_loss.center.clone(),
+                    None if run is None else (run.captures, run.replays)))
+    (le, se, te, ce, _), (lg, sg, tg, cg, counts) = out
+    temps = [float(DINOLoss(512, 2, 0.04, 0.07, 3, 40).teacher_temp_schedule[i // 2]) for i in range(1, steps)]
+    want = 1 + sum(a_ != b_ for a_, b_ in zip(temps, temps[1:]))          # one capture per teacher temperature met
+    assert counts == (want, steps - 1), (counts, want)
+    for i, (a_, b_) in enumerate(zip(le, lg)):
+        assert abs(a_ - b_) <= 1e-3 * max(1.0, abs(a_)), f"iteration {i}: eager loss {a_} vs graphed {b_}"
+    # updates compared in L2: an Adam step on a small batch turns atomics-order noise into +- lr element-wise - two EAGER runs
+    # of this schedule differ by ~5 % of the distance moved (measured on the CPU executor); a step that saw another
+    # iteration's lr / momentum / masks is an O(1) error
+    s0, t0 = (n.arena.flat for n in tiny_networks(device))
+    move, t_move = (se - s0).norm().item(), (te - t0).norm().item()
+    assert (se - sg).norm().item() <= 0.15 * move, ((se - sg).norm().item(), move)
+    assert (te - tg).norm().item() <= 0.15 * t_move, ((te - tg).norm().item(), t_move)
+    assert (ce - cg).norm().item() <= 0.05 * ce.norm().item(), ((ce - cg).norm().item(), ce.norm().item())
+
+
 def check_tiny_step(device, logit_tol=3e-2, loss_tol=2e-3, grad_rtol=6e-2):
     g = np.load(os.path.join(GOLD, "tiny_step.npz"))
     student, teacher = tiny_networks(device)

@@ -51,6 +51,10 @@ def test_optimizer_host_runs_ahead(hip):
     mc.check_optimizer_host_runs_ahead(hip.device)
 
 
+def test_graphed_training_step_matches_eager(hip):
+    mc.check_graphed_step_matches_eager(hip.device)
+
+
 def test_full_batch_iteration_equals_micro_batches(hip):
     report = mc.check_full_batch_equals_micro_batches(hip.device, B=256)
     os.makedirs("gpurun_out", exist_ok=True)

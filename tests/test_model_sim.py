@@ -83,3 +83,51 @@ def test_training_iterations_under_late_dma_model():
                         "tiny_training_iteration or finetune_against_oracle"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_graphed_training_step_bookkeeping_sim(sim, monkeypatch):
+    """pretrain.GraphedTrainingStep's host side on the CPU executor: there is no HIP graph here, so `_record` is replaced by a
+    stand-in whose replay() re-issues the captured launches with the launch-time constants of the capture (epoch / teacher
+    temperature closed over, the DropPath seed counter rewound to its value at capture) - what a graph replay does.  Everything
+    that must reach the kernels through device memory (momentum, seed offset, the AdamW table, the batch) then has to be right
+    for the run to agree with the eager one; re-captures are counted."""
+    from ccd_amd import engine, pretrain
+
+    def record(self, body):
+        seeds = engine._DROPPATH_SEED
+        at_capture, d_seed = seeds["calls"], seeds["device"]
+
+        class Replay:
+            def replay(_):
+                now = seeds["calls"]
+                seeds["calls"] = at_capture
+                engine.set_device_droppath_seed(d_seed)
+                try:
+                    body()
+                finally:
+                    engine.set_device_droppath_seed(None)
+                    seeds["calls"] = now
+        return Replay(), 1
+
+    masks, ema_args = [], []
+    real_scales, real_ema = engine.ops.droppath_scales, engine.ops.ema
+
+    def spy_scales(*a, **kw):
+        out = real_scales(*a, **kw)
+        masks.append(out.clone())
+        return out
+
+    def spy_ema(teacher, student, mirror, m, d_m=None):
+        ema_args.append(float(m) if d_m is None else float(d_m[0]))
+        return real_ema(teacher, student, mirror, m, d_m)
+
+    monkeypatch.setattr(engine.ops, "droppath_scales", spy_scales)
+    monkeypatch.setattr(engine.ops, "ema", spy_ema)
+    monkeypatch.setattr(pretrain.GraphedTrainingStep, "_record", record)
+    steps = 5
+    mc.check_graphed_step_matches_eager(sim.device, steps=steps, B=1, drop_path_rate=0.5)
+    # exactly the eager run's DropPath masks and momenta reached the kernels of the replays
+    assert len(masks) == 2 * steps and all(torch.equal(masks[i], masks[steps + i]) for i in range(steps))
+    assert len({m.numpy().tobytes() for m in masks[steps:]}) >= 3          # and they change from replay to replay
+    per = len(ema_args) // (2 * steps)
+    assert ema_args[:per * steps] == pytest.approx(ema_args[per * steps:], abs=1e-7), ema_args
