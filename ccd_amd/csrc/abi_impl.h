@@ -693,7 +693,7 @@ int ccd_augment_views(const uint8_t* img, const float* params, const float* thet
     if (batch == 0) return CCD_OK;
     CCD_LAUNCH(ccd::augment_spatial_kernel, dim3(2 * batch), dim3(256), (int)ccd::aug_spatial_smem(height, width), stream, img, params,
                staged_ws, height, width);
-    CCD_LAUNCH(ccd::augment_views_kernel, dim3((height * width + 255) / 256, batch), dim3(256), 0, stream, img, staged_ws, params, theta,
+    CCD_LAUNCH(ccd::augment_views_kernel, dim3((height * width + 255) / 256, batch), dim3(256), 0, stream, img, staged_ws, theta,
                out, batch, height, width, mean3[0], mean3[1], mean3[2], 1.0f / std3[0], 1.0f / std3[1], 1.0f / std3[2]);
     return ccd_rt_last_error();
 }

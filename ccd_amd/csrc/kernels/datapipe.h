@@ -9,11 +9,11 @@
 //     tests/golden/kmeans_masks.npz, where the global squared-error optimum differs in 10 of 48.  code = 1 for the brighter
 //     cluster; flipped when at least 3 of the 4 border lines are mostly 1 (sum > length // 2, integer compare).
 //     One workgroup per image of a ragged batch; integer arithmetic except the 256 scores.
-// (2) augment_views_kernel: the three views of a sample (datasetsupervised_kmeans.py:48-87): view 0 plain, view 1
-//     colour-augmented, view 2 colour-augmented + affine-warped; ImageNet mean/std normalisation (dataset.py:79-80,
-//     TF.normalize :80).  The colour stage is the pointwise family of the reference's imgaug pipelines (invert, grayscale
-//     blend, channel shuffle, gamma / linear contrast, brightness and per-channel gains, solarize, additive / multiplicative
-//     / impulse noise) behind one optional 3x3 filter (blur / sharpen / emboss / edge members); the warp samples the colour-augmented source with bilinear weights and zero fill, at
+// (2) augment_spatial_kernel + augment_views_kernel: the three views of a sample (datasetsupervised_kmeans.py:48-87): view 0
+//     plain, view 1 augmented, view 2 augmented + affine-warped; ImageNet mean/std normalisation (dataset.py:79-80).  The
+//     augmentation is the reference's imgaug chain (augmentation_pipelines.py:120-205): one member of each of `arithmetic`,
+//     `color`, `Blur`, `contrast`, in that order, applied by ONE workgroup per (sample, view) to a uint8 image held in LDS and
+//     rounded between the groups; the warp samples the augmented image with bilinear weights and zero fill at
 //     src = W_^-1 theta W_ (x, y, 1) - the exact inverse of how the dataset derives theta from the pixel matrix (:65-71).
 #pragma once
 
@@ -99,63 +99,37 @@ __global__ __launch_bounds__(KM_THREADS) void kmeans2_mask_kernel(const unsigned
 }
 
 // ---- augmentation ---------------------------------------------------------------------------------------------------
-constexpr int AUG_NP = 96;        // floats per (sample, view 1 | view 2): see ccd_amd/dataset/augment.py for the sampler
-// pointwise chain (aug_colour):
-// p[0] invert (0/1)  p[1] gray alpha  p[2] channel permutation id 0..5  p[3] gamma  p[4..6] per-channel gain
-// p[7] contrast alpha (around 128)  p[8] add  p[9] gaussian sigma  p[10] multiplicative noise half range
-// p[11] impulse probability  p[12] solarize threshold (>= 256: off)  p[13] noise seed (integer valued)
-// neighbourhood members (augment_spatial_kernel, a pre-pass that stages one uint8 image per (sample, view)):
-// p[25] JPEG quality 1..100 (0: off) - first, like the `arithmetic` group it belongs to (augmentation_pipelines.py:140)
-// p[14] 0 none | 1 7x7 correlation, coefficients p[32 + 7 (dy + 3) + (dx + 3)], BORDER_REFLECT_101 (Gaussian / average / motion
-//       blur, Sharpen, Emboss, EdgeDetect) | 2 median, k = p[15] in {3, 5, 7}, replicated border | 3 bilateral, d = p[15],
-//       sigma_color = p[26], sigma_space = p[27], BORDER_REFLECT_101            (the `Blur` group, :165-176)
-constexpr int AUG_P_MODE = 14, AUG_P_K = 15, AUG_P_JPEG = 25, AUG_P_SIGC = 26, AUG_P_SIGS = 27, AUG_P_KERN = 32;
+// One parameter row of AUG_NP floats per (sample, view 1 | view 2); ccd_amd/dataset/augment.py draws them with the member lists
+// and probabilities of the reference's imgaug pipelines (augmentation_pipelines.py:120-205; dataset_pretrain.py:79-158).  The
+// chain runs in the reference's order, ONE member per group, on a uint8 image that is rounded between the groups like imgaug's:
+//   p[0] seed   p[1] leading Invert (finetuning pipeline)
+//   group `arithmetic`: p[2] = member, p[3..8] = arguments a0..a5, p[9..17] = its 3 x 3 correlation kernel
+//      1 AddElementwise (a0 = R: integers -R..R, a1 = per channel)   2 AdditiveGaussianNoise (a0 = sigma, a1 = per channel)
+//      3 AdditiveLaplaceNoise (a0 = scale, a1)   4 AdditivePoissonNoise (a0 = lambda, a1)   5 Multiply (a0..a2 = channel gains)
+//      6 MultiplyElementwise (a0 = low, a1 = per channel, a2 = high)   7 Dropout (a0 = p, a1)
+//      8 CoarseDropout (a0 = p, a1, a2 x a3 = the low-resolution mask, nearest up-sampling)   9 Dropout2d (a0 = kept channels, bits)
+//      10 ImpulseNoise / SaltAndPepper / Salt / Pepper (a0 = p, a1, a2 = 0 both | 1 salt | 2 pepper; replacement 255 * Beta(0.5, 0.5))
+//      11 Invert   12 Solarize (a0 = threshold)   13 JpegCompression (a0 = PIL quality)
+//      14 Emboss / EdgeDetect / DirectedEdgeDetect (kernel, BORDER_REFLECT_101)
+//      15 pillike.FilterEdgeEnhanceMore / FilterContour (kernel, a0 = offset, a1 = scale; PIL copies the border pixels)
+//   group `color`: p[18] = member, p[19..23] = arguments; HSV = cv2's 8-bit RGB2HSV / HSV2RGB (H in 0..179)
+//      1 H += a0 on uint8, saturating (WithColorspace / ChangeColorspace + WithChannels(0, Add))   2 gains a0 * rgb + a1
+//      (MultiplyAndAddToBrightness, approximated in RGB)   3 MultiplyHueAndSaturation (a0, a1; H on imgaug's 0..255 scale,
+//      wrapped modulo 255)   4 AddToHueAndSaturation (a0 = hue shift in H units, a1 = saturation shift)   5 Grayscale (a0 = alpha)
+//      7 UniformColorQuantization (a0 = colours per channel)   8 channel gains a0..a2 (ChangeColorTemperature)   9 ChannelShuffle (a0 = permutation)
+//   group `Blur`: p[24] = 0 none | 1 7x7 correlation p[32..80], BORDER_REFLECT_101 (Gaussian / average / motion blur, Sharpen) |
+//      2 median, k = p[25] in {3, 5, 7}, replicated border | 3 bilateral, d = p[25], sigma_color = p[26], sigma_space = p[27]
+//   group `contrast`: p[28] = member, p[29], p[30]: 1 GammaContrast   2 LinearContrast (around 127)   3 SigmoidContrast (gain, cutoff)
+//      4 LogContrast (gain)   6 AllChannelsHistogramEqualization (cv2.equalizeHist per channel); imgaug's tables truncate
+// Members not reproduced keep their share of the draw and leave the image unchanged (the list is in INTEGRATION.md).
+constexpr int AUG_NP = 96;
+constexpr int AUG_P_SEED = 0, AUG_P_PREINV = 1, AUG_P_A = 2, AUG_P_AK = 9, AUG_P_B = 18, AUG_P_C = 24, AUG_P_D = 28, AUG_P_KERN = 32;
 __device__ __forceinline__ unsigned aug_hash(unsigned a, unsigned b) {
     unsigned z = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u);
     z ^= z >> 16; z *= 0x85EBCA6Bu; z ^= z >> 13; z *= 0xC2B2AE35u; z ^= z >> 16;
     return z;
 }
 __device__ __forceinline__ float aug_u01(unsigned h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
-// colour stage of one source pixel: rgb in 0..255 -> rgb in 0..255 (clamped, not rounded: the reference rounds to uint8
-// between augmenters; one rounding at the end of the chain is inside the noise every member adds)
-__device__ __forceinline__ void aug_colour(const float* __restrict__ p, float r, float g, float b, unsigned pix_id, float* out) {
-    float c[3] = {r, g, b};
-    if (p[0] != 0.f) { c[0] = 255.f - c[0]; c[1] = 255.f - c[1]; c[2] = 255.f - c[2]; }
-    if (p[12] < 256.f) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) c[k] = c[k] >= p[12] ? 255.f - c[k] : c[k];
-    }
-    const float gray = 0.299f * c[0] + 0.587f * c[1] + 0.114f * c[2];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) c[k] = c[k] + p[1] * (gray - c[k]);
-    const int perm = (int)p[2];
-    const int p0 = perm >> 1, rest0 = p0 == 0 ? 1 : 0, rest1 = p0 == 2 ? 1 : 2;
-    const int p1 = (perm & 1) ? rest1 : rest0, p2 = (perm & 1) ? rest0 : rest1;
-    const float s[3] = {c[p0], c[p1], c[p2]};
-    const unsigned seed = (unsigned)p[13];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        float v = s[k];
-        if (p[3] != 1.0f) v = 255.f * powf(fmaxf(v, 0.f) * (1.0f / 255.f), p[3]);
-        v = v * p[4 + k];
-        v = 128.f + p[7] * (v - 128.f) + p[8];
-        const unsigned h0 = aug_hash(pix_id * 3u + (unsigned)k, seed);
-        if (p[9] > 0.f) {          // Box-Muller
-            const unsigned h1 = aug_hash(h0, seed ^ 0xA511E9B3u);
-            v += p[9] * sqrtf(-2.0f * logf(fmaxf(aug_u01(h0), 1e-7f))) * cosf(6.2831853f * aug_u01(h1));
-        }
-        if (p[10] > 0.f) v *= 1.0f + p[10] * (2.0f * aug_u01(aug_hash(h0, seed ^ 0x3C6EF372u)) - 1.0f);
-        if (p[11] > 0.f) {
-            const float u = aug_u01(aug_hash(h0, seed ^ 0xDAA66D2Bu));
-            if (u < p[11]) v = u < 0.5f * p[11] ? 0.f : 255.f;
-        }
-        out[k] = fminf(fmaxf(v, 0.f), 255.f);
-    }
-}
-
-
-// ---- neighbourhood members: oracle/datapipe_np.py restates each (jpeg_roundtrip pinned against PIL / libjpeg, median_blur and
-// filter7 against scipy.ndimage, bilateral_blur after OpenCV's documented algorithm)
 __device__ __forceinline__ int aug_reflect101(int i, int n) {
     if (n == 1) return 0;
     i = i < 0 ? -i : i;
@@ -168,6 +142,42 @@ __device__ __forceinline__ unsigned char aug_round_u8(float v) {
     v = floorf(v + 0.5f);
     return (unsigned char)(v < 0.f ? 0.f : (v > 255.f ? 255.f : v));
 }
+__device__ __forceinline__ unsigned char aug_trunc_u8(float v) {          // np.clip(table, 0, 255).astype(uint8)
+    return (unsigned char)(v < 0.f ? 0.f : (v > 255.f ? 255.f : v));
+}
+// cv2 (color_hsv.cpp) RGB2HSV_b: 12-bit fixed point with division tables sdiv[v] = round(255 * 4096 / v), hdiv[d] = round(180 * 4096 / (6 d))
+__device__ __forceinline__ void aug_rgb2hsv(int r, int g, int b, int& h, int& s, int& v) {
+    v = r > g ? r : g; v = v > b ? v : b;
+    int vmin = r < g ? r : g; vmin = vmin < b ? vmin : b;
+    const int diff = v - vmin;
+    s = v ? (diff * (int)rint(1044480.0 / (double)v) + 2048) >> 12 : 0;
+    h = 0;
+    if (diff) {
+        const int hh = v == r ? g - b : (v == g ? b - r + 2 * diff : r - g + 4 * diff);
+        h = (hh * (int)rint(122880.0 / (double)diff) + 2048) >> 12;
+        if (h < 0) h += 180;
+    }
+}
+// cv2 HSV2RGB_b: through float, h * 6 / 180 reduced into [0, 6), saturate_cast<uchar>(x * 255) (round half to even)
+__device__ __forceinline__ void aug_hsv2rgb(int hi, int si, int vi, int& r, int& g, int& b) {
+    const float s = (float)si * (1.0f / 255.f), v = (float)vi * (1.0f / 255.f);
+    float fr = v, fg = v, fb = v;
+    if (si != 0) {
+        float h = (float)hi * (6.0f / 180.f);
+        while (h < 0.f) h += 6.f;
+        while (h >= 6.f) h -= 6.f;
+        int sector = (int)floorf(h);
+        h -= (float)sector;
+        if ((unsigned)sector >= 6u) { sector = 0; h = 0.f; }
+        const float tab[4] = {v, v * (1.f - s), v * (1.f - s * h), v * (1.f - s * (1.f - h))};
+        // (b, g, r) table indices per sector
+        const int ib = sector == 0 ? 1 : sector == 1 ? 1 : sector == 2 ? 3 : sector == 3 ? 0 : sector == 4 ? 0 : 2;
+        const int ig = sector == 0 ? 3 : sector == 1 ? 0 : sector == 2 ? 0 : sector == 3 ? 2 : sector == 4 ? 1 : 1;
+        const int ir = sector == 0 ? 0 : sector == 1 ? 2 : sector == 2 ? 1 : sector == 3 ? 1 : sector == 4 ? 3 : 0;
+        fb = tab[ib]; fg = tab[ig]; fr = tab[ir];
+    }
+    r = aug_clampi((int)rintf(fr * 255.f), 256); g = aug_clampi((int)rintf(fg * 255.f), 256); b = aug_clampi((int)rintf(fb * 255.f), 256);
+}
 // Annex-K base tables (libjpeg's std_luminance_quant_tbl / std_chrominance_quant_tbl), natural order
 __device__ __forceinline__ int aug_jpeg_base(bool luma, int i) {
     static constexpr unsigned char L[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56,
@@ -178,10 +188,60 @@ __device__ __forceinline__ int aug_jpeg_base(bool luma, int i) {
     return luma ? L[i] : (i < 32 ? C[i] : 99);
 }
 __host__ __device__ inline int aug_pad16(int n) { return (n + 15) / 16 * 16; }
-// dynamic LDS of the pre-pass: the uint8 image + (JPEG) sample planes and coefficient planes of the padded image
+// dynamic LDS of the chain: two uint8 images (a neighbourhood member reads one and writes the other) + (JPEG) sample and
+// coefficient planes of the padded image (the histogram member uses the start of that area)
+__host__ __device__ inline long aug_image_bytes(int H, int W) { return (((long)H * W * 3 + 15) / 16) * 16; }
 __host__ __device__ inline long aug_spatial_smem(int H, int W) {
     const long plane = (long)aug_pad16(H) * aug_pad16(W);
-    return (((long)H * W * 3 + 15) / 16) * 16 + 2 * (plane + plane / 2) * 4 + 64 * 4;
+    return 2 * aug_image_bytes(H, W) + 2 * (plane + plane / 2) * 4 + 64 * 4;
+}
+// the pointwise members of `arithmetic` on one channel value; (y, x) = the pixel, k = the channel
+__device__ __forceinline__ float aug_arith_point(const float* __restrict__ p, int op, float v, int y, int x, int k, int H, int W, unsigned seed) {
+    const float a0 = p[AUG_P_A + 1], a1 = p[AUG_P_A + 2], a2 = p[AUG_P_A + 3], a3 = p[AUG_P_A + 4];
+    const int ch = a1 != 0.f ? k : 0;                                     // per_channel: one draw per channel, else per pixel
+    const unsigned e = (unsigned)((y * W + x) * 3 + ch);
+    const unsigned h0 = aug_hash(e, seed ^ 0x51ED270Bu);
+    switch (op) {
+    case 1: return v + (float)((int)floorf(aug_u01(h0) * (2.f * a0 + 1.f)) - (int)a0);
+    case 2: {                                                              // Box-Muller
+        const unsigned h1 = aug_hash(h0, seed ^ 0xA511E9B3u);
+        return v + a0 * sqrtf(-2.0f * logf(fmaxf(aug_u01(h0), 1e-7f))) * cosf(6.2831853f * aug_u01(h1));
+    }
+    case 3: {
+        const float u = aug_u01(h0) - 0.5f, m = fmaxf(1.f - 2.f * fabsf(u), 1e-7f);
+        return v - a0 * (u < 0.f ? -1.f : 1.f) * logf(m);
+    }
+    case 4: {                                                              // Knuth: multiply uniforms until below exp(-lambda)
+        const float lim = expf(-a0);
+        float prod = 1.f;
+        int n = -1;
+        unsigned h = h0;
+        do {
+            prod *= fmaxf(aug_u01(h), 1e-7f);
+            h = aug_hash(h, seed ^ 0x3C6EF372u);
+            ++n;
+        } while (prod > lim && n < 200);
+        return v + (float)n;
+    }
+    case 5: return v * p[AUG_P_A + 1 + k];
+    case 6: return v * (a0 + (a2 - a0) * aug_u01(h0));
+    case 7: return aug_u01(h0) < a0 ? 0.f : v;
+    case 8: {
+        const int rows = (int)a2, cols = (int)a3;
+        const int cy = aug_clampi(y * rows / H, rows), cx = aug_clampi(x * cols / W, cols);
+        return aug_u01(aug_hash((unsigned)((cy * cols + cx) * 3 + ch), seed ^ 0x6A09E667u)) < a0 ? 0.f : v;
+    }
+    case 9: return ((int)a0 >> k) & 1 ? v : 0.f;
+    case 10: {
+        if (aug_u01(h0) >= a0) return v;
+        const float sn = sinf(1.5707963f * aug_u01(aug_hash(h0, seed ^ 0xDAA66D2Bu)));
+        const float beta = sn * sn, dev = fabsf(beta - 0.5f);            // Beta(0.5, 0.5): the arcsine law
+        return 255.f * (a2 == 1.f ? 0.5f + dev : (a2 == 2.f ? 0.5f - dev : beta));
+    }
+    case 11: return 255.f - v;
+    case 12: return v >= a0 ? 255.f - v : v;
+    default: return v;
+    }
 }
 // one workgroup per (sample, view): img uint8 [B, H, W, 3], params fp32 [B, 2, AUG_NP] -> staged uint8 [B, 2, H, W, 3]
 __global__ __launch_bounds__(256) void augment_spatial_kernel(const unsigned char* __restrict__ img, const float* __restrict__ params,
@@ -189,15 +249,39 @@ __global__ __launch_bounds__(256) void augment_spatial_kernel(const unsigned cha
     char* smem = dynamic_smem();
     const int t = threadIdx.x, b = blockIdx.x >> 1, npix = H * W;
     const float* p = params + (long)blockIdx.x * AUG_NP;
+    const long img_bytes = aug_image_bytes(H, W);
     unsigned char* cur = reinterpret_cast<unsigned char*>(smem);
+    unsigned char* alt = cur + img_bytes;
     const int Hp = aug_pad16(H), Wp = aug_pad16(W), Hc = Hp / 2, Wc = Wp / 2;
-    float* plane = reinterpret_cast<float*>(smem + ((npix * 3 + 15) / 16) * 16);      // Y [Hp][Wp], Cb [Hc][Wc], Cr [Hc][Wc]
+    float* plane = reinterpret_cast<float*>(smem + 2 * img_bytes);                     // Y [Hp][Wp], Cb [Hc][Wc], Cr [Hc][Wc]
     float* coef = plane + Hp * Wp + 2 * Hc * Wc;
     float* dct = coef + Hp * Wp + 2 * Hc * Wc;                                          // D[u][x]
     const unsigned char* src = img + (long)b * npix * 3;
-    for (int i = t; i < npix * 3; i += 256) cur[i] = src[i];
-    const int quality = (int)p[AUG_P_JPEG];
-    if (quality > 0) {
+    const unsigned seed = (unsigned)p[AUG_P_SEED];
+    const bool pre_invert = p[AUG_P_PREINV] != 0.f;
+    for (int i = t; i < npix * 3; i += 256) cur[i] = pre_invert ? (unsigned char)(255 - src[i]) : src[i];
+    __syncthreads();
+    // a 3 x 3 correlation cur -> alt, then the buffers swap
+    auto filter3 = [&](const float* kern, bool pil, float offset, float scale) {
+        for (int i = t; i < npix; i += 256) {
+            const int y = i / W, x = i % W;
+            const bool edge = pil && (y == 0 || x == 0 || y == H - 1 || x == W - 1);
+            for (int k = 0; k < 3; ++k) {
+                float acc = 0.f;
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx)
+                        acc = fmaf(kern[3 * (dy + 1) + (dx + 1)],
+                                   (float)cur[(aug_reflect101(y + dy, H) * W + aug_reflect101(x + dx, W)) * 3 + k], acc);
+                alt[i * 3 + k] = edge ? cur[i * 3 + k] : aug_round_u8(pil ? acc / scale + offset : acc);
+            }
+        }
+        __syncthreads();
+        unsigned char* tmp = cur; cur = alt; alt = tmp;
+    };
+    // ---------------------------------------------------------------- group `arithmetic`
+    const int opA = (int)p[AUG_P_A];
+    if (opA == 13) {
+        const int quality = (int)p[AUG_P_A + 1];
         if (t < 64) {
             const int u = t >> 3, x = t & 7;
             dct[t] = (u == 0 ? 0.35355339059327379f : 0.5f) * cosf((float)((2 * x + 1) * u) * 0.19634954084936207f);
@@ -286,69 +370,170 @@ __global__ __launch_bounds__(256) void augment_spatial_kernel(const unsigned cha
             cur[i * 3 + 1] = (unsigned char)aug_clampi(g, 256);
             cur[i * 3 + 2] = (unsigned char)aug_clampi(bl, 256);
         }
-    }
-    __syncthreads();
-    unsigned char* dst = staged + (long)blockIdx.x * npix * 3;
-    const int mode = (int)p[AUG_P_MODE];
-    for (int i = t; i < npix; i += 256) {
-        const int y = i / W, x = i % W;
-        if (mode == 1) {                                     // 7 x 7 correlation
-            float acc[3] = {0.f, 0.f, 0.f};
-            for (int dy = -3; dy <= 3; ++dy)
-                for (int dx = -3; dx <= 3; ++dx) {
-                    const float wgt = p[AUG_P_KERN + 7 * (dy + 3) + (dx + 3)];
-                    if (wgt == 0.f) continue;
-                    const int sp = (aug_reflect101(y + dy, H) * W + aug_reflect101(x + dx, W)) * 3;
-                    acc[0] = fmaf(wgt, (float)cur[sp], acc[0]); acc[1] = fmaf(wgt, (float)cur[sp + 1], acc[1]);
-                    acc[2] = fmaf(wgt, (float)cur[sp + 2], acc[2]);
-                }
+
+        __syncthreads();
+    } else if (opA == 14 || opA == 15) {
+        filter3(p + AUG_P_AK, opA == 15, p[AUG_P_A + 1], p[AUG_P_A + 2] != 0.f ? p[AUG_P_A + 2] : 1.f);
+    } else if (opA != 0) {
+        for (int i = t; i < npix; i += 256) {
+            const int y = i / W, x = i % W;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) dst[i * 3 + k] = aug_round_u8(acc[k]);
-        } else if (mode == 2) {                              // median of the k x k window: the value of rank (k k) / 2
-            const int r = (int)p[AUG_P_K] / 2, n = (2 * r + 1) * (2 * r + 1), want = n / 2;
-            for (int k = 0; k < 3; ++k) {
-                int med = cur[i * 3 + k];
-                for (int a = 0; a < n; ++a) {
-                    const int va = cur[(aug_clampi(y + a / (2 * r + 1) - r, H) * W + aug_clampi(x + a % (2 * r + 1) - r, W)) * 3 + k];
-                    int less = 0, leq = 0;
-                    for (int c = 0; c < n; ++c) {
-                        const int vc = cur[(aug_clampi(y + c / (2 * r + 1) - r, H) * W + aug_clampi(x + c % (2 * r + 1) - r, W)) * 3 + k];
-                        less += vc < va;
-                        leq += vc <= va;
-                    }
-                    if (less <= want && want < leq) { med = va; break; }
-                }
-                dst[i * 3 + k] = (unsigned char)med;
-            }
-        } else if (mode == 3) {                              // bilateral (OpenCV: L1 colour distance, circular window)
-            const int radius = (int)p[AUG_P_K] / 2;
-            const float gc = -0.5f / (p[AUG_P_SIGC] * p[AUG_P_SIGC]), gs = -0.5f / (p[AUG_P_SIGS] * p[AUG_P_SIGS]);
-            const float c0 = cur[i * 3], c1 = cur[i * 3 + 1], c2 = cur[i * 3 + 2];
-            float num[3] = {0.f, 0.f, 0.f}, den = 0.f;
-            for (int dy = -radius; dy <= radius; ++dy)
-                for (int dx = -radius; dx <= radius; ++dx) {
-                    const int rr = dy * dy + dx * dx;
-                    if (rr > radius * radius) continue;
-                    const int sp = (aug_reflect101(y + dy, H) * W + aug_reflect101(x + dx, W)) * 3;
-                    const float t0 = cur[sp], t1 = cur[sp + 1], t2 = cur[sp + 2];
-                    const float dist = fabsf(t0 - c0) + fabsf(t1 - c1) + fabsf(t2 - c2);
-                    const float wgt = expf((float)rr * gs) * expf(dist * dist * gc);
-                    num[0] += wgt * t0; num[1] += wgt * t1; num[2] += wgt * t2;
-                    den += wgt;
-                }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) dst[i * 3 + k] = aug_round_u8(num[k] / den);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) dst[i * 3 + k] = cur[i * 3 + k];
+            for (int k = 0; k < 3; ++k) cur[i * 3 + k] = aug_round_u8(aug_arith_point(p, opA, (float)cur[i * 3 + k], y, x, k, H, W, seed));
         }
+        __syncthreads();
     }
+    // ---------------------------------------------------------------- group `color`
+    const int opB = (int)p[AUG_P_B];
+    if (opB != 0) {
+        const float b0 = p[AUG_P_B + 1], b1 = p[AUG_P_B + 2], b2 = p[AUG_P_B + 3];
+        for (int i = t; i < npix; i += 256) {
+            int r = cur[i * 3], g = cur[i * 3 + 1], bl = cur[i * 3 + 2];
+            if (opB == 1 || opB == 3 || opB == 4) {
+                int h, s, v;
+                aug_rgb2hsv(r, g, bl, h, s, v);
+                if (opB == 1) {
+                    h = h + (int)b0; h = h > 255 ? 255 : h;
+                } else if (opB == 3) {
+                    int h255 = (int)rintf((float)h * (255.f / 180.f));
+                    h255 = (int)rintf((float)h255 * b0) % 255;
+                    if (h255 < 0) h255 += 255;
+                    h = (int)rintf((float)h255 * (180.f / 255.f));
+                    s = aug_clampi((int)rintf((float)s * b1), 256);
+                } else {
+                    h = (h + (int)b0) % 180;
+                    if (h < 0) h += 180;
+                    s = aug_clampi(s + (int)b1, 256);
+                }
+                aug_hsv2rgb(h, s, v, r, g, bl);
+            } else if (opB == 2) {
+                r = aug_round_u8((float)r * b0 + b1); g = aug_round_u8((float)g * b0 + b1); bl = aug_round_u8((float)bl * b0 + b1);
+            } else if (opB == 5) {                          // cv2 RGB2GRAY (14-bit fixed point), blended with alpha
+                const float gray = (float)((r * 4899 + g * 9617 + bl * 1868 + 8192) >> 14);
+                r = aug_round_u8((float)r + b0 * (gray - (float)r)); g = aug_round_u8((float)g + b0 * (gray - (float)g));
+                bl = aug_round_u8((float)bl + b0 * (gray - (float)bl));
+            } else if (opB == 7) {                          // bin centres of b0 equal bins
+                const float q = 256.f / b0;
+                r = aug_trunc_u8(floorf((float)r / q) * q + 0.5f * q); g = aug_trunc_u8(floorf((float)g / q) * q + 0.5f * q);
+                bl = aug_trunc_u8(floorf((float)bl / q) * q + 0.5f * q);
+            } else if (opB == 8) {
+                r = aug_round_u8((float)r * b0); g = aug_round_u8((float)g * b1); bl = aug_round_u8((float)bl * b2);
+            } else if (opB == 9) {
+                const int perm = (int)b0, p0 = perm >> 1, rest0 = p0 == 0 ? 1 : 0, rest1 = p0 == 2 ? 1 : 2;
+                const int p1 = (perm & 1) ? rest1 : rest0, p2 = (perm & 1) ? rest0 : rest1;
+                const int c[3] = {r, g, bl};
+                r = c[p0]; g = c[p1]; bl = c[p2];
+            }
+            cur[i * 3] = (unsigned char)r; cur[i * 3 + 1] = (unsigned char)g; cur[i * 3 + 2] = (unsigned char)bl;
+        }
+        __syncthreads();
+    }
+    // ---------------------------------------------------------------- group `Blur`
+    const int mode = (int)p[AUG_P_C];
+    if (mode != 0) {
+        for (int i = t; i < npix; i += 256) {
+            const int y = i / W, x = i % W;
+            if (mode == 1) {                                     // 7 x 7 correlation
+                float acc[3] = {0.f, 0.f, 0.f};
+                for (int dy = -3; dy <= 3; ++dy)
+                    for (int dx = -3; dx <= 3; ++dx) {
+                        const float wgt = p[AUG_P_KERN + 7 * (dy + 3) + (dx + 3)];
+                        if (wgt == 0.f) continue;
+                        const int sp = (aug_reflect101(y + dy, H) * W + aug_reflect101(x + dx, W)) * 3;
+                        acc[0] = fmaf(wgt, (float)cur[sp], acc[0]); acc[1] = fmaf(wgt, (float)cur[sp + 1], acc[1]);
+                        acc[2] = fmaf(wgt, (float)cur[sp + 2], acc[2]);
+                    }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) alt[i * 3 + k] = aug_round_u8(acc[k]);
+            } else if (mode == 2) {                              // median of the k x k window: the value of rank (k k) / 2
+                const int r = (int)p[AUG_P_C + 1] / 2, n = (2 * r + 1) * (2 * r + 1), want = n / 2;
+                for (int k = 0; k < 3; ++k) {
+                    int med = cur[i * 3 + k];
+                    for (int a = 0; a < n; ++a) {
+                        const int va = cur[(aug_clampi(y + a / (2 * r + 1) - r, H) * W + aug_clampi(x + a % (2 * r + 1) - r, W)) * 3 + k];
+                        int less = 0, leq = 0;
+                        for (int c = 0; c < n; ++c) {
+                            const int vc = cur[(aug_clampi(y + c / (2 * r + 1) - r, H) * W + aug_clampi(x + c % (2 * r + 1) - r, W)) * 3 + k];
+                            less += vc < va;
+                            leq += vc <= va;
+                        }
+                        if (less <= want && want < leq) { med = va; break; }
+                    }
+                    alt[i * 3 + k] = (unsigned char)med;
+                }
+            } else {                                             // bilateral (OpenCV: L1 colour distance, circular window)
+                const int radius = (int)p[AUG_P_C + 1] / 2;
+                const float sc_ = p[AUG_P_C + 2], ss_ = p[AUG_P_C + 3];
+                const float gc = -0.5f / (sc_ * sc_), gs = -0.5f / (ss_ * ss_);
+                const float c0 = cur[i * 3], c1 = cur[i * 3 + 1], c2 = cur[i * 3 + 2];
+                float num[3] = {0.f, 0.f, 0.f}, den = 0.f;
+                for (int dy = -radius; dy <= radius; ++dy)
+                    for (int dx = -radius; dx <= radius; ++dx) {
+                        const int rr = dy * dy + dx * dx;
+                        if (rr > radius * radius) continue;
+                        const int sp = (aug_reflect101(y + dy, H) * W + aug_reflect101(x + dx, W)) * 3;
+                        const float t0 = cur[sp], t1 = cur[sp + 1], t2 = cur[sp + 2];
+                        const float dist = fabsf(t0 - c0) + fabsf(t1 - c1) + fabsf(t2 - c2);
+                        const float wgt = expf((float)rr * gs) * expf(dist * dist * gc);
+                        num[0] += wgt * t0; num[1] += wgt * t1; num[2] += wgt * t2;
+                        den += wgt;
+                    }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) alt[i * 3 + k] = aug_round_u8(num[k] / den);
+            }
+        }
+        __syncthreads();
+        unsigned char* tmp = cur; cur = alt; alt = tmp;
+    }
+    // ---------------------------------------------------------------- group `contrast`
+    const int opD = (int)p[AUG_P_D];
+    if (opD >= 1 && opD <= 4) {
+        const float d0 = p[AUG_P_D + 1], d1 = p[AUG_P_D + 2];
+        for (int i = t; i < npix * 3; i += 256) {
+            const float v = (float)cur[i], u = v * (1.0f / 255.f);
+            float o;
+            if (opD == 1) o = 255.f * powf(u, d0);
+            else if (opD == 2) o = 127.f + d0 * (v - 127.f);
+            else if (opD == 3) o = 255.f / (1.f + expf(d0 * (d1 - u)));
+            else o = 255.f * d0 * log2f(1.f + u);
+            cur[i] = aug_trunc_u8(o);
+        }
+        __syncthreads();
+    } else if (opD == 6) {                                   // cv2.equalizeHist on each channel
+        int* hist = reinterpret_cast<int*>(plane);           // [3][256]
+        unsigned char* lut = reinterpret_cast<unsigned char*>(hist + 768);
+        for (int i = t; i < 768; i += 256) hist[i] = 0;
+        __syncthreads();
+        for (int i = t; i < npix * 3; i += 256) atomicAdd(&hist[(i % 3) * 256 + cur[i]], 1);
+        __syncthreads();
+        if (t < 3) {
+            const int* hc = hist + 256 * t;
+            unsigned char* lc = lut + 256 * t;
+            int i0 = 0;
+            while (hc[i0] == 0) ++i0;
+            if (hc[i0] == npix) {
+                for (int i = 0; i < 256; ++i) lc[i] = (unsigned char)i0;
+            } else {
+                const float scale = 255.f / (float)(npix - hc[i0]);
+                int sum = 0;
+                for (int i = 0; i <= i0; ++i) lc[i] = 0;
+                for (int i = i0 + 1; i < 256; ++i) {
+                    sum += hc[i];
+                    lc[i] = (unsigned char)aug_clampi((int)rintf((float)sum * scale), 256);
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = t; i < npix * 3; i += 256) cur[i] = lut[(i % 3) * 256 + cur[i]];
+        __syncthreads();
+    }
+    unsigned char* dst = staged + (long)blockIdx.x * npix * 3;
+    for (int i = t; i < npix * 3; i += 256) dst[i] = cur[i];
 }
 
-// img uint8 [B, H, W, 3]; staged uint8 [B, 2, H, W, 3] (augment_spatial_kernel: the neighbourhood members of views 1 / 2);
-// params fp32 [B, 2, AUG_NP] (view 1, view 2); theta fp32 [B, 3, 3]; out fp32 [B, 3 views, 3, H, W]
+// img uint8 [B, H, W, 3]; staged uint8 [B, 2, H, W, 3] (augment_spatial_kernel: the augmented images of views 1 / 2);
+// theta fp32 [B, 3, 3]; out fp32 [B, 3 views, 3, H, W]: view 0 plain, view 1 augmented, view 2 augmented and warped (bilinear, zero fill,
+// src = theta (x, y, 1) in normalised coordinates - the inverse of how the dataset derives theta, datasetsupervised_kmeans.py:65-71)
 __global__ __launch_bounds__(256) void augment_views_kernel(const unsigned char* __restrict__ img, const unsigned char* __restrict__ staged,
-                                                            const float* __restrict__ params,
                                                             const float* __restrict__ theta, float* __restrict__ out,
                                                             int B, int H, int W, float m0, float m1, float m2, float is0,
                                                             float is1, float is2) {
@@ -360,47 +545,35 @@ __global__ __launch_bounds__(256) void augment_views_kernel(const unsigned char*
     const float mean[3] = {m0, m1, m2}, istd[3] = {is0, is1, is2};
     float* o = out + (long)b * 9 * H * W + pix;
     const long plane = (long)H * W;
-    const float r = src[pix * 3], g = src[pix * 3 + 1], bl = src[pix * 3 + 2];
-    {
-        const float c[3] = {r, g, bl};
+    const unsigned char* s1 = staged + (long)(2 * b) * H * W * 3 + pix * 3;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) o[k * plane] = (c[k] * (1.0f / 255.f) - mean[k]) * istd[k];
+    for (int k = 0; k < 3; ++k) {
+        o[k * plane] = ((float)src[pix * 3 + k] * (1.0f / 255.f) - mean[k]) * istd[k];
+        o[(3 + k) * plane] = ((float)s1[k] * (1.0f / 255.f) - mean[k]) * istd[k];
     }
-    {
-        float c[3];
-        const unsigned char* s1 = staged + (long)(2 * b) * H * W * 3 + pix * 3;
-        aug_colour(params + (long)b * 2 * AUG_NP, (float)s1[0], (float)s1[1], (float)s1[2], (unsigned)pix, c);
+    const float* th = theta + (long)b * 9;
+    const unsigned char* s2 = staged + (long)(2 * b + 1) * H * W * 3;
+    const float xn = 2.0f * (float)x / (float)(W - 1) - 1.0f, yn = 2.0f * (float)y / (float)(H - 1) - 1.0f;
+    const float xs = ((th[0] * xn + th[1] * yn + th[2]) + 1.0f) * 0.5f * (float)(W - 1);
+    const float ys = ((th[3] * xn + th[4] * yn + th[5]) + 1.0f) * 0.5f * (float)(H - 1);
+    const float xf = floorf(xs), yf = floorf(ys);
+    const int x0 = (int)xf, y0 = (int)yf;
+    const float ax = xs - xf, ay = ys - yf;
+    float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) o[(3 + k) * plane] = (c[k] * (1.0f / 255.f) - mean[k]) * istd[k];
-    }
-    {
-        const float* th = theta + (long)b * 9;
-        const float* p2 = params + ((long)b * 2 + 1) * AUG_NP;
-        const unsigned char* s2 = staged + (long)(2 * b + 1) * H * W * 3;
-        const float xn = 2.0f * (float)x / (float)(W - 1) - 1.0f, yn = 2.0f * (float)y / (float)(H - 1) - 1.0f;
-        const float xs = ((th[0] * xn + th[1] * yn + th[2]) + 1.0f) * 0.5f * (float)(W - 1);
-        const float ys = ((th[3] * xn + th[4] * yn + th[5]) + 1.0f) * 0.5f * (float)(H - 1);
-        const float xf = floorf(xs), yf = floorf(ys);
-        const int x0 = (int)xf, y0 = (int)yf;
-        const float ax = xs - xf, ay = ys - yf;
-        float acc[3] = {0.f, 0.f, 0.f};
+    for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx) {
+            const int xx = x0 + dx, yy = y0 + dy;
+            const float wgt = (dx ? ax : 1.0f - ax) * (dy ? ay : 1.0f - ay);
+            if (xx >= 0 && xx < W && yy >= 0 && yy < H && wgt != 0.f) {
+                const int sp = (yy * W + xx) * 3;
 #pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                const int xx = x0 + dx, yy = y0 + dy;
-                const float wgt = (dx ? ax : 1.0f - ax) * (dy ? ay : 1.0f - ay);
-                if (xx >= 0 && xx < W && yy >= 0 && yy < H && wgt != 0.f) {
-                    const int sp = yy * W + xx;
-                    float c[3];
-                    aug_colour(p2, (float)s2[sp * 3], (float)s2[sp * 3 + 1], (float)s2[sp * 3 + 2], (unsigned)sp, c);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) acc[k] += wgt * c[k];
-                }
+                for (int k = 0; k < 3; ++k) acc[k] += wgt * (float)s2[sp + k];
             }
+        }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) o[(6 + k) * plane] = (acc[k] * (1.0f / 255.f) - mean[k]) * istd[k];
-    }
+    for (int k = 0; k < 3; ++k) o[(6 + k) * plane] = (acc[k] * (1.0f / 255.f) - mean[k]) * istd[k];
 }
 
 }  // namespace ccd

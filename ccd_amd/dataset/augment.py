@@ -6,18 +6,20 @@ to view 2 with probability 0.7 (datasetsupervised_kmeans.py:40-45,60), and `thet
 :65-71 does: theta = W_ . M_px^-1 . W_^-1 with W_ = [[2/(w-1),0,-1],[0,2/(h-1),-1],[0,0,1]] (the dataset's W_inv . M . W
 factors cancel when the augmentation runs at the network resolution, which it does here).  A sample whose 0.7 draw fails
 gets the PLAIN image as view 2 (:72-74): its colour parameters are the identity.
-Colour = the members of the imgaug pipelines the configs select (augmentation_pipelines.py: severity 5 for `augment_tfs`):
-* pointwise (augment_views_kernel): invert, grayscale blend, channel shuffle, gamma / linear contrast, brightness and
-  per-channel gains (MultiplyBrightness, ChangeColorTemperature), solarize, additive gaussian / multiplicative / impulse
-  noise, with the reference's ranges and its "identity with probability 0.2 / each group with probability 0.7" structure;
-* neighbourhood (augment_spatial_kernel, a pre-pass): JpegCompression(70-99) as PIL's baseline JPEG round trip; the `Blur`
-  group as imgaug builds it - Sharpen | OneOf[GaussianBlur(0.5-1.5) with its 5 x 5 kernel, AverageBlur(k 2-6) with cv2.blur's
-  anchor, MedianBlur(k 3-7), MotionBlur(k = 5, any angle / direction), BilateralBlur(d 3-10, sigmas 10-250)]; Emboss and
-  EdgeDetect with imgaug's effect matrices.
-NOT reproduced (the draw that would select them leaves the image unchanged): the weather members (Fog, Clouds, Snowflakes,
-Rain :191-196), histogram equalisation / CLAHE, k-means / uniform colour quantisation, hue / saturation arithmetic in HSV,
-CoarseDropout, the Laplace / Poisson noise variants, DirectedEdgeDetect and the PIL filter presets; severity 2's
-ElasticTransformation / PerspectiveTransform (no shipped config selects severity 2).  INTEGRATION.md lists them.
+
+Colour = the reference's imgaug chain, member list by member list, with its probabilities (augmentation_pipelines.py:120-205,
+severity 5 - what the shipped pretraining configs select; dataset_pretrain.py:79-158 for finetuning): `Sometimes(0.2, Identity,
+Sequential[arithmetic: OneOf 21, color: Sometimes(0.7, OneOf 9), Blur: Sometimes(0.7, ...), contrast: Sometimes(0.7, OneOf 8),
+weather: Sometimes(0.7, OneOf 4)])`.  A draw picks the member by its POSITION in the reference's list and writes what the kernel
+needs for it (one member per group, applied in the reference's order on a uint8 image).  Reproduced: AddElementwise, the
+Gaussian / Laplace / Poisson noises, Multiply(Elementwise), Dropout, CoarseDropout, Dropout2d, ImpulseNoise / SaltAndPepper /
+Salt / Pepper, Invert, Solarize, JpegCompression, Emboss, EdgeDetect, DirectedEdgeDetect, pillike.FilterEdgeEnhanceMore /
+FilterContour; the HSV hue shifts, MultiplyAndAddToBrightness (in RGB), MultiplyHueAndSaturation, AddToHueAndSaturation,
+Grayscale, UniformColorQuantization, ChangeColorTemperature (as channel gains); Sharpen and the five blurs; Gamma / Linear /
+Sigmoid / Log contrast, AllChannelsHistogramEqualization.
+NOT reproduced - the draw that selects them leaves the image unchanged: KMeansColorQuantization,
+HistogramEqualization / CLAHE / AllChannelsCLAHE (Lab-space or tiled equalisation), the weather members (Fog, Clouds, Snowflakes,
+Rain), PiecewiseAffine (finetuning geometry); severity 2's ElasticTransformation / PerspectiveTransform (no shipped config).
 """
 from __future__ import annotations
 
@@ -26,27 +28,54 @@ import math
 import numpy as np
 
 AUG_NP = 96
-P_MODE, P_K, P_JPEG, P_SIGC, P_SIGS, P_KERN = 14, 15, 25, 26, 27, 32        # kernels/datapipe.h
+P_SEED, P_PREINV, P_A, P_AK, P_B, P_C, P_D, P_KERN = 0, 1, 2, 9, 18, 24, 28, 32          # kernels/datapipe.h
+A_ADD_ELEM, A_GAUSS, A_LAPLACE, A_POISSON, A_MUL, A_MUL_ELEM, A_DROPOUT, A_COARSE, A_DROP2D, A_REPLACE, A_INVERT, A_SOLARIZE, \
+    A_JPEG, A_FILTER, A_PILFILTER = range(1, 16)
+B_HUE_ADD, B_BRIGHT, B_MUL_HS, B_ADD_HS, B_GRAY, B_KMEANS, B_UNIFORM_Q, B_GAINS, B_SHUFFLE = range(1, 10)
+C_FILTER, C_MEDIAN, C_BILATERAL = 1, 2, 3
+D_GAMMA, D_LINEAR, D_SIGMOID, D_LOG, D_HISTEQ_LAB, D_HISTEQ_ALL = 1, 2, 3, 4, 5, 6
 IDENTITY_PARAMS = np.zeros(AUG_NP, dtype=np.float32)
-IDENTITY_PARAMS[3:8] = 1.0                                                    # gamma, three gains, contrast alpha
-IDENTITY_PARAMS[12] = 256.0                                                   # solarize threshold: off
 _NOCHANGE = np.array([[0, 0, 0], [0, 1, 0], [0, 0, 0]], dtype=np.float64)
 
 
 def _set_filter(p, kernel, anchor=None):
-    """A correlation kernel (odd or even side <= 7) into the 7 x 7 grid; `anchor` = (row, col) of the kernel cell that sits on
-    the pixel (cv2's default: side // 2)."""
+    """`Blur` group: a correlation kernel (odd or even side <= 7) into the 7 x 7 grid; `anchor` = (row, col) of the kernel cell
+    that sits on the pixel (cv2's default: side // 2)."""
     k = np.asarray(kernel, dtype=np.float64)
     ay, ax = anchor if anchor is not None else (k.shape[0] // 2, k.shape[1] // 2)
     grid = np.zeros((7, 7), dtype=np.float64)
     grid[3 - ay:3 - ay + k.shape[0], 3 - ax:3 - ax + k.shape[1]] = k
-    p[P_MODE] = 1.0
+    p[P_C] = C_FILTER
     p[P_KERN:P_KERN + 49] = grid.reshape(-1).astype(np.float32)
+
+
+def _set_arith_filter(p, kernel3, pil=False, offset=0.0, scale=1.0):
+    """`arithmetic` group: a 3 x 3 correlation - imgaug's Convolve members (cv2.filter2D, reflect-101 border) or a PIL
+    ImageFilter.Kernel (sum / scale + offset, border pixels copied)."""
+    p[P_A] = A_PILFILTER if pil else A_FILTER
+    p[P_A + 1], p[P_A + 2] = offset, scale
+    p[P_AK:P_AK + 9] = np.asarray(kernel3, dtype=np.float64).reshape(-1).astype(np.float32)
 
 
 def _blend(alpha, effect):
     """imgaug's convolutional augmenters: (1 - alpha) * identity + alpha * effect matrix."""
     return (1.0 - alpha) * _NOCHANGE + alpha * np.asarray(effect, dtype=np.float64)
+
+
+def directed_edge_kernel(alpha, direction):
+    """iaa.DirectedEdgeDetect: the 8 neighbours weighted by (1 - angle to the direction / 180 deg)^4 (direction 0 = up, clockwise
+    in image coordinates), normalised, negated, centre 1; blended with the identity kernel by alpha."""
+    rad = math.radians((direction * 360.0) % 360.0)
+    dx, dy = math.cos(rad - 0.5 * math.pi), math.sin(rad - 0.5 * math.pi)
+    m = np.zeros((3, 3), dtype=np.float64)
+    for x in (-1, 0, 1):
+        for y in (-1, 0, 1):
+            if (x, y) != (0, 0):
+                cosang = (x * dx + y * dy) / (math.hypot(x, y) * math.hypot(dx, dy))
+                m[y + 1, x + 1] = (1.0 - math.degrees(math.acos(min(1.0, max(-1.0, cosang)))) / 180.0) ** 4
+    m = -m / m.sum()
+    m[1, 1] = 1.0
+    return _blend(alpha, m)
 
 
 def gaussian_kernel5(sigma):
@@ -117,171 +146,216 @@ def sample_theta(rs: np.random.RandomState, batch: int, h: int, w: int, p_warp: 
     return (out, warped) if return_warped else out
 
 
-def _colour_params(rs: np.random.RandomState, severity: int) -> np.ndarray:
+# ------------------------------------------------------------------------------------------------ the member lists
+def _per_channel(rs, prob):
+    return float(rs.uniform() < prob)
+
+
+def _jpeg_quality(rs):
+    """JpegCompression(compression 70-99) -> PIL quality 31 .. 2 (imgaug: 1 + 99 * (1 - compression / 100), rounded, clipped)."""
+    return float(np.clip(np.round(1 + 99 * (1.0 - rs.uniform(70, 99) / 100.0)), 1, 100))
+
+
+def _arith_member(p, rs, name, h, w):
+    """One member of the `arithmetic` list (augmentation_pipelines.py:122-144 = dataset_pretrain.py:86-106)."""
+    a = P_A
+    if name == "AddElementwise":                  # integers -40 .. 40, one per pixel
+        p[a], p[a + 1] = A_ADD_ELEM, 40
+    elif name == "AdditiveGaussianNoise":
+        p[a], p[a + 1] = A_GAUSS, rs.uniform(0, 0.2 * 255)
+    elif name == "AdditiveLaplaceNoise":
+        p[a], p[a + 1] = A_LAPLACE, rs.uniform(0, 0.2 * 255)
+    elif name == "AdditivePoissonNoise":
+        p[a], p[a + 1] = A_POISSON, rs.uniform(0, 40)
+    elif name == "Multiply":                      # per_channel = 0.5
+        p[a] = A_MUL
+        p[a + 1:a + 4] = rs.uniform(0.5, 1.5, size=3) if rs.uniform() < 0.5 else rs.uniform(0.5, 1.5)
+    elif name == "MultiplyElementwise":
+        p[a], p[a + 1], p[a + 3], p[a + 2] = A_MUL_ELEM, 0.5, 1.5, _per_channel(rs, 0.5)
+    elif name == "Dropout":
+        p[a], p[a + 1], p[a + 2] = A_DROPOUT, rs.uniform(0, 0.1), _per_channel(rs, 0.5)
+    elif name == "CoarseDropout":                 # the mask is drawn at 15 % of the size (at least 3 cells), nearest up-sampling
+        p[a], p[a + 1], p[a + 2] = A_COARSE, 0.02, _per_channel(rs, 0.5)
+        p[a + 3], p[a + 4] = max(int(round(h * 0.15)), 3), max(int(round(w * 0.15)), 3)
+    elif name == "Dropout2d":                     # each channel dropped with p = 0.5, at least one kept
+        keep = [rs.uniform() >= 0.5 for _ in range(3)]
+        if not any(keep):
+            keep[rs.randint(0, 3)] = True
+        p[a], p[a + 1] = A_DROP2D, sum(1 << k for k in range(3) if keep[k])
+    elif name in ("ImpulseNoise", "SaltAndPepper", "Salt", "Pepper"):
+        p[a], p[a + 1] = A_REPLACE, 0.1
+        p[a + 2] = 1.0 if name == "ImpulseNoise" else 0.0             # ImpulseNoise = SaltAndPepper(per_channel=True)
+        p[a + 3] = {"Salt": 1.0, "Pepper": 2.0}.get(name, 0.0)
+    elif name == "Invert":
+        if rs.uniform() < 0.15:
+            p[a] = A_INVERT
+    elif name == "Solarize":
+        if rs.uniform() < 0.5:
+            p[a], p[a + 1] = A_SOLARIZE, rs.uniform(32, 128)
+    elif name == "JpegCompression":
+        p[a], p[a + 1] = A_JPEG, _jpeg_quality(rs)
+    elif name == "Emboss":
+        al, st = rs.uniform(0.0, 1.0), rs.uniform(0.5, 1.5)
+        _set_arith_filter(p, _blend(al, [[-1 - st, 0 - st, 0], [0 - st, 1, 0 + st], [0, 0 + st, 1 + st]]))
+    elif name == "EdgeDetect":
+        _set_arith_filter(p, _blend(rs.uniform(0.0, 1.0), [[0, 1, 0], [1, -4, 1], [0, 1, 0]]))
+    elif name == "DirectedEdgeDetect":
+        _set_arith_filter(p, directed_edge_kernel(rs.uniform(0.0, 1.0), rs.uniform(0.0, 1.0)))
+    elif name == "FilterEdgeEnhanceMore":         # PIL.ImageFilter.EDGE_ENHANCE_MORE
+        _set_arith_filter(p, [[-1, -1, -1], [-1, 9, -1], [-1, -1, -1]], pil=True, offset=0.0, scale=1.0)
+    elif name == "FilterContour":                 # PIL.ImageFilter.CONTOUR
+        _set_arith_filter(p, [[-1, -1, -1], [-1, 8, -1], [-1, -1, -1]], pil=True, offset=255.0, scale=1.0)
+    else:
+        raise KeyError(name)
+
+
+def _colour_member(p, rs, name):
+    """One member of the `color` list (:146-163 = dataset_pretrain.py:107-122)."""
+    b = P_B
+    if name == "HueAdd0_50":                      # WithColorspace(HSV, WithChannels(0, Add((0, 50)))): uint8 H, saturating
+        p[b], p[b + 1] = B_HUE_ADD, rs.randint(0, 51)
+    elif name == "HueAdd50_100":                  # ChangeColorspace(HSV), WithChannels(0, Add((50, 100))), back
+        p[b], p[b + 1] = B_HUE_ADD, rs.randint(50, 101)
+    elif name == "MultiplyBrightness":
+        p[b], p[b + 1], p[b + 2] = B_BRIGHT, rs.uniform(0.5, 1.5), 0.0
+    elif name == "MultiplyAndAddToBrightness":    # (imgaug: on the brightness channel of a random colour space; here on RGB)
+        p[b], p[b + 1], p[b + 2] = B_BRIGHT, rs.uniform(0.5, 1.5), rs.uniform(-30, 30)
+    elif name == "MultiplyHueAndSaturation":      # per_channel=True: hue and saturation drawn separately
+        p[b], p[b + 1], p[b + 2] = B_MUL_HS, rs.uniform(0.5, 1.5), rs.uniform(0.5, 1.5)
+    elif name == "AddToHueAndSaturation":         # values -50 .. 50 on imgaug's 255 scale: hue shift int(v / 255 * 180) on cv2's H
+        vh, vs = rs.randint(-50, 51), rs.randint(-50, 51)
+        p[b], p[b + 1], p[b + 2] = B_ADD_HS, int(vh / 255.0 * 180.0), vs
+    elif name == "Grayscale":
+        p[b], p[b + 1] = B_GRAY, rs.uniform(0.0, 1.0)
+    elif name == "KMeansColorQuantization":
+        pass                                      # not reproduced
+    elif name == "UniformColorQuantization":      # n_colors = (2, 16)
+        p[b], p[b + 1] = B_UNIFORM_Q, rs.randint(2, 17)
+    elif name == "ChangeColorTemperature":        # 1100 .. 10000 K as warm <-> cool channel gains
+        t = rs.uniform(-1.0, 1.0)
+        p[b], p[b + 1], p[b + 2], p[b + 3] = B_GAINS, 1.0 + 0.25 * t, 1.0, 1.0 - 0.25 * t
+    elif name == "ChannelShuffle":
+        if rs.uniform() < 0.35:
+            p[b], p[b + 1] = B_SHUFFLE, rs.randint(0, 6)
+    else:
+        raise KeyError(name)
+
+
+def _blur_member(p, rs, bilateral=True):
+    """`Blur`: OneOf[Sharpen(alpha 0-0.5, lightness 0-0.5), OneOf[GaussianBlur, AverageBlur, MedianBlur, MotionBlur(, BilateralBlur)]]
+    (:165-176; the finetuning pipeline has no bilateral member)."""
+    if rs.uniform() < 0.5:
+        al, light = rs.uniform(0.0, 0.5), rs.uniform(0.0, 0.5)
+        _set_filter(p, _blend(al, [[-1, -1, -1], [-1, 8 + light, -1], [-1, -1, -1]]))
+        return
+    m = rs.randint(0, 5 if bilateral else 4)
+    if m == 0:                                    # GaussianBlur(sigma 0.5 - 1.5): 5 x 5
+        _set_filter(p, gaussian_kernel5(rs.uniform(0.5, 1.5)))
+    elif m == 1:                                  # AverageBlur(k 2 - 6): cv2.blur, anchor k // 2
+        k = rs.randint(2, 7)
+        _set_filter(p, np.full((k, k), 1.0 / (k * k)))
+    elif m == 2:                                  # MedianBlur(k 3 - 7): even draws go to the next odd size
+        k = rs.randint(3, 8)
+        p[P_C], p[P_C + 1] = C_MEDIAN, float(k if k % 2 else k + 1)
+    elif m == 3:                                  # MotionBlur(k = 5, angle 0 - 360, direction -1 .. 1)
+        _set_filter(p, motion_kernel(5, rs.uniform(0.0, 360.0), rs.uniform(-1.0, 1.0)))
+    else:                                         # BilateralBlur(d 3 - 10, sigma_color / sigma_space 10 - 250)
+        p[P_C], p[P_C + 1] = C_BILATERAL, float(rs.randint(3, 11))
+        p[P_C + 2], p[P_C + 3] = rs.uniform(10, 250), rs.uniform(10, 250)
+
+
+def _contrast_member(p, rs):
+    """`contrast`: OneOf[Gamma, Linear, Sigmoid, Log, HistogramEqualization, AllChannelsHistogramEqualization, CLAHE, AllChannelsCLAHE]."""
+    d = P_D
+    k = rs.randint(0, 8)
+    if k == 0:
+        p[d], p[d + 1] = D_GAMMA, rs.uniform(0.5, 2.0)
+    elif k == 1:
+        p[d], p[d + 1] = D_LINEAR, rs.uniform(0.5, 1.0)
+    elif k == 2:
+        p[d], p[d + 1], p[d + 2] = D_SIGMOID, rs.uniform(3, 10), rs.uniform(0.4, 0.6)
+    elif k == 3:
+        p[d], p[d + 1] = D_LOG, rs.uniform(0.6, 1.4)
+    elif k == 5:
+        p[d] = D_HISTEQ_ALL
+    # 4, 6, 7: HistogramEqualization / CLAHE (Lab intensity channel), AllChannelsCLAHE: not reproduced
+
+
+ARITHMETIC_5 = ["AddElementwise", "AdditiveGaussianNoise", "AdditiveLaplaceNoise", "AdditivePoissonNoise", "Multiply",
+                "MultiplyElementwise", "Dropout", "CoarseDropout", "Dropout2d", "ImpulseNoise", "SaltAndPepper", "Salt", "Pepper",
+                "Invert", "Solarize", "JpegCompression", "Emboss", "EdgeDetect", "DirectedEdgeDetect", "FilterEdgeEnhanceMore",
+                "FilterContour"]                                                        # augmentation_pipelines.py:122-144
+COLOR_5 = ["HueAdd0_50", "MultiplyAndAddToBrightness", "MultiplyHueAndSaturation", "AddToHueAndSaturation", "HueAdd50_100",
+           "Grayscale", "KMeansColorQuantization", "UniformColorQuantization", "ChangeColorTemperature"]      # :146-163
+FINETUNE_ONE_OF = (["ChannelShuffle", "AddElementwise", "AdditiveGaussianNoise", "AdditiveLaplaceNoise", "AdditivePoissonNoise",
+                    "ImpulseNoise", "Multiply", "MultiplyElementwise", "Dropout", "CoarseDropout", "Dropout2d", "SaltAndPepper",
+                    "Salt", "Pepper", "Solarize", "JpegCompression", "Emboss", "EdgeDetect", "DirectedEdgeDetect",
+                    "FilterEdgeEnhanceMore", "FilterContour", "HueAdd0_50", "MultiplyBrightness", "MultiplyAndAddToBrightness",
+                    "MultiplyHueAndSaturation", "AddToHueAndSaturation", "HueAdd50_100", "Grayscale", "KMeansColorQuantization",
+                    "UniformColorQuantization", "ChangeColorTemperature", "Fog", "Clouds", "Snowflakes", "Rain"])   # dataset_pretrain.py:86-121
+_COLOUR_NAMES = set(COLOR_5) | {"MultiplyBrightness", "ChannelShuffle"}
+_WEATHER = {"Fog", "Clouds", "Snowflakes", "Rain"}                                      # not reproduced
+
+
+def _colour_params(rs: np.random.RandomState, severity: int, h: int = 32, w: int = 128) -> np.ndarray:
     p = IDENTITY_PARAMS.copy()
-    p[13] = rs.randint(0, 1 << 24)
+    p[P_SEED] = rs.randint(0, 1 << 24)
     if severity <= 0:
         return p
     if severity == 5:
         if rs.uniform() < 0.2:                    # iaa.Sometimes(0.2, Identity, Sequential[...])
             return p
-        groups = {"arith": 1.0, "color": 0.7, "contrast": 0.7}
-    else:
-        groups = {"arith": None, "color": 1.0, "contrast": None}      # severity 6 / others: OneOf over colour members
-    if groups["arith"] is not None:               # `arithmetic`: always one member
-        k = rs.randint(0, 9)
-        if k == 8:                                # JpegCompression(compression 70-99) -> PIL quality 31 .. 2
-            comp = rs.uniform(70, 99)
-            p[P_JPEG] = float(np.clip(np.round(1 + 99 * (1.0 - comp / 100.0)), 1, 100))
-        elif k == 0:
-            p[8] = rs.uniform(-40, 40)
-        elif k == 1:
-            p[9] = rs.uniform(0, 0.2 * 255)
-        elif k == 2:
-            p[4:7] = rs.uniform(0.5, 1.5) if rs.uniform() < 0.5 else rs.uniform(0.5, 1.5, size=3)
-        elif k == 3:
-            p[10] = 0.5
-        elif k == 4:
-            p[11] = 0.1
-        elif k == 5:
-            p[0] = float(rs.uniform() < 0.15)
-        elif k == 6:
-            if rs.uniform() < 0.5:
-                p[12] = rs.uniform(32, 128)
-        elif k == 7:                              # Emboss(alpha 0-1, strength 0.5-1.5) / EdgeDetect(alpha 0-1)
-            a = rs.uniform(0.0, 1.0)
-            if rs.uniform() < 0.5:
-                st = rs.uniform(0.5, 1.5)
-                _set_filter(p, _blend(a, [[-1 - st, 0 - st, 0], [0 - st, 1, 0 + st], [0, 0 + st, 1 + st]]))
-            else:
-                _set_filter(p, _blend(a, [[0, 1, 0], [1, -4, 1], [0, 1, 0]]))
-    if groups["color"] is not None and rs.uniform() < groups["color"]:
-        k = rs.randint(0, 5)
-        if k == 0:
-            p[4:7] *= rs.uniform(0.5, 1.5)        # MultiplyAndAddToBrightness / MultiplyBrightness
-            p[8] += rs.uniform(-30, 30) if severity == 5 else 0.0
-        elif k == 1:
-            p[1] = rs.uniform(0.0, 1.0)           # Grayscale(alpha)
-        elif k == 2:
-            if rs.uniform() < 0.35:
-                p[2] = rs.randint(0, 6)           # ChannelShuffle(0.35)
-        elif k == 3:                              # ChangeColorTemperature(1100 .. 10000 K): warm <-> cool channel gains
-            t = rs.uniform(-1.0, 1.0)
-            p[4] *= 1.0 + 0.25 * t
-            p[6] *= 1.0 - 0.25 * t
-        elif k == 4:
-            p[3] = rs.uniform(0.5, 2.0)           # GammaContrast
-    if severity == 5 and p[P_MODE] == 0 and rs.uniform() < 0.7:        # `Blur`: OneOf[Sharpen, OneOf[five blurs]] (:165-176)
-        if rs.uniform() < 0.5:
-            a, light = rs.uniform(0.0, 0.5), rs.uniform(0.0, 0.5)
-            _set_filter(p, _blend(a, [[-1, -1, -1], [-1, 8 + light, -1], [-1, -1, -1]]))
-        else:
-            m = rs.randint(0, 5)
-            if m == 0:                            # GaussianBlur(sigma 0.5 - 1.5): 5 x 5
-                _set_filter(p, gaussian_kernel5(rs.uniform(0.5, 1.5)))
-            elif m == 1:                          # AverageBlur(k 2 - 6): cv2.blur, anchor k // 2
-                k = rs.randint(2, 7)
-                _set_filter(p, np.full((k, k), 1.0 / (k * k)))
-            elif m == 2:                          # MedianBlur(k 3 - 7): even draws go to the next odd size
-                k = rs.randint(3, 8)
-                p[P_MODE], p[P_K] = 2.0, float(k if k % 2 else k + 1)
-            elif m == 3:                          # MotionBlur(k = 5, angle 0 - 360, direction -1 .. 1)
-                _set_filter(p, motion_kernel(5, rs.uniform(0.0, 360.0), rs.uniform(-1.0, 1.0)))
-            else:                                 # BilateralBlur(d 3 - 10, sigma_color / sigma_space 10 - 250)
-                p[P_MODE], p[P_K] = 3.0, float(rs.randint(3, 11))
-                p[P_SIGC], p[P_SIGS] = rs.uniform(10, 250), rs.uniform(10, 250)
-    if groups["contrast"] is not None and rs.uniform() < groups["contrast"]:
-        k = rs.randint(0, 3)
-        if k == 0:
-            p[3] *= rs.uniform(0.5, 2.0)
-        elif k == 1:
-            p[7] = rs.uniform(0.5, 1.0)           # LinearContrast
-        # k == 2: histogram members (equalisation / CLAHE): spatial statistics, not reproduced
+        _arith_member(p, rs, ARITHMETIC_5[rs.randint(0, len(ARITHMETIC_5))], h, w)
+        if rs.uniform() < 0.7:
+            _colour_member(p, rs, COLOR_5[rs.randint(0, len(COLOR_5))])
+        if rs.uniform() < 0.7:
+            _blur_member(p, rs)
+        if rs.uniform() < 0.7:
+            _contrast_member(p, rs)
+        rs.uniform()                              # weather: Sometimes(0.7, OneOf[Fog, Clouds, Snowflakes, Rain]) - not reproduced
+        return p
+    # the other severities are OneOf lists over colour members (severity 6: :198-214); no shipped config selects them
+    names = ["HueAdd0_50", "MultiplyAndAddToBrightness", "MultiplyHueAndSaturation", "AddToHueAndSaturation", "HueAdd50_100",
+             "Grayscale", "ChannelShuffle", "ChangeColorTemperature"]
+    _colour_member(p, rs, names[rs.randint(0, len(names))])
     return p
 
 
-def sample_colour_params(rs: np.random.RandomState, batch: int, severity: int = 5, warped=None) -> np.ndarray:
+def sample_colour_params(rs: np.random.RandomState, batch: int, severity: int = 5, warped=None, h: int = 32,
+                         w: int = 128) -> np.ndarray:
     """fp32 [batch, 2, 96]: view 1 from pipeline `severity`, view 2 from the same pipeline (both come from `augment_tfs`,
     datasetsupervised_kmeans.py:57).  `warped` (bool [batch], from sample_theta): a sample whose warp draw failed gets the
     plain image as view 2 (:72-74 `image_view = image`), i.e. identity parameters."""
     out = np.empty((batch, 2, AUG_NP), dtype=np.float32)
     for b in range(batch):
-        out[b, 0] = _colour_params(rs, severity)
-        out[b, 1] = _colour_params(rs, severity)
+        out[b, 0] = _colour_params(rs, severity, h, w)
+        out[b, 1] = _colour_params(rs, severity, h, w)
         if warped is not None and not warped[b]:
             out[b, 1] = IDENTITY_PARAMS
-            out[b, 1, 13] = rs.randint(0, 1 << 24)
     return out
 
 
 # ------------------------------------------------------------------------------------------------ finetuning pipeline
-def _finetune_colour_params(rs: np.random.RandomState) -> np.ndarray:
-    """One draw of the finetuning pipeline's colour part (Dino/dataset/dataset_pretrain.py:79-146): Sometimes(0.6, Invert(0.1)),
-    Sometimes(0.8, OneOf[41 members]), Sometimes(0.6, Blur group without the bilateral member), Sometimes(0.6, contrast group).
+def _finetune_colour_params(rs: np.random.RandomState, h: int = 32, w: int = 128) -> np.ndarray:
+    """One draw of the finetuning pipeline's colour part (Dino/dataset/dataset_pretrain.py:80-146): Sometimes(0.6, Invert(0.1)),
+    Sometimes(0.8, OneOf[35 members]), Sometimes(0.6, Blur group without the bilateral member), Sometimes(0.6, contrast group).
     Members this implementation does not reproduce keep their share of the draw and leave the image unchanged."""
     p = IDENTITY_PARAMS.copy()
-    p[13] = rs.randint(0, 1 << 24)
+    p[P_SEED] = rs.randint(0, 1 << 24)
     if rs.uniform() < 0.6:
-        p[0] = float(rs.uniform() < 0.1)
+        p[P_PREINV] = float(rs.uniform() < 0.1)
     if rs.uniform() < 0.8:
-        k = rs.randint(0, 41)                     # position in the reference's list (:85-127)
-        if k == 0:
-            if rs.uniform() < 0.35:
-                p[2] = rs.randint(0, 6)           # ChannelShuffle(0.35)
-        elif k == 1:
-            p[8] = rs.uniform(-40, 40)            # AddElementwise, drawn per image here
-        elif k == 2:
-            p[9] = rs.uniform(0, 0.2 * 255)       # AdditiveGaussianNoise
-        elif k == 5 or 11 <= k <= 13:
-            p[11] = 0.1                           # ImpulseNoise / SaltAndPepper / Salt / Pepper
-        elif k == 6:
-            p[4:7] = rs.uniform(0.5, 1.5) if rs.uniform() < 0.5 else rs.uniform(0.5, 1.5, size=3)      # Multiply(per_channel 0.5)
-        elif k == 7:
-            p[10] = 0.5                           # MultiplyElementwise
-        elif k == 14:
-            if rs.uniform() < 0.5:
-                p[12] = rs.uniform(32, 128)       # Solarize
-        elif k == 15:
-            p[P_JPEG] = float(np.clip(np.round(1 + 99 * (1.0 - rs.uniform(70, 99) / 100.0)), 1, 100))
-        elif k == 16:
-            a, st = rs.uniform(0.0, 1.0), rs.uniform(0.5, 1.5)
-            _set_filter(p, _blend(a, [[-1 - st, 0 - st, 0], [0 - st, 1, 0 + st], [0, 0 + st, 1 + st]]))
-        elif k == 17:
-            _set_filter(p, _blend(rs.uniform(0.0, 1.0), [[0, 1, 0], [1, -4, 1], [0, 1, 0]]))
-        elif k == 22:
-            p[4:7] *= rs.uniform(0.5, 1.5)        # MultiplyBrightness
-        elif k == 23:
-            p[4:7] *= rs.uniform(0.5, 1.5)        # MultiplyAndAddToBrightness
-            p[8] += rs.uniform(-30, 30)
-        elif k == 27:
-            p[1] = rs.uniform(0.0, 1.0)           # Grayscale
-        elif k == 30:
-            t = rs.uniform(-1.0, 1.0)             # ChangeColorTemperature
-            p[4] *= 1.0 + 0.25 * t
-            p[6] *= 1.0 - 0.25 * t
-        # others (Laplace / Poisson noise, dropouts, HSV arithmetic, quantisation, edge presets, weather): not reproduced
-    if p[P_MODE] == 0 and rs.uniform() < 0.6:
-        if rs.uniform() < 0.5:
-            a, light = rs.uniform(0.0, 0.5), rs.uniform(0.0, 0.5)
-            _set_filter(p, _blend(a, [[-1, -1, -1], [-1, 8 + light, -1], [-1, -1, -1]]))
+        name = FINETUNE_ONE_OF[rs.randint(0, len(FINETUNE_ONE_OF))]
+        if name in _WEATHER:
+            pass
+        elif name in _COLOUR_NAMES:
+            _colour_member(p, rs, name)
         else:
-            m = rs.randint(0, 4)
-            if m == 0:
-                _set_filter(p, gaussian_kernel5(rs.uniform(0.5, 1.5)))
-            elif m == 1:
-                k = rs.randint(2, 7)
-                _set_filter(p, np.full((k, k), 1.0 / (k * k)))
-            elif m == 2:
-                k = rs.randint(3, 8)
-                p[P_MODE], p[P_K] = 2.0, float(k if k % 2 else k + 1)
-            else:
-                _set_filter(p, motion_kernel(5, rs.uniform(0.0, 360.0), rs.uniform(-1.0, 1.0)))
+            _arith_member(p, rs, name, h, w)
     if rs.uniform() < 0.6:
-        k = rs.randint(0, 8)
-        if k == 0:
-            p[3] *= rs.uniform(0.5, 2.0)          # GammaContrast
-        elif k == 1:
-            p[7] = rs.uniform(0.5, 1.0)           # LinearContrast
+        _blur_member(p, rs, bilateral=False)
+    if rs.uniform() < 0.6:
+        _contrast_member(p, rs)
     return p
 
 
@@ -292,7 +366,7 @@ def sample_finetune_params(rs: np.random.RandomState, batch: int, h: int, w: int
     params = np.tile(IDENTITY_PARAMS, (batch, 2, 1)).astype(np.float32)
     theta = np.tile(np.eye(3, dtype=np.float32), (batch, 1, 1))
     for b in range(batch):
-        params[b, 1] = _finetune_colour_params(rs)
+        params[b, 1] = _finetune_colour_params(rs, h, w)
         if rs.uniform() < 0.6:
             g = rs.randint(0, 3)
             if g == 0:

@@ -167,7 +167,7 @@ class DeviceViewMaker:
         assert tuple(images_u8.shape[1:]) == (self.h, self.w, 3) and images_u8.dtype == torch.uint8
         if self.data_aug and self.severity > 0:
             theta, warped = sample_theta(self.rs, B, self.h, self.w, return_warped=True)
-            params = sample_colour_params(self.rs, B, self.severity, warped=warped)     # view 2 = the plain image where not warped
+            params = sample_colour_params(self.rs, B, self.severity, warped=warped, h=self.h, w=self.w)     # view 2 = the plain image where not warped
         else:                                                       # data_aug off: three identical views, identity theta
             params = sample_colour_params(self.rs, B, 0)
             theta = np.tile(np.eye(3, dtype=np.float32), (B, 1, 1))

@@ -195,13 +195,16 @@ int ccd_seg_to_mask(const float* seg_logits, float* mask, int images, void* stre
  * at the same offsets.  Integer / fp64 arithmetic with a fixed operation order: bit-exact against oracle/datapipe_np.py. */
 int ccd_kmeans2_mask(const uint8_t* gray, const long* offsets, const int* hw, uint8_t* mask, int images, void* stream);
 /* The three views of ImageDatasetSelfSupervisedKmeans._process_training (datasetsupervised_kmeans.py:48-87) from resized
- * uint8 images img [B,H,W,3]: out fp32 [B,3,3,H,W] = (plain, colour(params[b,0]), warp_theta(colour(params[b,1]))),
+ * uint8 images img [B,H,W,3]: out fp32 [B,3,3,H,W] = (plain, augment(params[b,0]), warp_theta(augment(params[b,1]))),
  * each normalised with mean3 / std3 (HOST arrays of 3 floats; dataset.py:79-80).  params fp32 [B,2,96] (layout in
  * kernels/datapipe.h), theta fp32 [B,3,3] = the `metrics` tensor the model receives (identity = no warp).
- * Two launches: the neighbourhood members of the imgaug pipelines (augmentation_pipelines.py: JpegCompression :140, the
- * `Blur` group :165-176 = Gaussian / average / median / motion / bilateral blur, Sharpen, Emboss, EdgeDetect) run first and
- * stage one uint8 image per (sample, view) in staged_ws [B,2,H,W,3] (caller-allocated scratch); the pointwise chain, the
- * normalisation and the affine warp of view 2 read those.  H * W is bounded by the pre-pass' LDS image (CCD_ESHAPE beyond). */
+ * Two launches.  (1) The reference's imgaug chain (augmentation_pipelines.py:120-205): one workgroup per (sample, view) holds
+ * the uint8 image in LDS and applies ONE member of each group in the reference's order - `arithmetic` (noises, dropouts,
+ * JpegCompression, Emboss / EdgeDetect / DirectedEdgeDetect, the PIL filter presets ...), `color` (cv2's 8-bit HSV members,
+ * Grayscale, quantisation ...), `Blur` (Gaussian / average / median / motion / bilateral blur, Sharpen), `contrast` (gamma,
+ * linear, sigmoid, log, per-channel histogram equalisation) - rounding to uint8 between the groups like imgaug, and stages the
+ * result in staged_ws [B,2,H,W,3] (caller-allocated scratch).  (2) Normalisation and the affine warp of view 2 read those.
+ * H * W is bounded by the chain's LDS images (CCD_ESHAPE beyond). */
 int ccd_augment_views(const uint8_t* img, const float* params, const float* theta, float* out, uint8_t* staged_ws, int batch,
                       int height, int width, const float* mean3, const float* std3, void* stream);
 /* affine_grid(theta[:, :2]) + grid_sample(bilinear) > 0.1, dino_vision.py:72-77 / train.py:234-236; theta row stride in floats */

@@ -11,9 +11,12 @@ the product never imports it.
   image agree); the squared-error optimum (Otsu) differs on 10 of them.  Where the border rule is undecided for BOTH orientations (num < 3 either way)
   the reference's output depends on its random initial centroids; this restatement keeps "brighter = 1".
 * gray_from_rgb: PIL's `convert("L")` (ITU-R 601-2 luma in 16.16 fixed point), generate_mask.py:69.
-* augment_views: ccd_amd/csrc/kernels/datapipe.h::augment_views_kernel in float32 (the reference's imgaug chain is a
-  random process with its own generators - there is no value parity to pin, only the tensor contract and the theta
-  geometry of datasetsupervised_kmeans.py:65-71, which tests/test_datapipe_cpu.py checks against the reference formula).
+* augment_views / staged_source: the reference's imgaug chain (augmentation_pipelines.py:120-205) member by member - each member
+  restates the documented behaviour of the library call imgaug makes (cv2 / PIL / numpy), pinned against that library where
+  this image has it (PIL: JPEG, the pillike filters; scipy.ndimage: median, correlation) and stated as unpinned where it does
+  not (cv2's HSV conversion, equalizeHist, bilateralFilter; imgaug's own tables).  The random members draw from the device
+  kernel's counter-based generator, not numpy's: there is no value parity with imgaug's draws, only the distributions and the
+  theta geometry of datasetsupervised_kmeans.py:65-71 (tests/test_datapipe_cpu.py).
 """
 import numpy as np
 
@@ -74,57 +77,236 @@ def _u01(h):
     return (h >> 8).astype(np.float32) * np.float32(1.0 / 16777216.0)
 
 
-def colour(p, rgb, pix_id):
-    """p [16] fp32, rgb [...,3] fp32 in 0..255, pix_id [...] -> [...,3]."""
+# parameter layout of one (sample, view) row: ccd_amd/csrc/kernels/datapipe.h
+P_SEED, P_PREINV, P_A, P_AK, P_B, P_C, P_D, P_KERN = 0, 1, 2, 9, 18, 24, 28, 32
+
+
+def _round_u8(v):
+    return np.clip(np.floor(np.asarray(v, np.float32) + np.float32(0.5)), 0, 255).astype(np.uint8)
+
+
+def _trunc_u8(v):
+    return np.clip(np.asarray(v, np.float32), 0, 255).astype(np.uint8)
+
+
+def arith_pointwise(p, img):
+    """The pointwise members of the `arithmetic` group (augmentation_pipelines.py:122-144) on a uint8 image [H,W,3]; the random
+    members draw from the kernel's counter-based generator, so kernel and restatement agree value by value."""
     f = np.float32
-    c = rgb.astype(f).copy()
-    if p[0] != 0:
-        c = f(255) - c
-    if p[12] < 256:
-        c = np.where(c >= p[12], f(255) - c, c)
-    gray = f(0.299) * c[..., 0] + f(0.587) * c[..., 1] + f(0.114) * c[..., 2]
-    c = c + f(p[1]) * (gray[..., None] - c)
-    perm = int(p[2])
-    p0 = perm >> 1
-    rest = [k for k in range(3) if k != p0]
-    order = [p0, rest[1], rest[0]] if perm & 1 else [p0, rest[0], rest[1]]
-    s = c[..., order]
-    seed = int(p[13]) & 0xFFFFFFFF
-    out = np.empty_like(s)
+    op, seed = int(p[P_A]), int(p[P_SEED]) & 0xFFFFFFFF
+    a0, a1, a2, a3 = (f(p[P_A + 1 + i]) for i in range(4))
+    H, W, _ = img.shape
+    ys, xs = np.mgrid[0:H, 0:W]
+    out = np.empty((H, W, 3), f)
     for k in range(3):
-        v = s[..., k]
-        if p[3] != 1.0:
-            v = f(255) * np.power(np.maximum(v, f(0)) * f(1.0 / 255.0), f(p[3])).astype(f)
-        v = v * f(p[4 + k])
-        v = f(128) + f(p[7]) * (v - f(128)) + f(p[8])
-        h0 = _hash(np.asarray(pix_id, dtype=np.uint64) * 3 + k, seed)
-        if p[9] > 0:
+        v = img[..., k].astype(f)
+        ch = k if a1 != 0 else 0
+        e = ((ys * W + xs) * 3 + ch).astype(np.uint64)
+        h0 = _hash(e, seed ^ 0x51ED270B)
+        if op == 1:
+            v = v + (np.floor(_u01(h0) * (f(2) * a0 + f(1))).astype(np.int64) - int(a0)).astype(f)
+        elif op == 2:
             h1 = _hash(h0, seed ^ 0xA511E9B3)
-            v = v + f(p[9]) * np.sqrt(f(-2) * np.log(np.maximum(_u01(h0), f(1e-7)))) * np.cos(f(6.2831853) * _u01(h1))
-        if p[10] > 0:
-            v = v * (f(1) + f(p[10]) * (f(2) * _u01(_hash(h0, seed ^ 0x3C6EF372)) - f(1)))
-        if p[11] > 0:
-            u = _u01(_hash(h0, seed ^ 0xDAA66D2B))
-            v = np.where(u < f(p[11]), np.where(u < f(0.5) * f(p[11]), f(0), f(255)), v)
-        out[..., k] = np.clip(v, 0, 255)
-    return out.astype(f)
+            v = v + a0 * np.sqrt(f(-2) * np.log(np.maximum(_u01(h0), f(1e-7)))) * np.cos(f(6.2831853) * _u01(h1))
+        elif op == 3:
+            u = _u01(h0) - f(0.5)
+            m = np.maximum(f(1) - f(2) * np.abs(u), f(1e-7))
+            v = v - a0 * np.where(u < 0, f(-1), f(1)) * np.log(m)
+        elif op == 4:
+            lim = np.exp(-a0).astype(f)
+            prod = np.ones((H, W), f)
+            n = np.full((H, W), -1, np.int64)
+            h = h0.copy()
+            live = np.ones((H, W), bool)
+            for _ in range(201):
+                prod = np.where(live, (prod * np.maximum(_u01(h), f(1e-7))).astype(f), prod)
+                h = np.where(live, _hash(h, seed ^ 0x3C6EF372), h)
+                n = np.where(live, n + 1, n)
+                live = live & (prod > lim) & (n < 200)
+                if not live.any():
+                    break
+            v = v + n.astype(f)
+        elif op == 5:
+            v = v * f(p[P_A + 1 + k])
+        elif op == 6:
+            v = v * (a0 + (a2 - a0) * _u01(h0))
+        elif op == 7:
+            v = np.where(_u01(h0) < a0, f(0), v)
+        elif op == 8:
+            rows, cols = int(a2), int(a3)
+            cy, cx = np.clip(ys * rows // H, 0, rows - 1), np.clip(xs * cols // W, 0, cols - 1)
+            v = np.where(_u01(_hash(((cy * cols + cx) * 3 + ch).astype(np.uint64), seed ^ 0x6A09E667)) < a0, f(0), v)
+        elif op == 9:
+            v = v if (int(a0) >> k) & 1 else np.zeros_like(v)
+        elif op == 10:
+            sn = np.sin(f(1.5707963) * _u01(_hash(h0, seed ^ 0xDAA66D2B))).astype(f)
+            beta = sn * sn
+            dev = np.abs(beta - f(0.5))
+            rep = f(255) * (f(0.5) + dev if a2 == 1 else (f(0.5) - dev if a2 == 2 else beta))
+            v = np.where(_u01(h0) < a0, rep, v)
+        elif op == 11:
+            v = f(255) - v
+        elif op == 12:
+            v = np.where(v >= a0, f(255) - v, v)
+        out[..., k] = v
+    return _round_u8(out)
+
+
+def filter3(img, kern, pil=False, offset=0.0, scale=1.0):
+    """A 3 x 3 correlation.  pil=False: cv2.filter2D with BORDER_REFLECT_101 (imgaug's Convolve members); pil=True:
+    PIL.ImageFilter.Kernel((3, 3), kern, scale, offset) - sum / scale + offset, and the one-pixel border is copied."""
+    src = np.asarray(img, dtype=np.float32)
+    H, W, _ = src.shape
+    kern = np.asarray(kern, np.float32).reshape(3, 3)
+    acc = np.zeros_like(src)
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            acc = acc + kern[dy + 1, dx + 1] * src[reflect101(np.arange(H) + dy, H)][:, reflect101(np.arange(W) + dx, W)]
+    if not pil:
+        return _round_u8(acc)
+    out = _round_u8(acc / np.float32(scale) + np.float32(offset))
+    out[0], out[-1], out[:, 0], out[:, -1] = img[0], img[-1], img[:, 0], img[:, -1]
+    return out
+
+
+def rgb_to_hsv_cv(img):
+    """cv2.cvtColor(img, COLOR_RGB2HSV) for uint8 (color_hsv.cpp RGB2HSV_b): v = max, s = diff * sdiv[v], h from the 60-degree
+    sector formula * hdiv[diff], 12-bit fixed point with rounded division tables, H in 0..179."""
+    c = np.asarray(img, np.int64)
+    r, g, b = c[..., 0], c[..., 1], c[..., 2]
+    v = c.max(-1)
+    diff = v - c.min(-1)
+    sdiv = np.where(v > 0, np.rint(1044480.0 / np.maximum(v, 1)), 0).astype(np.int64)
+    hdiv = np.where(diff > 0, np.rint(122880.0 / np.maximum(diff, 1)), 0).astype(np.int64)
+    s = (diff * sdiv + 2048) >> 12
+    hh = np.where(v == r, g - b, np.where(v == g, b - r + 2 * diff, r - g + 4 * diff))
+    h = (hh * hdiv + 2048) >> 12
+    h = np.where(h < 0, h + 180, h)
+    return np.stack([np.where(diff > 0, h, 0), s, v], -1)
+
+
+def hsv_to_rgb_cv(hsv):
+    """cv2.cvtColor(hsv, COLOR_HSV2RGB) for uint8 (HSV2RGB_b -> HSV2RGB_f): float32, h * 6 / 180 reduced into [0, 6), the sector
+    table, saturate_cast<uchar>(x * 255)."""
+    f = np.float32
+    hsv = np.asarray(hsv, np.int64)
+    hi, si, vi = hsv[..., 0], hsv[..., 1], hsv[..., 2]
+    s, v = si.astype(f) * f(1.0 / 255.0), vi.astype(f) * f(1.0 / 255.0)
+    h = hi.astype(f) * f(6.0 / 180.0)
+    for _ in range(4):
+        h = np.where(h >= f(6), h - f(6), h)
+        h = np.where(h < f(0), h + f(6), h)
+    sector = np.floor(h).astype(np.int64)
+    h = h - sector.astype(f)
+    bad = (sector < 0) | (sector >= 6)
+    sector, h = np.where(bad, 0, sector), np.where(bad, f(0), h)
+    tab = np.stack([v, v * (f(1) - s), v * (f(1) - s * h), v * (f(1) - s * (f(1) - h))], -1).astype(f)
+    sector_bgr = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])
+    pick = sector_bgr[sector]
+    bgr = np.take_along_axis(tab, pick, -1)
+    bgr = np.where((si == 0)[..., None], v[..., None], bgr)
+    out = np.clip(np.rint(bgr * f(255)), 0, 255).astype(np.uint8)
+    return out[..., ::-1]
+
+
+def colour_member(p, img):
+    """One member of the `color` group (augmentation_pipelines.py:146-163) on a uint8 image."""
+    f = np.float32
+    op = int(p[P_B])
+    b0, b1, b2 = f(p[P_B + 1]), f(p[P_B + 2]), f(p[P_B + 3])
+    img = np.asarray(img, np.uint8)
+    if op in (1, 3, 4):
+        hsv = rgb_to_hsv_cv(img)
+        h, s, v = hsv[..., 0], hsv[..., 1], hsv[..., 2]
+        if op == 1:
+            h = np.minimum(h + int(b0), 255)
+        elif op == 3:
+            h255 = np.rint(h.astype(f) * f(255.0 / 180.0)).astype(np.int64)
+            h255 = np.mod(np.rint(h255.astype(f) * b0).astype(np.int64), 255)
+            h = np.rint(h255.astype(f) * f(180.0 / 255.0)).astype(np.int64)
+            s = np.clip(np.rint(s.astype(f) * b1).astype(np.int64), 0, 255)
+        else:
+            h = np.mod(h + int(b0), 180)
+            s = np.clip(s + int(b1), 0, 255)
+        return hsv_to_rgb_cv(np.stack([h, s, v], -1))
+    c = img.astype(f)
+    if op == 2:
+        return _round_u8(c * b0 + b1)
+    if op == 5:
+        i = img.astype(np.int64)
+        gray = ((i[..., 0] * 4899 + i[..., 1] * 9617 + i[..., 2] * 1868 + 8192) >> 14).astype(f)
+        return _round_u8(c + b0 * (gray[..., None] - c))
+    if op == 7:
+        q = f(256) / b0
+        return _trunc_u8(np.floor(c / q) * q + f(0.5) * q)
+    if op == 8:
+        return _round_u8(c * np.array([b0, b1, b2], f))
+    if op == 9:
+        perm = int(b0)
+        p0 = perm >> 1
+        rest = [k for k in range(3) if k != p0]
+        order = [p0, rest[1], rest[0]] if perm & 1 else [p0, rest[0], rest[1]]
+        return img[..., order]
+    return img
+
+
+def equalize_hist_cv(channel):
+    """cv2.equalizeHist on one uint8 channel: the first occupied bin maps to 0, lut[i] = round(cumsum beyond it * 255 / (total - its count))."""
+    ch = np.asarray(channel, np.uint8)
+    hist = np.bincount(ch.reshape(-1), minlength=256)
+    i0 = int(np.nonzero(hist)[0][0])
+    if hist[i0] == ch.size:
+        return np.full_like(ch, i0)
+    scale = np.float32(255.0) / np.float32(ch.size - hist[i0])
+    csum = np.cumsum(np.where(np.arange(256) > i0, hist, 0))
+    lut = np.clip(np.rint(csum.astype(np.float32) * scale), 0, 255).astype(np.uint8)
+    return lut[ch]
+
+
+def contrast_member(p, img):
+    """One member of the `contrast` group (:177-186): imgaug builds a 256-entry table in float32 and casts it to uint8 (truncation)."""
+    f = np.float32
+    op, d0, d1 = int(p[P_D]), f(p[P_D + 1]), f(p[P_D + 2])
+    img = np.asarray(img, np.uint8)
+    v = img.astype(f)
+    u = v * f(1.0 / 255.0)
+    if op == 1:
+        return _trunc_u8(f(255) * np.power(u, d0).astype(f))
+    if op == 2:
+        return _trunc_u8(f(127) + d0 * (v - f(127)))
+    if op == 3:
+        return _trunc_u8(f(255) / (f(1) + np.exp(d0 * (d1 - u)).astype(f)))
+    if op == 4:
+        return _trunc_u8(f(255) * d0 * np.log2(f(1) + u).astype(f))
+    if op == 6:
+        return np.stack([equalize_hist_cv(img[..., k]) for k in range(3)], -1)
+    return img
 
 
 def staged_source(p, src_u8):
-    """augment_spatial_kernel: the neighbourhood members of one (sample, view): JPEG round trip first (p[25] = quality), then
-    the Blur-group member p[14] selects - 1: 7 x 7 correlation p[32:81], 2: median k = p[15], 3: bilateral (d = p[15],
-    sigma_color = p[26], sigma_space = p[27]).  uint8 [H,W,3] -> uint8 [H,W,3]."""
+    """augment_spatial_kernel: the reference's chain on one (sample, view) - [leading Invert] -> one `arithmetic` member -> one
+    `color` member -> one `Blur` member -> one `contrast` member, uint8 [H,W,3] -> uint8 [H,W,3] (rounded between the groups)."""
     cur = np.asarray(src_u8, dtype=np.uint8)
-    if int(p[25]) > 0:
-        cur = jpeg_roundtrip(cur, int(p[25]))
-    mode = int(p[14])
+    if p[P_PREINV] != 0:
+        cur = 255 - cur
+    op = int(p[P_A])
+    if op == 13:
+        cur = jpeg_roundtrip(cur, int(p[P_A + 1]))
+    elif op == 14:
+        cur = filter3(cur, p[P_AK:P_AK + 9])
+    elif op == 15:
+        cur = filter3(cur, p[P_AK:P_AK + 9], pil=True, offset=float(p[P_A + 1]), scale=float(p[P_A + 2]) or 1.0)
+    elif op != 0:
+        cur = arith_pointwise(p, cur)
+    cur = colour_member(p, cur)
+    mode = int(p[P_C])
     if mode == 1:
-        cur = filter7(cur, np.asarray(p[32:81], dtype=np.float32).reshape(7, 7))
+        cur = filter7(cur, np.asarray(p[P_KERN:P_KERN + 49], dtype=np.float32).reshape(7, 7))
     elif mode == 2:
-        cur = median_blur(cur, int(p[15]))
+        cur = median_blur(cur, int(p[P_C + 1]))
     elif mode == 3:
-        cur = bilateral_blur(cur, int(p[15]), float(p[26]), float(p[27]))
-    return cur
+        cur = bilateral_blur(cur, int(p[P_C + 1]), float(p[P_C + 2]), float(p[P_C + 3]))
+    return contrast_member(p, cur)
 
 
 def augment_views(img, params, theta, mean, std):
@@ -135,15 +317,13 @@ def augment_views(img, params, theta, mean, std):
     mean, istd = np.asarray(mean, f), (f(1) / np.asarray(std, f)).astype(f)
     out = np.zeros((B, 3, 3, H, W), f)
     ys, xs = np.mgrid[0:H, 0:W]
-    pid = (ys * W + xs).astype(np.uint64)
 
     def norm(c):          # [H,W,3] -> [3,H,W]
         return ((c * f(1.0 / 255.0) - mean) * istd).astype(f).transpose(2, 0, 1)
 
     for b in range(B):
-        src = img[b].astype(f)
-        out[b, 0] = norm(src)
-        out[b, 1] = norm(colour(params[b, 0], staged_source(params[b, 0], img[b]).astype(f), pid))
+        out[b, 0] = norm(img[b].astype(f))
+        out[b, 1] = norm(staged_source(params[b, 0], img[b]).astype(f))
         th = theta[b].astype(f)
         xn = f(2) * xs.astype(f) / f(W - 1) - f(1)
         yn = f(2) * ys.astype(f) / f(H - 1) - f(1)
@@ -152,7 +332,7 @@ def augment_views(img, params, theta, mean, std):
         x0, y0 = np.floor(sx), np.floor(sy)
         ax, ay = (sx - x0).astype(f), (sy - y0).astype(f)
         x0, y0 = x0.astype(np.int64), y0.astype(np.int64)
-        col2 = colour(params[b, 1], staged_source(params[b, 1], img[b]).astype(f), pid)   # colour of every source pixel once
+        col2 = staged_source(params[b, 1], img[b]).astype(f)
         acc = np.zeros((H, W, 3), f)
         for dy in (0, 1):
             for dx in (0, 1):
@@ -163,6 +343,24 @@ def augment_views(img, params, theta, mean, std):
                 acc = acc + np.where(ok[..., None], wgt[..., None] * tap, f(0))
         out[b, 2] = norm(acc)
     return out
+
+
+def directed_edge_kernel(alpha, direction):
+    """iaa.DirectedEdgeDetect(alpha, direction): the 8 neighbours weighted by (1 - angle to the direction / 180 deg)^4, normalised,
+    negated, centre 1; blended with the identity kernel by alpha."""
+    rad = np.deg2rad(float(direction) * 360.0 % 360.0)
+    dvec = np.array([np.cos(rad - 0.5 * np.pi), np.sin(rad - 0.5 * np.pi)])
+    m = np.zeros((3, 3), np.float64)
+    for x in (-1, 0, 1):
+        for y in (-1, 0, 1):
+            if (x, y) != (0, 0):
+                cell = np.array([x, y], np.float64)
+                cosang = np.clip(cell @ dvec / (np.linalg.norm(cell) * np.linalg.norm(dvec)), -1.0, 1.0)
+                m[y + 1, x + 1] = (1.0 - np.rad2deg(np.arccos(cosang)) / 180.0) ** 4
+    m = -m / m.sum()
+    m[1, 1] = 1.0
+    ident = np.array([[0, 0, 0], [0, 1, 0], [0, 0, 0]], np.float64)
+    return ((1.0 - alpha) * ident + alpha * m).astype(np.float32)
 
 
 # ------------------------------------------------------------------------------------- spatial members of the pipelines

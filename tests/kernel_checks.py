@@ -328,72 +328,123 @@ def check_kmeans2_mask(dev, seed=51, extra=12):
     assert ops.kmeans2_mask([], device=dev) == []
 
 
-def _aug_params(**kw):
-    """One parameter row (kernels/datapipe.h layout) from named fields; `kern` = a correlation kernel embedded in the 7 x 7 grid."""
+def _aug_params(seed=1, preinv=0, a=0, a_args=(), a_kern=None, b=0, b_args=(), c=0, c_args=(), blur_kern=None, d=0, d_args=()):
+    """One parameter row (kernels/datapipe.h layout): member + arguments of each group; `a_kern` = the 3 x 3 kernel of an
+    `arithmetic` filter member, `blur_kern` = a correlation kernel embedded in the `Blur` group's 7 x 7 grid."""
     from ccd_amd.dataset import augment as A
     p = A.IDENTITY_PARAMS.copy()
-    kern = kw.pop("kern", None)
-    for k, v in kw.items():
-        p[{"invert": 0, "gray": 1, "perm": 2, "gamma": 3, "contrast": 7, "add": 8, "sigma": 9, "mulnoise": 10, "impulse": 11,
-           "solarize": 12, "seed": 13, "mode": 14, "k": 15, "jpeg": 25, "sigc": 26, "sigs": 27}[k]] = v
-    if kern is not None:
-        A._set_filter(p, kern)
+    p[A.P_SEED], p[A.P_PREINV] = seed, preinv
+    p[A.P_A], p[A.P_B], p[A.P_C], p[A.P_D] = a, b, c, d
+    p[A.P_A + 1:A.P_A + 1 + len(a_args)] = a_args
+    p[A.P_B + 1:A.P_B + 1 + len(b_args)] = b_args
+    p[A.P_C + 1:A.P_C + 1 + len(c_args)] = c_args
+    p[A.P_D + 1:A.P_D + 1 + len(d_args)] = d_args
+    if a_kern is not None:
+        p[A.P_AK:A.P_AK + 9] = np.asarray(a_kern, np.float32).reshape(-1)
+    if blur_kern is not None:
+        A._set_filter(p, blur_kern)
     return p
 
 
-def check_augment_views(dev, B=9, H=32, W=128, seed=52):
-    """The three views of a sample (datasetsupervised_kmeans.py:48-87) vs the numpy restatement, every member exercised -
-    pointwise chain, JPEG round trip, 7 x 7 correlations (Gaussian 5 x 5, even-sized average with cv2's anchor, motion blur,
-    sharpen), median 3 / 5 / 7, bilateral; geometry: view 2 of an un-coloured sample == F.grid_sample of view 0's pixels in the
-    dataset's (size-1)-normalised convention, and identity theta reproduces the colour view on view 2."""
+def _aug_member_rows():
+    """Every member of the chain at least once (alone), then combinations across the groups."""
+    from ccd_amd.dataset import augment as A
+    R = _aug_params
+    emboss = A._blend(0.6, [[-2.1, -1.1, 0], [-1.1, 1, 1.1], [0, 1.1, 2.1]])
+    rows = [
+        R(),                                                               # 0: identity (sample 0, both views)
+        R(),
+        R(seed=11, a=A.A_ADD_ELEM, a_args=(40, 0)), R(seed=12, a=A.A_ADD_ELEM, a_args=(40, 1)),
+        R(seed=13, a=A.A_GAUSS, a_args=(30.0, 0)), R(seed=14, a=A.A_GAUSS, a_args=(8.0, 1)),
+        R(seed=15, a=A.A_LAPLACE, a_args=(25.0, 0)), R(seed=16, a=A.A_LAPLACE, a_args=(5.0, 1)),
+        R(seed=17, a=A.A_POISSON, a_args=(31.0, 0)), R(seed=18, a=A.A_POISSON, a_args=(2.5, 1)),
+        R(seed=19, a=A.A_MUL, a_args=(1.3, 0.7, 1.1)), R(seed=20, a=A.A_MUL_ELEM, a_args=(0.5, 1, 1.5)),
+        R(seed=21, a=A.A_MUL_ELEM, a_args=(0.5, 0, 1.5)), R(seed=22, a=A.A_DROPOUT, a_args=(0.08, 0)),
+        R(seed=23, a=A.A_DROPOUT, a_args=(0.05, 1)), R(seed=24, a=A.A_COARSE, a_args=(0.2, 0, 5, 19)),
+        R(seed=25, a=A.A_COARSE, a_args=(0.2, 1, 3, 6)), R(seed=26, a=A.A_DROP2D, a_args=(5,)),
+        R(seed=27, a=A.A_REPLACE, a_args=(0.1, 1, 0)), R(seed=28, a=A.A_REPLACE, a_args=(0.1, 0, 0)),
+        R(seed=29, a=A.A_REPLACE, a_args=(0.1, 0, 1)), R(seed=30, a=A.A_REPLACE, a_args=(0.1, 0, 2)),
+        R(seed=31, a=A.A_INVERT), R(seed=32, a=A.A_SOLARIZE, a_args=(100.0,)),
+        R(seed=33, a=A.A_JPEG, a_args=(2,)), R(seed=34, a=A.A_JPEG, a_args=(31,)),
+        R(seed=35, a=A.A_FILTER, a_kern=emboss), R(seed=36, a=A.A_FILTER, a_kern=A.directed_edge_kernel(0.8, 0.3)),
+        R(seed=37, a=A.A_PILFILTER, a_args=(0.0, 1.0), a_kern=[-1, -1, -1, -1, 9, -1, -1, -1, -1]),
+        R(seed=38, a=A.A_PILFILTER, a_args=(255.0, 1.0), a_kern=[-1, -1, -1, -1, 8, -1, -1, -1, -1]),
+        R(seed=39, b=A.B_HUE_ADD, b_args=(37,)), R(seed=40, b=A.B_HUE_ADD, b_args=(100,)),
+        R(seed=41, b=A.B_BRIGHT, b_args=(1.4, -20.0)), R(seed=42, b=A.B_MUL_HS, b_args=(1.37, 0.6)),
+        R(seed=43, b=A.B_MUL_HS, b_args=(0.55, 1.45)), R(seed=44, b=A.B_ADD_HS, b_args=(-35, 40)),
+        R(seed=45, b=A.B_ADD_HS, b_args=(21, -50)), R(seed=46, b=A.B_GRAY, b_args=(0.65,)),
+        R(seed=47, b=A.B_UNIFORM_Q, b_args=(2,)), R(seed=48, b=A.B_UNIFORM_Q, b_args=(11,)),
+        R(seed=49, b=A.B_GAINS, b_args=(1.2, 1.0, 0.8)), R(seed=50, b=A.B_SHUFFLE, b_args=(4,)),
+        R(seed=51, blur_kern=A.gaussian_kernel5(0.8)), R(seed=52, blur_kern=np.full((6, 6), 1 / 36.0)),      # AverageBlur k = 6: offsets -3 .. 2
+        R(seed=53, blur_kern=np.full((2, 2), 0.25)), R(seed=54, blur_kern=A.motion_kernel(5, 37.0, -0.4)),
+        R(seed=55, blur_kern=A._blend(0.4, [[-1, -1, -1], [-1, 8.3, -1], [-1, -1, -1]])), R(seed=56, c=A.C_MEDIAN, c_args=(3,)),
+        R(seed=57, c=A.C_MEDIAN, c_args=(5,)), R(seed=58, c=A.C_MEDIAN, c_args=(7,)),
+        R(seed=59, c=A.C_BILATERAL, c_args=(9, 60.0, 120.0)), R(seed=60, c=A.C_BILATERAL, c_args=(4, 15.0, 10.0)),
+        R(seed=61, d=A.D_GAMMA, d_args=(1.7,)), R(seed=62, d=A.D_GAMMA, d_args=(0.55,)),
+        R(seed=63, d=A.D_LINEAR, d_args=(0.6,)), R(seed=64, d=A.D_SIGMOID, d_args=(7.0, 0.45)),
+        R(seed=65, d=A.D_LOG, d_args=(1.3,)), R(seed=66, d=A.D_HISTEQ_ALL),
+        # the chain: arithmetic -> color -> Blur -> contrast on one image, with the leading Invert of the finetuning pipeline
+        R(seed=67, preinv=1, a=A.A_GAUSS, a_args=(12.0, 0), b=A.B_MUL_HS, b_args=(1.2, 0.8), blur_kern=A.gaussian_kernel5(1.2),
+          d=A.D_SIGMOID, d_args=(5.0, 0.5)),
+        R(seed=68, a=A.A_JPEG, a_args=(17,), b=A.B_GRAY, b_args=(0.3,), c=A.C_MEDIAN, c_args=(3,), d=A.D_HISTEQ_ALL),
+        R(seed=69, a=A.A_FILTER, a_kern=emboss, b=A.B_ADD_HS, b_args=(10, 10), c=A.C_BILATERAL, c_args=(5, 40.0, 40.0),
+          d=A.D_LINEAR, d_args=(0.8,)),
+        R(seed=70, a=A.A_DROPOUT, a_args=(0.05, 0), b=A.B_UNIFORM_Q, b_args=(6,), blur_kern=np.full((3, 3), 1 / 9.0),
+          d=A.D_GAMMA, d_args=(1.3,)),
+    ]
+    return np.stack(rows).astype(np.float32)
+
+
+def check_augment_views(dev, H=32, W=128, seed=52, max_samples=None):
+    """The three views of a sample (datasetsupervised_kmeans.py:48-87) vs the numpy restatement (oracle/datapipe_np.py), EVERY
+    member of the reference's chain exercised alone and in combination (same counter-based random numbers on both sides);
+    geometry: view 2 of an un-augmented sample == F.grid_sample of view 0's pixels in the dataset's (size-1)-normalised
+    convention, and identity theta reproduces the augmented view on view 2."""
     from oracle import datapipe_np as D
     from ccd_amd.dataset import augment as A
     rs = np.random.RandomState(seed)
+    rows = _aug_member_rows()
+    if max_samples is not None:                                        # the CPU executor's run: the first rows + the chains
+        rows = np.concatenate([rows[:2 * max_samples - 4], rows[-4:]])
+    B = (len(rows) + 1) // 2
+    params = np.tile(A.IDENTITY_PARAMS, (B, 2, 1)).astype(np.float32)
+    params.reshape(-1, A.AUG_NP)[:len(rows)] = rows
     img = rs.randint(0, 256, size=(B, H, W, 3)).astype(np.uint8)
     for b in range(B):                                                 # text-like structure under the noise: blocks of colour
         img[b] = (0.35 * img[b] + 0.65 * np.array(rs.randint(0, 256, 3))).astype(np.uint8)
         for _ in range(5):
             y0, x0 = rs.randint(0, H - 6), rs.randint(0, W - 10)
             img[b, y0:y0 + rs.randint(3, H // 2), x0:x0 + rs.randint(3, 12)] = rs.randint(0, 256, 3)
-    theta, warped = A.sample_theta(rs, B, H, W, p_warp=1.0, return_warped=True)
-    params = A.sample_colour_params(rs, B, 5, warped=warped)
-    params[0, 0] = A.IDENTITY_PARAMS; params[0, 1] = A.IDENTITY_PARAMS
-    params[1, 0] = _aug_params(invert=1, gray=0.4, perm=3, gamma=1.7, contrast=0.7, add=12, sigma=9.0, mulnoise=0.3, impulse=0.05,
-                               solarize=100, seed=77, kern=np.full((3, 3), 1 / 9.0))
-    params[1, 0, 4:7] = (1.2, 0.8, 1.1)
-    params[1, 1] = _aug_params(gray=1.0, perm=5, gamma=0.6, add=-20, impulse=0.1, seed=123456,
-                               kern=A._blend(0.4, [[-1, -1, -1], [-1, 8.3, -1], [-1, -1, -1]]))
-    params[2, 0] = _aug_params(jpeg=2, seed=5)
-    params[2, 1] = _aug_params(jpeg=17, kern=A.gaussian_kernel5(0.8))                      # JPEG, then the blur on its output
-    params[3, 0] = _aug_params(mode=2, k=3)
-    params[3, 1] = _aug_params(mode=2, k=7, jpeg=31)
-    params[4, 0] = _aug_params(mode=2, k=5, add=9)
-    params[4, 1] = _aug_params(mode=3, k=9, sigc=60.0, sigs=120.0)
-    params[5, 0] = _aug_params(mode=3, k=4, sigc=15.0, sigs=10.0, gamma=1.3)
-    params[5, 1] = _aug_params(kern=A.motion_kernel(5, 37.0, -0.4))
-    params[6, 0] = _aug_params(kern=np.full((6, 6), 1 / 36.0))                               # AverageBlur k = 6: offsets -3 .. 2
-    params[6, 1] = _aug_params(kern=np.full((2, 2), 0.25))
+    img[1, :, :W // 2] = img[1, 0, 0]                                  # a flat half (the HSV / histogram members' degenerate inputs)
+    theta = A.sample_theta(rs, B, H, W, p_warp=1.0)
     theta[2] = np.eye(3)
     mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
     got = ops.augment_views(torch.from_numpy(img).to(dev), torch.from_numpy(params).to(dev), torch.from_numpy(theta).to(dev),
                             mean, std).cpu().numpy()
-    want = D.augment_views(img, params, theta, mean, std)
-    assert got.shape == (B, 3, 3, H, W)
-    err = np.abs(got - want)
-    # powf / logf / cosf / expf differ by ulps between libm and the device; impulse / solarize decisions, a uint8 rounding of the
-    # staged image or a DCT coefficient on a quantisation boundary can flip on a tie: a staged pixel that is one level off moves the
-    # normalised value by 1 / (255 * 0.22) = 0.018
-    assert np.quantile(err, 0.995) < 2e-3 and (err > 0.04).mean() < 3e-4, (err.max(), np.quantile(err, 0.995), (err > 0.04).mean())
+    assert got.shape == (B, 3, 3, H, W) and np.isfinite(got).all()
     # view 0 is the plain normalised image, exactly
     v0 = ((img.astype(np.float32) * np.float32(1 / 255.0) - np.float32(mean)) * (np.float32(1) / np.float32(std))).transpose(0, 3, 1, 2)
     np.testing.assert_allclose(got[:, 0], v0, rtol=0, atol=1e-6)
-    # the staged members alone (no pointwise change): view 1 of samples 2, 3, 6 is the restated member, to the level
-    for b in (2, 3, 6):
-        stg = D.staged_source(params[b, 0], img[b]).astype(np.float32)
+    # view 1 of every sample = the restated chain of its row, to the LEVEL.  powf / logf / expf / sinf differ by ulps between libm
+    # and the device, and a value on an x.5 tie (or a noise draw on a decision boundary, a DCT coefficient on a quantisation
+    # step) rounds either way: a small share of pixels may be one level off, JPEG blocks a few levels
+    istd255 = 255.0 * np.float32(std)[:, None, None]
+    for b in range(B):
+        p = params[b, 0]
+        stg = D.staged_source(p, img[b]).astype(np.float32)
         w1 = ((stg * np.float32(1 / 255.0) - np.float32(mean)) / np.float32(std)).transpose(2, 0, 1)
-        lvl = np.abs(got[b, 1] - w1) * 255.0 * np.float32(std)[:, None, None]
-        assert (lvl > 0.5).mean() < 6e-3 and lvl.max() < (40.0 if b == 2 else 1.5), (b, lvl.max(), (lvl > 0.5).mean())   # (x.5 ties round either way)
-    # sample 0: no colour change -> view 1 == view 0, and view 2 == bilinear warp of view 0's raw pixels (zeros outside)
+        lvl = np.abs(got[b, 1] - w1) * istd255
+        jpeg = int(p[A.P_A]) == A.A_JPEG
+        hsv = int(p[A.P_B]) in (A.B_HUE_ADD, A.B_MUL_HS, A.B_ADD_HS)
+        share, worst = (lvl > 0.5).mean(), lvl.max()
+        coarse_jpeg = jpeg and p[A.P_A + 1] <= 5          # quality <= 5: every table entry is 255 - one flipped coefficient moves a block by a lot
+        chain = sum(int(p[i]) != 0 for i in (A.P_A, A.P_B, A.P_C, A.P_D)) > 1      # a tie in one group is amplified by the next ones
+        assert share < (8e-2 if coarse_jpeg else 3e-2 if chain else 2e-2 if jpeg or hsv else 1e-2) and \
+            worst < (90.0 if coarse_jpeg else 40.0 if jpeg else 12.0 if chain else (3.5 if hsv else 1.5)), \
+            (b, [int(p[i]) for i in (A.P_A, A.P_B, A.P_C, A.P_D)], float(worst), float(share))
+        if int(p[A.P_A]) or int(p[A.P_B]) or int(p[A.P_C]) or int(p[A.P_D]):
+            assert np.abs(got[b, 1] - got[b, 0]).max() > 1e-3, (b, "the member changed nothing")
+    # sample 0: no augmentation -> view 1 == view 0, and view 2 == bilinear warp of view 0's raw pixels (zeros outside)
     np.testing.assert_allclose(got[0, 1], got[0, 0], rtol=0, atol=1e-5)
     raw = torch.from_numpy(img[0].astype(np.float32)).permute(2, 0, 1)[None]
     th = torch.from_numpy(theta[0])[None, :2, :]
@@ -401,9 +452,14 @@ def check_augment_views(dev, B=9, H=32, W=128, seed=52):
     warped_ref = F.grid_sample(raw, grid, mode="bilinear", padding_mode="zeros", align_corners=True)[0].numpy()
     want2 = (warped_ref * np.float32(1 / 255.0) - np.float32(mean)[:, None, None]) / np.float32(std)[:, None, None]
     np.testing.assert_allclose(got[0, 2], want2, rtol=0, atol=2e-4)
-    # sample 2: identity theta -> view 2 is a pure colour view of the same pixels
-    e2 = np.abs(got[2, 2] - D.augment_views(img[2:3], params[2:3], theta[2:3], mean, std)[0, 2])
-    assert np.quantile(e2, 0.995) < 2e-3, np.quantile(e2, 0.995)
+    # every sample: view 2 = the warp of ITS staged image (the restated chain of row [b, 1])
+    want = D.augment_views(img, params, theta, mean, std)
+    err = np.abs(got[:, 2] - want[:, 2])
+    assert np.quantile(err, 0.995) < 2e-2 and (err > 0.08).mean() < 2e-3, (err.max(), np.quantile(err, 0.995), (err > 0.08).mean())
+    # sample 2: identity theta -> view 2 is the augmented image itself
+    stg2 = D.staged_source(params[2, 1], img[2]).astype(np.float32)
+    w2 = ((stg2 * np.float32(1 / 255.0) - np.float32(mean)) / np.float32(std)).transpose(2, 0, 1)
+    assert (np.abs(got[2, 2] - w2) * istd255 > 0.5).mean() < 6e-3
 
 
 def check_seg_to_mask(dev, seed=23):

@@ -122,23 +122,136 @@ def test_theta_is_the_datasets_composition():
     ident = (th == np.eye(3, dtype=np.float32)).all(axis=(1, 2)).mean()
     assert 0.26 < ident < 0.34                                      # `random.random() > 0.3` -> warp
     assert np.allclose(th[:, 2], [0, 0, 1])
-    th, warped = sample_theta(np.random.RandomState(3), 800, img_h, img_w, return_warped=True)
-    p = sample_colour_params(np.random.RandomState(0), 800, 5, warped=warped)
-    assert p.shape == (800, 2, 96) and np.isfinite(p).all() and (p[..., 3] > 0).all() and (p[..., 2] < 6).all()
-    from ccd_amd.dataset.augment import IDENTITY_PARAMS
+    from ccd_amd.dataset import augment as A
+    th, warped = sample_theta(np.random.RandomState(3), 4000, img_h, img_w, return_warped=True)
+    p = sample_colour_params(np.random.RandomState(0), 4000, 5, warped=warped, h=img_h, w=img_w)
+    assert p.shape == (4000, 2, 96) and np.isfinite(p).all()
     ident = sample_colour_params(np.random.RandomState(0), 4, 0)
-    assert (ident[..., :13] == IDENTITY_PARAMS[:13]).all() and (ident[..., 14:] == IDENTITY_PARAMS[14:]).all()   # severity 0
+    assert (ident[..., 1:] == A.IDENTITY_PARAMS[1:]).all()                                       # severity 0: only the seed differs
     # a sample whose warp draw failed gets the plain image as view 2 (datasetsupervised_kmeans.py:72-74)
-    assert (p[~warped, 1, :13] == IDENTITY_PARAMS[:13]).all() and (p[~warped, 1, 14:] == 0).all()
-    assert (p[warped, 1] != IDENTITY_PARAMS).any()
+    assert (p[~warped, 1] == A.IDENTITY_PARAMS).all() and (p[warped, 1] != A.IDENTITY_PARAMS).any()
     v1 = p[:, 0]
-    mode = v1[:, 14]
-    assert 0.2 < (mode == 1).mean() < 0.7 and (mode == 2).sum() > 5 and (mode == 3).sum() > 5        # every Blur member is drawn
-    assert set(np.unique(v1[mode == 2, 15])) == {3.0, 5.0, 7.0} and v1[mode == 3, 15].min() >= 3 and v1[mode == 3, 15].max() <= 10
-    kern = v1[mode == 1][:, 32:81]
-    assert np.abs(kern.sum(1)).max() < 3.0 and (np.abs(kern) > 0).sum(1).max() <= 49
-    jq = v1[:, 25]
-    assert 0.02 < (jq > 0).mean() < 0.2 and jq[jq > 0].min() >= 2 and jq[jq > 0].max() <= 31        # compression 70-99 -> quality 31 .. 2
+    live = 0.8                                                       # Sometimes(0.2, Identity, Sequential[...])
+    a_op, b_op, c_op, d_op = (v1[:, i].astype(int) for i in (A.P_A, A.P_B, A.P_C, A.P_D))
+    share = lambda sel: sel.mean() / live
+    # `arithmetic`: OneOf over the reference's 21 members (augmentation_pipelines.py:122-144), each 1 / 21 of the live draws
+    want_a = {A.A_ADD_ELEM: 1, A.A_GAUSS: 1, A.A_LAPLACE: 1, A.A_POISSON: 1, A.A_MUL: 1, A.A_MUL_ELEM: 1, A.A_DROPOUT: 1, A.A_COARSE: 1,
+              A.A_DROP2D: 1, A.A_REPLACE: 4, A.A_INVERT: 0.15, A.A_SOLARIZE: 0.5, A.A_JPEG: 1, A.A_FILTER: 3, A.A_PILFILTER: 2}
+    for op, mult in want_a.items():
+        assert abs(share(a_op == op) - mult / 21.0) < 0.02, (op, share(a_op == op), mult / 21.0)
+    # `color`: Sometimes(0.7, OneOf 9) with KMeansColorQuantization left out (identity)
+    want_b = {A.B_HUE_ADD: 2, A.B_BRIGHT: 1, A.B_MUL_HS: 1, A.B_ADD_HS: 1, A.B_GRAY: 1, A.B_UNIFORM_Q: 1, A.B_GAINS: 1}
+    for op, mult in want_b.items():
+        assert abs(share(b_op == op) - 0.7 * mult / 9.0) < 0.02, (op, share(b_op == op))
+    assert (b_op == A.B_KMEANS).sum() == 0
+    # `Blur`: Sometimes(0.7, OneOf[Sharpen, OneOf[5 blurs]]): filters = Sharpen + Gaussian + Average + Motion
+    assert abs(share(c_op == A.C_FILTER) - 0.7 * (0.5 + 0.5 * 3 / 5)) < 0.03 and abs(share(c_op == A.C_MEDIAN) - 0.07) < 0.02
+    assert abs(share(c_op == A.C_BILATERAL) - 0.07) < 0.02
+    assert set(np.unique(v1[c_op == A.C_MEDIAN, A.P_C + 1])) == {3.0, 5.0, 7.0}
+    bil = v1[c_op == A.C_BILATERAL]
+    assert bil[:, A.P_C + 1].min() >= 3 and bil[:, A.P_C + 1].max() <= 10 and bil[:, A.P_C + 2].min() >= 10 and bil[:, A.P_C + 3].max() <= 250
+    kern = v1[c_op == A.C_FILTER][:, A.P_KERN:A.P_KERN + 49]
+    ks = kern.sum(1)                                                # the blurs preserve the mean; Sharpen(lightness 0 - 0.5) sums to 1 - alpha (1 - lightness)
+    assert ks.max() < 1.0 + 1e-4 and ks.min() >= 0.5 and (np.abs(ks - 1.0) < 1e-4).mean() > 0.3
+    # `contrast`: Sometimes(0.7, OneOf 8), three of the eight not reproduced
+    for op in (A.D_GAMMA, A.D_LINEAR, A.D_SIGMOID, A.D_LOG, A.D_HISTEQ_ALL):
+        assert abs(share(d_op == op) - 0.7 / 8.0) < 0.02, (op, share(d_op == op))
+    jq = v1[a_op == A.A_JPEG, A.P_A + 1]
+    assert jq.min() >= 2 and jq.max() <= 31                         # compression 70-99 -> PIL quality 31 .. 2
+    cd = v1[a_op == A.A_COARSE]
+    assert (cd[:, A.P_A + 3] == 5).all() and (cd[:, A.P_A + 4] == 19).all() and (cd[:, A.P_A + 1] == np.float32(0.02)).all()
+    hs = v1[b_op == A.B_ADD_HS]
+    assert np.abs(hs[:, A.P_B + 1]).max() <= 35 and np.abs(hs[:, A.P_B + 2]).max() <= 50 and (hs[:, A.P_B + 1] == np.round(hs[:, A.P_B + 1])).all()
+    # the finetuning pipeline (dataset_pretrain.py:80-146): 35-member OneOf behind Sometimes(0.8), leading Invert 0.6 * 0.1
+    pf, thf = A.sample_finetune_params(np.random.RandomState(1), 6000, img_h, img_w)
+    f1 = pf[:, 1]
+    assert abs(f1[:, A.P_PREINV].mean() - 0.06) < 0.015
+    fa, fb, fc = (f1[:, i].astype(int) for i in (A.P_A, A.P_B, A.P_C))
+    assert abs((fa == A.A_JPEG).mean() - 0.8 / 35) < 0.01 and abs((fb == A.B_HUE_ADD).mean() - 0.8 * 2 / 35) < 0.012
+    assert abs((fb == A.B_SHUFFLE).mean() - 0.8 * 0.35 / 35) < 0.006 and (fc == A.C_BILATERAL).sum() == 0
+    assert ((fa != 0) & (fb != 0)).sum() == 0                       # ONE member of the combined list
+    assert abs((thf != np.eye(3, dtype=np.float32)).any(axis=(1, 2)).mean() - 0.6 * 2 / 3) < 0.03      # PiecewiseAffine's third: identity
+
+
+def test_member_restatements_of_the_colour_chain():
+    """oracle/datapipe_np.py's pointwise / 3 x 3 members: the PIL filter presets against PIL itself; the restated cv2 conversions
+    and tables against independent definitions (colorsys for HSV within its 8-bit quantisation, the textbook cumulative
+    histogram for equalizeHist); DirectedEdgeDetect's kernel against the sampler's; the noise members' distributions."""
+    import colorsys
+    from PIL import Image, ImageFilter
+    from ccd_amd.dataset import augment as A
+    rs = np.random.RandomState(11)
+    img = rs.randint(0, 256, size=(24, 56, 3)).astype(np.uint8)
+    img[:8, :16] = (200, 30, 30)
+    # pillike.FilterEdgeEnhanceMore / FilterContour ARE PIL's filters (kernel, scale, offset, copied border)
+    for filt, kern, off in ((ImageFilter.EDGE_ENHANCE_MORE, [-1, -1, -1, -1, 9, -1, -1, -1, -1], 0.0),
+                            (ImageFilter.CONTOUR, [-1, -1, -1, -1, 8, -1, -1, -1, -1], 255.0)):
+        want = np.array(Image.fromarray(img).filter(filt))
+        np.testing.assert_array_equal(D.filter3(img, kern, pil=True, offset=off, scale=1.0), want)
+    # cv2's 8-bit HSV: H in units of 2 degrees (0..179), S and V on 0..255
+    hsv = D.rgb_to_hsv_cv(img)
+    for (y, x) in [(0, 0), (3, 40), (10, 20), (23, 55), (12, 7)]:
+        h, s_, v = colorsys.rgb_to_hsv(*(img[y, x] / 255.0))
+        dh = abs(hsv[y, x, 0] - h * 180.0)
+        assert min(dh, 180 - dh) <= 1.0 and abs(hsv[y, x, 1] - s_ * 255.0) <= 1.0 and hsv[y, x, 2] == img[y, x].max()
+    gray = np.repeat(rs.randint(0, 256, size=(4, 4, 1)), 3, axis=2).astype(np.uint8)
+    assert (D.rgb_to_hsv_cv(gray)[..., :2] == 0).all()              # no hue / saturation on the grey axis
+    back = D.hsv_to_rgb_cv(hsv)
+    assert np.abs(back.astype(int) - img.astype(int)).max() <= 6    # H is quantised to 2 degrees
+    np.testing.assert_array_equal(D.hsv_to_rgb_cv(D.rgb_to_hsv_cv(gray)), gray)
+    shifted = D.colour_member(_row(b=A.B_ADD_HS, b_args=(90, 0)), img)            # + 180 degrees twice = the identity (up to quantisation)
+    twice = D.colour_member(_row(b=A.B_ADD_HS, b_args=(90, 0)), shifted)
+    assert np.abs(twice.astype(int) - img.astype(int)).max() <= 12
+    # equalizeHist: monotone table, first occupied bin -> 0, last -> 255, a constant channel stays
+    ch = np.clip(rs.normal(120, 20, size=(32, 128)), 0, 255).astype(np.uint8)
+    eq = D.equalize_hist_cv(ch)
+    lo, hi = ch.min(), ch.max()
+    assert eq[ch == lo].max() == 0 and eq[ch == hi].min() == 255 and (np.diff(eq.reshape(-1)[np.argsort(ch.reshape(-1), kind="stable")]) >= 0).all()
+    cdf = np.cumsum(np.bincount(ch.reshape(-1), minlength=256))
+    textbook = np.rint((cdf - cdf[lo]) * 255.0 / (ch.size - cdf[lo]))
+    np.testing.assert_array_equal(eq, textbook[ch].astype(np.uint8))
+    np.testing.assert_array_equal(D.equalize_hist_cv(np.full((5, 5), 9, np.uint8)), np.full((5, 5), 9, np.uint8))
+    # the contrast tables at their fixed points (imgaug's docs: 127 + alpha (v - 127); sigmoid(cutoff) = 1 / 2; log2(2) = 1)
+    ramp = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, axis=2)
+    assert D.contrast_member(_row(d=A.D_LINEAR, d_args=(0.5,)), ramp)[0, 127, 0] == 127
+    assert D.contrast_member(_row(d=A.D_LINEAR, d_args=(0.5,)), ramp)[0, 255, 0] == 191
+    assert D.contrast_member(_row(d=A.D_SIGMOID, d_args=(10.0, 0.4)), ramp)[0, 102, 0] == 127          # 255 / 2, truncated
+    assert D.contrast_member(_row(d=A.D_LOG, d_args=(1.0,)), ramp)[0, 255, 0] == 255
+    assert D.contrast_member(_row(d=A.D_GAMMA, d_args=(2.0,)), ramp)[0, 128, 0] == int(255 * (128 / 255) ** 2)
+    q = D.colour_member(_row(b=A.B_UNIFORM_Q, b_args=(4,)), ramp)[0, :, 0]
+    assert sorted(set(q.tolist())) == [32, 96, 160, 224]            # bin centres
+    # DirectedEdgeDetect: direction 0 looks up, 0.25 to the right; the sampler's kernel == the restatement's
+    np.testing.assert_allclose(A.directed_edge_kernel(0.7, 0.3), D.directed_edge_kernel(0.7, 0.3), atol=1e-6)
+    k0, k1 = D.directed_edge_kernel(1.0, 0.0), D.directed_edge_kernel(1.0, 0.25)
+    assert k0[0, 1] == k0.min() and k1[1, 2] == k1.min() and abs(k0.sum()) < 1e-6 and k0[1, 1] == 1.0
+    # the noise members: distributions of the counter-based draws (what the device kernel uses too)
+    flat = np.full((64, 128, 3), 128, np.uint8)
+    g = D.arith_pointwise(_row(seed=5, a=A.A_GAUSS, a_args=(20.0, 1)), flat).astype(float) - 128
+    assert abs(g.mean()) < 0.5 and abs(g.std() - 20.0) < 0.6
+    shared = D.arith_pointwise(_row(seed=5, a=A.A_GAUSS, a_args=(20.0, 0)), flat)
+    assert (shared[..., 0] == shared[..., 1]).all() and (shared[..., 1] == shared[..., 2]).all()       # per_channel=False
+    lap = D.arith_pointwise(_row(seed=6, a=A.A_LAPLACE, a_args=(10.0, 1)), flat).astype(float) - 128
+    assert abs(lap.mean()) < 0.5 and abs(np.abs(lap).mean() - 10.0) < 0.5          # E|x| = scale
+    poi = D.arith_pointwise(_row(seed=7, a=A.A_POISSON, a_args=(30.0, 1)), np.zeros_like(flat)).astype(float)
+    assert abs(poi.mean() - 30.0) < 0.3 and abs(poi.var() - 30.0) < 2.0
+    add = D.arith_pointwise(_row(seed=8, a=A.A_ADD_ELEM, a_args=(40, 1)), flat).astype(int) - 128
+    assert add.min() == -40 and add.max() == 40 and abs(add.mean()) < 0.6
+    drop = D.arith_pointwise(_row(seed=9, a=A.A_DROPOUT, a_args=(0.1, 0)), flat)
+    assert abs((drop[..., 0] == 0).mean() - 0.1) < 0.01 and ((drop == 0).all(-1) == (drop == 0).any(-1)).all()
+    coarse = D.arith_pointwise(_row(seed=10, a=A.A_COARSE, a_args=(0.3, 0, 5, 19)), flat)[..., 0] == 0
+    cells = coarse.reshape(64, 128)
+    assert 0.1 < cells.mean() < 0.5 and (cells[:12] == cells[0]).all()            # constant inside a coarse cell (64 / 5 rows)
+    sp = D.arith_pointwise(_row(seed=11, a=A.A_REPLACE, a_args=(0.1, 0, 0)), flat)[..., 0].astype(int)
+    hit = sp != 128
+    assert abs(hit.mean() - 0.1) < 0.012 and (sp[hit] < 30).mean() > 0.18 and (sp[hit] > 225).mean() > 0.18   # the arcsine law: 0.22 in each tail (uniform: 0.12)
+    assert D.arith_pointwise(_row(seed=11, a=A.A_REPLACE, a_args=(0.1, 0, 1)), flat).min() >= 127
+    assert D.arith_pointwise(_row(seed=11, a=A.A_REPLACE, a_args=(0.1, 0, 2)), flat).max() <= 128
+    np.testing.assert_array_equal(D.arith_pointwise(_row(a=A.A_DROP2D, a_args=(5,)), flat)[0, 0], [128, 0, 128])
+
+
+def _row(**kw):
+    from kernel_checks import _aug_params
+    return _aug_params(**kw)
 
 
 def test_spatial_member_restatements_are_pinned():

@@ -116,11 +116,11 @@ def test_finetune_dataset_augments_on_the_device(hip, tmp_path):
     got = ops.augment_views(u8[None].to(hip.device), torch.from_numpy(ident).to(hip.device),
                             torch.eye(3, device=hip.device)[None].contiguous(), A_MEAN, A_STD)[0, 2]
     torch.testing.assert_close(got.cpu(), ref, rtol=0, atol=1e-5)
-    p, th = A.sample_finetune_params(np.random.RandomState(0), 600, 32, 128)
-    assert p.shape == (600, 2, 96) and (p[:, 0] == A.IDENTITY_PARAMS).all() and np.isfinite(p).all()
+    p, th = A.sample_finetune_params(np.random.RandomState(0), 2000, 32, 128)
+    assert p.shape == (2000, 2, 96) and (p[:, 0] == A.IDENTITY_PARAMS).all() and np.isfinite(p).all()
     warped = ~(th == np.eye(3, dtype=np.float32)).all(axis=(1, 2))
     assert 0.3 < warped.mean() < 0.5                                  # 0.6 x (Affine | Rotate) of three geometric members
-    assert (p[:, 1, 14] == 2).any() and (p[:, 1, 25] > 0).any() and (p[:, 1, 14] != 3).all()        # no bilateral member here
+    assert (p[:, 1, A.P_C] == A.C_MEDIAN).any() and (p[:, 1, A.P_A] == A.A_JPEG).any() and (p[:, 1, A.P_C] != A.C_BILATERAL).all()   # no bilateral member here
 
 
 A_MEAN, A_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)

@@ -282,7 +282,7 @@ def test_kmeans2_mask_sim(sim):
 
 
 def test_augment_views_sim(sim):
-    kc.check_augment_views(sim.device, B=7, H=16, W=40)
+    kc.check_augment_views(sim.device, H=16, W=40)
 
 
 def test_cu_reserve_window_sim(sim, monkeypatch):
