@@ -161,7 +161,7 @@ static int ccd_launch_gemm256(const ccd::GemmParams& p, int epilogue, void* stre
     const int tiles = ((p.M + ccd::G256_BM - 1) / ccd::G256_BM) * ((p.N + BN - 1) / BN);
     const int cus = ccd_grid_cus();
     const dim3 grid(tiles < cus ? tiles : cus), block(ccd::G256_THREADS);
-    const size_t smem = ccd::G256_SMEM_BYTES;
+    const size_t smem = ccd::g256_smem_bytes(p.N, p.colsum != nullptr);
     switch (epilogue) {
         case CCD_EPI_BF16: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_BF16, BN, DEEP>), grid, block, smem, stream, p); break;
         case CCD_EPI_GELU: CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_GELU, BN, DEEP>), grid, block, smem, stream, p); break;
@@ -282,12 +282,13 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
     // fp32 / residual epilogues take the 256-row tile where the columns fill whole tiles (vit_base, N = 512: 6.6 vs 7.6 ms per
     // step); at N = 384 (one and a half tiles) the 128-row kernels are faster
     const bool f32_256 = epilogue != CCD_EPI_ATOMIC && (pol.gemm_256_f32 || N % 256 == 0);
+    const bool colsum_fits = !colsum || N <= ccd::G256_MAX_COLSUM_N;      // gemm256.h keeps the column sums of every column in LDS
     if (pol.gemm_256 >= 1 && (bf16_out || f32_256) && M >= pol.gemm_256_min_m &&
-        N >= pol.gemm_256_min_n) {
+        N >= pol.gemm_256_min_n && colsum_fits) {
         if (pol.gemm_256_deep) return ccd_launch_gemm256<256, true>(p, epilogue, stream);
         return ccd_launch_gemm256<256>(p, epilogue, stream);
     }
-    if (pol.gemm_256 >= 2 && epilogue != CCD_EPI_ATOMIC && M >= pol.gemm_256_min_m) return ccd_launch_gemm256<128>(p, epilogue, stream);
+    if (pol.gemm_256 >= 2 && epilogue != CCD_EPI_ATOMIC && M >= pol.gemm_256_min_m && colsum_fits) return ccd_launch_gemm256<128>(p, epilogue, stream);
     int splits = 1;
     if (epilogue == CCD_EPI_ATOMIC && K >= 16384) {      // few output tiles, long contraction (the head's data gradient,
         p.k_per_split = 8192;                            // K = 65536: 52 live tiles): slices of 8192 accumulate by fp32 atomics

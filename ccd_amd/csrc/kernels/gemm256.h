@@ -24,6 +24,8 @@ namespace ccd {
 constexpr int G256_BM = 256, G256_BN = 256, G256_BK = 64, G256_THREADS = 512;
 constexpr int G256_OPERAND_BYTES = G256_BM * G256_BK * 2;            // 32 KiB per operand and buffer
 constexpr int G256_SMEM_BYTES = 4 * G256_OPERAND_BYTES;             // 2 buffers x (A + B) = 128 KiB
+constexpr int G256_MAX_COLSUM_N = 6144;                              // (+ 24 KiB of column sums at most: 152 of 160 KiB)
+__host__ __device__ inline int g256_smem_bytes(int N, bool colsum) { return G256_SMEM_BYTES + (colsum ? N * 4 : 0); }
 
 // BN = 256: waves 2 (M) x 4 (N), 128x64 per wave.  BN = 128 (the N = 384 products): waves 4 x 2, 64x64 per wave.
 // DEEP = true: BK = 32 and FOUR 32-KiB buffers instead of BK = 64 and two 64-KiB ones - three k-steps of DMA in flight
@@ -78,6 +80,15 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
     }
 
     if (slot >= cnt_x) return;
+    // column sums (bias gradients): LDS accumulators behind the operand buffers for every column of the product, flushed by
+    // one pass of global atomics when the workgroup is done (was: per tile a transpose through the staging image, three
+    // barriers and 256 global atomics - 40 us of a 360-us launch).  The launcher sizes the LDS (g256_smem_bytes).
+    float* cs_lds = reinterpret_cast<float*>(smem + G256_SMEM_BYTES);
+    const bool cs_on = (EPI == EPI_DGELU || EPI == EPI_BF16) && p.colsum != nullptr;
+    if (cs_on) {
+        for (int i = t; i < p.N; i += G256_THREADS) cs_lds[i] = 0.f;
+        __syncthreads();                                        // (nothing in flight yet)
+    }
     // DMA source pointers of the current item: wave w moves chunks 4w .. 4w+3 (8 rows each) of both operands
     // a 1-KiB DMA chunk = 8 rows of 128 B (BK = 64) or 16 rows of 64 B (BK = 32); wave w moves ACH / BCHK chunks per buffer
     constexpr int RPC = 1024 / ROW;                         // rows per chunk
@@ -356,6 +367,10 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
             G256_STAMP(4)
             lds_barrier();
             G256_STAMP(5)
+            if (EPI == EPI_DGELU) {           // every row of this pass has arrived BEFORE the first store (prelude: needed_here)
+#pragma unroll
+                for (int pass = 0; pass < SROWS / RSTEP; ++pass) needed_here(auxw[pass]);
+            }
 #pragma unroll
             for (int pass = 0; pass < SROWS / RSTEP; ++pass) {
                 const int s2 = pass * RSTEP + rr;
@@ -417,22 +432,31 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
             lds_barrier();                                   // staging image read out
             G256_STAMP(5)
         }
-        if (want_stats) {                                    // RSTEP row-threads per 8-column group -> one atomic per column
-            float* red = reinterpret_cast<float*>(stg);
+        if (want_stats) {
+            // a wave holds every column thread twice (CT = 32: lanes l and l ^ 32 are the same 8 columns, two row threads; CT = 16:
+            // four row threads, lanes l, l ^ 16, l ^ 32, l ^ 48): fold inside the wave, one LDS atomic per column and wave
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[rr * BN + 8 * ct + e] = csum[e];
-            lds_barrier();
-            if (t < BN && en0 + t < p.N) {
-                float a = 0.f;
-#pragma unroll 8
-                for (int r = 0; r < RSTEP; ++r) a += red[r * BN + t];
-                atomicAdd(p.colsum + en0 + t, a);
+            for (int e = 0; e < 8; ++e) {
+                float v = csum[e] + shfl_xor(csum[e], 32);
+                if (CT == 16) v += shfl_xor(v, 16);
+                if (lane < CT && gn + e < p.N) atomicAdd(cs_lds + gn + e, v);
             }
-            lds_barrier();
         }
         }
         if (!has_next) break;
         item = next;
+    }
+    if (cs_on) {
+        lds_barrier();
+        // every workgroup starts its sweep at another column: 256 workgroups adding to the SAME address at the same moment
+        // serialise in the L2's atomic unit (28 us of tail measured with the sweeps aligned)
+        const int rot = (int)(((unsigned)blockIdx.x * 2654435761u >> 8) % (unsigned)p.N);
+        for (int i = t; i < p.N; i += G256_THREADS) {
+            int c = i + rot;
+            c = c >= p.N ? c - p.N : c;
+            const float v = cs_lds[c];
+            if (v != 0.f) atomicAdd(p.colsum + c, v);
+        }
     }
 #ifdef CCD_GEMM_LAB
     if ((p.m_fastest & 64) && p.colsum && t == 0)

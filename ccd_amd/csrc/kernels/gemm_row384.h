@@ -219,10 +219,12 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
                             }
                         }
                     }
+                    float sc_pre[2] = {1.0f, 1.0f};                      // DropPath scale of the two rows (RESID_LN)
                     if (EPI == EPI_RESID_LN) {
 #pragma unroll
                         for (int step = 0; step < 2; ++step) {
                             const int gm = em0 + 64 * h + 32 * q + 16 * step + 2 * w + hf;
+                            if (gm < p.M && p.rowscale) sc_pre[step] = p.rowscale[p.rps_shift >= 0 ? gm >> p.rps_shift : gm / p.rows_per_sample];
 #pragma unroll
                             for (int c3 = 0; c3 < 3; ++c3) {
                                 const int gnc = 4 * ((lane & 31) + 32 * c3);
@@ -323,13 +325,20 @@ __global__ __launch_bounds__(GR_THREADS, 1) void gemm_row384_kernel(GemmParams p
                         // 16-byte chunks = 384 columns): the row sums are five shuffles, no LDS traffic, one sweep.
                         const int L = lane & 31;
                         const float inv_n = 1.0f / (float)p.N;
+                        // everything this pass loaded has arrived BEFORE its first store (prelude: needed_here): a wait behind a
+                        // store is `vmcnt(0)` - the store's round trip, once per row (and the scale was loaded right there)
+#pragma unroll
+                        for (int step = 0; step < 2; ++step) {
+                            needed_here(sc_pre[step]);
+#pragma unroll
+                            for (int c3 = 0; c3 < 3; ++c3) needed_here(rpre[step][c3]);
+                        }
 #pragma unroll
                         for (int step = 0; step < 2; ++step) {
                             const int s2 = 16 * step + 2 * w + hf;
                             const int gm = em0 + 64 * h + 32 * q + s2;
                             const bool row_ok = gm < p.M;
-                            const float sc = (row_ok && p.rowscale)
-                                                 ? p.rowscale[p.rps_shift >= 0 ? gm >> p.rps_shift : gm / p.rows_per_sample] : 1.0f;
+                            const float sc = sc_pre[step];
                             f32x4v o[3];
                             float s1 = 0.f, sq = 0.f;
 #pragma unroll

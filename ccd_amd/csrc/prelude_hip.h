@@ -75,6 +75,16 @@ __device__ __forceinline__ void buf_load16_late(buf_u32x4& dst, buf_desc r, unsi
 }
 template <int N>
 __device__ __forceinline__ void vm_arrived(buf_u32x4& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+a"(a) : "n"(N)); }
+// "this value is needed HERE": the compiler places its wait for a load in front of the first instruction that reads the result.
+// In an unrolled loop that consumes several prefetched rows and stores after each, that puts a wait for row i + 1 BEHIND the
+// stores of row i - and with loads and stores pending on the one vmcnt the compiler makes it `s_waitcnt vmcnt(0)`: the store
+// round trip is paid once per row.  Touching every prefetched value before the first store moves all those waits in front.
+template <typename T>
+__device__ __forceinline__ void needed_here(T& v) {
+#ifndef CCD_LAB_NO_NEEDED_HERE      // (lab build: the A/B of this placement)
+    asm volatile("" : "+v"(v));
+#endif
+}
 // streaming variants: non-temporal cache policy (aux = 2, "nt"): data that is touched once must not push the L2-resident
 // operands (weights) of the same kernel out of the XCD's 4-MiB L2
 __device__ __forceinline__ buf_u32x4 buf_load16_nt(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset) {
