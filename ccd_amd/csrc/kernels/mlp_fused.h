@@ -278,10 +278,17 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
         const int row = r0 + lq, grow = row < p.M ? row : p.M - 1;
         // DropPath: out = x + sc * (h . W2^T + b2), sc per sample (0 for a dropped one).  A tile of dropped samples only
         // (rows_per_sample a multiple of the tile height) skips the products altogether.
-        float sc = 1.0f;
-        if (p.rowscale) sc = p.rowscale[grow / p.rows_per_sample];
-        const bool tile_dead = p.rowscale != nullptr && p.rows_per_sample % MLP_BM == 0 &&
-                               p.rowscale[m0 / p.rows_per_sample] == 0.0f;
+        // A tile inside ONE sample has one scale: read through the scalar cache (lgkmcnt).  A vector load here - even on a path
+        // that is not taken - puts `s_waitcnt vmcnt(0)` at the top of every tile: the weight ring's requests and the previous
+        // tile's stores drained before the tile's own rows are even requested.  A tile that spans samples reads its per-row
+        // scale where it is used, in the epilogue.
+        float sc_tile = 1.0f;
+        bool tile_dead = false;
+        const bool one_sample = p.rows_per_sample % MLP_BM == 0;
+        if (p.rowscale && one_sample) {
+            sc_tile = scalar_load_f32(p.rowscale + uniform_i32(m0 / p.rows_per_sample));
+            tile_dead = sc_tile == 0.0f;
+        }
         if (tile_dead) {
             // x_out = x, y_next = LayerNorm(x): half a wave per row, row sums by shuffles (as gemm_row384.h's epilogue)
             constexpr int C3 = (E / 4 + 31) / 32;              // 16-byte chunks of a row per lane
@@ -497,6 +504,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
             }
         }
         // ---- epilogue: rows are complete inside their two lanes (lane, lane ^ 32).
+        const float sc = (p.rowscale && !one_sample) ? p.rowscale[grow / p.rows_per_sample] : sc_tile;
         // Pass A: out = x + (acc + b2) * sc written back into the accumulators, LayerNorm statistics on the way; the
         // residual rows stream in two tiles ahead of their use.
         float s1 = 0.f, s2 = 0.f;

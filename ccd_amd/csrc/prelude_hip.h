@@ -85,6 +85,14 @@ __device__ __forceinline__ void needed_here(T& v) {
     asm volatile("" : "+v"(v));
 #endif
 }
+// A wave-uniform fp32 through the SCALAR cache: retired by lgkmcnt, so its wait does not drain the vector memory queue (the weight
+// ring, the previous tile's stores) the way a vector load's `vmcnt(0)` does.  The address must be wave-uniform; the data must
+// not be written by this kernel (the scalar cache is invalidated at kernel boundaries only).
+__device__ __forceinline__ float scalar_load_f32(const float* p) {
+    float v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
 // streaming variants: non-temporal cache policy (aux = 2, "nt"): data that is touched once must not push the L2-resident
 // operands (weights) of the same kernel out of the XCD's 4-MiB L2
 __device__ __forceinline__ buf_u32x4 buf_load16_nt(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset) {
