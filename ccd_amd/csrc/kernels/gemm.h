@@ -235,11 +235,14 @@ __device__ __forceinline__ void gemm_store_tn(char* tile, const u32x4 (&r)[4]) {
     }
 }
 
+// bias8: the 8 bias values of columns gn .. gn + 7 when the caller loaded them ONCE per tile (gemm.h's row pass: the same 8
+// columns in every pass - loaded inside the pass they sit behind the previous pass's store, and a wait behind a store is
+// `s_waitcnt vmcnt(0)`: one store round trip per pass, 8 per tile; the head's K = 256 products spent 2/3 of a tile there)
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_row8(const GemmParams& p, int gm, int gn, float* v) {
+__device__ __forceinline__ void gemm_epilogue_row8(const GemmParams& p, int gm, int gn, float* v, const float* bias8 = nullptr) {
     if (EPI != EPI_ATOMIC && EPI != EPI_DGELU && p.bias) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += p.bias[gn + e];
+        for (int e = 0; e < 8; ++e) v[e] += bias8 ? bias8[e] : p.bias[gn + e];
     }
     if (EPI == EPI_BF16) {
         *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = pack8(v);
@@ -531,6 +534,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         } else {
             const bool want_stats = p.colsum != nullptr || p.colsumsq != nullptr;
             const bool publish = tiles_n > 1 || !has_next;   // defer while the next tile has the same columns
+            float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (EPI != EPI_DGELU && p.bias && en0 + (t & 15) * 8 < p.N) {
+                const f32x4v b0 = *reinterpret_cast<const f32x4v*>(p.bias + en0 + (t & 15) * 8);
+                const f32x4v b1 = *reinterpret_cast<const f32x4v*>(p.bias + en0 + (t & 15) * 8 + 4);
+                bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+                bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) needed_here(bias8[e]);
+            }
 #pragma unroll
             for (int pass = 0; pass < 8; ++pass) {       // unrolled: the 16 LDS reads go out first, the stores stream
                 const int row = pass * 16 + (t >> 4), col = (t & 15) * 8;
@@ -547,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
                         const int n = gm >> hw, oy = (gm >> p.g_w_log2) & ((1 << p.g_h_log2) - 1), ox = gm & ((1 << p.g_w_log2) - 1);
                         gm_out = (((n << (p.g_h_log2 + 1)) + 2 * oy + p.c_py) << (p.g_w_log2 + 1)) + 2 * ox + p.c_px;
                     }
-                    if (LAB_ON(2)) gemm_epilogue_row8<EPI>(p, gm_out, gn, v);
+                    if (LAB_ON(2)) gemm_epilogue_row8<EPI>(p, gm_out, gn, v, bias8);
                     if ((EPI == EPI_DGELU || EPI == EPI_BF16) && want_stats) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * v[e]; }
