@@ -57,16 +57,24 @@ static int ccd_launch_gemm(ccd::GemmParams p, int epilogue, int splits, void* st
     return ccd_rt_last_error();
 }
 
+// blocks of 256 threads for a grid-stride elementwise kernel over `total` 16-byte chunks, `per_thread` chunks per loop trip:
+// enough to give every thread one trip, at most 16 blocks per CU (the stride stays a multiple of 256)
+static unsigned ccd_stream_blocks(long total, int per_thread) {
+    long blocks = (total + 256L * per_thread - 1) / (256L * per_thread);
+    const long cap = 16L * ccd_rt_num_cus();
+    if (blocks > cap) blocks = cap;
+    return (unsigned)(blocks < 1 ? 1 : blocks);
+}
 // launch geometry of the column reductions (colsum_bf16, bn_relu_bwd_reduce): cgn = 2^cgn_log2 column groups of 8
-// per 1024-thread block (<= 32), every block streams >= 1 MiB, at most 2 blocks per CU (the publishing atomics are
-// the expensive part: few, fat blocks)
+// per 1024-thread block (<= 32), every block streams >= 128 KiB (1 MiB left a 17-MB tensor on 32 of the 256 CUs: 60 us where
+// 10 do), at most 2 blocks per CU
 static void ccd_reduce_geometry(long rows, int N, int* cgn_log2, int* col_blocks, int* rows_per_block, int* row_blocks) {
     int lg = 0;
     while (lg < 5 && (8 << lg) < N) ++lg;
     const int cgn = 1 << lg, rln = ccd::COLSUM_THREADS >> lg;
     *cgn_log2 = lg;
     *col_blocks = (N + 8 * cgn - 1) / (8 * cgn);
-    long rb = (rows * (long)(16 * cgn) + (1L << 20) - 1) / (1L << 20);           // bytes per block-column / 1 MiB
+    long rb = (rows * (long)(16 * cgn) + (1L << 17) - 1) / (1L << 17);           // bytes per block-column / 128 KiB
     const long cap = (2L * ccd_rt_num_cus() + *col_blocks - 1) / *col_blocks;
     if (rb > cap) rb = cap;
     if (rb < 1) rb = 1;
@@ -722,7 +730,7 @@ int ccd_region_pool_fwd(const ccd_bf16* feat, const uint8_t* tok_plane, const fl
                         const int* offset, const int* total, ccd_bf16* rows, int batch, int E, void* stream) {
     CCD_CHECK(feat && tok_plane && tok_coef && nsel && offset && total && rows && batch > 0 && E > 0, CCD_EINVAL);
     const size_t smem = (size_t)ccd::CM_PLANES * E * 4;
-    CCD_CHECK(smem <= 120 * 1024, CCD_ESHAPE);
+    CCD_CHECK(smem <= 120 * 1024 && E % 2 == 0, CCD_ESHAPE);
     CCD_LAUNCH(ccd::region_pool_fwd_kernel, dim3(2 * batch), dim3(256), smem, stream, feat, tok_plane, tok_coef, nsel,
                offset, total, rows, batch, E);
     return ccd_rt_last_error();
@@ -968,8 +976,9 @@ int ccd_bn_relu_fwd(const ccd_bf16* x, long ldx, const float* mean_rstd, const f
     CCD_CHECK(x && mean_rstd && gamma && beta && y && CCD_ALIGNED16(x) && CCD_ALIGNED16(y), CCD_EINVAL);
     if (rows == 0) return CCD_OK;
     CCD_CHECK(rows > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, CCD_ESHAPE);
+    CCD_CHECK(C <= 256, CCD_ESHAPE);                          // (the grid-stride keeps a thread on its channels: C / 8 divides 256)
     const long total = rows * (C / 8);
-    CCD_LAUNCH(ccd::bn_relu_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, ldx, mean_rstd,
+    CCD_LAUNCH(ccd::bn_relu_fwd_kernel, dim3(ccd_stream_blocks(total, 4)), dim3(256), 0, stream, x, ldx, mean_rstd,
                gamma, beta, y, ldy, rows, C);
     return ccd_rt_last_error();
 }
@@ -994,7 +1003,7 @@ int ccd_bn_relu_bwd_apply(const ccd_bf16* dy, long lddy, const ccd_bf16* x, long
     if (rows == 0) return CCD_OK;
     CCD_CHECK(rows > 0 && C > 0 && C % 8 == 0 && C <= 256 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, CCD_ESHAPE);
     const long total = rows * (C / 8);
-    CCD_LAUNCH(ccd::bn_relu_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dy, lddy, x,
+    CCD_LAUNCH(ccd::bn_relu_bwd_apply_kernel, dim3(ccd_stream_blocks(total, 2)), dim3(256), 0, stream, dy, lddy, x,
                ldx, mean_rstd, gamma, beta, red, count, red_local, dgamma, dbeta, dx, lddx, rows, C);
     return ccd_rt_last_error();
 }

@@ -49,24 +49,51 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, float count,
     running_var[c] = (1.0f - momentum) * running_var[c] + momentum * var * (count / (count - 1.0f));
 }
 
-// y = relu((x - mean) * rstd * gamma + beta); x [rows, ldx], y [rows, ldy] bf16; 8 channels per thread
+// y = relu((x - mean) * rstd * gamma + beta); x [rows, ldx], y [rows, ldy] bf16; 8 channels per thread.
+// A thread walks chunks 256 apart (a multiple of C / 8: it keeps ITS 8 channels, their 32 parameters are loaded once; the row
+// index advances by 256 / (C / 8) - as one chunk per thread the kernel did a 64-bit division and 32 parameter loads per 16-byte
+// data load and ran at 2.0 TB/s), four chunks in flight per thread.
 __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const bf16_t* __restrict__ x, long ldx,
                                                           const float* __restrict__ mean_rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           bf16_t* __restrict__ y, long ldy, long rows, int C) {
     const int c8 = C >> 3;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * c8) return;
-    const long r = i / c8;
+    // a block streams ONE contiguous range of chunks (a multiple of 256, so a thread stays on its 8 channels): linear walks
+    // reach the HBM rate, a grid-wide stride (16 MB between a thread's chunks) stayed at 2.6 TB/s
+    const long total = rows * c8, T = 256;
+    const long per_block = (((total + gridDim.x - 1) / gridDim.x + 255) / 256) * 256;
+    long i = (long)blockIdx.x * per_block + threadIdx.x;
+    const long end = (i - threadIdx.x + per_block) < total ? (i - threadIdx.x + per_block) : total;
+    if (i >= end) return;
     const int c = (int)(i % c8) * 8;
-    float v[8];
-    unpack8(*reinterpret_cast<const u32x4*>(x + r * ldx + c), v);
+    float mu[8], rs[8], ga[8], be[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float o = (v[e] - mean_rstd[c + e]) * mean_rstd[C + c + e] * gamma[c + e] + beta[c + e];
-        v[e] = o > 0.f ? o : 0.f;
+    for (int e = 0; e < 8; ++e) { mu[e] = mean_rstd[c + e]; rs[e] = mean_rstd[C + c + e]; ga[e] = gamma[c + e]; be[e] = beta[c + e]; }
+    auto one = [&](const u32x4& w) {
+        float v[8];
+        unpack8(w, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float o = (v[e] - mu[e]) * rs[e] * ga[e] + be[e];
+            v[e] = o > 0.f ? o : 0.f;
+        }
+        return pack8(v);
+    };
+    // (the row index advances by T / c8 per stride: no 64-bit division per chunk - that alone held the kernel at 2 TB/s)
+    long r = i / c8;
+    const long dr = T / c8;
+    for (; i + 3 * T < end; i += 4 * T, r += 4 * dr) {
+        u32x4 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const u32x4*>(x + (r + u * dr) * ldx + c);
+        // (all four have arrived before the first store: left alone the scheduler sinks every load next to its use - one load
+        // in flight per thread, each behind `vmcnt(0)`, i.e. behind the previous store's round trip: 2.6 TB/s instead of 6)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) needed_here(w[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<u32x4*>(y + (r + u * dr) * ldy + c) = one(w[u]);
     }
-    *reinterpret_cast<u32x4*>(y + r * ldy + c) = pack8(v);
+    for (; i < end; i += T, r += dr) *reinterpret_cast<u32x4*>(y + r * ldy + c) = one(*reinterpret_cast<const u32x4*>(x + r * ldx + c));
 }
 
 // red[0:C] += sum dy*[y>0], red[C:2C] += sum dy*[y>0]*xhat     (dy [rows, lddy] bf16); geometry as colsum_bf16
@@ -128,7 +155,7 @@ __global__ __launch_bounds__(COLSUM_THREADS) void bn_relu_bwd_reduce_kernel(cons
     }
 }
 
-// dx = gamma*rstd*(dy*[y>0] - red0/count - xhat*red1/count)      (red already summed over ranks)
+// dx = gamma*rstd*(dy*[y>0] - red0/count - xhat*red1/count)      (red already summed over ranks); grid-stride as bn_relu_fwd
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const bf16_t* __restrict__ dy, long lddy,
                                                                 const bf16_t* __restrict__ x, long ldx,
                                                                 const float* __restrict__ mean_rstd,
@@ -143,22 +170,48 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const bf16_t* __
         dgamma[threadIdx.x] += red_local[C + threadIdx.x];
     }
     const int c8 = C >> 3;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * c8) return;
-    const long r = i / c8;
+    const long total = rows * c8, T = 256;
+    const long per_block = (((total + gridDim.x - 1) / gridDim.x + 255) / 256) * 256;
+    long i = (long)blockIdx.x * per_block + threadIdx.x;
+    const long end = (i - threadIdx.x + per_block) < total ? (i - threadIdx.x + per_block) : total;
+    if (i >= end) return;
     const int c = (int)(i % c8) * 8;
-    float xv[8], dv[8], o[8];
-    unpack8(*reinterpret_cast<const u32x4*>(x + r * ldx + c), xv);
-    unpack8(*reinterpret_cast<const u32x4*>(dy + r * lddy + c), dv);
     const float inv = 1.0f / count;
+    float mu[8], rs[8], ga[8], be[8], k0[8], k1[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float rs = mean_rstd[C + c + e], ga = gamma[c + e];
-        const float xh = (xv[e] - mean_rstd[c + e]) * rs;
-        const float d = (xh * ga + beta[c + e]) > 0.f ? dv[e] : 0.f;
-        o[e] = ga * rs * (d - red[c + e] * inv - xh * red[C + c + e] * inv);
+        mu[e] = mean_rstd[c + e]; rs[e] = mean_rstd[C + c + e]; ga[e] = gamma[c + e]; be[e] = beta[c + e];
+        k0[e] = red[c + e] * inv; k1[e] = red[C + c + e] * inv;
     }
-    *reinterpret_cast<u32x4*>(dx + r * lddx + c) = pack8(o);
+    auto one = [&](const u32x4& xw, const u32x4& dw) {
+        float xv[8], dv[8], o[8];
+        unpack8(xw, xv);
+        unpack8(dw, dv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xh = (xv[e] - mu[e]) * rs[e];
+            const float d = (xh * ga[e] + be[e]) > 0.f ? dv[e] : 0.f;
+            o[e] = ga[e] * rs[e] * (d - k0[e] - xh * k1[e]);
+        }
+        return pack8(o);
+    };
+    long r = i / c8;
+    const long dr = T / c8;
+    for (; i + 1 * T < end; i += 2 * T, r += 2 * dr) {      // (two chunks of x and dy = four 16-byte loads in flight)
+        u32x4 xw[2], dw[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            xw[u] = *reinterpret_cast<const u32x4*>(x + (r + u * dr) * ldx + c);
+            dw[u] = *reinterpret_cast<const u32x4*>(dy + (r + u * dr) * lddy + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { needed_here(xw[u]); needed_here(dw[u]); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<u32x4*>(dx + (r + u * dr) * lddx + c) = one(xw[u], dw[u]);
+    }
+    for (; i < end; i += T, r += dr)
+        *reinterpret_cast<u32x4*>(dx + r * lddx + c) = one(*reinterpret_cast<const u32x4*>(x + r * ldx + c),
+                                                           *reinterpret_cast<const u32x4*>(dy + r * lddy + c));
 }
 
 // ------------------------------------------------------------------------------- classifier conv 3x3, C -> 2

@@ -92,9 +92,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         dbi[i] = zero;
     }
     for (int row = row_begin + w; row < row_end; row += 4) {
-        const float mu = mean[row], rs = rstd[row];
+        // everything the row needs is requested up front - x, dy AND the gradient row it accumulates into (requested behind the
+        // two wave reductions it used to wait for a second HBM round trip per row) - and has arrived before the first store
         const float* xr = x + (long)row * E;
         const bf16_t* dyr = dy + (long)row * E;
+        float* gr = g + (long)row * E;
+        f32x4v xv[LN_STEPS], gv[LN_STEPS];
+        u32x2 dw[LN_STEPS];
+#pragma unroll
+        for (int i = 0; i < LN_STEPS; ++i) {
+            const int c = LN_VEC * (lane + 64 * i);
+            xv[i] = zero; gv[i] = zero; dw[i] = u32x2{0u, 0u};
+            if (c < E) {
+                xv[i] = *reinterpret_cast<const f32x4v*>(xr + c);
+                dw[i] = *reinterpret_cast<const u32x2*>(dyr + c);
+                if (ACCUM) gv[i] = *reinterpret_cast<const f32x4v*>(gr + c);
+            }
+        }
+        const float mu = mean[row], rs = rstd[row];
+        const float sc = (gb && rowscale) ? rowscale[row / rows_per_sample] : 1.0f;
         f32x4v xh[LN_STEPS], d[LN_STEPS];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -103,10 +119,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             xh[i] = zero;
             d[i] = zero;
             if (c < E) {
-                const f32x4v xv = *reinterpret_cast<const f32x4v*>(xr + c);
-                const u32x2 dw = *reinterpret_cast<const u32x2*>(dyr + c);
-                const f32x4v dyv = {bf_lo(dw.x), bf_hi(dw.x), bf_lo(dw.y), bf_hi(dw.y)};
-                xh[i] = (xv - mu) * rs;
+                const f32x4v dyv = {bf_lo(dw[i].x), bf_hi(dw[i].x), bf_lo(dw[i].y), bf_hi(dw[i].y)};
+                xh[i] = (xv[i] - mu) * rs;
                 d[i] = dyv * gam[i];
                 dg[i] += dyv * xh[i];
                 db[i] += dyv;
@@ -117,14 +131,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         }
         s1 = wave_sum(s1) / (float)E;
         s2 = wave_sum(s2) / (float)E;
-        float* gr = g + (long)row * E;
-        const float sc = (gb && rowscale) ? rowscale[row / rows_per_sample] : 1.0f;
+        if (ACCUM) {
+#pragma unroll
+            for (int i = 0; i < LN_STEPS; ++i) needed_here(gv[i]);
+        }
 #pragma unroll
         for (int i = 0; i < LN_STEPS; ++i) {
             const int c = LN_VEC * (lane + 64 * i);
             if (c < E) {
                 f32x4v dx = (d[i] - s1 - xh[i] * s2) * rs;
-                if (ACCUM) dx += *reinterpret_cast<const f32x4v*>(gr + c);
+                if (ACCUM) dx += gv[i];
                 *reinterpret_cast<f32x4v*>(gr + c) = dx;
                 if (gb) {
                     const f32x4v o = dx * sc;
