@@ -117,10 +117,7 @@ __global__ __launch_bounds__(256) void dino_loss_bwd_kernel(const float* __restr
     const float* s = s_logits + (long)i * K;
     const float* tr = t_logits + (long)j * K;
     bf16_t* d = d_logits + (long)i * K;
-    for (int k = threadIdx.x * 4; k < K; k += 1024) {
-        const f32x4v sv = *reinterpret_cast<const f32x4v*>(s + k);
-        const f32x4v tv = *reinterpret_cast<const f32x4v*>(tr + k);
-        const f32x4v cv = *reinterpret_cast<const f32x4v*>(center + k);
+    auto one = [&](const f32x4v& sv, const f32x4v& tv, const f32x4v& cv, int k) {
         float o[4];
         const float sx[4] = {sv.x, sv.y, sv.z, sv.w}, tx[4] = {tv.x - cv.x, tv.y - cv.y, tv.z - cv.z, tv.w - cv.w};
 #pragma unroll
@@ -130,7 +127,25 @@ __global__ __launch_bounds__(256) void dino_loss_bwd_kernel(const float* __restr
         pk.x = pack_bf2(o[0], o[1]);
         pk.y = pack_bf2(o[2], o[3]);
         *reinterpret_cast<u32x2*>(d + k) = pk;
+    };
+    // two trips at a time, their six loads in front of the first store (one trip per iteration put every trip's loads behind
+    // the previous trip's store: `vmcnt(0)`, the store's round trip, 64 times per row)
+    int k = threadIdx.x * 4;
+    for (; k + 1024 < K; k += 2048) {
+        f32x4v sv[2], tv[2], cv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            sv[u] = *reinterpret_cast<const f32x4v*>(s + k + 1024 * u);
+            tv[u] = *reinterpret_cast<const f32x4v*>(tr + k + 1024 * u);
+            cv[u] = *reinterpret_cast<const f32x4v*>(center + k + 1024 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { needed_here(sv[u]); needed_here(tv[u]); needed_here(cv[u]); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) one(sv[u], tv[u], cv[u], k + 1024 * u);
     }
+    for (; k < K; k += 1024)
+        one(*reinterpret_cast<const f32x4v*>(s + k), *reinterpret_cast<const f32x4v*>(tr + k), *reinterpret_cast<const f32x4v*>(center + k), k);
 }
 
 // out[c] += sum over rows [r0, r1) of x[r, c]   (fp32; teacher logits -> batch centre), rows = rows_mul * d_rows[0]
@@ -144,7 +159,15 @@ __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict
     const int r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     if (k >= K || r0 >= r1) return;
     f32x4v a = {0.f, 0.f, 0.f, 0.f};
-    for (int r = r0; r < r1; ++r) {
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {                             // four rows in flight (one load per trip left the walk latency-bound)
+        f32x4v v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4v*>(x + (long)(r + u) * K + k);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    }
+    for (; r < r1; ++r) {
         const f32x4v v = *reinterpret_cast<const f32x4v*>(x + (long)r * K + k);
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }

@@ -75,21 +75,44 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ param, c
         const float cc = clip / (sqrtf(norm2[seg]) + 1e-6f);
         if (cc < 1.0f) coef = cc;
     }
-    const long base = chunk_begin[c];
+    const long base = chunk_begin[c];                        // 64-element aligned (arena.py ALIGN): 16-byte accesses
     const int len = chunk_len[c];
-    for (int i = threadIdx.x; i < len; i += 256) {
-        const long k = base + i;
-        const float g = grad[k] * coef;
-        float p = param[k];
+    auto one = [&](float g, float& p, float& m, float& v) {
+        g *= coef;
         p *= 1.0f - h.lr_wd;
-        const float m = exp_avg[k] * beta1 + (1.0f - beta1) * g;
-        const float v = exp_avg_sq[k] * beta2 + (1.0f - beta2) * g * g;
+        m = m * beta1 + (1.0f - beta1) * g;
+        v = v * beta2 + (1.0f - beta2) * g * g;
         const float denom = sqrtf(v) * h.inv_sqrt_bc2 + eps;
         p -= h.step_size * (m / denom);
-        param[k] = p;
-        exp_avg[k] = m;
-        exp_avg_sq[k] = v;
-        if (mirror) mirror[k] = f2bf(p);
+    };
+    for (int i4 = threadIdx.x * 4; i4 < len; i4 += 1024) {
+        const long k = base + i4;
+        if (i4 + 3 < len) {                                  // four 16-byte loads in flight, then three 16-byte stores (+ 8 bytes)
+            const f32x4v gq = *reinterpret_cast<const f32x4v*>(grad + k);
+            const f32x4v pq = *reinterpret_cast<const f32x4v*>(param + k);
+            const f32x4v mq = *reinterpret_cast<const f32x4v*>(exp_avg + k);
+            const f32x4v vq = *reinterpret_cast<const f32x4v*>(exp_avg_sq + k);
+            const float g[4] = {gq.x, gq.y, gq.z, gq.w};
+            float p[4] = {pq.x, pq.y, pq.z, pq.w}, m[4] = {mq.x, mq.y, mq.z, mq.w}, v[4] = {vq.x, vq.y, vq.z, vq.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) one(g[e], p[e], m[e], v[e]);
+            *reinterpret_cast<f32x4v*>(param + k) = f32x4v{p[0], p[1], p[2], p[3]};
+            *reinterpret_cast<f32x4v*>(exp_avg + k) = f32x4v{m[0], m[1], m[2], m[3]};
+            *reinterpret_cast<f32x4v*>(exp_avg_sq + k) = f32x4v{v[0], v[1], v[2], v[3]};
+            if (mirror) {
+                u32x2 o;
+                o.x = pack_bf2(p[0], p[1]);
+                o.y = pack_bf2(p[2], p[3]);
+                *reinterpret_cast<u32x2*>(mirror + k) = o;
+            }
+        } else {
+            for (int i = i4; i < len; ++i) {
+                float p = param[base + i], m = exp_avg[base + i], v = exp_avg_sq[base + i];
+                one(grad[base + i], p, m, v);
+                param[base + i] = p; exp_avg[base + i] = m; exp_avg_sq[base + i] = v;
+                if (mirror) mirror[base + i] = f2bf(p);
+            }
+        }
     }
 }
 
