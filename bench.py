@@ -208,10 +208,6 @@ def main_finetune(a, world, rank, dev, use_dist):
                            "step_frac_of_mfma_peak": round(ips / world * gf_img / 1e3 / PEAK_BF16_TF, 4),
                            "final_loss": round(final_loss, 4)}}
         line.update(census)
-        if graphed is not None:
-            line["config"]["workload"] += ", step replayed as one HIP graph"
-            line["hip_graph"] = {"captures": graphed.captures, "replays": graphed.replays,
-                                 "roofline_source": "eager warm-up step (HIP events cannot be read out of a graph replay)"}
         if timer is not None:
             summ = timer.summary()
             key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])

@@ -54,3 +54,53 @@ def test_bench_refuses_more_gpus_than_present():
         pytest.skip("needs a node with fewer than 64 GPUs")
     r = _run(["--gpus", "64"], extra_env={"BENCH_BACKEND": "nccl"})
     assert r.returncode != 0 and "exposes" in r.stderr
+
+
+def test_bench_functions_use_only_names_they_can_see():
+    """bench.py's finetune / recognize paths only run on a GPU box: a name that exists in one `main_*` function and was pasted into
+    another (it happened: `graphed` in main_finetune) must fail HERE.  Every name a function loads is a local, an enclosing or
+    module-level name, or a builtin."""
+    import ast
+    import builtins
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    module_names = set(dir(builtins)) | {"__file__", "__name__", "__doc__"}
+    for node in tree.body:
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+            module_names.add(node.name)
+        elif isinstance(node, (ast.Import, ast.ImportFrom)):
+            module_names.update((a.asname or a.name).split(".")[0] for a in node.names)
+        elif isinstance(node, (ast.Assign, ast.AnnAssign, ast.AugAssign)):
+            for t in ast.walk(node):
+                if isinstance(t, ast.Name) and isinstance(t.ctx, ast.Store):
+                    module_names.add(t.id)
+
+    def bound_in(fn):
+        names = {a.arg for a in fn.args.args + fn.args.kwonlyargs}
+        if fn.args.vararg:
+            names.add(fn.args.vararg.arg)
+        if fn.args.kwarg:
+            names.add(fn.args.kwarg.arg)
+        for n in ast.walk(fn):
+            if isinstance(n, ast.Name) and isinstance(n.ctx, (ast.Store, ast.Del)):
+                names.add(n.id)
+            elif isinstance(n, (ast.Import, ast.ImportFrom)):
+                names.update((a.asname or a.name).split(".")[0] for a in n.names)
+            elif isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n is not fn:
+                names.add(n.name)
+                names.update(a.arg for a in getattr(n, "args", ast.arguments(args=[], kwonlyargs=[], posonlyargs=[], defaults=[], kw_defaults=[])).args)
+            elif isinstance(n, ast.Lambda):
+                names.update(a.arg for a in n.args.args)
+            elif isinstance(n, ast.ExceptHandler) and n.name:
+                names.add(n.name)
+            elif isinstance(n, ast.comprehension):
+                names.update(t.id for t in ast.walk(n.target) if isinstance(t, ast.Name))
+        return names
+
+    problems = []
+    for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+        visible = bound_in(fn) | module_names
+        for n in ast.walk(fn):
+            if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id not in visible:
+                problems.append((fn.name, n.id, n.lineno))
+    assert not problems, problems
