@@ -327,21 +327,24 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
         float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int ct = t % CT, rr = t / CT;                   // row pass: 8 columns per thread, RSTEP rows per step
         const int gn = en0 + 8 * ct;
+        // gelu'(u) epilogue: the pre-activations of a pass's rows are requested ONE PASS AHEAD - after the previous pass's rows have
+        // been waited for and before its stores go out - so their HBM latency is spent under that pass's row sweep (requested at the
+        // top of their own pass they cost a round trip per pass: four per tile, a quarter of the kernel)
+        u32x4 auxq[2][SROWS / RSTEP];
+        auto load_aux = [&](int q, u32x4 (&dst)[SROWS / RSTEP]) {
+#pragma unroll
+            for (int pass = 0; pass < SROWS / RSTEP; ++pass) {
+                const int s2 = pass * RSTEP + rr;
+                const int gm = em0 + WROWS * (s2 >> 5) + 32 * q + (s2 & 31);
+                dst[pass] = u32x4{0u, 0u, 0u, 0u};
+                if (gm < p.M && gn < p.N) dst[pass] = *reinterpret_cast<const u32x4*>(p.aux + (long)gm * p.ldaux + gn);
+            }
+        };
+        if (EPI == EPI_DGELU) load_aux(0, auxq[0]);
 #pragma unroll
         for (int q = 0; q < TI; ++q) {
             const int srow = 32 * wm + lq;
-            // gelu'(u) epilogue: the pre-activations of this pass's rows are requested BEFORE the staging writes and the
-            // barrier, so their HBM latency is spent there and not serially in front of every row of the row pass
-            u32x4 auxw[SROWS / RSTEP];
-            if (EPI == EPI_DGELU) {
-#pragma unroll
-                for (int pass = 0; pass < SROWS / RSTEP; ++pass) {
-                    const int s2 = pass * RSTEP + rr;
-                    const int gm = em0 + WROWS * (s2 >> 5) + 32 * q + (s2 & 31);
-                    auxw[pass] = u32x4{0u, 0u, 0u, 0u};
-                    if (gm < p.M && gn < p.N) auxw[pass] = *reinterpret_cast<const u32x4*>(p.aux + (long)gm * p.ldaux + gn);
-                }
-            }
+            u32x4 (&auxw)[SROWS / RSTEP] = auxq[q & 1];
             if (ewave_live)
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
@@ -370,6 +373,7 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
             if (EPI == EPI_DGELU) {           // every row of this pass has arrived BEFORE the first store (prelude: needed_here)
 #pragma unroll
                 for (int pass = 0; pass < SROWS / RSTEP; ++pass) needed_here(auxw[pass]);
+                if (q + 1 < TI) load_aux(q + 1, auxq[(q + 1) & 1]);
             }
 #pragma unroll
             for (int pass = 0; pass < SROWS / RSTEP; ++pass) {
