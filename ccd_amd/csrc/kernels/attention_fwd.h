@@ -79,6 +79,16 @@ __device__ __forceinline__ void att_store_row16(bf16_t* row_ptr, const f32x16 (&
         }
 }
 
+constexpr int ATT_DEPTH = 6;             // fragment reads in flight ahead of their MFMA
+struct AttMapQK {          // step k = 4 kt + kk: key tile kt (32 rows x 128 B = 4 KiB apart), k-step kk
+    static constexpr int reg(int k) { return k & 3; }
+    static constexpr int off(int k) { return (k >> 2) * 4096; }
+};
+struct AttMapPV {          // step k = 4 kt + 2 s2 + dt: address register 2 kt + s2, d tile dt (32 rows x 512 B apart)
+    static constexpr int reg(int k) { return k >> 1; }
+    static constexpr int off(int k) { return (k & 1) * 16384; }
+};
+
 __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, int heads, float scale) {
     char* smem = dynamic_smem();
@@ -95,6 +105,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const bf16_t* __r
     att_stage_rows(k_base, row_stride, k_img);
     att_stage_transposed(v_base, row_stride, vt_img);
     __syncthreads();
+    const unsigned k_addr = lds_addr_of(k_img), vt_addr = lds_addr_of(vt_img);
 
 #pragma unroll 1
     for (int qt = 0; qt < 2; ++qt) {
@@ -117,16 +128,23 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const bf16_t* __r
         for (int ch = 0; ch < 2; ++ch) {
             f32x16 s[4];
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+            for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-                const int row = 128 * ch + 32 * kt + lq;
+            {   // S^T chunk = K rows . Q^T: the 16 K fragments are read by hand, ATT_DEPTH ahead of their MFMA (mlp_fused.h:
+                // mlp_product).  Left to the compiler every product sat behind its own read and `lgkmcnt(0)`: an LDS round trip
+                // per MFMA.  Row 128 ch + 32 kt + lq: the swizzle term (row >> 1) & 7 is the lane's, tiles are immediate offsets.
+                unsigned areg[4];
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int slot = (2 * kk + hf) ^ ((row >> 1) & 7);
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_img + row * 128 + slot * 16);
-                    s[kt] = mfma_32x32x16_bf16(kf, qf[kk], s[kt]);
-                }
+                for (int kk = 0; kk < 4; ++kk)
+                    areg[kk] = k_addr + (unsigned)(ch * 16384 + lq * 128 + ((((2 * kk + hf) ^ ((lq >> 1) & 7))) << 4));
+                mlp_product<16, ATT_DEPTH, AttMapQK, MlpNoExtra>(
+                    areg,
+                    [&](auto K, const bf16x8& kf) {
+                        constexpr int k = decltype(K)::value;
+                        s[k >> 2] = mfma_32x32x16_bf16(kf, qf[k & 3], s[k >> 2]);
+                    },
+                    [](auto) {});
             }
             float cm = -3.0e38f;
 #pragma unroll
@@ -153,22 +171,24 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const bf16_t* __r
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            {   // O^T += V^T . P: fragment (kt, s2, dt) = V^T rows 32 dt + lq, keys 16 ks .. + 15 with ks = 2 (4 ch + kt) + s2; the
+                // swizzle XORs the low bits of ks with the lane's (d & 15): one address register per ks & 7 = 2 kt + s2
+                unsigned vreg[8];
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+                for (int j = 0; j < 8; ++j)
+                    vreg[j] = vt_addr + (unsigned)(lq * 512 + ch * 256 + ((hf ^ (lq & 1)) << 4) + ((j ^ ((lq >> 1) & 7)) << 5));
+                bf16x8 pf;
+                mlp_product<16, ATT_DEPTH, AttMapPV, MlpNoExtra>(
+                    vreg,
+                    [&](auto K, const bf16x8& vf) {
+                        constexpr int k = decltype(K)::value, kt = k >> 2, s2 = (k >> 1) & 1, dt = k & 1;
+                        if constexpr (dt == 0) {
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    bf16x8 pf;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) pf[e] = (short)f2bf(s[kt][8 * s2 + e]);
-                    const int ks = 2 * (4 * ch + kt) + s2;
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        const int d = 32 * dt + lq;
-                        const int slot = (2 * ks + hf) ^ (d & 15);
-                        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vt_img + d * 512 + slot * 16);
+                            for (int e = 0; e < 8; ++e) pf[e] = (short)f2bf(s[kt][8 * s2 + e]);
+                        }
                         o[dt] = mfma_32x32x16_bf16(vf, pf, o[dt]);
-                    }
-                }
+                    },
+                    [](auto) {});
             }
         }
         const float inv = 1.0f / sum;

@@ -107,8 +107,8 @@ constexpr int mlp_behind(int k) {
     }
     return n;
 }
-template <int N, int DEPTH, typename Map, typename Extra, typename Mma, typename Filler>
-__device__ __forceinline__ void mlp_product(const unsigned (&areg)[4], Mma mma, Filler filler) {
+template <int N, int DEPTH, typename Map, typename Extra, int NREG, typename Mma, typename Filler>
+__device__ __forceinline__ void mlp_product(const unsigned (&areg)[NREG], Mma mma, Filler filler) {
     bf16x8 fr[DEPTH];
     mlp_static_for<0, DEPTH>([&](auto K) {
         constexpr int k = decltype(K)::value;
