@@ -101,12 +101,6 @@ __device__ __forceinline__ bf16x8 attb_row_frag(const char* img, int row, int kk
 __device__ __forceinline__ bf16x8 attb_tr_frag(const char* img, int d, int ks, int hf) {
     return *reinterpret_cast<const bf16x8*>(img + d * 512 + (((2 * ks + hf) ^ (d & 15)) * 16));
 }
-// Hand-issued fragment reads (mlp_fused.h: mlp_product; attention_fwd.h says why): the two score products of a 32-row tile
-// read the SAME slots of two row images ATTB_IMG apart - step k = 2 kk + image, address register kk, the image an immediate.
-struct AttbMapS {
-    static constexpr int reg(int k) { return k >> 1; }
-    static constexpr int off(int k) { return (k & 1) * ATTB_IMG; }
-};
 __device__ __forceinline__ void attb_store_t(bf16_t* row_ptr, const f32x16 (&acc)[2], int hf, bool live = true) {
     att_store_row16(row_ptr, acc, hf, 1.0f, live);           // (attention_fwd.h: 16-byte stores after a half-wave exchange)
 }
@@ -190,7 +184,6 @@ __global__ __launch_bounds__(512) void attention_bwd_dq_kernel(const bf16_t* __r
     char* kt_img = smem + 2 * ATTB_IMG;
     float* cs = reinterpret_cast<float*>(smem + 3 * ATTB_IMG);       // [heads][64] column sums of dQ over this workgroup's blocks
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hf = lane >> 5, lq = lane & 31;
-    const unsigned k_addr = lds_addr_of(k_img), kt_addr = lds_addr_of(kt_img);       // (V's image sits ATTB_IMG behind K's)
     const int E = heads * ATT_D;
     if (bias_ws)
         for (int i = threadIdx.x; i < E; i += ATTB_THREADS) cs[i] = 0.f;     // (published by the first block's barrier)
@@ -250,30 +243,11 @@ __global__ __launch_bounds__(512) void attention_bwd_dq_kernel(const bf16_t* __r
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-            {   // S and dP of key tile kt: K and V row fragments, read by hand ahead of their MFMA
-                unsigned areg[4];
+            const int row = 32 * kt + lq;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    areg[kk] = k_addr + (unsigned)(kt * 4096 + lq * 128 + (((2 * kk + hf) ^ ((lq >> 1) & 7)) << 4));
-                mlp_product<8, 4, AttbMapS, MlpNoExtra>(         // (four ahead: with six the kernel spills at its 256 registers)
-                    areg,
-                    [&](auto K, const bf16x8& fr) {
-                        constexpr int k = decltype(K)::value;
-                        if constexpr ((k & 1) == 0) s = mfma_32x32x16_bf16(fr, qf[k >> 1], s);
-                        else dp = mfma_32x32x16_bf16(fr, dof[k >> 1], dp);
-                    },
-                    [](auto) {});
-            }
-            // the four K^T fragments of the dQ products are requested BEFORE the softmax arithmetic and land under it:
-            // (d tile dt, key step ks = 2 kt + s2) at kt_img + (32 dt + lq) * 512 + (((2 ks + hf) ^ (lq & 15)) << 4)
-            bf16x8 tf[4];
-            {
-                const unsigned tb = kt_addr + (unsigned)(lq * 512);
-                const unsigned t0 = tb + (unsigned)((((4 * kt + hf) ^ (lq & 15))) << 4), t1 = tb + (unsigned)((((4 * kt + 2 + hf) ^ (lq & 15))) << 4);
-                lds_read_frag<0>(tf[0], t0);
-                lds_read_frag<16384>(tf[1], t0);
-                lds_read_frag<0>(tf[2], t1);
-                lds_read_frag<16384>(tf[3], t1);
+            for (int kk = 0; kk < 4; ++kk) {
+                s = mfma_32x32x16_bf16(attb_row_frag(k_img, row, kk, hf), qf[kk], s);
+                dp = mfma_32x32x16_bf16(attb_row_frag(v_img, row, kk, hf), dof[kk], dp);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -285,17 +259,9 @@ __global__ __launch_bounds__(512) void attention_bwd_dq_kernel(const bf16_t* __r
                 bf16x8 dsf;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dsf[e] = (short)f2bf(s[8 * s2 + e]);
-                if (s2 == 0) {
-                    lds_wait_frag<3>(tf[0]);
-                    dq[0] = mfma_32x32x16_bf16(tf[0], dsf, dq[0]);
-                    lds_wait_frag<2>(tf[1]);
-                    dq[1] = mfma_32x32x16_bf16(tf[1], dsf, dq[1]);
-                } else {
-                    lds_wait_frag<1>(tf[2]);
-                    dq[0] = mfma_32x32x16_bf16(tf[2], dsf, dq[0]);
-                    lds_wait_frag<0>(tf[3]);
-                    dq[1] = mfma_32x32x16_bf16(tf[3], dsf, dq[1]);
-                }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    dq[dt] = mfma_32x32x16_bf16(attb_tr_frag(kt_img, 32 * dt + lq, 2 * kt + s2, hf), dsf, dq[dt]);
             }
         }
         attb_store_t(dqkv + ((long)view * ATT_T + q) * rs3 + head * ATT_D, dq, hf);
@@ -529,19 +495,14 @@ __global__ __launch_bounds__(512) void attention_bwd_dkv_tr_kernel(const bf16_t*
         auto scores = [&](int qt, f32x16& s, f32x16& dp) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-            const int f = attb_swz2(lq);                         // (the swizzle of row 32 qt + lq is the lane's)
-            unsigned areg[4];
+            const int row = 32 * qt + lq;
+            const int f = attb_swz2(row);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                areg[kk] = smem_addr + (unsigned)(buf * ATTB_TR_BUF + qt * 4096 + lq * 128 + (((2 * kk + hf) ^ f) << 4));
-            mlp_product<8, 6, AttbMapS, MlpNoExtra>(
-                areg,
-                [&](auto K, const bf16x8& fr) {
-                    constexpr int k = decltype(K)::value;
-                    if constexpr ((k & 1) == 0) s = mfma_32x32x16_bf16(fr, kf[k >> 1], s);      // S[q][key]  (Q image)
-                    else dp = mfma_32x32x16_bf16(fr, vf[k >> 1], dp);                            // dP[q][key] (dO image, ATTB_IMG behind)
-                },
-                [](auto) {});
+            for (int kk = 0; kk < 4; ++kk) {
+                const int off = row * 128 + (((2 * kk + hf) ^ f) << 4);
+                s = mfma_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(q_img + off), kf[kk], s);       // S[q][key]
+                dp = mfma_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(do_img + off), vf[kk], dp);    // dP[q][key]
+            }
         };
         f32x16 s, dp;
         scores(0, s, dp);
