@@ -33,6 +33,8 @@ SIGNATURES = {
     "ccd_gemm_tn": [P, L, P, L, I, I, I, I, P, L, F, I, P, I, P],
     "ccd_gemm_tn_colsum": [P, L, P, L, I, I, I, P, L, P, I, P],
     "ccd_gemm_tn_pair": [P, L, P, L, I, I, P, L, P, L, P, L, I, I, P, L, I, P],
+    "ccd_gemm_tn_pair_ws": [P, L, P, L, I, I, P, L, P, L, P, L, I, I, P, L, I, P, L, P],
+    "ccd_gemm_tn_pair_ws_floats": [I, I, I, I],
     "ccd_gemm_nt_lnbwd": [P, L, P, L, I, I, I, P, L, P, P, P, P, L, I, P, P, P, L, P, I, P, P],
     "ccd_mlp_fused": [P, L, P, L, P, P, L, P, P, L, P, I, P, L, P, P, F, P, L, P, P, P, L, P, L, I, I, I, P],
     "ccd_ln_fwd": [P, P, P, P, P, P, I, I, F, P],
@@ -92,7 +94,7 @@ SIGNATURES = {
     "ccd_tf_loss_bwd": [P, L, I, P, I, I, I, P, P, P, P, L, P],
     "ccd_greedy_step": [P, L, I, I, P, I, I, P, I, P],
 }
-_RESTYPES = {"ccd_build_info": C.c_char_p, "ccd_attention_bwd_ws_floats": L}
+_RESTYPES = {"ccd_build_info": C.c_char_p, "ccd_attention_bwd_ws_floats": L, "ccd_gemm_tn_pair_ws_floats": L}
 
 
 def bind(lib: C.CDLL) -> C.CDLL:

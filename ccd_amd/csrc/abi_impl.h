@@ -104,6 +104,7 @@ struct CcdPolicy {
     int cu_reserve = 0;         // compute units the persistent grids leave free (set while an RCCL gradient reducer is attached)
     int cu_reserve_window = -1; // -1: every launch leaves them free; N >= 0: only the next `cu_reserve_left` launches do (the reducer
     int cu_reserve_left = 0;    // re-arms it with N whenever it starts a bucket's all-reduce: the kernels that run beside the collective)
+    int tn_ws = 1;              // paired weight gradients: per-slice partial stores + a reduction pass when the caller lends a workspace (0 = fp32 atomics)
     int lab = 0;                // scratch switch for kernel experiments (tools/*_lab.py); 0 in production
 };
 struct CcdPolicyKey { const char* name; int CcdPolicy::*field; };
@@ -112,7 +113,7 @@ static const CcdPolicyKey ccd_policy_keys[] = {
     {"gemm_256_min_n", &CcdPolicy::gemm_256_min_n}, {"gemm_256_f32", &CcdPolicy::gemm_256_f32},
     {"gemm_256_deep", &CcdPolicy::gemm_256_deep}, {"gemm_row384", &CcdPolicy::gemm_row384},
     {"rowproj", &CcdPolicy::rowproj}, {"rowproj_min_m", &CcdPolicy::rowproj_min_m},
-    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"lab", &CcdPolicy::lab}};
+    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"tn_ws", &CcdPolicy::tn_ws}, {"lab", &CcdPolicy::lab}};
 static CcdPolicy& ccd_policy() {
     static CcdPolicy pol = [] {
         CcdPolicy q;
@@ -200,7 +201,7 @@ static int ccd_launch_gemm_row384(const ccd::GemmParams& p, int epilogue, void* 
 
 // gemm_tn384.h launch for one workgroup geometry (see ccd_launch_tn384 below)
 template <int WM, int WN, int STAGES, int TI, int TJ>
-static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, void* stream) {
+static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, float* ws, long ws_floats, void* stream) {
     using G = ccd::Tn3Geom<WM, WN, STAGES, TI, TJ>;
     const int per_cu = 8 / G::WAVES;
     const int t1 = (p.M / G::TP) * (p.N / G::TQ), t2 = (p.M2 / G::TP) * (p.N2 / G::TQ), slots = per_cu * ccd_grid_cus();
@@ -233,14 +234,29 @@ static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, void* stream) {
     p.k_per_split = rows_per(s1); p.work_items = s1;
     if (t2 > 0) { p.per2 = rows_per(s2); p.slices2 = s2; }
     p.units1 = units1; p.units2 = units2; p.m_fastest = xcds;
+    // split-K partial sums by plain stores + one reduction pass when the caller lent a workspace that holds every slice's plane
+    // (and there is more than one slice to add up); the fp32-atomic epilogue otherwise
+    const long need1 = (long)s1 * p.M * p.N, need2 = t2 > 0 ? (long)s2 * p.M2 * p.N2 : 0;
+    const bool use_ws = ws && need1 + need2 <= ws_floats && (s1 > 1 || s2 > 1) && p.ldc % 4 == 0 && (t2 == 0 || p.ldc2 % 4 == 0) &&
+                        !(p.rps_shift & 1);
+    p.ws = use_ws ? ws : nullptr;
+    p.ws2 = use_ws ? ws + need1 : nullptr;
     CCD_LAUNCH((ccd::gemm_tn384_kernel<WM, WN, STAGES, TI, TJ>), dim3(xcds * spx), dim3(G::THREADS), G::SMEM_BYTES, stream, p);
+    if (use_ws) {
+        ccd::Tn3ReduceParams r;
+        r.ws[0] = p.ws; r.ws[1] = p.ws2; r.C[0] = reinterpret_cast<float*>(p.C); r.C[1] = reinterpret_cast<float*>(p.C2);
+        r.ldc[0] = p.ldc; r.ldc[1] = p.ldc2; r.S[0] = s1; r.S[1] = t2 > 0 ? s2 : 0; r.P[0] = p.M; r.P[1] = t2 > 0 ? p.M2 : 0;
+        r.Q[0] = p.N; r.Q[1] = t2 > 0 ? p.N2 : 0; r.alpha = p.alpha;
+        const long n4 = ((long)p.M * p.N + (t2 > 0 ? (long)p.M2 * p.N2 : 0)) / 4;
+        CCD_LAUNCH(ccd::tn3_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, r);
+    }
     return ccd_rt_last_error();
 }
 
 extern "C" {
 
-int ccd_abi_version(void) { return 6; }   // 6: device-side momentum / DropPath seed (HIP graph of the training step); 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
-const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi6"; }
+int ccd_abi_version(void) { return 7; }   // 7: ccd_gemm_tn_pair_ws (split-K workspace instead of fp32 atomics); 6: device-side momentum / DropPath seed (HIP graph of the training step); 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
+const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi7"; }
 int ccd_policy_set(const char* key, int value) {
     CCD_CHECK(key, CCD_EINVAL);
     for (const CcdPolicyKey& k : ccd_policy_keys)
@@ -443,20 +459,33 @@ static int ccd_tn384_tiles(int geom, int P, int Q) {
 }
 static int ccd_launch_tn384(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P, int Q, float* C, long ldc,
                             const ccd_bf16* A2, long lda2, const ccd_bf16* B2, long ldb2, int P2, int Q2, float* C2, long ldc2,
-                            int Mc, float alpha, float* lab_out, void* stream) {
+                            int Mc, float alpha, float* lab_out, float* ws, long ws_floats, void* stream) {
     ccd::GemmParams p = ccd::GemmParams();
     p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.M = P; p.N = Q; p.K = Mc; p.C = C; p.ldc = ldc;
     p.A2 = A2; p.B2 = B2; p.lda2 = lda2; p.ldb2 = ldb2; p.M2 = P2; p.N2 = Q2; p.C2 = C2; p.ldc2 = ldc2;
     p.alpha = alpha; p.rps_shift = ccd_policy().lab; p.colsum_a = lab_out;
     const int geom = ccd_tn384_geom(P, Q, Mc);
     if (geom < 0 || (P2 > 0 && ccd_tn384_geom(P2, Q2, Mc) != geom)) return CCD_ESHAPE;
-    if (geom == 2) return ccd_launch_tn384_geom<4, 2, 3, 4, 2>(p, Mc, stream);
-    return ccd_launch_tn384_geom<4, 2, 4, 3, 3>(p, Mc, stream);
+    if (geom == 2) return ccd_launch_tn384_geom<4, 2, 3, 4, 2>(p, Mc, ws, ws_floats, stream);
+    return ccd_launch_tn384_geom<4, 2, 4, 3, 3>(p, Mc, ws, ws_floats, stream);
 }
 int ccd_gemm_tn_pair(const ccd_bf16* A1, long lda1, const ccd_bf16* B1, long ldb1, int P1, int Q1, float* C1, long ldc1,
                      const ccd_bf16* A2, long lda2, const ccd_bf16* B2, long ldb2, int P2, int Q2, float* C2, long ldc2, int Mc,
                      void* stream) {
+    return ccd_gemm_tn_pair_ws(A1, lda1, B1, ldb1, P1, Q1, C1, ldc1, A2, lda2, B2, ldb2, P2, Q2, C2, ldc2, Mc, nullptr, 0, stream);
+}
+long ccd_gemm_tn_pair_ws_floats(int P1, int Q1, int P2, int Q2) {
+    // one plane per contraction slice and problem; a launch never has more slices than workgroup slots (one per CU)
+    const long t1 = (long)(P1 / 384) * (Q1 / 192), t2 = (long)(P2 / 384) * (Q2 / 192);
+    if (P1 % 384 || Q1 % 192 || P2 % 384 || Q2 % 192 || t1 < 1 || t2 < 1) return 0;
+    const long cus = ccd_rt_num_cus();
+    return (cus / t1 + 8) * (long)P1 * Q1 + (cus / t2 + 8) * (long)P2 * Q2;
+}
+int ccd_gemm_tn_pair_ws(const ccd_bf16* A1, long lda1, const ccd_bf16* B1, long ldb1, int P1, int Q1, float* C1, long ldc1,
+                        const ccd_bf16* A2, long lda2, const ccd_bf16* B2, long ldb2, int P2, int Q2, float* C2, long ldc2, int Mc,
+                        float* ws, long ws_floats, void* stream) {
     CCD_CHECK(A1 && B1 && C1 && A2 && B2 && C2, CCD_EINVAL);
+    CCD_CHECK(!ws || (CCD_ALIGNED16(ws) && ws_floats >= 0), CCD_EINVAL);
     CCD_CHECK(CCD_ALIGNED16(A1) && CCD_ALIGNED16(B1) && CCD_ALIGNED16(C1) && CCD_ALIGNED16(A2) && CCD_ALIGNED16(B2) && CCD_ALIGNED16(C2),
               CCD_EINVAL);
     CCD_CHECK(P1 > 0 && Q1 > 0 && P2 > 0 && Q2 > 0 && Mc >= 0, CCD_EINVAL);
@@ -464,7 +493,8 @@ int ccd_gemm_tn_pair(const ccd_bf16* A1, long lda1, const ccd_bf16* B1, long ldb
     CCD_CHECK(lda1 % 8 == 0 && ldb1 % 8 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && ldc1 % 4 == 0 && ldc2 % 4 == 0, CCD_ESHAPE);
     if (ccd_policy().gemm_tn384 && ccd_policy().gemm_tn384 != 2 && ccd_tn384_geom(P1, Q1, Mc) >= 0 &&
         ccd_tn384_geom(P1, Q1, Mc) == ccd_tn384_geom(P2, Q2, Mc)) {
-        const int rc = ccd_launch_tn384(A1, lda1, B1, ldb1, P1, Q1, C1, ldc1, A2, lda2, B2, ldb2, P2, Q2, C2, ldc2, Mc, 1.0f, nullptr, stream);
+        const int rc = ccd_launch_tn384(A1, lda1, B1, ldb1, P1, Q1, C1, ldc1, A2, lda2, B2, ldb2, P2, Q2, C2, ldc2, Mc, 1.0f, nullptr,
+                                        ccd_policy().tn_ws ? ws : nullptr, ws_floats, stream);
         if (rc != CCD_ESHAPE) return rc;
     }
     const int rc = ccd_gemm_tn_impl(A1, lda1, B1, ldb1, P1, Q1, Mc, CCD_EPI_ATOMIC, C1, ldc1, 1.0f, 0, nullptr, 1, nullptr, stream);
@@ -491,7 +521,7 @@ static int ccd_gemm_tn_impl(const ccd_bf16* A, long lda, const ccd_bf16* B, long
     if (ccd_policy().gemm_tn384 && epilogue == CCD_EPI_ATOMIC && !d_rows && (!colsum_a || (ccd_policy().lab & 4)) &&
         ccd_tn384_geom(P, Q, Mc) >= 0 &&
         ccd_tn384_tiles(ccd_tn384_geom(P, Q, Mc), P, Q) >= ccd_policy().gemm_tn384_min_tiles) {
-        const int rc = ccd_launch_tn384(A, lda, B, ldb, P, Q, C, ldc, nullptr, 0, nullptr, 0, 0, 0, nullptr, 0, Mc, alpha, colsum_a, stream);
+        const int rc = ccd_launch_tn384(A, lda, B, ldb, P, Q, C, ldc, nullptr, 0, nullptr, 0, 0, 0, nullptr, 0, Mc, alpha, colsum_a, nullptr, 0, stream);
         if (rc != CCD_ESHAPE) return rc;
     }
     if (splits < 1) {   // as many slices as fit ONE resident wave of workgroups (2 per CU): one extra workgroup would

@@ -60,6 +60,10 @@ struct GemmParams {
     // per XCD); a group works on one contraction slice of ITS problem: slices2 slices of per2 rows for the second problem
     unsigned long long units1, units2;
     int slices2, per2;
+    // optional split-K workspaces (round 4): slice s of a problem STORES its tile into ws[(s * P + row) * Q + col] instead of adding it
+    // to C with fp32 atomics; tn3_reduce_kernel then adds the slices' sum to C in one pass.  null = atomic epilogue
+    float* ws;
+    float* ws2;
     float* colsumsq;        // optional [N] fp32: += column sums of squares (BatchNorm batch statistics), EPI_BF16 only
     // ---- implicit-GEMM convolution (NT, GATHER instantiation): A row r is pixel (n, oy, ox) of a 2^gh x 2^gw grid,
     // contraction index k = tap * cin + c reads source pixel (oy*s_mul + dy(tap), ox*s_mul + dx(tap)) of an s_h x s_w

@@ -91,8 +91,8 @@ __global__ __launch_bounds__(64 * WM * WN, 8 / (WM * WN)) void gemm_tn384_kernel
         if (s2 >= u2 * tiles2) return;
         tile = s2 % tiles2;
         slice = base2 + s2 / tiles2;
-        p.A = p.A2; p.B = p.B2; p.lda = p.lda2; p.ldb = p.ldb2; p.N = p.N2; p.C = p.C2; p.ldc = p.ldc2;
-        p.k_per_split = p.per2; p.work_items = p.slices2;
+        p.A = p.A2; p.B = p.B2; p.lda = p.lda2; p.ldb = p.ldb2; p.M = p.M2; p.N = p.N2; p.C = p.C2; p.ldc = p.ldc2;
+        p.k_per_split = p.per2; p.work_items = p.slices2; p.ws = p.ws2;
     }
     if (slice >= p.work_items) return;
     const int tiles_q = p.N / G::TQ;
@@ -345,6 +345,21 @@ __global__ __launch_bounds__(64 * WM * WN, 8 / (WM * WN)) void gemm_tn384_kernel
     // ---- epilogue: D[p][q], a lane owns column q = lq of 16 rows per tile; 32 lanes = 128 contiguous bytes per atomic
     float* C = reinterpret_cast<float*>(p.C);
     if (p.rps_shift & 1) return;                             // (lab bit 1: no epilogue)
+    if (p.ws) {
+        // round 4: this slice's tile leaves by PLAIN stores into its own plane of the workspace (a half wave = 128 contiguous bytes
+        // per store); tn3_reduce_kernel sums the planes into C.  The atomic form below moved 75 MB of fp32 atomics per MLP pair at
+        // ~1.4 TB/s (40 - 55 us per launch); stores + one reduction pass move the same bytes twice at streaming rate.
+        float* W = p.ws + (long)slice * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int jj = 0; jj < TJ; ++jj) {
+                float* cp = W + (long)(p0 + 32 * TI * wm + 32 * i + 4 * hf) * p.N + (q0 + 32 * TJ * wn + 32 * jj + lq);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cp[(long)((r & 3) + 8 * (r >> 2)) * p.N] = acc[i][jj][r];
+            }
+        return;
+    }
     // (Rotating the order of the 3 x 3 sub-tiles by the slice number, so that concurrent slices add onto different cache lines,
     // changed nothing - 0.1914 vs 0.1905 ms: the epilogue is bound by the L2's atomic throughput, not by same-line contention.)
 #pragma unroll
@@ -355,6 +370,42 @@ __global__ __launch_bounds__(64 * WM * WN, 8 / (WM * WN)) void gemm_tn384_kernel
 #pragma unroll
             for (int r = 0; r < 16; ++r) atomicAdd(cp + (long)((r & 3) + 8 * (r >> 2)) * p.ldc, acc[i][jj][r] * p.alpha);
         }
+}
+
+// C[P, Q] += alpha * sum over the S slice planes of ws ([S][P][Q] fp32, what gemm_tn384_kernel's workspace epilogue wrote), for up
+// to two problems in one launch: thread -> one float4 of the first problem's output, then of the second's.  16 planes x 16 B in
+// flight per thread; the planes were written a few microseconds ago (L2 / MALL resident where they fit).
+struct Tn3ReduceParams {
+    const float* ws[2];
+    float* C[2];
+    long ldc[2];
+    int S[2], P[2], Q[2];
+    float alpha;
+};
+__global__ __launch_bounds__(256) void tn3_reduce_kernel(Tn3ReduceParams p) {
+    const long n0 = (long)p.P[0] * p.Q[0] / 4, n1 = (long)p.P[1] * p.Q[1] / 4;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    int which = 0;
+    if (i >= n0) { i -= n0; which = 1; if (i >= n1) return; }
+    const long plane = (long)p.P[which] * p.Q[which];
+    const float* src = p.ws[which] + 4 * i;
+    f32x4v s = {0.f, 0.f, 0.f, 0.f};
+    const int S = p.S[which];
+    int k = 0;
+    for (; k + 4 <= S; k += 4) {
+        const f32x4v a = *reinterpret_cast<const f32x4v*>(src + (long)k * plane), b = *reinterpret_cast<const f32x4v*>(src + (long)(k + 1) * plane);
+        const f32x4v c = *reinterpret_cast<const f32x4v*>(src + (long)(k + 2) * plane), d = *reinterpret_cast<const f32x4v*>(src + (long)(k + 3) * plane);
+        s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y); s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
+    }
+    for (; k < S; ++k) {
+        const f32x4v a = *reinterpret_cast<const f32x4v*>(src + (long)k * plane);
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    const long e = 4 * i, row = e / p.Q[which], col = e % p.Q[which];
+    float* dst = p.C[which] + row * p.ldc[which] + col;
+    f32x4v o = *reinterpret_cast<f32x4v*>(dst);
+    o.x += p.alpha * s.x; o.y += p.alpha * s.y; o.z += p.alpha * s.z; o.w += p.alpha * s.w;
+    *reinterpret_cast<f32x4v*>(dst) = o;
 }
 
 }  // namespace ccd

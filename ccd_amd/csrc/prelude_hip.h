@@ -54,8 +54,17 @@ __device__ __forceinline__ buf_u32x4 buf_load16(buf_rsrc r, unsigned byte_offset
 __device__ __forceinline__ buf_u32x4 buf_load16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_offset, (int)uniform_offset, 0);
 }
+// STORE-DATA HAZARD (found in round 4 on rowgemm8.h, two waves per SIMD): a 16-byte buffer store reads its data registers a few
+// cycles AFTER it issues.  LLVM's hazard recogniser inserts the wait state only when the store has no SGPR soffset (GCNHazardRecognizer:
+// "this hazard only exists if the instruction is not using a register in the soffset field") - ours always has one, and on gfx950 a
+// VALU write to the first data register right behind the store (`v_mov_b32 v18, 0`, an address computation) reached memory instead
+// of the data in the last lanes of each half wave: run-to-run different values in rows 25 / 27 / 29 / 31 of a tile, lab_r04 notes in
+// DESIGN section 4d.  The empty-bodied `s_nop` below takes the data as an INPUT: the registers stay allocated until two wait
+// states have passed.
+__device__ __forceinline__ void buf_store_data_hold(buf_u32x4 v) { asm volatile("s_nop 1" : : "v"(v)); }
 __device__ __forceinline__ void buf_store16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset, buf_u32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)lane_offset, (int)uniform_offset, 0);
+    buf_store_data_hold(v);
 }
 // Buffer loads whose ARRIVAL THE KERNEL TRACKS (rowgemm.h's activation blocks).  The compiler's own bookkeeping turns every
 // wait for a builtin load inside a loop that also carries LDS-DMA requests and (from the previous tile's epilogue) stores
@@ -100,6 +109,7 @@ __device__ __forceinline__ buf_u32x4 buf_load16_nt(buf_rsrc r, unsigned lane_off
 }
 __device__ __forceinline__ void buf_store16_nt(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset, buf_u32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)lane_offset, (int)uniform_offset, 2);
+    buf_store_data_hold(v);
 }
 __device__ __forceinline__ void wave_nap(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); }        // ~n * 64 cycles
 __device__ __forceinline__ void wave_sleep(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127); }   // ~n * 8 k cycles

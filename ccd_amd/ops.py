@@ -225,9 +225,26 @@ def gemm_tn_colsum(a, b, out, colsum, *, splits=0):
     return out
 
 
-def gemm_tn_pair(a1, b1, out1, a2, b2, out2):
+_TN_WS = {}
+
+
+def tn_pair_workspace(device, P1, Q1, P2, Q2):
+    """The split-K workspace ccd_gemm_tn_pair_ws wants for these shapes: ONE fp32 buffer per device, grown to the largest
+    request (every launch that uses it runs on the calling stream, in order).  None where the grouped kernel does not apply."""
+    n = int(_lib.get().ccd_gemm_tn_pair_ws_floats(int(P1), int(Q1), int(P2), int(Q2)))
+    if n <= 0:
+        return None
+    ws = _TN_WS.get(device)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(n, dtype=torch.float32, device=device)
+        _TN_WS[device] = ws
+    return ws
+
+
+def gemm_tn_pair(a1, b1, out1, a2, b2, out2, *, workspace=True):
     """out1 += a1^T @ b1 and out2 += a2^T @ b2 (same number of contraction rows) in one launch where the shapes allow it
-    (ccd_gemm_tn_pair); equal to two gemm_tn calls up to fp32 summation order."""
+    (ccd_gemm_tn_pair_ws: per-slice partial tiles in a workspace + one reduction pass; workspace=False: ccd_gemm_tn_pair's fp32
+    atomics); equal to two gemm_tn calls up to fp32 summation order."""
     for t, n in ((a1, "a1"), (b1, "b1"), (a2, "a2"), (b2, "b2")):
         _chk(t, BF16, n)
     _chk(out1, F32, "out1"); _chk(out2, F32, "out2")
@@ -239,9 +256,10 @@ def gemm_tn_pair(a1, b1, out1, a2, b2, out2):
     span = TIMER.span("gemm_tn_atomic", flops, nbytes) if TIMER is not None else None
     if span:
         span[0].record()
-    _call("ccd_gemm_tn_pair", _lib.ptr(a1), a1.stride(0), _lib.ptr(b1), b1.stride(0), a1.shape[1], b1.shape[1], _lib.ptr(out1),
+    ws = tn_pair_workspace(a1.device, a1.shape[1], b1.shape[1], a2.shape[1], b2.shape[1]) if workspace else None
+    _call("ccd_gemm_tn_pair_ws", _lib.ptr(a1), a1.stride(0), _lib.ptr(b1), b1.stride(0), a1.shape[1], b1.shape[1], _lib.ptr(out1),
           out1.stride(0), _lib.ptr(a2), a2.stride(0), _lib.ptr(b2), b2.stride(0), a2.shape[1], b2.shape[1], _lib.ptr(out2),
-          out2.stride(0), Mc)
+          out2.stride(0), Mc, _lib.ptr(ws), ws.numel() if ws is not None else 0)
     if span:
         span[1].record()
 

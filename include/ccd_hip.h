@@ -120,6 +120,15 @@ int ccd_gemm_tn_colsum(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb,
 int ccd_gemm_tn_pair(const ccd_bf16* A1, long lda1, const ccd_bf16* B1, long ldb1, int P1, int Q1, float* C1, long ldc1,
                      const ccd_bf16* A2, long lda2, const ccd_bf16* B2, long ldb2, int P2, int Q2, float* C2, long ldc2, int Mc,
                      void* stream);
+/* The same with a caller-owned fp32 WORKSPACE (round 4): each contraction slice stores its partial tile into its own plane of ws
+ * (plain stores) and one reduction pass adds the planes to C1 / C2 - replaces 75 MB of fp32 atomics per MLP pair.  ws_floats >=
+ * ccd_gemm_tn_pair_ws_floats(P1, Q1, P2, Q2) guarantees the path is taken (0 = shapes the grouped kernel does not cover); a null or
+ * too small workspace falls back to ccd_gemm_tn_pair's atomics.  The workspace is scratch: its contents are undefined afterwards and
+ * launches that share it must be ordered on one stream. */
+long ccd_gemm_tn_pair_ws_floats(int P1, int Q1, int P2, int Q2);
+int ccd_gemm_tn_pair_ws(const ccd_bf16* A1, long lda1, const ccd_bf16* B1, long ldb1, int P1, int Q1, float* C1, long ldc1,
+                        const ccd_bf16* A2, long lda2, const ccd_bf16* B2, long ldb2, int P2, int Q2, float* C2, long ldc2, int Mc,
+                        float* ws, long ws_floats, void* stream);
 /* d_rows (optional, both GEMMs): device int; the effective row count (NT: M, TN: Mc) is
  * min(static value, d_rows[0] * rows_mul) so data-dependent row counts never reach the host. */
 

@@ -152,15 +152,18 @@ def check_gemm_tn(dev, Mc, P, Q, seed=1, splits=0):
 def check_gemm_tn_pair(dev, Mc, shape1, shape2, seed=5):
     """Two weight-gradient products over the same rows in one call (ccd_gemm_tn_pair): accumulation onto existing values."""
     g = torch.Generator().manual_seed(seed)
-    outs, wants, args = [], [], []
+    bases, wants, args = [], [], []
     for P, Q in (shape1, shape2):
         a = rnd((Mc, P), g).to(BF); b = rnd((Mc, Q), g).to(BF)
         base = rnd((P, Q), g)
-        outs.append(base.clone().to(dev)); wants.append(base + a.float().t() @ b.float()); args.append((a.to(dev), b.to(dev)))
-    ops.gemm_tn_pair(args[0][0], args[0][1], outs[0], args[1][0], args[1][1], outs[1])
+        bases.append(base); wants.append(base + a.float().t() @ b.float()); args.append((a.to(dev), b.to(dev)))
     tol = 1e-3 * math.sqrt(Mc)
-    close(outs[0], wants[0], 1e-4, tol, "tn_pair/first")
-    close(outs[1], wants[1], 1e-4, tol, "tn_pair/second")
+    # split-K workspace (per-slice partial tiles + reduction pass; round 4) and the fp32-atomic epilogue
+    for workspace in (True, False):
+        outs = [b.clone().to(dev) for b in bases]
+        ops.gemm_tn_pair(args[0][0], args[0][1], outs[0], args[1][0], args[1][1], outs[1], workspace=workspace)
+        close(outs[0], wants[0], 1e-4, tol, f"tn_pair/first ws={workspace}")
+        close(outs[1], wants[1], 1e-4, tol, f"tn_pair/second ws={workspace}")
 
 
 def check_layernorm(dev, rows, E, seed=2):

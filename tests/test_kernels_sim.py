@@ -223,6 +223,7 @@ LATE_DMA = os.environ.get("CCD_SIM_DMA", "").startswith("l")
 def test_gemm_lnbwd_sim(sim):
     from ccd_amd import ops
     kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=384)      # rowgemm.h (N in {128, 256, 384, 512})
+    kc.check_gemm_lnbwd(sim.device, M=1100, N=384, K=576, seed=34)      # 9 row tiles on 4 workgroups: the rings run across tiles
     kc.check_gemm_lnbwd(sim.device, M=200, N=128, K=256)
     kc.check_gemm_lnbwd(sim.device, M=260, N=256, K=256)
     kc.check_gemm_lnbwd(sim.device, M=130, N=512, K=128)

@@ -62,15 +62,15 @@ def main():
         for K in (384, 1152, 1536):
             aa = torch.randn(M, K, generator=g).to(BF).to(dev)
             w = (torch.randn(E, K, generator=g) * 0.05).to(BF).to(dev)
-            for rowgemm, lab in [(1, 0), (2, 0), (0, 0)] + [(1, int(v)) for v in os.environ.get("RG_LAB", "").split(",") if v]:
+            for rowgemm, lab, rg8 in [(1, 0, 1), (1, 0, 0), (0, 0, 0)] + [(1, int(v), 1) for v in os.environ.get("RG_LAB", "").split(",") if v]:
                 for tail in (False, True):
                     for acc in (True,) if os.environ.get("RG_QUICK") else (True, False):
-                        with ops.policy(rowgemm=rowgemm, lab=lab):
+                        with ops.policy(rowgemm=rowgemm, lab=lab, rowgemm_adma=rg8):
                             ms = timeit(lambda: ops.gemm_nt_lnbwd(aa, w, x, mean, rstd, gamma, gbuf, dgam, dbet, accumulate=acc,
                                                                   gb=gb if tail else None, rowscale=rowscale if tail else None,
                                                                   rows_per_sample=256, dbias=dbias if tail else None))
                         nbytes = M * (2.0 * K + E * (4 + 4 + (4 if acc else 0) + (2 if tail else 0)))
-                        print(json.dumps({"M": M, "K": K, "rowgemm": rowgemm, "lab": lab, "tail": tail, "acc": acc, "ms": round(ms, 4),
+                        print(json.dumps({"M": M, "K": K, "rowgemm": rowgemm, "adma": rg8, "lab": lab, "tail": tail, "acc": acc, "ms": round(ms, 4),
                                           "tflops": round(2.0 * M * E * K / ms / 1e9, 1), "algorithmic_gbs": round(nbytes / ms / 1e6, 1)}),
                               flush=True)
 

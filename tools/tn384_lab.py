@@ -45,7 +45,8 @@ def pairs(dev, R=131072, E=384):
         with ops.policy(lab=1):
             ms1 = timeit(lambda: ops.gemm_tn_pair(a1, b1, c1, a2, b2, c2), iters=20)
         print(json.dumps({"pair": name, "main_loop_ms": round(ms1, 4)}), flush=True)
-        for what, fn, pol in (("pair", lambda: ops.gemm_tn_pair(a1, b1, c1, a2, b2, c2), {}),
+        for what, fn, pol in (("pair, split-K workspace + reduction (round 4)", lambda: ops.gemm_tn_pair(a1, b1, c1, a2, b2, c2), {}),
+                              ("pair, fp32 atomics", lambda: ops.gemm_tn_pair(a1, b1, c1, a2, b2, c2, workspace=False), {}),
                               ("two calls, defaults", lambda: (ops.gemm_tn(a1, b1, c1), ops.gemm_tn(a2, b2, c2)), {}),
                               ("two calls, 128-square", lambda: (ops.gemm_tn(a1, b1, c1), ops.gemm_tn(a2, b2, c2)), dict(gemm_tn384=0))):
             with ops.policy(**pol):
