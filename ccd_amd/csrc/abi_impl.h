@@ -104,6 +104,7 @@ struct CcdPolicy {
     int cu_reserve = 0;         // compute units the persistent grids leave free (set while an RCCL gradient reducer is attached)
     int cu_reserve_window = -1; // -1: every launch leaves them free; N >= 0: only the next `cu_reserve_left` launches do (the reducer
     int cu_reserve_left = 0;    // re-arms it with N whenever it starts a bucket's all-reduce: the kernels that run beside the collective)
+    int rowgemm_adma = 1;       // row-owner products at N = 384: the activation rows by LDS-DMA into per-wave images (rowgemm.h, ADMA); 0 = row-per-lane register loads
     int tn_ws = 1;              // paired weight gradients: per-slice partial stores + a reduction pass when the caller lends a workspace (0 = fp32 atomics)
     int lab = 0;                // scratch switch for kernel experiments (tools/*_lab.py); 0 in production
 };
@@ -113,7 +114,7 @@ static const CcdPolicyKey ccd_policy_keys[] = {
     {"gemm_256_min_n", &CcdPolicy::gemm_256_min_n}, {"gemm_256_f32", &CcdPolicy::gemm_256_f32},
     {"gemm_256_deep", &CcdPolicy::gemm_256_deep}, {"gemm_row384", &CcdPolicy::gemm_row384},
     {"rowproj", &CcdPolicy::rowproj}, {"rowproj_min_m", &CcdPolicy::rowproj_min_m},
-    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"tn_ws", &CcdPolicy::tn_ws}, {"lab", &CcdPolicy::lab}};
+    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"rowgemm_adma", &CcdPolicy::rowgemm_adma}, {"tn_ws", &CcdPolicy::tn_ws}, {"lab", &CcdPolicy::lab}};
 static CcdPolicy& ccd_policy() {
     static CcdPolicy pol = [] {
         CcdPolicy q;
@@ -347,6 +348,8 @@ int ccd_gemm_nt_resid_ln(const ccd_bf16* A, long lda, const ccd_bf16* B, long ld
         const int tiles = (M + ccd::RG_BM - 1) / ccd::RG_BM, smem = ccd::rg_smem_bytes(N);
         const dim3 grid(tiles < cus ? tiles : cus), block(ccd::RG_THREADS);
         if (N == 512) CCD_LAUNCH((ccd::rowgemm_kernel<512, ccd::rg_ring(512), ccd::RG_RESID_LN>), grid, block, smem, stream, q);
+        else if (N == 384 && ccd_policy().rowgemm_adma)
+            CCD_LAUNCH((ccd::rowgemm_kernel<384, 3, ccd::RG_RESID_LN, true>), grid, block, ccd::rg_smem_bytes_adma(384), stream, q);
         else if (N == 384) CCD_LAUNCH((ccd::rowgemm_kernel<384, ccd::rg_ring(384), ccd::RG_RESID_LN>), grid, block, smem, stream, q);
         else if (N == 256) CCD_LAUNCH((ccd::rowgemm_kernel<256, ccd::rg_ring(256), ccd::RG_RESID_LN>), grid, block, smem, stream, q);
         else CCD_LAUNCH((ccd::rowgemm_kernel<128, ccd::rg_ring(128), ccd::RG_RESID_LN>), grid, block, smem, stream, q);
@@ -388,6 +391,8 @@ int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, 
         const int tiles = (M + ccd::RG_BM - 1) / ccd::RG_BM, smem = ccd::rg_smem_bytes(N);
         const dim3 grid(tiles < cus ? tiles : cus), block(ccd::RG_THREADS);
         if (N == 512) CCD_LAUNCH((ccd::rowgemm_kernel<512, ccd::rg_ring(512), ccd::RG_LNBWD>), grid, block, smem, stream, q);
+        else if (N == 384 && ccd_policy().rowgemm_adma)   // round 4: the activation rows by LDS-DMA too
+            CCD_LAUNCH((ccd::rowgemm_kernel<384, 3, ccd::RG_LNBWD, true>), grid, block, ccd::rg_smem_bytes_adma(384), stream, q);
         else if (N == 384) CCD_LAUNCH((ccd::rowgemm_kernel<384, ccd::rg_ring(384), ccd::RG_LNBWD>), grid, block, smem, stream, q);
         else if (N == 256) CCD_LAUNCH((ccd::rowgemm_kernel<256, ccd::rg_ring(256), ccd::RG_LNBWD>), grid, block, smem, stream, q);
         else CCD_LAUNCH((ccd::rowgemm_kernel<128, ccd::rg_ring(128), ccd::RG_LNBWD>), grid, block, smem, stream, q);

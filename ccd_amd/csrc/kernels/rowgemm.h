@@ -64,6 +64,22 @@ struct RowGemmParams {
 
 constexpr int RG_SCRATCH = 4096, RG_THREADS = 256, RG_BM = 128;
 constexpr int RG_LNBWD = 0, RG_RESID_LN = 1;
+// ---- ADMA (round 4): the activation rows arrive by LDS-DMA too.
+// Measured on the 8-wave experiment of this round (profiles/r04_rowgemm8_lab.jsonl): a row-per-lane `buffer_load_dwordx4` (every lane
+// 16 bytes of ITS row: 64 separate requests) costs ~61 cycles of the CU's vector-memory address path per instruction, a DMA of
+// 8 rows x 128 contiguous bytes ~16 - and this kernel issued 8 of the former per 24-MFMA window (a third of the window's time).
+// With ADMA a wave moves the next k-block of ITS 32 rows as 4 such DMA instructions (buffer form: rows behind M arrive as zeros) into a
+// private 3-slot image ([32 rows][128 B], the pieces' swizzle) and reads the four B-operand fragments of a block from there - one
+// window ahead of the block, between the MFMAs, on the same in-order LDS queue as the weight fragments (mlp_product's Extra count).
+// Nobody else reads those rows: the wave's own counted vmcnt orders the reads behind the DMA, no barrier.  LDS: the weight ring
+// shrinks to 4 slots (96 KiB) for the 48 KiB of activation images; the epilogue's scratch image is the ring slot of the piece
+// consumed last (free until the next tile's first window refills it; one barrier per tile in front of its first use).
+// VMEM per window: hh = 0 issues the 4 activation DMAs (steps 0, 2, 4, 6: block b + 3, slot b % 3) and KT ring requests (steps
+// 1, 5, ...), hh = 1 the KT requests only: any two consecutive windows issue 2 KT + 4, the ring's counted wait.
+__host__ __device__ inline int rg_smem_bytes_adma(int E) { return 4 * mlp_piece_bytes(E) + 4 * 3 * 4096 + 4 * E * 4; }
+struct RgAdmaExtra {       // window hh = 1: the next block's four fragment reads ride behind MFMA steps 2, 6, 10, 14
+    static constexpr int at(int k) { return (k % 4 == 2 && k < 16) ? 1 : 0; }
+};
 // ring slots: 5 (four pieces ahead) where 160 KiB allow it, 4 at E = 512 (32-KiB pieces)
 __host__ __device__ constexpr int rg_slots(int E) { return E <= 384 ? 5 : 4; }
 __host__ __device__ inline int rg_smem_bytes(int E) {
@@ -116,17 +132,18 @@ __device__ __forceinline__ void rg_colsum16(const float (&v)[16], float* dst, in
     atomicAdd(dst + 8 * ((lq >> 2) & 3) + 4 * hf + (lq & 3), rg_fold16(v, lq));
 }
 
-template <int E, int R, int EPI>
+template <int E, int R, int EPI, bool ADMA = false>
 __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p) {
-    constexpr int RG_NSLOT = rg_slots(E);
+    constexpr int RG_NSLOT = ADMA ? 4 : rg_slots(E);
+    static_assert(!ADMA || (E == 384 && R == 3), "activation DMA: 3 image slots per wave, 160 KiB of LDS at E = 384");
     constexpr int KT = E / 64;             // ring requests (1 KiB wave instructions) per wave and piece
     constexpr int NT = E / 32, NTH = NT / 2;
     constexpr int PIECE = mlp_piece_bytes(E);
     constexpr int AHEAD = RG_NSLOT - 1;
     constexpr int DEPTH = 6;               // fragment reads in flight ahead of their MFMA
     constexpr int NSTEP = 4 * NTH;         // MFMAs per piece
-    constexpr int WIN_VM = KT + 2;         // VMEM instructions per window
-    constexpr bool AB_LATE = E <= 384;     // hand-tracked activation loads into accumulator registers; at E = 512 the accumulators
+    constexpr int WIN_VM = KT + 2;         // VMEM instructions per window (ADMA: KT + 4 and KT in turn, the same per pair)
+    constexpr bool AB_LATE = E <= 384 && !ADMA;     // hand-tracked activation loads into accumulator registers; at E = 512 the accumulators
                                            // fill that file: the blocks stay compiler-managed loads there (with its drains)
     static_assert(E % 128 == 0 && NSTEP == 4 * KT && AHEAD >= 2, "ring bookkeeping");
     static_assert(rg_younger(0, KT, R) <= 63 && rg_younger(1, KT, R) <= 63 && rg_younger(2, KT, R) >= 0 && rg_younger(3, KT, R) >= 0,
@@ -134,8 +151,9 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
     char* smem = dynamic_smem();
     const int t = threadIdx.x, lane = t & 63, hf = lane >> 5, lq = lane & 31;
     const int w = uniform_i32(t >> 6);
-    char* scratch = smem + RG_NSLOT * PIECE + w * RG_SCRATCH;
-    float* vga = reinterpret_cast<float*>(smem + RG_NSLOT * PIECE + 4 * RG_SCRATCH);
+    char* scratch = smem + RG_NSLOT * PIECE + w * RG_SCRATCH;       // (ADMA: re-pointed per tile, see the epilogue)
+    char* aring = smem + RG_NSLOT * PIECE + w * (3 * 4096);         // ADMA: this wave's activation images
+    float* vga = reinterpret_cast<float*>(smem + RG_NSLOT * PIECE + (ADMA ? 4 * 3 * 4096 : 4 * RG_SCRATCH));
     float* cs = vga + E;                   // RG_LNBWD: [3][E] dgamma, dbeta, dbias of this workgroup
     float* vbe = vga + E;                  // RG_RESID_LN: beta, bias
     float* vbi = vbe + E;
@@ -177,7 +195,7 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
     };
     const unsigned smem_addr = lds_addr_of(smem);
     auto acquire = [&]() -> unsigned {
-        glds_wait<(AHEAD - 1) * WIN_VM>();
+        glds_wait<ADMA ? (AHEAD - 1) * (KT + 2) : (AHEAD - 1) * WIN_VM>();     // (ADMA, AHEAD - 1 = 2: one window of each kind)
         RG_STAMP(1)
         lds_barrier();
         RG_STAMP(2)
@@ -223,6 +241,31 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
         if constexpr (AB_LATE) buf_load16_late(dst, ds_a, lo_a, so);
         else dst = buf_load16(rs_a, lo_a, so);
     };
+    // ADMA: instruction jj of a block = rows 8 jj .. + 7 of the wave, 128 bytes each; LDS position dp of image row r holds the
+    // logical slot dp ^ swz(r) (the fragment reads are the pieces': off2)
+    unsigned lane_dma[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+        lane_dma[jj] = (unsigned)(((8 * jj + (lane >> 3)) * p.lda) * 2 + (((lane & 7) ^ mlp_swz(8 * jj + (lane >> 3))) * 16));
+    auto dma_a = [&](int jj, int tt, int b, int slot) {
+        bufdma16(rs_a, lane_dma[jj], (unsigned)(tt * RG_BM + 32 * w) * (unsigned)(p.lda * 2) + (unsigned)(128 * b), aring + slot * 4096 + jj * 1024);
+    };
+    bf16x8 fr[3][4];                       // ADMA: B-operand fragments of the block with index % 3 == slot (k-step j = fr[.][j])
+    const unsigned aring_addr = lds_addr_of(aring);
+    if constexpr (ADMA) {
+        if ((int)blockIdx.x < tiles) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) dma_a(jj, blockIdx.x, b, b);
+        }
+        glds_wait_all();
+        wave_lds_fence();                  // (no instruction: the wave's vmcnt covers all of its lanes; the CPU executor runs lanes as fibers)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_read_frag<0>(fr[0][j], aring_addr + off2[j]);
+        lds_drain();
+        lds_landed4(fr[0]);
+    } else {
     if ((int)blockIdx.x < tiles) {
 #pragma unroll
         for (int b = 0; b < R - 1; ++b)
@@ -231,6 +274,7 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
     }
     // the counted waits of the main loop assume a full pipeline behind them: start from a drained queue (once per workgroup)
     glds_wait_all();
+    }
     const float inv_e = 1.0f / (float)E;
     if (p.lab > 0 && p.lab < 16 && (blockIdx.x & 1)) wave_sleep(p.lab);
 
@@ -254,6 +298,47 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
                 if (tb >= NB) { tb -= NB; tt += G; }
                 if (tt >= tiles) tt = tile;        // behind the last tile: re-read this one (an out-of-range load of the whole wave
                                                    // need not keep its place in the return order)
+                if constexpr (ADMA) {
+                    // block (grp, i): fragments in fr[i]; block + 3 (maybe of the next tile) goes into image slot i in window 0,
+                    // block + 1's fragments come out of image slot (i + 1) % 3 in window 1
+                    int tb3 = grp * R + i + 3, tt3 = tile;
+                    if (tb3 >= NB) { tb3 -= NB; tt3 += G; }
+                    if (tt3 >= tiles) tt3 = tile;
+                    {
+                        const unsigned sb = acquire();
+                        const unsigned areg[4] = {sb + off2[0], sb + off2[1], sb + off2[2], sb + off2[3]};
+                        mlp_product<NSTEP, DEPTH, MlpMapP2<NTH>, MlpNoExtra>(
+                            areg,
+                            [&](auto K, const bf16x8& a) {
+                                constexpr int k = decltype(K)::value;
+                                acc[k % NTH] = mfma_32x32x16_bf16(a, fr[i][k / NTH], acc[k % NTH]);
+                            },
+                            [&](auto K) {
+                                constexpr int k = decltype(K)::value;
+                                if constexpr (k % 4 == 1) issue_one(k / 4);
+                                if constexpr (k % 2 == 0 && k < 8) dma_a(k / 2, tt3, tb3, i);
+                            });
+                        RG_STAMP(3)
+                    }
+                    {
+                        const unsigned sb = acquire();
+                        const unsigned areg[4] = {sb + off2[0], sb + off2[1], sb + off2[2], sb + off2[3]};
+                        constexpr int nx = (i + 1) % 3;
+                        mlp_product<NSTEP, DEPTH, MlpMapP2<NTH>, RgAdmaExtra>(
+                            areg,
+                            [&](auto K, const bf16x8& a) {
+                                constexpr int k = decltype(K)::value;
+                                acc[NTH + k % NTH] = mfma_32x32x16_bf16(a, fr[i][k / NTH], acc[NTH + k % NTH]);
+                            },
+                            [&](auto K) {
+                                constexpr int k = decltype(K)::value;
+                                if constexpr (k % 4 == 1) issue_one(k / 4);
+                                if constexpr (RgAdmaExtra::at(k) != 0) lds_read_frag<0>(fr[nx][k / 4], aring_addr + (unsigned)(nx * 4096) + off2[k / 4]);
+                            });
+                        lds_landed4(fr[nx]);       // (the window's last fragment wait drained the queue: every extra read sits in front of read 23)
+                        RG_STAMP(3)
+                    }
+                } else
                 mlp_static_for<0, 2>([&](auto HH) {
                     constexpr int hh = decltype(HH)::value;
                     const unsigned sb = acquire();
@@ -276,6 +361,12 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
             });
         }
         // ---- epilogue: a row is complete inside its two lanes (lane, lane ^ 32); acc[nt][4 g + e] = column 32 nt + 8 g + 4 hf + e.
+        if constexpr (ADMA) {
+            // the scratch image: the ring slot of the piece consumed last - every wave is done with it behind this barrier, and its
+            // refill is issued behind the next tile's first barrier
+            lds_barrier();
+            scratch = smem + (slot_c == 0 ? RG_NSLOT - 1 : slot_c - 1) * PIECE + w * RG_SCRATCH;
+        }
         if constexpr (EPI == RG_RESID_LN) {
             // (mlp_fused.h's epilogue)  Pass A: out = x + (acc + bias) * sc back into the accumulators, LayerNorm statistics
             float sc = 1.0f;

@@ -119,6 +119,11 @@ __device__ __forceinline__ void glds16(const void* gptr, char* lds_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
                                      (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
+// the same through a buffer descriptor (buffer_load_dwordx4 ... lds): address = base + lane_offset + uniform_offset, a lane whose
+// offset is out of range moves ZEROS into its 16 bytes of LDS (checked on the GPU by the LayerNorm-backward tests: rows behind M)
+__device__ __forceinline__ void bufdma16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset, char* lds_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_base, 16, (int)lane_offset, (int)uniform_offset, 0, 0);
+}
 // 4-byte form: lane l's dword lands at lds_base + 4 l
 __device__ __forceinline__ void glds4(const void* gptr, char* lds_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
@@ -158,6 +163,8 @@ __device__ __forceinline__ void lds_gather_f32(float& dst, unsigned lds_addr) {
 }
 __device__ __forceinline__ void lds_landed(float& a, float& b) { asm volatile("" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// four hand-issued fragment reads become visible to the compiler (no instruction: a counted or draining wait has passed)
+__device__ __forceinline__ void lds_landed4(bf16x8 (&f)[4]) { asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])); }
 // the value lane (l ^ M) holds, M in {1, 2, 4, 8, 16}: DPP where gfx950 has a pattern for it (no LDS crossbar traffic), the
 // swizzle unit otherwise
 template <int M>

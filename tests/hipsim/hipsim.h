@@ -206,6 +206,7 @@ template <int OFF>
 inline void lds_read_frag(bf16x8& dst, unsigned lds_addr) { std::memcpy(&dst, sim::curblk->dyn_smem + lds_addr + OFF, 16); }
 template <int N>
 inline void lds_wait_frag(bf16x8&) {}
+inline void lds_landed4(bf16x8 (&)[4]) {}
 inline void lds_gather_f32(float& dst, unsigned lds_addr) { std::memcpy(&dst, sim::curblk->dyn_smem + lds_addr, 4); }
 inline void lds_landed(float&, float&) {}
 inline void lds_drain() {}
@@ -240,6 +241,14 @@ inline buf_u32x4 buf_load16(buf_rsrc r, unsigned lane_offset, unsigned uniform_o
     buf_u32x4 v = {0u, 0u, 0u, 0u};
     if (o + 16ull <= (unsigned long long)r.bytes) std::memcpy(&v, r.base + o, 16);
     return v;
+}
+inline void bufdma16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset, char* lds_base) {
+    const unsigned long long o = (unsigned long long)lane_offset + uniform_offset;
+    const bool in_range = o + 16ull <= (unsigned long long)r.bytes;
+    char* dst = lds_base + 16 * sim::cur->lane;
+    if (::sim_dma_late()) sim::cur->dma.push_back({dst, in_range ? r.base + o : nullptr, 16});
+    else if (in_range) std::memcpy(dst, r.base + o, 16);
+    else std::memset(dst, 0, 16);
 }
 inline void buf_store16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset, buf_u32x4 v) {
     const unsigned long long o = (unsigned long long)lane_offset + uniform_offset;
