@@ -118,8 +118,13 @@ def check_graphed_step_matches_eager(device, steps=8, B=8, drop_path_rate=0.1):
     assert (ce - cg).norm().item() <= 0.05 * ce.norm().item(), ((ce - cg).norm().item(), ce.norm().item())
 
 
-def check_tiny_step(device, logit_tol=3e-2, loss_tol=2e-3, grad_rtol=6e-2):
-    g = np.load(os.path.join(GOLD, "tiny_step.npz"))
+def check_tiny_step(device, logit_tol=3e-2, loss_tol=None, grad_rtol=6e-2, batch=2):
+    """The reference's 3-block E = 192 model, every stage + one full iteration.  batch = 8 (tiny8_step.npz) is the GPU gate at the
+    north-star tolerance 1e-3; batch = 2 (tiny_step.npz, what the CPU executor can afford) averages ~14 selected rows in its loss,
+    whose bf16 logit noise does not average out - measured over seeds in profiles/r04_parity_tiny_budget.json - and keeps 2e-3."""
+    if loss_tol is None:
+        loss_tol = 1e-3 if batch >= 8 else 2e-3
+    g = np.load(os.path.join(GOLD, "tiny_step.npz" if batch == 2 else f"tiny{batch}_step.npz"))
     student, teacher = tiny_networks(device)
     # 1. same seed -> bit-identical initial weights as the reference (construction order / RNG stream)
     sd = student.state_dict()
@@ -127,7 +132,7 @@ def check_tiny_step(device, logit_tol=3e-2, loss_tol=2e-3, grad_rtol=6e-2):
         assert_init_stat(stat(sd[str(n)]), row, n)
     dino_loss = DINOLoss(512, 2, 0.04, 0.04, 0, 40).to(device)
     opt = pretrain.make_optimizer(student, clip_grad=float(g["hyper"][4]))
-    images, masks, metrics = make_batch(2, seed=11, device=device)
+    images, masks, metrics = make_batch(batch, seed=11, device=device)
     epoch, lr, wd, mom, clip, freeze = g["hyper"]
     # forward pieces first (so individual stages can be compared), then the full iteration on fresh grads
     bn_state = {k: v.clone() for k, v in student.state_dict().items() if "running_" in k or "num_batches" in k}
@@ -780,7 +785,7 @@ def check_finetune_golden(device, tag="tiny", loss_tol=2e-3):
     assert compared >= 4 * B, compared
 
 
-def check_pretrain_arch_vs_oracle(device, arch="vit_base", B=4, out_dim=4096, loss_tol=2e-3, dims=None):
+def check_pretrain_arch_vs_oracle(device, arch="vit_base", B=4, out_dim=4096, loss_tol=1e-3, dims=None):
     """One pretraining iteration of another shipped architecture (BASELINE config #4: vit_base = E 512 / 8 heads, which
     takes the non-fused residual / LayerNorm kernels; vit_base_768 = the 768 / 12 shape that config names) against the
     pinned CPU oracle: index maps bit-exact, losses, every gradient norm, centre.  `dims` = (embed_dim, depth, heads, taps):
@@ -824,7 +829,29 @@ def check_pretrain_arch_vs_oracle(device, arch="vit_base", B=4, out_dim=4096, lo
         got_l2 = student.arena.g(name).double().pow(2).sum().sqrt().item()
         if want_l2 > 1e-5 and name not in NOISE_DOMINATED:
             assert abs(got_l2 - want_l2) <= 8e-2 * want_l2, f"grad norm {name}: {got_l2} vs oracle {want_l2}"
-    return {"hip": got.tolist(), "oracle": want.tolist()}
+    report = {"arch": arch, "B": B, "out_dim": out_dim, "hip": got.tolist(), "oracle": want.tolist(),
+              "delta_vs_oracle": (got - want).tolist()}
+    # ... and against ONE ITERATION OF THE REAL REFERENCE (tests/golden/arch_step.npz, tools/gen_golden.py::gen_arch: the same seed,
+    # batch and hyper-parameters) where the fixture holds this configuration
+    fx = os.path.join(GOLD, "arch_step.npz")
+    if dims is None and os.path.isfile(fx):
+        g = np.load(fx)
+        p = arch + "/"
+        if p + "hyper" in g.files and int(g[p + "hyper"][7]) == B and int(g[p + "hyper"][8]) == out_dim:
+            np.testing.assert_array_equal(out.raw("selection").idmap.cpu().numpy(), g[p + "zero_idmap"])
+            np.testing.assert_array_equal(out["index"].cpu().numpy(), g[p + "new_index"])
+            np.testing.assert_allclose(got, g[p + "losses"], atol=loss_tol, rtol=0, err_msg=f"{arch}: losses vs the reference")
+            assert float(np.abs(dino_loss.center.cpu().numpy() - g[p + "center_after"]).max()) < 3e-3
+            worst = 0.0
+            for n, row in zip(g[p + "grad_names"], g[p + "grad_stats"]):
+                if str(n) in NOISE_DOMINATED or row[2] <= 1e-5:
+                    continue
+                got_l2 = student.arena.g(str(n)).double().pow(2).sum().sqrt().item()
+                worst = max(worst, abs(got_l2 - row[2]) / row[2])
+                assert abs(got_l2 - row[2]) <= 8e-2 * row[2], f"grad norm {n}: {got_l2} vs reference {row[2]}"
+            report.update({"reference": g[p + "losses"].tolist(), "delta_vs_reference": (got - g[p + "losses"]).tolist(),
+                           "worst_grad_norm_rel_err_vs_reference": worst, "index_maps": "bit-exact"})
+    return report
 
 
 def check_finetune_properties_full_size(device, B=512):

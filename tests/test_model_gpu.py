@@ -9,6 +9,7 @@ from backends import Backend
 import model_checks as mc
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -20,7 +21,8 @@ def hip():
 
 
 def test_tiny_training_iteration(hip):
-    mc.check_tiny_step(hip.device)
+    mc.check_tiny_step(hip.device, batch=8)     # the north-star tolerance (1e-3) on ~56 selected rows
+    mc.check_tiny_step(hip.device, batch=2)
 
 
 def test_vit_small_b8_two_iterations_vs_reference(hip):
@@ -113,8 +115,11 @@ def test_greedy_decoding_hip_graph_matches_eager(hip, monkeypatch):
 def test_other_archs_pretrain_iteration_vs_oracle(hip, arch):
     """BASELINE config #4's architecture (vit_base: E 512 / 8 heads, unfused residual + LayerNorm path; vit_base_768: the
     768 / 12 shape that config's text names) and vit_tiny."""
-    rep = mc.check_pretrain_arch_vs_oracle(hip.device, arch, B=2 if arch == "vit_base_768" else 4)
+    rep = mc.check_pretrain_arch_vs_oracle(hip.device, arch, B=4)
     print(arch, rep)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)      # kept: the deltas are part of the parity record (profiles/)
+    with open(os.path.join(ROOT, "gpurun_out", f"parity_arch_{arch}.json"), "w") as f:
+        json.dump(rep, f, indent=1)
 
 
 def test_finetune_properties_at_full_batch(hip):

@@ -64,11 +64,12 @@ def _tiny_spec():
                   head_bottleneck=64, norm_last_layer=False, seg_in=192)
 
 
-def test_tiny_step(golden_dir):
-    g = np.load(os.path.join(golden_dir, "tiny_step.npz"))
+@pytest.mark.parametrize("B,name", [(2, "tiny_step.npz"), (8, "tiny8_step.npz")])
+def test_tiny_step(golden_dir, B, name):
+    g = np.load(os.path.join(golden_dir, name))
     student, teacher = O.build_pair(_tiny_spec(), seed=3)
     _check_stats(g["init_names"], g["init_stats"], student.P, rtol=0, atol=0, what="init")
-    batch = make_batch(2, seed=11)
+    batch = make_batch(B, seed=11)
     np.testing.assert_array_equal(batch[1].numpy().astype(np.uint8), g["masks"])
     np.testing.assert_array_equal(batch[2].numpy(), g["metrics"])
     epoch, lr, wd, mom, clip, freeze = g["hyper"]
@@ -91,6 +92,24 @@ def test_tiny_step(golden_dir):
             np.testing.assert_allclose(rec["grads_raw"][k[5:]].numpy(), g[k], rtol=1e-3, atol=1e-7, err_msg=k)
     _check_stats(g["post_names"], g["post_stats"], student.P, rtol=1e-4, atol=1e-7, what="post")
     _check_stats(g["teacher_post_names"], g["teacher_post_stats"], teacher.P, rtol=1e-4, atol=1e-7, what="ema")
+
+
+@pytest.mark.parametrize("arch", ["vit_base", "vit_base_768"])
+def test_arch_step(golden_dir, arch):
+    """BASELINE config #4's architectures: the oracle against one iteration of the real reference (tools/gen_golden.py::gen_arch)."""
+    g = np.load(os.path.join(golden_dir, "arch_step.npz"))
+    p = arch + "/"
+    epoch, lr, wd, mom, clip, freeze, seed, B, K = g[p + "hyper"]
+    spec = O.Spec(norm_last_layer=False, out_dim=int(K), seg_in=O.ARCH[arch]["embed_dim"], **O.ARCH[arch])
+    student, teacher = O.build_pair(spec, seed=0)
+    _check_stats(g[p + "init_names"], g[p + "init_stats"], student.P, rtol=0, atol=0, what="init")
+    rec = O.train_iteration(student, teacher, torch.zeros(1, int(K)), O.AdamWState(), make_batch(int(B), seed=int(seed)), int(epoch), lr,
+                            wd, mom, clip=clip, freeze_last_layer=int(freeze))
+    np.testing.assert_array_equal(rec["s_out"]["idmap"], g[p + "zero_idmap"])
+    np.testing.assert_array_equal(rec["s_out"]["index"].numpy(), g[p + "new_index"])
+    np.testing.assert_allclose([rec["loss"], rec["mask_loss"], rec["dino_loss"]], g[p + "losses"], rtol=2e-6)
+    np.testing.assert_allclose(rec["center"].numpy(), g[p + "center_after"], rtol=1e-5, atol=1e-8)
+    _check_stats(g[p + "grad_names"], g[p + "grad_stats"], rec["grads_raw"], rtol=5e-4, atol=1e-9, what="grad")
 
 
 def test_small_step(golden_dir):

@@ -11,7 +11,8 @@ seeded synthetic inputs (ccd_amd/synthetic.py) are recorded.
 Fixtures (all small):
   sched.npz        cosine_iter_scheduler / teacher-temp schedule arrays           (modules/utils.py:200-210)
   ccl_cases.npz    adversarial masks -> label_cluster outputs as uint8 id maps     (utils/DBSCAN.py:61-103)
-  tiny_step.npz    3-block E=192 model, B=2: full tensors of every stage + grads
+  tiny_step.npz    3-block E=192 model, B=2: full tensors of every stage + grads (tiny8_step.npz: the same at B=8)
+  arch_step.npz    BASELINE config #4's two architectures (vit_base = 512 / 8 heads, the 768 / 12 shape): one iteration each, B = 4
   small_step.npz   CCD_pretrain_ViT_small hyper-parameters, B=8, 2 iterations: losses, index maps,
                    sampled logits, per-parameter grad norms / post-step checksums
   small3_step.npz  the same model with perturbed head biases: 3 consecutive iterations + one at epoch 30 (predicted masks)
@@ -248,10 +249,18 @@ def reference_iteration(student, teacher, dino_loss, optimizer, batch, epoch, lr
 
 
 def gen_tiny():
+    # B = 2 (tiny_step.npz: what the CPU SIMT executor can afford, three times per CPU test run) and, round 4, B = 8 (tiny8_step.npz: the
+    # GPU parity gate at the north-star tolerance - at B = 2 the loss averages ~14 selected rows and their bf16 logit noise does not
+    # average out: profiles/r04_parity_tiny_budget.json)
+    for B, name in ((2, "tiny_step.npz"), (8, "tiny8_step.npz")):
+        gen_tiny_batch(B, name)
+
+
+def gen_tiny_batch(B, name):
     ensure_pg()
     from Dino.modules import utils as rutils
     from Dino.loss.Dino_loss import DINOLoss
-    B, K = 2, 512
+    K = 512
     arch = dict(patch_size=4, embed_dim=192, depth=3, num_heads=3, out_indices=[1, 2, 3])
     head = dict(out_dim=K, hidden_dim=256, bottleneck_dim=64)
     student, teacher = build_reference_pair(arch, head, 192, seed=3, drop_path_rate=0.0, tiny=True)
@@ -287,8 +296,8 @@ def gen_tiny():
     out["post_names"], out["post_stats"] = state_stats(student.state_dict().items())
     out["teacher_post_names"], out["teacher_post_stats"] = state_stats(teacher.state_dict().items())
     out["hyper"] = np.array([1, 2e-4, 0.05, 0.99, 3.0, 1])  # epoch lr wd mom clip freeze
-    np.savez_compressed(os.path.join(GOLD, "tiny_step.npz"), **out)
-    print("tiny_step.npz written; losses", out["losses"], "M", int(out["new_index"].sum()))
+    np.savez_compressed(os.path.join(GOLD, name), **out)
+    print(name, "written; losses", out["losses"], "M", int(out["new_index"].sum()))
 
 
 def gen_small():
@@ -472,6 +481,42 @@ def gen_small3():
               f"  planes/img={[int((np.unique(m) != 255).sum()) for m in out[p + 'zero_idmap'][:B]]}")
     np.savez_compressed(os.path.join(GOLD, "small3_step.npz"), **out)
     print("small3_step.npz written")
+
+
+def gen_arch():
+    """One reference iteration of BASELINE config #4's architectures: vit_base (the reference's factory,
+    vision_transformer.py:287-291: 512 / 8 heads) and the 768 / 12 shape the config's text names (the VisionTransformer
+    constructor's defaults), B = 4, out_dim 4096, hyper-parameters of tests/model_checks.py::check_pretrain_arch_vs_oracle."""
+    ensure_pg()
+    from Dino.modules import utils as rutils
+    from Dino.loss.Dino_loss import DINOLoss
+    B, K = 4, 4096
+    out = {}
+    for arch in ("vit_base", "vit_base_768"):
+        if arch == "vit_base_768":
+            student, teacher = build_reference_pair(dict(embed_dim=768, depth=12, num_heads=12, patch_size=4), dict(out_dim=K), 768,
+                                                    seed=0, drop_path_rate=0.0, tiny=True)
+        else:
+            student, teacher = build_reference_pair(dict(arch=arch), dict(out_dim=K), 512, seed=0, drop_path_rate=0.0, tiny=False)
+        p = arch + "/"
+        out[p + "init_names"], out[p + "init_stats"] = state_stats(student.state_dict().items())
+        dino_loss = DINOLoss(K, 2, 0.04, 0.04, 0, 40)
+        optimizer = torch.optim.AdamW(rutils.get_params_groups(student))
+        batch = make_batch(B, seed=21)
+        rec = reference_iteration(student, teacher, dino_loss, optimizer, batch, epoch=1, lr=1e-4, wd=0.04, mom=0.9995,
+                                  clip=3.0, freeze_last_layer=1, record={})
+        s_out, t_out = rec["s_out"], rec["t_out"]
+        out[p + "hyper"] = np.array([1, 1e-4, 0.04, 0.9995, 3.0, 1, 21, B, K])
+        out[p + "zero_idmap"] = planes_to_idmap(s_out["zero"].numpy())
+        out[p + "new_index"] = s_out["index"].numpy()
+        out[p + "losses"] = np.array([rec["loss"], rec["mask_loss"], rec["dino_loss"]])
+        out[p + "student_logits_stat"] = stat(s_out["instances_view"].detach())
+        out[p + "teacher_logits_stat"] = stat(t_out["instances_view"].detach())
+        out[p + "center_after"] = dino_loss.center.numpy()
+        out[p + "grad_names"], out[p + "grad_stats"] = state_stats(rec["grads_raw"].items())
+        print(arch, "losses", out[p + "losses"], "M", int(out[p + "new_index"].sum()))
+    np.savez_compressed(os.path.join(GOLD, "arch_step.npz"), **out)
+    print("arch_step.npz written")
 
 
 def gen_keys():
@@ -679,7 +724,7 @@ if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     os.chdir("/root/reference")  # Config() and friends use relative paths; we never write here
     torch.set_num_threads(8)
-    todo = [a.only] if a.only else ["sched", "ccl", "tiny", "small", "small3", "keys", "finetune", "kmeans", "eval"]
+    todo = [a.only] if a.only else ["sched", "ccl", "tiny", "small", "small3", "arch", "keys", "finetune", "kmeans", "eval"]
     for t in todo:
-        {"sched": gen_sched, "ccl": gen_ccl, "tiny": gen_tiny, "small": gen_small, "small3": gen_small3, "keys": gen_keys,
+        {"sched": gen_sched, "ccl": gen_ccl, "tiny": gen_tiny, "arch": gen_arch, "small": gen_small, "small3": gen_small3, "keys": gen_keys,
          "finetune": gen_finetune, "kmeans": gen_kmeans, "eval": gen_eval}[t]()
