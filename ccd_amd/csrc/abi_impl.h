@@ -13,6 +13,7 @@
 #include "kernels/rowproj.h"
 #include "kernels/attention_fwd.h"
 #include "kernels/attention_bwd.h"
+#include "kernels/attention_bwd1.h"
 #include "kernels/gemm_tn384.h"
 #include "kernels/layernorm.h"
 #include "kernels/charmap.h"
@@ -97,6 +98,7 @@ struct CcdPolicy {
     int ln_bwd_bpc = 5;         // LayerNorm backward: blocks per CU (one resident wave; more blocks = more dgamma/dbeta atomics)
     int dec_attn_simt = 0;      // decoder attention: force the general SIMT kernels
     int attn_tr = 1;            // attention backward dK/dV: double-buffered LDS-DMA row images + ds_read_b64_tr_b16 (0 = four register-staged images)
+    int attn_onepass = 1;       // attention backward: ONE kernel with five products, dS exchanged through LDS (attention_bwd1.h); 0 = the dQ + dK/dV pair
     int attn_skew = 0;          // attention backward: waves 4..7 start each block ~skew * 64 cycles late (lab; no effect once clocks are warm)
     int gemm_tn384 = 1;         // weight gradients with P % 384 == 0, Q % 192 == 0: XCD-grouped 384x192 LDS-DMA kernel (gemm_tn384.h); 0 = 128-square kernel, 2 = never as a pair
     int gemm_tn384_geom = 0;    // its workgroup: 0 = 384x192 tile, 8 waves, one per CU; 2 = 0 + 512x128 tiles for the shapes 384x192 does not divide (E = 512)
@@ -114,7 +116,7 @@ static const CcdPolicyKey ccd_policy_keys[] = {
     {"gemm_256_min_n", &CcdPolicy::gemm_256_min_n}, {"gemm_256_f32", &CcdPolicy::gemm_256_f32},
     {"gemm_256_deep", &CcdPolicy::gemm_256_deep}, {"gemm_row384", &CcdPolicy::gemm_row384},
     {"rowproj", &CcdPolicy::rowproj}, {"rowproj_min_m", &CcdPolicy::rowproj_min_m},
-    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"rowgemm_adma", &CcdPolicy::rowgemm_adma}, {"tn_ws", &CcdPolicy::tn_ws}, {"lab", &CcdPolicy::lab}};
+    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_onepass", &CcdPolicy::attn_onepass}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"rowgemm_adma", &CcdPolicy::rowgemm_adma}, {"tn_ws", &CcdPolicy::tn_ws}, {"lab", &CcdPolicy::lab}};
 static CcdPolicy& ccd_policy() {
     static CcdPolicy pol = [] {
         CcdPolicy q;
@@ -608,6 +610,10 @@ int ccd_attention_bwd(const ccd_bf16* qkv, const ccd_bf16* out, const ccd_bf16* 
     const int cus = ccd_rt_num_cus();
     const int grid = nblocks < cus ? nblocks : cus;
     float* ws = d_qkv_bias ? bias_ws : nullptr;             // [grid][E] partial column sums of dQ
+    if (ccd_policy().attn_onepass)          // round 4: one pass, five products (attention_bwd1.h)
+        CCD_LAUNCH(ccd::attention_bwd_onepass_kernel, dim3(grid), dim3(512), ccd::ATTB1_SMEM, stream, qkv, out, d_out, lse, d_qkv, ws,
+                   heads, scale, nblocks);
+    else {
     CCD_LAUNCH(ccd::attention_bwd_dq_kernel, dim3(grid), dim3(512), ccd::ATTB_DQ_SMEM, stream, qkv,
                out, d_out, lse, delta_ws, d_qkv, ws, heads, scale, nblocks, ccd_policy().attn_skew);
     if (ccd_policy().attn_tr)               // dK / dV on the double-buffered LDS-DMA image with transposing LDS reads
@@ -616,6 +622,7 @@ int ccd_attention_bwd(const ccd_bf16* qkv, const ccd_bf16* out, const ccd_bf16* 
     else
         CCD_LAUNCH(ccd::attention_bwd_dkv_kernel, dim3(grid), dim3(512), ccd::ATTB_DKV_SMEM, stream, qkv,
                    d_out, lse, delta_ws, d_qkv, heads, scale, nblocks, ccd_policy().attn_skew);
+    }
     if (ws) {
         const int E = heads * ccd::ATT_D;
         CCD_LAUNCH(ccd::qkv_bias_finish_kernel, dim3((E + 63) / 64, 2), dim3(1024), 0, stream, ws, grid, dout_colsum_vec,

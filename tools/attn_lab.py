@@ -33,6 +33,15 @@ def main():
         with ops.policy(attn_tr=tr, attn_skew=0):
             ms = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, scale))
         print(json.dumps({"kernel": "attention_bwd (dq + dkv)", "attn_tr": tr, "views": a.views, "ms": round(ms, 4)}), flush=True)
+    d_bias = torch.zeros(3 * E, device=dev); dcs = torch.zeros(E, device=dev)
+    for onepass in (1, 0):
+        with ops.policy(attn_onepass=onepass):
+            ms = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, scale))
+            msb = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, scale, d_bias=d_bias, dout_colsum=dcs))
+        print(json.dumps({"kernel": "attention_bwd one pass (round 4)" if onepass else "attention_bwd (dq + dkv_tr)", "views": a.views,
+                          "ms": round(ms, 4), "ms_with_qkv_bias_gradient": round(msb, 4)}), flush=True)
+    if os.environ.get("ATTN_LAB_SHORT"):
+        return
     for lab, what in ((1, "no stores"), (2, "no loads"), (3, "no loads, no stores")):
         with ops.policy(attn_tr=1, attn_skew=0, lab=lab):
             ms = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, scale))
