@@ -612,7 +612,7 @@ int ccd_attention_bwd(const ccd_bf16* qkv, const ccd_bf16* out, const ccd_bf16* 
     float* ws = d_qkv_bias ? bias_ws : nullptr;             // [grid][E] partial column sums of dQ
     if (ccd_policy().attn_onepass)          // round 4: one pass, five products (attention_bwd1.h)
         CCD_LAUNCH(ccd::attention_bwd_onepass_kernel, dim3(grid), dim3(512), ccd::ATTB1_SMEM, stream, qkv, out, d_out, lse, d_qkv, ws,
-                   heads, scale, nblocks);
+                   heads, scale, nblocks, ccd_policy().lab);
     else {
     CCD_LAUNCH(ccd::attention_bwd_dq_kernel, dim3(grid), dim3(512), ccd::ATTB_DQ_SMEM, stream, qkv,
                out, d_out, lse, delta_ws, d_qkv, ws, heads, scale, nblocks, ccd_policy().attn_skew);

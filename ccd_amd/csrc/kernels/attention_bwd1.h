@@ -17,24 +17,34 @@
 namespace ccd {
 
 constexpr int ATTB1_XBUF = 16384;                                        // one exchange buffer: 8 waves x [32 keys][64 B]
-constexpr int ATTB1_SMEM = 3 * ATTB_IMG + 2 * ATTB1_XBUF + 2 * ATT_T * 4 + ATTB_CS_BYTES;
+constexpr int ATTB1_RING = 9 * 4096;                                     // Q / dO row images as rings of nine 32-row tile slots
+constexpr int ATTB1_SMEM = 2 * ATTB1_RING + ATTB_IMG + 2 * ATTB1_XBUF + 4 * ATT_T * 4 + ATTB_CS_BYTES;
 // 8-byte slot swizzle of an exchange row (32 queries = 8 slots): writes (16 keys x one slot) and transposing reads (4 keys x 4 slots
 // per 16-lane group, two groups per LDS cycle) both touch every bank once
 __device__ __forceinline__ int attb1_fx(int key) { return ((key >> 2) & 3) | ((key >> 1) & 4); }
 
+// Cross-block prefetch without a second set of images (they would not fit): the Q / dO images are RINGS of nine tile slots - block
+// number `it` of a workgroup keeps tile qt in slot (8 it + qt) % 9, so one slot is always free: the next block's tile 0 goes there at
+// once and tile qt + 1 into the slot tile qt leaves behind the step's barrier (one 1-KiB DMA piece per wave and step).  The K image
+// is dead once the block's fragments are in registers: the next block's K rows land in it during the steps.  The next block's v rows
+// and o rows (delta) are requested into the registers of this block's k / v fragments right behind the last score products.  All
+// of it has landed when the last dQ product is done (`vmcnt(0)` in front of the block's LAST stores, which then drain under the
+// next block's start).
 __global__ __launch_bounds__(512) void attention_bwd_onepass_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                     const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                     bf16_t* __restrict__ dqkv, float* __restrict__ bias_ws,
-                                                                    int heads, float scale, int nblocks) {
+                                                                    int heads, float scale, int nblocks, int lab) {
     char* smem = dynamic_smem();
-    char* q_img = smem;
-    char* do_img = smem + ATTB_IMG;
-    char* k_img = smem + 2 * ATTB_IMG;
-    char* x_buf = smem + 3 * ATTB_IMG;                                   // [2][8 waves][32 keys][64 B]; V rows at block start
-    float* lse_s = reinterpret_cast<float*>(smem + 3 * ATTB_IMG + 2 * ATTB1_XBUF);
-    float* del_s = lse_s + ATT_T;
-    float* cs = del_s + ATT_T;                                           // [heads][64] column sums of dQ over this workgroup's blocks
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hf = lane >> 5, lq = lane & 31;
+    char* q_ring = smem;
+    char* do_ring = smem + ATTB1_RING;
+    char* k_img = smem + 2 * ATTB1_RING;
+    char* x_buf = k_img + ATTB_IMG;                                      // [2][8 waves][32 keys][64 B]
+    float* lse_s = reinterpret_cast<float*>(x_buf + 2 * ATTB1_XBUF);     // [2][256]: this block's and the next one's
+    float* del_s = lse_s + 2 * ATT_T;
+    float* lse_sw = del_s + ATT_T;
+    float* cs = lse_sw + ATT_T;                                           // [heads][64] column sums of dQ over this workgroup's blocks
+    const int lane = threadIdx.x & 63, hf = lane >> 5, lq = lane & 31;
+    const int w = uniform_i32(threadIdx.x >> 6);             // wave index as a scalar: what derives from it stays in SGPRs
     const int E = heads * ATT_D;
     const long rs3 = 3L * E;
     const int key = 32 * w + lq;
@@ -42,21 +52,39 @@ __global__ __launch_bounds__(512) void attention_bwd_onepass_kernel(const bf16_t
     if (bias_ws)
         for (int i = threadIdx.x; i < E; i += ATTB_THREADS) cs[i] = 0.f;    // (published by the first block's barrier)
 
-    // LDS-DMA of a block's four row images (1-KiB piece = 8 rows; wave w moves pieces 4 w .. 4 w + 3 of each) and of lse
-    auto dma_block = [&](int blk) {
-        const int view = blk / heads, head = blk % heads;
-        const bf16_t* q_base = qkv + (long)view * ATT_T * rs3 + head * ATT_D;
-        const bf16_t* do_base = d_o + (long)view * ATT_T * E + head * ATT_D;
+    // ---- requests (1-KiB LDS-DMA piece = 8 rows x 128 B; lane L fetches the 16 bytes the swizzle puts at row L / 8, position L % 8)
+    const int views = nblocks / heads;                       // block b = (head b / views, view b % views): a workgroup's consecutive blocks
+                                                             // share the head, its dQ column sums are flushed once per head
+    auto dma_tile = [&](int blk, int qt, int slot) {         // tile qt of Q (waves 0-3: 8 rows each) and of dO (waves 4-7)
+        const int view = blk % views, head = blk / views;
+        const int ln = opaque_vgpr((int)threadIdx.x) & 63;
+        const int r = 8 * (w & 3) + (ln >> 3), row = 32 * qt + r, src = (ln & 7) ^ attb_swz2(r);
+        if (w < 4) glds16(qkv + ((long)view * ATT_T + row) * rs3 + head * ATT_D + src * 8, q_ring + slot * 4096 + (w & 3) * 1024);
+        else glds16(d_o + ((long)view * ATT_T + row) * E + head * ATT_D + src * 8, do_ring + slot * 4096 + (w & 3) * 1024);
+    };
+    auto dma_k_lse = [&](int blk, int par) {                 // the K rows (4 pieces per wave) and lse of a block
+        const int view = blk % views, head = blk / views;
+        const bf16_t* k_base = qkv + (long)view * ATT_T * rs3 + head * ATT_D + E;
         const int ln = opaque_vgpr((int)threadIdx.x) & 63;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = 8 * (4 * w + i) + (ln >> 3), src = (ln & 7) ^ attb_swz2(row);
-            glds16(q_base + (unsigned)(row * (int)rs3 + src * 8), q_img + (4 * w + i) * 1024);
-            glds16(do_base + (unsigned)(row * E + src * 8), do_img + (4 * w + i) * 1024);
-            glds16(q_base + E + (unsigned)(row * (int)rs3 + src * 8), k_img + (4 * w + i) * 1024);
-            glds16(q_base + 2 * E + (unsigned)(row * (int)rs3 + src * 8), x_buf + (4 * w + i) * 1024);
+            glds16(k_base + (unsigned)(row * (int)rs3 + src * 8), k_img + (4 * w + i) * 1024);
         }
-        if (w < 4) glds4(lse + ((long)view * heads + head) * ATT_T + 64 * w + ln, reinterpret_cast<char*>(lse_s) + 256 * w);
+        if (w < 4) glds4(lse + ((long)view * heads + head) * ATT_T + 64 * w + ln, reinterpret_cast<char*>(lse_s + par * ATT_T) + 256 * w);
+    };
+    // kfw: this wave's k fragments - and, between a block's last score products and the next block's delta, the o rows of its 32
+    // queries (index 32 w + lq); vfw: its v fragments = the v rows as they lie in memory.  One register set for both lives.
+    u32x4 kfw[4], vfw[4];
+    auto request_vo = [&](int blk) {
+        const int view = blk % views, head = blk / views;
+        // (one base pointer per tensor + immediate offsets, derived here from an opaque lane id: eight precomputed 64-bit addresses
+        // held across the steps were what the register allocator spilled)
+        const int ln = opaque_vgpr((int)threadIdx.x) & 63, kq = 32 * w + (ln & 31);
+        const bf16_t* vrow = qkv + ((long)view * ATT_T + kq) * rs3 + head * ATT_D + 2 * E + 8 * (ln >> 5);
+        const bf16_t* orow = o + ((long)view * ATT_T + kq) * E + head * ATT_D + 8 * (ln >> 5);
+        global_load16_late<0>(vfw[0], vrow); global_load16_late<32>(vfw[1], vrow); global_load16_late<64>(vfw[2], vrow); global_load16_late<96>(vfw[3], vrow);
+        global_load16_late<0>(kfw[0], orow); global_load16_late<32>(kfw[1], orow); global_load16_late<64>(kfw[2], orow); global_load16_late<96>(kfw[3], orow);
     };
     // transposing reads of the dV / dK products (attention_bwd_dkv_tr_kernel's): dO^T / Q^T fragments out of the row images
     unsigned troff[2][2];                                                // [d tile][rows 0-3 / 8-11 of the 16-query step]
@@ -80,7 +108,9 @@ __global__ __launch_bounds__(512) void attention_bwd_onepass_kernel(const bf16_t
         xoff[rsel] = (unsigned)(kk * 64 + (((4 * q16 + (l16 & 3)) ^ attb1_fx(kk)) << 3));
     }
     const unsigned smem_addr = lds_addr_of(smem);
-    const unsigned q_addr = smem_addr, do_addr = smem_addr + ATTB_IMG, k_addr = smem_addr + 2 * ATTB_IMG, x_addr = smem_addr + 3 * ATTB_IMG;
+    const unsigned q_addr = smem_addr, do_addr = smem_addr + ATTB1_RING, k_addr = smem_addr + 2 * ATTB1_RING;
+    const unsigned x_addr = k_addr + ATTB_IMG;
+    const unsigned stat_addr = lds_addr_of(lse_sw) + (unsigned)(16 * hf);       // (delta: ATT_T floats below)
     float csq[4] = {0.f, 0.f, 0.f, 0.f};
     int cs_head = -1;
     auto flush_cs = [&]() {                                              // this wave's dQ column sums of the blocks of one head
@@ -95,49 +125,87 @@ __global__ __launch_bounds__(512) void attention_bwd_onepass_kernel(const bf16_t
         }
     };
 
-    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-        const int view = blk / heads, head = blk % heads;
-        if (head != cs_head) { flush_cs(); cs_head = head; }
-        dma_block(blk);
-        u32x4 ow[4];
-        {
-            const long orow = ((long)view * ATT_T + key) * E + head * ATT_D;     // (query index = this thread's key index: 32 w + lq)
+#ifdef CCD_ATTB1_LAB      // lab build: cycle totals of wave 0 / wave 7 per phase -> bias_ws[blockIdx.x * E + 16 (w == 7) + i] as floats
+    unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#define AB1_STAMP(i) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph[i] += tn_ - tprev; tprev = tn_; }
+#else
+#define AB1_STAMP(i)
+#endif
+    int blk = blockIdx.x;
+    if (blk >= nblocks) return;
+    if (w >= 4 && !(lab & 1)) wave_prio<1>();                // (guide: static priority for the younger half of an 8-wave workgroup;
+                                                             // lab bit 1: none, bit 2: the older half instead)
+    if (w < 4 && (lab & 2)) wave_prio<1>();
+    {                                                        // the first block: everything up front
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) ow[kk] = *reinterpret_cast<const u32x4*>(o + orow + 16 * kk + 8 * hf);
-        }
+        for (int qt = 0; qt < 8; ++qt) dma_tile(blk, qt, qt);
+        dma_k_lse(blk, 0);
+        request_vo(blk);
         glds_wait_all();
-        lds_barrier();
+    }
+    int b0 = 0;                                              // ring slot of this block's tile 0
+    for (int it = 0; blk < nblocks; blk += gridDim.x, ++it) {
+        const int view = blk % views, head = blk / views, nxt = blk + (int)gridDim.x;
+        const bool more = nxt < nblocks;
+        if (head != cs_head) { flush_cs(); cs_head = head; }
+        const float* lse_b = lse_s + (it & 1) * ATT_T;       // as the DMA wrote it; lse_sw: scaled for exp2
+        AB1_STAMP(0)
+        lds_barrier();                                       // this block's images are complete (every wave drained its requests) and
+                                                             // every wave has left the previous block
+        AB1_STAMP(1)
         // ---- per block: k / v fragments of this wave's keys, delta of its 32 queries, the K^T fragments of its 16 d columns
-        bf16x8 kf[4], vf[4], kT[8];
+        bf16x8 kT[8];
+        vm_landed4(vfw);
+        vm_landed4(kfw);
         {
             const int f = attb_swz2(key);
+            const int dslot = b0 + w >= 9 ? b0 + w - 9 : b0 + w;        // dO rows of this wave's queries: tile w
             float dsum = 0.f;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const int off = key * 128 + (((2 * kk + hf) ^ f) << 4);
-                kf[kk] = *reinterpret_cast<const bf16x8*>(k_img + off);
-                vf[kk] = *reinterpret_cast<const bf16x8*>(x_buf + off);
-                const u32x4 dw = *reinterpret_cast<const u32x4*>(do_img + off);
+                const u32x4 dw = *reinterpret_cast<const u32x4*>(do_ring + dslot * 4096 + lq * 128 + (((2 * kk + hf) ^ attb_swz2(lq)) << 4));
                 float a[8], b[8];
                 unpack8(dw, a);
-                unpack8(ow[kk], b);
+                unpack8(kfw[kk], b);                         // (the o rows)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dsum += a[e] * b[e];
             }
             dsum += shfl_xor(dsum, 32);
             if (hf == 0) del_s[key] = dsum;
+            // lse -> - lse * log2(e), once per block instead of once per score (the softmax below is the block's largest VALU item)
+            if (threadIdx.x < ATT_T) lse_sw[threadIdx.x] = lse_b[threadIdx.x] * -1.4426950408889634f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) kfw[kk] = *reinterpret_cast<const u32x4*>(k_img + key * 128 + (((2 * kk + hf) ^ f) << 4));
+            tr_u32x2 tl[8], th[8];
+            unsigned koff[2];                                // (from an opaque lane id: not kept in registers across the steps)
+            {
+                const int ln = opaque_vgpr((int)threadIdx.x) & 63, lg4 = ln >> 4, ll16 = ln & 15;
+#pragma unroll
+                for (int rsel = 0; rsel < 2; ++rsel) {
+                    const int kk = 8 * lg4 + 4 * rsel + (ll16 >> 2), d0 = 16 * d16 + 4 * (ll16 & 3);
+                    koff[rsel] = (unsigned)(kk * 128 + (((d0 >> 3) ^ attb_swz2(kk)) << 4) + (d0 & 7) * 2);  // (+ 32 ks rows: swz2 has period 16)
+                }
+            }
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                tr_u32x2 lo, hi;
-                const int r4 = l16 >> 2, d0 = 16 * d16 + 4 * (l16 & 3);
-                const int row0 = 32 * ks + 8 * g4 + r4, row1 = row0 + 4;
-                lds_read_tr<0>(lo, k_addr + (unsigned)(row0 * 128 + (((d0 >> 3) ^ attb_swz2(row0)) << 4) + (d0 & 7) * 2));
-                lds_read_tr<0>(hi, k_addr + (unsigned)(row1 * 128 + (((d0 >> 3) ^ attb_swz2(row1)) << 4) + (d0 & 7) * 2));
-                lds_drain();
-                kT[ks] = frag_from_tr(lo, hi);
+                lds_read_tr<0>(tl[ks], k_addr + (unsigned)(ks * 4096) + koff[0]);
+                lds_read_tr<0>(th[ks], k_addr + (unsigned)(ks * 4096) + koff[1]);
+            }
+            lds_drain();
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                kT[ks] = frag_from_tr(tl[ks], th[ks]);
+                asm volatile("" : "+v"(kT[ks]));
             }
         }
-        lds_barrier();                                       // delta is published; the V rows in the exchange image have been read
+        AB1_STAMP(2)
+        lds_barrier();                                       // delta is published; every wave is done with the K image
+        AB1_STAMP(1)
+        if (more) {
+            dma_k_lse(nxt, (it + 1) & 1);
+            dma_tile(nxt, 0, b0 + 8 >= 9 ? b0 - 1 : b0 + 8);
+        }
 
         f32x16 dk[2], dv[2];
 #pragma unroll
@@ -146,25 +214,70 @@ __global__ __launch_bounds__(512) void attention_bwd_onepass_kernel(const bf16_t
             for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
 #pragma unroll 1
         for (int qt = 0; qt < 8; ++qt) {
+            const int slot = b0 + qt >= 9 ? b0 + qt - 9 : b0 + qt;
+            const unsigned tile = (unsigned)(slot * 4096);
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
             {
-                const int row = 32 * qt + lq, f = attb_swz2(row);
+                // the eight row fragments of the step by hand, all in flight at once (left to the compiler: read two, lgkmcnt(0),
+                // two products, four LDS round trips in a row - the score products were 22 % of a block)
+                const int f = attb_swz2(lq);
+                bf16x8 qa[4], da[4];
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const int off = row * 128 + (((2 * kk + hf) ^ f) << 4);
-                    s = mfma_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(q_img + off), kf[kk], s);       // S[q][key]
-                    dp = mfma_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(do_img + off), vf[kk], dp);    // dP[q][key]
+                    const unsigned off = tile + (unsigned)(lq * 128 + (((2 * kk + hf) ^ f) << 4));
+                    lds_read_frag<0>(qa[kk], q_addr + off);
+                    lds_read_frag<0>(da[kk], do_addr + off);
                 }
-            }
+                // The step's statistics (this lane's 16 queries: 4 x 16 bytes of - lse log2 e, 4 x 16 of delta) ride in the registers the
+                // first / last four fragments leave: requested between the products, they land under them instead of as four LDS round
+                // trips in front of the exponentials (left to the compiler the softmax was 30 % of a block).
+                auto stat_read = [&](bf16x8& dst, int j, int which) {
+                    lds_read_frag<0>(dst, stat_addr + (unsigned)(qt * 128 + j * 32) - (unsigned)(which * ATT_T * 4));
+                };
+                lds_wait_frag<7>(qa[0]);
+                s = mfma_32x32x16_bf16(qa[0], __builtin_bit_cast(bf16x8, kfw[0]), s);           // S[q][key]
+                lds_wait_frag<6>(da[0]);
+                dp = mfma_32x32x16_bf16(da[0], __builtin_bit_cast(bf16x8, vfw[0]), dp);         // dP[q][key]
+                lds_wait_frag<5>(qa[1]);
+                s = mfma_32x32x16_bf16(qa[1], __builtin_bit_cast(bf16x8, kfw[1]), s);
+                lds_wait_frag<4>(da[1]);
+                dp = mfma_32x32x16_bf16(da[1], __builtin_bit_cast(bf16x8, vfw[1]), dp);
+                stat_read(qa[0], 0, 0); stat_read(da[0], 1, 0); stat_read(qa[1], 2, 0); stat_read(da[1], 3, 0);
+                lds_wait_frag<7>(qa[2]);
+                s = mfma_32x32x16_bf16(qa[2], __builtin_bit_cast(bf16x8, kfw[2]), s);
+                lds_wait_frag<6>(da[2]);
+                dp = mfma_32x32x16_bf16(da[2], __builtin_bit_cast(bf16x8, vfw[2]), dp);
+                lds_wait_frag<5>(qa[3]);
+                s = mfma_32x32x16_bf16(qa[3], __builtin_bit_cast(bf16x8, kfw[3]), s);
+                lds_wait_frag<4>(da[3]);
+                dp = mfma_32x32x16_bf16(da[3], __builtin_bit_cast(bf16x8, vfw[3]), dp);
+                stat_read(qa[2], 0, 1); stat_read(da[2], 1, 1); stat_read(qa[3], 2, 1); stat_read(da[3], 3, 1);
+                if (qt == 7 && more) request_vo(nxt);        // (the k / v fragments have fed their last products)
+                AB1_STAMP(3)
+                // p = exp2(S scale log2 e - lse log2 e) for the 16 scores, then dS / scale = p (dP - delta): the factor goes onto dK and
+                // dQ where they leave (4 + 2 x 16 values per step and block instead of 16 per step)
+                bf16x8* const stl[4] = {&qa[0], &da[0], &qa[1], &da[1]};
+                bf16x8* const std_[4] = {&qa[2], &da[2], &qa[3], &da[3]};
+                mlp_static_for<0, 4>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    lds_wait_frag<7 - j>(*stl[j]);
+                    const f32x4v lv = __builtin_bit_cast(f32x4v, *stl[j]);
+                    const float l4[4] = {lv.x, lv.y, lv.z, lv.w};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qq = 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                const float p = fast_exp2(fmaf(s[r], scale * 1.4426950408889634f, -lse_s[qq] * 1.4426950408889634f));
-                s[r] = p;
-                dp[r] = p * (dp[r] - del_s[qq]) * scale;
+                    for (int i = 0; i < 4; ++i) s[4 * j + i] = fast_exp2(fmaf(s[4 * j + i], scale * 1.4426950408889634f, l4[i]));
+                });
+                mlp_static_for<0, 4>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    lds_wait_frag<3 - j>(*std_[j]);
+                    const f32x4v dl = __builtin_bit_cast(f32x4v, *std_[j]);
+                    const float d4[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dp[4 * j + i] = s[4 * j + i] * (dp[4 * j + i] - d4[i]);
+                });
             }
+            AB1_STAMP(4)
             // the dS tile for the dQ product: [key = this lane][queries 8 j + 4 hf .. + 3] = 8 bytes, slot 2 j + hf of the key's row
             char* xw = x_buf + (qt & 1) * ATTB1_XBUF + w * 2048 + lq * 64;
             const int fx = attb1_fx(lq);
@@ -175,7 +288,6 @@ __global__ __launch_bounds__(512) void attention_bwd_onepass_kernel(const bf16_t
                 pk.y = pack_bf2(dp[4 * j + 2], dp[4 * j + 3]);
                 *reinterpret_cast<u32x2*>(xw + (((2 * j + hf) ^ fx) << 3)) = pk;
             }
-            const unsigned tile = (unsigned)(qt * 32 * 128);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 tr_u32x2 x[4][2];
@@ -201,42 +313,59 @@ __global__ __launch_bounds__(512) void attention_bwd_onepass_kernel(const bf16_t
                 lds_wait_frag<0>(d);
                 dk[1] = mfma_32x32x16_bf16(d, dsf, dk[1]);
             }
-            lds_barrier();                                   // every wave's dS tile of this step is in the exchange image (LDS-only
-                                                             // barrier: the dQ stores of the previous step stay in flight)
+            AB1_STAMP(5)
+            lds_barrier();                                   // every wave's dS tile of this step is in the exchange image, and every
+                                                             // wave is done with this step's Q / dO tile (LDS-only barrier: the dQ
+                                                             // stores and the prefetch requests stay in flight)
+            AB1_STAMP(6)
+            if (more && qt < 7) dma_tile(nxt, qt + 1, slot);
             // ---- dQ piece [16 d][16 queries] of this step over all 256 keys
             f32x4 dq = {0.f, 0.f, 0.f, 0.f};
             const unsigned xb = x_addr + (unsigned)((qt & 1) * ATTB1_XBUF);
-            tr_u32x2 xl[8], xh[8];
+            mlp_static_for<0, 2>([&](auto HB) {              // two batches of four key tiles (eight transposing reads in flight)
+                constexpr int hb = decltype(HB)::value;
+                tr_u32x2 xl[4], xh[4];
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                lds_read_tr<0>(xl[ks], xb + (unsigned)(ks * 2048) + xoff[0]);
-                lds_read_tr<0>(xh[ks], xb + (unsigned)(ks * 2048) + xoff[1]);
-            }
-            mlp_static_for<0, 8>([&](auto KS) {
-                constexpr int ks = decltype(KS)::value;
-                bf16x8 bfr = frag_from_tr(xl[ks], xh[ks]);
-                lds_wait_frag<2 * (7 - ks)>(bfr);
-                dq = mfma_16x16x32_bf16(kT[ks], bfr, dq);
+                for (int ks = 0; ks < 4; ++ks) {
+                    lds_read_tr<0>(xl[ks], xb + (unsigned)((4 * hb + ks) * 2048) + xoff[0]);
+                    lds_read_tr<0>(xh[ks], xb + (unsigned)((4 * hb + ks) * 2048) + xoff[1]);
+                }
+                mlp_static_for<0, 4>([&](auto KS) {
+                    constexpr int ks = decltype(KS)::value;
+                    bf16x8 bfr = frag_from_tr(xl[ks], xh[ks]);
+                    lds_wait_frag<2 * (3 - ks)>(bfr);
+                    dq = mfma_16x16x32_bf16(kT[4 * hb + ks], bfr, dq);
+                });
             });
+            AB1_STAMP(7)
+            if (qt == 7) glds_wait_all();                    // the next block's images and rows have landed (requested at least a step ago;
+                                                             // what is still in flight are the stores of earlier steps)
             {
                 u32x2 pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { dq[r] *= scale; csq[r] += dq[r]; }
                 pk.x = pack_bf2(dq[0], dq[1]);
                 pk.y = pack_bf2(dq[2], dq[3]);
                 bf16_t* dst = dqkv + ((long)view * ATT_T + 32 * qt + 16 * q16 + l16) * rs3 + head * ATT_D + 16 * d16 + 4 * g4;
                 *reinterpret_cast<u32x2*>(dst) = pk;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) csq[r] += dq[r];
             }
+            AB1_STAMP(8)
         }
         bf16_t* drow = dqkv + ((long)view * ATT_T + key) * rs3 + head * ATT_D;
-        attb_store_t(drow + E, dk, hf);
+        att_store_row16(drow + E, dk, hf, scale);
         attb_store_t(drow + 2 * E, dv, hf);
-        lds_barrier();                                       // the images are rewritten by the next block's DMA
+        b0 = b0 + 8 >= 9 ? b0 - 1 : b0 + 8;
+        AB1_STAMP(9)
     }
     flush_cs();
     __syncthreads();
     if (bias_ws)
         for (int i = threadIdx.x; i < E; i += ATTB_THREADS) bias_ws[(long)blockIdx.x * E + i] = cs[i];
+#ifdef CCD_ATTB1_LAB
+    __syncthreads();
+    if (bias_ws && lane == 0 && (w == 0 || w == 7))
+        for (int i = 0; i < 10; ++i) bias_ws[(long)blockIdx.x * E + (w == 7 ? 16 : 0) + i] = (float)ph[i];
+#endif
 }
 
 }  // namespace ccd

@@ -84,6 +84,14 @@ __device__ __forceinline__ void buf_load16_late(buf_u32x4& dst, buf_desc r, unsi
 }
 template <int N>
 __device__ __forceinline__ void vm_arrived(buf_u32x4& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+a"(a) : "n"(N)); }
+// a 16-byte global load whose arrival the kernel tracks itself (attention_bwd1.h: the next block's v / o rows, requested under the
+// current block's last products): the compiler sees no VMEM operation, the value may only be used behind a vmcnt wait of the
+// kernel's own followed by vm_landed4 (no instruction: the dependency that keeps every use behind the wait)
+template <int OFF = 0>
+__device__ __forceinline__ void global_load16_late(buf_u32x4& dst, const void* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void vm_landed4(buf_u32x4 (&a)[4]) { asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])); }
 // "this value is needed HERE": the compiler places its wait for a load in front of the first instruction that reads the result.
 // In an unrolled loop that consumes several prefetched rows and stores after each, that puts a wait for row i + 1 BEHIND the
 // stores of row i - and with loads and stores pending on the one vmcnt the compiler makes it `s_waitcnt vmcnt(0)`: the store

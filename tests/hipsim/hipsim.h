@@ -276,6 +276,17 @@ inline void buf_load16_late(buf_u32x4& dst, buf_desc r, unsigned lane_offset, un
 }
 template <int N>
 inline void vm_arrived(buf_u32x4&) { ::sim_dma_retire((size_t)N); }
+template <int OFF = 0>
+inline void global_load16_late(buf_u32x4& dst, const void* p0) {
+    const void* p = reinterpret_cast<const char*>(p0) + OFF;
+    if (::sim_dma_late()) {
+        dst = buf_u32x4{0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u};
+        sim::cur->dma.push_back({reinterpret_cast<char*>(&dst), p, 16});
+    } else {
+        std::memcpy(&dst, p, 16);
+    }
+}
+inline void vm_landed4(buf_u32x4 (&)[4]) {}
 inline void buf_store16_nt(buf_rsrc r, unsigned a, unsigned b, buf_u32x4 v) { buf_store16(r, a, b, v); }
 inline void wave_sleep(int) {}
 inline void wave_nap(int) {}

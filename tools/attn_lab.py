@@ -40,6 +40,10 @@ def main():
             msb = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, scale, d_bias=d_bias, dout_colsum=dcs))
         print(json.dumps({"kernel": "attention_bwd one pass (round 4)" if onepass else "attention_bwd (dq + dkv_tr)", "views": a.views,
                           "ms": round(ms, 4), "ms_with_qkv_bias_gradient": round(msb, 4)}), flush=True)
+    for lab, what in ((1, "no static priority"), (3, "priority on the older half")):
+        with ops.policy(attn_onepass=1, lab=lab):
+            ms = timeit(lambda: ops.attention_bwd(qkv, out, d_out, lse, heads, scale, d_bias=d_bias, dout_colsum=dcs))
+        print(json.dumps({"kernel": "attention_bwd one pass", "lab": what, "ms_with_qkv_bias_gradient": round(ms, 4)}), flush=True)
     if os.environ.get("ATTN_LAB_SHORT"):
         return
     for lab, what in ((1, "no stores"), (2, "no loads"), (3, "no loads, no stores")):
