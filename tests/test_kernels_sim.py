@@ -112,6 +112,8 @@ def test_attention_sim(sim):
     with ops.policy(attn_tr=0):                              # dK / dV on the four register-staged images
         kc.check_attention(sim.device, views=1, heads=2)
     kc.check_attention(sim.device, views=3, heads=1, seed=4)
+    with ops.policy(attn_onepass=0):             # the dQ + dK/dV pair (rounds 1-3)
+        kc.check_attention(sim.device, views=2, heads=2, seed=6)
     with ops.policy(attn_onepass=1):             # round 4: one pass, five products, dS exchanged through LDS (attention_bwd1.h)
         kc.check_attention(sim.device, views=1, heads=2)
         kc.check_attention(sim.device, views=6, heads=3, seed=5)      # 18 blocks on 4 workgroups: heads change inside a workgroup's walk
