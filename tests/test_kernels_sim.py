@@ -281,6 +281,7 @@ def test_mlp_fused_sim(sim):
     kc.check_mlp_fused(sim.device, M=300, E=128, H=256, rps=128)
     kc.check_mlp_fused(sim.device, M=200, E=384, H=128, rps=8, store_u=False)     # per-row DropPath scales
     kc.check_mlp_fused(sim.device, M=130, E=512, H=128, rps=8)                     # 3-slot ring (vit_base)
+    kc.check_mlp_fused(sim.device, M=140, E=384, H=320, rps=8)                     # 5 hidden chunks at E = 384
 
 
 def test_kmeans2_mask_sim(sim):
