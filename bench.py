@@ -89,6 +89,8 @@ def pmc_traffic(kind, a):
     if table.get("_kernel_sources_sha256") != kernel_sources_digest():
         return None
     rec = table.get(kind)
+    if kind.startswith("_"):                # whole-step totals are plain numbers
+        return rec
     return rec["bytes_per_launch"] if rec else None
 
 
@@ -506,6 +508,9 @@ def main():
                                 "unit": "GB/s" if hbm_bound else "TFLOP/s",
                                 "frac": round(gbs / PEAK_HBM_GBS if hbm_bound else tflops / PEAK_BF16_TF, 4),
                                 "traffic": pmc_traffic(key, a),
+                                # HBM bytes of ONE WHOLE STEP from the same PMC passes (every dispatch, fetch + write; DESIGN section 4d has
+                                # the budget by tensor) - null unless the shipped kernel sources are the ones the passes ran on
+                                "step_bytes": pmc_traffic("_step_bytes", a),
                                 "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
                                 "algorithmic_flops_per_launch": round(d["flops"] / d["launches"]),
                                 "arithmetic_intensity_flop_per_byte": round(intensity, 1),

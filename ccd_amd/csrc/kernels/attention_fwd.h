@@ -127,10 +127,6 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const bf16_t* __r
 #pragma unroll 1
         for (int ch = 0; ch < 2; ++ch) {
             f32x16 s[4];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
             {   // S^T chunk = K rows . Q^T: the 16 K fragments are read by hand, ATT_DEPTH ahead of their MFMA (mlp_fused.h:
                 // mlp_product).  Left to the compiler every product sat behind its own read and `lgkmcnt(0)`: an LDS round trip
                 // per MFMA.  Row 128 ch + 32 kt + lq: the swizzle term (row >> 1) & 7 is the lane's, tiles are immediate offsets.
@@ -142,7 +138,9 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const bf16_t* __r
                     areg,
                     [&](auto K, const bf16x8& kf) {
                         constexpr int k = decltype(K)::value;
-                        s[k >> 2] = mfma_32x32x16_bf16(kf, qf[k & 3], s[k >> 2]);
+                        // (the first product of a tile takes the constant 0 as its accumulator input: 64 v_mov per chunk less)
+                        if constexpr ((k & 3) == 0) s[k >> 2] = mfma_32x32x16_bf16(kf, qf[0], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
+                        else s[k >> 2] = mfma_32x32x16_bf16(kf, qf[k & 3], s[k >> 2]);
                     },
                     [](auto) {});
             }
@@ -156,21 +154,24 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const bf16_t* __r
             const float alpha = fast_exp2((mx - nm) * c2);            // 0 for the first chunk
             mx = nm;
             const float mc2 = nm * c2;
-            float csum = 0.f;
+            float cs4[4] = {0.f, 0.f, 0.f, 0.f};             // (four partial sums: independent chains, pairable adds)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float p = fast_exp2(fmaf(s[kt][r], c2, -mc2));
                     s[kt][r] = p;
-                    csum += p;
+                    cs4[r & 3] += p;
                 }
+            float csum = (cs4[0] + cs4[1]) + (cs4[2] + cs4[3]);
             csum += shfl_xor(csum, 32);
             sum = sum * alpha + csum;
+            if (ch > 0) {                                    // (the first chunk's accumulators are still zero: nothing to rescale)
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+                for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            }
             {   // O^T += V^T . P: fragment (kt, s2, dt) = V^T rows 32 dt + lq, keys 16 ks .. + 15 with ks = 2 (4 ch + kt) + s2; the
                 // swizzle XORs the low bits of ks with the lane's (d & 15): one address register per ks & 7 = 2 kt + s2
                 unsigned vreg[8];

@@ -255,14 +255,15 @@ static inline const void* ccd_fn_ptr(F* f) { return reinterpret_cast<const void*
 #define CCD_LAUNCH(kernel, grid, block, smem, stream, ...)                                                      \
     do {                                                                                                        \
         if ((smem) > 65536) {                                                                                   \
-            static unsigned long long ccd_devs_ = 0; /* the attribute is per function AND per device */         \
+            /* the attribute is per function AND per device; a call site whose smem varies between launches (rowproj +N*4,   \
+               gemm256 with column sums, augment_spatial by image size) must raise it again: keep the largest set so far */   \
+            static int ccd_max_[64] = {0};                                                                      \
             int ccd_dev_ = 0;                                                                                   \
             (void)hipGetDevice(&ccd_dev_);                                                                      \
-            const unsigned long long ccd_bit_ = 1ull << (ccd_dev_ & 63);                                        \
-            if (!(ccd_devs_ & ccd_bit_)) {                                                                      \
+            if ((int)(smem) > ccd_max_[ccd_dev_ & 63]) {                                                        \
                 (void)hipFuncSetAttribute(ccd_fn_ptr(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                           (int)(smem));                                                         \
-                ccd_devs_ |= ccd_bit_;                                                                          \
+                ccd_max_[ccd_dev_ & 63] = (int)(smem);                                                          \
             }                                                                                                   \
         }                                                                                                       \
         hipLaunchKernelGGL(kernel, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__);                \

@@ -7,7 +7,9 @@ to view 2 with probability 0.7 (datasetsupervised_kmeans.py:40-45,60), and `thet
 factors cancel when the augmentation runs at the network resolution, which it does here).  A sample whose 0.7 draw fails
 gets the PLAIN image as view 2 (:72-74): its colour parameters are the identity.
 
-Colour = the reference's imgaug chain, member list by member list, with its probabilities (augmentation_pipelines.py:120-205,
+Colour = the reference's imgaug chain: its member LISTS and probabilities, 42 of its 50 members reproduced (the other eight - listed
+below - are drawn and leave the image unchanged, so the augmentation distribution is WEAKER than the reference's; README parity
+claims say so) (augmentation_pipelines.py:120-205,
 severity 5 - what the shipped pretraining configs select; dataset_pretrain.py:79-158 for finetuning): `Sometimes(0.2, Identity,
 Sequential[arithmetic: OneOf 21, color: Sometimes(0.7, OneOf 9), Blur: Sometimes(0.7, ...), contrast: Sometimes(0.7, OneOf 8),
 weather: Sometimes(0.7, OneOf 4)])`.  A draw picks the member by its POSITION in the reference's list and writes what the kernel

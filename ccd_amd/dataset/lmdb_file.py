@@ -239,7 +239,10 @@ def write_lmdb(path, items, psize=4096, presorted=False):
     nodemax = (((psize - PAGEHDR) // 2) & ~1) - 2    # me_nodemax: larger leaf nodes put their data on overflow pages
     counts = {"leaf": 0, "branch": 0, "ovf": 0, "entries": 0}
     state = {"next_pg": 2}
-    f = builtins.open(os.path.join(path, "data.mdb"), "wb")
+    # (written next to the target and moved over it at the end: a bad key or an exception inside a streaming `items` generator must
+    # not leave a truncated database with zeroed meta pages where a good one was)
+    final_path, tmp_path = os.path.join(path, "data.mdb"), os.path.join(path, "data.mdb.tmp")
+    f = builtins.open(tmp_path, "wb")
     f.write(b"\0" * (2 * psize))                      # the two meta pages are written last
 
     def emit(image):
@@ -348,8 +351,15 @@ def write_lmdb(path, items, psize=4096, presorted=False):
         f.seek(0)
         f.write(meta(0, 0, False))          # the state before the load (txn 0), as mdb_env_init_meta leaves it
         f.write(meta(1, 1, True))           # the committed load (txn 1 -> meta page 1)
-    finally:
+    except BaseException:
         f.close()
+        try:
+            os.unlink(tmp_path)
+        except OSError:
+            pass
+        raise
+    f.close()
+    os.replace(tmp_path, final_path)
     with builtins.open(os.path.join(path, "lock.mdb"), "wb") as fl:
         fl.write(b"\0" * 8192)
     return {"entries": counts["entries"], "depth": depth, "leaf_pages": counts["leaf"], "branch_pages": counts["branch"],

@@ -105,7 +105,8 @@ class GraphedTrainingStep:
         during the temperature warm-up, once at epoch 30).
     The first `eager_steps` calls run eagerly (they are real iterations): lazily built tables, MIOpen's algorithm search and
     the allocator's pools settle before anything is captured.  Single process only - the gradient all-reduce of
-    parallel.DataParallel is launched from autograd hooks on a side stream and is not captured."""
+    parallel.DataParallel is launched from autograd hooks on a side stream and is not captured.  Bench-only (`bench.py --graph`):
+    train.py runs the eager iteration, whose finite-loss check reads the loss every step."""
 
     def __init__(self, student, teacher, dino_loss: DINOLoss, optimizer: FusedClipAdamW, eager_steps=2):
         if hasattr(student, "finish_gradient_sync"):
@@ -115,13 +116,17 @@ class GraphedTrainingStep:
         dev = student.arena.device
         self._mom = HostStaging((2,), torch.float32, dev)
         self._seed = HostStaging((1,), torch.int64, dev)
+        if int(eager_steps) < 1:     # the first capture relies on tables an eager step builds (optimizer table, weight transposes), and
+            raise ValueError("GraphedTrainingStep needs at least one eager step before it captures")    # the DropPath seed draw syncs
         self.eager_left = int(eager_steps)
         self.key = self.graph = None
         self.captures = self.replays = 0
 
     def _key(self, images, masks, metrics, epoch):
+        from . import engine
+        fusion = tuple(sorted((k, v) for k, v in vars(engine.Fusion).items() if not k.startswith("_") and isinstance(v, (bool, int, type(None)))))
         return (tuple(images.shape), images.dtype, tuple(masks.shape), masks.dtype, tuple(metrics.shape), metrics.dtype,
-                epoch < 30, float(self.dino_loss.teacher_temp_schedule[epoch]))
+                epoch < 30, float(self.dino_loss.teacher_temp_schedule[epoch]), bool(getattr(self.student, "training", True)), fusion)
 
     def _record(self, body):
         """-> (something with .replay(), DropPath seeds drawn by one pass of `body`).  Capturing launches nothing."""

@@ -50,6 +50,8 @@ def collect(path, counter):
                 key = "gemm_nt_lnbwd" if (m and m.group(1) == "0") else "gemm_nt_resid"
             elif "attention_fwd_kernel" in name:
                 key = "attention_fwd"
+            elif "attention_bwd_onepass_kernel" in name:     # round 4: one kernel per ops.attention_bwd call
+                key = "attention_bwd"
             elif "attention_bwd_dq_kernel" in name:
                 key = "attention_bwd_dq"
             elif "attention_bwd_dkv" in name:
@@ -57,8 +59,10 @@ def collect(path, counter):
             elif "ln_fwd_kernel" in name:
                 key = "ln_fwd"
             else:
-                continue
-            per[key].append(float(r["Counter_Value"]))
+                key = None
+            per["_all"].append(float(r["Counter_Value"]))    # every dispatch of the run: the step's total traffic
+            if key is not None:
+                per[key].append(float(r["Counter_Value"]))
     return per
 
 
@@ -78,8 +82,14 @@ out = {"_method": {"fetch": "FETCH_SIZE[KiB] * 1024 * 2 (gfx950 128-B requests t
                    "write": f"WRITE_SIZE[KiB] * 1024 * {wcal:.4f} (calibrated on ccd::ln_fwd_kernel, known {ln_write:.0f} B)",
                    "fetch_check": round(ln_f / ln_read, 4), "source": [sys.argv[1].split("gpurun_out/")[-1],
                                                                         sys.argv[2].split("gpurun_out/")[-1]]}}
+# the whole step (the bytes budget): every dispatch of the two timed steps, the same corrections (the x 2 of
+# FETCH_SIZE is exact for wide coalesced reads - what the step's large kernels issue - and an upper bound elsewhere)
+_fa, _wa = steady(fetch["_all"]), steady(write["_all"])
+out["_step_bytes"] = round((sum(_fa) * 1024 * 2 + sum(_wa) * 1024 * wcal) / 2)
+out["_step_fetch_bytes"] = round(sum(_fa) * 1024 * 2 / 2)
+out["_step_write_bytes"] = round(sum(_wa) * 1024 * wcal / 2)
 for k in sorted(fetch):
-    if k == "ln_fwd":
+    if k == "ln_fwd" or k == "_all":
         continue
     fv, wv = steady(fetch[k]), steady(write.get(k, [0.0]))
     fb = sum(fv) / len(fv) * 1024 * 2
