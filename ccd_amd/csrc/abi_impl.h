@@ -310,12 +310,15 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
     // step); at N = 384 (one and a half tiles) the 128-row kernels are faster
     const bool f32_256 = epilogue != CCD_EPI_ATOMIC && (pol.gemm_256_f32 || N % 256 == 0);
     const bool colsum_fits = !colsum || N <= ccd::G256_MAX_COLSUM_N;      // gemm256.h keeps the column sums of every column in LDS
+    // gemm256.h's gelu'(u) epilogue addresses u and both outputs with 32-bit byte offsets (buffer loads / stores)
+    const bool dgelu_fits = epilogue != CCD_EPI_DGELU || (((long)M * ldaux + N) * 2 < CCD_MAX_OPERAND_BYTES &&
+        ((long)M * ldc + N) * 2 < CCD_MAX_OPERAND_BYTES && (!C2 || ((long)M * ldc2 + N) * 2 < CCD_MAX_OPERAND_BYTES));
     if (pol.gemm_256 >= 1 && (bf16_out || f32_256) && M >= pol.gemm_256_min_m &&
-        N >= pol.gemm_256_min_n && colsum_fits) {
+        N >= pol.gemm_256_min_n && colsum_fits && dgelu_fits) {
         if (pol.gemm_256_deep) return ccd_launch_gemm256<256, true>(p, epilogue, stream);
         return ccd_launch_gemm256<256>(p, epilogue, stream);
     }
-    if (pol.gemm_256 >= 2 && epilogue != CCD_EPI_ATOMIC && M >= pol.gemm_256_min_m && colsum_fits) return ccd_launch_gemm256<128>(p, epilogue, stream);
+    if (pol.gemm_256 >= 2 && epilogue != CCD_EPI_ATOMIC && M >= pol.gemm_256_min_m && colsum_fits && dgelu_fits) return ccd_launch_gemm256<128>(p, epilogue, stream);
     int splits = 1;
     if (epilogue == CCD_EPI_ATOMIC && K >= 16384) {      // few output tiles, long contraction (the head's data gradient,
         p.k_per_split = 8192;                            // K = 65536: 52 live tiles): slices of 8192 accumulate by fp32 atomics

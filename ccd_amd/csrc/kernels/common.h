@@ -5,6 +5,7 @@ namespace ccd {
 typedef unsigned short bf16_t;                                    // raw bfloat16 storage
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;       // one 16-byte global/LDS transaction per lane
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;   // packed 16-bit integer VALU (v_pk_*_u16)
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
 
 __device__ __forceinline__ unsigned f2bits(float f) { unsigned u; __builtin_memcpy(&u, &f, 4); return u; }

@@ -80,6 +80,9 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
     }
 
     if (slot >= cnt_x) return;
+    // (Round 4 measured a phase skew here - workgroup slot s starting (s % phases) * delay late, 2 / 4 / 8 phases, 8 - 32 k cycles -
+    // on the theory that 256 CUs storing their epilogues at once saturate HBM while the main loops leave it idle: 0.349 - 0.352
+    // against 0.355 ms for the gelu' product, nothing.  The workgroups are not phase-locked)
     // column sums (bias gradients): LDS accumulators behind the operand buffers for every column of the product, flushed by
     // one pass of global atomics when the workgroup is done (was: per tile a transpose through the staging image, three
     // barriers and 256 global atomics - 40 us of a 360-us launch).  The launcher sizes the LDS (g256_smem_bytes).
@@ -152,6 +155,13 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
         bias_r = 0.f;
         if (BIAS_LDS && p.bias && t < BN && n0 + t < p.N) bias_r = p.bias[n0 + t];
     };
+    // gelu'(u) epilogue: descriptors of the pre-activations and the two outputs (rows < M only; the ABI keeps them below 2 GiB)
+    buf_rsrc r_aux = make_rsrc(nullptr, 0), r_c = make_rsrc(nullptr, 0), r_c2 = make_rsrc(nullptr, 0);
+    if (EPI == EPI_DGELU) {
+        r_aux = make_rsrc(p.aux, (unsigned)((((long)p.M - 1) * p.ldaux + p.N) * 2));
+        r_c = make_rsrc(p.C, (unsigned)((((long)p.M - 1) * p.ldc + p.N) * 2));
+        if (p.C2) r_c2 = make_rsrc(p.C2, (unsigned)((((long)p.M - 1) * p.ldc2 + p.N) * 2));
+    }
     unsigned item = slot;
     setup(item);
     load_bias();
@@ -293,24 +303,48 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
         constexpr int ROWB = STAGE_BF16 ? BN * 2 : BN * 4;    // bytes per staged row
         constexpr int CT = BN / 8;                            // column threads (8 columns each) in the row pass
         constexpr int RSTEP = G256_THREADS / CT;              // rows per row-pass step
+        // Table layout: entry i (|u| = bf16 bit pattern LUT_LO + i) of the non-negative half, then the same 1536 entries for negative u
+        // (f(-u) = 1 - f(u), folded in when the table is built): the row pass needs no compare / subtract / select per element.  The gelu'
+        // epilogue keeps {gelu'(u), Phi(u)} side by side - ONE 8-byte gather per element serves both outputs.  The gathers of a row
+        // step are issued back to back by hand and waited for ONCE: compiler-issued, each ds_read_b32 was followed by its own
+        // `s_waitcnt lgkmcnt(0)` - 16 serialised LDS round trips per 8 elements, two thirds of this kernel's epilogue (round 4).
+        constexpr unsigned LUT_N = LUT_HI - LUT_LO;
+        constexpr int LUT_STRIDE = EPI == EPI_DGELU ? 8 : 4;              // bytes per entry
+        constexpr int LUT_NEG = 16384;                                    // gelu' table: byte offset of the negative half (32 KiB in all)
         float* lut = reinterpret_cast<float*>(stg + SROWS * ROWB);        // behind the (single) bf16 staging image
-        float* lut_cdf = lut + (LUT_HI - LUT_LO);             // gelu'(u) epilogue that also emits gelu(u): second table, Phi
         const bool want_gelu = EPI == EPI_DGELU && p.C2 != nullptr;
         if (USE_LUT) {
-            for (unsigned i = t; i < LUT_HI - LUT_LO; i += G256_THREADS) {
+            for (unsigned i = t; i < LUT_N; i += G256_THREADS) {
                 const float x = bf2f((bf16_t)(LUT_LO + i));
                 const GeluTerms gt = gelu_terms(x);
-                lut[i] = EPI == EPI_GELU ? gt.cdf : fmaf(x * 0.3989422804014327f, gt.gauss, gt.cdf);
-                if (want_gelu) lut_cdf[i] = gt.cdf;
+                if (EPI == EPI_GELU) {
+                    lut[i] = gt.cdf;
+                    lut[LUT_N + i] = 1.0f - gt.cdf;
+                } else {
+                    const float d = fmaf(x * 0.3989422804014327f, gt.gauss, gt.cdf);
+                    lut[2 * i] = d;
+                    lut[2 * i + 1] = gt.cdf;
+                    lut[LUT_NEG / 4 + 2 * i] = 1.0f - d;
+                    lut[LUT_NEG / 4 + 2 * i + 1] = 1.0f - gt.cdf;
+                }
             }
         }
-        auto lut_from = [&](const float* table, unsigned bits16) -> float {     // f(u) for the bf16 bit pattern of u
-            const unsigned mag = bits16 & 0x7fffu;
-            const unsigned idx = (mag < LUT_LO ? LUT_LO : (mag > LUT_HI - 1u ? LUT_HI - 1u : mag)) - LUT_LO;
-            const float f = table[idx];
-            return (bits16 & 0x8000u) ? 1.0f - f : f;
+        const unsigned lut_addr = lds_addr_of(lut);
+        // the same for the TWO bf16 patterns of a dword, as two 16-bit byte offsets into the gelu' table (packed 16-bit VALU: and, max,
+        // min, sub, shift for two elements; the negative half of that table starts LUT_NEG = 16 KiB in, so the sign bit, shifted
+        // right by one, IS its offset)
+        auto lut_offsets2 = [&](unsigned w) -> unsigned {
+            const u16x2 lo2 = {(unsigned short)LUT_LO, (unsigned short)LUT_LO}, hi2 = {(unsigned short)(LUT_HI - 1u), (unsigned short)(LUT_HI - 1u)};
+            u16x2 m = __builtin_bit_cast(u16x2, w & 0x7fff7fffu);
+            m = __builtin_elementwise_min(__builtin_elementwise_max(m, lo2), hi2);
+            const u16x2 off = (m - lo2) << 3;                                  // < 12 288
+            return __builtin_bit_cast(unsigned, off) | ((w >> 1) & 0x40004000u);    // sign bit -> + LUT_NEG bytes
         };
-        auto lut_at = [&](unsigned bits16) -> float { return lut_from(lut, bits16); };
+        auto lut_entry = [&](unsigned bits) -> unsigned {          // LDS address of the entry of the bf16 pattern in bits[15:0]
+            const unsigned mag = bits & 0x7fffu;
+            const unsigned c = mag < LUT_LO ? LUT_LO : (mag > LUT_HI - 1u ? LUT_HI - 1u : mag);
+            return lut_addr + (c - LUT_LO) * LUT_STRIDE + ((bits >> 15) & 1u) * (LUT_N * LUT_STRIDE);
+        };
         if (p.alpha != 1.0f) {
 #pragma unroll
             for (int i = 0; i < TI; ++i)
@@ -331,14 +365,20 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
         // been waited for and before its stores go out - so their HBM latency is spent under that pass's row sweep (requested at the
         // top of their own pass they cost a round trip per pass: four per tile, a quarter of the kernel)
         u32x4 auxq[2][SROWS / RSTEP];
+        // gelu'(u) epilogue: buffer addressing - the lane part (the thread's row inside a step, its 8 columns; a column past N is
+        // out of range) is computed once per tile, the step's first row is a wave-uniform SGPR offset, rows past M fall outside the
+        // descriptor: no 64-bit address arithmetic and no exec-mask branch per step (10 of ~150 VALU instructions per step before)
+        auto step_row = [&](int q, int pass) -> int {            // first tile row of row step `pass` of pass q
+            return em0 + WROWS * ((pass * RSTEP) >> 5) + 32 * q + ((pass * RSTEP) & 31);
+        };
+        const bool col_ok = gn < p.N;
+        const unsigned v_aux = col_ok ? (unsigned)((rr * p.ldaux + gn) * 2) : BUF_OOB;
+        const unsigned v_c = col_ok ? (unsigned)((rr * p.ldc + gn) * 2) : BUF_OOB;
+        const unsigned v_c2 = col_ok ? (unsigned)((rr * p.ldc2 + gn) * 2) : BUF_OOB;
         auto load_aux = [&](int q, u32x4 (&dst)[SROWS / RSTEP]) {
 #pragma unroll
-            for (int pass = 0; pass < SROWS / RSTEP; ++pass) {
-                const int s2 = pass * RSTEP + rr;
-                const int gm = em0 + WROWS * (s2 >> 5) + 32 * q + (s2 & 31);
-                dst[pass] = u32x4{0u, 0u, 0u, 0u};
-                if (gm < p.M && gn < p.N) dst[pass] = *reinterpret_cast<const u32x4*>(p.aux + (long)gm * p.ldaux + gn);
-            }
+            for (int pass = 0; pass < SROWS / RSTEP; ++pass)
+                dst[pass] = buf_load16(r_aux, v_aux, (unsigned)(step_row(q, pass) * (int)p.ldaux * 2));
         };
         if (EPI == EPI_DGELU) load_aux(0, auxq[0]);
 #pragma unroll
@@ -374,7 +414,48 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
 #pragma unroll
                 for (int pass = 0; pass < SROWS / RSTEP; ++pass) needed_here(auxw[pass]);
                 if (q + 1 < TI) load_aux(q + 1, auxq[(q + 1) & 1]);
+                G256_STAMP(7)
             }
+            if (EPI == EPI_DGELU) {
+#pragma unroll
+                for (int pass = 0; pass < SROWS / RSTEP; ++pass) {
+                    const int s2 = pass * RSTEP + rr;
+                    const u32x4 uw = auxw[pass];
+                    f32x2 tab[8];                             // {gelu'(u), Phi(u)} of the 8 pre-activations
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned o2 = lut_offsets2(uw[i]);
+                        lds_gather_f32x2(tab[2 * i], lut_addr + (o2 & 0xffffu));
+                        lds_gather_f32x2(tab[2 * i + 1], lut_addr + (o2 >> 16));
+                    }
+                    const u32x4 pw = *reinterpret_cast<const u32x4*>(stg + s2 * ROWB + ((ct ^ (s2 & 15)) * 16));
+                    lds_drain();
+                    lds_landed8(tab);
+                    f32x2 r[8];                               // {product * gelu'(u), u * Phi(u)}: one packed multiply per element
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned pe = pw[e >> 1], ue = uw[e >> 1];
+                        f32x2 x;
+                        x.x = __builtin_bit_cast(float, (e & 1) ? (pe & 0xffff0000u) : (pe << 16));
+                        x.y = __builtin_bit_cast(float, (e & 1) ? (ue & 0xffff0000u) : (ue << 16));
+                        r[e] = x * tab[e];
+                    }
+                    u32x4 oc, og;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        oc[i] = pack_bf2(r[2 * i].x, r[2 * i + 1].x);
+                        og[i] = pack_bf2(r[2 * i].y, r[2 * i + 1].y);
+                    }
+                    buf_store16(r_c, v_c, (unsigned)(step_row(q, pass) * (int)p.ldc * 2), oc);
+                    if (want_gelu) buf_store16(r_c2, v_c2, (unsigned)(step_row(q, pass) * (int)p.ldc2 * 2), og);
+                    if (want_stats) {                         // rows past M: products of clamped operand rows - not counted
+                        if (step_row(q, pass) + rr < p.M) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) csum[e] += r[e].x;
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int pass = 0; pass < SROWS / RSTEP; ++pass) {
                 const int s2 = pass * RSTEP + rr;
@@ -382,25 +463,7 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                 if (gm < p.M && gn < p.N) {
                     if (STAGE_BF16) {
                         const char* src = stg + s2 * ROWB + ((ct ^ (s2 & 15)) * 16);
-                        if (EPI == EPI_DGELU) {
-                            float v[8];
-                            unpack8(*reinterpret_cast<const u32x4*>(src), v);
-                            const u32x4 uw = auxw[pass];
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] *= lut_at((uw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
-                            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = pack8(v);
-                            if (want_stats) {
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) csum[e] += v[e];
-                            }
-                            if (want_gelu) {                  // gelu(u) = u Phi(u) for the weight-gradient product that follows
-                                float gq[8];
-                                unpack8(uw, gq);
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) gq[e] *= lut_from(lut_cdf, (uw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
-                                *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + (long)gm * p.ldc2 + gn) = pack8(gq);
-                            }
-                        } else if (EPI == EPI_BF16 || p.C) {
+                        if (EPI == EPI_BF16 || p.C) {
                             const u32x4 wv = *reinterpret_cast<const u32x4*>(src);
                             *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = wv;
                             if (want_stats) {
@@ -412,10 +475,15 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                         }
                         if (EPI == EPI_GELU) {                // gelu(u) of the bf16 pre-activation that backward will see
                             const u32x4 uw = *reinterpret_cast<const u32x4*>(src);
+                            float cdf[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) lds_gather_f32(cdf[e], lut_entry(uw[e >> 1] >> (16 * (e & 1))));
                             float gq[8];
                             unpack8(uw, gq);
+                            lds_drain();
+                            lds_landed(cdf[0], cdf[1]); lds_landed(cdf[2], cdf[3]); lds_landed(cdf[4], cdf[5]); lds_landed(cdf[6], cdf[7]);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) gq[e] *= lut_at((uw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+                            for (int e = 0; e < 8; ++e) gq[e] *= cdf[e];
                             *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + (long)gm * p.ldc2 + gn) = pack8(gq);
                         }
                     } else {

@@ -170,6 +170,13 @@ __device__ __forceinline__ void lds_gather_f32(float& dst, unsigned lds_addr) {
     asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(lds_addr));
 }
 __device__ __forceinline__ void lds_landed(float& a, float& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ void lds_gather_f32x2(f32x2& dst, unsigned lds_addr) {
+    asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(lds_addr));
+}
+__device__ __forceinline__ void lds_landed8(f32x2 (&f)[8]) {
+    asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]));
+}
 __device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // four hand-issued fragment reads become visible to the compiler (no instruction: a counted or draining wait has passed)
 __device__ __forceinline__ void lds_landed4(bf16x8 (&f)[4]) { asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])); }

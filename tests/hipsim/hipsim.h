@@ -209,6 +209,9 @@ inline void lds_wait_frag(bf16x8&) {}
 inline void lds_landed4(bf16x8 (&)[4]) {}
 inline void lds_gather_f32(float& dst, unsigned lds_addr) { std::memcpy(&dst, sim::curblk->dyn_smem + lds_addr, 4); }
 inline void lds_landed(float&, float&) {}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+inline void lds_gather_f32x2(f32x2& dst, unsigned lds_addr) { std::memcpy(&dst, sim::curblk->dyn_smem + lds_addr, 8); }
+inline void lds_landed8(f32x2 (&)[8]) {}
 inline void lds_drain() {}
 template <int P>
 inline void wave_prio() {}
