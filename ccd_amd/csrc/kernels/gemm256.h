@@ -378,7 +378,7 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
         auto load_aux = [&](int q, u32x4 (&dst)[SROWS / RSTEP]) {
 #pragma unroll
             for (int pass = 0; pass < SROWS / RSTEP; ++pass)
-                dst[pass] = buf_load16(r_aux, v_aux, (unsigned)(step_row(q, pass) * (int)p.ldaux * 2));
+                dst[pass] = stream_load16<NT_DGELU>(r_aux, v_aux, (unsigned)(step_row(q, pass) * (int)p.ldaux * 2));
         };
         if (EPI == EPI_DGELU) load_aux(0, auxq[0]);
 #pragma unroll
@@ -446,8 +446,8 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                         oc[i] = pack_bf2(r[2 * i].x, r[2 * i + 1].x);
                         og[i] = pack_bf2(r[2 * i].y, r[2 * i + 1].y);
                     }
-                    buf_store16(r_c, v_c, (unsigned)(step_row(q, pass) * (int)p.ldc * 2), oc);
-                    if (want_gelu) buf_store16(r_c2, v_c2, (unsigned)(step_row(q, pass) * (int)p.ldc2 * 2), og);
+                    stream_store16<NT_DGELU>(r_c, v_c, (unsigned)(step_row(q, pass) * (int)p.ldc * 2), oc);
+                    if (want_gelu) stream_store16<NT_DGELU>(r_c2, v_c2, (unsigned)(step_row(q, pass) * (int)p.ldc2 * 2), og);
                     if (want_stats) {                         // rows past M: products of clamped operand rows - not counted
                         if (step_row(q, pass) + rr < p.M) {
 #pragma unroll

@@ -129,12 +129,12 @@ __global__ __launch_bounds__(64 * WM * WN, 8 / (WM * WN)) void gemm_tn384_kernel
     auto dma_piece = [&](int s, int i) {
         char* base = smem + (s % STAGES) * G::STAGE_BYTES;
         if (i < G::A_PIECES) {
-            glds16(ga[i], base + (G::A_PIECES * w + i) * 1024);
+            stream_glds16<NT_TN>(ga[i], base + (G::A_PIECES * w + i) * 1024);
             ga[i] += a_step;
         } else {
             const int ib = i - G::A_PIECES;
             if (ib < G::B_PIECES - 1 || b_last) {
-                glds16(gb[ib], base + G::A_BYTES + (w + G::WAVES * ib) * 1024);
+                stream_glds16<NT_TN>(gb[ib], base + G::A_BYTES + (w + G::WAVES * ib) * 1024);
                 gb[ib] += b_step;
             }
         }

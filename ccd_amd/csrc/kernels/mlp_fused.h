@@ -332,7 +332,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                 for (int cc = 0; cc < p.H / 64; ++cc)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        buf_store16(rs_u, lo_u, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldu * 2) + 128 * cc, u32x4{0u, 0u, 0u, 0u});
+                        stream_store16<NT_MLP_U>(rs_u, lo_u, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldu * 2) + 128 * cc, u32x4{0u, 0u, 0u, 0u});
                 if (store_g) {
                     const unsigned lo_g = LaneOff(t).rows8(p.ldga, 2);
 #pragma unroll 1
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
             {
                 const unsigned so = (unsigned)r0 * (unsigned)(p.ldy_in * 2), lo_y = LaneOff(t).frag(p.ldy_in, 2, 8);
 #pragma unroll
-                for (int j = 0; j < KJ; ++j) yf[j] = __builtin_bit_cast(bf16x8, buf_load16(rs_y, lo_y, so + 32 * j));
+                for (int j = 0; j < KJ; ++j) yf[j] = __builtin_bit_cast(bf16x8, stream_load16<NT_MLP_Y>(rs_y, lo_y, so + 32 * j));
             }
             f32x16 h[2];                   // H^T of the chunk being produced: 2 tiles of [32 hidden][32 rows]
             u32x4 hbw[4];                  // gelu(H) of the chunk being consumed, as packed bf16 B operands (k-step s = hbw[s])
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const u32x4 v = *reinterpret_cast<const u32x4*>(scratch + lo.scr_rd(i));
-                        buf_store16(rs_u, lo_u, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldu * 2) + 128 * c, v);
+                        stream_store16<NT_MLP_U>(rs_u, lo_u, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldu * 2) + 128 * c, v);
                     }
                     wave_lds_fence();
                     if (store_g) {         // gelu(u): the packed B operands of the second product ARE the image's 16-byte slots
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
             u32x4 xb[3][4];
             auto load_x = [&](int nt) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) xb[nt % 3][g] = buf_load16(rs_x, lo_x, so + (32 * nt + 8 * g) * 4);
+                for (int g = 0; g < 4; ++g) xb[nt % 3][g] = stream_load16<NT_MLP_X>(rs_x, lo_x, so + (32 * nt + 8 * g) * 4);
             };
             load_x(0);
             if (NT > 1) load_x(1);
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const u32x4 v = *reinterpret_cast<const u32x4*>(scratch + lo.scr_rd(i));
-                    buf_store16(rs_o, lo_o, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldc * 4) + 128 * nt, v);
+                    stream_store16<NT_MLP_OUT>(rs_o, lo_o, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldc * 4) + 128 * nt, v);
                 }
                 wave_lds_fence();
             }

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
     for (int jj = 0; jj < 4; ++jj)
         lane_dma[jj] = (unsigned)(((8 * jj + (lane >> 3)) * p.lda) * 2 + (((lane & 7) ^ mlp_swz(8 * jj + (lane >> 3))) * 16));
     auto dma_a = [&](int jj, int tt, int b, int slot) {
-        bufdma16(rs_a, lane_dma[jj], (unsigned)(tt * RG_BM + 32 * w) * (unsigned)(p.lda * 2) + (unsigned)(128 * b), aring + slot * 4096 + jj * 1024);
+        stream_bufdma16<NT_RG_A>(rs_a, lane_dma[jj], (unsigned)(tt * RG_BM + 32 * w) * (unsigned)(p.lda * 2) + (unsigned)(128 * b), aring + slot * 4096 + jj * 1024);
     };
     bf16x8 fr[3][4];                       // ADMA: B-operand fragments of the block with index % 3 == slot (k-step j = fr[.][j])
     const unsigned aring_addr = lds_addr_of(aring);
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
             u32x4 xb[PA][4];
             auto load_x = [&](int nt) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) xb[nt % PA][g] = buf_load16(rs_x, lo_x, so_x + (32 * nt + 8 * g) * 4);
+                for (int g = 0; g < 4; ++g) xb[nt % PA][g] = stream_load16<NT_RG_X>(rs_x, lo_x, so_x + (32 * nt + 8 * g) * 4);
             };
 #pragma unroll
             for (int nt = 0; nt < PA - 1 && nt < NT; ++nt) load_x(nt);
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     gbuf[nt % PB][g] = u32x4{0u, 0u, 0u, 0u};
-                    if (p.accumulate) gbuf[nt % PB][g] = buf_load16(rs_g, lo_gl, so_g + (32 * nt + 8 * g) * 4);
+                    if (p.accumulate) gbuf[nt % PB][g] = stream_load16<NT_RG_G>(rs_g, lo_gl, so_g + (32 * nt + 8 * g) * 4);
                 }
             };
 #pragma unroll
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const u32x4 o = *reinterpret_cast<const u32x4*>(scratch + lo.scr_rd(i));
-                        buf_store16(rs_g, lo_o, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldg * 4) + 128 * nt, o);
+                        stream_store16<NT_RG_G>(rs_g, lo_o, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldg * 4) + 128 * nt, o);
                     }
                     wave_lds_fence();
                     CCD_SCHED_FENCE();
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const u32x4 o = *reinterpret_cast<const u32x4*>(scratch + lo.scr_rd(i));
-                        buf_store16(rs_b, lo_n, (unsigned)(r0 + 8 * i) * (unsigned)(p.ld_gb * 2) + 128 * np, o);
+                        stream_store16<NT_RG_GB>(rs_b, lo_n, (unsigned)(r0 + 8 * i) * (unsigned)(p.ld_gb * 2) + 128 * np, o);
                     }
                     wave_lds_fence();
                 }

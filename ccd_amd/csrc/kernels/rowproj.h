@@ -106,7 +106,7 @@ __global__ __launch_bounds__(RP_THREADS, 1) void rowproj_kernel(RowProjParams p)
             for (int rb = 0; rb < RB; ++rb) {
                 const unsigned so = (unsigned)(r0 + 32 * rb) * (unsigned)(p.lda * 2);
 #pragma unroll
-                for (int j = 0; j < KJ; ++j) af[rb][j] = __builtin_bit_cast(bf16x8, buf_load16(rs_a, lo_a, so + 32 * j));
+                for (int j = 0; j < KJ; ++j) af[rb][j] = __builtin_bit_cast(bf16x8, stream_load16<NT_RP_A>(rs_a, lo_a, so + 32 * j));
             }
         }
 #pragma unroll 1
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(RP_THREADS, 1) void rowproj_kernel(RowProjParams p)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const u32x4 v = *reinterpret_cast<const u32x4*>(scratch + (ldr_ + 8 * i) * 128 + ((ldp ^ ldr_) * 16));
-                    buf_store16(rs_o, lo_o, (unsigned)(r0 + 32 * rb + 8 * i) * (unsigned)(p.ldc * 2) + 128 * c, v);
+                    stream_store16<NT_RP_OUT>(rs_o, lo_o, (unsigned)(r0 + 32 * rb + 8 * i) * (unsigned)(p.ldc * 2) + 128 * c, v);
                 }
                 wave_lds_fence();
             }

@@ -119,6 +119,24 @@ __device__ __forceinline__ void buf_store16_nt(buf_rsrc r, unsigned lane_offset,
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)lane_offset, (int)uniform_offset, 2);
     buf_store_data_hold(v);
 }
+// One-touch streams of the large kernels: which of them carry the non-temporal policy is a compile-time table (bit B of CCD_NT;
+// lab builds override it with -DCCD_NT=mask, tools/lab/nt_ab.sh), so that a kernel names its stream once: stream_load16<B> etc.
+#ifndef CCD_NT
+#define CCD_NT CCD_NT_DEFAULT
+#endif
+constexpr int NT_RG_A = 0, NT_RG_X = 1, NT_RG_G = 2, NT_MLP_U = 3, NT_MLP_Y = 4, NT_MLP_X = 5, NT_MLP_OUT = 6, NT_RP_A = 7, NT_RP_OUT = 8,
+              NT_DGELU = 9, NT_TN = 10, NT_RG_GB = 11, NT_ATTB_OUT = 12;
+constexpr unsigned CCD_NT_DEFAULT = 1u << NT_DGELU;
+template <int B>
+__device__ __forceinline__ buf_u32x4 stream_load16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset) {
+    if constexpr ((CCD_NT >> B) & 1) return buf_load16_nt(r, lane_offset, uniform_offset);
+    else return buf_load16(r, lane_offset, uniform_offset);
+}
+template <int B>
+__device__ __forceinline__ void stream_store16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset, buf_u32x4 v) {
+    if constexpr ((CCD_NT >> B) & 1) buf_store16_nt(r, lane_offset, uniform_offset, v);
+    else buf_store16(r, lane_offset, uniform_offset, v);
+}
 __device__ __forceinline__ void wave_nap(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); }        // ~n * 64 cycles
 __device__ __forceinline__ void wave_sleep(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127); }   // ~n * 8 k cycles
 // LDS-DMA: one wave instruction copies 64 x 16 B from per-lane global addresses straight into LDS at
@@ -131,6 +149,16 @@ __device__ __forceinline__ void glds16(const void* gptr, char* lds_base) {
 // offset is out of range moves ZEROS into its 16 bytes of LDS (checked on the GPU by the LayerNorm-backward tests: rows behind M)
 __device__ __forceinline__ void bufdma16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset, char* lds_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_base, 16, (int)lane_offset, (int)uniform_offset, 0, 0);
+}
+template <int B>
+__device__ __forceinline__ void stream_glds16(const void* gptr, char* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, ((CCD_NT >> B) & 1) ? 2 : 0);
+}
+template <int B>
+__device__ __forceinline__ void stream_bufdma16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset, char* lds_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_base, 16, (int)lane_offset, (int)uniform_offset, 0,
+                                             ((CCD_NT >> B) & 1) ? 2 : 0);
 }
 // 4-byte form: lane l's dword lands at lds_base + 4 l
 __device__ __forceinline__ void glds4(const void* gptr, char* lds_base) {

@@ -258,6 +258,9 @@ inline void buf_store16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offse
     if (o + 16ull <= (unsigned long long)r.bytes) std::memcpy(const_cast<char*>(r.base) + o, &v, 16);
 }
 inline buf_u32x4 buf_load16_nt(buf_rsrc r, unsigned a, unsigned b) { return buf_load16(r, a, b); }
+constexpr int NT_RG_A = 0, NT_RG_X = 1, NT_RG_G = 2, NT_MLP_U = 3, NT_MLP_Y = 4, NT_MLP_X = 5, NT_MLP_OUT = 6, NT_RP_A = 7, NT_RP_OUT = 8,
+              NT_DGELU = 9, NT_TN = 10, NT_RG_GB = 11, NT_ATTB_OUT = 12;
+template <int B> inline buf_u32x4 stream_load16(buf_rsrc r, unsigned a, unsigned b) { return buf_load16(r, a, b); }
 template <typename T>
 inline void needed_here(T&) {}
 inline float scalar_load_f32(const float* p) { return *p; }
@@ -291,6 +294,9 @@ inline void global_load16_late(buf_u32x4& dst, const void* p0) {
 }
 inline void vm_landed4(buf_u32x4 (&)[4]) {}
 inline void buf_store16_nt(buf_rsrc r, unsigned a, unsigned b, buf_u32x4 v) { buf_store16(r, a, b, v); }
+template <int B> inline void stream_store16(buf_rsrc r, unsigned a, unsigned b, buf_u32x4 v) { buf_store16(r, a, b, v); }
+template <int B> inline void stream_glds16(const void* gptr, char* lds_base) { glds16(gptr, lds_base); }
+template <int B> inline void stream_bufdma16(buf_rsrc r, unsigned a, unsigned b, char* lds_base) { bufdma16(r, a, b, lds_base); }
 inline void wave_sleep(int) {}
 inline void wave_nap(int) {}
 inline int lane_id() { return sim::cur->lane; }
