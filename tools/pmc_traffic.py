@@ -22,11 +22,22 @@ KINDS = {"<false, 0, false>": "gemm_nt_bf16", "<false, 1, false>": "gemm_nt_gelu
 
 
 def collect(path, counter):
-    per = collections.defaultdict(list)
+    """{kind: [counter values of the dispatches of the LAST TWO training steps]}.  A step ends with its ccd::adamw_kernel dispatch:
+    the run is initialisation (hundreds of small dispatches), one warm-up step, two timed steps - a cut by dispatch COUNT (what this
+    file did until round 4) lands inside the initialisation and keeps all three steps."""
+    rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
-            if r["Counter_Name"] != counter:
-                continue
+            if r["Counter_Name"] == counter:
+                rows.append(r)
+    ends = [i for i, r in enumerate(rows) if "adamw_kernel" in r["Kernel_Name"]]
+    if len(ends) >= 3:
+        rows = rows[ends[-3] + 1:ends[-1] + 1]
+    elif len(ends) == 2:                                   # no warm-up step in the run: everything after the first step
+        rows = rows[ends[0] + 1:ends[1] + 1] * 2
+    per = collections.defaultdict(list)
+    if True:
+        for r in rows:
             name = r["Kernel_Name"]
             if "gemm_bf16_kernel" in name:
                 m = re.search(r"gemm_bf16_kernel(<[^>]*>)", name)
@@ -67,9 +78,8 @@ def collect(path, counter):
 
 
 def steady(vals):
-    """bench.py ran 1 warm-up + 2 timed steps: keep the last two thirds of the launches."""
-    n = len(vals)
-    return vals[n // 3:]
+    """(collect() already keeps the dispatches of the two timed steps only)"""
+    return vals
 
 
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
