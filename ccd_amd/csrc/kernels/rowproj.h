@@ -12,7 +12,11 @@
 //   * RB = 2: every weight fragment read from LDS feeds TWO MFMAs (one per row block).  In the fused MLP (RB = 1) four waves
 //     reading a 1-KiB fragment per 32-cycle MFMA ask the LDS for exactly its 128 B / clk peak; here they ask for half;
 //   * a finished 64-column chunk leaves through the wave's 4-KiB scratch image as 128-byte row segments (8 rows per store
-//     instruction); the stores drain under the next chunk's products.
+//     instruction) - ONE CHUNK LATE (round 4): at its end a chunk is only packed to bf16 (32 registers); its scratch writes, scratch
+//     reads and stores are issued between the MFMAs of the NEXT chunk's two pieces (row block rb under piece rb), on the product's own
+//     counted LDS queue.  Issued in a burst at the chunk's end, the 8 stores of all 256 CUs (8 MB) arrived at HBM together: the
+//     product phases left HBM idle and the store phases left the MFMAs idle (0.143 ms for the qkv shape, 0.093 with the stores
+//     removed); spread over the next product they cost nothing.
 // Ring protocol, fragment scheduling (mlp_product: reads issued 6 steps ahead, counted lgkmcnt) and the row-order trick that
 // makes 8 consecutive columns land in consecutive accumulator registers (bits 2 and 3 of the weight row index swapped) are
 // mlp_fused.h's.
@@ -34,6 +38,14 @@ struct RowProjParams {
 constexpr int RP_THREADS = 256, RP_SCRATCH = 4096;
 __host__ __device__ constexpr int rp_rows(int RB) { return 4 * 32 * RB; }              // rows of a workgroup tile
 __host__ __device__ inline int rp_smem_bytes(int E, int N) { return mlp_slots(E) * mlp_piece_bytes(E) + 4 * RP_SCRATCH + N * 4; }
+
+// the late chunk's LDS operations inside a piece of KJ >= 24 steps: scratch writes behind steps 2, 3, 4, 6, scratch reads behind 13 .. 16
+// (every write has retired when the wait of step 13 passes: read 13 was issued behind the last write), stores behind 20 .. 23 (the
+// read issued behind step 13 + i has retired at the wait of step 20 + i)
+struct RpLateExtra {
+    static constexpr int at(int k) { return (k == 2 || k == 3 || k == 4 || k == 6 || (k >= 13 && k <= 16)) ? 1 : 0; }
+    static constexpr int write_unit(int k) { return k == 2 ? 0 : k == 3 ? 1 : k == 4 ? 2 : k == 6 ? 3 : -1; }
+};
 
 template <int E, int RB>
 __global__ __launch_bounds__(RP_THREADS, 1) void rowproj_kernel(RowProjParams p) {
@@ -97,6 +109,18 @@ __global__ __launch_bounds__(RP_THREADS, 1) void rowproj_kernel(RowProjParams p)
     const buf_rsrc rs_a = make_rsrc(p.a, (unsigned)((((long)p.M - 1) * p.lda + E) * 2));
     const buf_rsrc rs_o = make_rsrc(p.out, (unsigned)((((long)p.M - 1) * p.ldc + p.N) * 2));
 
+    // the chunk that has not left yet: packed bf16 (register 4 * tt + 2 * s + (0, 1) pairs of columns, as the scratch writes want them),
+    // the byte offset of its first row and column (BUF_OOB: none)
+    constexpr bool LATE = KJ >= 24;
+    u32x4 pend[RB][4];
+    unsigned pend_so[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        pend_so[rb] = BUF_OOB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pend[rb][j] = u32x4{0u, 0u, 0u, 0u};
+    }
+    const unsigned scr_addr = lds_addr_of(scratch);
     for (int tile = blockIdx.x; tile < tiles; tile += G) {
         const int r0 = tile * BM + 32 * RB * w;              // this wave's first row
         bf16x8 af[RB][KJ];                                   // row lq of block rb: k = 16 j + 8 hf .. + 7
@@ -129,6 +153,40 @@ __global__ __launch_bounds__(RP_THREADS, 1) void rowproj_kernel(RowProjParams p)
                 constexpr int kh = decltype(KH)::value;
                 const unsigned sb = acquire();
                 const unsigned areg[4] = {sb + off1[0], sb + off1[1], sb + off1[2], sb + off1[3]};
+                if constexpr (LATE && kh < RB) {
+                    // row block kh of the PREVIOUS chunk leaves under this piece
+                    const int ln = opaque_vgpr(t) & 63, lhf = ln >> 5, llq = ln & 31, ldr_ = ln >> 3, ldp = ln & 7;
+                    const unsigned wr_base = scr_addr + (unsigned)(llq * 128), rd_base = scr_addr + (unsigned)(ldr_ * 128 + ((ldp ^ ldr_) * 16));
+#if defined(CCD_RP_LAB) && (CCD_RP_LAB & 4)      // lab build: every (tile, chunk, wave, row block) leaves as ONE contiguous 4 KiB (not the matrix layout)
+                    const unsigned lo_o = (unsigned)(ldr_ * 128 + ldp * 16);
+                    const unsigned row_step = 8 * 128;
+#else
+                    const unsigned lo_o = (unsigned)(ldr_ * p.ldc * 2 + ldp * 16);
+                    const unsigned row_step = 8u * (unsigned)(p.ldc * 2);
+#endif
+                    u32x4 ob[4];
+                    mlp_product<KJ, DEPTH, MlpMapP1<KT / 2>, RpLateExtra>(
+                        areg,
+                        [&](auto K, const bf16x8& a) {
+                            constexpr int k = decltype(K)::value;
+#pragma unroll
+                            for (int rb = 0; rb < RB; ++rb)
+                                h[rb][k & 1] = mfma_32x32x16_bf16(a, af[rb][(KJ / 2) * kh + (k >> 1)], h[rb][k & 1]);
+                        },
+                        [&](auto K) {
+                            constexpr int k = decltype(K)::value, stride = KJ / KT;
+                            if constexpr (k % stride == 1 && k / stride < KT) issue_one(k / stride);
+                            if constexpr (RpLateExtra::write_unit(k) >= 0) {
+                                constexpr int j = RpLateExtra::write_unit(k);           // unit (tt, s) = (j >> 1, j & 1): columns 8 * slot16 .. + 7
+                                lds_write16(wr_base + (unsigned)((((2 * j + lhf) ^ (llq & 7))) * 16), pend[kh][j]);
+                            }
+                            if constexpr (k >= 13 && k <= 16) lds_read16(ob[k - 13], rd_base + (unsigned)((k - 13) * 8 * 128));
+                            if constexpr (k >= 20 && k <= 23) {
+                                needed_here(ob[k - 20]);
+                                stream_store16<NT_RP_OUT>(rs_o, lo_o, pend_so[kh] + (unsigned)(k - 20) * row_step, ob[k - 20]);
+                            }
+                        });
+                } else
                 mlp_product<KJ, DEPTH, MlpMapP1<KT / 2>, MlpNoExtra>(
                     areg,
                     [&](auto K, const bf16x8& a) {
@@ -144,6 +202,25 @@ __global__ __launch_bounds__(RP_THREADS, 1) void rowproj_kernel(RowProjParams p)
             };
             piece(std::integral_constant<int, 0>{});
             piece(std::integral_constant<int, 1>{});
+            if constexpr (LATE) {
+                // ---- the chunk is packed and waits for the next chunk's products (a row block that RB < 2 pieces cannot carry would leave here)
+                static_assert(RB <= 2, "one row block per piece of the next chunk");
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int sq = 0; sq < 2; ++sq)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pend[rb][2 * tt + sq][e] = pack_bf2(h[rb][tt][8 * sq + 2 * e], h[rb][tt][8 * sq + 2 * e + 1]);
+                    pend_so[rb] = (unsigned)(r0 + 32 * rb) * (unsigned)(p.ldc * 2) + 128 * c;
+#ifdef CCD_RP_LAB       // lab build: the stores are issued but fall outside the descriptor (no HBM writes) / contiguous blocks
+                    if (CCD_RP_LAB & 2) pend_so[rb] = BUF_OOB;
+                    if (CCD_RP_LAB & 4) pend_so[rb] = (unsigned)((((tile * NC + c) * 4 + w) * RB + rb) * 4096);
+#endif
+                }
+                continue;
+            }
             // ---- the chunk leaves: [32 rows][64 columns] bf16 image in the wave's scratch -> 128-byte row segments
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -167,6 +244,23 @@ __global__ __launch_bounds__(RP_THREADS, 1) void rowproj_kernel(RowProjParams p)
                 }
                 wave_lds_fence();
             }
+        }
+    }
+    if constexpr (LATE) {                  // the last chunk of the workgroup's last tile: nothing left to hide it under
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int ln = opaque_vgpr(t) & 63, lhf = ln >> 5, llq = ln & 31, ldr_ = ln >> 3, ldp = ln & 7;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<u32x4*>(scratch + llq * 128 + (((2 * j + lhf) ^ (llq & 7)) * 16)) = pend[rb][j];
+            wave_lds_fence();
+            const unsigned lo_o = (unsigned)(ldr_ * p.ldc * 2 + ldp * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(scratch + (ldr_ + 8 * i) * 128 + ((ldp ^ ldr_) * 16));
+                stream_store16<NT_RP_OUT>(rs_o, lo_o, pend_so[rb] + (unsigned)(8 * i) * (unsigned)(p.ldc * 2), v);
+            }
+            wave_lds_fence();
         }
     }
     glds_wait_all();                       // requested pieces that no tile consumed must not outlive the workgroup's LDS

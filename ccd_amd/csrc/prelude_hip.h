@@ -189,6 +189,13 @@ template <int OFF>
 __device__ __forceinline__ void lds_read_frag(bf16x8& dst, unsigned lds_addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFF));
 }
+// 16-byte LDS write / read issued by hand on the same in-order queue (the caller's counted waits cover them: mlp_product's Extra)
+__device__ __forceinline__ void lds_write16(unsigned lds_addr, const buf_u32x4& v) {
+    asm volatile("ds_write_b128 %0, %1" : : "v"(lds_addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_read16(buf_u32x4& dst, unsigned lds_addr) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(lds_addr));
+}
 template <int N>
 __device__ __forceinline__ void lds_wait_frag(bf16x8& frag) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N)); }
 // a 4-byte LDS gather issued by hand (same in-order queue as the fragment reads), and the two ways its result becomes

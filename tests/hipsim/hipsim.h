@@ -294,6 +294,8 @@ inline void global_load16_late(buf_u32x4& dst, const void* p0) {
 }
 inline void vm_landed4(buf_u32x4 (&)[4]) {}
 inline void buf_store16_nt(buf_rsrc r, unsigned a, unsigned b, buf_u32x4 v) { buf_store16(r, a, b, v); }
+inline void lds_write16(unsigned lds_addr, const buf_u32x4& v) { std::memcpy(sim::curblk->dyn_smem + lds_addr, &v, 16); }
+inline void lds_read16(buf_u32x4& dst, unsigned lds_addr) { std::memcpy(&dst, sim::curblk->dyn_smem + lds_addr, 16); }
 template <int B> inline void stream_store16(buf_rsrc r, unsigned a, unsigned b, buf_u32x4 v) { buf_store16(r, a, b, v); }
 template <int B> inline void stream_glds16(const void* gptr, char* lds_base) { glds16(gptr, lds_base); }
 template <int B> inline void stream_bufdma16(buf_rsrc r, unsigned a, unsigned b, char* lds_base) { bufdma16(r, a, b, lds_base); }
