@@ -2,7 +2,7 @@
 # round 4: the evidence run - whole GPU suite, smoke, PMC traffic + SQ + LDS passes, kernel trace, the bench lines kept under profiles/
 cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -q 2>&1 | tail -12 > gpurun_out/r04_gputests.log
+python -m pytest tests -m gpu -q 2>&1 | grep -v "Warning\|WeightNorm.apply\|^$" | tail -8 > gpurun_out/r04_gputests.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r04_smoke.log 2>&1
 bash tools/pmc_traffic.sh r04 > gpurun_out/r04_pmc_traffic.log 2>&1
 bash tools/pmc_sq.sh r04 > gpurun_out/r04_pmc_sq.log 2>&1
