@@ -164,7 +164,9 @@ def check_gemm_tn_pair(dev, Mc, shape1, shape2, seed=5):
         ops.gemm_tn_pair(args[0][0], args[0][1], outs[0], args[1][0], args[1][1], outs[1], workspace=workspace)
         close(outs[0], wants[0], 1e-4, tol, f"tn_pair/first ws={workspace}")
         close(outs[1], wants[1], 1e-4, tol, f"tn_pair/second ws={workspace}")
-        if workspace and ops.policy_get("gemm_tn384") and all(P % 384 == 0 and Q % 192 == 0 for P, Q in (shape1, shape2)):   # (gemm_tn384.h; the fallback adds by atomics)
+        # (on the GPU, gemm_tn384.h's shapes; a pair that does not fit the chip's slots - the CPU executor's 2-CU chips - falls back to
+        # single products that add by atomics)
+        if workspace and dev.type == "cuda" and ops.policy_get("gemm_tn384") and all(P % 384 == 0 and Q % 192 == 0 for P, Q in (shape1, shape2)):
             # plain stores + one reduction in a fixed order: the same bits on every run
             again = [b.clone().to(dev) for b in bases]
             ops.gemm_tn_pair(args[0][0], args[0][1], again[0], args[1][0], args[1][1], again[1], workspace=True)
