@@ -35,6 +35,7 @@ GF_PER_IMAGE = {"vit_small": (96.7 + 8.7, 44.56e-3 * 4), "vit_base": (167.6 + 10
 # timer kind (ccd_amd/ops.py spans) -> the kernel(s) of ccd_amd/csrc/kernels that the launches of that kind run at the default policy
 KIND_KERNEL = {
     "mlp_fused": "ccd::mlp_fused_kernel<E, store_u> (mlp_fused.h)",
+    "proj_mlp_fused": "ccd::mlp_fused_kernel<E, store_u, PROJ = true> (mlp_fused.h)",
     "gemm_nt_lnbwd": "ccd::rowgemm_kernel<E, ring, RG_LNBWD> (rowgemm.h)",
     "gemm_nt_resid": "ccd::gemm_row384_kernel<EPI_RESID_LN> (gemm_row384.h) / gemm_bf16_kernel<NT, EPI_RESID> (gemm.h)",
     "gemm_nt_bf16": "ccd::gemm256_kernel<EPI_BF16> (gemm256.h) / gemm_bf16_kernel<NT, EPI_BF16> (gemm.h)",
@@ -526,7 +527,7 @@ def main():
             line["roofline"].update({
                 "by_kind_source": "last warm-up step (every GEMM / attention / LayerNorm / loss launch timed)" if warm_summary else "timed region",
                 "timed_ms_per_step": round(sum(v["ms"] for v in table.values()) / per, 3),
-                "gemm_ms_per_step": round(sum(v["ms"] for k, v in table.items() if k.startswith(("gemm", "mlp", "conv"))) / per, 3),
+                "gemm_ms_per_step": round(sum(v["ms"] for k, v in table.items() if k.startswith(("gemm", "mlp", "proj_mlp", "conv"))) / per, 3),
                 "by_kind_ms_per_step": {k: round(v["ms"] / per, 3) for k, v in sorted(table.items())},
                 "by_kind_tflops": {k: round(v["flops"] / v["ms"] / 1e9, 1) for k, v in sorted(table.items())},
                 "by_kind_algorithmic_gbs": {k: round(v["bytes"] / v["ms"] / 1e6, 1) for k, v in sorted(table.items())}})

@@ -258,8 +258,8 @@ static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, float* ws, long ws_
 
 extern "C" {
 
-int ccd_abi_version(void) { return 7; }   // 7: ccd_gemm_tn_pair_ws (split-K workspace instead of fp32 atomics); 6: device-side momentum / DropPath seed (HIP graph of the training step); 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
-const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi7"; }
+int ccd_abi_version(void) { return 8; }   // 8: ccd_proj_mlp_fused (proj + residual + LayerNorm-2 in front of the fused MLP); 7: ccd_gemm_tn_pair_ws (split-K workspace instead of fp32 atomics); 6: device-side momentum / DropPath seed (HIP graph of the training step); 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
+const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi8"; }
 int ccd_policy_set(const char* key, int value) {
     CCD_CHECK(key, CCD_EINVAL);
     for (const CcdPolicyKey& k : ccd_policy_keys)
@@ -434,6 +434,8 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
     p.rowscale = rowscale; p.rows_per_sample = rowscale ? rows_per_sample : 1; p.out = out; p.ldc = ldc;
     p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_eps = ln_eps; p.ln_y = ln_y; p.ld_y = ld_y; p.ln_mean = ln_mean;
     p.ln_rstd = ln_rstd; p.u = u; p.ldu = ldu; p.gact = gact; p.ldga = ldga; p.M = M; p.H = H; p.lab = ccd_policy().lab;
+    p.a = nullptr; p.lda = 0; p.wp = nullptr; p.ldp = 0; p.bp = nullptr; p.rowscale1 = nullptr; p.ln2_gamma = p.ln2_beta = nullptr;
+    p.xmid = nullptr; p.ldxm = 0; p.y2 = nullptr; p.ldy2 = 0; p.mean2 = p.rstd2 = nullptr;
     const int tiles = (M + ccd::MLP_BM - 1) / ccd::MLP_BM, cus = ccd_grid_cus();
     const dim3 grid(tiles < cus ? tiles : cus), block(ccd::MLP_THREADS);
     if (E == 512) {
@@ -448,6 +450,49 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
     } else {
         if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<128, true>), grid, block, smem, stream, p);
         else CCD_LAUNCH((ccd::mlp_fused_kernel<128, false>), grid, block, smem, stream, p);
+    }
+    return ccd_rt_last_error();
+}
+
+int ccd_proj_mlp_fused(const ccd_bf16* a, long lda, const ccd_bf16* wp, long ldp, const float* bp, const float* resid, long ldr,
+                       const float* rowscale1, const float* ln2_gamma, const float* ln2_beta, float* xmid, long ldxm, ccd_bf16* y2,
+                       long ldy2, float* mean2, float* rstd2, const ccd_bf16* w1, long ld1, const float* b1, const ccd_bf16* w2,
+                       long ld2, const float* b2, const float* rowscale2, int rows_per_sample, float* out, long ldc,
+                       const float* ln_gamma, const float* ln_beta, float ln_eps, ccd_bf16* ln_y, long ld_y, float* ln_mean,
+                       float* ln_rstd, ccd_bf16* u, long ldu, int M, int E, int H, void* stream) {
+    CCD_CHECK(a && wp && bp && resid && ln2_gamma && ln2_beta && w1 && b1 && w2 && b2 && out && ln_gamma && ln_beta && ln_y && ln_mean &&
+              ln_rstd, CCD_EINVAL);
+    CCD_CHECK((xmid != nullptr) == (y2 != nullptr) && (xmid != nullptr) == (mean2 != nullptr) && (xmid != nullptr) == (rstd2 != nullptr),
+              CCD_EINVAL);
+    CCD_CHECK(CCD_ALIGNED16(a) && CCD_ALIGNED16(wp) && CCD_ALIGNED16(w1) && CCD_ALIGNED16(w2) && CCD_ALIGNED16(resid) && CCD_ALIGNED16(out) &&
+              CCD_ALIGNED16(ln_y) && CCD_ALIGNED16(u) && CCD_ALIGNED16(xmid) && CCD_ALIGNED16(y2), CCD_EINVAL);
+    if (M == 0) return CCD_OK;
+    CCD_CHECK(M > 0 && H > 0 && ((!rowscale1 && !rowscale2) || rows_per_sample > 0), CCD_EINVAL);
+    // a DropPath scale is read once per 128-row tile (a dropped branch's weight pieces are skipped): tiles must not span samples
+    CCD_CHECK((!rowscale1 && !rowscale2) || rows_per_sample % ccd::MLP_BM == 0, CCD_ESHAPE);
+    CCD_CHECK((E == 128 || E == 256 || E == 384) && H % 64 == 0 && lda % 8 == 0 && ldp % 8 == 0 && ld1 % 8 == 0 && ld2 % 8 == 0 && ldr % 4 == 0 &&
+              ldc % 4 == 0 && ld_y % 8 == 0 && (!u || ldu % 8 == 0) && (!xmid || (ldxm % 4 == 0 && ldy2 % 8 == 0)), CCD_ESHAPE);
+    CCD_CHECK((long)H * ld1 * 2 < CCD_MAX_OPERAND_BYTES && (long)E * ld2 * 2 < CCD_MAX_OPERAND_BYTES && (long)E * ldp * 2 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
+    const int smem = ccd::mlp_smem_bytes(E, H, true);
+    CCD_CHECK(smem <= 160 * 1024, CCD_ESHAPE);
+    ccd::MlpParams p;
+    p.y = nullptr; p.ldy_in = 0; p.w1 = w1; p.ld1 = ld1; p.b1 = b1; p.w2 = w2; p.ld2 = ld2; p.b2 = b2; p.resid = resid; p.ldr = ldr;
+    p.rowscale = rowscale2; p.rows_per_sample = (rowscale1 || rowscale2) ? rows_per_sample : ccd::MLP_BM; p.out = out; p.ldc = ldc;
+    p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_eps = ln_eps; p.ln_y = ln_y; p.ld_y = ld_y; p.ln_mean = ln_mean;
+    p.ln_rstd = ln_rstd; p.u = u; p.ldu = ldu; p.gact = nullptr; p.ldga = 0; p.M = M; p.H = H; p.lab = ccd_policy().lab;
+    p.a = a; p.lda = lda; p.wp = wp; p.ldp = ldp; p.bp = bp; p.rowscale1 = rowscale1; p.ln2_gamma = ln2_gamma; p.ln2_beta = ln2_beta;
+    p.xmid = xmid; p.ldxm = ldxm; p.y2 = y2; p.ldy2 = ldy2; p.mean2 = mean2; p.rstd2 = rstd2;
+    const int tiles = (M + ccd::MLP_BM - 1) / ccd::MLP_BM, cus = ccd_grid_cus();
+    const dim3 grid(tiles < cus ? tiles : cus), block(ccd::MLP_THREADS);
+    if (E == 384) {
+        if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<384, true, true>), grid, block, smem, stream, p);
+        else CCD_LAUNCH((ccd::mlp_fused_kernel<384, false, true>), grid, block, smem, stream, p);
+    } else if (E == 256) {
+        if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<256, true, true>), grid, block, smem, stream, p);
+        else CCD_LAUNCH((ccd::mlp_fused_kernel<256, false, true>), grid, block, smem, stream, p);
+    } else {
+        if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<128, true, true>), grid, block, smem, stream, p);
+        else CCD_LAUNCH((ccd::mlp_fused_kernel<128, false, true>), grid, block, smem, stream, p);
     }
     return ccd_rt_last_error();
 }

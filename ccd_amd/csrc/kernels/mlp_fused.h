@@ -61,14 +61,32 @@ struct MlpParams {
     long ldga;              // here, the gelu'(u) product of the backward pass neither gathers Phi a second time nor writes gelu(u)
     int M, H;
     int lab;                // experiment switch (policy key "lab"): n > 0 delays odd workgroups by ~n * 8 k cycles
+    // PROJ (round 5): the tail of the attention branch in front of the MLP, in the same launch -
+    //     x_mid = resid + rowscale1 * (a . Wp^T + bp) ;   y2 = LayerNorm2(x_mid)   (vision_transformer.py:108-110)
+    // x_mid stays in the accumulators (the second product adds onto it), y2 in the operand registers: neither is read back from
+    // HBM, and a forward pass that keeps nothing for a backward pass (the teacher) does not write them either.  `y` is unused.
+    const bf16_t* a;        // [M, E] bf16: attention output (heads concatenated), the projection's input
+    long lda;
+    const bf16_t* wp;       // proj.weight [E, E] bf16
+    long ldp;
+    const float* bp;        // [E]
+    const float* rowscale1; // DropPath scale of the attention branch per sample, or null (rows_per_sample % 128 == 0 with either scale)
+    const float* ln2_gamma; // norm2
+    const float* ln2_beta;
+    float* xmid;            // optional [M, E] fp32: x_mid, with y2 / mean2 / rstd2 (all four or none): what the backward pass reads
+    long ldxm;
+    bf16_t* y2;
+    long ldy2;
+    float* mean2;
+    float* rstd2;
 };
 
 constexpr int MLP_SCRATCH = 4096, MLP_THREADS = 256, MLP_BM = 128;
 // ring slots: 5 (four pieces ahead) where 160 KiB allow it; 3 at E = 512 (32-KiB pieces, H = 2048 vectors)
 __host__ __device__ constexpr int mlp_slots(int E) { return E <= 384 ? 5 : 3; }
 __host__ __device__ constexpr int mlp_piece_bytes(int E) { return 32 * E * 2; }
-__host__ __device__ inline int mlp_smem_bytes(int E, int H) {
-    return mlp_slots(E) * mlp_piece_bytes(E) + 4 * MLP_SCRATCH + (1536 + H + 3 * E) * 4;    // ring, scratch, Phi table, vectors
+__host__ __device__ inline int mlp_smem_bytes(int E, int H, bool proj = false) {
+    return mlp_slots(E) * mlp_piece_bytes(E) + 4 * MLP_SCRATCH + (1536 + H + (proj ? 6 : 3) * E) * 4;    // ring, scratch, Phi table, vectors
 }
 // 16-byte slot swizzle of a 128-byte image row (rows taken modulo 32: a piece is a stack of 32-row blocks)
 __device__ __forceinline__ int mlp_swz(int row) { return (((row & 31) >> 1) ^ ((row & 31) >> 4)) & 7; }
@@ -133,12 +151,14 @@ struct MlpGeluSchedule {
 };
 constexpr unsigned MLP_LUT_LO = 0x3B80u, MLP_LUT_HI = 0x4180u;      // bf16 magnitudes 2^-8 .. 16: 1536 table entries
 
-template <int E, bool STORE_U>
+template <int E, bool STORE_U, bool PROJ = false>
 __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) {
     constexpr int KT = E / 64;             // 64-wide k-tiles of a W1 piece = DMA instructions per wave and piece
     constexpr int KJ = E / 16;             // MFMA k-steps of the first product
     constexpr int NT = E / 32;             // 32-column output tiles of a row
     constexpr int NTH = NT / 2;            // ... per W2 piece
+    constexpr int KC = E / 64;             // PROJ: 64-wide k-chunks of the projection (two pieces each, as a W2 chunk)
+    constexpr int NPP = PROJ ? 2 * KC : 0; // PROJ: pieces of the projection in front of a row tile's stream
     constexpr int PIECE = mlp_piece_bytes(E);
     constexpr int MLP_NSLOT = mlp_slots(E);
     constexpr int AHEAD = MLP_NSLOT - 1;   // pieces issued ahead of the one being consumed
@@ -153,13 +173,17 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
     float* vb2 = vb1 + p.H;
     float* vga = vb2 + E;
     float* vbe = vga + E;
+    float* vbp = vbe + E;                  // PROJ: projection bias, norm2 gamma / beta
+    float* vga2 = vbp + E;
+    float* vbe2 = vga2 + E;
     for (int i = t; i < p.H; i += MLP_THREADS) vb1[i] = p.b1[i];
     for (int i = t; i < E; i += MLP_THREADS) { vb2[i] = p.b2[i]; vga[i] = p.ln_gamma[i]; vbe[i] = p.ln_beta[i]; }
+    if constexpr (PROJ)
+        for (int i = t; i < E; i += MLP_THREADS) { vbp[i] = p.bp[i]; vga2[i] = p.ln2_gamma[i]; vbe2[i] = p.ln2_beta[i]; }
     for (unsigned i = t; i < MLP_LUT_HI - MLP_LUT_LO; i += MLP_THREADS) lut[i] = gelu_terms(bf2f((bf16_t)(MLP_LUT_LO + i))).cdf;
     __syncthreads();                       // (plain loads only so far: nothing in flight that a drain would hurt)
-    const float* lut_biased = lut - MLP_LUT_LO;
 
-    const int NC = p.H / 64, NP = 4 * NC;  // hidden chunks, pieces per row tile
+    const int NC = p.H / 64, NP = NPP + 4 * NC;  // hidden chunks, pieces per row tile
     const int tiles = (p.M + MLP_BM - 1) / MLP_BM, G = gridDim.x;
 #ifdef CCD_MLP_LAB      // lab build only: cycle totals of wave 0 per phase -> first 64 bytes per workgroup of ln_mean (destroyed)
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -173,13 +197,14 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
     // 8-row block index is w modulo 4, so ONE per-lane offset per weight matrix serves all of its instructions:
     //   W1 piece [KT/2 k-tiles of one K half][64 hidden rows][128 B]: instruction i = rows 32 (i & 1) + 8w .. + 7 of k-tile i >> 1
     //   W2 piece [E/2 output rows][128 B = 64 hidden units]: instruction i = rows 32 i + 8w .. + 7
+    //   Wp piece (PROJ) = a W2 piece of proj.weight: [E/2 output rows][128 B = 64 input columns]
     const int dr = lane >> 3, dp = lane & 7;
     const int drow = 8 * w + dr;
     // per-lane byte offset of a request = drow2 * (row stride of the matrix) + swz16: one multiply-add where it is needed
     // (two precomputed offsets selected by the piece type became a scratch array)
     const unsigned drow2 = (unsigned)(2 * drow), swz16 = (unsigned)((dp ^ mlp_swz(drow)) * 16);
     int slot_i = 0, slot_c = 0, pos_i = 0; // ring slots of the next request / consumption, stream position of the next request
-    // stream of a row tile (NP pieces): P1(0)a P1(0)b | P1(1)a P1(1)b P2(0)a P2(0)b | ... | P2(NC-1)a P2(NC-1)b
+    // stream of a row tile (NP pieces): [PROJ: Pp(0)a Pp(0)b ... Pp(KC-1)a Pp(KC-1)b |] P1(0)a P1(0)b | P1(1)a P1(1)b P2(0)a P2(0)b | ... | P2(NC-1)a P2(NC-1)b
     // A request is PREPARED once (scalar state: where the piece starts, its two strides, its ring slot) and its KT
     // instructions are then issued one at a time between the MFMAs of the piece being consumed: an LDS-DMA instruction keeps
     // the issuing wave busy for tens of cycles, and 6 of them back to back (with their address arithmetic) measured a quarter
@@ -188,15 +213,26 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
     long req_step_a = 0, req_step_b = 0;
     unsigned req_lane = 0;
     char* req_lds = nullptr;
-    auto issue_prepare = [&]() {
-        int is_p2, chunk, half;
-        if (pos_i < 2) { is_p2 = 0; chunk = 0; half = pos_i; }
+    auto issue_prepare = [&]() __attribute__((always_inline)) {
+        int is_p2 = 0, chunk = 0, half = 0, pi = pos_i;
+        bool is_pp = false;
+        if constexpr (PROJ) {
+            if (pi < NPP) is_pp = true;
+            else pi -= NPP;
+        }
+        if (is_pp) { chunk = pi >> 1; half = pi & 1; }
+        else if (pi < 2) { is_p2 = 0; chunk = 0; half = pi; }
         else {
-            const int q = pos_i - 2, grp = q >> 2, r = q & 3;
+            const int q = pi - 2, grp = q >> 2, r = q & 3;
             if (grp < NC - 1) { is_p2 = r >> 1; chunk = is_p2 ? grp : grp + 1; half = r & 1; }
             else { is_p2 = 1; chunk = NC - 1; half = r; }
         }
-        if (!is_p2) {      // rows 64 chunk + 32 (i & 1) + .., K half `half`, k-tile i >> 1
+        if (is_pp) {       // rows half * E/2 + 32 i + .., input columns 64 chunk ..
+            req_base = reinterpret_cast<const char*>(p.wp) + ((long)(half * (E / 2)) * p.ldp + 64 * chunk) * 2;
+            req_step_a = 64 * p.ldp;
+            req_step_b = 128 * p.ldp;
+            req_lane = drow2 * (unsigned)p.ldp + swz16;
+        } else if (!is_p2) {      // rows 64 chunk + 32 (i & 1) + .., K half `half`, k-tile i >> 1
             req_base = reinterpret_cast<const char*>(p.w1) + ((long)(64 * chunk) * p.ld1 + half * (E / 2)) * 2;
             req_step_a = 64 * p.ld1;
             req_step_b = 128;
@@ -211,7 +247,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
         slot_i = slot_i + 1 == MLP_NSLOT ? 0 : slot_i + 1;
         pos_i = pos_i + 1 == NP ? 0 : pos_i + 1;
     };
-    auto issue_one = [&](int i) {
+    auto issue_one = [&](int i) __attribute__((always_inline)) {
         glds16(req_base + ((i & 1) * req_step_a + (i >> 1) * req_step_b) + req_lane, req_lds + 4096 * i);
     };
     // step of the ring: my quarter of the next piece has landed (three younger pieces stay in flight), everybody's has
@@ -219,7 +255,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
     // the caller spreads over its product (dma_slot below).  Requests run past the last tile (the weights are the same for
     // every tile; the surplus is drained at the end).
     const unsigned smem_addr = lds_addr_of(smem);
-    auto acquire = [&]() -> unsigned {
+    auto acquire = [&]() __attribute__((always_inline)) -> unsigned {
         glds_wait<(AHEAD - 1) * KT>();
         lds_barrier();
         MLP_STAMP(1)                         // lab: wait for the DMA + barrier
@@ -234,12 +270,26 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
         constexpr int k = decltype(K)::value, stride = decltype(NSTEPS)::value / KT;
         if constexpr (k % stride == 1 && k / stride < KT) issue_one(k / stride);
     };
+    auto ring_fill = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < AHEAD; ++j) {
-        issue_prepare();
+        for (int j = 0; j < AHEAD; ++j) {
+            issue_prepare();
 #pragma unroll
-        for (int i = 0; i < KT; ++i) issue_one(i);
-    }
+            for (int i = 0; i < KT; ++i) issue_one(i);
+        }
+    };
+    // PROJ: the stream jumps to position `pos` of a row tile (a DropPath-dropped branch is not multiplied: its pieces are
+    // skipped).  Called by all four waves between two pieces: every request has landed, nobody reads a slot any more, the ring
+    // starts over as at kernel entry.
+    auto ring_seek = [&](int pos) __attribute__((always_inline)) {
+        glds_wait_all();
+        lds_barrier();
+        pos_i = pos;
+        slot_i = 0;
+        slot_c = 0;
+        ring_fill();
+    };
+    ring_fill();
 
     // ---- fragment read offsets inside a piece (one register per k-step; tiles / k-tiles are immediate offsets)
     const int prow = (lq & 19) | ((lq & 4) << 1) | ((lq & 8) >> 1);      // bits 2 and 3 of the row index swapped
@@ -252,13 +302,16 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
     const float inv_e = 1.0f / (float)E;
     // global traffic of the row tiles goes through buffer descriptors: one per-lane offset register per tensor, the tile /
     // column part of every address in SGPRs, and rows beyond M cost no predicate (loads return 0, stores are dropped)
-    const buf_rsrc rs_y = make_rsrc(p.y, (unsigned)((((long)p.M - 1) * p.ldy_in + E) * 2));
+    const buf_rsrc rs_y = PROJ ? make_rsrc(p.a, (unsigned)((((long)p.M - 1) * p.lda + E) * 2))
+                               : make_rsrc(p.y, (unsigned)((((long)p.M - 1) * p.ldy_in + E) * 2));
+    const long ld_yin = PROJ ? p.lda : p.ldy_in;
     const buf_rsrc rs_x = make_rsrc(p.resid, (unsigned)((((long)p.M - 1) * p.ldr + E) * 4));
     const buf_rsrc rs_o = make_rsrc(p.out, (unsigned)((((long)p.M - 1) * p.ldc + E) * 4));
     const buf_rsrc rs_n = make_rsrc(p.ln_y, (unsigned)((((long)p.M - 1) * p.ld_y + E) * 2));
     const buf_rsrc rs_u = make_rsrc(STORE_U ? p.u : nullptr, STORE_U ? (unsigned)((((long)p.M - 1) * p.ldu + p.H) * 2) : 0u);
     const bool store_g = STORE_U && p.gact != nullptr;
     const buf_rsrc rs_ga = make_rsrc(store_g ? p.gact : nullptr, store_g ? (unsigned)((((long)p.M - 1) * p.ldga + p.H) * 2) : 0u);
+    const bool keep_mid = PROJ && p.xmid != nullptr;     // x_mid, y2 and their statistics are written (the student)
     // per-lane offsets of the row-tile traffic are recomputed from the lane id where they are used (LaneOff below): kept in
     // registers across the main loop they were the first values the allocator spilled, and a scratch reload in front of
     // every store (s_waitcnt vmcnt(0)!) serialised the whole epilogue
@@ -282,15 +335,22 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
         // that is not taken - puts `s_waitcnt vmcnt(0)` at the top of every tile: the weight ring's requests and the previous
         // tile's stores drained before the tile's own rows are even requested.  A tile that spans samples reads its per-row
         // scale where it is used, in the epilogue.
-        float sc_tile = 1.0f;
-        bool tile_dead = false;
+        float sc_tile = 1.0f, sc1_tile = 1.0f;
+        bool tile_dead = false, dead1 = false;
         const bool one_sample = p.rows_per_sample % MLP_BM == 0;
         if (p.rowscale && one_sample) {
-            sc_tile = scalar_load_f32(p.rowscale + uniform_i32(m0 / p.rows_per_sample));
+            sc_tile = scalar_load_f32(uniform_ptr(p.rowscale + uniform_i32(m0 / p.rows_per_sample)));
             tile_dead = sc_tile == 0.0f;
         }
-        if (tile_dead) {
-            // x_out = x, y_next = LayerNorm(x): half a wave per row, row sums by shuffles (as gemm_row384.h's epilogue)
+        if constexpr (PROJ) {
+            if (p.rowscale1) {                 // (the host guarantees one_sample whenever PROJ comes with a scale)
+                sc1_tile = scalar_load_f32(uniform_ptr(p.rowscale1 + uniform_i32(m0 / p.rows_per_sample)));
+                dead1 = sc1_tile == 0.0f;
+            }
+        }
+        // x_out = x, y_next = LayerNorm(x) for this wave's 32 rows: half a wave per row, row sums by shuffles (as gemm_row384.h's epilogue)
+        auto dead_rows = [&](const buf_rsrc& rs_dst, long ld_dst, const float* ga_, const float* be_, bf16_t* yp, long ldyp,
+                             float* meanp, float* rstdp) __attribute__((always_inline)) {
             constexpr int C3 = (E / 4 + 31) / 32;              // 16-byte chunks of a row per lane
 #pragma unroll 1
             for (int it = 0; it < 16; ++it) {
@@ -315,18 +375,20 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                 for (int c3 = 0; c3 < C3; ++c3) {
                     const int chunk = lq + 32 * c3;
                     if (chunk < E / 4) {
-                        buf_store16(rs_o, (unsigned)(chunk * 16), rr * (unsigned)(p.ldc * 4), __builtin_bit_cast(u32x4, o[c3]));
-                        const f32x4v ga = *reinterpret_cast<const f32x4v*>(vga + 4 * chunk), be = *reinterpret_cast<const f32x4v*>(vbe + 4 * chunk);
+                        buf_store16(rs_dst, (unsigned)(chunk * 16), rr * (unsigned)(ld_dst * 4), __builtin_bit_cast(u32x4, o[c3]));
+                        const f32x4v ga = *reinterpret_cast<const f32x4v*>(ga_ + 4 * chunk), be = *reinterpret_cast<const f32x4v*>(be_ + 4 * chunk);
                         u32x2 pk;
                         pk.x = pack_bf2((o[c3].x - mean) * rstd * ga.x + be.x, (o[c3].y - mean) * rstd * ga.y + be.y);
                         pk.y = pack_bf2((o[c3].z - mean) * rstd * ga.z + be.z, (o[c3].w - mean) * rstd * ga.w + be.w);
-                        if (rr < (unsigned)p.M) *reinterpret_cast<u32x2*>(p.ln_y + (long)rr * p.ld_y + 4 * chunk) = pk;
+                        if (rr < (unsigned)p.M) *reinterpret_cast<u32x2*>(yp + (long)rr * ldyp + 4 * chunk) = pk;
                     }
                 }
-                if (lq == 0 && rr < (unsigned)p.M) { p.ln_mean[rr] = mean; p.ln_rstd[rr] = rstd; }
+                if (lq == 0 && rr < (unsigned)p.M) { meanp[rr] = mean; rstdp[rr] = rstd; }
             }
-            if (STORE_U) {
-                // the backward pass multiplies a zero gradient by gelu'(u) for these rows: u must be finite
+        };
+        // the backward pass multiplies a zero gradient by gelu'(u) for the rows of a dropped MLP branch: u must be finite
+        auto zero_u = [&]() __attribute__((always_inline)) {
+            if constexpr (STORE_U) {
                 const unsigned lo_u = LaneOff(t).rows8(p.ldu, 2);
 #pragma unroll 1
                 for (int cc = 0; cc < p.H / 64; ++cc)
@@ -342,6 +404,16 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                             buf_store16(rs_ga, lo_g, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldga * 2) + 128 * cc, u32x4{0u, 0u, 0u, 0u});
                 }
             }
+        };
+        if (tile_dead && (!PROJ || dead1)) {       // nothing of this tile is multiplied (PROJ: both branches dropped; the ring stays at the tile's start)
+            if constexpr (PROJ) {
+                if (keep_mid) {
+                    const buf_rsrc rs_xm = make_rsrc(p.xmid, (unsigned)((((long)p.M - 1) * p.ldxm + E) * 4));
+                    dead_rows(rs_xm, p.ldxm, vga2, vbe2, p.y2, p.ldy2, p.mean2, p.rstd2);
+                }
+            }
+            dead_rows(rs_o, p.ldc, vga, vbe, p.ln_y, p.ld_y, p.ln_mean, p.ln_rstd);
+            zero_u();
             continue;
         }
         f32x16 acc[NT];
@@ -349,13 +421,194 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-        {
-            bf16x8 yf[KJ];                 // this lane's row of y2 as B operands of the first product: k = 16 j + 8 hf .. + 7
-            {
-                const unsigned so = (unsigned)r0 * (unsigned)(p.ldy_in * 2), lo_y = LaneOff(t).frag(p.ldy_in, 2, 8);
+        bf16x8 yf[KJ];                     // this lane's row of y2 (PROJ: first of the attention output) as B operands: k = 16 j + 8 hf .. + 7
+        auto load_rows = [&]() __attribute__((always_inline)) {
+            const unsigned so = (unsigned)r0 * (unsigned)(ld_yin * 2), lo_y = LaneOff(t).frag(ld_yin, 2, 8);
 #pragma unroll
-                for (int j = 0; j < KJ; ++j) yf[j] = __builtin_bit_cast(bf16x8, stream_load16<NT_MLP_Y>(rs_y, lo_y, so + 32 * j));
+            for (int j = 0; j < KJ; ++j) yf[j] = __builtin_bit_cast(bf16x8, stream_load16<NT_MLP_Y>(rs_y, lo_y, so + 32 * j));
+        };
+        // ---- row passes over the accumulators (rows are complete inside their two lanes: lane, lane ^ 32).
+        // Pass A: v = x + (acc + bias) * sc (WITH_X: the residual rows stream in two tiles ahead of their use) or v = acc * sc, written
+        // back into the accumulators, LayerNorm statistics on the way.
+        float mean = 0.f, rstd = 0.f;
+        auto pass_a = [&](auto WITH_X, const float* vbias, float sc) __attribute__((always_inline)) {
+            float s1 = 0.f, s2 = 0.f;
+            if constexpr (decltype(WITH_X)::value) {
+                const unsigned so = (unsigned)r0 * (unsigned)(p.ldr * 4), lo_x = LaneOff(t).frag(p.ldr, 4, 4);
+                u32x4 xb[3][4];
+                auto load_x = [&](int nt) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) xb[nt % 3][g] = stream_load16<NT_MLP_X>(rs_x, lo_x, so + (32 * nt + 8 * g) * 4);
+                };
+                load_x(0);
+                if (NT > 1) load_x(1);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (nt + 2 < NT) load_x(nt + 2);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4v x = __builtin_bit_cast(f32x4v, xb[nt % 3][g]);
+                        const f32x4v b = *reinterpret_cast<const f32x4v*>(vbias + 32 * nt + 8 * g + 4 * hf);
+                        const float xx[4] = {x.x, x.y, x.z, x.w}, bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = xx[e] + (acc[nt][4 * g + e] + bb[e]) * sc;
+                            acc[nt][4 * g + e] = v;
+                            s1 += v;
+                            s2 = fmaf(v, v, s2);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[nt][r] * sc;
+                        acc[nt][r] = v;
+                        s1 += v;
+                        s2 = fmaf(v, v, s2);
+                    }
             }
+            s1 += shfl_xor(s1, 32);
+            s2 += shfl_xor(s2, 32);
+            mean = s1 * inv_e;
+            float var = s2 * inv_e - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            rstd = 1.0f / sqrtf(var + p.ln_eps);
+        };
+        // Pass B, per pair of 32-column tiles: the rows (fp32, one tile at a time) and their LayerNorm (bf16, both tiles) leave through
+        // the scratch image as 128-byte row segments (STORE), and / or the LayerNorm becomes the operand registers yf (TO_YF: the two
+        // half-waves exchange quads - v_permlane32_swap - so that a lane holds the 8 consecutive columns 16 j + 8 hf .. of k-step j)
+        auto pass_b = [&](auto STORE, auto TO_YF, const buf_rsrc& rs_of, long ldo, const buf_rsrc& rs_nf, long ldn, const float* ga_,
+                          const float* be_, float* meanp, float* rstdp) __attribute__((always_inline)) {
+            constexpr bool store = decltype(STORE)::value, to_yf = decltype(TO_YF)::value;
+            if (store && hf == 0 && row < p.M) { meanp[row] = mean; rstdp[row] = rstd; }
+            const LaneOff lo(t);
+            const unsigned lo_o = lo.rows8(ldo, 4), lo_n = lo.rows8(ldn, 2);
+#pragma unroll
+            for (int np = 0; np < NT / 2; ++np) {
+                u32x2 ypk[2][4];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int nt = 2 * np + tt;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float v[4] = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
+                        if constexpr (store) {
+                            const f32x4v o = {v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<f32x4v*>(scratch + lo.scr_wr(2 * g + lo.hf)) = o;
+                        }
+                        const int n = 32 * nt + 8 * g + 4 * hf;
+                        const f32x4v ga = *reinterpret_cast<const f32x4v*>(ga_ + n), be = *reinterpret_cast<const f32x4v*>(be_ + n);
+                        ypk[tt][g].x = pack_bf2((v[0] - mean) * rstd * ga.x + be.x, (v[1] - mean) * rstd * ga.y + be.y);
+                        ypk[tt][g].y = pack_bf2((v[2] - mean) * rstd * ga.z + be.z, (v[3] - mean) * rstd * ga.w + be.w);
+                    }
+                    if constexpr (store) {
+                        wave_lds_fence();
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const u32x4 v = *reinterpret_cast<const u32x4*>(scratch + lo.scr_rd(i));
+                            stream_store16<NT_MLP_OUT>(rs_of, lo_o, (unsigned)(r0 + 8 * i) * (unsigned)(ldo * 4) + 128 * nt, v);
+                        }
+                        wave_lds_fence();
+                    }
+                }
+                if constexpr (store) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<u32x2*>(scratch + lo.scr_wr(4 * tt + g) + 8 * lo.hf) = ypk[tt][g];
+                    wave_lds_fence();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(scratch + lo.scr_rd(i));
+                        buf_store16(rs_nf, lo_n, (unsigned)(r0 + 8 * i) * (unsigned)(ldn * 2) + 128 * np, v);
+                    }
+                    wave_lds_fence();
+                }
+                if constexpr (to_yf) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            // own quads: columns 16 j + 4 hf .. + 3 (a) and 16 j + 8 + 4 hf .. + 3 (b) of k-step j = 2 nt + s
+                            unsigned ax = ypk[tt][2 * s].x, ay = ypk[tt][2 * s].y, bx = ypk[tt][2 * s + 1].x, by = ypk[tt][2 * s + 1].y;
+                            lane32_swap(ax, bx);
+                            lane32_swap(ay, by);
+                            const u32x4 f = {ax, ay, bx, by};
+                            yf[2 * (2 * np + tt) + s] = __builtin_bit_cast(bf16x8, f);
+                        }
+                }
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using Yes = std::true_type;
+        using No = std::false_type;
+        // acc[half hh] += (piece of W2 / Wp: E/2 output rows x 64 k) . B, B = four k-steps of packed operands
+        auto p2_piece = [&](auto HH, const bf16x8& b0, const bf16x8& b1, const bf16x8& b2, const bf16x8& b3) __attribute__((always_inline)) {
+            constexpr int hh = decltype(HH)::value;
+            const unsigned sb = acquire();
+            const unsigned areg[4] = {sb + off2[0], sb + off2[1], sb + off2[2], sb + off2[3]};
+            mlp_product<4 * NTH, DEPTH, MlpMapP2<NTH>, MlpNoExtra>(
+                areg,
+                [&](auto K, const bf16x8& a) {
+                    constexpr int k = decltype(K)::value, ks = k / NTH;
+                    const bf16x8& b = ks == 0 ? b0 : ks == 1 ? b1 : ks == 2 ? b2 : b3;
+                    acc[NTH * hh + k % NTH] = mfma_32x32x16_bf16(a, b, acc[NTH * hh + k % NTH]);
+                },
+                [&](auto K) { dma_slot(K, std::integral_constant<int, 4 * NTH>{}); });
+        };
+        float sc_fin = 1.0f;                // what the accumulators are multiplied by at the end (PROJ)
+        bool run_mlp = true;
+        if constexpr (PROJ) {
+            // ---- the attention branch's tail: acc = a . Wp^T, then x_mid = x + (acc + bp) * sc1 and its LayerNorm
+            if (!dead1) {
+                load_rows();
+                MLP_STAMP(0)
+                mlp_static_for<0, KC>([&](auto KCI) {
+                    constexpr int kc = decltype(KCI)::value;
+                    p2_piece(I0{}, yf[4 * kc], yf[4 * kc + 1], yf[4 * kc + 2], yf[4 * kc + 3]);
+                    p2_piece(I1{}, yf[4 * kc], yf[4 * kc + 1], yf[4 * kc + 2], yf[4 * kc + 3]);
+                });
+                MLP_STAMP(6)
+            } else {
+                ring_seek(NPP);            // (the MLP branch is live, or the tile would have been skipped above)
+            }
+            pass_a(Yes{}, vbp, sc1_tile);
+            if (keep_mid) {
+                const buf_rsrc rs_xm = make_rsrc(p.xmid, (unsigned)((((long)p.M - 1) * p.ldxm + E) * 4));
+                const buf_rsrc rs_y2 = make_rsrc(p.y2, (unsigned)((((long)p.M - 1) * p.ldy2 + E) * 2));
+                pass_b(Yes{}, Yes{}, rs_xm, p.ldxm, rs_y2, p.ldy2, vga2, vbe2, p.mean2, p.rstd2);
+            } else {
+                pass_b(No{}, Yes{}, rs_o, p.ldc, rs_n, p.ld_y, vga2, vbe2, p.mean2, p.rstd2);
+            }
+            MLP_STAMP(7)
+            if (tile_dead) {               // the MLP branch is dropped: x_out = x_mid; its pieces (in flight behind the projection's) are skipped
+                ring_seek(0);
+                zero_u();
+                run_mlp = false;
+            } else {
+                // the second product accumulates ON x_mid: acc = x_mid / sc2 + b2, x_out = acc * sc2
+                const float inv2 = 1.0f / sc_tile;
+                sc_fin = sc_tile;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4v b = *reinterpret_cast<const f32x4v*>(vb2 + 32 * nt + 8 * g + 4 * hf);
+                        acc[nt][4 * g] = fmaf(acc[nt][4 * g], inv2, b.x);
+                        acc[nt][4 * g + 1] = fmaf(acc[nt][4 * g + 1], inv2, b.y);
+                        acc[nt][4 * g + 2] = fmaf(acc[nt][4 * g + 2], inv2, b.z);
+                        acc[nt][4 * g + 3] = fmaf(acc[nt][4 * g + 3], inv2, b.w);
+                    }
+            }
+        } else {
+            load_rows();
+        }
+        if (run_mlp) {
             f32x16 h[2];                   // H^T of the chunk being produced: 2 tiles of [32 hidden][32 rows]
             u32x4 hbw[4];                  // gelu(H) of the chunk being consumed, as packed bf16 B operands (k-step s = hbw[s])
             const unsigned lut_addr = lds_addr_of(lut) - 4u * MLP_LUT_LO;       // byte address of entry "magnitude 0"
@@ -387,21 +640,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                         filler(K);
                     });
             };
-            auto p2_piece = [&](auto HH) {                   // acc[half hh] += W2 piece . gelu(H)
-                constexpr int hh = decltype(HH)::value;
-                const unsigned sb = acquire();
-                const unsigned areg[4] = {sb + off2[0], sb + off2[1], sb + off2[2], sb + off2[3]};
-                mlp_product<4 * NTH, DEPTH, MlpMapP2<NTH>, MlpNoExtra>(
-                    areg,
-                    [&](auto K, const bf16x8& a) {
-                        constexpr int k = decltype(K)::value;
-                        acc[NTH * hh + k % NTH] = mfma_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, hbw[k / NTH]), acc[NTH * hh + k % NTH]);
-                    },
-                    [&](auto K) { dma_slot(K, std::integral_constant<int, 4 * NTH>{}); });
-            };
-            using I0 = std::integral_constant<int, 0>;
-            using I1 = std::integral_constant<int, 1>;
-            MLP_STAMP(0)
+            if constexpr (!PROJ) { MLP_STAMP(0) }
             p1_piece(I0{}, 0, MlpNoExtra{}, [](auto) {});
             MLP_STAMP(3)
             p1_piece(I1{}, 0, MlpNoExtra{}, [](auto) {});
@@ -497,93 +736,22 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                     }
                 }
                 MLP_STAMP(5)
-                p2_piece(I0{});
+                p2_piece(I0{}, __builtin_bit_cast(bf16x8, hbw[0]), __builtin_bit_cast(bf16x8, hbw[1]), __builtin_bit_cast(bf16x8, hbw[2]),
+                         __builtin_bit_cast(bf16x8, hbw[3]));
                 MLP_STAMP(6)
-                p2_piece(I1{});
+                p2_piece(I1{}, __builtin_bit_cast(bf16x8, hbw[0]), __builtin_bit_cast(bf16x8, hbw[1]), __builtin_bit_cast(bf16x8, hbw[2]),
+                         __builtin_bit_cast(bf16x8, hbw[3]));
                 MLP_STAMP(6)
             }
         }
-        // ---- epilogue: rows are complete inside their two lanes (lane, lane ^ 32).
-        const float sc = (p.rowscale && !one_sample) ? p.rowscale[grow / p.rows_per_sample] : sc_tile;
-        // Pass A: out = x + (acc + b2) * sc written back into the accumulators, LayerNorm statistics on the way; the
-        // residual rows stream in two tiles ahead of their use.
-        float s1 = 0.f, s2 = 0.f;
-        {
-            const unsigned so = (unsigned)r0 * (unsigned)(p.ldr * 4), lo_x = LaneOff(t).frag(p.ldr, 4, 4);
-            u32x4 xb[3][4];
-            auto load_x = [&](int nt) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) xb[nt % 3][g] = stream_load16<NT_MLP_X>(rs_x, lo_x, so + (32 * nt + 8 * g) * 4);
-            };
-            load_x(0);
-            if (NT > 1) load_x(1);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                if (nt + 2 < NT) load_x(nt + 2);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4v x = __builtin_bit_cast(f32x4v, xb[nt % 3][g]);
-                    const f32x4v b = *reinterpret_cast<const f32x4v*>(vb2 + 32 * nt + 8 * g + 4 * hf);
-                    const float xx[4] = {x.x, x.y, x.z, x.w}, bb[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = xx[e] + (acc[nt][4 * g + e] + bb[e]) * sc;
-                        acc[nt][4 * g + e] = v;
-                        s1 += v;
-                        s2 = fmaf(v, v, s2);
-                    }
-                }
-            }
+        // ---- epilogue: x_out into the accumulators + statistics, then x_out and y_next leave
+        if constexpr (PROJ) {
+            pass_a(No{}, vb2, sc_fin);
+        } else {
+            const float sc = (p.rowscale && !one_sample) ? p.rowscale[grow / p.rows_per_sample] : sc_tile;
+            pass_a(Yes{}, vb2, sc);
         }
-        s1 += shfl_xor(s1, 32);
-        s2 += shfl_xor(s2, 32);
-        const float mean = s1 * inv_e;
-        float var = s2 * inv_e - mean * mean;
-        var = var > 0.f ? var : 0.f;
-        const float rstd = 1.0f / sqrtf(var + p.ln_eps);
-        if (hf == 0 && row < p.M) { p.ln_mean[row] = mean; p.ln_rstd[row] = rstd; }
-        const LaneOff lo(t);
-        const unsigned lo_o = lo.rows8(p.ldc, 4), lo_n = lo.rows8(p.ld_y, 2);
-        // Pass B:
-        // per pair of 32-column tiles: x_out (fp32, one tile at a time) and y_next (bf16, both tiles) through the scratch
-        // image, leaving as 128-byte row segments
-#pragma unroll
-        for (int np = 0; np < NT / 2; ++np) {
-            u32x2 ypk[2][4];
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const int nt = 2 * np + tt;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float v[4] = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
-                    const f32x4v o = {v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4v*>(scratch + lo.scr_wr(2 * g + lo.hf)) = o;
-                    const int n = 32 * nt + 8 * g + 4 * hf;
-                    const f32x4v ga = *reinterpret_cast<const f32x4v*>(vga + n), be = *reinterpret_cast<const f32x4v*>(vbe + n);
-                    ypk[tt][g].x = pack_bf2((v[0] - mean) * rstd * ga.x + be.x, (v[1] - mean) * rstd * ga.y + be.y);
-                    ypk[tt][g].y = pack_bf2((v[2] - mean) * rstd * ga.z + be.z, (v[3] - mean) * rstd * ga.w + be.w);
-                }
-                wave_lds_fence();
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(scratch + lo.scr_rd(i));
-                    stream_store16<NT_MLP_OUT>(rs_o, lo_o, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldc * 4) + 128 * nt, v);
-                }
-                wave_lds_fence();
-            }
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<u32x2*>(scratch + lo.scr_wr(4 * tt + g) + 8 * lo.hf) = ypk[tt][g];
-            wave_lds_fence();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(scratch + lo.scr_rd(i));
-                buf_store16(rs_n, lo_n, (unsigned)(r0 + 8 * i) * (unsigned)(p.ld_y * 2) + 128 * np, v);
-            }
-            wave_lds_fence();
-        }
+        pass_b(Yes{}, No{}, rs_o, p.ldc, rs_n, p.ld_y, vga, vbe, p.ln_mean, p.ln_rstd);
         MLP_STAMP(7)
     }
     glds_wait_all();                       // requested pieces that no tile consumed must not outlive the workgroup's LDS

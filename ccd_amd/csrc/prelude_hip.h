@@ -110,6 +110,12 @@ __device__ __forceinline__ float scalar_load_f32(const float* p) {
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
     return v;
 }
+// a pointer the compiler must treat as wave-uniform (both halves through v_readfirstlane): scalar_load_f32's "s" operand
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+    const unsigned long long a = (unsigned long long)(uintptr_t)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return reinterpret_cast<const float*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+}
 // streaming variants: non-temporal cache policy (aux = 2, "nt"): data that is touched once must not push the L2-resident
 // operands (weights) of the same kernel out of the XCD's 4-MiB L2
 __device__ __forceinline__ buf_u32x4 buf_load16_nt(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset) {

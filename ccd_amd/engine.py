@@ -48,6 +48,7 @@ class Fusion:
     store_gact = _env_switch("CCD_STORE_GACT")     # the fused MLP forward also stores gelu(u) for the backward pass (default: off -
     if store_gact is None:                         # a measured tie, 52.9 vs 53.0 ms per step: + 0.47 ms forward, - 0.75 ms gelu'(u)
         store_gact = False                         # product, + 0.2 GB per block of saved activations at B = 256)
+    proj_mlp = _env_switch("CCD_FUSE_PROJ")        # proj + residual + LayerNorm-2 in front of the fused MLP, one launch per block half (default: with `mlp`, E <= 384)
     side_stream = bool(_env_switch("CCD_SIDE_STREAM"))
     double_gb = False                       # tests: rotate the two gb buffers of the side-stream mode also without a side stream
 
@@ -57,6 +58,11 @@ class Fusion:
         mlp = ln and E % 128 == 0 and (cls.mlp if cls.mlp is not None else True)
         lnbwd = (E <= 384 or E == 512) and E % 8 == 0 and (cls.lnbwd if cls.lnbwd is not None else True)
         return ln, mlp, lnbwd
+
+    @classmethod
+    def resolve_proj(cls, E):
+        """ccd_proj_mlp_fused (round 5) replaces ccd_gemm_nt_resid_ln + ccd_mlp_fused where both would run (it cannot store gelu(u))."""
+        return cls.resolve(E)[1] and E <= 384 and not cls.store_gact and (cls.proj_mlp if cls.proj_mlp is not None else True)
 
 
 _DROPPATH_SEED = {"base": None, "calls": 0, "device": None}
@@ -137,6 +143,7 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
     # per lane leave a 3-slot weight ring and spills: 51.9 ms per step against 47.0 with only the LayerNorm-backward product
     # fused, 47.3 unfused; B = 128, one MI355X)
     fuse_ln, fuse_mlp, _ = Fusion.resolve(E)
+    fuse_proj = Fusion.resolve_proj(E)
     # the whole MLP branch in one kernel (csrc/kernels/mlp_fused.h): the hidden activation never reaches HBM; when
     # activations are saved only the bf16 pre-activation u is stored and backward re-derives gelu(u) in the epilogue
     # that already reads u (ccd_gemm_nt, EPI_DGELU with a second output)
@@ -156,7 +163,19 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
             c.y1, c.mean1, c.rstd1 = pending
         c.qkv = ops.gemm_nt(c.y1, arena.wb(b + "attn.qkv.weight"), bias=arena.w(b + "attn.qkv.bias"))
         c.att, c.lse = ops.attention_fwd(c.qkv.view(N, 256, 3 * E), spec.heads, scale)
-        if fuse_ln:
+        if fuse_proj:
+            # the block's second half in ONE launch: x_mid and y2 stay in registers (a pass that saves nothing writes neither)
+            nxt = f"{pre}blocks.{i + 1}.norm1." if i + 1 < spec.depth else pre + "norm."
+            x, y_n, mean_n, rstd_n, kept = ops.proj_mlp_fused(
+                c.att.view(R, E), arena.wb(b + "attn.proj.weight"), arena.w(b + "attn.proj.bias"), resid=x, rowscale1=c.ds1,
+                gamma2=arena.w(b + "norm2.weight"), beta2=arena.w(b + "norm2.bias"), w1=arena.wb(b + "mlp.fc1.weight"),
+                b1=arena.w(b + "mlp.fc1.bias"), w2=arena.wb(b + "mlp.fc2.weight"), b2=arena.w(b + "mlp.fc2.bias"), rowscale2=c.ds2,
+                rows_per_sample=256, gamma=arena.w(nxt + "weight"), beta=arena.w(nxt + "bias"), eps=spec.eps, save=save)
+            if save:
+                c.x_mid, c.y2, c.mean2, c.rstd2, c.u = kept
+            c.gact = None
+            pending = [y_n, mean_n, rstd_n]
+        elif fuse_ln:
             c.x_mid, c.y2, c.mean2, c.rstd2 = ops.gemm_nt_resid_ln(
                 c.att.view(R, E), arena.wb(b + "attn.proj.weight"), bias=arena.w(b + "attn.proj.bias"), resid=x,
                 rowscale=c.ds1, rows_per_sample=256, gamma=arena.w(b + "norm2.weight"), beta=arena.w(b + "norm2.bias"),
@@ -165,7 +184,9 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
             c.x_mid = ops.gemm_nt(c.att.view(R, E), arena.wb(b + "attn.proj.weight"), epilogue=ops.EPI_RESID,
                                   bias=arena.w(b + "attn.proj.bias"), resid=x, rowscale=c.ds1, rows_per_sample=256)
             c.y2, c.mean2, c.rstd2 = ops.ln_fwd(c.x_mid, arena.w(b + "norm2.weight"), arena.w(b + "norm2.bias"), spec.eps)
-        if fuse_mlp:
+        if fuse_proj:
+            pass
+        elif fuse_mlp:
             nxt = f"{pre}blocks.{i + 1}.norm1." if i + 1 < spec.depth else pre + "norm."
             # (store_gact: gelu(u) leaves the forward kernel too - its packed second-product operands ARE that tensor - so the
             # backward's gelu'(u) product gathers one table instead of two and writes du only)
@@ -393,14 +414,37 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
         on_block_done(pre + "patch_embed.")
 
 
+class ForwardHop:
+    """Where BackboneFn.forward runs while set as engine.FORWARD_HOP: `stream` (CU-masked), persistent grids sized to leave
+    `reserve` compute units to the other partition; join=False leaves it to the caller to make its stream wait for `stream`."""
+
+    def __init__(self, stream, reserve, join=True):
+        self.stream, self.reserve, self.join = stream, int(reserve), bool(join)
+
+
+FORWARD_HOP = None
+
+
 class BackboneFn(torch.autograd.Function):
     """tokens, tap0, tap1, tap2 = BackboneFn.apply(anchor, img, module)   (anchor: any tensor that requires grad)."""
 
     @staticmethod
     def forward(ctx, anchor, img, module, need_taps=True):
         save = ctx.needs_input_grad[0]      # False under no_grad / frozen teacher
-        tokens, taps, saved = backbone_forward(module.arena, module.arena_prefix, module.spec, img, module.resample,
-                                               save, module.training, need_taps)
+        hop = FORWARD_HOP
+        if hop is not None and img.is_cuda:
+            # the pass runs on a CU-masked stream (ccd_amd/streams.py) beside the other network's; the stream switch happens INSIDE
+            # the Function, so autograd still files the node under the caller's stream and the backward pass gets the whole chip
+            main = torch.cuda.current_stream(img.device)
+            hop.stream.wait_stream(main)
+            with torch.cuda.stream(hop.stream), ops.policy(cu_reserve=hop.reserve, cu_reserve_window=-1):
+                tokens, taps, saved = backbone_forward(module.arena, module.arena_prefix, module.spec, img, module.resample,
+                                                       save, module.training, need_taps)
+            if hop.join:
+                main.wait_stream(hop.stream)
+        else:
+            tokens, taps, saved = backbone_forward(module.arena, module.arena_prefix, module.spec, img, module.resample,
+                                                   save, module.training, need_taps)
         ctx.module, ctx.saved = module, saved
         N, E = img.shape[0], module.spec.E
         outs = [tokens.view(N, 256, E)] + [t.view(N, 256, E) for t in taps]

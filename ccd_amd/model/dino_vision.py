@@ -94,11 +94,21 @@ class ABIDINOModel(ArenaModule):
         w = onehot * tok_coef.unsqueeze(-1)                                  # [N,256,26], tiny glue for API parity
         return torch.bmm(w.transpose(1, 2), tokens), present.bool()
 
-    def forward(self, x, metrics, target_mask, epoch, clusters=None, index=None):
+    def backbone_tokens(self, x):
+        """Final-norm tokens of both views [2B,256,E] (no taps): the teacher's backbone pass on its own, so that it can be
+        enqueued before the student's clusters exist (pretrain._forward_backward with a CU partition)."""
+        self.ensure_arena()
+        tokens, = self.backbone.tokens_and_taps(torch.cat([x[:, 1], x[:, 2]]), need_taps=False)
+        return tokens
+
+    def forward(self, x, metrics, target_mask, epoch, clusters=None, index=None, tokens=None):
         self.ensure_arena()
         B = x.shape[0]
-        views = torch.cat([x[:, 1], x[:, 2]])
-        tokens, *taps = self.backbone.tokens_and_taps(views, need_taps=clusters is None)
+        if tokens is None:
+            views = torch.cat([x[:, 1], x[:, 2]])
+            tokens, *taps = self.backbone.tokens_and_taps(views, need_taps=clusters is None)
+        else:
+            assert clusters is not None, "precomputed tokens are the teacher's (no segmentation taps)"
         if clusters is None:
             seg_in = [self.backbone.to_2D(t) for t in taps]
             seg = self.segmentation(seg_in)                                    # [2B,2,32,128] fp32

@@ -56,12 +56,77 @@ def _set_schedule(optimizer, lr, wd):
             g["weight_decay"] = float(wd)
 
 
+FWD_SPLIT = None          # ("cu" | "xcd", teacher share): student / teacher backbone passes on CU-masked streams; None = one after the other
+_FWD_SPLIT_ENV_READ = False
+
+
+def _forward_split(device):
+    global FWD_SPLIT, _FWD_SPLIT_ENV_READ
+    if not _FWD_SPLIT_ENV_READ:
+        _FWD_SPLIT_ENV_READ = True
+        if FWD_SPLIT is None:
+            from .streams import env_partition
+            FWD_SPLIT = env_partition()
+    if FWD_SPLIT is None or torch.device(device).type != "cuda":
+        return None
+    from .streams import partition
+    return partition(device, teacher_per_xcd=FWD_SPLIT[1], layout=FWD_SPLIT[0])
+
+
 def _forward_backward(student, teacher, dino_loss, optimizer, images, masks, metrics, epoch, check_finite=False):
     """train.py:221-246: both networks, the loss, zero_grad, backward (+ the gradient all-reduce of a wrapped student)."""
+    split = _forward_split(images.device)
+    if split is None:
+        return _forward_backward_on_stream(student, teacher, dino_loss, optimizer, images, masks, metrics, epoch, check_finite, None)
+    # The CU-masked streams are BLOCKING streams (hipExtStreamCreateWithCUMask takes no flags): any operation on the legacy
+    # default stream - an event record is one - waits for everything queued on them and holds back everything queued after it.
+    # torch's default stream IS that stream, so the pass runs on a non-blocking stream of its own and joins the caller's at the end
+    # (measured with the default stream in the middle: the two partitions ran one after the other, 67 ms per step instead of 50).
+    dev = images.device
+    caller = torch.cuda.current_stream(dev)
+    work = _work_stream(dev)
+    work.wait_stream(caller)
+    with torch.cuda.stream(work):
+        loss = _forward_backward_on_stream(student, teacher, dino_loss, optimizer, images, masks, metrics, epoch, check_finite, split)
+    caller.wait_stream(work)
+    loss.record_stream(caller)
+    return loss
+
+
+_WORK_STREAMS = {}
+
+
+def _work_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _WORK_STREAMS:
+        _WORK_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _WORK_STREAMS[key]
+
+
+def _forward_backward_on_stream(student, teacher, dino_loss, optimizer, images, masks, metrics, epoch, check_finite, split):
     metrics = metrics.float()
-    s_out = student(images, metrics, masks, epoch, clusters=None)
-    with torch.no_grad():
-        t_out = teacher(images, metrics, None, None, clusters=s_out["zero"], index=None)
+    if split is None:
+        s_out = student(images, metrics, masks, epoch, clusters=None)
+        with torch.no_grad():
+            t_out = teacher(images, metrics, None, None, clusters=s_out["zero"], index=None)
+    else:
+        # both backbone passes side by side on disjoint compute units (ccd_amd/streams.py): the teacher's is enqueued first and
+        # nobody waits for it until its tokens are pooled; the student's joins the calling stream when it returns
+        from . import engine
+        s_stream, t_stream, s_cus, t_cus = split
+        t_mod = teacher.module if hasattr(teacher, "module") else teacher
+        main = torch.cuda.current_stream(images.device)
+        try:
+            engine.FORWARD_HOP = engine.ForwardHop(t_stream, s_cus, join=False)
+            with torch.no_grad():
+                t_tokens = t_mod.backbone_tokens(images)
+            engine.FORWARD_HOP = engine.ForwardHop(s_stream, t_cus, join=True)
+            s_out = student(images, metrics, masks, epoch, clusters=None)
+        finally:
+            engine.FORWARD_HOP = None
+        main.wait_stream(t_stream)
+        with torch.no_grad():
+            t_out = teacher(images, metrics, None, None, clusters=s_out["zero"], index=None, tokens=t_tokens)
     # gt = [masks, warped masks > 0.1]  (train.py:234-237); the warped half stays an id map on the device
     masks_image = ops.warp_idmap(ops.mask_to_idmap(masks.contiguous().float()), metrics.contiguous())
     s_out["gt"] = [masks, masks_image]

@@ -101,6 +101,21 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
                   const float* b2, const float* resid, long ldr, const float* rowscale, int rows_per_sample, float* out,
                   long ldc, const float* ln_gamma, const float* ln_beta, float ln_eps, ccd_bf16* ln_y, long ld_y,
                   float* ln_mean, float* ln_rstd, ccd_bf16* u, long ldu, ccd_bf16* gact, long ldga, int M, int E, int H, void* stream);
+/* The whole second half of a transformer block in one launch (round 5): the tail of the attention branch in front of the fused MLP,
+ *     x_mid = resid + rowscale1[row / rps] * (a . Wp^T + bp)            vision_transformer.py:91 (proj), :108 (residual + DropPath)
+ *     y2    = LayerNorm(x_mid) * ln2_gamma + ln2_beta                   :109 (norm2)
+ *     out   = x_mid + rowscale2[row / rps] * (gelu(y2 . W1^T + b1) . W2^T + b2);   ln_y = LayerNorm(out) * ln_gamma + ln_beta
+ * x_mid never leaves the accumulator registers and y2 never leaves the operand registers: a forward pass that keeps nothing
+ * (xmid = y2 = mean2 = rstd2 = u = NULL: the teacher) reads a and resid and writes out and ln_y - 604 MB per 131 072 rows instead
+ * of the 1 208 MB of ccd_gemm_nt_resid_ln + ccd_mlp_fused.  With xmid / y2 / mean2 / rstd2 (all four or none) and u the tensors
+ * the backward pass needs are written on the way.  E in {128, 256, 384}; with a DropPath scale rows_per_sample % 128 == 0
+ * (CCD_ESHAPE otherwise: the caller takes the two separate launches).  Replaces ccd_gemm_nt_resid_ln + ccd_mlp_fused. */
+int ccd_proj_mlp_fused(const ccd_bf16* a, long lda, const ccd_bf16* wp, long ldp, const float* bp, const float* resid, long ldr,
+                       const float* rowscale1, const float* ln2_gamma, const float* ln2_beta, float* xmid, long ldxm, ccd_bf16* y2,
+                       long ldy2, float* mean2, float* rstd2, const ccd_bf16* w1, long ld1, const float* b1, const ccd_bf16* w2,
+                       long ld2, const float* b2, const float* rowscale2, int rows_per_sample, float* out, long ldc,
+                       const float* ln_gamma, const float* ln_beta, float ln_eps, ccd_bf16* ln_y, long ld_y, float* ln_mean,
+                       float* ln_rstd, ccd_bf16* u, long ldu, int M, int E, int H, void* stream);
 /* colsum (optional, epilogues BF16 / DGELU): [N] fp32, += column sums of the output (bias gradient of the producer).
  * CCD_EPI_GELU accepts C == NULL (only gelu(u) is stored: forward passes that keep no activations). */
 /* C[P,Q] (+)= sum_m A[m,P] * B[m,Q]   (weight gradients dW = dY^T X of every Linear; autograd of the above)

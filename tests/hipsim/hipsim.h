@@ -264,6 +264,7 @@ template <int B> inline buf_u32x4 stream_load16(buf_rsrc r, unsigned a, unsigned
 template <typename T>
 inline void needed_here(T&) {}
 inline float scalar_load_f32(const float* p) { return *p; }
+inline const float* uniform_ptr(const float* p) { return p; }
 // hand-tracked buffer loads (prelude_hip.h: buf_load16_late / vm_arrived).  Late mode: the destination is poisoned (bf16 NaNs)
 // at issue and receives its data only when a counted wait of this lane retires the request - the latest the hardware may
 // deliver it, in the same in-order queue as the LDS-DMA requests: a use in front of a sufficient wait sees NaNs.

@@ -1024,6 +1024,72 @@ def check_mlp_fused(dev, M, E, H, rps=128, seed=31, store_u=True):
             assert torch.equal(out[lo:hi].cpu(), resid[lo:hi]), "dropped sample: the stream must pass through unchanged"
 
 
+def check_proj_mlp_fused(dev, M, E, H, rps=128, seed=41, save=True, drops=True):
+    """ccd_proj_mlp_fused == proj + residual (DropPath) + LayerNorm-2 + fc1 + GELU + fc2 + residual (DropPath) + LayerNorm in plain
+    fp32 math on the same bf16-rounded operands (y2, u and gelu(u) rounded to bf16 where the kernels round them), i.e.
+    == ops.gemm_nt_resid_ln followed by ops.mlp_fused.  drops: samples with either branch, both or none dropped."""
+    g = torch.Generator().manual_seed(seed)
+    a = rnd((M, E), g).to(BF); wp = rnd((E, E), g, 0.08).to(BF)
+    w1 = rnd((H, E), g, 0.08).to(BF); w2 = rnd((E, H), g, 0.05).to(BF)
+    bp, b1, b2 = rnd((E,), g), rnd((H,), g) * 0.5, rnd((E,), g)
+    resid = rnd((M, E), g) * 3 + 0.5
+    ns = (M + rps - 1) // rps
+    rs1 = (torch.rand(ns, generator=g) > 0.3).float() * 1.25
+    rs2 = (torch.rand(ns, generator=g) > 0.3).float() * 1.25
+    pattern = [(1.25, 1.25), (0.0, 1.25), (1.25, 0.0), (0.0, 0.0), (1.25, 1.25)]      # every combination is present when M allows
+    for i in range(min(ns, len(pattern))):
+        rs1[i], rs2[i] = pattern[i]
+    ga2, be2 = rnd((E,), g).abs() + 0.5, rnd((E,), g) * 0.3
+    ga, be = rnd((E,), g).abs() + 0.5, rnd((E,), g) * 0.3
+    for use in ((True, False) if drops else (False,)):
+        r1, r2 = (rs1, rs2) if use else (None, None)
+        out, yn, mean, rstd, saved = ops.proj_mlp_fused(
+            a.to(dev), wp.to(dev), bp.to(dev), resid=resid.to(dev), rowscale1=None if r1 is None else r1.to(dev), gamma2=ga2.to(dev),
+            beta2=be2.to(dev), w1=w1.to(dev), b1=b1.to(dev), w2=w2.to(dev), b2=b2.to(dev), rowscale2=None if r2 is None else r2.to(dev),
+            rows_per_sample=rps, gamma=ga.to(dev), beta=be.to(dev), eps=1e-6, save=save)
+        s1 = 1.0 if r1 is None else r1.repeat_interleave(rps)[:M, None]
+        s2 = 1.0 if r2 is None else r2.repeat_interleave(rps)[:M, None]
+        xmid_ref = resid + (a.float() @ wp.float().t() + bp) * s1
+        y2_ref = F.layer_norm(xmid_ref, (E,), ga2, be2, 1e-6).to(BF)
+        u_ref = (y2_ref.float() @ w1.float().t() + b1).to(BF)
+        h_ref = F.gelu(u_ref.float()).to(BF).float()
+        want = xmid_ref + (h_ref @ w2.float().t() + b2) * s2
+        tag = "proj_mlp_fused" + ("" if use else "/noscale") + ("" if save else "/nosave")
+        if save:
+            xmid, y2, mean2, rstd2, u = saved
+            close(xmid, xmid_ref, 1e-4, 2e-4, tag + "/x_mid")
+            close(mean2, xmid_ref.mean(1), 1e-3, 1e-3, tag + "/mean2")
+            close(rstd2, (xmid_ref.var(1, unbiased=False) + 1e-6).rsqrt(), 2e-3, 1e-4, tag + "/rstd2")
+            close(y2, y2_ref, 1e-2, 2e-2, tag + "/y2")
+            u_want = u_ref.clone()
+            if r2 is not None:
+                for t0 in range(0, M, 128):
+                    if r2[t0 // rps] == 0:
+                        u_want[t0:t0 + 128] = 0            # a dropped MLP branch stores u = 0 (finite) and multiplies nothing
+            close(u, u_want, 1.6e-2, 2e-3, tag + "/u")
+        else:
+            assert saved is None
+        close(out, want, 2e-3, 3e-3 * max(1.0, (H / 128) ** 0.5), tag + "/out")
+        mu, var = want.mean(1), want.var(1, unbiased=False)
+        close(mean, mu, 1e-3, 1e-3, tag + "/mean")
+        close(rstd, (var + 1e-6).rsqrt(), 2e-3, 1e-4, tag + "/rstd")
+        close(yn, F.layer_norm(want, (E,), ga, be, 1e-6), 1e-2, 2e-2, tag + "/y")
+        if use:
+            for i in range(min(ns, len(pattern))):
+                lo, hi = i * rps, min((i + 1) * rps, M)
+                if rs1[i] == 0 and rs2[i] == 0:
+                    assert torch.equal(out[lo:hi].cpu(), resid[lo:hi]), "both branches dropped: the stream must pass through unchanged"
+                if rs2[i] == 0 and save:
+                    assert torch.equal(out[lo:hi].cpu(), saved[0][lo:hi].cpu()), "dropped MLP branch: x_out must equal x_mid"
+        # the same rows through the two separate launches it replaces
+        o2, y2b, m2b, r2b = ops.gemm_nt_resid_ln(a.to(dev), wp.to(dev), bias=bp.to(dev), resid=resid.to(dev),
+                                                 rowscale=None if r1 is None else r1.to(dev), rows_per_sample=rps, gamma=ga2.to(dev),
+                                                 beta=be2.to(dev), eps=1e-6)
+        o3 = ops.mlp_fused(y2b, w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), resid=o2, rowscale=None if r2 is None else r2.to(dev),
+                           rows_per_sample=rps, gamma=ga.to(dev), beta=be.to(dev), eps=1e-6, store_u=False)
+        close(out, o3[0].float().cpu(), 2e-3, 3e-3 * max(1.0, (H / 128) ** 0.5), tag + "/out vs the two launches")
+
+
 def check_gemm_lnbwd(dev, M, N, K, seed=33):
     """Data-gradient product with the LayerNorm backward in its epilogue == gemm_nt followed by ln_bwd, and both == autograd."""
     g = torch.Generator().manual_seed(seed)

@@ -251,6 +251,38 @@ def test_gemm_resid_ln_policy_off_rejects_n512(hip):
             kc.check_gemm_resid_ln(hip.device, M=256, N=512, K=512)
 
 
+@pytest.mark.parametrize("M,E,H,rps", [(128 * 5 + 40, 128, 256, 128), (300, 384, 128, 128), (40000, 384, 1536, 256), (4096, 256, 1024, 256)])
+def test_proj_mlp_fused(hip, M, E, H, rps):
+    """proj + residual + LayerNorm-2 + fc1 + GELU + fc2 + residual + LayerNorm in one launch (ccd_proj_mlp_fused) vs fp32 torch and
+    vs the two launches it replaces: ragged tiles, many tiles per workgroup, every combination of dropped branches (the ring
+    skips their weight pieces), with and without the tensors saved for the backward pass."""
+    for save in (True, False):
+        kc.check_proj_mlp_fused(hip.device, M=M, E=E, H=H, rps=rps, save=save)
+    with pytest.raises(RuntimeError):            # a DropPath scale with tiles that span samples: the caller takes the two launches
+        kc.check_proj_mlp_fused(hip.device, M=256, E=384, H=128, rps=8)
+
+
+def test_proj_mlp_fused_repeatable(hip):
+    import torch
+    from ccd_amd import ops
+    g = torch.Generator().manual_seed(5)
+    dev = hip.device
+    M, E, H = 16384, 384, 1536
+    mk = lambda *s, dt=torch.bfloat16, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dt).to(dev)
+    a, wp, w1, w2 = mk(M, E), mk(E, E, sc=0.05), mk(H, E, sc=0.05), mk(E, H, sc=0.05)
+    bp, b1, b2, ga2, be2, ga, be = (mk(n, dt=torch.float32) for n in (E, H, E, E, E, E, E))
+    resid = mk(M, E, dt=torch.float32)
+    ref = None
+    for _ in range(4):
+        out, yn, mean, rstd, kept = ops.proj_mlp_fused(a, wp, bp, resid=resid, rowscale1=None, gamma2=ga2, beta2=be2, w1=w1, b1=b1, w2=w2,
+                                                       b2=b2, rowscale2=None, rows_per_sample=256, gamma=ga, beta=be, eps=1e-6, save=True)
+        cur = (out, yn, mean, rstd) + kept
+        if ref is None:
+            ref = [t.clone() for t in cur]
+        else:
+            assert all(torch.equal(x, y) for x, y in zip(ref, cur)), "proj_mlp_fused is not run-to-run deterministic"
+
+
 @pytest.mark.parametrize("M,E,H,rps", [(300, 128, 256, 128), (200, 384, 128, 8), (40000, 384, 1536, 256), (4096, 256, 1024, 256),
                                        (33000, 512, 2048, 256)])
 def test_mlp_fused(hip, M, E, H, rps):

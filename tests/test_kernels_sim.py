@@ -276,6 +276,15 @@ def test_decoder_abi_rejects_unsupported_arguments(sim):
     assert ops.dropout(torch.zeros(0), 0.1, 1).numel() == 0
 
 
+def test_proj_mlp_fused_sim(sim):
+    """mlp_fused.h with the projection + residual + LayerNorm-2 prologue (PROJ): ring seeks over dropped branches, both epilogues,
+    several tiles per workgroup (1 CU), with and without the tensors saved for the backward pass."""
+    kc.check_proj_mlp_fused(sim.device, M=128 * 5 + 40, E=128, H=256, rps=128)
+    kc.check_proj_mlp_fused(sim.device, M=300, E=384, H=128, rps=128, save=False)
+    kc.check_proj_mlp_fused(sim.device, M=200, E=384, H=320, rps=256, seed=43)
+    kc.check_proj_mlp_fused(sim.device, M=130, E=256, H=128, rps=128, seed=44, drops=False)
+
+
 def test_mlp_fused_sim(sim):
     """Ragged last tile, several tiles per workgroup (1 CU), a dropped sample, both instantiations of E."""
     kc.check_mlp_fused(sim.device, M=300, E=128, H=256, rps=128)

@@ -56,11 +56,15 @@ def test_finetune_dropout_sim(sim):
 def test_finetune_fused_mlp_sim(sim, monkeypatch):
     """A backbone whose width is a multiple of 128 takes the fused MLP kernel in both passes (forward keeps only the
     pre-activation, backward re-derives gelu(u)): the whole iteration against the oracle, gradients included."""
-    from ccd_amd import ops
-    calls = []
-    real = ops.mlp_fused
+    from ccd_amd import engine, ops
+    calls, pcalls = [], []
+    real, preal = ops.mlp_fused, ops.proj_mlp_fused
     monkeypatch.setattr(ops, "mlp_fused", lambda *a, **k: (calls.append(k.get("store_u")), real(*a, **k))[1])
-    _run_fused(sim)
+    monkeypatch.setattr(ops, "proj_mlp_fused", lambda *a, **k: (pcalls.append(k.get("save")), preal(*a, **k))[1])
+    _run_fused(sim)      # default: proj + residual + LayerNorm-2 ride in front of the fused MLP (ccd_proj_mlp_fused)
+    assert pcalls and any(pcalls) and not calls, "the fused block-half kernel was not on the path"
+    monkeypatch.setattr(engine.Fusion, "proj_mlp", False)
+    _run_fused(sim)      # the two separate launches it replaces
     assert calls and any(calls), "the fused MLP kernel was not on the path"
 
 
