@@ -462,8 +462,9 @@ int ccd_proj_mlp_fused(const ccd_bf16* a, long lda, const ccd_bf16* wp, long ldp
                        float* ln_rstd, ccd_bf16* u, long ldu, int M, int E, int H, void* stream) {
     CCD_CHECK(a && wp && bp && resid && ln2_gamma && ln2_beta && w1 && b1 && w2 && b2 && out && ln_gamma && ln_beta && ln_y && ln_mean &&
               ln_rstd, CCD_EINVAL);
-    CCD_CHECK((xmid != nullptr) == (y2 != nullptr) && (xmid != nullptr) == (mean2 != nullptr) && (xmid != nullptr) == (rstd2 != nullptr),
-              CCD_EINVAL);
+    CCD_CHECK((xmid != nullptr) == (y2 != nullptr) && (xmid != nullptr) == (mean2 != nullptr) && (xmid != nullptr) == (rstd2 != nullptr) &&
+              (xmid != nullptr) == (u != nullptr), CCD_EINVAL);       // what the backward pass reads: all five or none
+    CCD_CHECK(!rowscale2 || xmid, CCD_EINVAL);    // a dropped MLP branch reads x_mid back (only a pass that trains drops branches)
     CCD_CHECK(CCD_ALIGNED16(a) && CCD_ALIGNED16(wp) && CCD_ALIGNED16(w1) && CCD_ALIGNED16(w2) && CCD_ALIGNED16(resid) && CCD_ALIGNED16(out) &&
               CCD_ALIGNED16(ln_y) && CCD_ALIGNED16(u) && CCD_ALIGNED16(xmid) && CCD_ALIGNED16(y2), CCD_EINVAL);
     if (M == 0) return CCD_OK;

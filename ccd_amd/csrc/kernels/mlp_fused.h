@@ -202,7 +202,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
     const int drow = 8 * w + dr;
     // per-lane byte offset of a request = drow2 * (row stride of the matrix) + swz16: one multiply-add where it is needed
     // (two precomputed offsets selected by the piece type became a scratch array)
-    const unsigned drow2 = (unsigned)(2 * drow), swz16 = (unsigned)((dp ^ mlp_swz(drow)) * 16);
+    const unsigned drow2_ = (unsigned)(2 * drow), swz16_ = (unsigned)((dp ^ mlp_swz(drow)) * 16);
     int slot_i = 0, slot_c = 0, pos_i = 0; // ring slots of the next request / consumption, stream position of the next request
     // stream of a row tile (NP pieces): [PROJ: Pp(0)a Pp(0)b ... Pp(KC-1)a Pp(KC-1)b |] P1(0)a P1(0)b | P1(1)a P1(1)b P2(0)a P2(0)b | ... | P2(NC-1)a P2(NC-1)b
     // A request is PREPARED once (scalar state: where the piece starts, its two strides, its ring slot) and its KT
@@ -215,6 +215,9 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
     char* req_lds = nullptr;
     auto issue_prepare = [&]() __attribute__((always_inline)) {
         int is_p2 = 0, chunk = 0, half = 0, pi = pos_i;
+        // (opaque: with the stream positions of a ring_seek known at compile time the optimiser otherwise precomputes every
+        // request's per-lane address outside the tile loop - 2 x 24 64-bit values that it then keeps in scratch)
+        const unsigned drow2 = (unsigned)opaque_vgpr((int)drow2_), swz16 = (unsigned)opaque_vgpr((int)swz16_);
         bool is_pp = false;
         if constexpr (PROJ) {
             if (pi < NPP) is_pp = true;
@@ -278,27 +281,14 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
             for (int i = 0; i < KT; ++i) issue_one(i);
         }
     };
-    // PROJ: the stream jumps to position `pos` of a row tile (a DropPath-dropped branch is not multiplied: its pieces are
-    // skipped).  Called by all four waves between two pieces: every request has landed, nobody reads a slot any more, the ring
-    // starts over as at kernel entry.
-    auto ring_seek = [&](int pos) __attribute__((always_inline)) {
-        glds_wait_all();
-        lds_barrier();
-        pos_i = pos;
-        slot_i = 0;
-        slot_c = 0;
-        ring_fill();
-    };
     ring_fill();
 
     // ---- fragment read offsets inside a piece (one register per k-step; tiles / k-tiles are immediate offsets)
     const int prow = (lq & 19) | ((lq & 4) << 1) | ((lq & 8) >> 1);      // bits 2 and 3 of the row index swapped
-    unsigned off1[4], off2[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        off1[kk] = (unsigned)(prow * 128 + (((2 * kk + hf) ^ mlp_swz(prow)) * 16));
-        off2[kk] = (unsigned)(lq * 128 + (((2 * kk + hf) ^ mlp_swz(lq)) * 16));
-    }
+    // offset of k-step kk = off[0] ^ (kk << 5): 2 kk sits in bits 1-2 of the 16-byte slot index, the swizzle is an XOR on the same
+    // bits (gemm256.h's form) - ONE register per image kind lives across the main loop instead of four
+    const unsigned off1_0 = (unsigned)(prow * 128 + ((hf ^ mlp_swz(prow)) * 16));
+    const unsigned off2_0 = (unsigned)(lq * 128 + ((hf ^ mlp_swz(lq)) * 16));
     const float inv_e = 1.0f / (float)E;
     // global traffic of the row tiles goes through buffer descriptors: one per-lane offset register per tensor, the tile /
     // column part of every address in SGPRs, and rows beyond M cost no predicate (loads return 0, stores are dropped)
@@ -311,7 +301,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
     const buf_rsrc rs_u = make_rsrc(STORE_U ? p.u : nullptr, STORE_U ? (unsigned)((((long)p.M - 1) * p.ldu + p.H) * 2) : 0u);
     const bool store_g = STORE_U && p.gact != nullptr;
     const buf_rsrc rs_ga = make_rsrc(store_g ? p.gact : nullptr, store_g ? (unsigned)((((long)p.M - 1) * p.ldga + p.H) * 2) : 0u);
-    const bool keep_mid = PROJ && p.xmid != nullptr;     // x_mid, y2 and their statistics are written (the student)
+    constexpr bool keep_mid = PROJ && STORE_U;           // x_mid, y2 and their statistics are written with u (the host checks: all or none)
     // per-lane offsets of the row-tile traffic are recomputed from the lane id where they are used (LaneOff below): kept in
     // registers across the main loop they were the first values the allocator spilled, and a scratch reload in front of
     // every store (s_waitcnt vmcnt(0)!) serialised the whole epilogue
@@ -336,17 +326,18 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
         // tile's stores drained before the tile's own rows are even requested.  A tile that spans samples reads its per-row
         // scale where it is used, in the epilogue.
         float sc_tile = 1.0f, sc1_tile = 1.0f;
-        bool tile_dead = false, dead1 = false;
+        bool tile_dead = false;
         const bool one_sample = p.rows_per_sample % MLP_BM == 0;
         if (p.rowscale && one_sample) {
             sc_tile = scalar_load_f32(uniform_ptr(p.rowscale + uniform_i32(m0 / p.rows_per_sample)));
             tile_dead = sc_tile == 0.0f;
         }
         if constexpr (PROJ) {
-            if (p.rowscale1) {                 // (the host guarantees one_sample whenever PROJ comes with a scale)
-                sc1_tile = scalar_load_f32(uniform_ptr(p.rowscale1 + uniform_i32(m0 / p.rows_per_sample)));
-                dead1 = sc1_tile == 0.0f;
-            }
+            // (the host guarantees one_sample whenever PROJ comes with a scale.)  A dropped branch is NOT skipped here: its products run
+            // and are discarded - scale 0 for the projection; for the MLP branch x_mid is read back at the end - so that the common
+            // path has no branches around the ring (with ring seeks over the dropped pieces the register allocator moved a third
+            // of the accumulators through scratch at every join: 227 spilled registers).  Dropped tiles are ~5 % of the student's.
+            if (p.rowscale1) sc1_tile = scalar_load_f32(uniform_ptr(p.rowscale1 + uniform_i32(m0 / p.rows_per_sample)));
         }
         // x_out = x, y_next = LayerNorm(x) for this wave's 32 rows: half a wave per row, row sums by shuffles (as gemm_row384.h's epilogue)
         auto dead_rows = [&](const buf_rsrc& rs_dst, long ld_dst, const float* ga_, const float* be_, bf16_t* yp, long ldyp,
@@ -405,13 +396,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                 }
             }
         };
-        if (tile_dead && (!PROJ || dead1)) {       // nothing of this tile is multiplied (PROJ: both branches dropped; the ring stays at the tile's start)
-            if constexpr (PROJ) {
-                if (keep_mid) {
-                    const buf_rsrc rs_xm = make_rsrc(p.xmid, (unsigned)((((long)p.M - 1) * p.ldxm + E) * 4));
-                    dead_rows(rs_xm, p.ldxm, vga2, vbe2, p.y2, p.ldy2, p.mean2, p.rstd2);
-                }
-            }
+        if (!PROJ && tile_dead) {
             dead_rows(rs_o, p.ldc, vga, vbe, p.ln_y, p.ld_y, p.ln_mean, p.ln_rstd);
             zero_u();
             continue;
@@ -428,17 +413,21 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
             for (int j = 0; j < KJ; ++j) yf[j] = __builtin_bit_cast(bf16x8, stream_load16<NT_MLP_Y>(rs_y, lo_y, so + 32 * j));
         };
         // ---- row passes over the accumulators (rows are complete inside their two lanes: lane, lane ^ 32).
-        // Pass A: v = x + (acc + bias) * sc (WITH_X: the residual rows stream in two tiles ahead of their use) or v = acc * sc, written
+        // Pass A: v = x + (acc + bias) * sc (the residual rows stream in two tiles ahead of their use), v = acc * sc or v = x, written
         // back into the accumulators, LayerNorm statistics on the way.
         float mean = 0.f, rstd = 0.f;
-        auto pass_a = [&](auto WITH_X, const float* vbias, float sc) __attribute__((always_inline)) {
+        auto pass_a = [&](auto MODE, const buf_rsrc& rs_src, long ld_src, const float* vbias, float sc) __attribute__((always_inline)) {
+            constexpr int mode = decltype(MODE)::value;      // 0: v = acc * sc;  1: v = x + (acc + bias) * sc;  2: v = x (read past the L1)
             float s1 = 0.f, s2 = 0.f;
-            if constexpr (decltype(WITH_X)::value) {
-                const unsigned so = (unsigned)r0 * (unsigned)(p.ldr * 4), lo_x = LaneOff(t).frag(p.ldr, 4, 4);
+            if constexpr (mode != 0) {
+                const unsigned so = (unsigned)r0 * (unsigned)(ld_src * 4), lo_x = LaneOff(t).frag(ld_src, 4, 4);
                 u32x4 xb[3][4];
                 auto load_x = [&](int nt) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) xb[nt % 3][g] = stream_load16<NT_MLP_X>(rs_x, lo_x, so + (32 * nt + 8 * g) * 4);
+                    for (int g = 0; g < 4; ++g) {
+                        if constexpr (mode == 2) xb[nt % 3][g] = buf_load16_coherent(rs_src, lo_x, so + (32 * nt + 8 * g) * 4);
+                        else xb[nt % 3][g] = stream_load16<NT_MLP_X>(rs_src, lo_x, so + (32 * nt + 8 * g) * 4);
+                    }
                 };
                 load_x(0);
                 if (NT > 1) load_x(1);
@@ -452,7 +441,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                         const float xx[4] = {x.x, x.y, x.z, x.w}, bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float v = xx[e] + (acc[nt][4 * g + e] + bb[e]) * sc;
+                            const float v = mode == 2 ? xx[e] : xx[e] + (acc[nt][4 * g + e] + bb[e]) * sc;
                             acc[nt][4 * g + e] = v;
                             s1 += v;
                             s2 = fmaf(v, v, s2);
@@ -551,7 +540,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
         auto p2_piece = [&](auto HH, const bf16x8& b0, const bf16x8& b1, const bf16x8& b2, const bf16x8& b3) __attribute__((always_inline)) {
             constexpr int hh = decltype(HH)::value;
             const unsigned sb = acquire();
-            const unsigned areg[4] = {sb + off2[0], sb + off2[1], sb + off2[2], sb + off2[3]};
+            const unsigned a0_ = sb + off2_0, areg[4] = {a0_, a0_ ^ 32u, a0_ ^ 64u, a0_ ^ 96u};
             mlp_product<4 * NTH, DEPTH, MlpMapP2<NTH>, MlpNoExtra>(
                 areg,
                 [&](auto K, const bf16x8& a) {
@@ -562,23 +551,22 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                 [&](auto K) { dma_slot(K, std::integral_constant<int, 4 * NTH>{}); });
         };
         float sc_fin = 1.0f;                // what the accumulators are multiplied by at the end (PROJ)
-        bool run_mlp = true;
         if constexpr (PROJ) {
             // ---- the attention branch's tail: acc = a . Wp^T, then x_mid = x + (acc + bp) * sc1 and its LayerNorm
-            if (!dead1) {
-                load_rows();
-                MLP_STAMP(0)
-                mlp_static_for<0, KC>([&](auto KCI) {
-                    constexpr int kc = decltype(KCI)::value;
-                    p2_piece(I0{}, yf[4 * kc], yf[4 * kc + 1], yf[4 * kc + 2], yf[4 * kc + 3]);
-                    p2_piece(I1{}, yf[4 * kc], yf[4 * kc + 1], yf[4 * kc + 2], yf[4 * kc + 3]);
-                });
-                MLP_STAMP(6)
-            } else {
-                ring_seek(NPP);            // (the MLP branch is live, or the tile would have been skipped above)
-            }
-            pass_a(Yes{}, vbp, sc1_tile);
-            if (keep_mid) {
+            load_rows();
+            MLP_STAMP(0)
+            mlp_static_for<0, KC>([&](auto KCI) {
+                constexpr int kc = decltype(KCI)::value;
+                p2_piece(I0{}, yf[4 * kc], yf[4 * kc + 1], yf[4 * kc + 2], yf[4 * kc + 3]);
+                p2_piece(I1{}, yf[4 * kc], yf[4 * kc + 1], yf[4 * kc + 2], yf[4 * kc + 3]);
+            });
+            MLP_STAMP(6)
+            pass_a(std::integral_constant<int, 1>{}, rs_x, p.ldr, vbp, sc1_tile);
+            // the second product accumulates ON x_mid: acc = x_mid / sc2 + b2, x_out = acc * sc2 (a dropped MLP branch, sc2 = 0: the
+            // products run on whatever and x_mid is read back at the end)
+            sc_fin = tile_dead ? 1.0f : sc_tile;
+            const float inv2 = 1.0f / sc_fin;
+            if constexpr (keep_mid) {
                 const buf_rsrc rs_xm = make_rsrc(p.xmid, (unsigned)((((long)p.M - 1) * p.ldxm + E) * 4));
                 const buf_rsrc rs_y2 = make_rsrc(p.y2, (unsigned)((((long)p.M - 1) * p.ldy2 + E) * 2));
                 pass_b(Yes{}, Yes{}, rs_xm, p.ldxm, rs_y2, p.ldy2, vga2, vbe2, p.mean2, p.rstd2);
@@ -586,29 +574,24 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                 pass_b(No{}, Yes{}, rs_o, p.ldc, rs_n, p.ld_y, vga2, vbe2, p.mean2, p.rstd2);
             }
             MLP_STAMP(7)
-            if (tile_dead) {               // the MLP branch is dropped: x_out = x_mid; its pieces (in flight behind the projection's) are skipped
-                ring_seek(0);
-                zero_u();
-                run_mlp = false;
-            } else {
-                // the second product accumulates ON x_mid: acc = x_mid / sc2 + b2, x_out = acc * sc2
-                const float inv2 = 1.0f / sc_tile;
-                sc_fin = sc_tile;
+            // (one 32-column tile at a time: left to itself the scheduler reads all 192 accumulators into registers before it writes
+            // the first one back, on top of the 96 operand registers just built)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4v b = *reinterpret_cast<const f32x4v*>(vb2 + 32 * nt + 8 * g + 4 * hf);
-                        acc[nt][4 * g] = fmaf(acc[nt][4 * g], inv2, b.x);
-                        acc[nt][4 * g + 1] = fmaf(acc[nt][4 * g + 1], inv2, b.y);
-                        acc[nt][4 * g + 2] = fmaf(acc[nt][4 * g + 2], inv2, b.z);
-                        acc[nt][4 * g + 3] = fmaf(acc[nt][4 * g + 3], inv2, b.w);
-                    }
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4v b = *reinterpret_cast<const f32x4v*>(vb2 + 32 * nt + 8 * g + 4 * hf);
+                    acc[nt][4 * g] = fmaf(acc[nt][4 * g], inv2, b.x);
+                    acc[nt][4 * g + 1] = fmaf(acc[nt][4 * g + 1], inv2, b.y);
+                    acc[nt][4 * g + 2] = fmaf(acc[nt][4 * g + 2], inv2, b.z);
+                    acc[nt][4 * g + 3] = fmaf(acc[nt][4 * g + 3], inv2, b.w);
+                }
+                CCD_SCHED_FENCE();
             }
         } else {
             load_rows();
         }
-        if (run_mlp) {
+        {
             f32x16 h[2];                   // H^T of the chunk being produced: 2 tiles of [32 hidden][32 rows]
             u32x4 hbw[4];                  // gelu(H) of the chunk being consumed, as packed bf16 B operands (k-step s = hbw[s])
             const unsigned lut_addr = lds_addr_of(lut) - 4u * MLP_LUT_LO;       // byte address of entry "magnitude 0"
@@ -616,7 +599,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                 constexpr int kh = decltype(KH)::value;
                 using Extra = decltype(extra);
                 const unsigned sb = acquire();
-                const unsigned areg[4] = {sb + off1[0], sb + off1[1], sb + off1[2], sb + off1[3]};
+                const unsigned a0_ = sb + off1_0, areg[4] = {a0_, a0_ ^ 32u, a0_ ^ 64u, a0_ ^ 96u};
                 if constexpr (kh == 0) {
                     // the accumulators start at the bias: register r of tile tt is hidden unit 32 tt + 16 (r >> 3) + 8 hf +
                     // (r & 7) for every row (column of H^T).  Read here, with the LDS queue empty, not between the MFMAs.
@@ -746,10 +729,17 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
         }
         // ---- epilogue: x_out into the accumulators + statistics, then x_out and y_next leave
         if constexpr (PROJ) {
-            pass_a(No{}, vb2, sc_fin);
+            if (tile_dead) {                // (rare) x_out = x_mid exactly: this wave's own rows, written ~100 us ago, read past the L1
+                if constexpr (keep_mid) {
+                    const buf_rsrc rs_xm = make_rsrc(p.xmid, (unsigned)((((long)p.M - 1) * p.ldxm + E) * 4));
+                    pass_a(std::integral_constant<int, 2>{}, rs_xm, p.ldxm, vb2, 1.0f);
+                }
+            } else {
+                pass_a(std::integral_constant<int, 0>{}, rs_x, p.ldr, vb2, sc_fin);
+            }
         } else {
             const float sc = (p.rowscale && !one_sample) ? p.rowscale[grow / p.rows_per_sample] : sc_tile;
-            pass_a(Yes{}, vb2, sc);
+            pass_a(std::integral_constant<int, 1>{}, rs_x, p.ldr, vb2, sc);
         }
         pass_b(Yes{}, No{}, rs_o, p.ldc, rs_n, p.ld_y, vga, vbe, p.ln_mean, p.ln_rstd);
         MLP_STAMP(7)

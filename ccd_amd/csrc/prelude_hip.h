@@ -121,6 +121,10 @@ __device__ __forceinline__ const float* uniform_ptr(const float* p) {
 __device__ __forceinline__ buf_u32x4 buf_load16_nt(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_offset, (int)uniform_offset, 2);
 }
+// system-coherent read (aux bit 0, "sc0"/glc): past the CU's vector L1 - data this kernel itself wrote earlier
+__device__ __forceinline__ buf_u32x4 buf_load16_coherent(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_offset, (int)uniform_offset, 1);
+}
 __device__ __forceinline__ void buf_store16_nt(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset, buf_u32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)lane_offset, (int)uniform_offset, 2);
     buf_store_data_hold(v);

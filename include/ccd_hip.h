@@ -107,9 +107,11 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
  *     out   = x_mid + rowscale2[row / rps] * (gelu(y2 . W1^T + b1) . W2^T + b2);   ln_y = LayerNorm(out) * ln_gamma + ln_beta
  * x_mid never leaves the accumulator registers and y2 never leaves the operand registers: a forward pass that keeps nothing
  * (xmid = y2 = mean2 = rstd2 = u = NULL: the teacher) reads a and resid and writes out and ln_y - 604 MB per 131 072 rows instead
- * of the 1 208 MB of ccd_gemm_nt_resid_ln + ccd_mlp_fused.  With xmid / y2 / mean2 / rstd2 (all four or none) and u the tensors
+ * of the 1 208 MB of ccd_gemm_nt_resid_ln + ccd_mlp_fused.  With xmid / y2 / mean2 / rstd2 / u (all five or none) the tensors
  * the backward pass needs are written on the way.  E in {128, 256, 384}; with a DropPath scale rows_per_sample % 128 == 0
- * (CCD_ESHAPE otherwise: the caller takes the two separate launches).  Replaces ccd_gemm_nt_resid_ln + ccd_mlp_fused. */
+ * (CCD_ESHAPE otherwise: the caller takes the two separate launches); rowscale2 needs xmid (a dropped MLP branch still runs its
+ * products - no branch around the weight ring - and reads x_mid back: out == x_mid exactly, u holds the real pre-activation).
+ * Replaces ccd_gemm_nt_resid_ln + ccd_mlp_fused. */
 int ccd_proj_mlp_fused(const ccd_bf16* a, long lda, const ccd_bf16* wp, long ldp, const float* bp, const float* resid, long ldr,
                        const float* rowscale1, const float* ln2_gamma, const float* ln2_beta, float* xmid, long ldxm, ccd_bf16* y2,
                        long ldy2, float* mean2, float* rstd2, const ccd_bf16* w1, long ld1, const float* b1, const ccd_bf16* w2,

@@ -258,6 +258,7 @@ inline void buf_store16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offse
     if (o + 16ull <= (unsigned long long)r.bytes) std::memcpy(const_cast<char*>(r.base) + o, &v, 16);
 }
 inline buf_u32x4 buf_load16_nt(buf_rsrc r, unsigned a, unsigned b) { return buf_load16(r, a, b); }
+inline buf_u32x4 buf_load16_coherent(buf_rsrc r, unsigned a, unsigned b) { return buf_load16(r, a, b); }
 constexpr int NT_RG_A = 0, NT_RG_X = 1, NT_RG_G = 2, NT_MLP_U = 3, NT_MLP_Y = 4, NT_MLP_X = 5, NT_MLP_OUT = 6, NT_RP_A = 7, NT_RP_OUT = 8,
               NT_DGELU = 9, NT_TN = 10, NT_RG_GB = 11, NT_ATTB_OUT = 12;
 template <int B> inline buf_u32x4 stream_load16(buf_rsrc r, unsigned a, unsigned b) { return buf_load16(r, a, b); }

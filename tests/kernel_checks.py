@@ -1042,7 +1042,7 @@ def check_proj_mlp_fused(dev, M, E, H, rps=128, seed=41, save=True, drops=True):
     ga2, be2 = rnd((E,), g).abs() + 0.5, rnd((E,), g) * 0.3
     ga, be = rnd((E,), g).abs() + 0.5, rnd((E,), g) * 0.3
     for use in ((True, False) if drops else (False,)):
-        r1, r2 = (rs1, rs2) if use else (None, None)
+        r1, r2 = (rs1, rs2 if save else None) if use else (None, None)      # (a dropped MLP branch reads x_mid back: only with save)
         out, yn, mean, rstd, saved = ops.proj_mlp_fused(
             a.to(dev), wp.to(dev), bp.to(dev), resid=resid.to(dev), rowscale1=None if r1 is None else r1.to(dev), gamma2=ga2.to(dev),
             beta2=be2.to(dev), w1=w1.to(dev), b1=b1.to(dev), w2=w2.to(dev), b2=b2.to(dev), rowscale2=None if r2 is None else r2.to(dev),
@@ -1061,12 +1061,11 @@ def check_proj_mlp_fused(dev, M, E, H, rps=128, seed=41, save=True, drops=True):
             close(mean2, xmid_ref.mean(1), 1e-3, 1e-3, tag + "/mean2")
             close(rstd2, (xmid_ref.var(1, unbiased=False) + 1e-6).rsqrt(), 2e-3, 1e-4, tag + "/rstd2")
             close(y2, y2_ref, 1e-2, 2e-2, tag + "/y2")
-            u_want = u_ref.clone()
-            if r2 is not None:
-                for t0 in range(0, M, 128):
-                    if r2[t0 // rps] == 0:
-                        u_want[t0:t0 + 128] = 0            # a dropped MLP branch stores u = 0 (finite) and multiplies nothing
-            close(u, u_want, 1.6e-2, 2e-3, tag + "/u")
+            # u against the kernel's OWN y2 to a bf16 ulp (also under a dropped MLP branch: its products run and are discarded); against
+            # the reference's y2 only loosely - y2 elements that round the other way (LayerNorm arithmetic in another order) move a
+            # 384-long sum by ~1e-3 each, 0.03 at the tail of 40 000 elements
+            close(u, (y2.float().cpu() @ w1.float().t() + b1).to(BF), 8e-3, 1e-3, tag + "/u (from the stored y2)")
+            close(u, u_ref, 1.6e-2, 8e-2, tag + "/u")
         else:
             assert saved is None
         close(out, want, 2e-3, 3e-3 * max(1.0, (H / 128) ** 0.5), tag + "/out")
@@ -1077,7 +1076,7 @@ def check_proj_mlp_fused(dev, M, E, H, rps=128, seed=41, save=True, drops=True):
         if use:
             for i in range(min(ns, len(pattern))):
                 lo, hi = i * rps, min((i + 1) * rps, M)
-                if rs1[i] == 0 and rs2[i] == 0:
+                if rs1[i] == 0 and rs2[i] == 0 and save:
                     assert torch.equal(out[lo:hi].cpu(), resid[lo:hi]), "both branches dropped: the stream must pass through unchanged"
                 if rs2[i] == 0 and save:
                     assert torch.equal(out[lo:hi].cpu(), saved[0][lo:hi].cpu()), "dropped MLP branch: x_out must equal x_mid"
