@@ -311,8 +311,10 @@ int ccd_gemm_nt(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M,
     const bool f32_256 = epilogue != CCD_EPI_ATOMIC && (pol.gemm_256_f32 || N % 256 == 0);
     const bool colsum_fits = !colsum || N <= ccd::G256_MAX_COLSUM_N;      // gemm256.h keeps the column sums of every column in LDS
     // gemm256.h's gelu'(u) epilogue addresses u and both outputs with 32-bit byte offsets (buffer loads / stores)
-    const bool dgelu_fits = epilogue != CCD_EPI_DGELU || (((long)M * ldaux + N) * 2 < CCD_MAX_OPERAND_BYTES &&
-        ((long)M * ldc + N) * 2 < CCD_MAX_OPERAND_BYTES && (!C2 || ((long)M * ldc2 + N) * 2 < CCD_MAX_OPERAND_BYTES));
+    // (its row steps run up to 255 rows past M before the descriptor's range check drops them: the same margin as rowproj's check,
+    // so that step_row * ld * 2 stays below 2^31 and an out-of-range lane's BUF_OOB + offset cannot wrap back into the buffer)
+    const bool dgelu_fits = epilogue != CCD_EPI_DGELU || (((long)M + 256) * ldaux * 2 < CCD_MAX_OPERAND_BYTES &&
+        ((long)M + 256) * ldc * 2 < CCD_MAX_OPERAND_BYTES && (!C2 || ((long)M + 256) * ldc2 * 2 < CCD_MAX_OPERAND_BYTES));
     if (pol.gemm_256 >= 1 && (bf16_out || f32_256) && M >= pol.gemm_256_min_m &&
         N >= pol.gemm_256_min_n && colsum_fits && dgelu_fits) {
         if (pol.gemm_256_deep) return ccd_launch_gemm256<256, true>(p, epilogue, stream);
@@ -531,9 +533,13 @@ int ccd_gemm_tn_pair(const ccd_bf16* A1, long lda1, const ccd_bf16* B1, long ldb
     return ccd_gemm_tn_pair_ws(A1, lda1, B1, ldb1, P1, Q1, C1, ldc1, A2, lda2, B2, ldb2, P2, Q2, C2, ldc2, Mc, nullptr, 0, stream);
 }
 long ccd_gemm_tn_pair_ws_floats(int P1, int Q1, int P2, int Q2) {
-    // one plane per contraction slice and problem; a launch never has more slices than workgroup slots (one per CU)
-    const long t1 = (long)(P1 / 384) * (Q1 / 192), t2 = (long)(P2 / 384) * (Q2 / 192);
-    if (P1 % 384 || Q1 % 192 || P2 % 384 || Q2 % 192 || t1 < 1 || t2 < 1) return 0;
+    // one plane per contraction slice and problem; a launch never has more slices than workgroup slots (geometry 0: one 8-wave
+    // workgroup per CU; geometry 2 - 512 x 128 tiles, policy gemm_tn384_geom = 2 - the same).  Whatever geometry ccd_tn384_geom picks
+    // for the pair (both problems the same one), or 0 where the grouped kernel does not apply.
+    const int g1 = ccd_tn384_geom(P1, Q1, 2048), g2 = ccd_tn384_geom(P2, Q2, 2048);
+    if (g1 < 0 || g1 != g2) return 0;
+    const long t1 = ccd_tn384_tiles(g1, P1, Q1), t2 = ccd_tn384_tiles(g2, P2, Q2);
+    if (t1 < 1 || t2 < 1) return 0;
     const long cus = ccd_rt_num_cus();
     return (cus / t1 + 8) * (long)P1 * Q1 + (cus / t2 + 8) * (long)P2 * Q2;
 }

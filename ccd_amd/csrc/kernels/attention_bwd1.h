@@ -75,7 +75,7 @@ __global__ __launch_bounds__(512) void attention_bwd_onepass_kernel(const bf16_t
     };
     // kfw: this wave's k fragments - and, between a block's last score products and the next block's delta, the o rows of its 32
     // queries (index 32 w + lq); vfw: its v fragments = the v rows as they lie in memory.  One register set for both lives.
-    u32x4 kfw[4], vfw[4];
+    u32x4 kfw[4] = {}, vfw[4] = {};        // (defined: the tracked loads below take them as in-out operands)
     auto request_vo = [&](int blk) {
         const int view = blk % views, head = blk / views;
         // (one base pointer per tensor + immediate offsets, derived here from an opaque lane id: eight precomputed 64-bit addresses

@@ -89,7 +89,9 @@ __device__ __forceinline__ void vm_arrived(buf_u32x4& a) { asm volatile("s_waitc
 // kernel's own followed by vm_landed4 (no instruction: the dependency that keeps every use behind the wait)
 template <int OFF = 0>
 __device__ __forceinline__ void global_load16_late(buf_u32x4& dst, const void* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
+    // ("+v": the load writes IN PLACE - with a plain output the allocator may give the result a fresh register and copy it into the
+    // loop-carried one at the join, i.e. read it before the data has arrived)
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "+v"(dst) : "v"(p), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void vm_landed4(buf_u32x4 (&a)[4]) { asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])); }
 // "this value is needed HERE": the compiler places its wait for a load in front of the first instruction that reads the result.

@@ -267,18 +267,23 @@ def gemm_tn_colsum(a, b, out, colsum, *, splits=0):
 
 
 _TN_WS = {}
+_TN_WS_RETIRED = []      # outgrown workspaces stay allocated: a captured HIP graph (pretrain.GraphedTrainingStep) may still write to them
 
 
 def tn_pair_workspace(device, P1, Q1, P2, Q2):
-    """The split-K workspace ccd_gemm_tn_pair_ws wants for these shapes: ONE fp32 buffer per device, grown to the largest
-    request (every launch that uses it runs on the calling stream, in order).  None where the grouped kernel does not apply."""
+    """The split-K workspace ccd_gemm_tn_pair_ws wants for these shapes: ONE fp32 buffer per (device, stream), grown to the largest
+    request - launches on one stream use it in order, another stream gets its own.  A buffer that is outgrown is never freed (a graph
+    captured earlier keeps its pointer).  None where the grouped kernel does not apply."""
     n = int(_lib.get().ccd_gemm_tn_pair_ws_floats(int(P1), int(Q1), int(P2), int(Q2)))
     if n <= 0:
         return None
-    ws = _TN_WS.get(device)
+    key = (device, _lib.stream())
+    ws = _TN_WS.get(key)
     if ws is None or ws.numel() < n:
+        if ws is not None:
+            _TN_WS_RETIRED.append(ws)
         ws = torch.empty(n, dtype=torch.float32, device=device)
-        _TN_WS[device] = ws
+        _TN_WS[key] = ws
     return ws
 
 

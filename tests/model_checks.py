@@ -179,7 +179,8 @@ def check_tiny_step(device, logit_tol=3e-2, loss_tol=None, grad_rtol=6e-2, batch
             denom = np.abs(want).max() + 1e-12
             rms = np.sqrt(np.mean((got_g - want) ** 2)) / (np.sqrt(np.mean(want ** 2)) + 1e-12)
             assert rms < 0.15, f"{k}: rms rel err {rms}"
-            assert np.abs(got_g - want).max() / denom < 0.2, f"{k}: rel err {np.abs(got_g - want).max() / denom}"
+            seg_branch = k[5:].startswith(("segmentation.", "backbone.norm_seg."))      # (only these carry the looser maximum)
+            assert np.abs(got_g - want).max() / denom < (0.2 if seg_branch else 0.15), f"{k}: rel err {np.abs(got_g - want).max() / denom}"
     # post-step weights and teacher EMA
     sd = student.state_dict()
     for n, row in zip(g["post_names"], g["post_stats"]):
@@ -730,9 +731,12 @@ def check_finetune_dropout(device, B=2, n_layers=1):
     assert abs(analytic - numeric) < 0.15 * abs(numeric) + 2e-3, (analytic, numeric)
 
 
-def check_finetune_golden(device, tag="tiny", loss_tol=2e-3):
+def check_finetune_golden(device, tag="tiny", loss_tol=1e-3, report=None):
     """Product vs the REAL reference's recorded run (tests/golden/finetune_step.npz, tools/gen_golden.py): initial
-    weights, two AdamW iterations (loss, attention map, every gradient norm), then greedy decoding."""
+    weights, two AdamW iterations (loss, attention map, every gradient norm), then greedy decoding.  -> report (losses of both
+    sides, worst gradient-norm ratio per iteration) for profiles/."""
+    report = {} if report is None else report      # (filled as it goes: the caller dumps it also when a gate below fails)
+    report.update({"fixture": "finetune_step.npz/" + tag, "loss_tol": loss_tol, "steps": []})
     from ccd_amd import finetune as ft
     g = np.load(os.path.join(GOLD, "finetune_step.npz"))
     arch, n_layers, B = {"tiny": ("vit_tiny", 2, 4), "small": ("vit_small", 6, 8)}[tag]
@@ -756,6 +760,7 @@ def check_finetune_golden(device, tag="tiny", loss_tol=2e-3):
         loss, attn = model(img.to(device), targets, return_loss=True)
         opt.zero_grad()
         loss.backward()
+        report["steps"].append({"loss_hip": float(loss.item()), "loss_reference": float(loss_ref), "delta": float(loss.item() - loss_ref)})
         assert abs(loss.item() - loss_ref) < loss_tol, (step, loss.item(), loss_ref)
         am = attn.float().mean(1).cpu().numpy()
         assert np.abs(am - g[p + "attn_mean"]).max() < 2e-2 * g[p + "attn_mean"].max() + 1e-4
@@ -766,6 +771,10 @@ def check_finetune_golden(device, tag="tiny", loss_tol=2e-3):
                 assert got[2] < 1e-4, n
             else:
                 assert abs(got[2] / row[2] - 1) < 8e-2, (step, n, got[2], row[2])
+                worst = report["steps"][-1].get("worst_grad_norm_ratio", 1.0)
+                if abs(got[2] / row[2] - 1) > abs(worst - 1):
+                    report["steps"][-1]["worst_grad_norm_ratio"] = float(got[2] / row[2])
+                    report["steps"][-1]["worst_grad_tensor"] = n
         assert set(names) == {n for n, q in model.named_parameters()} - set(model.unused_parameter_names())
         opt.step()
         lr_sum = float(sum(g[f"{tag}/s{i}/loss"][1] for i in range(step + 1)))
@@ -788,6 +797,8 @@ def check_finetune_golden(device, tag="tiny", loss_tol=2e-3):
             compared += int(same_prefix.sum())
         same_prefix &= probs[:, t].argmax(-1) == ref[:, t].argmax(-1)
     assert compared >= 4 * B, compared
+    report["decoded_positions_compared"] = compared
+    return report
 
 
 def check_pretrain_arch_vs_oracle(device, arch="vit_base", B=4, out_dim=4096, loss_tol=1e-3, dims=None):

@@ -77,7 +77,13 @@ def test_smoke_entry(hip):
 @pytest.mark.parametrize("tag", ["tiny", "small"])
 def test_finetune_vs_reference(hip, tag):
     """DINO_Finetune against the real reference's recorded iterations (vit_tiny/2 layers, vit_small/6)."""
-    mc.check_finetune_golden(hip.device, tag)
+    report = {}
+    try:
+        mc.check_finetune_golden(hip.device, tag, report=report)
+    finally:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(f"gpurun_out/parity_finetune_{tag}.json", "w") as f:
+            json.dump(report, f)
 
 
 def test_finetune_vs_oracle(hip):

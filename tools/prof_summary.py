@@ -45,11 +45,23 @@ def main():
     print(f"# steady-state kernel summary: last {a.steps} iteration(s) of `{a.trace}`\n")
     print(f"wall {wall_ms / a.steps:.3f} ms/iteration, kernel-busy {busy_ms / a.steps:.3f} ms/iteration "
           f"({100 * busy_ms / wall_ms:.1f} % of wall)\n")
-    print("| kernel | calls/iter | total ms/iter | % busy | avg us | min us | max us | VGPR+AGPR | LDS B |")
+    # registers: the trace's VGPR_Count / Accum_VGPR_Count columns read 256 + 0 for a kernel that holds 512 (256 of them accumulator
+    # registers) - the code object's own metadata is what the table shows where the library is at hand (tools/codeobj_regs.py)
+    try:
+        import os
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import codeobj_regs
+        meta = codeobj_regs.load()
+    except Exception:
+        meta = {}
+    print("| kernel | calls/iter | total ms/iter | % busy | avg us | min us | max us | registers: total (accumulator) | LDS B |")
     print("|---|---|---|---|---|---|---|---|---|")
     for k, d in sorted(agg.items(), key=lambda kv: -kv[1]["ns"]):
+        m = meta.get(k)
+        regs = f"{m['vgpr']} ({m['agpr']})" if m else f"{d['vgpr']}+{d['agpr']} (trace)"
         print(f"| `{k}` | {d['calls'] / a.steps:.1f} | {d['ns'] / 1e6 / a.steps:.3f} | {100 * d['ns'] / 1e6 / busy_ms:.1f} | "
-              f"{d['ns'] / d['calls'] / 1e3:.1f} | {d['min'] / 1e3:.1f} | {d['max'] / 1e3:.1f} | {d['vgpr']}+{d['agpr']} | {d['lds']} |")
+              f"{d['ns'] / d['calls'] / 1e3:.1f} | {d['min'] / 1e3:.1f} | {d['max'] / 1e3:.1f} | {regs} | {d['lds']} |")
 
 
 if __name__ == "__main__":
