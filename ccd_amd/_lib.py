@@ -69,6 +69,7 @@ SIGNATURES = {
     "ccd_dino_loss_fwd": [P, P, P, I, P, I, F, F, P, P, P],
     "ccd_dino_loss_bwd": [P, P, P, I, P, I, F, F, P, F, P, P, P],
     "ccd_colsum_f32": [P, I, P, I, I, P, P],
+    "ccd_matvec_bf16": [P, L, P, I, I, P, P],
     "ccd_center_ema": [P, P, I, P, I, F, P],
     "ccd_seg_loss": [P, P, P, I, F, P, P, P],
     "ccd_seg_sumsq": [P, P, P, P, I, P, P],

@@ -258,7 +258,7 @@ static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, float* ws, long ws_
 
 extern "C" {
 
-int ccd_abi_version(void) { return 8; }   // 8: ccd_proj_mlp_fused (proj + residual + LayerNorm-2 in front of the fused MLP); 7: ccd_gemm_tn_pair_ws (split-K workspace instead of fp32 atomics); 6: device-side momentum / DropPath seed (HIP graph of the training step); 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
+int ccd_abi_version(void) { return 8; }   // 8: ccd_proj_mlp_fused (proj + residual + LayerNorm-2 in front of the fused MLP), ccd_matvec_bf16; 7: ccd_gemm_tn_pair_ws (split-K workspace instead of fp32 atomics); 6: device-side momentum / DropPath seed (HIP graph of the training step); 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
 const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi8"; }
 int ccd_policy_set(const char* key, int value) {
     CCD_CHECK(key, CCD_EINVAL);
@@ -922,6 +922,14 @@ int ccd_colsum_f32(const float* x, int K, const int* d_rows, int rows_mul, int m
     row_blocks = (max_rows + rpb - 1) / rpb;
     CCD_LAUNCH(ccd::colsum_f32_kernel, dim3(col_blocks, row_blocks), dim3(256), 0, stream, x, K, d_rows, rows_mul,
                max_rows, rpb, out);
+    return ccd_rt_last_error();
+}
+int ccd_matvec_bf16(const ccd_bf16* w, long ldw, const float* v, int K, int D, float* out, void* stream) {
+    CCD_CHECK(w && v && out && K > 0 && D > 0 && D % 256 == 0 && ldw % 8 == 0 && CCD_ALIGNED16(w) && CCD_ALIGNED16(v), CCD_EINVAL);
+    int blocks = (K + 7) / 8;                       // a block = 4 waves = 8 rows per trip
+    const int cap = 4 * ccd_rt_num_cus();
+    if (blocks > cap) blocks = cap;
+    CCD_LAUNCH(ccd::matvec_bf16_kernel, dim3(blocks), dim3(256), 0, stream, w, ldw, v, K, D, out);
     return ccd_rt_last_error();
 }
 int ccd_center_ema(float* center, const float* batch_sum, int K, const int* d_m, int world, float momentum,

@@ -173,6 +173,27 @@ __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict
     }
     atomicAdd(out + k, a.x); atomicAdd(out + k + 1, a.y); atomicAdd(out + k + 2, a.z); atomicAdd(out + k + 3, a.w);
 }
+// out[k] += sum_d w[k, d] * v[d]   (w [K, D] bf16 row-major, D % 256 == 0, v fp32): the batch centre WITHOUT a pass over the teacher
+// logits - their column sums are a matrix-vector product, sum_r (zn[r, :] . w[k, :]) = (sum_r zn[r, :]) . w[k, :] (Dino_loss.py:136:
+// torch.sum(teacher_output, dim=0) of teacher_output = zn @ w^T).  Half a wave per row: 32 lanes x 8 elements per 256-wide step.
+__global__ __launch_bounds__(256) void matvec_bf16_kernel(const bf16_t* __restrict__ w, long ldw, const float* __restrict__ v, int K, int D,
+                                                          float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, hf = lane >> 5, lq = lane & 31;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (int k = 2 * wave + hf; k < K; k += 2 * nwaves) {
+        float acc = 0.f;
+        for (int d0 = 0; d0 < D; d0 += 256) {
+            const u32x4 pk = *reinterpret_cast<const u32x4*>(w + (long)k * ldw + d0 + 8 * lq);
+            const f32x4v v0 = *reinterpret_cast<const f32x4v*>(v + d0 + 8 * lq), v1 = *reinterpret_cast<const f32x4v*>(v + d0 + 8 * lq + 4);
+            float x[8];
+            unpack8(pk, x);
+            acc += (x[0] * v0.x + x[1] * v0.y) + (x[2] * v0.z + x[3] * v0.w) + (x[4] * v1.x + x[5] * v1.y) + (x[6] * v1.z + x[7] * v1.w);
+        }
+#pragma unroll
+        for (int msk = 16; msk >= 1; msk >>= 1) acc += shfl_xor(acc, msk);
+        if (lq == 0) out[k] += acc;
+    }
+}
 // center = center*momentum + (batch_sum / (2M * world)) * (1 - momentum)        Dino_loss.py:140-143
 __global__ void center_ema_kernel(float* __restrict__ center, const float* __restrict__ batch_sum, int K,
                                   const int* __restrict__ d_m, int world, float momentum) {

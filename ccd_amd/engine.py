@@ -520,8 +520,30 @@ def head_forward(arena, pre, rows, d_total, save, rows_mul=2):
     ops.weightnorm_fwd(v, gw, w, w_t, winv)
     logits = torch.empty((rows.shape[0], K), dtype=F32, device=dev)
     ops.gemm_nt(zn, w, epilogue=ops.EPI_F32, out=logits, m_fastest=1, **dyn)
+    if not save:
+        # the factors of a pass that keeps nothing (the teacher): DINOLoss.update_center takes the logits' column sums from them - a
+        # matrix-vector product over w instead of a pass over the [rows, K] logits.  ONE slot: whatever an earlier pass left is dropped.
+        _LOGIT_FACTORS.clear()
+        if D % 256 == 0:
+            _LOGIT_FACTORS[logits.data_ptr()] = (zn, w)
     saved = (rows, u0, a0, u1, a1, z, zn, inv, w_t, winv) if save else None
     return logits, saved
+
+
+_LOGIT_FACTORS = {}      # logits buffer address -> (zn bf16 [rows, D], w bf16 [K, D]) with logits = zn @ w^T (see head_forward)
+
+
+def logit_column_sums(logits, d_total, out, rows_mul=2):
+    """out[k] += sum over the first rows_mul * d_total[0] rows of logits[:, k] - through the factors head_forward parked for this
+    buffer when it has them (colsum of zn, then w . that), by a pass over the logits otherwise."""
+    fac = _LOGIT_FACTORS.pop(logits.data_ptr(), None)
+    if fac is None or fac[0].shape[0] != logits.shape[0]:
+        ops.colsum_f32(logits, out, d_rows=d_total, rows_mul=rows_mul)
+        return out
+    zn, w = fac
+    zsum = torch.zeros(zn.shape[1], dtype=F32, device=zn.device)
+    ops.colsum_bf16(zn, zsum, d_rows=d_total, rows_mul=rows_mul)
+    return ops.matvec_bf16(w, zsum, out)
 
 
 def head_backward(arena, pre, saved, d_logits, d_total, last_layer_trainable_g, rows_mul=2):

@@ -61,7 +61,7 @@ class DINOLoss(nn.Module):
         if d_total is None:
             d_total = torch.full((1,), teacher_logits.shape[0] // 2, dtype=torch.int32, device=teacher_logits.device)
         batch_sum = torch.zeros(self.center.shape[1], dtype=torch.float32, device=teacher_logits.device)
-        ops.colsum_f32(teacher_logits, batch_sum, d_rows=d_total, rows_mul=2)
+        engine.logit_column_sums(teacher_logits, d_total, batch_sum, rows_mul=2)      # (a matrix-vector product where the head left its factors)
         world = 1
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(batch_sum)

@@ -610,6 +610,15 @@ def colsum_f32(x, out, d_rows=None, rows_mul=1):
     _call("ccd_colsum_f32", _lib.ptr(x), K, _lib.ptr(d_rows), rows_mul, max_rows, _lib.ptr(out))
 
 
+def matvec_bf16(w, v, out):
+    """out[k] += w[k, :] . v   (w [K, D] bf16, v / out fp32; D % 256 == 0)."""
+    _chk(w, BF16, "w"); _chk(v, F32, "v"); _chk(out, F32, "out")
+    K, D = w.shape
+    assert v.numel() == D and out.numel() == K
+    _call("ccd_matvec_bf16", _lib.ptr(w), w.stride(0), _lib.ptr(v), K, D, _lib.ptr(out))
+    return out
+
+
 def center_ema(center, batch_sum, d_m, world, momentum):
     _call("ccd_center_ema", _lib.ptr(center), _lib.ptr(batch_sum), center.numel(), _lib.ptr(d_m), int(world),
           float(momentum))

@@ -271,6 +271,10 @@ int ccd_dino_loss_bwd(const float* s_logits, const float* t_logits, const float*
                       const float* d_grad_scale /* optional device scalar, multiplied in */, ccd_bf16* d_logits,
                       void* stream);
 int ccd_colsum_f32(const float* x, int K, const int* d_rows, int rows_mul, int max_rows, float* out, void* stream);
+/* out[k] += sum_d w[k, d] * v[d]  (w [K, D] bf16, D % 256 == 0, v and out fp32).  The teacher centre of Dino_loss.py:133-143 without a
+ * pass over the [2M, K] teacher logits: their column sums are (sum of the rows of zn) . W^T - ccd_colsum_bf16 of the l2-normalised
+ * bottleneck rows, then this product against the weight-normed last layer (33 MB read instead of 865). */
+int ccd_matvec_bf16(const ccd_bf16* w, long ldw, const float* v, int K, int D, float* out, void* stream);
 int ccd_center_ema(float* center, const float* batch_sum, int K, const int* d_m, int world, float momentum,
                    void* stream);
 /* softmax -> cross_entropy (double softmax) of the seg logits [2*half,2,32,128]; d_logits may be NULL */

@@ -1068,11 +1068,20 @@ def check_proj_mlp_fused(dev, M, E, H, rps=128, seed=41, save=True, drops=True):
             close(u, u_ref, 1.6e-2, 8e-2, tag + "/u")
         else:
             assert saved is None
-        close(out, want, 2e-3, 3e-3 * max(1.0, (H / 128) ** 0.5), tag + "/out")
+        # Against a chain with an INDEPENDENT LayerNorm-2: y2 elements that round the other way (a few per cent of them, the sum
+        # order of the statistics differs) move a hidden row, and through gelu' . w2 the output by ~4e-4 each - 7e-3 at the tail of
+        # 10^5 elements.  The tight comparison is the one on the kernel's own y2 (save=True) below.
+        loose = 1.2e-2 * max(1.0, (H / 128) ** 0.5)
+        close(out, want, 2e-3, loose, tag + "/out")
+        if save:
+            xm_k, y2_k = saved[0].float().cpu(), saved[1].float().cpu()
+            u_k = (y2_k @ w1.float().t() + b1).to(BF)
+            h_k = F.gelu(u_k.float()).to(BF).float()
+            close(out, xm_k + (h_k @ w2.float().t() + b2) * s2, 2e-3, 3e-3 * max(1.0, (H / 128) ** 0.5), tag + "/out (from the stored x_mid, y2)")
         mu, var = want.mean(1), want.var(1, unbiased=False)
         close(mean, mu, 1e-3, 1e-3, tag + "/mean")
         close(rstd, (var + 1e-6).rsqrt(), 2e-3, 1e-4, tag + "/rstd")
-        close(yn, F.layer_norm(want, (E,), ga, be, 1e-6), 1e-2, 2e-2, tag + "/y")
+        close(yn, F.layer_norm(want, (E,), ga, be, 1e-6), 1e-2, 3e-2, tag + "/y")
         if use:
             for i in range(min(ns, len(pattern))):
                 lo, hi = i * rps, min((i + 1) * rps, M)
@@ -1086,7 +1095,25 @@ def check_proj_mlp_fused(dev, M, E, H, rps=128, seed=41, save=True, drops=True):
                                                  beta=be2.to(dev), eps=1e-6)
         o3 = ops.mlp_fused(y2b, w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), resid=o2, rowscale=None if r2 is None else r2.to(dev),
                            rows_per_sample=rps, gamma=ga.to(dev), beta=be.to(dev), eps=1e-6, store_u=False)
-        close(out, o3[0].float().cpu(), 2e-3, 3e-3 * max(1.0, (H / 128) ** 0.5), tag + "/out vs the two launches")
+        close(out, o3[0].float().cpu(), 2e-3, loose, tag + "/out vs the two launches")
+
+
+def check_matvec_bf16(dev, K=1000, D=256, seed=51):
+    """out += w . v, and what it is for: the column sums of logits = zn @ w^T without the logits (the teacher centre)."""
+    g = torch.Generator().manual_seed(seed)
+    w = rnd((K, D), g, 0.1).to(BF)
+    v = rnd((D,), g)
+    out0 = rnd((K,), g)
+    out = ops.matvec_bf16(w.to(dev), v.to(dev), out0.clone().to(dev))
+    close(out, out0 + w.float() @ v, 1e-5, 1e-4, "matvec_bf16")
+    rows = 37
+    zn = rnd((rows + 5, D), g, 0.06).to(BF)
+    d_rows = torch.tensor([rows // 2 + 1], dtype=torch.int32)            # rows_mul * d_rows = 38 > 37 live rows is clamped by the caller's buffer
+    live = min(2 * int(d_rows[0]), zn.shape[0])
+    zsum = ops.colsum_bf16(zn.to(dev), torch.zeros(D, device=dev), d_rows=d_rows.to(dev), rows_mul=2)
+    cs = ops.matvec_bf16(w.to(dev), zsum, torch.zeros(K, device=dev))
+    logits = zn.float()[:live] @ w.float().t()
+    close(cs, logits.sum(0), 1e-4, 1e-4, "column sums of zn @ w^T through the factors")
 
 
 def check_gemm_lnbwd(dev, M, N, K, seed=33):

@@ -262,6 +262,11 @@ def test_proj_mlp_fused(hip, M, E, H, rps):
         kc.check_proj_mlp_fused(hip.device, M=256, E=384, H=128, rps=8)
 
 
+def test_matvec_bf16(hip):
+    kc.check_matvec_bf16(hip.device)
+    kc.check_matvec_bf16(hip.device, K=65536, D=256, seed=53)
+
+
 def test_proj_mlp_fused_repeatable(hip):
     import torch
     from ccd_amd import ops

@@ -276,6 +276,11 @@ def test_decoder_abi_rejects_unsupported_arguments(sim):
     assert ops.dropout(torch.zeros(0), 0.1, 1).numel() == 0
 
 
+def test_matvec_bf16_sim(sim):
+    kc.check_matvec_bf16(sim.device)
+    kc.check_matvec_bf16(sim.device, K=70, D=512, seed=52)
+
+
 def test_proj_mlp_fused_sim(sim):
     """mlp_fused.h with the projection + residual + LayerNorm-2 prologue (PROJ): ring seeks over dropped branches, both epilogues,
     several tiles per workgroup (1 CU), with and without the tensors saved for the backward pass."""

@@ -368,12 +368,14 @@ def gen_small():
 
 def gen_small_noise():
     """How far does the REFERENCE's own iteration-1 loss of small_step.npz move when only its summation order changes?  The same two
-    iterations as gen_small (state: seed 0 + the fixture's fitted segmentation classifier) under 1 / 2 / 4 / 8 intra-op threads -
+    iterations as the committed small_step.npz (its starting state: iteration 0 reproduces the recorded losses) under 1 / 2 / 4 / 8 intra-op threads -
     oneDNN / ATen split their reductions by thread count.  At iteration 0 the head biases are exactly zero, the all-zero pooled row
     of every image reaches F.normalize as an exact zero vector, and its backward multiplies fp32 rounding residue by 1 / eps: the
     first update of three head-bias tensors is amplified noise, and every later loss inherits it.  The spread
     recorded here is the band tests/model_checks.py::check_small_steps allows between the HIP path and the recorded reference at
-    iteration 1 (it was a chosen 2e-2 before)."""
+    iteration 1 (it was a chosen 2e-2 before).  Thread counts turned out NOT to move it (the residue comes from row-wise softmax
+    arithmetic, which is not split across threads); permuting the K output units of the last layer - the same permutation in both
+    networks, an exact symmetry of the loss - does: it changes the order of every sum over k."""
     import json
     ensure_pg()
     from Dino.modules import utils as rutils
@@ -381,18 +383,36 @@ def gen_small_noise():
     B, K = 8, 65536
     g = np.load(os.path.join(GOLD, "small_step.npz"))
     runs = []
-    for threads in (1, 2, 4, 8):
+    # (threads, permutation seed): a permutation of the K output units of the last layer - the same one for student and teacher - is
+    # an exact symmetry of the loss (softmax, centre and cross entropy are sums over k); it only changes the ORDER of those sums
+    # ... and, last, the loss's log_softmax evaluated in float64 (this harness swaps the function the reference's loss module calls;
+    # nothing of the reference changes): the residue is exp(log_softmax(0)) - softmax(0) = -2.3e-12 per logit of an exactly-uniform
+    # row - a property of THIS platform's fp32 expf / logf, the same for every k, hence independent of any summation order - and in
+    # float64 it is ~1e-17: the amplified head-bias gradients vanish and iteration 1 lands where an exact implementation lands
+    import torch.nn.functional as tF
+    fp32_log_softmax = tF.log_softmax
+    for threads, perm_seed, ls64 in ((1, None, False), (2, None, False), (4, None, False), (8, None, False), (8, 1, False), (8, 2, False),
+                                     (8, 3, False), (8, None, True)):
+        tF.log_softmax = (lambda x, dim=None, **kw: fp32_log_softmax(x.double(), dim=dim).to(x.dtype)) if ls64 else fp32_log_softmax
         torch.set_num_threads(threads)
         student, teacher = build_reference_pair(dict(arch="vit_small"), dict(out_dim=K), 384, seed=0, drop_path_rate=0.0, tiny=False)
-        with torch.no_grad():
-            student.segmentation.cls.weight.copy_(torch.from_numpy(g["cls_weight"]))
-            student.segmentation.cls.bias.copy_(torch.from_numpy(g["cls_bias"]))
+        if perm_seed is not None:
+            perm = torch.randperm(K, generator=torch.Generator().manual_seed(perm_seed))
+            with torch.no_grad():
+                for net in (student, teacher):
+                    for name in ("weight_v", "weight_g"):
+                        t = getattr(net.head.last_layer, name)
+                        t.copy_(t[perm].clone())
+        if "cls_weight" in g.files:        # (the committed small_step.npz starts from the plain seed-0 state: iteration 0 below must
+            with torch.no_grad():          # reproduce its recorded losses, which is checked)
+                student.segmentation.cls.weight.copy_(torch.from_numpy(g["cls_weight"]))
+                student.segmentation.cls.bias.copy_(torch.from_numpy(g["cls_bias"]))
         dino_loss = DINOLoss(K, 2, 0.04, 0.04, 0, 40)
         optimizer = torch.optim.AdamW(rutils.get_params_groups(student))
         lr_s = rutils.cosine_iter_scheduler(0.0005 * B / 256.0, 1e-6, 50, warmup_iters=10)
         wd_s = rutils.cosine_iter_scheduler(0.04, 0.4, 50)
         mom_s = rutils.cosine_iter_scheduler(0.9995, 1, 50)
-        row = {"threads": threads}
+        row = {"threads": threads, "output_permutation_seed": perm_seed, "loss_log_softmax_in_float64": ls64}
         for step, (it, epoch, seed) in enumerate([(5, 0, 0), (6, 1, 1)]):
             rec = reference_iteration(student, teacher, dino_loss, optimizer, make_batch(B, seed=seed), epoch=epoch, lr=lr_s[it],
                                       wd=wd_s[it], mom=mom_s[it], clip=3.0, freeze_last_layer=1, record={})
@@ -400,13 +420,20 @@ def gen_small_noise():
             head_bias = [n for n in rec["grads_raw"] if n.startswith("head.mlp") and n.endswith("bias")]
             row[f"s{step}_head_bias_grad_l2"] = {n: float(rec["grads_raw"][n].float().norm()) for n in head_bias}
         print(row)
+        tF.log_softmax = fp32_log_softmax
+        assert np.abs(np.array(row["s0"]) - g["s0/losses"]).max() < 1e-4, ("not the fixture's starting state", row["s0"], g["s0/losses"])
         runs.append(row)
     torch.set_num_threads(8)
     fix = [float(x) for x in g["s1/losses"]]
-    s1 = np.array([r["s1"] for r in runs])
-    out = {"what": "reference iteration-1 losses [total, mask, dino] of small_step.npz's two iterations under 1/2/4/8 intra-op threads",
+    exact = [r for r in runs if r["loss_log_softmax_in_float64"]]
+    runs32 = [r for r in runs if not r["loss_log_softmax_in_float64"]]
+    s1 = np.array([r["s1"] for r in runs32])
+    out = {"what": "reference losses [total, mask, dino] of small_step.npz's two iterations under 1/2/4/8 intra-op threads and under "
+                   "three permutations of the last layer's 65536 output units (an exact symmetry of the loss: only summation orders change)",
            "runs": runs, "fixture_s1_losses": fix,
-           "s0_spread": (np.array([r["s0"] for r in runs]).max(0) - np.array([r["s0"] for r in runs]).min(0)).tolist(),
+           "s0_spread": (np.array([r["s0"] for r in runs32]).max(0) - np.array([r["s0"] for r in runs32]).min(0)).tolist(),
+           "s1_losses_with_float64_log_softmax": exact[0]["s1"] if exact else None,
+           "s1_shift_fp32_vs_float64_log_softmax": (np.array(exact[0]["s1"]) - s1[0]).tolist() if exact else None,
            "s1_spread": (s1.max(0) - s1.min(0)).tolist(),
            "s1_max_abs_from_fixture": np.abs(s1 - np.array(fix)).max(0).tolist()}
     with open(os.path.join(GOLD, "small_step_ref_noise.json"), "w") as f:
