@@ -36,7 +36,8 @@ SIGNATURES = {
     "ccd_gemm_tn_pair_ws": [P, L, P, L, I, I, P, L, P, L, P, L, I, I, P, L, I, P, L, P],
     "ccd_gemm_tn_pair_ws_floats": [I, I, I, I],
     "ccd_gemm_nt_lnbwd": [P, L, P, L, I, I, I, P, L, P, P, P, P, L, I, P, P, P, L, P, I, P, P],
-    "ccd_proj_mlp_fused": [P, L, P, L, P, P, L, P, P, P, P, L, P, L, P, P, P, L, P, P, L, P, P, I, P, L, P, P, F, P, L, P, P, P, L, I, I, I, P],
+    "ccd_proj_mlp_fused": [P, L, P, L, P, P, L, P, P, P, P, L, P, L, P, P, P, L, P, P, L, P, P, I, P, L, P, P, F, P, L, P, P, P, L, P, P, P, L,
+                           I, I, I, P],
     "ccd_mlp_fused": [P, L, P, L, P, P, L, P, P, L, P, I, P, L, P, P, F, P, L, P, P, P, L, P, L, I, I, I, P],
     "ccd_ln_fwd": [P, P, P, P, P, P, I, I, F, P],
     "ccd_ln_bwd": [P, P, P, P, P, P, I, P, P, P, P, I, P, I, I, P],

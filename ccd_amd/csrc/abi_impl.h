@@ -94,6 +94,7 @@ struct CcdPolicy {
     int gemm_row384 = 0;        // 1 = full-row kernel for N <= 384 residual / fp32 epilogues, 2 = bf16 too
     int rowproj = 1;            // K = 384 / 512 bf16 projections (qkv, proj data gradient) with the activation rows resident in registers (rowproj.h); 0 = gemm256.h / gemm.h
     int rowproj_min_m = 16384;  // ... from this many rows on (a workgroup tile is 256 rows: below ~64 tiles the 128-row kernels fill the chip better)
+    int rowproj_rb = 0;         // row blocks per wave at K = 384: 2 (256-row tiles), 1 (128-row tiles), 0 = 1 where 256-row tiles leave compute units idle (64 images per GPU: 32 768 rows = 128 tiles)
     int rowgemm = 1;            // row-owner kernels (rowgemm.h) for the N in {128, 256, 384} row-wise epilogues; 0 = gemm_row384.h
     int ln_bwd_bpc = 5;         // LayerNorm backward: blocks per CU (one resident wave; more blocks = more dgamma/dbeta atomics)
     int dec_attn_simt = 0;      // decoder attention: force the general SIMT kernels
@@ -115,7 +116,7 @@ static const CcdPolicyKey ccd_policy_keys[] = {
     {"gemm_256", &CcdPolicy::gemm_256}, {"gemm_256_min_m", &CcdPolicy::gemm_256_min_m},
     {"gemm_256_min_n", &CcdPolicy::gemm_256_min_n}, {"gemm_256_f32", &CcdPolicy::gemm_256_f32},
     {"gemm_256_deep", &CcdPolicy::gemm_256_deep}, {"gemm_row384", &CcdPolicy::gemm_row384},
-    {"rowproj", &CcdPolicy::rowproj}, {"rowproj_min_m", &CcdPolicy::rowproj_min_m},
+    {"rowproj", &CcdPolicy::rowproj}, {"rowproj_min_m", &CcdPolicy::rowproj_min_m}, {"rowproj_rb", &CcdPolicy::rowproj_rb},
     {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_onepass", &CcdPolicy::attn_onepass}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"rowgemm_adma", &CcdPolicy::rowgemm_adma}, {"tn_ws", &CcdPolicy::tn_ws}, {"lab", &CcdPolicy::lab}};
 static CcdPolicy& ccd_policy() {
     static CcdPolicy pol = [] {
@@ -159,8 +160,13 @@ static int ccd_launch_rowproj(const ccd::GemmParams& p, void* stream) {
     q.bias = p.bias; q.out = reinterpret_cast<ccd::bf16_t*>(p.C); q.ldc = p.ldc; q.M = p.M; q.N = p.N;
     const int cus = ccd_grid_cus(), smem = ccd::rp_smem_bytes(p.K, p.N);
     if (p.K == 384) {
-        const int tiles = (p.M + ccd::rp_rows(2) - 1) / ccd::rp_rows(2);
-        CCD_LAUNCH((ccd::rowproj_kernel<384, 2>), dim3(tiles < cus ? tiles : cus), dim3(ccd::RP_THREADS), smem, stream, q);
+        const int tiles = (p.M + ccd::rp_rows(2) - 1) / ccd::rp_rows(2), rb = ccd_policy().rowproj_rb;
+        if (rb == 1 || (rb == 0 && tiles < cus)) {       // (round 5) the chip is not full of 256-row tiles: half the rows per workgroup
+            const int tiles1 = (p.M + ccd::rp_rows(1) - 1) / ccd::rp_rows(1);
+            CCD_LAUNCH((ccd::rowproj_kernel<384, 1>), dim3(tiles1 < cus ? tiles1 : cus), dim3(ccd::RP_THREADS), smem, stream, q);
+        } else {
+            CCD_LAUNCH((ccd::rowproj_kernel<384, 2>), dim3(tiles < cus ? tiles : cus), dim3(ccd::RP_THREADS), smem, stream, q);
+        }
     } else {
         const int tiles = (p.M + ccd::rp_rows(1) - 1) / ccd::rp_rows(1);
         CCD_LAUNCH((ccd::rowproj_kernel<512, 1>), dim3(tiles < cus ? tiles : cus), dim3(ccd::RP_THREADS), smem, stream, q);
@@ -438,6 +444,7 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
     p.ln_rstd = ln_rstd; p.u = u; p.ldu = ldu; p.gact = gact; p.ldga = ldga; p.M = M; p.H = H; p.lab = ccd_policy().lab;
     p.a = nullptr; p.lda = 0; p.wp = nullptr; p.ldp = 0; p.bp = nullptr; p.rowscale1 = nullptr; p.ln2_gamma = p.ln2_beta = nullptr;
     p.xmid = nullptr; p.ldxm = 0; p.y2 = nullptr; p.ldy2 = 0; p.mean2 = p.rstd2 = nullptr;
+    p.tap_gamma = p.tap_beta = nullptr; p.tap_y = nullptr; p.ld_tap = 0;
     const int tiles = (M + ccd::MLP_BM - 1) / ccd::MLP_BM, cus = ccd_grid_cus();
     const dim3 grid(tiles < cus ? tiles : cus), block(ccd::MLP_THREADS);
     if (E == 512) {
@@ -461,7 +468,10 @@ int ccd_proj_mlp_fused(const ccd_bf16* a, long lda, const ccd_bf16* wp, long ldp
                        long ldy2, float* mean2, float* rstd2, const ccd_bf16* w1, long ld1, const float* b1, const ccd_bf16* w2,
                        long ld2, const float* b2, const float* rowscale2, int rows_per_sample, float* out, long ldc,
                        const float* ln_gamma, const float* ln_beta, float ln_eps, ccd_bf16* ln_y, long ld_y, float* ln_mean,
-                       float* ln_rstd, ccd_bf16* u, long ldu, int M, int E, int H, void* stream) {
+                       float* ln_rstd, ccd_bf16* u, long ldu, const float* tap_gamma, const float* tap_beta, ccd_bf16* tap_y, long ld_tap,
+                       int M, int E, int H, void* stream) {
+    CCD_CHECK((tap_y != nullptr) == (tap_gamma != nullptr) && (tap_y != nullptr) == (tap_beta != nullptr) && CCD_ALIGNED16(tap_y) &&
+              (!tap_y || ld_tap % 8 == 0), CCD_EINVAL);
     CCD_CHECK(a && wp && bp && resid && ln2_gamma && ln2_beta && w1 && b1 && w2 && b2 && out && ln_gamma && ln_beta && ln_y && ln_mean &&
               ln_rstd, CCD_EINVAL);
     CCD_CHECK((xmid != nullptr) == (y2 != nullptr) && (xmid != nullptr) == (mean2 != nullptr) && (xmid != nullptr) == (rstd2 != nullptr) &&
@@ -485,6 +495,7 @@ int ccd_proj_mlp_fused(const ccd_bf16* a, long lda, const ccd_bf16* wp, long ldp
     p.ln_rstd = ln_rstd; p.u = u; p.ldu = ldu; p.gact = nullptr; p.ldga = 0; p.M = M; p.H = H; p.lab = ccd_policy().lab;
     p.a = a; p.lda = lda; p.wp = wp; p.ldp = ldp; p.bp = bp; p.rowscale1 = rowscale1; p.ln2_gamma = ln2_gamma; p.ln2_beta = ln2_beta;
     p.xmid = xmid; p.ldxm = ldxm; p.y2 = y2; p.ldy2 = ldy2; p.mean2 = mean2; p.rstd2 = rstd2;
+    p.tap_gamma = tap_gamma; p.tap_beta = tap_beta; p.tap_y = tap_y; p.ld_tap = ld_tap;
     const int tiles = (M + ccd::MLP_BM - 1) / ccd::MLP_BM, cus = ccd_grid_cus();
     const dim3 grid(tiles < cus ? tiles : cus), block(ccd::MLP_THREADS);
     if (E == 384) {

@@ -79,6 +79,12 @@ struct MlpParams {
     long ldy2;
     float* mean2;
     float* rstd2;
+    // a second LayerNorm of the SAME output rows (other gamma / beta, same statistics): the segmentation tap that follows some blocks
+    // (vision_transformer.py:245-249, norm_seg) - optional, PROJ only
+    const float* tap_gamma;
+    const float* tap_beta;
+    bf16_t* tap_y;          // [M, E] bf16 or null
+    long ld_tap;
 };
 
 constexpr int MLP_SCRATCH = 4096, MLP_THREADS = 256, MLP_BM = 128;
@@ -86,7 +92,7 @@ constexpr int MLP_SCRATCH = 4096, MLP_THREADS = 256, MLP_BM = 128;
 __host__ __device__ constexpr int mlp_slots(int E) { return E <= 384 ? 5 : 3; }
 __host__ __device__ constexpr int mlp_piece_bytes(int E) { return 32 * E * 2; }
 __host__ __device__ inline int mlp_smem_bytes(int E, int H, bool proj = false) {
-    return mlp_slots(E) * mlp_piece_bytes(E) + 4 * MLP_SCRATCH + (1536 + H + (proj ? 6 : 3) * E) * 4;    // ring, scratch, Phi table, vectors
+    return mlp_slots(E) * mlp_piece_bytes(E) + 4 * MLP_SCRATCH + (1536 + H + (proj ? 8 : 3) * E) * 4;    // ring, scratch, Phi table, vectors
 }
 // 16-byte slot swizzle of a 128-byte image row (rows taken modulo 32: a piece is a stack of 32-row blocks)
 __device__ __forceinline__ int mlp_swz(int row) { return (((row & 31) >> 1) ^ ((row & 31) >> 4)) & 7; }
@@ -176,10 +182,15 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
     float* vbp = vbe + E;                  // PROJ: projection bias, norm2 gamma / beta
     float* vga2 = vbp + E;
     float* vbe2 = vga2 + E;
+    float* vgat = vbe2 + E;                // PROJ: the tap's gamma / beta
+    float* vbet = vgat + E;
     for (int i = t; i < p.H; i += MLP_THREADS) vb1[i] = p.b1[i];
     for (int i = t; i < E; i += MLP_THREADS) { vb2[i] = p.b2[i]; vga[i] = p.ln_gamma[i]; vbe[i] = p.ln_beta[i]; }
-    if constexpr (PROJ)
+    if constexpr (PROJ) {
         for (int i = t; i < E; i += MLP_THREADS) { vbp[i] = p.bp[i]; vga2[i] = p.ln2_gamma[i]; vbe2[i] = p.ln2_beta[i]; }
+        if (p.tap_y)
+            for (int i = t; i < E; i += MLP_THREADS) { vgat[i] = p.tap_gamma[i]; vbet[i] = p.tap_beta[i]; }
+    }
     for (unsigned i = t; i < MLP_LUT_HI - MLP_LUT_LO; i += MLP_THREADS) lut[i] = gelu_terms(bf2f((bf16_t)(MLP_LUT_LO + i))).cdf;
     __syncthreads();                       // (plain loads only so far: nothing in flight that a drain would hurt)
 
@@ -470,8 +481,9 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
         // the scratch image as 128-byte row segments (STORE), and / or the LayerNorm becomes the operand registers yf (TO_YF: the two
         // half-waves exchange quads - v_permlane32_swap - so that a lane holds the 8 consecutive columns 16 j + 8 hf .. of k-step j)
         auto pass_b = [&](auto STORE, auto TO_YF, const buf_rsrc& rs_of, long ldo, const buf_rsrc& rs_nf, long ldn, const float* ga_,
-                          const float* be_, float* meanp, float* rstdp) __attribute__((always_inline)) {
+                          const float* be_, float* meanp, float* rstdp, bool tap = false) __attribute__((always_inline)) {
             constexpr bool store = decltype(STORE)::value, to_yf = decltype(TO_YF)::value;
+            const buf_rsrc rs_tap = make_rsrc(tap ? p.tap_y : nullptr, tap ? (unsigned)((((long)p.M - 1) * p.ld_tap + E) * 2) : 0u);
             if (store && hf == 0 && row < p.M) { meanp[row] = mean; rstdp[row] = rstd; }
             const LaneOff lo(t);
             const unsigned lo_o = lo.rows8(ldo, 4), lo_n = lo.rows8(ldn, 2);
@@ -516,6 +528,27 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                         buf_store16(rs_nf, lo_n, (unsigned)(r0 + 8 * i) * (unsigned)(ldn * 2) + 128 * np, v);
                     }
                     wave_lds_fence();
+                    if (tap) {             // the same rows under the tap's gamma / beta (same mean / rstd), same way out
+                        const unsigned lo_t = lo.rows8(p.ld_tap, 2);
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int nt = 2 * np + tt, n = 32 * nt + 8 * g + 4 * hf;
+                                const f32x4v ga = *reinterpret_cast<const f32x4v*>(vgat + n), be = *reinterpret_cast<const f32x4v*>(vbet + n);
+                                u32x2 tp;
+                                tp.x = pack_bf2((acc[nt][4 * g] - mean) * rstd * ga.x + be.x, (acc[nt][4 * g + 1] - mean) * rstd * ga.y + be.y);
+                                tp.y = pack_bf2((acc[nt][4 * g + 2] - mean) * rstd * ga.z + be.z, (acc[nt][4 * g + 3] - mean) * rstd * ga.w + be.w);
+                                *reinterpret_cast<u32x2*>(scratch + lo.scr_wr(4 * tt + g) + 8 * lo.hf) = tp;
+                            }
+                        wave_lds_fence();
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const u32x4 v = *reinterpret_cast<const u32x4*>(scratch + lo.scr_rd(i));
+                            buf_store16(rs_tap, lo_t, (unsigned)(r0 + 8 * i) * (unsigned)(p.ld_tap * 2) + 128 * np, v);
+                        }
+                        wave_lds_fence();
+                    }
                 }
                 if constexpr (to_yf) {
 #pragma unroll
@@ -741,7 +774,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
             const float sc = (p.rowscale && !one_sample) ? p.rowscale[grow / p.rows_per_sample] : sc_tile;
             pass_a(std::integral_constant<int, 1>{}, rs_x, p.ldr, vb2, sc);
         }
-        pass_b(Yes{}, No{}, rs_o, p.ldc, rs_n, p.ld_y, vga, vbe, p.ln_mean, p.ln_rstd);
+        pass_b(Yes{}, No{}, rs_o, p.ldc, rs_n, p.ld_y, vga, vbe, p.ln_mean, p.ln_rstd, PROJ && p.tap_y != nullptr);
         MLP_STAMP(7)
     }
     glds_wait_all();                       // requested pieces that no tile consumed must not outlive the workgroup's LDS

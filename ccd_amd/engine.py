@@ -166,11 +166,14 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
         if fuse_proj:
             # the block's second half in ONE launch: x_mid and y2 stay in registers (a pass that saves nothing writes neither)
             nxt = f"{pre}blocks.{i + 1}.norm1." if i + 1 < spec.depth else pre + "norm."
-            x, y_n, mean_n, rstd_n, kept = ops.proj_mlp_fused(
+            # a segmentation tap behind this block is one more LayerNorm of the same rows: the kernel emits it (same statistics)
+            tap_j = len(taps) if (need_taps and i + 1 in spec.taps) else None
+            tap_kw = {} if tap_j is None else dict(tap_gamma=arena.w(f"{pre}norm_seg.{tap_j}.weight"), tap_beta=arena.w(f"{pre}norm_seg.{tap_j}.bias"))
+            x, y_n, mean_n, rstd_n, kept, *tap_out = ops.proj_mlp_fused(
                 c.att.view(R, E), arena.wb(b + "attn.proj.weight"), arena.w(b + "attn.proj.bias"), resid=x, rowscale1=c.ds1,
                 gamma2=arena.w(b + "norm2.weight"), beta2=arena.w(b + "norm2.bias"), w1=arena.wb(b + "mlp.fc1.weight"),
                 b1=arena.w(b + "mlp.fc1.bias"), w2=arena.wb(b + "mlp.fc2.weight"), b2=arena.w(b + "mlp.fc2.bias"), rowscale2=c.ds2,
-                rows_per_sample=256, gamma=arena.w(nxt + "weight"), beta=arena.w(nxt + "bias"), eps=spec.eps, save=save)
+                rows_per_sample=256, gamma=arena.w(nxt + "weight"), beta=arena.w(nxt + "bias"), eps=spec.eps, save=save, **tap_kw)
             if save:
                 c.x_mid, c.y2, c.mean2, c.rstd2, c.u = kept
             c.gact = None
@@ -215,7 +218,10 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
         ctxs.append(c if save else None)
         if need_taps and i + 1 in spec.taps:
             j = len(taps)
-            t, mu, rs = ops.ln_fwd(x, arena.w(f"{pre}norm_seg.{j}.weight"), arena.w(f"{pre}norm_seg.{j}.bias"), spec.eps)
+            if fuse_proj:
+                t, mu, rs = tap_out[0], mean_n, rstd_n           # (LayerNorm statistics depend on the rows only)
+            else:
+                t, mu, rs = ops.ln_fwd(x, arena.w(f"{pre}norm_seg.{j}.weight"), arena.w(f"{pre}norm_seg.{j}.bias"), spec.eps)
             taps.append(t)
             tap_ctx.append((i, x, mu, rs))
     if pending is None:

@@ -209,12 +209,13 @@ def mlp_fused(y, w1, b1, w2, b2, *, resid, rowscale, rows_per_sample, gamma, bet
 
 
 def proj_mlp_fused(a, wp, bp, *, resid, rowscale1, gamma2, beta2, w1, b1, w2, b2, rowscale2, rows_per_sample, gamma, beta, eps,
-                   save=False, out=None):
+                   save=False, out=None, tap_gamma=None, tap_beta=None):
     """The second half of a transformer block in one launch (include/ccd_hip.h: ccd_proj_mlp_fused):
         x_mid = resid + (a @ wp^T + bp) * rowscale1;   y2 = LayerNorm(x_mid) * gamma2 + beta2
         out   = x_mid + (gelu(y2 @ w1^T + b1) @ w2^T + b2) * rowscale2;   y_next = LayerNorm(out) * gamma + beta
     -> (out, y_next, mean, rstd, saved) with saved = (x_mid, y2, mean2, rstd2, u) when `save` (what the backward pass reads), else None:
-    then x_mid and y2 never reach HBM.  Raises RuntimeError('unsupported shape') where the kernel does not apply."""
+    then x_mid and y2 never reach HBM.  With tap_gamma / tap_beta a sixth result: LayerNorm(out) * tap_gamma + tap_beta (bf16).
+    Raises RuntimeError('unsupported shape') where the kernel does not apply."""
     _chk(a, BF16, "a"); _chk(wp, BF16, "wp"); _chk(w1, BF16, "w1"); _chk(w2, BF16, "w2"); _chk(resid, F32, "resid")
     _chk(rowscale1, F32, "rowscale1"); _chk(rowscale2, F32, "rowscale2")
     M, E = a.shape
@@ -233,8 +234,10 @@ def proj_mlp_fused(a, wp, bp, *, resid, rowscale1, gamma2, beta2, w1, b1, w2, b2
         mean2 = torch.empty(M, dtype=F32, device=dev)
         rstd2 = torch.empty(M, dtype=F32, device=dev)
         u = torch.empty((M, H), dtype=BF16, device=dev)
+    tap = torch.empty((M, E), dtype=BF16, device=dev) if tap_gamma is not None else None
     # algorithmic bytes: a and resid read, out + y_next written (+ x_mid, y2, u when saved), the three weight matrices once
-    nbytes = M * E * (2.0 + 4.0 + 4.0 + 2.0) + (M * E * 6.0 + 2.0 * M * H if save else 0.0) + 4.0 * E * H + 2.0 * E * E
+    nbytes = M * E * (2.0 + 4.0 + 4.0 + 2.0) + (M * E * 6.0 + 2.0 * M * H if save else 0.0) + 4.0 * E * H + 2.0 * E * E + \
+        (2.0 * M * E if tap is not None else 0.0)
     span = TIMER.span("proj_mlp_fused", 4.0 * M * E * H + 2.0 * M * E * E, nbytes) if TIMER is not None else None
     if span:
         span[0].record()
@@ -243,10 +246,12 @@ def proj_mlp_fused(a, wp, bp, *, resid, rowscale1, gamma2, beta2, w1, b1, w2, b2
           0 if y2 is None else y2.stride(0), _lib.ptr(mean2), _lib.ptr(rstd2), _lib.ptr(w1), w1.stride(0), _lib.ptr(b1), _lib.ptr(w2),
           w2.stride(0), _lib.ptr(b2), _lib.ptr(rowscale2), int(rows_per_sample), _lib.ptr(out), out.stride(0), _lib.ptr(gamma),
           _lib.ptr(beta), float(eps), _lib.ptr(yn), yn.stride(0), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(u),
-          0 if u is None else u.stride(0), M, E, H)
+          0 if u is None else u.stride(0), _lib.ptr(tap_gamma), _lib.ptr(tap_beta), _lib.ptr(tap), 0 if tap is None else tap.stride(0),
+          M, E, H)
     if span:
         span[1].record()
-    return out, yn, mean, rstd, ((xmid, y2, mean2, rstd2, u) if save else None)
+    res = (out, yn, mean, rstd, ((xmid, y2, mean2, rstd2, u) if save else None))
+    return res + (tap,) if tap is not None else res
 
 
 def gemm_tn_colsum(a, b, out, colsum, *, splits=0):

@@ -111,13 +111,16 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
  * the backward pass needs are written on the way.  E in {128, 256, 384}; with a DropPath scale rows_per_sample % 128 == 0
  * (CCD_ESHAPE otherwise: the caller takes the two separate launches); rowscale2 needs xmid (a dropped MLP branch still runs its
  * products - no branch around the weight ring - and reads x_mid back: out == x_mid exactly, u holds the real pre-activation).
- * Replaces ccd_gemm_nt_resid_ln + ccd_mlp_fused. */
+ * tap_y (optional, with tap_gamma / tap_beta): a second LayerNorm of the same output rows, LayerNorm(out) * tap_gamma + tap_beta - the
+ * segmentation tap that follows some blocks (vision_transformer.py:245-249) - instead of a ccd_ln_fwd pass over out.
+ * Replaces ccd_gemm_nt_resid_ln + ccd_mlp_fused (+ ccd_ln_fwd). */
 int ccd_proj_mlp_fused(const ccd_bf16* a, long lda, const ccd_bf16* wp, long ldp, const float* bp, const float* resid, long ldr,
                        const float* rowscale1, const float* ln2_gamma, const float* ln2_beta, float* xmid, long ldxm, ccd_bf16* y2,
                        long ldy2, float* mean2, float* rstd2, const ccd_bf16* w1, long ld1, const float* b1, const ccd_bf16* w2,
                        long ld2, const float* b2, const float* rowscale2, int rows_per_sample, float* out, long ldc,
                        const float* ln_gamma, const float* ln_beta, float ln_eps, ccd_bf16* ln_y, long ld_y, float* ln_mean,
-                       float* ln_rstd, ccd_bf16* u, long ldu, int M, int E, int H, void* stream);
+                       float* ln_rstd, ccd_bf16* u, long ldu, const float* tap_gamma, const float* tap_beta, ccd_bf16* tap_y, long ld_tap,
+                       int M, int E, int H, void* stream);
 /* colsum (optional, epilogues BF16 / DGELU): [N] fp32, += column sums of the output (bias gradient of the producer).
  * CCD_EPI_GELU accepts C == NULL (only gelu(u) is stored: forward passes that keep no activations). */
 /* C[P,Q] (+)= sum_m A[m,P] * B[m,Q]   (weight gradients dW = dY^T X of every Linear; autograd of the above)

@@ -1041,12 +1041,15 @@ def check_proj_mlp_fused(dev, M, E, H, rps=128, seed=41, save=True, drops=True):
         rs1[i], rs2[i] = pattern[i]
     ga2, be2 = rnd((E,), g).abs() + 0.5, rnd((E,), g) * 0.3
     ga, be = rnd((E,), g).abs() + 0.5, rnd((E,), g) * 0.3
+    gat, bet = rnd((E,), g).abs() + 0.5, rnd((E,), g) * 0.3
     for use in ((True, False) if drops else (False,)):
         r1, r2 = (rs1, rs2 if save else None) if use else (None, None)      # (a dropped MLP branch reads x_mid back: only with save)
-        out, yn, mean, rstd, saved = ops.proj_mlp_fused(
+        tap_kw = dict(tap_gamma=gat.to(dev), tap_beta=bet.to(dev)) if use == save else {}     # (with and without the tap output)
+        out, yn, mean, rstd, saved, *tap = ops.proj_mlp_fused(
             a.to(dev), wp.to(dev), bp.to(dev), resid=resid.to(dev), rowscale1=None if r1 is None else r1.to(dev), gamma2=ga2.to(dev),
             beta2=be2.to(dev), w1=w1.to(dev), b1=b1.to(dev), w2=w2.to(dev), b2=b2.to(dev), rowscale2=None if r2 is None else r2.to(dev),
-            rows_per_sample=rps, gamma=ga.to(dev), beta=be.to(dev), eps=1e-6, save=save)
+            rows_per_sample=rps, gamma=ga.to(dev), beta=be.to(dev), eps=1e-6, save=save, **tap_kw)
+        assert len(tap) == (1 if tap_kw else 0)
         s1 = 1.0 if r1 is None else r1.repeat_interleave(rps)[:M, None]
         s2 = 1.0 if r2 is None else r2.repeat_interleave(rps)[:M, None]
         xmid_ref = resid + (a.float() @ wp.float().t() + bp) * s1
@@ -1082,6 +1085,9 @@ def check_proj_mlp_fused(dev, M, E, H, rps=128, seed=41, save=True, drops=True):
         close(mean, mu, 1e-3, 1e-3, tag + "/mean")
         close(rstd, (var + 1e-6).rsqrt(), 2e-3, 1e-4, tag + "/rstd")
         close(yn, F.layer_norm(want, (E,), ga, be, 1e-6), 1e-2, 3e-2, tag + "/y")
+        if tap:
+            close(tap[0], F.layer_norm(want, (E,), gat, bet, 1e-6), 1e-2, 3e-2, tag + "/tap")
+            close(tap[0], F.layer_norm(out.float().cpu(), (E,), gat, bet, 1e-6), 1e-2, 1e-2, tag + "/tap (of the kernel's own rows)")
         if use:
             for i in range(min(ns, len(pattern))):
                 lo, hi = i * rps, min((i + 1) * rps, M)

@@ -214,9 +214,17 @@ def check_small_steps(device, loss_tol=1e-3):
     dino_loss = DINOLoss(65536, 2, 0.04, 0.04, 0, 40).to(device)
     opt = pretrain.make_optimizer(student, clip_grad=3.0)
     report = {}
-    # The reference's trajectory after the first update depends on amplified rounding noise (see NOISE_DOMINATED and
-    # oracle.dino_head_forward(exact_zero_rows=...)); from iteration 1 on we therefore compare with the CPU oracle
-    # run with that single pathology removed, and only loosely with the recorded reference numbers.
+    # The reference's trajectory after the first update depends on an amplified rounding residue (see NOISE_DOMINATED and
+    # oracle.dino_head_forward(exact_zero_rows=...)): exp(log_softmax(0)) - softmax(0) = -2.3e-12 per logit of an exactly-uniform row,
+    # a property of the platform's fp32 expf / logf that F.normalize's backward multiplies by 1 / eps = 1e12.  It is deterministic on
+    # one platform - tests/golden/small_step_ref_noise.json (tools/gen_golden.py --only small_noise): the REAL reference's iteration-1
+    # loss does not move by more than 2e-6 under 1 / 2 / 4 / 8 threads or permutations of the 65 536 output units - and it is gone
+    # when the reference's loss evaluates its log-softmax in float64: iteration 1 then lands 9.3e-3 away, where the exact oracle and
+    # the HIP path land.  From iteration 1 on the gates are therefore (a) the CPU oracle with that single residue removed, (b) the
+    # real reference with float64 log-softmax, both at `loss_tol`, and (c) the recorded fp32 reference within the measured shift.
+    import json
+    with open(os.path.join(GOLD, "small_step_ref_noise.json")) as f:
+        ref_noise = json.load(f)
     from oracle import ccd_oracle as O
     o_student, o_teacher = O.build_pair(O.Spec(norm_last_layer=False, **O.ARCH["vit_small"]), seed=0)
     o_center, o_opt = torch.zeros(1, 65536), O.AdamWState()
@@ -249,7 +257,12 @@ def check_small_steps(device, loss_tol=1e-3):
         report[f"step{step}"] = {"hip": losses.tolist(), "reference": g[p + "losses"].tolist(),
                                  "oracle_exact_zero_rows": exact.tolist()}
         np.testing.assert_allclose(losses, exact, atol=loss_tol, rtol=0, err_msg=f"losses vs exact oracle, step {step}")
-        ref_tol = loss_tol if step == 0 else 2e-2
+        if step == 1:
+            ref64 = np.array(ref_noise["s1_losses_with_float64_log_softmax"])
+            report["step1"]["reference_with_float64_log_softmax"] = ref64.tolist()
+            np.testing.assert_allclose(losses, ref64, atol=loss_tol, rtol=0, err_msg="losses vs the reference with float64 log-softmax, step 1")
+        shift = float(np.abs(np.array(ref_noise["s1_shift_fp32_vs_float64_log_softmax"])).max())       # 9.3e-3, measured
+        ref_tol = loss_tol if step == 0 else shift + loss_tol
         np.testing.assert_allclose(losses, g[p + "losses"], atol=ref_tol, rtol=0, err_msg=f"losses vs reference, step {step}")
         r, c = g[p + "rows"], g[p + "cols"]
         sl = out["instances_view"].detach().float()[torch.as_tensor(r)][:, torch.as_tensor(c)].cpu().numpy()

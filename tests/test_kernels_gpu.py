@@ -82,6 +82,16 @@ def test_rowproj(hip, M, N, K):
     kc.check_rowproj(hip.device, M=M, N=N, K=K, seed=M % 7)
 
 
+def test_rowproj_half_height_tiles(hip):
+    """K = 384 with one row block per wave: chosen when 256-row tiles would leave compute units idle (32 768 rows = 64 images), forced here."""
+    from ccd_amd import ops
+    kc.check_rowproj(hip.device, M=32768, N=1152, K=384, seed=2)          # auto: 128 tiles of 256 rows < 256 CUs -> 128-row tiles
+    with ops.policy(rowproj_rb=1):
+        kc.check_rowproj(hip.device, M=40000, N=384, K=384, seed=3)
+    with ops.policy(rowproj_rb=2):
+        kc.check_rowproj(hip.device, M=32768, N=1152, K=384, seed=2)
+
+
 def test_rowproj_is_the_default_for_the_vit_projections(hip):
     """At the benchmark shapes ccd_gemm_nt (EPI_BF16, K = 384, 131072 rows) runs rowproj.h: 20 launches must be bit-identical
     (a row-owner kernel has no split-K atomics) and equal the tiled kernel to bf16 rounding."""

@@ -99,6 +99,11 @@ def test_rowproj_sim(sim, monkeypatch):
     kc.check_rowproj(sim.device, M=300, N=128, K=384)            # 2 tiles of 256 rows on 2 workgroups
     kc.check_rowproj(sim.device, M=256 * 3 + 40, N=192, K=384, seed=3)   # 4 tiles on 2 workgroups: 2 each
     kc.check_rowproj(sim.device, M=200, N=64, K=512, seed=4, strided=False)
+    from ccd_amd import ops
+    with ops.policy(rowproj_rb=1):                # 128-row tiles at K = 384 (what a half-empty chip gets)
+        kc.check_rowproj(sim.device, M=128 * 3 + 40, N=192, K=384, seed=5)
+    with ops.policy(rowproj_rb=2):
+        kc.check_rowproj(sim.device, M=300, N=128, K=384, seed=6)
 
 
 def test_layernorm_sim(sim):
