@@ -18,6 +18,13 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) { return cvt_pk
 __device__ __forceinline__ float bf_lo(unsigned w) { return bits2f(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return bits2f(w & 0xffff0000u); }
 
+// IEEE binary16 -> fp32 by bit arithmetic (subnormals included): the overlay planes of the data pipeline
+__device__ __forceinline__ float half2f(unsigned short h) {
+    const unsigned sign = (unsigned)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+    if (e == 0) return bits2f(sign) == 0.f ? (float)m * 5.9604644775390625e-8f : -((float)m * 5.9604644775390625e-8f);     // m * 2^-24
+    if (e == 31) return bits2f(sign | 0x7f800000u | (m << 13));
+    return bits2f(sign | ((e + 112u) << 23) | (m << 13));
+}
 __device__ __forceinline__ void unpack8(const u32x4& w, float* v) {
     v[0] = bf_lo(w.x); v[1] = bf_hi(w.x); v[2] = bf_lo(w.y); v[3] = bf_hi(w.y);
     v[4] = bf_lo(w.z); v[5] = bf_hi(w.z); v[6] = bf_lo(w.w); v[7] = bf_hi(w.w);

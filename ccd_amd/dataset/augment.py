@@ -7,7 +7,7 @@ to view 2 with probability 0.7 (datasetsupervised_kmeans.py:40-45,60), and `thet
 factors cancel when the augmentation runs at the network resolution, which it does here).  A sample whose 0.7 draw fails
 gets the PLAIN image as view 2 (:72-74): its colour parameters are the identity.
 
-Colour = the reference's imgaug chain: its member LISTS and probabilities, 42 of its 50 members reproduced (the other eight - listed
+Colour = the reference's imgaug chain: its member LISTS and probabilities, 44 of its 50 members reproduced (the other six - listed
 below - are drawn and leave the image unchanged, so the augmentation distribution is WEAKER than the reference's; README parity
 claims say so) (augmentation_pipelines.py:120-205,
 severity 5 - what the shipped pretraining configs select; dataset_pretrain.py:79-158 for finetuning): `Sometimes(0.2, Identity,
@@ -18,10 +18,11 @@ Gaussian / Laplace / Poisson noises, Multiply(Elementwise), Dropout, CoarseDropo
 Salt / Pepper, Invert, Solarize, JpegCompression, Emboss, EdgeDetect, DirectedEdgeDetect, pillike.FilterEdgeEnhanceMore /
 FilterContour; the HSV hue shifts, MultiplyAndAddToBrightness (in RGB), MultiplyHueAndSaturation, AddToHueAndSaturation,
 Grayscale, UniformColorQuantization, ChangeColorTemperature (as channel gains); Sharpen and the five blurs; Gamma / Linear /
-Sigmoid / Log contrast, AllChannelsHistogramEqualization.
+Sigmoid / Log contrast, AllChannelsHistogramEqualization; Fog and Clouds (round 5: cloud layers drawn on the host - weather.py - and
+blended on the device).
 NOT reproduced - the draw that selects them leaves the image unchanged: KMeansColorQuantization,
-HistogramEqualization / CLAHE / AllChannelsCLAHE (Lab-space or tiled equalisation), the weather members (Fog, Clouds, Snowflakes,
-Rain), PiecewiseAffine (finetuning geometry); severity 2's ElasticTransformation / PerspectiveTransform (no shipped config).
+HistogramEqualization / CLAHE / AllChannelsCLAHE (Lab-space or tiled equalisation), Snowflakes, Rain, PiecewiseAffine (finetuning
+geometry); severity 2's ElasticTransformation / PerspectiveTransform (no shipped config).
 """
 from __future__ import annotations
 
@@ -30,7 +31,7 @@ import math
 import numpy as np
 
 AUG_NP = 96
-P_SEED, P_PREINV, P_A, P_AK, P_B, P_C, P_D, P_KERN = 0, 1, 2, 9, 18, 24, 28, 32          # kernels/datapipe.h
+P_SEED, P_PREINV, P_A, P_AK, P_B, P_C, P_D, P_KERN, P_W = 0, 1, 2, 9, 18, 24, 28, 32, 81    # kernels/datapipe.h
 A_ADD_ELEM, A_GAUSS, A_LAPLACE, A_POISSON, A_MUL, A_MUL_ELEM, A_DROPOUT, A_COARSE, A_DROP2D, A_REPLACE, A_INVERT, A_SOLARIZE, \
     A_JPEG, A_FILTER, A_PILFILTER = range(1, 16)
 B_HUE_ADD, B_BRIGHT, B_MUL_HS, B_ADD_HS, B_GRAY, B_KMEANS, B_UNIFORM_Q, B_GAINS, B_SHUFFLE = range(1, 10)
@@ -296,10 +297,24 @@ FINETUNE_ONE_OF = (["ChannelShuffle", "AddElementwise", "AdditiveGaussianNoise",
                     "MultiplyHueAndSaturation", "AddToHueAndSaturation", "HueAdd50_100", "Grayscale", "KMeansColorQuantization",
                     "UniformColorQuantization", "ChangeColorTemperature", "Fog", "Clouds", "Snowflakes", "Rain"])   # dataset_pretrain.py:86-121
 _COLOUR_NAMES = set(COLOR_5) | {"MultiplyBrightness", "ChannelShuffle"}
-_WEATHER = {"Fog", "Clouds", "Snowflakes", "Rain"}                                      # not reproduced
+_WEATHER = {"Fog", "Clouds", "Snowflakes", "Rain"}                                      # Fog / Clouds: cloud layers; the others not reproduced
 
 
-def _colour_params(rs: np.random.RandomState, severity: int, h: int = 32, w: int = 128) -> np.ndarray:
+def _weather_member(p, rs, name, h, w, overlays):
+    """`weather`: Fog / Clouds = cloud layers generated HERE (ccd_amd/dataset/weather.py) and blended on the device: the row names the
+    first of its layers among the batch's overlay planes and their number.  Snowflakes / Rain: not reproduced.  Without a collector
+    (`overlays` None: a caller that does not ship overlay planes) nothing is drawn."""
+    if overlays is None or name not in ("Fog", "Clouds"):
+        return
+    from . import weather
+    layers = weather.fog_layers(rs, h, w) if name == "Fog" else weather.clouds_layers(rs, h, w)
+    p[P_W], p[P_W + 1] = len(layers), overlays.add(layers)
+
+
+WEATHER_5 = ["Fog", "Clouds", "Snowflakes", "Rain"]                                    # augmentation_pipelines.py:192-195
+
+
+def _colour_params(rs: np.random.RandomState, severity: int, h: int = 32, w: int = 128, overlays=None) -> np.ndarray:
     p = IDENTITY_PARAMS.copy()
     p[P_SEED] = rs.randint(0, 1 << 24)
     if severity <= 0:
@@ -314,7 +329,8 @@ def _colour_params(rs: np.random.RandomState, severity: int, h: int = 32, w: int
             _blur_member(p, rs)
         if rs.uniform() < 0.7:
             _contrast_member(p, rs)
-        rs.uniform()                              # weather: Sometimes(0.7, OneOf[Fog, Clouds, Snowflakes, Rain]) - not reproduced
+        if rs.uniform() < 0.7:                    # weather: Sometimes(0.7, OneOf[Fog, Clouds, Snowflakes, Rain])
+            _weather_member(p, rs, WEATHER_5[rs.randint(0, len(WEATHER_5))], h, w, overlays)
         return p
     # the other severities are OneOf lists over colour members (severity 6: :198-214); no shipped config selects them
     names = ["HueAdd0_50", "MultiplyAndAddToBrightness", "MultiplyHueAndSaturation", "AddToHueAndSaturation", "HueAdd50_100",
@@ -324,21 +340,22 @@ def _colour_params(rs: np.random.RandomState, severity: int, h: int = 32, w: int
 
 
 def sample_colour_params(rs: np.random.RandomState, batch: int, severity: int = 5, warped=None, h: int = 32,
-                         w: int = 128) -> np.ndarray:
+                         w: int = 128, overlays=None) -> np.ndarray:
     """fp32 [batch, 2, 96]: view 1 from pipeline `severity`, view 2 from the same pipeline (both come from `augment_tfs`,
     datasetsupervised_kmeans.py:57).  `warped` (bool [batch], from sample_theta): a sample whose warp draw failed gets the
-    plain image as view 2 (:72-74 `image_view = image`), i.e. identity parameters."""
+    plain image as view 2 (:72-74 `image_view = image`), i.e. identity parameters.  `overlays` (weather.Overlays): collects the
+    cloud layers of the rows that drew Fog / Clouds - hand its planes() to ops.augment_views together with the rows."""
     out = np.empty((batch, 2, AUG_NP), dtype=np.float32)
     for b in range(batch):
-        out[b, 0] = _colour_params(rs, severity, h, w)
-        out[b, 1] = _colour_params(rs, severity, h, w)
+        out[b, 0] = _colour_params(rs, severity, h, w, overlays)
+        out[b, 1] = _colour_params(rs, severity, h, w, overlays)
         if warped is not None and not warped[b]:
-            out[b, 1] = IDENTITY_PARAMS
+            out[b, 1] = IDENTITY_PARAMS           # (layers it may have drawn stay in the collector, unreferenced)
     return out
 
 
 # ------------------------------------------------------------------------------------------------ finetuning pipeline
-def _finetune_colour_params(rs: np.random.RandomState, h: int = 32, w: int = 128) -> np.ndarray:
+def _finetune_colour_params(rs: np.random.RandomState, h: int = 32, w: int = 128, overlays=None) -> np.ndarray:
     """One draw of the finetuning pipeline's colour part (Dino/dataset/dataset_pretrain.py:80-146): Sometimes(0.6, Invert(0.1)),
     Sometimes(0.8, OneOf[35 members]), Sometimes(0.6, Blur group without the bilateral member), Sometimes(0.6, contrast group).
     Members this implementation does not reproduce keep their share of the draw and leave the image unchanged."""
@@ -349,8 +366,8 @@ def _finetune_colour_params(rs: np.random.RandomState, h: int = 32, w: int = 128
     if rs.uniform() < 0.8:
         name = FINETUNE_ONE_OF[rs.randint(0, len(FINETUNE_ONE_OF))]
         if name in _WEATHER:
-            pass
-        elif name in _COLOUR_NAMES:
+            _weather_member(p, rs, name, h, w, overlays)     # (the blend runs after the contrast group on the device; the reference's OneOf
+        elif name in _COLOUR_NAMES:                          # puts it before the blur / contrast groups - an ordering difference, noted)
             _colour_member(p, rs, name)
         else:
             _arith_member(p, rs, name, h, w)
@@ -361,14 +378,14 @@ def _finetune_colour_params(rs: np.random.RandomState, h: int = 32, w: int = 128
     return p
 
 
-def sample_finetune_params(rs: np.random.RandomState, batch: int, h: int, w: int):
+def sample_finetune_params(rs: np.random.RandomState, batch: int, h: int, w: int, overlays=None):
     """(params fp32 [batch, 2, 96] - only row 1 is used, theta fp32 [batch, 3, 3]) for the finetuning augmentation
     (dataset_pretrain.py:79-158): colour as above, geometry = Sometimes(0.6, OneOf[Affine (the pretraining ranges), PiecewiseAffine
     (not reproduced), Rotate(-45, 45)])."""
     params = np.tile(IDENTITY_PARAMS, (batch, 2, 1)).astype(np.float32)
     theta = np.tile(np.eye(3, dtype=np.float32), (batch, 1, 1))
     for b in range(batch):
-        params[b, 1] = _finetune_colour_params(rs, h, w)
+        params[b, 1] = _finetune_colour_params(rs, h, w, overlays)
         if rs.uniform() < 0.6:
             g = rs.randint(0, 3)
             if g == 0:

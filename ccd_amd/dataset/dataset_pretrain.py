@@ -118,7 +118,11 @@ class DeviceImageAugmenter:
         dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
         B = images_u8.shape[0]
         assert tuple(images_u8.shape[1:]) == (self.h, self.w, 3) and images_u8.dtype == torch.uint8
-        params, theta = sample_finetune_params(self.rs, B, self.h, self.w)
+        from .weather import Overlays
+        overlays = Overlays(self.h, self.w)
+        params, theta = sample_finetune_params(self.rs, B, self.h, self.w, overlays=overlays)
+        planes = overlays.planes()
         out = ops.augment_views(images_u8.to(dev, non_blocking=True).contiguous(), torch.from_numpy(params).to(dev),
-                                torch.from_numpy(theta).to(dev), MEAN, STD)
+                                torch.from_numpy(theta).to(dev), MEAN, STD,
+                                overlay=None if planes is None else torch.from_numpy(planes).to(dev))
         return out[:, 2].contiguous()

@@ -167,10 +167,15 @@ class DeviceViewMaker:
         assert tuple(images_u8.shape[1:]) == (self.h, self.w, 3) and images_u8.dtype == torch.uint8
         if self.data_aug and self.severity > 0:
             theta, warped = sample_theta(self.rs, B, self.h, self.w, return_warped=True)
-            params = sample_colour_params(self.rs, B, self.severity, warped=warped, h=self.h, w=self.w)     # view 2 = the plain image where not warped
+            from .weather import Overlays
+            overlays = Overlays(self.h, self.w)
+            params = sample_colour_params(self.rs, B, self.severity, warped=warped, h=self.h, w=self.w, overlays=overlays)     # view 2 = the plain image where not warped
+            planes = overlays.planes()
         else:                                                       # data_aug off: three identical views, identity theta
             params = sample_colour_params(self.rs, B, 0)
             theta = np.tile(np.eye(3, dtype=np.float32), (B, 1, 1))
+            planes = None
         img_d = images_u8.to(dev, non_blocking=True).contiguous()
-        out = ops.augment_views(img_d, torch.from_numpy(params).to(dev), torch.from_numpy(theta).to(dev), MEAN, STD)
+        out = ops.augment_views(img_d, torch.from_numpy(params).to(dev), torch.from_numpy(theta).to(dev), MEAN, STD,
+                                overlay=None if planes is None else torch.from_numpy(planes).to(dev))
         return out, masks.to(dev, non_blocking=True).float(), torch.from_numpy(theta).to(dev)

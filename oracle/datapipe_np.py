@@ -78,7 +78,7 @@ def _u01(h):
 
 
 # parameter layout of one (sample, view) row: ccd_amd/csrc/kernels/datapipe.h
-P_SEED, P_PREINV, P_A, P_AK, P_B, P_C, P_D, P_KERN = 0, 1, 2, 9, 18, 24, 28, 32
+P_SEED, P_PREINV, P_A, P_AK, P_B, P_C, P_D, P_KERN, P_W = 0, 1, 2, 9, 18, 24, 28, 32, 81
 
 
 def _round_u8(v):
@@ -283,9 +283,20 @@ def contrast_member(p, img):
     return img
 
 
-def staged_source(p, src_u8):
+def cloud_blend(cur_u8, alpha, intensity):
+    """imgaug's CloudLayer.draw_on_image (augmenters/weather.py; augmentation_pipelines.py:192-193 Fog / Clouds) on a uint8 image:
+    clip((1 - alpha) * image + alpha * intensity, 0, 255).astype(uint8) in float32, alpha / intensity [H,W] broadcast over channels."""
+    f = np.float32
+    a = np.asarray(alpha, f)[..., None]
+    it = np.asarray(intensity, f)[..., None]
+    v = (f(1) - a) * np.asarray(cur_u8, np.uint8).astype(f) + a * it
+    return _trunc_u8(v)
+
+
+def staged_source(p, src_u8, overlay=None):
     """augment_spatial_kernel: the reference's chain on one (sample, view) - [leading Invert] -> one `arithmetic` member -> one
-    `color` member -> one `Blur` member -> one `contrast` member, uint8 [H,W,3] -> uint8 [H,W,3] (rounded between the groups)."""
+    `color` member -> one `Blur` member -> one `contrast` member -> the cloud layers of a `weather` member (overlay: fp16
+    [layers, 2, H, W], the row names its first layer and their number), uint8 [H,W,3] -> uint8 [H,W,3] (rounded between the groups)."""
     cur = np.asarray(src_u8, dtype=np.uint8)
     if p[P_PREINV] != 0:
         cur = 255 - cur
@@ -306,10 +317,15 @@ def staged_source(p, src_u8):
         cur = median_blur(cur, int(p[P_C + 1]))
     elif mode == 3:
         cur = bilateral_blur(cur, int(p[P_C + 1]), float(p[P_C + 2]), float(p[P_C + 3]))
-    return contrast_member(p, cur)
+    cur = contrast_member(p, cur)
+    n, first = int(p[P_W]), int(p[P_W + 1])
+    if overlay is not None and n > 0:
+        for l in range(first, first + n):
+            cur = cloud_blend(cur, overlay[l, 0], overlay[l, 1])
+    return cur
 
 
-def augment_views(img, params, theta, mean, std):
+def augment_views(img, params, theta, mean, std, overlay=None):
     """img uint8 [B,H,W,3], params [B,2,96], theta [B,3,3] -> fp32 [B,3,3,H,W]."""
     f = np.float32
     img = np.asarray(img)
@@ -323,7 +339,7 @@ def augment_views(img, params, theta, mean, std):
 
     for b in range(B):
         out[b, 0] = norm(img[b].astype(f))
-        out[b, 1] = norm(staged_source(params[b, 0], img[b]).astype(f))
+        out[b, 1] = norm(staged_source(params[b, 0], img[b], overlay).astype(f))
         th = theta[b].astype(f)
         xn = f(2) * xs.astype(f) / f(W - 1) - f(1)
         yn = f(2) * ys.astype(f) / f(H - 1) - f(1)
@@ -332,7 +348,7 @@ def augment_views(img, params, theta, mean, std):
         x0, y0 = np.floor(sx), np.floor(sy)
         ax, ay = (sx - x0).astype(f), (sy - y0).astype(f)
         x0, y0 = x0.astype(np.int64), y0.astype(np.int64)
-        col2 = staged_source(params[b, 1], img[b]).astype(f)
+        col2 = staged_source(params[b, 1], img[b], overlay).astype(f)
         acc = np.zeros((H, W, 3), f)
         for dy in (0, 1):
             for dx in (0, 1):

@@ -419,6 +419,18 @@ def check_augment_views(dev, H=32, W=128, seed=52, max_samples=None):
     B = (len(rows) + 1) // 2
     params = np.tile(A.IDENTITY_PARAMS, (B, 2, 1)).astype(np.float32)
     params.reshape(-1, A.AUG_NP)[:len(rows)] = rows
+    # `weather`: cloud layers drawn by the product's host side (ccd_amd/dataset/weather.py) - Fog alone on a plain row, Clouds (one
+    # or two layers) behind a whole chain, Fog on a view-2 row; the blend is what is compared, on the same fp16 planes
+    from ccd_amd.dataset import weather as Wt
+    ov = Wt.Overlays(H, W)
+    flat = params.reshape(-1, A.AUG_NP)
+    wrows = {}
+    for r, layers in ((6, Wt.fog_layers(rs, H, W)), (len(rows) - 2, Wt.clouds_layers(rs, H, W) + Wt.clouds_layers(rs, H, W)[:1]), (9, Wt.fog_layers(rs, H, W))):
+        if r >= len(flat):
+            continue
+        flat[r, A.P_W], flat[r, A.P_W + 1] = len(layers), ov.add(layers)
+        wrows[r] = len(layers)
+    planes = ov.planes()
     img = rs.randint(0, 256, size=(B, H, W, 3)).astype(np.uint8)
     for b in range(B):                                                 # text-like structure under the noise: blocks of colour
         img[b] = (0.35 * img[b] + 0.65 * np.array(rs.randint(0, 256, 3))).astype(np.uint8)
@@ -430,8 +442,12 @@ def check_augment_views(dev, H=32, W=128, seed=52, max_samples=None):
     theta[2] = np.eye(3)
     mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
     got = ops.augment_views(torch.from_numpy(img).to(dev), torch.from_numpy(params).to(dev), torch.from_numpy(theta).to(dev),
-                            mean, std).cpu().numpy()
+                            mean, std, overlay=torch.from_numpy(planes).to(dev)).cpu().numpy()
     assert got.shape == (B, 3, 3, H, W) and np.isfinite(got).all()
+    plain = ops.augment_views(torch.from_numpy(img).to(dev), torch.from_numpy(params).to(dev), torch.from_numpy(theta).to(dev),
+                              mean, std).cpu().numpy()           # without the planes the rows' weather entries are ignored
+    for r in wrows:
+        assert np.abs(got[r // 2, 1 + r % 2] - plain[r // 2, 1 + r % 2]).max() > 0.05, (r, "the cloud layers changed nothing")
     # view 0 is the plain normalised image, exactly
     v0 = ((img.astype(np.float32) * np.float32(1 / 255.0) - np.float32(mean)) * (np.float32(1) / np.float32(std))).transpose(0, 3, 1, 2)
     np.testing.assert_allclose(got[:, 0], v0, rtol=0, atol=1e-6)
@@ -441,7 +457,7 @@ def check_augment_views(dev, H=32, W=128, seed=52, max_samples=None):
     istd255 = 255.0 * np.float32(std)[:, None, None]
     for b in range(B):
         p = params[b, 0]
-        stg = D.staged_source(p, img[b]).astype(np.float32)
+        stg = D.staged_source(p, img[b], planes).astype(np.float32)
         w1 = ((stg * np.float32(1 / 255.0) - np.float32(mean)) / np.float32(std)).transpose(2, 0, 1)
         lvl = np.abs(got[b, 1] - w1) * istd255
         jpeg = int(p[A.P_A]) == A.A_JPEG
@@ -463,11 +479,11 @@ def check_augment_views(dev, H=32, W=128, seed=52, max_samples=None):
     want2 = (warped_ref * np.float32(1 / 255.0) - np.float32(mean)[:, None, None]) / np.float32(std)[:, None, None]
     np.testing.assert_allclose(got[0, 2], want2, rtol=0, atol=2e-4)
     # every sample: view 2 = the warp of ITS staged image (the restated chain of row [b, 1])
-    want = D.augment_views(img, params, theta, mean, std)
+    want = D.augment_views(img, params, theta, mean, std, overlay=planes)
     err = np.abs(got[:, 2] - want[:, 2])
     assert np.quantile(err, 0.995) < 2e-2 and (err > 0.08).mean() < 2e-3, (err.max(), np.quantile(err, 0.995), (err > 0.08).mean())
     # sample 2: identity theta -> view 2 is the augmented image itself
-    stg2 = D.staged_source(params[2, 1], img[2]).astype(np.float32)
+    stg2 = D.staged_source(params[2, 1], img[2], planes).astype(np.float32)
     w2 = ((stg2 * np.float32(1 / 255.0) - np.float32(mean)) / np.float32(std)).transpose(2, 0, 1)
     assert (np.abs(got[2, 2] - w2) * istd255 > 0.5).mean() < 6e-3
 

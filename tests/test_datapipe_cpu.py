@@ -396,3 +396,47 @@ def test_dataset_records_and_collate(tmp_path):
     assert len(half) == 6
     with pytest.raises(AssertionError):
         ImageDatasetSelfSupervisedKmeans(path=root + "_missing", mask_path=mask_root)
+
+
+def test_cloud_layers_host_side():
+    """ccd_amd/dataset/weather.py (imgaug's FrequencyNoise / CloudLayer / Fog / Clouds restated): the bicubic resize against torch's
+    (the same A = -0.75 kernel, half-pixel centres, clamped border), the noise's normalisation and spectrum slope, the maps' ranges
+    and the members' share of the draw in the sampler."""
+    import torch
+    import torch.nn.functional as F
+    from ccd_amd.dataset import augment as A, weather as Wt
+    rs = np.random.RandomState(5)
+    src = rs.rand(8, 8)
+    want = F.interpolate(torch.from_numpy(src)[None, None], size=(32, 128), mode="bicubic", align_corners=False)[0, 0].numpy()
+    np.testing.assert_allclose(Wt.resize_cubic(src, 32, 128), want, atol=1e-6)
+    small = rs.rand(4, 7)
+    want = F.interpolate(torch.from_numpy(small)[None, None], size=(16, 40), mode="bicubic", align_corners=False)[0, 0].numpy()
+    np.testing.assert_allclose(Wt.resize_cubic(small, 16, 40), want, atol=1e-6)
+    # full-resolution frequency noise: exactly 0..1, and smoother (more low-frequency energy) for a more negative exponent
+    n_a, n_b = Wt.frequency_noise(rs, 32, 128, -1.0, 128), Wt.frequency_noise(rs, 32, 128, -3.0, 128)
+    for n in (n_a, n_b):
+        assert n.shape == (32, 128) and n.dtype == np.float32 and n.min() == 0.0 and n.max() == 1.0
+    rough = lambda n: np.abs(np.diff(n, axis=1)).mean()
+    assert rough(n_b) < 0.5 * rough(n_a)
+    low = Wt.frequency_noise(rs, 32, 128, -2.0, 5)                     # generated at 4 x 5, up-sampled through 8 bits
+    assert low.shape == (32, 128) and 0.0 <= low.min() and low.max() <= 1.0 and rough(low) < 0.02
+    for layers, lo_mean in ((Wt.fog_layers(rs, 32, 128), 220.0), (Wt.clouds_layers(rs, 32, 128), 150.0)):
+        assert 1 <= len(layers) <= 2
+        for m in layers:
+            assert m.shape == (2, 32, 128) and 0.0 <= m[0].min() and m[0].max() <= 1.0 and 0.0 <= m[1].min() and m[1].max() <= 255.0
+            assert m[1].mean() > lo_mean - 60.0
+    fog_alpha = np.mean([Wt.fog_layers(rs, 32, 128)[0][0].mean() for _ in range(40)])
+    assert 0.3 < fog_alpha < 0.8, fog_alpha                                # (0.7..0.9 + 0.3 n) ** 0.9 * (0.4..0.9)
+    # the sampler: 0.8 * 0.7 * 2 / 4 = 28 % of the rows carry cloud layers; without a collector none does
+    ov = Wt.Overlays(32, 128)
+    p = A.sample_colour_params(np.random.RandomState(3), 600, 5, overlays=ov)
+    share = (p[:, :, A.P_W] > 0).mean()
+    assert 0.22 < share < 0.34, share
+    planes = ov.planes()
+    assert planes.dtype == np.float16 and planes.shape[1:] == (2, 32, 128)
+    rows = p.reshape(-1, A.AUG_NP)
+    used = rows[rows[:, A.P_W] > 0]
+    assert (used[:, A.P_W + 1] + used[:, A.P_W] <= len(planes)).all() and len(planes) == int(used[:, A.P_W].sum())
+    assert (A.sample_colour_params(np.random.RandomState(3), 200, 5)[:, :, A.P_W] == 0).all()
+    pf, _ = A.sample_finetune_params(np.random.RandomState(1), 800, 32, 128, overlays=Wt.Overlays(32, 128))
+    assert 0.02 < (pf[:, 1, A.P_W] > 0).mean() < 0.08                  # 0.8 * 2 / 35

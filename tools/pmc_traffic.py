@@ -52,8 +52,8 @@ def collect(path, counter):
                     m.group(1), "gemm_row384?") if m else "gemm_row384?"
             elif "gemm_tn384_kernel" in name:                # weight-gradient products (single or paired) of the ViT blocks
                 key = "gemm_tn_atomic"
-            elif "mlp_fused_kernel" in name:                 # fc1 + GELU + fc2 + residual + LayerNorm in one launch
-                key = "mlp_fused"
+            elif "mlp_fused_kernel" in name:                 # fc1 + GELU + fc2 + residual + LayerNorm in one launch; <E, store_u, true>: with
+                key = "proj_mlp_fused" if re.search(r"mlp_fused_kernel<\d+, (true|false), true>", name) else "mlp_fused"   # the projection prologue (round 5)
             elif "rowproj_kernel" in name:                   # K = E bf16 projections with resident activation rows (round 3)
                 key = "gemm_nt_bf16"
             elif "rowgemm_kernel" in name:                   # row-owner products with a row-wise epilogue
