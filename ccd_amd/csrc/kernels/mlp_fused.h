@@ -303,12 +303,15 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
     const float inv_e = 1.0f / (float)E;
     // global traffic of the row tiles goes through buffer descriptors: one per-lane offset register per tensor, the tile /
     // column part of every address in SGPRs, and rows beyond M cost no predicate (loads return 0, stores are dropped)
-    const buf_rsrc rs_y = PROJ ? make_rsrc(p.a, (unsigned)((((long)p.M - 1) * p.lda + E) * 2))
-                               : make_rsrc(p.y, (unsigned)((((long)p.M - 1) * p.ldy_in + E) * 2));
+    // (the descriptors of the tensors that only the row passes touch are built where they are used, on a size the optimiser cannot hoist
+    // - a dozen of them held in scalar registers across the product loops had the allocator spill 122 scalars into vector lanes and read
+    // 16 of them back per weight piece, each a slot of the issue stream the MFMAs share)
+#define MLP_RS_Y (PROJ ? make_rsrc(p.a, opaque_u32((unsigned)((((long)p.M - 1) * p.lda + E) * 2))) \
+                       : make_rsrc(p.y, opaque_u32((unsigned)((((long)p.M - 1) * p.ldy_in + E) * 2))))
+#define MLP_RS_X make_rsrc(p.resid, opaque_u32((unsigned)((((long)p.M - 1) * p.ldr + E) * 4)))
+#define MLP_RS_O make_rsrc(p.out, opaque_u32((unsigned)((((long)p.M - 1) * p.ldc + E) * 4)))
+#define MLP_RS_N make_rsrc(p.ln_y, opaque_u32((unsigned)((((long)p.M - 1) * p.ld_y + E) * 2)))
     const long ld_yin = PROJ ? p.lda : p.ldy_in;
-    const buf_rsrc rs_x = make_rsrc(p.resid, (unsigned)((((long)p.M - 1) * p.ldr + E) * 4));
-    const buf_rsrc rs_o = make_rsrc(p.out, (unsigned)((((long)p.M - 1) * p.ldc + E) * 4));
-    const buf_rsrc rs_n = make_rsrc(p.ln_y, (unsigned)((((long)p.M - 1) * p.ld_y + E) * 2));
     const buf_rsrc rs_u = make_rsrc(STORE_U ? p.u : nullptr, STORE_U ? (unsigned)((((long)p.M - 1) * p.ldu + p.H) * 2) : 0u);
     const bool store_g = STORE_U && p.gact != nullptr;
     const buf_rsrc rs_ga = make_rsrc(store_g ? p.gact : nullptr, store_g ? (unsigned)((((long)p.M - 1) * p.ldga + p.H) * 2) : 0u);
@@ -354,6 +357,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
         auto dead_rows = [&](const buf_rsrc& rs_dst, long ld_dst, const float* ga_, const float* be_, bf16_t* yp, long ldyp,
                              float* meanp, float* rstdp) __attribute__((always_inline)) {
             constexpr int C3 = (E / 4 + 31) / 32;              // 16-byte chunks of a row per lane
+            const buf_rsrc rs_x = MLP_RS_X;
 #pragma unroll 1
             for (int it = 0; it < 16; ++it) {
                 const unsigned rr = (unsigned)(r0 + 2 * it + hf);
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
             }
         };
         if (!PROJ && tile_dead) {
-            dead_rows(rs_o, p.ldc, vga, vbe, p.ln_y, p.ld_y, p.ln_mean, p.ln_rstd);
+            dead_rows(MLP_RS_O, p.ldc, vga, vbe, p.ln_y, p.ld_y, p.ln_mean, p.ln_rstd);
             zero_u();
             continue;
         }
@@ -420,6 +424,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
         bf16x8 yf[KJ];                     // this lane's row of y2 (PROJ: first of the attention output) as B operands: k = 16 j + 8 hf .. + 7
         auto load_rows = [&]() __attribute__((always_inline)) {
             const unsigned so = (unsigned)r0 * (unsigned)(ld_yin * 2), lo_y = LaneOff(t).frag(ld_yin, 2, 8);
+            const buf_rsrc rs_y = MLP_RS_Y;
 #pragma unroll
             for (int j = 0; j < KJ; ++j) yf[j] = __builtin_bit_cast(bf16x8, stream_load16<NT_MLP_Y>(rs_y, lo_y, so + 32 * j));
         };
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                 p2_piece(I1{}, yf[4 * kc], yf[4 * kc + 1], yf[4 * kc + 2], yf[4 * kc + 3]);
             });
             MLP_STAMP(6)
-            pass_a(std::integral_constant<int, 1>{}, rs_x, p.ldr, vbp, sc1_tile);
+            pass_a(std::integral_constant<int, 1>{}, MLP_RS_X, p.ldr, vbp, sc1_tile);
             // the second product accumulates ON x_mid: acc = x_mid / sc2 + b2, x_out = acc * sc2 (a dropped MLP branch, sc2 = 0: the
             // products run on whatever and x_mid is read back at the end)
             sc_fin = tile_dead ? 1.0f : sc_tile;
@@ -604,7 +609,7 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                 const buf_rsrc rs_y2 = make_rsrc(p.y2, (unsigned)((((long)p.M - 1) * p.ldy2 + E) * 2));
                 pass_b(Yes{}, Yes{}, rs_xm, p.ldxm, rs_y2, p.ldy2, vga2, vbe2, p.mean2, p.rstd2);
             } else {
-                pass_b(No{}, Yes{}, rs_o, p.ldc, rs_n, p.ld_y, vga2, vbe2, p.mean2, p.rstd2);
+                pass_b(No{}, Yes{}, MLP_RS_O, p.ldc, MLP_RS_N, p.ld_y, vga2, vbe2, p.mean2, p.rstd2);
             }
             MLP_STAMP(7)
             // (one 32-column tile at a time: left to itself the scheduler reads all 192 accumulators into registers before it writes
@@ -768,15 +773,19 @@ __global__ __launch_bounds__(MLP_THREADS, 1) void mlp_fused_kernel(MlpParams p) 
                     pass_a(std::integral_constant<int, 2>{}, rs_xm, p.ldxm, vb2, 1.0f);
                 }
             } else {
-                pass_a(std::integral_constant<int, 0>{}, rs_x, p.ldr, vb2, sc_fin);
+                pass_a(std::integral_constant<int, 0>{}, MLP_RS_X, p.ldr, vb2, sc_fin);
             }
         } else {
             const float sc = (p.rowscale && !one_sample) ? p.rowscale[grow / p.rows_per_sample] : sc_tile;
-            pass_a(std::integral_constant<int, 1>{}, rs_x, p.ldr, vb2, sc);
+            pass_a(std::integral_constant<int, 1>{}, MLP_RS_X, p.ldr, vb2, sc);
         }
-        pass_b(Yes{}, No{}, rs_o, p.ldc, rs_n, p.ld_y, vga, vbe, p.ln_mean, p.ln_rstd, PROJ && p.tap_y != nullptr);
+        pass_b(Yes{}, No{}, MLP_RS_O, p.ldc, MLP_RS_N, p.ld_y, vga, vbe, p.ln_mean, p.ln_rstd, PROJ && p.tap_y != nullptr);
         MLP_STAMP(7)
     }
+#undef MLP_RS_Y
+#undef MLP_RS_X
+#undef MLP_RS_O
+#undef MLP_RS_N
     glds_wait_all();                       // requested pieces that no tile consumed must not outlive the workgroup's LDS
 #ifdef CCD_MLP_LAB
     if (t == 0)
