@@ -116,11 +116,13 @@ __global__ __launch_bounds__(KM_THREADS) void kmeans2_mask_kernel(const unsigned
 //      1 H += a0 on uint8, saturating (WithColorspace / ChangeColorspace + WithChannels(0, Add))   2 gains a0 * rgb + a1
 //      (MultiplyAndAddToBrightness, approximated in RGB)   3 MultiplyHueAndSaturation (a0, a1; H on imgaug's 0..255 scale,
 //      wrapped modulo 255)   4 AddToHueAndSaturation (a0 = hue shift in H units, a1 = saturation shift)   5 Grayscale (a0 = alpha)
-//      7 UniformColorQuantization (a0 = colours per channel)   8 channel gains a0..a2 (ChangeColorTemperature)   9 ChannelShuffle (a0 = permutation)
+//      6 KMeansColorQuantization (a0 = k: Lloyd's iteration on the 8-bit Lab triples)   7 UniformColorQuantization (a0 = colours per channel)   8 channel gains a0..a2 (ChangeColorTemperature)   9 ChannelShuffle (a0 = permutation)
 //   group `Blur`: p[24] = 0 none | 1 7x7 correlation p[32..80], BORDER_REFLECT_101 (Gaussian / average / motion blur, Sharpen) |
 //      2 median, k = p[25] in {3, 5, 7}, replicated border | 3 bilateral, d = p[25], sigma_color = p[26], sigma_space = p[27]
 //   group `contrast`: p[28] = member, p[29], p[30]: 1 GammaContrast   2 LinearContrast (around 127)   3 SigmoidContrast (gain, cutoff)
-//      4 LogContrast (gain)   6 AllChannelsHistogramEqualization (cv2.equalizeHist per channel); imgaug's tables truncate
+//      4 LogContrast (gain)   6 AllChannelsHistogramEqualization (cv2.equalizeHist per channel)   5 HistogramEqualization (the same on the L
+//      channel of 8-bit Lab)   8 AllChannelsCLAHE (p[29] = clip limit, p[30] = tiles a side: cv2.createCLAHE per channel)   7 CLAHE (on L);
+//      imgaug's tables truncate
 //   group `weather`: p[81] = number of cloud layers (Fog: 1, Clouds: 1 or 2), p[82] = the first one's index among the launch's overlay planes
 //      (fp16 [layers][alpha | intensity][H][W], drawn on the host: ccd_amd/dataset/weather.py): v = trunc(clip((1 - alpha) v + alpha intensity))
 // Members not reproduced keep their share of the draw and leave the image unchanged (the list is in INTEGRATION.md).
@@ -195,7 +197,10 @@ __host__ __device__ inline int aug_pad16(int n) { return (n + 15) / 16 * 16; }
 __host__ __device__ inline long aug_image_bytes(int H, int W) { return (((long)H * W * 3 + 15) / 16) * 16; }
 __host__ __device__ inline long aug_spatial_smem(int H, int W) {
     const long plane = (long)aug_pad16(H) * aug_pad16(W);
-    return 2 * aug_image_bytes(H, W) + 2 * (plane + plane / 2) * 4 + 64 * 4;
+    long work = 2 * (plane + plane / 2) * 4 + 64 * 4;                 // JPEG planes + DCT table
+    const long clahe = 12L * 12 * 256 + 4 * 256 * 4;                   // CLAHE: 144 tile tables + a histogram per wave (same area)
+    if (work < clahe) work = clahe;
+    return 2 * aug_image_bytes(H, W) + work;
 }
 // the pointwise members of `arithmetic` on one channel value; (y, x) = the pixel, k = the channel
 __device__ __forceinline__ float aug_arith_point(const float* __restrict__ p, int op, float v, int y, int x, int k, int H, int W, unsigned seed) {
@@ -245,6 +250,38 @@ __device__ __forceinline__ float aug_arith_point(const float* __restrict__ p, in
     default: return v;
     }
 }
+// RGB <-> CIE L*a*b* on 8-bit values as cv2.COLOR_RGB2Lab / COLOR_Lab2RGB define them for uint8 images (sRGB transfer function, D65 white,
+// L * 255 / 100, a + 128, b + 128) - in float arithmetic; OpenCV's own 8-bit path is a fixed-point approximation of the same formulas
+// and differs from this by a level here and there (stated in INTEGRATION.md: an approximation, unpinned).
+__device__ __forceinline__ float aug_lab_f(float t) { return t > 0.008856f ? cbrtf(t) : 7.787f * t + 16.0f / 116.0f; }
+__device__ __forceinline__ void aug_rgb2lab(int r, int g, int b, int& L, int& A, int& B) {
+    auto lin = [](int c) { const float v = (float)c * (1.0f / 255.f); return v > 0.04045f ? powf((v + 0.055f) * (1.0f / 1.055f), 2.4f) : v * (1.0f / 12.92f); };
+    const float fr = lin(r), fg = lin(g), fb = lin(b);
+    const float X = (0.412453f * fr + 0.357580f * fg + 0.180423f * fb) * (1.0f / 0.950456f);
+    const float Y = 0.212671f * fr + 0.715160f * fg + 0.072169f * fb;
+    const float Z = (0.019334f * fr + 0.119193f * fg + 0.950227f * fb) * (1.0f / 1.088754f);
+    const float fx = aug_lab_f(X), fy = aug_lab_f(Y), fz = aug_lab_f(Z);
+    const float l = Y > 0.008856f ? 116.0f * fy - 16.0f : 903.3f * Y;
+    L = aug_clampi((int)rintf(l * 2.55f), 256);
+    A = aug_clampi((int)rintf(500.0f * (fx - fy) + 128.0f), 256);
+    B = aug_clampi((int)rintf(200.0f * (fy - fz) + 128.0f), 256);
+}
+__device__ __forceinline__ void aug_lab2rgb(int L, int A, int B, int& r, int& g, int& b) {
+    const float l = (float)L * (100.0f / 255.f), a = (float)A - 128.f, bb = (float)B - 128.f;
+    float fy, Y;
+    if (l <= 8.0f) { Y = l * (1.0f / 903.3f); fy = 7.787f * Y + 16.0f / 116.0f; }
+    else { fy = (l + 16.0f) * (1.0f / 116.0f); Y = fy * fy * fy; }
+    const float fx = a * (1.0f / 500.0f) + fy, fz = fy - bb * (1.0f / 200.0f);
+    auto inv = [](float f) { return f <= 0.2068966f ? (f - 16.0f / 116.0f) * (1.0f / 7.787f) : f * f * f; };
+    const float X = inv(fx) * 0.950456f, Z = inv(fz) * 1.088754f;
+    const float fr = 3.240479f * X - 1.53715f * Y - 0.498535f * Z;
+    const float fg = -0.969256f * X + 1.875991f * Y + 0.041556f * Z;
+    const float fb = 0.055648f * X - 0.204043f * Y + 1.057311f * Z;
+    auto gam = [](float v) { v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v); return v > 0.0031308f ? 1.055f * powf(v, 1.0f / 2.4f) - 0.055f : 12.92f * v; };
+    r = aug_clampi((int)rintf(gam(fr) * 255.f), 256); g = aug_clampi((int)rintf(gam(fg) * 255.f), 256); b = aug_clampi((int)rintf(gam(fb) * 255.f), 256);
+}
+constexpr int AUG_CLAHE_MAX_TILES = 12;                 // imgaug draws 3 .. 12 tiles a side
+constexpr long AUG_CLAHE_BYTES = (long)AUG_CLAHE_MAX_TILES * AUG_CLAHE_MAX_TILES * 256 + 4 * 256 * 4;      // tile tables + one histogram per wave
 // one workgroup per (sample, view): img uint8 [B, H, W, 3], params fp32 [B, 2, AUG_NP] -> staged uint8 [B, 2, H, W, 3]
 __global__ __launch_bounds__(256) void augment_spatial_kernel(const unsigned char* __restrict__ img, const float* __restrict__ params,
                                                               unsigned char* __restrict__ staged, int H, int W,
@@ -387,7 +424,115 @@ __global__ __launch_bounds__(256) void augment_spatial_kernel(const unsigned cha
     }
     // ---------------------------------------------------------------- group `color`
     const int opB = (int)p[AUG_P_B];
-    if (opB != 0) {
+    if (opB == 6) {
+        // KMeansColorQuantization (imgaug: quantize_colors_kmeans in 8-bit Lab - to_colorspace = [RGB, Lab] -, cv2.kmeans with random
+        // centres, <= 10 iterations, eps 1.0, one attempt): Lloyd's iteration on the Lab triples.  k = b0 centres start uniformly inside the
+        // data's bounding box widened by a third a side (cv2's generateRandomCenter), an empty cluster takes the point of the most
+        // populous cluster that lies farthest from its centre; every pixel becomes its centre, rounded.  Integer sums per cluster: the
+        // means do not depend on the order of the additions (the numpy restatement reproduces them exactly).  cv2's own RNG stream is
+        // not reproduced (nothing of the reference's augmentation stream is).
+        const int k = aug_clampi((int)p[AUG_P_B + 1], 17) < 2 ? 2 : aug_clampi((int)p[AUG_P_B + 1], 17);
+        unsigned char* label = reinterpret_cast<unsigned char*>(plane);                  // [npix]
+        int* sums = reinterpret_cast<int*>(label + ((npix + 15) / 16) * 16);             // [16][4]: L, a, b sums and the count
+        float* cen = reinterpret_cast<float*>(sums + 64);                                // [16][3]
+        int* box = reinterpret_cast<int*>(cen + 48);                                     // [3][2] min, max; [6] = changed flag
+        float* fard = reinterpret_cast<float*>(box + 8);                                 // [4 waves]: farthest distance / its pixel
+        int* fari = reinterpret_cast<int*>(fard + 4);
+        for (int i = t; i < npix; i += 256) {
+            int L, A, B;
+            aug_rgb2lab(cur[3 * i], cur[3 * i + 1], cur[3 * i + 2], L, A, B);
+            cur[3 * i] = (unsigned char)L; cur[3 * i + 1] = (unsigned char)A; cur[3 * i + 2] = (unsigned char)B;
+        }
+        if (t < 3) { box[2 * t] = 255; box[2 * t + 1] = 0; }
+        __syncthreads();
+        for (int i = t; i < npix * 3; i += 256) { atomicMin(&box[2 * (i % 3)], (int)cur[i]); atomicMax(&box[2 * (i % 3) + 1], (int)cur[i]); }
+        __syncthreads();
+        if (t < 3 * k) {
+            const int j = t / 3, d = t % 3;
+            const float u = aug_u01(aug_hash(seed ^ 0x6b6d6e73u, (unsigned)t));
+            cen[3 * j + d] = (u * (1.0f + 2.0f / 3.0f) - 1.0f / 3.0f) * (float)(box[2 * d + 1] - box[2 * d]) + (float)box[2 * d];
+        }
+        __syncthreads();
+        for (int iter = 0; iter < 10; ++iter) {
+            if (t < 64) sums[t] = 0;
+            __syncthreads();
+            for (int i = t; i < npix; i += 256) {
+                const float x = (float)cur[3 * i], y = (float)cur[3 * i + 1], z = (float)cur[3 * i + 2];
+                int best = 0;
+                float bd = 3.0e38f;
+                for (int j = 0; j < k; ++j) {
+                    const float dx = x - cen[3 * j], dy = y - cen[3 * j + 1], dz = z - cen[3 * j + 2];
+                    const float dd = (dx * dx + dy * dy) + dz * dz;
+                    if (dd < bd) { bd = dd; best = j; }
+                }
+                label[i] = (unsigned char)best;
+                atomicAdd(&sums[4 * best], (int)cur[3 * i]); atomicAdd(&sums[4 * best + 1], (int)cur[3 * i + 1]);
+                atomicAdd(&sums[4 * best + 2], (int)cur[3 * i + 2]); atomicAdd(&sums[4 * best + 3], 1);
+            }
+            __syncthreads();
+            // empty clusters, one at a time in index order: the farthest point of the most populous cluster moves over
+            for (int j = 0; j < k; ++j) {
+                if (sums[4 * j + 3] != 0) continue;                 // (uniform: everybody reads the same counts)
+                int big = 0;
+                for (int q = 1; q < k; ++q) if (sums[4 * q + 3] > sums[4 * big + 3]) big = q;
+                const float c0 = (float)sums[4 * big] / (float)sums[4 * big + 3], c1 = (float)sums[4 * big + 1] / (float)sums[4 * big + 3],
+                            c2 = (float)sums[4 * big + 2] / (float)sums[4 * big + 3];
+                float fd = -1.f;
+                int fi = 0x7fffffff;
+                for (int i = t; i < npix; i += 256)
+                    if (label[i] == big) {
+                        const float dx = (float)cur[3 * i] - c0, dy = (float)cur[3 * i + 1] - c1, dz = (float)cur[3 * i + 2] - c2;
+                        const float dd = (dx * dx + dy * dy) + dz * dz;
+                        if (dd > fd || (dd == fd && i < fi)) { fd = dd; fi = i; }
+                    }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    const float od = shfl_xor(fd, m);
+                    const int oi = shfl_xor(fi, m);
+                    if (od > fd || (od == fd && oi < fi)) { fd = od; fi = oi; }
+                }
+                if ((t & 63) == 0) { fard[t >> 6] = fd; fari[t >> 6] = fi; }
+                __syncthreads();
+                if (t == 0) {
+                    float bd2 = fard[0];
+                    int bi = fari[0];
+                    for (int q = 1; q < 4; ++q) if (fard[q] > bd2 || (fard[q] == bd2 && fari[q] < bi)) { bd2 = fard[q]; bi = fari[q]; }
+                    label[bi] = (unsigned char)j;
+                    for (int d = 0; d < 3; ++d) { sums[4 * big + d] -= (int)cur[3 * bi + d]; sums[4 * j + d] = (int)cur[3 * bi + d]; }
+                    sums[4 * big + 3] -= 1; sums[4 * j + 3] = 1;
+                }
+                __syncthreads();
+            }
+            if (t == 0) box[6] = 0;
+            __syncthreads();
+            if (t < k) {
+                float shift = 0.f;
+                for (int d = 0; d < 3; ++d) {
+                    const float nc = (float)sums[4 * t + d] / (float)sums[4 * t + 3];
+                    const float dd = nc - cen[3 * t + d];
+                    shift += dd * dd;
+                    cen[3 * t + d] = nc;
+                }
+                if (shift > 1.0f) atomicMax(&box[6], 1);           // eps = 1.0 on the centres' squared movement
+            }
+            __syncthreads();
+            if (box[6] == 0) break;
+        }
+        for (int i = t; i < npix; i += 256) {                 // (the labels of the FINAL centres, as cv2.kmeans returns them)
+            const float x = (float)cur[3 * i], y = (float)cur[3 * i + 1], z = (float)cur[3 * i + 2];
+            int j = 0;
+            float bd = 3.0e38f;
+            for (int q = 0; q < k; ++q) {
+                const float dx = x - cen[3 * q], dy = y - cen[3 * q + 1], dz = z - cen[3 * q + 2];
+                const float dd = (dx * dx + dy * dy) + dz * dz;
+                if (dd < bd) { bd = dd; j = q; }
+            }
+            int r, g, b;
+            aug_lab2rgb(aug_clampi((int)rintf(cen[3 * j]), 256), aug_clampi((int)rintf(cen[3 * j + 1]), 256), aug_clampi((int)rintf(cen[3 * j + 2]), 256), r, g, b);
+            cur[3 * i] = (unsigned char)r; cur[3 * i + 1] = (unsigned char)g; cur[3 * i + 2] = (unsigned char)b;
+        }
+        __syncthreads();
+    } else if (opB != 0) {
         const float b0 = p[AUG_P_B + 1], b1 = p[AUG_P_B + 2], b2 = p[AUG_P_B + 3];
         for (int i = t; i < npix; i += 256) {
             int r = cur[i * 3], g = cur[i * 3 + 1], bl = cur[i * 3 + 2];
@@ -501,33 +646,141 @@ __global__ __launch_bounds__(256) void augment_spatial_kernel(const unsigned cha
             cur[i] = aug_trunc_u8(o);
         }
         __syncthreads();
-    } else if (opD == 6) {                                   // cv2.equalizeHist on each channel
-        int* hist = reinterpret_cast<int*>(plane);           // [3][256]
-        unsigned char* lut = reinterpret_cast<unsigned char*>(hist + 768);
-        for (int i = t; i < 768; i += 256) hist[i] = 0;
-        __syncthreads();
-        for (int i = t; i < npix * 3; i += 256) atomicAdd(&hist[(i % 3) * 256 + cur[i]], 1);
-        __syncthreads();
-        if (t < 3) {
-            const int* hc = hist + 256 * t;
-            unsigned char* lc = lut + 256 * t;
-            int i0 = 0;
-            while (hc[i0] == 0) ++i0;
-            if (hc[i0] == npix) {
-                for (int i = 0; i < 256; ++i) lc[i] = (unsigned char)i0;
-            } else {
-                const float scale = 255.f / (float)(npix - hc[i0]);
-                int sum = 0;
-                for (int i = 0; i <= i0; ++i) lc[i] = 0;
-                for (int i = i0 + 1; i < 256; ++i) {
-                    sum += hc[i];
-                    lc[i] = (unsigned char)aug_clampi((int)rintf((float)sum * scale), 256);
+    } else if (opD >= 5 && opD <= 8) {
+        // 5 HistogramEqualization / 7 CLAHE: on the L channel of cv2's 8-bit Lab; 6 AllChannelsHistogramEqualization / 8 AllChannelsCLAHE:
+        // on every channel of the RGB image
+        const bool lab = opD == 5 || opD == 7;
+        const int nch = lab ? 1 : 3;
+        if (lab) {
+            for (int i = t; i < npix; i += 256) {
+                int L, A, B;
+                aug_rgb2lab(cur[3 * i], cur[3 * i + 1], cur[3 * i + 2], L, A, B);
+                cur[3 * i] = (unsigned char)L; cur[3 * i + 1] = (unsigned char)A; cur[3 * i + 2] = (unsigned char)B;
+            }
+            __syncthreads();
+        }
+        if (opD <= 6) {                                      // cv2.equalizeHist per channel
+            int* hist = reinterpret_cast<int*>(plane);           // [3][256]
+            unsigned char* lut = reinterpret_cast<unsigned char*>(hist + 768);
+            for (int i = t; i < 768; i += 256) hist[i] = 0;
+            __syncthreads();
+            for (int i = t; i < npix * 3; i += 256)
+                if (i % 3 < nch) atomicAdd(&hist[(i % 3) * 256 + cur[i]], 1);
+            __syncthreads();
+            if (t < nch) {
+                const int* hc = hist + 256 * t;
+                unsigned char* lc = lut + 256 * t;
+                int i0 = 0;
+                while (hc[i0] == 0) ++i0;
+                if (hc[i0] == npix) {
+                    for (int i = 0; i < 256; ++i) lc[i] = (unsigned char)i0;
+                } else {
+                    const float scale = 255.f / (float)(npix - hc[i0]);
+                    int sum = 0;
+                    for (int i = 0; i <= i0; ++i) lc[i] = 0;
+                    for (int i = i0 + 1; i < 256; ++i) {
+                        sum += hc[i];
+                        lc[i] = (unsigned char)aug_clampi((int)rintf((float)sum * scale), 256);
+                    }
                 }
             }
+            __syncthreads();
+            for (int i = t; i < npix * 3; i += 256)
+                if (i % 3 < nch) cur[i] = lut[(i % 3) * 256 + cur[i]];
+            __syncthreads();
+        } else {
+            // cv2.createCLAHE(clipLimit, tileGridSize = (n, n)).apply(channel) (modules/imgproc/src/clahe.cpp): the image padded to whole
+            // tiles (BORDER_REFLECT_101), per tile a clipped histogram whose excess is spread over all bins, its cumulative table, and
+            // bilinear interpolation between the four nearest tiles' tables.  One wave per tile, four bins per lane.
+            const float clip = p[AUG_P_D + 1];
+            int tn = (int)p[AUG_P_D + 2];
+            tn = tn < 1 ? 1 : (tn > AUG_CLAHE_MAX_TILES ? AUG_CLAHE_MAX_TILES : tn);
+            const bool whole = (W % tn == 0) && (H % tn == 0);
+            const int We = whole ? W : W + (tn - W % tn), He = whole ? H : H + (tn - H % tn);
+            const int tw = We / tn, th = He / tn, area = tw * th;
+            int climit = 0;
+            if (clip > 0.f) { climit = (int)(clip * (float)area / 256.f); climit = climit < 1 ? 1 : climit; }
+            const float lut_scale = 255.f / (float)area;
+            unsigned char* luts = reinterpret_cast<unsigned char*>(plane);                       // [tn * tn][256]
+            int* whist = reinterpret_cast<int*>(luts + AUG_CLAHE_MAX_TILES * AUG_CLAHE_MAX_TILES * 256) + (t >> 6) * 256;
+            const int lane = t & 63, wave = t >> 6;
+            for (int c = 0; c < nch; ++c) {
+                for (int tile = wave; tile < tn * tn; tile += 4) {
+                    const int ty = tile / tn, tx = tile % tn;
+                    for (int i = lane; i < 256; i += 64) whist[i] = 0;
+                    wave_lds_fence();
+                    for (int i = lane; i < area; i += 64) {
+                        const int y = aug_reflect101(ty * th + i / tw, H), x = aug_reflect101(tx * tw + i % tw, W);
+                        atomicAdd(&whist[cur[(y * W + x) * 3 + c]], 1);
+                    }
+                    wave_lds_fence();
+                    int hv[4], clipped = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        hv[j] = whist[4 * lane + j];
+                        if (climit > 0 && hv[j] > climit) { clipped += hv[j] - climit; hv[j] = climit; }
+                    }
+                    if (climit > 0) {
+#pragma unroll
+                        for (int m = 32; m >= 1; m >>= 1) clipped += shfl_xor(clipped, m);
+                        const int batch = clipped / 256;
+                        int residual = clipped - batch * 256;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) hv[j] += batch;
+                        if (residual != 0) {
+                            int step = 256 / residual;
+                            step = step < 1 ? 1 : step;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int bin = 4 * lane + j;
+                                if (bin % step == 0 && bin / step < residual) hv[j] += 1;
+                            }
+                        }
+                    }
+                    // cumulative sums over the 256 bins: four per lane, then a scan over the lanes
+                    const int own = hv[0] + hv[1] + hv[2] + hv[3];
+                    int incl = own;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const int up = shfl(incl, lane - d < 0 ? lane : lane - d);
+                        if (lane >= d) incl += up;
+                    }
+                    int run = incl - own;
+                    unsigned char* lt = luts + tile * 256;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        run += hv[j];
+                        lt[4 * lane + j] = (unsigned char)aug_clampi((int)rintf((float)run * lut_scale), 256);
+                    }
+                    wave_lds_fence();
+                }
+                __syncthreads();
+                const float inv_tw = 1.0f / (float)tw, inv_th = 1.0f / (float)th;
+                for (int i = t; i < npix; i += 256) {
+                    const int y = i / W, x = i % W, v = cur[i * 3 + c];
+                    const float tyf = (float)y * inv_th - 0.5f, txf = (float)x * inv_tw - 0.5f;
+                    int ty1 = (int)floorf(tyf), tx1 = (int)floorf(txf);
+                    const float ya = tyf - (float)ty1, xa = txf - (float)tx1;
+                    int ty2 = ty1 + 1, tx2 = tx1 + 1;
+                    ty1 = ty1 < 0 ? 0 : ty1; tx1 = tx1 < 0 ? 0 : tx1;
+                    ty2 = ty2 > tn - 1 ? tn - 1 : ty2; tx2 = tx2 > tn - 1 ? tn - 1 : tx2;
+                    const float r0 = (float)luts[(ty1 * tn + tx1) * 256 + v] * (1.0f - xa) + (float)luts[(ty1 * tn + tx2) * 256 + v] * xa;
+                    const float r1 = (float)luts[(ty2 * tn + tx1) * 256 + v] * (1.0f - xa) + (float)luts[(ty2 * tn + tx2) * 256 + v] * xa;
+                    alt[i] = (unsigned char)aug_clampi((int)rintf(r0 * (1.0f - ya) + r1 * ya), 256);
+                }
+                __syncthreads();
+                for (int i = t; i < npix; i += 256) cur[i * 3 + c] = alt[i];
+                __syncthreads();
+            }
         }
-        __syncthreads();
-        for (int i = t; i < npix * 3; i += 256) cur[i] = lut[(i % 3) * 256 + cur[i]];
-        __syncthreads();
+        if (lab) {
+            for (int i = t; i < npix; i += 256) {
+                int r, g, b;
+                aug_lab2rgb(cur[3 * i], cur[3 * i + 1], cur[3 * i + 2], r, g, b);
+                cur[3 * i] = (unsigned char)r; cur[3 * i + 1] = (unsigned char)g; cur[3 * i + 2] = (unsigned char)b;
+            }
+            __syncthreads();
+        }
     }
     // ---------------------------------------------------------------- group `weather`: cloud layers (Fog / Clouds), one after the other
     const int nlay = (int)p[AUG_P_W], lay0 = (int)p[AUG_P_W + 1];

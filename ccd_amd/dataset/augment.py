@@ -7,7 +7,7 @@ to view 2 with probability 0.7 (datasetsupervised_kmeans.py:40-45,60), and `thet
 factors cancel when the augmentation runs at the network resolution, which it does here).  A sample whose 0.7 draw fails
 gets the PLAIN image as view 2 (:72-74): its colour parameters are the identity.
 
-Colour = the reference's imgaug chain: its member LISTS and probabilities, 44 of its 50 members reproduced (the other six - listed
+Colour = the reference's imgaug chain: its member LISTS and probabilities, 48 of its 50 members reproduced (the other two - listed
 below - are drawn and leave the image unchanged, so the augmentation distribution is WEAKER than the reference's; README parity
 claims say so) (augmentation_pipelines.py:120-205,
 severity 5 - what the shipped pretraining configs select; dataset_pretrain.py:79-158 for finetuning): `Sometimes(0.2, Identity,
@@ -20,8 +20,9 @@ FilterContour; the HSV hue shifts, MultiplyAndAddToBrightness (in RGB), Multiply
 Grayscale, UniformColorQuantization, ChangeColorTemperature (as channel gains); Sharpen and the five blurs; Gamma / Linear /
 Sigmoid / Log contrast, AllChannelsHistogramEqualization; Fog and Clouds (round 5: cloud layers drawn on the host - weather.py - and
 blended on the device).
-NOT reproduced - the draw that selects them leaves the image unchanged: KMeansColorQuantization,
-HistogramEqualization / CLAHE / AllChannelsCLAHE (Lab-space or tiled equalisation), Snowflakes, Rain, PiecewiseAffine (finetuning
+HistogramEqualization / CLAHE (the L channel of 8-bit Lab, float formulas) and AllChannelsCLAHE (round 5: OpenCV's tile algorithm).
+KMeansColorQuantization (round 5: Lloyd's iteration on the Lab triples, cv2.kmeans' rules).
+NOT reproduced - the draw that selects them leaves the image unchanged: Snowflakes, Rain, PiecewiseAffine (finetuning
 geometry); severity 2's ElasticTransformation / PerspectiveTransform (no shipped config).
 """
 from __future__ import annotations
@@ -36,7 +37,7 @@ A_ADD_ELEM, A_GAUSS, A_LAPLACE, A_POISSON, A_MUL, A_MUL_ELEM, A_DROPOUT, A_COARS
     A_JPEG, A_FILTER, A_PILFILTER = range(1, 16)
 B_HUE_ADD, B_BRIGHT, B_MUL_HS, B_ADD_HS, B_GRAY, B_KMEANS, B_UNIFORM_Q, B_GAINS, B_SHUFFLE = range(1, 10)
 C_FILTER, C_MEDIAN, C_BILATERAL = 1, 2, 3
-D_GAMMA, D_LINEAR, D_SIGMOID, D_LOG, D_HISTEQ_LAB, D_HISTEQ_ALL = 1, 2, 3, 4, 5, 6
+D_GAMMA, D_LINEAR, D_SIGMOID, D_LOG, D_HISTEQ_LAB, D_HISTEQ_ALL, D_CLAHE_LAB, D_CLAHE_ALL = 1, 2, 3, 4, 5, 6, 7, 8
 IDENTITY_PARAMS = np.zeros(AUG_NP, dtype=np.float32)
 _NOCHANGE = np.array([[0, 0, 0], [0, 1, 0], [0, 0, 0]], dtype=np.float64)
 
@@ -230,8 +231,8 @@ def _colour_member(p, rs, name):
         p[b], p[b + 1], p[b + 2] = B_ADD_HS, int(vh / 255.0 * 180.0), vs
     elif name == "Grayscale":
         p[b], p[b + 1] = B_GRAY, rs.uniform(0.0, 1.0)
-    elif name == "KMeansColorQuantization":
-        pass                                      # not reproduced
+    elif name == "KMeansColorQuantization":       # n_colors = (2, 16): Lloyd's iteration on the 8-bit Lab triples, on the device
+        p[b], p[b + 1] = B_KMEANS, rs.randint(2, 17)
     elif name == "UniformColorQuantization":      # n_colors = (2, 16)
         p[b], p[b + 1] = B_UNIFORM_Q, rs.randint(2, 17)
     elif name == "ChangeColorTemperature":        # 1100 .. 10000 K as warm <-> cool channel gains
@@ -279,9 +280,13 @@ def _contrast_member(p, rs):
         p[d], p[d + 1], p[d + 2] = D_SIGMOID, rs.uniform(3, 10), rs.uniform(0.4, 0.6)
     elif k == 3:
         p[d], p[d + 1] = D_LOG, rs.uniform(0.6, 1.4)
+    elif k == 4:
+        p[d] = D_HISTEQ_LAB                       # HistogramEqualization: equalizeHist on the L channel of 8-bit Lab
     elif k == 5:
         p[d] = D_HISTEQ_ALL
-    # 4, 6, 7: HistogramEqualization / CLAHE (Lab intensity channel), AllChannelsCLAHE: not reproduced
+    else:                                         # CLAHE (k = 6: on L of Lab) / AllChannelsCLAHE (k = 7): clip_limit (0.1, 8), tile_grid_size_px (3, 12)
+        p[d] = D_CLAHE_LAB if k == 6 else D_CLAHE_ALL     # - one draw for both sides; imgaug hands it to cv2 as the NUMBER of tiles a side
+        p[d + 1], p[d + 2] = rs.uniform(0.1, 8.0), rs.randint(3, 13)
 
 
 ARITHMETIC_5 = ["AddElementwise", "AdditiveGaussianNoise", "AdditiveLaplaceNoise", "AdditivePoissonNoise", "Multiply",

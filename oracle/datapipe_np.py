@@ -229,6 +229,8 @@ def colour_member(p, img):
             h = np.mod(h + int(b0), 180)
             s = np.clip(s + int(b1), 0, 255)
         return hsv_to_rgb_cv(np.stack([h, s, v], -1))
+    if op == 6:
+        return kmeans_quantize(img, int(b0), int(p[P_SEED]))
     c = img.astype(f)
     if op == 2:
         return _round_u8(c * b0 + b1)
@@ -250,6 +252,56 @@ def colour_member(p, img):
     return img
 
 
+def kmeans_quantize(img, k, seed):
+    """KMeansColorQuantization (imgaug.augmenters.color.quantize_colors_kmeans in 8-bit Lab; cv2.kmeans: random centres inside the data's
+    bounding box widened by 1/3 a side, <= 10 Lloyd iterations, stop when no centre moves by more than eps = 1 (squared), an empty cluster
+    takes the farthest point of the most populous one; labels of the final centres) - the device's counter-based draws for the centres."""
+    f = np.float32
+    k = min(max(int(k), 2), 16)
+    lab = rgb_to_lab_u8(img)
+    pts = lab.reshape(-1, 3).astype(np.int64)
+    x = pts.astype(f)
+    lo, hi = pts.min(0), pts.max(0)
+    cen = np.zeros((k, 3), f)
+    for t in range(3 * k):
+        j, d = t // 3, t % 3
+        u = _u01(_hash(np.uint32(seed) ^ np.uint32(0x6b6d6e73), np.uint32(t)))
+        cen[j, d] = (f(u) * (f(1.0) + f(2.0) / f(3.0)) - f(1.0) / f(3.0)) * f(hi[d] - lo[d]) + f(lo[d])
+
+    def assign(c):
+        d = x[:, None, :] - c[None, :, :]
+        dd = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+        return np.argmin(dd, axis=1)
+
+    for _ in range(10):
+        label = assign(cen)
+        sums = np.zeros((k, 3), np.int64)
+        cnt = np.zeros(k, np.int64)
+        np.add.at(sums, label, pts)
+        np.add.at(cnt, label, 1)
+        for j in range(k):
+            if cnt[j] != 0:
+                continue
+            big = int(np.argmax(cnt))                                  # (first of the most populous ones)
+            c = (sums[big].astype(f) / f(cnt[big])).astype(f)
+            idx = np.nonzero(label == big)[0]
+            d = x[idx] - c[None]
+            dd = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            bi = idx[int(np.argmax(dd))]                               # (the first of the farthest ones)
+            label[bi] = j
+            sums[big] -= pts[bi]; cnt[big] -= 1
+            sums[j] = pts[bi]; cnt[j] = 1
+        new = (sums.astype(f) / cnt.astype(f)[:, None]).astype(f)
+        dlt = new - cen
+        shift = (dlt[:, 0] * dlt[:, 0] + dlt[:, 1] * dlt[:, 1]) + dlt[:, 2] * dlt[:, 2]
+        cen = new
+        if not (shift > f(1.0)).any():
+            break
+    label = assign(cen)
+    q = np.clip(np.rint(cen), 0, 255).astype(np.uint8)
+    return lab_to_rgb_u8(q[label].reshape(lab.shape))
+
+
 def equalize_hist_cv(channel):
     """cv2.equalizeHist on one uint8 channel: the first occupied bin maps to 0, lut[i] = round(cumsum beyond it * 255 / (total - its count))."""
     ch = np.asarray(channel, np.uint8)
@@ -261,6 +313,91 @@ def equalize_hist_cv(channel):
     csum = np.cumsum(np.where(np.arange(256) > i0, hist, 0))
     lut = np.clip(np.rint(csum.astype(np.float32) * scale), 0, 255).astype(np.uint8)
     return lut[ch]
+
+
+def rgb_to_lab_u8(img):
+    """cv2.COLOR_RGB2Lab on uint8 as its documentation defines it (sRGB transfer function, D65, L * 255 / 100, a + 128, b + 128), in float32
+    (OpenCV's 8-bit path is a fixed-point approximation of these formulas: unpinned, a level of difference here and there)."""
+    f = np.float32
+    v = np.asarray(img, np.uint8).astype(f) * f(1.0 / 255.0)
+    lin = np.where(v > f(0.04045), np.power((v + f(0.055)) * f(1.0 / 1.055), f(2.4)).astype(f), v * f(1.0 / 12.92)).astype(f)
+    r, g, b = lin[..., 0], lin[..., 1], lin[..., 2]
+    X = (f(0.412453) * r + f(0.357580) * g + f(0.180423) * b) * f(1.0 / 0.950456)
+    Y = f(0.212671) * r + f(0.715160) * g + f(0.072169) * b
+    Z = (f(0.019334) * r + f(0.119193) * g + f(0.950227) * b) * f(1.0 / 1.088754)
+    fn = lambda t: np.where(t > f(0.008856), np.cbrt(t).astype(f), f(7.787) * t + f(16.0 / 116.0)).astype(f)
+    fx, fy, fz = fn(X), fn(Y), fn(Z)
+    L = np.where(Y > f(0.008856), f(116.0) * fy - f(16.0), f(903.3) * Y).astype(f)
+    out = np.stack([np.rint(L * f(2.55)), np.rint(f(500.0) * (fx - fy) + f(128.0)), np.rint(f(200.0) * (fy - fz) + f(128.0))], -1)
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def lab_to_rgb_u8(lab):
+    f = np.float32
+    lab = np.asarray(lab, np.uint8).astype(f)
+    l, a, b = lab[..., 0] * f(100.0 / 255.0), lab[..., 1] - f(128), lab[..., 2] - f(128)
+    low = l <= f(8.0)
+    Y_low = l * f(1.0 / 903.3)
+    fy = np.where(low, f(7.787) * Y_low + f(16.0 / 116.0), (l + f(16.0)) * f(1.0 / 116.0)).astype(f)
+    Y = np.where(low, Y_low, fy * fy * fy).astype(f)
+    fx, fz = a * f(1.0 / 500.0) + fy, fy - b * f(1.0 / 200.0)
+    inv = lambda t: np.where(t <= f(0.2068966), (t - f(16.0 / 116.0)) * f(1.0 / 7.787), t * t * t).astype(f)
+    X, Z = inv(fx) * f(0.950456), inv(fz) * f(1.088754)
+    r = f(3.240479) * X - f(1.53715) * Y - f(0.498535) * Z
+    g = f(-0.969256) * X + f(1.875991) * Y + f(0.041556) * Z
+    bl = f(0.055648) * X - f(0.204043) * Y + f(1.057311) * Z
+
+    def gam(v):
+        v = np.clip(v, f(0), f(1)).astype(f)
+        return np.where(v > f(0.0031308), f(1.055) * np.power(v, f(1.0 / 2.4)).astype(f) - f(0.055), f(12.92) * v).astype(f)
+
+    out = np.stack([np.rint(gam(r) * f(255)), np.rint(gam(g) * f(255)), np.rint(gam(bl) * f(255))], -1)
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def clahe_cv(channel, clip, tn):
+    """cv2.createCLAHE(clipLimit=clip, tileGridSize=(tn, tn)).apply(channel) on one uint8 channel (modules/imgproc/src/clahe.cpp): pad to
+    whole tiles (BORDER_REFLECT_101; BOTH sides get a remainder's worth when either does not divide), per tile clip the histogram at
+    max(1, int(clip * area / 256)), spread the excess (whole batches over all bins, the residual one by one at a stride), cumulative
+    table * 255 / area rounded; every pixel interpolates the tables of its four nearest tiles."""
+    f = np.float32
+    ch = np.asarray(channel, np.uint8)
+    H, W = ch.shape
+    whole = W % tn == 0 and H % tn == 0
+    We, He = (W, H) if whole else (W + (tn - W % tn), H + (tn - H % tn))
+    tw, th = We // tn, He // tn
+    area = tw * th
+    ys = np.array([reflect101(np.array([y]), H)[0] for y in range(He)])
+    xs = np.array([reflect101(np.array([x]), W)[0] for x in range(We)])
+    ext = ch[ys][:, xs]
+    climit = max(1, int(f(clip) * f(area) / f(256.0))) if clip > 0 else 0
+    scale = f(255.0) / f(area)
+    luts = np.zeros((tn, tn, 256), np.uint8)
+    for ty in range(tn):
+        for tx in range(tn):
+            hist = np.bincount(ext[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw].reshape(-1), minlength=256).astype(np.int64)
+            if climit > 0:
+                clipped = int(np.maximum(hist - climit, 0).sum())
+                hist = np.minimum(hist, climit)
+                batch = clipped // 256
+                residual = clipped - batch * 256
+                hist = hist + batch
+                if residual:
+                    step = max(256 // residual, 1)
+                    idx = np.arange(0, 256, step)[:residual]
+                    hist[idx] += 1
+            luts[ty, tx] = np.clip(np.rint(np.cumsum(hist).astype(f) * scale), 0, 255).astype(np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    tyf = yy.astype(f) * (f(1.0) / f(th)) - f(0.5)
+    txf = xx.astype(f) * (f(1.0) / f(tw)) - f(0.5)
+    ty1, tx1 = np.floor(tyf).astype(np.int64), np.floor(txf).astype(np.int64)
+    ya, xa = (tyf - ty1.astype(f)).astype(f), (txf - tx1.astype(f)).astype(f)
+    ty2, tx2 = np.minimum(ty1 + 1, tn - 1), np.minimum(tx1 + 1, tn - 1)
+    ty1, tx1 = np.maximum(ty1, 0), np.maximum(tx1, 0)
+    v = ch.astype(np.int64)
+    r0 = luts[ty1, tx1, v].astype(f) * (f(1) - xa) + luts[ty1, tx2, v].astype(f) * xa
+    r1 = luts[ty2, tx1, v].astype(f) * (f(1) - xa) + luts[ty2, tx2, v].astype(f) * xa
+    return np.clip(np.rint(r0 * (f(1) - ya) + r1 * ya), 0, 255).astype(np.uint8)
 
 
 def contrast_member(p, img):
@@ -280,6 +417,12 @@ def contrast_member(p, img):
         return _trunc_u8(f(255) * d0 * np.log2(f(1) + u).astype(f))
     if op == 6:
         return np.stack([equalize_hist_cv(img[..., k]) for k in range(3)], -1)
+    if op == 8:
+        return np.stack([clahe_cv(img[..., k], float(d0), int(d1)) for k in range(3)], -1)
+    if op in (5, 7):               # the L channel of 8-bit Lab (HistogramEqualization / CLAHE)
+        lab = rgb_to_lab_u8(img)
+        lab[..., 0] = equalize_hist_cv(lab[..., 0]) if op == 5 else clahe_cv(lab[..., 0], float(d0), int(d1))
+        return lab_to_rgb_u8(lab)
     return img
 
 

