@@ -123,8 +123,9 @@ __global__ __launch_bounds__(KM_THREADS) void kmeans2_mask_kernel(const unsigned
 //      4 LogContrast (gain)   6 AllChannelsHistogramEqualization (cv2.equalizeHist per channel)   5 HistogramEqualization (the same on the L
 //      channel of 8-bit Lab)   8 AllChannelsCLAHE (p[29] = clip limit, p[30] = tiles a side: cv2.createCLAHE per channel)   7 CLAHE (on L);
 //      imgaug's tables truncate
-//   group `weather`: p[81] = number of cloud layers (Fog: 1, Clouds: 1 or 2), p[82] = the first one's index among the launch's overlay planes
-//      (fp16 [layers][alpha | intensity][H][W], drawn on the host: ccd_amd/dataset/weather.py): v = trunc(clip((1 - alpha) v + alpha intensity))
+//   group `weather`: p[81] = number of layers (Fog: 1, Clouds: 1 - 2, Snowflakes / Rain: 1 - 3), p[82] = the first one's index among the launch's overlay
+//      planes (fp16 [layers][2][H][W], drawn on the host: ccd_amd/dataset/weather.py), p[83] = blend: 0 cloud / rain, v = trunc(clip((1 - plane0) v +
+//      plane0 * plane1)); 1 snow, v = round(max(clip(v + plane0), plane1))
 // Members not reproduced keep their share of the draw and leave the image unchanged (the list is in INTEGRATION.md).
 constexpr int AUG_NP = 96;
 constexpr int AUG_P_SEED = 0, AUG_P_PREINV = 1, AUG_P_A = 2, AUG_P_AK = 9, AUG_P_B = 18, AUG_P_C = 24, AUG_P_D = 28, AUG_P_KERN = 32, AUG_P_W = 81;
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(256) void augment_spatial_kernel(const unsigned cha
         }
     }
     // ---------------------------------------------------------------- group `weather`: cloud layers (Fog / Clouds), one after the other
-    const int nlay = (int)p[AUG_P_W], lay0 = (int)p[AUG_P_W + 1];
+    const int nlay = (int)p[AUG_P_W], lay0 = (int)p[AUG_P_W + 1], snow = (int)p[AUG_P_W + 2];
     if (overlay && nlay > 0 && lay0 >= 0 && lay0 + nlay <= overlay_layers) {
         for (int l = 0; l < nlay; ++l) {
             const unsigned short* al = overlay + (long)(lay0 + l) * 2 * npix;
@@ -792,8 +793,14 @@ __global__ __launch_bounds__(256) void augment_spatial_kernel(const unsigned cha
                 const float a = half2f(al[i]), it = half2f(in[i]);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const float v = (1.0f - a) * (float)cur[i * 3 + k] + a * it;
-                    cur[i * 3 + k] = aug_trunc_u8(v);
+                    const float c = (float)cur[i * 3 + k];
+                    if (snow) {              // SnowflakesLayer: blend by sum (plane 0), then by maximum (plane 1)
+                        float v = c + a;
+                        v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+                        cur[i * 3 + k] = aug_round_u8(v > it ? v : it);
+                    } else {                 // CloudLayer / RainLayer: alpha (plane 0) towards an intensity (plane 1)
+                        cur[i * 3 + k] = aug_trunc_u8((1.0f - a) * c + a * it);
+                    }
                 }
             }
             __syncthreads();

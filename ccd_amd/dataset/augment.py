@@ -7,7 +7,7 @@ to view 2 with probability 0.7 (datasetsupervised_kmeans.py:40-45,60), and `thet
 factors cancel when the augmentation runs at the network resolution, which it does here).  A sample whose 0.7 draw fails
 gets the PLAIN image as view 2 (:72-74): its colour parameters are the identity.
 
-Colour = the reference's imgaug chain: its member LISTS and probabilities, 48 of its 50 members reproduced (the other two - listed
+Colour = the reference's imgaug chain: its member LISTS and probabilities, all 50 members of the pretraining chain reproduced (the finetuning geometry's PiecewiseAffine is not - listed
 below - are drawn and leave the image unchanged, so the augmentation distribution is WEAKER than the reference's; README parity
 claims say so) (augmentation_pipelines.py:120-205,
 severity 5 - what the shipped pretraining configs select; dataset_pretrain.py:79-158 for finetuning): `Sometimes(0.2, Identity,
@@ -22,8 +22,8 @@ Sigmoid / Log contrast, AllChannelsHistogramEqualization; Fog and Clouds (round 
 blended on the device).
 HistogramEqualization / CLAHE (the L channel of 8-bit Lab, float formulas) and AllChannelsCLAHE (round 5: OpenCV's tile algorithm).
 KMeansColorQuantization (round 5: Lloyd's iteration on the Lab triples, cv2.kmeans' rules).
-NOT reproduced - the draw that selects them leaves the image unchanged: Snowflakes, Rain, PiecewiseAffine (finetuning
-geometry); severity 2's ElasticTransformation / PerspectiveTransform (no shipped config).
+Snowflakes and Rain (round 5: salt noise on a shrunk canvas, gated, up-sampled, blurred, motion-smeared - on the host like the clouds).
+NOT reproduced - the draw that selects it leaves the image unchanged: PiecewiseAffine (finetuning geometry); severity 2's ElasticTransformation / PerspectiveTransform (no shipped config).
 """
 from __future__ import annotations
 
@@ -302,18 +302,20 @@ FINETUNE_ONE_OF = (["ChannelShuffle", "AddElementwise", "AdditiveGaussianNoise",
                     "MultiplyHueAndSaturation", "AddToHueAndSaturation", "HueAdd50_100", "Grayscale", "KMeansColorQuantization",
                     "UniformColorQuantization", "ChangeColorTemperature", "Fog", "Clouds", "Snowflakes", "Rain"])   # dataset_pretrain.py:86-121
 _COLOUR_NAMES = set(COLOR_5) | {"MultiplyBrightness", "ChannelShuffle"}
-_WEATHER = {"Fog", "Clouds", "Snowflakes", "Rain"}                                      # Fog / Clouds: cloud layers; the others not reproduced
+_WEATHER = {"Fog", "Clouds", "Snowflakes", "Rain"}                                      # layers drawn on the host (weather.py)
 
 
 def _weather_member(p, rs, name, h, w, overlays):
-    """`weather`: Fog / Clouds = cloud layers generated HERE (ccd_amd/dataset/weather.py) and blended on the device: the row names the
-    first of its layers among the batch's overlay planes and their number.  Snowflakes / Rain: not reproduced.  Without a collector
-    (`overlays` None: a caller that does not ship overlay planes) nothing is drawn."""
-    if overlays is None or name not in ("Fog", "Clouds"):
+    """`weather`: the layers of Fog / Clouds / Snowflakes / Rain are generated HERE (ccd_amd/dataset/weather.py) and blended on the
+    device: the row names the first of its layers among the batch's overlay planes, their number and the blend (cloud / rain: alpha
+    towards an intensity; snow: add, then raise).  Without a collector (`overlays` None: a caller that does not ship overlay planes)
+    nothing is drawn."""
+    if overlays is None:
         return
     from . import weather
-    layers = weather.fog_layers(rs, h, w) if name == "Fog" else weather.clouds_layers(rs, h, w)
-    p[P_W], p[P_W + 1] = len(layers), overlays.add(layers)
+    # (-1, task id, blend) until Overlays.resolve() has the layers: then (their number, the first one's index, blend)
+    p[P_W], p[P_W + 1] = -1, overlays.add_task(name, rs.randint(0, 1 << 31))
+    p[P_W + 2] = weather.SNOW_MODE if name == "Snowflakes" else weather.CLOUD_MODE      # how the device blends the planes
 
 
 WEATHER_5 = ["Fog", "Clouds", "Snowflakes", "Rain"]                                    # augmentation_pipelines.py:192-195
@@ -345,17 +347,23 @@ def _colour_params(rs: np.random.RandomState, severity: int, h: int = 32, w: int
 
 
 def sample_colour_params(rs: np.random.RandomState, batch: int, severity: int = 5, warped=None, h: int = 32,
-                         w: int = 128, overlays=None) -> np.ndarray:
+                         w: int = 128, overlays=None, resolve: bool = True) -> np.ndarray:
     """fp32 [batch, 2, 96]: view 1 from pipeline `severity`, view 2 from the same pipeline (both come from `augment_tfs`,
     datasetsupervised_kmeans.py:57).  `warped` (bool [batch], from sample_theta): a sample whose warp draw failed gets the
     plain image as view 2 (:72-74 `image_view = image`), i.e. identity parameters.  `overlays` (weather.Overlays): collects the
-    cloud layers of the rows that drew Fog / Clouds - hand its planes() to ops.augment_views together with the rows."""
+    layers of the rows that drew a weather member: the rows carry task ids until `overlays.resolve(params, P_W)` (called here unless
+    `resolve=False`: a caller that overlaps the drawing with other work starts it and resolves later) - hand its planes() to
+    ops.augment_views together with the rows."""
     out = np.empty((batch, 2, AUG_NP), dtype=np.float32)
     for b in range(batch):
         out[b, 0] = _colour_params(rs, severity, h, w, overlays)
         out[b, 1] = _colour_params(rs, severity, h, w, overlays)
         if warped is not None and not warped[b]:
-            out[b, 1] = IDENTITY_PARAMS           # (layers it may have drawn stay in the collector, unreferenced)
+            out[b, 1] = IDENTITY_PARAMS           # (a task it may have registered is never looked at)
+    if overlays is not None:
+        overlays.start()
+        if resolve:
+            overlays.resolve(out, P_W)
     return out
 
 
@@ -383,7 +391,7 @@ def _finetune_colour_params(rs: np.random.RandomState, h: int = 32, w: int = 128
     return p
 
 
-def sample_finetune_params(rs: np.random.RandomState, batch: int, h: int, w: int, overlays=None):
+def sample_finetune_params(rs: np.random.RandomState, batch: int, h: int, w: int, overlays=None, resolve: bool = True):
     """(params fp32 [batch, 2, 96] - only row 1 is used, theta fp32 [batch, 3, 3]) for the finetuning augmentation
     (dataset_pretrain.py:79-158): colour as above, geometry = Sometimes(0.6, OneOf[Affine (the pretraining ranges), PiecewiseAffine
     (not reproduced), Rotate(-45, 45)])."""
@@ -402,4 +410,8 @@ def sample_finetune_params(rs: np.random.RandomState, batch: int, h: int, w: int
                 back = np.array([[1, 0, cx], [0, 1, cy], [0, 0, 1]], dtype=np.float64)
                 rotm = np.array([[math.cos(rot), -math.sin(rot), 0], [math.sin(rot), math.cos(rot), 0], [0, 0, 1]])
                 theta[b] = theta_from_pixel_matrix(back @ rotm @ to_o, h, w)
+    if overlays is not None:
+        overlays.start()
+        if resolve:
+            overlays.resolve(params, P_W)
     return params, theta

@@ -108,21 +108,33 @@ class DeviceImageAugmenter:
     (dataset_pretrain.py:250-253: augment_tfs, resize, ToTensor, normalize) with the augmentation after the resize, one
     launch pair per batch (ops.augment_views: the colour + warp view)."""
 
-    def __init__(self, img_h=32, img_w=128, seed=0, device=None):
+    def __init__(self, img_h=32, img_w=128, seed=0, device=None, workers=None):
         self.h, self.w, self.device = int(img_h), int(img_w), device
+        self.workers, self._farm, self._ahead = workers, None, None
         self.rs = np.random.RandomState(seed)
+
+    def _draw(self, B):
+        from .augment import sample_finetune_params
+        from .weather import LayerFarm, Overlays
+        if self._farm is None:
+            self._farm = LayerFarm(self.workers)
+        overlays = Overlays(self.h, self.w, self._farm)
+        params, theta = sample_finetune_params(self.rs, B, self.h, self.w, overlays=overlays, resolve=False)
+        return B, params, theta, overlays
 
     def __call__(self, images_u8):
         from .. import ops
-        from .augment import sample_finetune_params
+        from .augment import P_W
         dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
         B = images_u8.shape[0]
         assert tuple(images_u8.shape[1:]) == (self.h, self.w, 3) and images_u8.dtype == torch.uint8
-        from .weather import Overlays
-        overlays = Overlays(self.h, self.w)
-        params, theta = sample_finetune_params(self.rs, B, self.h, self.w, overlays=overlays)
-        planes = overlays.planes()
+        if self._ahead is None or self._ahead[0] != B:               # drawn one call ahead: the weather layers are computed by the
+            self._ahead = self._draw(B)                              # worker pool while the GPU runs the iteration in between
+        _, params, theta, overlays = self._ahead
+        planes = overlays.resolve(params, P_W)
         out = ops.augment_views(images_u8.to(dev, non_blocking=True).contiguous(), torch.from_numpy(params).to(dev),
                                 torch.from_numpy(theta).to(dev), MEAN, STD,
                                 overlay=None if planes is None else torch.from_numpy(planes).to(dev))
-        return out[:, 2].contiguous()
+        view = out[:, 2].contiguous()
+        self._ahead = self._draw(B)                                  # (after the launches: the host draws while the device works)
+        return view

@@ -29,7 +29,7 @@ import torch
 from torch.utils.data import Dataset
 
 from . import lmdb_file
-from .augment import sample_colour_params, sample_theta
+from .augment import P_W, sample_colour_params, sample_theta
 
 MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)          # dataset.py:79-80
 
@@ -155,10 +155,21 @@ class DeviceViewMaker:
     """(images uint8 [B,H,W,3], masks [B,H,W]) -> (image_tensors fp32 [B,3,3,H,W], masks fp32 [B,H,W], metrics fp32 [B,3,3])
     on the GPU: the per-batch half of `_process_training` (datasetsupervised_kmeans.py:48-81)."""
 
-    def __init__(self, img_h=32, img_w=128, severity=5, data_aug=True, seed=0, device=None):
+    def __init__(self, img_h=32, img_w=128, severity=5, data_aug=True, seed=0, device=None, workers=None):
         self.h, self.w, self.severity, self.data_aug = int(img_h), int(img_w), int(severity), bool(data_aug)
+        self.workers, self._farm, self._ahead = workers, None, None      # weather-layer worker processes (None: half the cores, at most 32)
         self.rs = np.random.RandomState(seed)
         self.device = device
+
+    def _draw(self, B):
+        from .weather import LayerFarm, Overlays
+        if self._farm is None:
+            self._farm = LayerFarm(self.workers)
+        theta, warped = sample_theta(self.rs, B, self.h, self.w, return_warped=True)
+        overlays = Overlays(self.h, self.w, self._farm)
+        params = sample_colour_params(self.rs, B, self.severity, warped=warped, h=self.h, w=self.w, overlays=overlays,
+                                      resolve=False)               # view 2 = the plain image where not warped
+        return B, theta, params, overlays
 
     def __call__(self, images_u8, masks):
         from .. import ops
@@ -166,11 +177,14 @@ class DeviceViewMaker:
         B = images_u8.shape[0]
         assert tuple(images_u8.shape[1:]) == (self.h, self.w, 3) and images_u8.dtype == torch.uint8
         if self.data_aug and self.severity > 0:
-            theta, warped = sample_theta(self.rs, B, self.h, self.w, return_warped=True)
-            from .weather import Overlays
-            overlays = Overlays(self.h, self.w)
-            params = sample_colour_params(self.rs, B, self.severity, warped=warped, h=self.h, w=self.w, overlays=overlays)     # view 2 = the plain image where not warped
-            planes = overlays.planes()
+            # The parameters of a batch do not depend on its images: they are drawn ONE CALL AHEAD, and the weather layers they ask
+            # for (frequency-noise maps etc., ~1 ms of numpy each, ~500 per 256 samples) are computed by the worker pool while the
+            # GPU runs the iteration in between.  A batch of another size (the last one of an epoch) is drawn on the spot.
+            if self._ahead is None or self._ahead[0] != B:
+                self._ahead = self._draw(B)
+            _, theta, params, overlays = self._ahead
+            planes = overlays.resolve(params, P_W)
+            self._ahead = None
         else:                                                       # data_aug off: three identical views, identity theta
             params = sample_colour_params(self.rs, B, 0)
             theta = np.tile(np.eye(3, dtype=np.float32), (B, 1, 1))
@@ -178,4 +192,7 @@ class DeviceViewMaker:
         img_d = images_u8.to(dev, non_blocking=True).contiguous()
         out = ops.augment_views(img_d, torch.from_numpy(params).to(dev), torch.from_numpy(theta).to(dev), MEAN, STD,
                                 overlay=None if planes is None else torch.from_numpy(planes).to(dev))
-        return out, masks.to(dev, non_blocking=True).float(), torch.from_numpy(theta).to(dev)
+        result = out, masks.to(dev, non_blocking=True).float(), torch.from_numpy(theta).to(dev)
+        if self.data_aug and self.severity > 0:
+            self._ahead = self._draw(B)                             # (after the launches: the host draws while the device works)
+        return result

@@ -1,4 +1,4 @@
-"""The cloud-layer members of the reference's `weather` group (augmentation_pipelines.py:187-196: iaa.Fog, iaa.Clouds; the finetuning
+"""The reference's `weather` group (augmentation_pipelines.py:187-196: iaa.Fog, iaa.Clouds, iaa.Snowflakes, iaa.Rain; the finetuning
 list dataset_pretrain.py:117-120 has them too) - host side.
 
 imgaug draws a cloud layer as two low-frequency noise maps per image, an opacity `alpha` and an `intensity`, and blends
@@ -118,18 +118,167 @@ def clouds_layers(rs, h, w):
     return [cloud_layer(rs, h, w, **CLOUDS[k]) for k in picked]
 
 
+# ---------------------------------------------------------------------------------------------------- Snowflakes / Rain
+# imgaug's SnowflakesLayer / RainLayer (augmenters/weather.py): salt noise on a canvas shrunk by the flake size, thinned by a coarse
+# Beta-distributed gate, up-sampled (cubic), Gaussian-blurred a little (snow only) and smeared by a motion-blur kernel along the
+# falling direction.  Snow is blended by sum (a faint glow) then by maximum (the flakes); rain is an alpha blend towards a grey drop
+# colour - the same form as a cloud layer, alpha = noise / 255.
+SNOW_MODE, CLOUD_MODE = 1, 0
+
+
+def _salt_canvas(rs, h, w, density):
+    """arithmetic.Salt(p=density) on a black uint8 canvas: a pixel is replaced with probability `density` by the upper half of
+    255 * Beta(0.5, 0.5)."""
+    hit = rs.rand(h, w) < density
+    val = 0.5 + np.abs(rs.beta(0.5, 0.5, size=(h, w)) - 0.5)
+    return np.where(hit, np.clip(np.round(val * 255.0), 0, 255), 0).astype(np.uint8)
+
+
+def _falling_noise(rs, h, w, *, density, density_uniformity, flake_size, flake_size_uniformity, angle, speed, blur_sigma_fraction,
+                   blur: bool):
+    """-> (noise uint8 [h, w] after the blurs, speed, flake_size_uniformity) of one layer."""
+    from scipy import ndimage
+    from .augment import motion_kernel
+    flake = _draw(rs, flake_size)
+    uniformity = _draw(rs, flake_size_uniformity)
+    ang, spd = _draw(rs, angle), _draw(rs, speed)
+    sig_frac = _draw(rs, blur_sigma_fraction)
+    dens, dens_uni = _draw(rs, density), _draw(rs, density_uniformity)
+    down = min(max(1.0 - flake, 0.001), 1.0)
+    hd, wd = max(1, int(h * down)), max(1, int(w * down))
+    noise = _salt_canvas(rs, hd, wd, dens)
+    gate = resize_cubic(rs.beta(1.0, max(1.0 - dens_uni, 1e-6), size=(8, 8)), hd, wd)          # most of its weight near 1: little gating
+    noise = np.clip(noise.astype(np.float64) * np.clip(gate, 0.0, 1.0), 0, 255).astype(np.uint8)
+    noise = resize_cubic(noise, h, w, as_uint8=True)
+    if blur:
+        sigma = min(max(max(h, w) * sig_frac, 0.5), 3.75)
+        noise = np.clip(np.round(ndimage.gaussian_filter(noise, sigma=sigma, mode="mirror")), 0, 255)
+    k = int(spd * max(h, w))
+    if k > 1:
+        kern = motion_kernel(max(k, 3), ang, 1.0)
+        noise = np.clip(np.round(ndimage.correlate(noise.astype(np.float64), kern, mode="mirror")), 0, 255)
+    return noise.astype(np.uint8), spd, uniformity
+
+
+SNOWFLAKES = dict(density=(0.005, 0.075), density_uniformity=(0.3, 0.9), flake_size=(0.1, 0.4), flake_size_uniformity=(0.4, 0.8),
+                  angle=(-30, 30), speed=(0.01, 0.05), blur_sigma_fraction=(0.0001, 0.001))      # iaa.Snowflakes(flake_size=(0.1, 0.4), speed=(0.01, 0.05))
+RAIN = dict(density=(0.03, 0.14), density_uniformity=(0.8, 1.0), flake_size=(0.01, 0.02), flake_size_uniformity=(0.2, 0.5),
+            angle=(-15, 15), speed=(0.1, 0.3), blur_sigma_fraction=(0.001, 0.001))                 # iaa.Rain(speed=(0.1, 0.3))
+
+
+def snowflake_layers(rs, h, w):
+    """iaa.Snowflakes: SomeOf((1, 3)) of three identically-specified layers.  Planes of a layer: (what is ADDED, what the result is
+    raised to at least) - out = max(clip(v + plane0, 0, 255), plane1), the device's snow mode."""
+    out = []
+    for _ in range(rs.randint(1, 4)):
+        noise, spd, uni = _falling_noise(rs, h, w, blur=True, **SNOWFLAKES)
+        gain, gain_adj = 1.0 + 2.0 * (1.0 - uni), 1.0 + 5.0 * (1.0 - uni)
+        n = np.floor(255.0 * np.power(noise.astype(np.float64) / 255.0, gain)) * gain_adj        # GammaContrast's truncating table, then the re-gain
+        out.append(np.stack([(0.1 + 20.0 * spd) * n, (1.0 + 20.0 * spd) * n]).astype(np.float32))
+    return out
+
+
+def rain_layers(rs, h, w):
+    """iaa.Rain: 1 - 3 RainLayers; a layer is an alpha blend towards the drop colour the library derives from the noise itself
+    (110 + (240 - 110) % sum of its first 1000 values): planes (alpha = noise / 255, intensity = that colour) - the cloud blend."""
+    out = []
+    for _ in range(rs.randint(1, 4)):
+        noise, _, _ = _falling_noise(rs, h, w, blur=False, **RAIN)
+        total = float(noise.reshape(-1)[:1000].astype(np.float64).sum() * 3.0)                    # (the library sums the RGB-tiled noise)
+        colour = 110.0 + (130.0 % (total if total > 0 else 1.0))
+        out.append(np.stack([noise.astype(np.float32) / 255.0, np.full((h, w), colour, np.float32)]).astype(np.float32))
+    return out
+
+
+MAKERS = {"Fog": fog_layers, "Clouds": clouds_layers, "Snowflakes": snowflake_layers, "Rain": rain_layers}
+
+
+def draw_layers(task):
+    """(member name, seed, h, w) -> the member's layers as fp16 [n, 2, h, w]: a pure function of its arguments (worker processes call it)."""
+    name, seed, h, w = task
+    layers = MAKERS[name](np.random.RandomState(int(seed)), int(h), int(w))
+    return np.stack(layers).astype(np.float16)
+
+
+class LayerFarm:
+    """A pool of worker processes that draw weather layers (~1 ms of numpy / scipy each; a batch of 256 samples needs ~500 of them:
+    1.1 s on one core against a 50-ms training step).  Forked lazily, like a DataLoader's workers; the workers never touch the GPU."""
+
+    def __init__(self, workers=None):
+        import os
+        self.workers = int(workers) if workers is not None else max(1, min(32, (os.cpu_count() or 2) // 2))
+        self.pool = None
+
+    def submit(self, tasks):
+        """-> an object with .get() -> [fp16 [n, 2, h, w]] in task order."""
+        if not tasks:
+            return _Ready([])
+        if self.workers <= 1:
+            return _Ready([draw_layers(t) for t in tasks])
+        if self.pool is None:
+            import multiprocessing as mp
+            self.pool = mp.get_context("fork").Pool(self.workers)
+        return self.pool.map_async(draw_layers, tasks, chunksize=max(1, len(tasks) // (4 * self.workers)))
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.terminate()
+            self.pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _Ready:
+    def __init__(self, value):
+        self.value = value
+
+    def get(self, timeout=None):
+        return self.value
+
+
 class Overlays:
-    """Collects the layers a batch's parameter rows refer to: `planes()` -> fp16 [layers, 2, H, W] (or None when nobody drew one)."""
+    """The weather layers of one batch.  The sampler registers a task per (sample, view) row that drew a weather member
+    (`add_task` -> a task id, parked in the row); `start()` hands the tasks to a LayerFarm (or draws them in place) and `resolve(params)`
+    waits, stacks the layers and writes every row's first layer and layer count: `planes()` -> fp16 [layers, 2, H, W] (None when nobody
+    drew one).  A layer depends on (member, seed) only, so a batch is reproducible whatever the workers' scheduling."""
 
-    def __init__(self, h: int, w: int):
-        self.h, self.w, self.layers = h, w, []
+    def __init__(self, h: int, w: int, farm: "LayerFarm | None" = None):
+        self.h, self.w, self.farm = int(h), int(w), farm
+        self.tasks, self.pending, self._planes = [], None, None
 
-    def add(self, layers) -> int:
-        first = len(self.layers)
-        self.layers.extend(layers)
-        return first
+    def add_task(self, name: str, seed: int) -> int:
+        self.tasks.append((name, int(seed), self.h, self.w))
+        return len(self.tasks) - 1
+
+    def start(self):
+        if self.pending is None:
+            self.pending = self.farm.submit(self.tasks) if self.farm is not None else _Ready([draw_layers(t) for t in self.tasks])
+        return self
+
+    def resolve(self, params: np.ndarray, p_w: int):
+        """params: fp32 [..., AUG_NP] whose weather rows carry (-1, task id, blend) at p_w .. p_w + 2 -> (count, first layer, blend)."""
+        self.start()
+        try:
+            results = self.pending.get(timeout=120.0)
+        except Exception as exc:                         # a wedged or killed worker must not stall the training: draw here, say so once
+            import warnings
+            warnings.warn(f"weather-layer workers did not answer ({type(exc).__name__}); drawing {len(self.tasks)} layers in the training process")
+            results = [draw_layers(t) for t in self.tasks]
+        flat = params.reshape(-1, params.shape[-1])
+        rows = np.nonzero(flat[:, p_w] < 0)[0]
+        layers, first = [], {}
+        for r in rows:                                   # (rows that were overwritten - an unwarped view 2 - no longer refer to their task)
+            tid = int(flat[r, p_w + 1])
+            if tid not in first:
+                first[tid] = sum(len(x) for x in layers)
+                layers.append(results[tid])
+            flat[r, p_w], flat[r, p_w + 1] = len(results[tid]), first[tid]
+        self._planes = np.concatenate(layers) if layers else None
+        return self._planes
 
     def planes(self):
-        if not self.layers:
-            return None
-        return np.stack(self.layers).astype(np.float16)
+        return self._planes

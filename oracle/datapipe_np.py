@@ -436,6 +436,13 @@ def cloud_blend(cur_u8, alpha, intensity):
     return _trunc_u8(v)
 
 
+def snow_blend(cur_u8, add, floor_):
+    """imgaug's SnowflakesLayer blend on a uint8 image: by sum with `add` (clipped to 0..255), then by maximum with `floor_`; rounded."""
+    f = np.float32
+    v = np.clip(np.asarray(cur_u8, np.uint8).astype(f) + np.asarray(add, f)[..., None], f(0), f(255))
+    return _round_u8(np.maximum(v, np.asarray(floor_, f)[..., None]))
+
+
 def staged_source(p, src_u8, overlay=None):
     """augment_spatial_kernel: the reference's chain on one (sample, view) - [leading Invert] -> one `arithmetic` member -> one
     `color` member -> one `Blur` member -> one `contrast` member -> the cloud layers of a `weather` member (overlay: fp16
@@ -461,10 +468,10 @@ def staged_source(p, src_u8, overlay=None):
     elif mode == 3:
         cur = bilateral_blur(cur, int(p[P_C + 1]), float(p[P_C + 2]), float(p[P_C + 3]))
     cur = contrast_member(p, cur)
-    n, first = int(p[P_W]), int(p[P_W + 1])
+    n, first, snow = int(p[P_W]), int(p[P_W + 1]), int(p[P_W + 2])
     if overlay is not None and n > 0:
         for l in range(first, first + n):
-            cur = cloud_blend(cur, overlay[l, 0], overlay[l, 1])
+            cur = snow_blend(cur, overlay[l, 0], overlay[l, 1]) if snow else cloud_blend(cur, overlay[l, 0], overlay[l, 1])
     return cur
 
 

@@ -430,12 +430,14 @@ def check_augment_views(dev, H=32, W=128, seed=52, max_samples=None):
     ov = Wt.Overlays(H, W)
     flat = params.reshape(-1, A.AUG_NP)
     wrows = {}
-    for r, layers in ((6, Wt.fog_layers(rs, H, W)), (len(rows) - 2, Wt.clouds_layers(rs, H, W) + Wt.clouds_layers(rs, H, W)[:1]), (9, Wt.fog_layers(rs, H, W))):
+    for r, name in ((6, "Fog"), (len(rows) - 2, "Clouds"), (9, "Fog"), (12, "Snowflakes"), (15, "Rain"), (len(rows) - 4, "Snowflakes")):
         if r >= len(flat):
             continue
-        flat[r, A.P_W], flat[r, A.P_W + 1] = len(layers), ov.add(layers)
-        wrows[r] = len(layers)
-    planes = ov.planes()
+        flat[r, A.P_W], flat[r, A.P_W + 1] = -1, ov.add_task(name, int(rs.randint(0, 1 << 31)))
+        flat[r, A.P_W + 2] = Wt.SNOW_MODE if name == "Snowflakes" else Wt.CLOUD_MODE
+        wrows[r] = name
+    planes = ov.resolve(params, A.P_W)
+    assert planes is not None and planes.dtype == np.float16 and (flat[list(wrows), A.P_W] >= 1).all()
     img = rs.randint(0, 256, size=(B, H, W, 3)).astype(np.uint8)
     for b in range(B):                                                 # text-like structure under the noise: blocks of colour
         img[b] = (0.35 * img[b] + 0.65 * np.array(rs.randint(0, 256, 3))).astype(np.uint8)

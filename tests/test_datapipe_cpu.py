@@ -139,11 +139,12 @@ def test_theta_is_the_datasets_composition():
               A.A_DROP2D: 1, A.A_REPLACE: 4, A.A_INVERT: 0.15, A.A_SOLARIZE: 0.5, A.A_JPEG: 1, A.A_FILTER: 3, A.A_PILFILTER: 2}
     for op, mult in want_a.items():
         assert abs(share(a_op == op) - mult / 21.0) < 0.02, (op, share(a_op == op), mult / 21.0)
-    # `color`: Sometimes(0.7, OneOf 9) with KMeansColorQuantization left out (identity)
-    want_b = {A.B_HUE_ADD: 2, A.B_BRIGHT: 1, A.B_MUL_HS: 1, A.B_ADD_HS: 1, A.B_GRAY: 1, A.B_UNIFORM_Q: 1, A.B_GAINS: 1}
+    # `color`: Sometimes(0.7, OneOf 9)
+    want_b = {A.B_HUE_ADD: 2, A.B_BRIGHT: 1, A.B_MUL_HS: 1, A.B_ADD_HS: 1, A.B_GRAY: 1, A.B_UNIFORM_Q: 1, A.B_GAINS: 1, A.B_KMEANS: 1}
     for op, mult in want_b.items():
         assert abs(share(b_op == op) - 0.7 * mult / 9.0) < 0.02, (op, share(b_op == op))
-    assert (b_op == A.B_KMEANS).sum() == 0
+    km = v1[b_op == A.B_KMEANS]
+    assert km[:, A.P_B + 1].min() >= 2 and km[:, A.P_B + 1].max() <= 16            # n_colors (2, 16)
     # `Blur`: Sometimes(0.7, OneOf[Sharpen, OneOf[5 blurs]]): filters = Sharpen + Gaussian + Average + Motion
     assert abs(share(c_op == A.C_FILTER) - 0.7 * (0.5 + 0.5 * 3 / 5)) < 0.03 and abs(share(c_op == A.C_MEDIAN) - 0.07) < 0.02
     assert abs(share(c_op == A.C_BILATERAL) - 0.07) < 0.02
@@ -153,8 +154,8 @@ def test_theta_is_the_datasets_composition():
     kern = v1[c_op == A.C_FILTER][:, A.P_KERN:A.P_KERN + 49]
     ks = kern.sum(1)                                                # the blurs preserve the mean; Sharpen(lightness 0 - 0.5) sums to 1 - alpha (1 - lightness)
     assert ks.max() < 1.0 + 1e-4 and ks.min() >= 0.5 and (np.abs(ks - 1.0) < 1e-4).mean() > 0.3
-    # `contrast`: Sometimes(0.7, OneOf 8), three of the eight not reproduced
-    for op in (A.D_GAMMA, A.D_LINEAR, A.D_SIGMOID, A.D_LOG, A.D_HISTEQ_ALL):
+    # `contrast`: Sometimes(0.7, OneOf 8)
+    for op in (A.D_GAMMA, A.D_LINEAR, A.D_SIGMOID, A.D_LOG, A.D_HISTEQ_ALL, A.D_HISTEQ_LAB, A.D_CLAHE_LAB, A.D_CLAHE_ALL):
         assert abs(share(d_op == op) - 0.7 / 8.0) < 0.02, (op, share(d_op == op))
     jq = v1[a_op == A.A_JPEG, A.P_A + 1]
     assert jq.min() >= 2 and jq.max() <= 31                         # compression 70-99 -> PIL quality 31 .. 2
@@ -427,11 +428,13 @@ def test_cloud_layers_host_side():
             assert m[1].mean() > lo_mean - 60.0
     fog_alpha = np.mean([Wt.fog_layers(rs, 32, 128)[0][0].mean() for _ in range(40)])
     assert 0.3 < fog_alpha < 0.8, fog_alpha                                # (0.7..0.9 + 0.3 n) ** 0.9 * (0.4..0.9)
-    # the sampler: 0.8 * 0.7 * 2 / 4 = 28 % of the rows carry cloud layers; without a collector none does
+    # the sampler: Sometimes(0.8) x Sometimes(0.7, OneOf 4 weather members) = 56 % of the rows carry layers; without a collector none does
     ov = Wt.Overlays(32, 128)
     p = A.sample_colour_params(np.random.RandomState(3), 600, 5, overlays=ov)
     share = (p[:, :, A.P_W] > 0).mean()
-    assert 0.22 < share < 0.34, share
+    assert 0.50 < share < 0.62, share
+    snow = (p[:, :, A.P_W + 2] == Wt.SNOW_MODE) & (p[:, :, A.P_W] > 0)
+    assert 0.10 < snow.mean() < 0.18                                     # Snowflakes: a quarter of them
     planes = ov.planes()
     assert planes.dtype == np.float16 and planes.shape[1:] == (2, 32, 128)
     rows = p.reshape(-1, A.AUG_NP)
@@ -439,7 +442,45 @@ def test_cloud_layers_host_side():
     assert (used[:, A.P_W + 1] + used[:, A.P_W] <= len(planes)).all() and len(planes) == int(used[:, A.P_W].sum())
     assert (A.sample_colour_params(np.random.RandomState(3), 200, 5)[:, :, A.P_W] == 0).all()
     pf, _ = A.sample_finetune_params(np.random.RandomState(1), 800, 32, 128, overlays=Wt.Overlays(32, 128))
-    assert 0.02 < (pf[:, 1, A.P_W] > 0).mean() < 0.08                  # 0.8 * 2 / 35
+    assert 0.06 < (pf[:, 1, A.P_W] > 0).mean() < 0.12                  # 0.8 * 4 / 35
+
+
+def test_snow_rain_layers_and_the_layer_farm():
+    """Snowflakes / Rain (imgaug SnowflakesLayer / RainLayer restated in weather.py): layer counts, flake statistics, the blend modes; the
+    worker pool returns exactly what an in-place draw returns (a layer is a function of (member, seed) only), and a batch drawn one call
+    ahead (resolve=False ... resolve()) equals the batch drawn at once."""
+    from ccd_amd.dataset import augment as A, weather as Wt
+    rs = np.random.RandomState(11)
+    for name, lo, hi in (("Snowflakes", 1, 3), ("Rain", 1, 3)):
+        counts = set()
+        for _ in range(12):
+            layers = Wt.MAKERS[name](rs, 32, 128)
+            counts.add(len(layers))
+            assert lo <= len(layers) <= hi
+            for m in layers:
+                assert m.shape == (2, 32, 128) and np.isfinite(m).all()
+                if name == "Rain":                                       # (alpha, drop colour 110..240)
+                    assert 0.0 <= m[0].min() and m[0].max() <= 1.0 and 110.0 <= m[1].min() and m[1].max() <= 240.0
+                    assert m[0].mean() < 0.6                             # drops are sparse: most of the image shows through
+                else:                                                    # (what is added, the floor): floor = (1 + 20 s) / (0.1 + 20 s) x added
+                    assert m[0].min() >= 0.0 and (m[1] >= m[0]).all() and m[1].max() < 6e4      # fits fp16
+                    assert (m[0] == 0).mean() > 0.2                      # flakes are sparse
+        assert len(counts) >= 2, (name, counts)
+    tasks = [(n, 100 + i, 32, 128) for i, n in enumerate(("Fog", "Clouds", "Snowflakes", "Rain") * 3)]
+    direct = [Wt.draw_layers(t) for t in tasks]
+    farm = Wt.LayerFarm(2)
+    try:
+        pooled = farm.submit(tasks).get(timeout=120)
+        for a, b in zip(direct, pooled):
+            assert a.dtype == np.float16 and a.shape == b.shape and (a == b).all()
+        ov_a, ov_b = Wt.Overlays(32, 128), Wt.Overlays(32, 128, farm)
+        pa = A.sample_colour_params(np.random.RandomState(4), 24, 5, overlays=ov_a)
+        pb = A.sample_colour_params(np.random.RandomState(4), 24, 5, overlays=ov_b, resolve=False)
+        assert (pb[:, :, A.P_W] <= 0).all() and (pb[:, :, A.P_W] < 0).any()          # task ids parked in the rows
+        planes_b = ov_b.resolve(pb, A.P_W)
+        assert (pa == pb).all() and (ov_a.planes() == planes_b).all()
+    finally:
+        farm.close()
 
 
 def test_lab_and_clahe_restatements():
