@@ -86,6 +86,9 @@ SIGNATURES = {
     "ccd_bn_relu_bwd_apply": [P, L, P, L, P, P, P, P, F, P, P, P, P, L, L, I, P],
     "ccd_cls_gather_fwd": [P, L, P, P, I, I, I, P],
     "ccd_cls_grad_cols": [P, P, I, I, I, P],
+    "ccd_cls_tail_fwd": [P, L, P, P, P, P, P, P, I, I, I, I, P],
+    "ccd_cls_tail_bwd_reduce": [P, P, L, P, P, P, P, P, P, I, I, I, I, P],
+    "ccd_cls_tail_bwd_apply": [P, P, L, P, P, P, P, P, F, P, P, P, P, P, P, L, I, I, I, I, P],
     "ccd_permute4": [P, P, P, P, P, I, P],
     "ccd_dropout": [P, I, P, P, I, L, U64, F, P],
     "ccd_droppath_scales": [P, P, I, I, U64, P, P],

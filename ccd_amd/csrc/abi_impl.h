@@ -23,6 +23,7 @@
 #include "kernels/loss.h"
 #include "kernels/optim.h"
 #include "kernels/conv.h"
+#include "kernels/cls_tail.h"
 #include "kernels/decoder.h"
 #include "kernels/decoder_xattn.h"
 
@@ -264,7 +265,7 @@ static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, float* ws, long ws_
 
 extern "C" {
 
-int ccd_abi_version(void) { return 8; }   // 8: ccd_proj_mlp_fused (proj + residual + LayerNorm-2 in front of the fused MLP), ccd_matvec_bf16; 7: ccd_gemm_tn_pair_ws (split-K workspace instead of fp32 atomics); 6: device-side momentum / DropPath seed (HIP graph of the training step); 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
+int ccd_abi_version(void) { return 9; }   // 9: ccd_cls_tail_fwd / _bwd_reduce / _bwd_apply (BatchNorm + ReLU + classifier conv of the segmentation head fused); 8: ccd_proj_mlp_fused (proj + residual + LayerNorm-2 in front of the fused MLP), ccd_matvec_bf16; 7: ccd_gemm_tn_pair_ws (split-K workspace instead of fp32 atomics); 6: device-side momentum / DropPath seed (HIP graph of the training step); 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
 const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi8"; }
 int ccd_policy_set(const char* key, int value) {
     CCD_CHECK(key, CCD_EINVAL);
@@ -1147,6 +1148,58 @@ int ccd_cls_grad_cols(const float* dlogits, ccd_bf16* g, int images, int H, int 
     const long total = (long)images * H * W * 8;
     CCD_LAUNCH(ccd::cls_grad_cols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dlogits, g, images,
                H, W);
+    return ccd_rt_last_error();
+}
+
+static bool ccd_cls_tail_shape(int images, int H, int W, int C, long ld) {
+    return images > 0 && H == ccd::CT_H && W == ccd::CT_W && C == ccd::CT_C && ld >= C && ld % 8 == 0;
+}
+
+int ccd_cls_tail_fwd(const ccd_bf16* y, long ldy, const float* mean_rstd, const float* gamma, const float* beta,
+                     const float* w, const float* bias, float* logits, int images, int H, int W, int C, void* stream) {
+    CCD_CHECK(y && mean_rstd && gamma && beta && w && bias && logits && CCD_ALIGNED16(y), CCD_EINVAL);
+    if (images == 0) return CCD_OK;
+    CCD_CHECK(ccd_cls_tail_shape(images, H, W, C, ldy), CCD_ESHAPE);
+    // a band re-derives the z rows above and below it: 16-row bands (+ 12 % of y read twice) once they fill the chip twice over
+    const int band_rows = (long)images * 2 >= 2L * ccd_rt_num_cus() ? 16 : 8;
+    CCD_LAUNCH(ccd::cls_tail_fwd_kernel, dim3((unsigned)(images * (ccd::CT_H / band_rows))), dim3(256), 0, stream, y, ldy,
+               mean_rstd, gamma, beta, w, bias, logits, band_rows);
+    return ccd_rt_last_error();
+}
+
+static unsigned ccd_cls_tail_grid(int nbands, int per_cu) {
+    const long cap = (long)per_cu * ccd_rt_num_cus();
+    return (unsigned)(nbands < cap ? nbands : cap);
+}
+
+int ccd_cls_tail_bwd_reduce(const float* dlogits, const ccd_bf16* y, long ldy, const float* mean_rstd, const float* gamma,
+                            const float* beta, const float* w, float* red, float* db_cls, int images, int H, int W, int C,
+                            void* stream) {
+    CCD_CHECK(dlogits && y && mean_rstd && gamma && beta && w && red && db_cls && CCD_ALIGNED16(y), CCD_EINVAL);
+    if (images == 0) return CCD_OK;
+    CCD_CHECK(ccd_cls_tail_shape(images, H, W, C, ldy), CCD_ESHAPE);
+    // (two workgroups per CU is what the kernel's registers allow: a third of the grid queued behind them cost 20 %)
+    constexpr int RB = 4;
+    const int nbands = images * (ccd::CT_H / RB);
+    CCD_LAUNCH((ccd::cls_tail_bwd_kernel<false, RB>), dim3(ccd_cls_tail_grid(nbands, 2)), dim3(256), 0, stream, dlogits, y, ldy,
+               mean_rstd, gamma, beta, w, red, 1.0f, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+               db_cls, (float*)nullptr, (ccd::bf16_t*)nullptr, 0L, nbands);
+    return ccd_rt_last_error();
+}
+
+int ccd_cls_tail_bwd_apply(const float* dlogits, const ccd_bf16* y, long ldy, const float* mean_rstd, const float* gamma,
+                           const float* beta, const float* w, const float* red, float count, const float* red_local,
+                           float* dgamma, float* dbeta, float* dw_cls, float* dbias_t, ccd_bf16* dy, long lddy, int images,
+                           int H, int W, int C, void* stream) {
+    CCD_CHECK(dlogits && y && mean_rstd && gamma && beta && w && red && red_local && dgamma && dbeta && dw_cls && dbias_t && dy &&
+                  CCD_ALIGNED16(y) && CCD_ALIGNED16(dy) && count > 0.f, CCD_EINVAL);
+    if (images == 0) return CCD_OK;
+    CCD_CHECK(ccd_cls_tail_shape(images, H, W, C, ldy) && lddy >= C && lddy % 8 == 0, CCD_ESHAPE);
+    constexpr int RB = 4;
+    const int nbands = images * (ccd::CT_H / RB);
+    CCD_LAUNCH((ccd::cls_tail_bwd_kernel<true, RB>), dim3(ccd_cls_tail_grid(nbands, 2)), dim3(256), 0, stream, dlogits, y, ldy,
+               mean_rstd, gamma, beta, w, const_cast<float*>(red), count, red_local, dgamma, dbeta, dw_cls, (float*)nullptr,
+               dbias_t, dy, lddy, nbands);
     return ccd_rt_last_error();
 }
 

@@ -778,6 +778,47 @@ def cls_grad_cols(dlogits, images, H, W):
     return g
 
 
+def cls_tail_supported(y, H, W):
+    """The fused BatchNorm + ReLU + classifier kernels exist for the reference's head shape only (kernels/cls_tail.h)."""
+    return y.shape[1] == 128 and (H, W) == (32, 128) and y.stride(0) % 8 == 0
+
+
+def cls_tail_fwd(y, mean_rstd, gamma, beta, w, bias, images, H, W):
+    """logits fp32 [images, 2, H, W] = Conv2d(C, 2, 3, padding=1)(relu(bn(y))); y bf16 [images*H*W, C] BEFORE its BatchNorm."""
+    _chk(y, BF16, "y"); _chk(mean_rstd, F32, "mean_rstd"); _chk(w, F32, "w"); _chk(bias, F32, "bias")
+    C = y.shape[1]
+    assert y.shape[0] == images * H * W and y.stride(1) == 1 and w.is_contiguous() and tuple(w.shape) == (2, C, 3, 3)
+    logits = torch.empty((images, 2, H, W), dtype=F32, device=y.device)
+    _call("ccd_cls_tail_fwd", _lib.ptr(y), y.stride(0), _lib.ptr(mean_rstd), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(w),
+          _lib.ptr(bias), _lib.ptr(logits), images, H, W, C)
+    return logits
+
+
+def cls_tail_bwd_reduce(dlogits, y, mean_rstd, gamma, beta, w, red, db_cls, images, H, W):
+    """red [2C] += BatchNorm's two backward sums of d(relu(bn(y))) under the classifier; db_cls [2] += sum dlogits."""
+    _chk(dlogits, F32, "dlogits"); _chk(y, BF16, "y"); _chk(red, F32, "red"); _chk(db_cls, F32, "db_cls")
+    C = y.shape[1]
+    assert dlogits.is_contiguous() and tuple(dlogits.shape) == (images, 2, H, W) and y.shape[0] == images * H * W
+    assert w.is_contiguous() and red.numel() == 2 * C and red.is_contiguous() and db_cls.is_contiguous()
+    _call("ccd_cls_tail_bwd_reduce", _lib.ptr(dlogits), _lib.ptr(y), y.stride(0), _lib.ptr(mean_rstd), _lib.ptr(gamma),
+          _lib.ptr(beta), _lib.ptr(w), _lib.ptr(red), _lib.ptr(db_cls), images, H, W, C)
+    return red
+
+
+def cls_tail_bwd_apply(dlogits, y, mean_rstd, gamma, beta, w, red, count, red_local, dgamma, dbeta, dw_cls, dbias_t, dy,
+                       images, H, W):
+    """dy bf16 [images*H*W, C] = gradient w.r.t. y; dgamma / dbeta / dw_cls [2, C, 3, 3] / dbias_t [C] accumulate (fp32)."""
+    _chk(dlogits, F32, "dlogits"); _chk(y, BF16, "y"); _chk(dy, BF16, "dy"); _chk(dw_cls, F32, "dw_cls")
+    C = y.shape[1]
+    assert dlogits.is_contiguous() and y.shape[0] == images * H * W and dy.shape == y.shape and dy.stride(1) == 1
+    assert dw_cls.is_contiguous() and tuple(dw_cls.shape) == (2, C, 3, 3) and dbias_t.is_contiguous() and dbias_t.numel() == C
+    assert dgamma.is_contiguous() and dbeta.is_contiguous() and red.is_contiguous() and red_local.is_contiguous()
+    _call("ccd_cls_tail_bwd_apply", _lib.ptr(dlogits), _lib.ptr(y), y.stride(0), _lib.ptr(mean_rstd), _lib.ptr(gamma),
+          _lib.ptr(beta), _lib.ptr(w), _lib.ptr(red), float(count), _lib.ptr(red_local), _lib.ptr(dgamma), _lib.ptr(dbeta),
+          _lib.ptr(dw_cls), _lib.ptr(dbias_t), _lib.ptr(dy), dy.stride(0), images, H, W, C)
+    return dy
+
+
 def permute4(src, strides, dims, dst, accumulate=False, dst_strides=None):
     """dst[idx . dst_strides] (bf16 cast, or fp32 += when accumulate) <- src.flatten()[idx . strides]; dst_strides
     default to contiguous over `dims`."""

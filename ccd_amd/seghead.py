@@ -39,6 +39,15 @@ def _parity_taps(py, px):
     return [(ky, kx, dy, dx) for ky, dy in _KY[py] for kx, dx in _KY[px]]
 
 
+def _env_switch(name):
+    import os
+    v = os.environ.get(name)
+    return None if v is None else v not in ("0", "", "false", "off")
+
+
+# The last level - unpool2's BatchNorm + ReLU and the classifier conv - as the three fused kernels of kernels/cls_tail.h (read ONCE
+# at import from CCD_FUSE_CLS_TAIL, a lab switch; tests may assign it).  Default: on where the shape is the reference's.
+FUSE_CLS_TAIL = _env_switch("CCD_FUSE_CLS_TAIL")
 FORCE_SYNC = False      # 1-GPU smoke of the N > 1 path: SyncBatchNorm layers exchange their statistics on a single rank too
 
 
@@ -117,6 +126,23 @@ class _BNGroup:
             dist.all_reduce(red)
         loc = [red_local[o:o + n] for o, n in zip(self._offs, self._sizes)]
         return [b.backward_apply(dy, x, dx, r, rl) for b, dy, x, dx, r, rl in zip(self.bns, dys, xs, dxs, slices, loc)]
+
+    def backward_cls_tail(self, d_logits, y, cls, dbias_t, images, H, W):
+        """The group of the LAST level (one BatchNorm) under the classifier `cls`: kernels/cls_tail.h.  -> d(y) bf16; cls.weight.grad,
+        cls.bias.grad, the BatchNorm's parameter gradients and dbias_t (the transposed conv's bias gradient) accumulate."""
+        bn = self.bns[0]
+        mod = bn.mod
+        w = cls.weight.detach()
+        red = torch.zeros_like(self.buf)
+        ops.cls_tail_bwd_reduce(d_logits, y, bn.mean_rstd, mod.weight.detach(), mod.bias.detach(), w, red, cls.bias.grad, images, H, W)
+        red_local = red
+        if self.sync:
+            red_local = red.clone()
+            dist.all_reduce(red)
+        if not mod.training:                              # eval-mode BN is an affine map: no batch terms
+            red = torch.zeros_like(red)
+        return ops.cls_tail_bwd_apply(d_logits, y, bn.mean_rstd, mod.weight.detach(), mod.bias.detach(), w, red, bn.count, red_local,
+                                      mod.weight.grad, mod.bias.grad, cls.weight.grad, dbias_t, torch.empty_like(y), images, H, W)
 
 
 def _ensure_grads(module):
@@ -210,11 +236,20 @@ class SegHeadFn(torch.autograd.Function):
                     ops.conv_gemm(x, desc, wp, rows, y, bias=convt.bias, colsum=bn.stats[:cout],
                                   colsumsq=bn.stats[cout:])
             grp.finalize()
-            a = bn.forward(y, torch.empty_like(y))
             ups.append((x, y, grp, grid))
-            x, grid = a, (2 * grid[0], 2 * grid[1])
-        logits = cls_forward(x, head.cls.weight.detach(), head.cls.bias.detach(), images, grid[0], grid[1])
+            grid = (2 * grid[0], 2 * grid[1])
+            last = seq is head.unpool2
+            fused_tail = (last and FUSE_CLS_TAIL is not False and head.cls.out_channels == 2
+                          and ops.cls_tail_supported(y, grid[0], grid[1]))
+            # (the last level's relu(bn(y)) is consumed by the classifier only: formed in its kernel's registers, never written)
+            x = None if fused_tail else bn.forward(y, torch.empty_like(y))
+        if fused_tail:
+            logits = ops.cls_tail_fwd(y, bn.mean_rstd, bn.mod.weight.detach(), bn.mod.bias.detach(), head.cls.weight.detach(),
+                                      head.cls.bias.detach(), images, grid[0], grid[1])
+        else:
+            logits = cls_forward(x, head.cls.weight.detach(), head.cls.bias.detach(), images, grid[0], grid[1])
         ctx.head, ctx.images, ctx.saved, ctx.ups, ctx.a_last, ctx.grid = head, images, saved, ups, x, grid
+        ctx.fused_tail = fused_tail
         ctx.dims = (E, mid, out_c, M)
         return logits
 
@@ -227,16 +262,21 @@ class SegHeadFn(torch.autograd.Function):
         for m in (head.unpool1, head.unpool2, head.cls):
             _ensure_grads(m)
         H, W = ctx.grid
-        d = cls_backward(d_logits.contiguous().float(), ctx.a_last, head.cls.weight.detach(), head.cls.weight.grad,
-                         head.cls.bias.grad, images, H, W)
+        d_logits = d_logits.contiguous().float()
+        d = None
+        if not ctx.fused_tail:
+            d = cls_backward(d_logits, ctx.a_last, head.cls.weight.detach(), head.cls.weight.grad, head.cls.bias.grad, images, H, W)
         ctx.a_last = None
         # ---- transposed convs, last first
         for seq, (x_in, y, grp, grid) in zip((head.unpool2, head.unpool1), reversed(ctx.ups)):
             convt = seq[0]
             cin, cout = convt.in_channels, convt.out_channels
             rows = images * grid[0] * grid[1]
-            dyc = grp.backward([d], [y], [d])[0]                                    # in place: d(convT output)
-            ops.colsum_bf16(dyc, convt.bias.grad)
+            if d is None:                                                           # classifier + BatchNorm backward, fused
+                dyc = grp.backward_cls_tail(d_logits, y, head.cls, convt.bias.grad, images, H, W)
+            else:
+                dyc = grp.backward([d], [y], [d])[0]                                # in place: d(convT output)
+                ops.colsum_bf16(dyc, convt.bias.grad)
             desc = ops.conv_desc(grid, (2 * grid[0], 2 * grid[1]), cout, TAPS_T_GRAD, s_mul=2)
             stage = torch.zeros((cin, 16 * cout), dtype=F32, device=dev)
             ops.conv_wgrad(x_in, dyc, desc, stage)                                  # [ci][tap][co]

@@ -348,6 +348,26 @@ int ccd_bn_relu_bwd_apply(const ccd_bf16* dy, long lddy, const ccd_bf16* x, long
 int ccd_cls_gather_fwd(const float* zT, long ldz, const float* bias, float* logits, int images, int H, int W,
                        void* stream);
 int ccd_cls_grad_cols(const float* dlogits, ccd_bf16* g, int images, int H, int W, void* stream);
+/* The same tail - unpool2's BatchNorm2d + ReLU, then `cls` (segmentor.py:84-95) - FUSED for the reference's own head shape
+ * (C = 128 channels, H x W = 32 x 128 pixels per image, 2 classes; anything else: CCD_ESHAPE, take the kernels above).
+ * y: the transposed conv's output before its BatchNorm, bf16 [images*H*W, ldy]; w: cls.weight fp32 [2, C, 3, 3] (the
+ * parameter itself, no re-laid operand); relu(bn(y)) is never materialised (kernels/cls_tail.h).
+ *   ccd_cls_tail_fwd        : logits fp32 [images, 2, H, W] = cls(relu(bn(y)))
+ *   ccd_cls_tail_bwd_reduce : red[0:C] += sum d*[a>0], red[C:2C] += sum d*[a>0]*xhat with d = d(a) of cls computed on
+ *                             the fly from dlogits fp32 [images, 2, H, W]; db_cls[2] += sum dlogits
+ *   ccd_cls_tail_bwd_apply  : dy bf16 [images*H*W, lddy] = gamma*rstd*(d*[a>0] - red0/count - xhat*red1/count)  (red: summed
+ *                             over the ranks by the caller); dgamma += red_local[C:2C], dbeta += red_local[0:C];
+ *                             dbias_t[C] += column sums of dy (the transposed conv's bias gradient);
+ *                             dw_cls fp32 [2, C, 3, 3] += sum_pixels g (x) a                                              */
+int ccd_cls_tail_fwd(const ccd_bf16* y, long ldy, const float* mean_rstd, const float* gamma, const float* beta,
+                     const float* w, const float* bias, float* logits, int images, int H, int W, int C, void* stream);
+int ccd_cls_tail_bwd_reduce(const float* dlogits, const ccd_bf16* y, long ldy, const float* mean_rstd, const float* gamma,
+                            const float* beta, const float* w, float* red, float* db_cls, int images, int H, int W, int C,
+                            void* stream);
+int ccd_cls_tail_bwd_apply(const float* dlogits, const ccd_bf16* y, long ldy, const float* mean_rstd, const float* gamma,
+                           const float* beta, const float* w, const float* red, float count, const float* red_local,
+                           float* dgamma, float* dbeta, float* dw_cls, float* dbias_t, ccd_bf16* dy, long lddy, int images,
+                           int H, int W, int C, void* stream);
 /* dst[sum_i idx_i*dst_strides[i]] <- src[sum_i idx_i*src_strides[i]] over dims[4] (host arrays); accumulate = 0: dst
  * is bf16 (cast), accumulate = 1: dst is fp32 and += (conv weights <-> GEMM operand layouts, weight gradients back). */
 int ccd_permute4(const float* src, const long* src_strides, const long* dst_strides, const int* dims, void* dst,

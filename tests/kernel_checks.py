@@ -934,6 +934,81 @@ def check_conv_pieces(dev, seed=20):
     close(dw, wct_q.grad, 1e-2, 0.2, "cls/dw"); close(db, bct.grad, 1e-2, 0.2, "cls/db")
 
 
+def check_cls_tail(dev, images=2, seed=61, ld_pad=0):
+    """The fused tail of the segmentation head (kernels/cls_tail.h: BatchNorm + ReLU + Conv2d(128, 2, 3) forward; the classifier's
+    data gradient + BatchNorm's backward sums; dy, the transposed conv's bias gradient, cls.weight's gradient) against torch
+    (F.conv2d + autograd in fp64 on the operands the kernels see: a and dlogits rounded to bf16, w rounded to bf16) and against
+    the unfused kernels of conv.h it replaces."""
+    from ccd_amd import seghead as sh
+    g = torch.Generator().manual_seed(seed)
+    C, H, W = 128, 32, 128
+    P = images * H * W
+    y_full = torch.empty((P, C + ld_pad), dtype=BF)
+    y_full[:, :C] = (rnd((P, C), g) * 1.3 + 0.2).to(BF)
+    y_full[:, C:] = 77.0                                                      # (a padded row pitch: never read)
+    y = y_full[:, :C]
+    yf = y.float()
+    mean, var = yf.mean(0) + 0.05 * rnd((C,), g), yf.var(0, unbiased=False) * (1.0 + 0.1 * torch.rand((C,), generator=g))
+    mean_rstd = torch.cat([mean, torch.rsqrt(var + 1e-5)]).contiguous()
+    gamma, beta = torch.empty(C).uniform_(0.5, 1.5, generator=g), torch.empty(C).uniform_(-0.3, 0.3, generator=g)
+    w, bias = rnd((2, C, 3, 3), g, 0.05), rnd((2,), g, 0.1)
+    dl = rnd((images, 2, H, W), g) / 64.0
+    dl[0, :, 0, :5] *= 40.0                                                   # corners / edges carry weight (the zero padding)
+    dl[-1, :, H - 1, W - 3:] *= 40.0
+    yd = y_full.to(dev)[:, :C]
+    mr_d, ga_d, be_d, w_d, b_d, dl_d = (t.to(dev) for t in (mean_rstd, gamma, beta, w, bias, dl))
+    assert ops.cls_tail_supported(yd, H, W)
+    # ---- forward
+    got = ops.cls_tail_fwd(yd, mr_d, ga_d, be_d, w_d, b_d, images, H, W)
+    xh = (yf - mean) * mean_rstd[C:]
+    pre = xh * gamma + beta
+    a = torch.relu(pre).to(BF).double()                                       # the operand of the product
+    wq = w.to(BF).double()
+    a_img = a.view(images, H, W, C).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    wq.requires_grad_(True)
+    want = F.conv2d(a_img, wq, bias.double(), padding=1)
+    close(got, want, 2e-4, 2e-4, "cls_tail/logits")
+    a_dev = ops.bn_relu_fwd(yd, mr_d, ga_d, be_d, torch.empty((P, C), dtype=BF, device=dev))
+    unfused = sh.cls_forward(a_dev, w_d, b_d, images, H, W)
+    close(got, unfused, 1e-5, 2e-5, "cls_tail/logits vs conv.h")
+    # ---- backward: the sums
+    dlq = dl.to(BF).double()
+    want.backward(dlq)
+    d_a = a_img.grad.permute(0, 2, 3, 1).reshape(P, C)
+    mask = (pre > 0).double()
+    d = d_a * mask
+    red_want = torch.cat([d.sum(0), (d * xh.double()).sum(0)])
+    red = torch.zeros(2 * C, device=dev)
+    db = torch.full((2,), 0.25, device=dev)
+    ops.cls_tail_bwd_reduce(dl_d, yd, mr_d, ga_d, be_d, w_d, red, db, images, H, W)
+    scale = float(red_want.abs().max())
+    close(red, red_want, 2e-3, 2e-3 * scale, "cls_tail/red")
+    close(db, 0.25 + dl.double().sum((0, 2, 3)), 1e-4, 1e-5, "cls_tail/db_cls")
+    # ---- backward: dy and the parameter gradients (red as another rank would have changed it: not this rank's own sums)
+    red_all = (red_want * 1.7).float()
+    count = float(P) * 1.7
+    k0, k1 = red_all[:C].double() / count, red_all[C:].double() / count
+    dy_want = (gamma * mean_rstd[C:]).double() * (d - k0 - xh.double() * k1)
+    dy_full = torch.full((P, C + ld_pad), 5.0, dtype=BF, device=dev)
+    dgamma, dbeta = torch.full((C,), 1.0, device=dev), torch.full((C,), -2.0, device=dev)
+    dw, dbt = torch.full((2, C, 3, 3), 0.5, device=dev), torch.full((C,), 3.0, device=dev)
+    red_local = torch.cat([d.sum(0), (d * xh.double()).sum(0)]).float().to(dev)
+    ops.cls_tail_bwd_apply(dl_d, yd, mr_d, ga_d, be_d, w_d, red_all.to(dev), count, red_local, dgamma, dbeta, dw, dbt, dy_full[:, :C],
+                           images, H, W)
+    close(dy_full[:, :C], dy_want, 1.2e-2, 1e-2 * float(dy_want.abs().max()) / 50, "cls_tail/dy")
+    if ld_pad:
+        assert bool((dy_full[:, C:].float() == 5.0).all()), "cls_tail/dy wrote past its 128 columns"
+    close(dbeta, -2.0 + red_local[:C], 1e-6, 1e-6, "cls_tail/dbeta")
+    close(dgamma, 1.0 + red_local[C:], 1e-6, 1e-6, "cls_tail/dgamma")
+    close(dbt, 3.0 + dy_full[:, :C].double().sum(0), 1e-3, 1e-3 * float(dy_want.abs().max()) * math.sqrt(P), "cls_tail/dbias_t")
+    close(dw, 0.5 + wq.grad, 2e-3, 2e-3 * float(wq.grad.abs().max()), "cls_tail/dw_cls")
+    # ---- and against the unfused chain on the same inputs
+    dx_u = sh.cls_backward(dl_d, a_dev, w_d, torch.zeros((2, C, 3, 3), device=dev), torch.zeros(2, device=dev), images, H, W)
+    red_u = torch.zeros(2 * C, device=dev)
+    ops.bn_relu_bwd_reduce(dx_u, yd, mr_d, ga_d, be_d, red_u)
+    close(red, red_u, 2e-2, 2e-2 * scale, "cls_tail/red vs conv.h")            # (conv.h rounds d(a) to bf16 on the way)
+
+
 def check_seghead(dev, images=1, E=64, seed=21, build_ref=None):
     """SegHeadFn (HIP) vs the reference-shaped nn.Module stack in fp32 (torch library convs) on the same weights."""
     import copy

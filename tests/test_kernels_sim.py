@@ -307,6 +307,10 @@ def test_kmeans2_mask_sim(sim):
     kc.check_kmeans2_mask(sim.device, extra=4)
 
 
+def test_cls_tail_sim(sim):
+    kc.check_cls_tail(sim.device, images=1)
+
+
 def test_augment_views_sim(sim):
     kc.check_augment_views(sim.device, H=16, W=40)
 

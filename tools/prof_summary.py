@@ -23,15 +23,28 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
     ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--sequence", default=None, help="also write the LAST iteration launch by launch (markdown) to this file")
     a = ap.parse_args()
     rows = []
     with open(a.trace) as f:
         for r in csv.DictReader(f):
+            grid = int(r.get("Grid_Size_X", 0) or 0) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
+            wg = int(r.get("Workgroup_Size_X", 1) or 1) * int(r.get("Workgroup_Size_Y", 1) or 1) * int(r.get("Workgroup_Size_Z", 1) or 1)
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["VGPR_Count"]),
-                         int(r["Accum_VGPR_Count"]), int(r["LDS_Block_Size"])))
+                         int(r["Accum_VGPR_Count"]), int(r["LDS_Block_Size"]), grid // max(wg, 1), wg))
     rows.sort()
     marks = [i for i, r in enumerate(rows) if "patch_embed_fwd_kernel" in r[2]]
     assert len(marks) >= 2 * a.steps, "trace too short"
+    if a.sequence:
+        last = rows[marks[-2]:]
+        with open(a.sequence, "w") as f:
+            f.write(f"# the last iteration of `{a.trace}`, launch by launch ({len(last)} launches)\n\n")
+            f.write("| # | start ms | kernel | workgroups x threads | us | gap before us |\n|---|---|---|---|---|---|\n")
+            t0, prev_end = last[0][0], last[0][0]
+            for i, (s_, e_, n, v, av, lds, wgs, wg) in enumerate(last):
+                f.write(f"| {i} | {(s_ - t0) / 1e6:.3f} | `{short(n)[:70]}` | {wgs} x {wg} | {(e_ - s_) / 1e3:.1f} | {(s_ - prev_end) / 1e3:.1f} |\n")
+                prev_end = max(prev_end, e_)
+    rows = [r[:6] for r in rows]
     begin = marks[-2 * a.steps]                      # two launches per iteration: student, then teacher
     sel = rows[begin:]
     wall_ms = (sel[-1][1] - sel[0][0]) / 1e6
