@@ -90,6 +90,8 @@ SIGNATURES = {
     "ccd_cls_tail_bwd_reduce": [P, P, L, P, P, P, P, P, P, I, I, I, I, P],
     "ccd_cls_tail_bwd_apply": [P, P, L, P, P, P, P, P, F, P, P, P, P, P, P, L, I, I, I, I, P],
     "ccd_permute4": [P, P, P, P, P, I, P],
+    "ccd_permute4_multi": [P, I, I, P],
+    "ccd_bn_finalize_multi": [P, I, P],
     "ccd_dropout": [P, I, P, P, I, L, U64, F, P],
     "ccd_droppath_scales": [P, P, I, I, U64, P, P],
     "ccd_dec_embed_fwd": [P, P, P, P, I, I, I, I, U64, F, P],

@@ -1219,6 +1219,43 @@ int ccd_permute4(const float* src, const long* src_strides, const long* dst_stri
     return ccd_rt_last_error();
 }
 
+int ccd_permute4_multi(const ccd_permute4_job* jobs, int n, int accumulate, void* stream) {
+    CCD_CHECK(jobs && n >= 0 && n <= ccd::PERMUTE_MULTI_MAX, CCD_EINVAL);
+    if (n == 0) return CCD_OK;
+    ccd::PermuteJobs t;
+    t.n = n;
+    unsigned blocks = 0;
+    for (int k = 0; k < n; ++k) {
+        CCD_CHECK(jobs[k].src && jobs[k].dst, CCD_EINVAL);
+        long total = 1;
+        for (int i = 0; i < 4; ++i) {
+            CCD_CHECK(jobs[k].dims[i] > 0, CCD_EINVAL);
+            t.j[k].q.s[i] = jobs[k].src_strides[i]; t.j[k].q.d[i] = jobs[k].dst_strides[i]; t.j[k].q.n[i] = jobs[k].dims[i];
+            total *= jobs[k].dims[i];
+        }
+        t.j[k].src = jobs[k].src; t.j[k].dst = jobs[k].dst; t.j[k].total = total; t.j[k].first_block = blocks;
+        blocks += (unsigned)((total + 255) / 256);
+    }
+    if (accumulate) CCD_LAUNCH((ccd::permute4_multi_kernel<true>), dim3(blocks), dim3(256), 0, stream, t);
+    else CCD_LAUNCH((ccd::permute4_multi_kernel<false>), dim3(blocks), dim3(256), 0, stream, t);
+    return ccd_rt_last_error();
+}
+
+int ccd_bn_finalize_multi(const ccd_bn_finalize_job* jobs, int n, void* stream) {
+    CCD_CHECK(jobs && n >= 0 && n <= ccd::BN_MULTI_MAX, CCD_EINVAL);
+    if (n == 0) return CCD_OK;
+    ccd::BnFinalizeJobs t;
+    int cmax = 0;
+    for (int k = 0; k < ccd::BN_MULTI_MAX; ++k) {
+        const ccd_bn_finalize_job& q = jobs[k < n ? k : 0];
+        if (k < n) CCD_CHECK(q.stats && q.mean_rstd && q.running_mean && q.running_var && q.C > 0 && q.count > 1.0f, CCD_EINVAL);
+        t.j[k] = ccd::BnFinalizeJob{q.stats, q.mean_rstd, q.running_mean, q.running_var, q.batches, q.count, q.eps, q.momentum, q.C};
+        if (k < n && q.C > cmax) cmax = q.C;
+    }
+    CCD_LAUNCH(ccd::bn_finalize_multi_kernel, dim3((cmax + 63) / 64, n), dim3(64), 0, stream, t);
+    return ccd_rt_last_error();
+}
+
 // ------------------------------------------------------------------------------------------ finetune path
 static void ccd_drop_consts(float p, unsigned* thr, float* scale) {
     if (!(p > 0.f)) { *thr = 0u; *scale = 1.0f; return; }

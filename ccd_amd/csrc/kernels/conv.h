@@ -49,6 +49,28 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, float count,
     running_var[c] = (1.0f - momentum) * running_var[c] + momentum * var * (count / (count - 1.0f));
 }
 
+// The same for up to BN_MULTI_MAX layers in ONE launch (blockIdx.y = layer), which also counts the batch (num_batches_tracked += 1):
+// the head has 8 BatchNorm layers in 4 dependent groups, and a 5-us launch per layer and per counter was 16 launches of a 1.6-ms forward.
+constexpr int BN_MULTI_MAX = 4;
+struct BnFinalizeJob {
+    const float* stats; float* mean_rstd; float* running_mean; float* running_var; long* batches;
+    float count, eps, momentum; int C;
+};
+struct BnFinalizeJobs { BnFinalizeJob j[BN_MULTI_MAX]; };
+__global__ void bn_finalize_multi_kernel(BnFinalizeJobs jobs) {
+    const BnFinalizeJob& q = jobs.j[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && q.batches) *q.batches += 1;
+    if (c >= q.C) return;
+    const float mean = q.stats[c] / q.count;
+    float var = q.stats[q.C + c] / q.count - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    q.mean_rstd[c] = mean;
+    q.mean_rstd[q.C + c] = 1.0f / sqrtf(var + q.eps);
+    q.running_mean[c] = (1.0f - q.momentum) * q.running_mean[c] + q.momentum * mean;
+    q.running_var[c] = (1.0f - q.momentum) * q.running_var[c] + q.momentum * var * (q.count / (q.count - 1.0f));
+}
+
 // y = relu((x - mean) * rstd * gamma + beta); x [rows, ldx], y [rows, ldy] bf16; 8 channels per thread.
 // A thread walks chunks 256 apart (a multiple of C / 8: it keeps ITS 8 channels, their 32 parameters are loaded once; the row
 // index advances by 256 / (C / 8) - as one chunk per thread the kernel did a 64-bit division and 32 parameter loads per 16-byte
@@ -286,6 +308,27 @@ __global__ __launch_bounds__(256) void permute4_kernel(const float* __restrict__
     const long o = i0 * q.d[0] + i1 * q.d[1] + i2 * q.d[2] + i3 * q.d[3];
     if (ACC) reinterpret_cast<float*>(dst)[o] += v;
     else reinterpret_cast<bf16_t*>(dst)[o] = f2bf(v);
+}
+
+// Up to PERMUTE_MULTI_MAX re-layouts in one launch (the head re-lays 22 weight tensors into GEMM operands per step and folds 5 staged
+// weight gradients back: 27 launches of ~5 us); a block finds its job in the table of first blocks (wave-uniform scan).
+constexpr int PERMUTE_MULTI_MAX = 24;
+struct PermuteJob { const float* src; void* dst; Permute4 q; long total; unsigned first_block; };
+struct PermuteJobs { PermuteJob j[PERMUTE_MULTI_MAX]; int n; };
+template <bool ACC>
+__global__ __launch_bounds__(256) void permute4_multi_kernel(PermuteJobs jobs) {
+    int k = 0;
+    while (k + 1 < jobs.n && blockIdx.x >= jobs.j[k + 1].first_block) ++k;
+    const PermuteJob& jb = jobs.j[k];
+    const Permute4& q = jb.q;
+    const long i = (long)(blockIdx.x - jb.first_block) * 256 + threadIdx.x;
+    if (i >= jb.total) return;
+    const int i3 = (int)(i % q.n[3]), i2 = (int)((i / q.n[3]) % q.n[2]), i1 = (int)((i / ((long)q.n[3] * q.n[2])) % q.n[1]);
+    const long i0 = i / ((long)q.n[3] * q.n[2] * q.n[1]);
+    const float v = jb.src[i0 * q.s[0] + i1 * q.s[1] + i2 * q.s[2] + i3 * q.s[3]];
+    const long o = i0 * q.d[0] + i1 * q.d[1] + i2 * q.d[2] + i3 * q.d[3];
+    if (ACC) reinterpret_cast<float*>(jb.dst)[o] += v;
+    else reinterpret_cast<bf16_t*>(jb.dst)[o] = f2bf(v);
 }
 
 }  // namespace ccd

@@ -835,6 +835,56 @@ def permute4(src, strides, dims, dst, accumulate=False, dst_strides=None):
     return dst
 
 
+class _PermuteJob(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("src_strides", ctypes.c_long * 4),
+                ("dst_strides", ctypes.c_long * 4), ("dims", ctypes.c_int * 4)]
+
+
+PERMUTE_MULTI_MAX = 24
+
+
+def permute4_multi(jobs, accumulate=False):
+    """jobs: [(src, strides, dims, dst[, dst_strides])] - ops.permute4's arguments, up to 24 of them in ONE launch."""
+    for lo in range(0, len(jobs), PERMUTE_MULTI_MAX):
+        part = jobs[lo:lo + PERMUTE_MULTI_MAX]
+        arr = (_PermuteJob * len(part))()
+        for k, job in enumerate(part):
+            src, strides, dims, dst = job[:4]
+            dst_strides = job[4] if len(job) > 4 else None
+            _chk(src, F32, "src"); _chk(dst, F32 if accumulate else BF16, "dst")
+            n = list(dims) + [1] * (4 - len(dims))
+            s_ = list(strides) + [0] * (4 - len(strides))
+            if dst_strides is None:
+                d = [n[1] * n[2] * n[3], n[2] * n[3], n[3], 1]
+                assert dst.is_contiguous() and dst.numel() == n[0] * n[1] * n[2] * n[3]
+            else:
+                d = list(dst_strides) + [0] * (4 - len(dst_strides))
+            arr[k].src, arr[k].dst = _lib.ptr(src), _lib.ptr(dst)
+            arr[k].src_strides[:], arr[k].dst_strides[:], arr[k].dims[:] = s_, d, n
+        _call("ccd_permute4_multi", ctypes.cast(arr, ctypes.c_void_p).value, len(part), 1 if accumulate else 0)
+
+
+class _BnFinalizeJob(ctypes.Structure):
+    _fields_ = [("stats", ctypes.c_void_p), ("mean_rstd", ctypes.c_void_p), ("running_mean", ctypes.c_void_p),
+                ("running_var", ctypes.c_void_p), ("batches", ctypes.c_void_p), ("count", ctypes.c_float), ("eps", ctypes.c_float),
+                ("momentum", ctypes.c_float), ("C", ctypes.c_int)]
+
+
+def bn_finalize_multi(jobs):
+    """jobs: [(stats, count, eps, momentum, mean_rstd, running_mean, running_var, num_batches_tracked or None)], at most 4: the
+    BatchNorm layers of one level in one launch (mean / rstd, running statistics, batch counter)."""
+    assert 1 <= len(jobs) <= 4
+    arr = (_BnFinalizeJob * len(jobs))()
+    for k, (stats, count, eps, momentum, mean_rstd, rm, rv, nb) in enumerate(jobs):
+        C = rm.numel()
+        assert stats.numel() == 2 * C and mean_rstd.numel() == 2 * C and (nb is None or nb.dtype == torch.int64)
+        arr[k].stats, arr[k].mean_rstd, arr[k].running_mean, arr[k].running_var = (_lib.ptr(stats), _lib.ptr(mean_rstd), _lib.ptr(rm),
+                                                                                    _lib.ptr(rv))
+        arr[k].batches = _lib.ptr(nb) if nb is not None else None
+        arr[k].count, arr[k].eps, arr[k].momentum, arr[k].C = float(count), float(eps), float(momentum), C
+    _call("ccd_bn_finalize_multi", ctypes.cast(arr, ctypes.c_void_p).value, len(jobs))
+
+
 # ------------------------------------------------------------------------------------------------ finetune path
 I64 = torch.int64
 

@@ -100,9 +100,10 @@ class _BN:
 class _BNGroup:
     """BatchNorm layers of one level whose statistics are exchanged together."""
 
-    def __init__(self, mods, rows, device):
+    def __init__(self, mods, rows, device, buf=None):
         sizes = [2 * m.num_features for m in mods]
-        self.buf = torch.zeros(sum(sizes), dtype=F32, device=device)
+        self.buf = buf if buf is not None else torch.zeros(sum(sizes), dtype=F32, device=device)      # (buf: a zeroed slice of the caller's arena)
+        assert self.buf.numel() == sum(sizes)
         offs = [sum(sizes[:i]) for i in range(len(sizes))]
         self.bns = [_BN(m, rows, device, self.buf[o:o + n]) for m, o, n in zip(mods, offs, sizes)]
         self.sync = any(b.sync for b in self.bns)
@@ -111,12 +112,17 @@ class _BNGroup:
     def finalize(self):
         if self.sync and self.bns[0].mod.training:
             dist.all_reduce(self.buf)                 # one collective for the whole level
+        if all(b.mod.training and b.mod.momentum is not None for b in self.bns) and len(self.bns) <= 4:
+            # one launch for the level: mean / rstd, running statistics and the batch counters of all its layers
+            ops.bn_finalize_multi([(b.stats, b.count, b.mod.eps, b.mod.momentum, b.mean_rstd, b.mod.running_mean, b.mod.running_var,
+                                    b.mod.num_batches_tracked) for b in self.bns])
+            return
         for b in self.bns:
             b.finalize()
 
-    def backward(self, dys, xs, dxs):
-        """dys / xs / dxs: per layer.  Reduce all layers, ONE all-reduce, apply all layers."""
-        red = torch.zeros_like(self.buf)
+    def backward(self, dys, xs, dxs, red=None):
+        """dys / xs / dxs: per layer.  Reduce all layers, ONE all-reduce, apply all layers.  red: a zeroed slice of the caller's arena."""
+        red = red if red is not None else torch.zeros_like(self.buf)
         slices = [red[o:o + n] for o, n in zip(self._offs, self._sizes)]
         for b, dy, x, r in zip(self.bns, dys, xs, slices):
             b.backward_reduce(dy, x, r)
@@ -127,13 +133,13 @@ class _BNGroup:
         loc = [red_local[o:o + n] for o, n in zip(self._offs, self._sizes)]
         return [b.backward_apply(dy, x, dx, r, rl) for b, dy, x, dx, r, rl in zip(self.bns, dys, xs, dxs, slices, loc)]
 
-    def backward_cls_tail(self, d_logits, y, cls, dbias_t, images, H, W):
+    def backward_cls_tail(self, d_logits, y, cls, dbias_t, images, H, W, red=None):
         """The group of the LAST level (one BatchNorm) under the classifier `cls`: kernels/cls_tail.h.  -> d(y) bf16; cls.weight.grad,
         cls.bias.grad, the BatchNorm's parameter gradients and dbias_t (the transposed conv's bias gradient) accumulate."""
         bn = self.bns[0]
         mod = bn.mod
         w = cls.weight.detach()
-        red = torch.zeros_like(self.buf)
+        red = red if red is not None else torch.zeros_like(self.buf)
         ops.cls_tail_bwd_reduce(d_logits, y, bn.mean_rstd, mod.weight.detach(), mod.bias.detach(), w, red, cls.bias.grad, images, H, W)
         red_local = red
         if self.sync:
@@ -143,6 +149,21 @@ class _BNGroup:
             red = torch.zeros_like(red)
         return ops.cls_tail_bwd_apply(d_logits, y, bn.mean_rstd, mod.weight.detach(), mod.bias.detach(), w, red, bn.count, red_local,
                                       mod.weight.grad, mod.bias.grad, cls.weight.grad, dbias_t, torch.empty_like(y), images, H, W)
+
+
+class _Zeros:
+    """One zero-filled fp32 allocation handed out in slices: the head's statistics / reduction / staging buffers were a dozen
+    `torch.zeros` (a 5-us fill launch each) per pass."""
+
+    def __init__(self, sizes, device):
+        self.buf = torch.zeros(sum(-(-n // 64) * 64 for n in sizes), dtype=F32, device=device)       # (256-byte aligned slices)
+        self.at = 0
+
+    def take(self, n):
+        out = self.buf[self.at:self.at + n]
+        self.at += -(-n // 64) * 64
+        assert self.at <= self.buf.numel()
+        return out
 
 
 def _ensure_grads(module):
@@ -176,6 +197,41 @@ def cls_backward(d_logits, x, w, dw, db, images, H, W):
     return dx
 
 
+def _relaid_weights(head, E, mid, out_c, dev):
+    """Every bf16 GEMM operand the head's forward AND backward take from its fp32 master weights, re-laid in ONE launch
+    (ops.permute4_multi; they were 22 launches of ~5 us per step).  -> dict of tensors."""
+    heads = [head.mlahead.head2, head.mlahead.head3, head.mlahead.head4]
+    w, jobs = {"w1": [], "w2": [], "w2t": [], "w1d": [], "wp": [], "wt": []}, []
+
+    def job(key, src, strides, dims, shape):
+        dst = torch.empty(shape, dtype=BF16, device=dev)
+        jobs.append((src, strides, dims, dst))
+        w[key].append(dst)
+
+    for seq in heads:
+        w3, w1x1 = seq[0].weight.detach(), seq[3].weight.detach()
+        job("w1", w3, (E * 9, 1, 9), (mid, 9, E), (mid, 9 * E))                    # forward 3x3: [co][tap][ci]
+        job("w2", w1x1, (mid, 1), (out_c, mid), (out_c, mid))                      # forward 1x1
+        job("w2t", w1x1, (1, mid), (mid, out_c), (mid, out_c))                     # its data gradient
+        job("w1d", w3, (9, 1, E * 9), (E, 9, mid), (E, 9 * mid))                   # 3x3 data gradient: [ci][tap][co] <- W[co][ci][tap]
+    for seq in (head.unpool1, head.unpool2):
+        convt = seq[0]
+        cin, cout = convt.in_channels, convt.out_channels
+        wsrc = convt.weight.detach()                                               # [cin, cout, 4, 4]
+        per = []
+        for py in (0, 1):
+            for px in (0, 1):
+                pt = _parity_taps(py, px)
+                ky0, kx0 = pt[0][0], pt[0][1]                                      # taps advance by +2 in ky (outer) / kx (inner)
+                dst = torch.empty((cout, 4 * cin), dtype=BF16, device=dev)
+                jobs.append((wsrc.reshape(-1)[ky0 * 4 + kx0:], (16, 8, 2, cout * 16), (cout, 2, 2, cin), dst))
+                per.append(dst)
+        w["wp"].append(per)
+        job("wt", wsrc, (cout * 16, 1, 16), (cin, 16, cout), (cin, 16 * cout))     # data gradient: [ci][tap][co] <- W[ci][co][tap]
+    ops.permute4_multi(jobs)
+    return w
+
+
 class SegHeadFn(torch.autograd.Function):
     """(tap2, tap3, tap4: bf16 [N*256, E]) -> fp32 logits [N, 2, 32, 128]; parameter gradients go straight to .grad."""
 
@@ -190,27 +246,26 @@ class SegHeadFn(torch.autograd.Function):
         mla = head.mlahead
         heads = [mla.head2, mla.head3, mla.head4]
         mid, out_c = heads[0][0].out_channels, heads[0][3].out_channels
+        ups_mods = (head.unpool1, head.unpool2)
         d3 = ops.conv_desc((gh, gw), (gh, gw), E, TAPS3)
         d1 = ops.conv_desc((gh, gw), (gh, gw), mid, TAPS1)
         cat = torch.empty((M, 3 * out_c), dtype=BF16, device=dev)
-        saved = {"taps": taps, "y1": [], "a1": [], "y2": [], "w2": []}
+        wts = _relaid_weights(head, E, mid, out_c, dev)
+        zeros = _Zeros([6 * mid, 6 * out_c] + [2 * seq[0].out_channels for seq in ups_mods], dev)     # the four levels' statistics
+        saved = {"taps": taps, "y1": [], "a1": [], "y2": [], "w": wts}
         # level 1 of the three independent branches (3x3 conv), ONE statistics exchange, then level 2 (1x1 conv), ONE more
-        g1 = _BNGroup([seq[1] for seq in heads], M, dev)
+        g1 = _BNGroup([seq[1] for seq in heads], M, dev, zeros.take(6 * mid))
         for i, seq in enumerate(heads):
-            w1 = ops.permute4(seq[0].weight.detach(), (E * 9, 1, 9), (mid, 9, E),
-                              torch.empty((mid, 9 * E), dtype=BF16, device=dev))
             y1 = torch.empty((M, mid), dtype=BF16, device=dev)
-            ops.conv_gemm(taps[i], d3, w1, M, y1, colsum=g1.bns[i].stats[:mid], colsumsq=g1.bns[i].stats[mid:])
+            ops.conv_gemm(taps[i], d3, wts["w1"][i], M, y1, colsum=g1.bns[i].stats[:mid], colsumsq=g1.bns[i].stats[mid:])
             saved["y1"].append(y1)
         g1.finalize()
-        g2 = _BNGroup([seq[4] for seq in heads], M, dev)
+        g2 = _BNGroup([seq[4] for seq in heads], M, dev, zeros.take(6 * out_c))
         for i, seq in enumerate(heads):
             a1 = g1.bns[i].forward(saved["y1"][i], torch.empty_like(saved["y1"][i]))
-            w2 = torch.empty((out_c, mid), dtype=BF16, device=dev)
-            ops.permute4(seq[3].weight.detach(), (mid, 1), (out_c, mid), w2)
             y2 = torch.empty((M, out_c), dtype=BF16, device=dev)
-            ops.conv_gemm(a1, d1, w2, M, y2, colsum=g2.bns[i].stats[:out_c], colsumsq=g2.bns[i].stats[out_c:])
-            for k, v in (("a1", a1), ("y2", y2), ("w2", w2)):
+            ops.conv_gemm(a1, d1, wts["w2"][i], M, y2, colsum=g2.bns[i].stats[:out_c], colsumsq=g2.bns[i].stats[out_c:])
+            for k, v in (("a1", a1), ("y2", y2)):
                 saved[k].append(v)
         g2.finalize()
         for i in range(3):
@@ -218,23 +273,18 @@ class SegHeadFn(torch.autograd.Function):
         saved["g1"], saved["g2"] = g1, g2
         x, grid = cat, (gh, gw)
         ups = []
-        for seq in (head.unpool1, head.unpool2):
+        for lvl, seq in enumerate(ups_mods):
             convt, bnm = seq[0], seq[1]
             cin, cout = convt.in_channels, convt.out_channels
             rows = images * grid[0] * grid[1]
             y = torch.empty((4 * rows, cout), dtype=BF16, device=dev)
-            grp = _BNGroup([bnm], 4 * rows, dev)
+            grp = _BNGroup([bnm], 4 * rows, dev, zeros.take(2 * cout))
             bn = grp.bns[0]
-            wsrc = convt.weight.detach()                                   # [cin, cout, 4, 4]
-            for py in (0, 1):
-                for px in (0, 1):
-                    pt = _parity_taps(py, px)
-                    desc = ops.conv_desc(grid, grid, cin, [(dy, dx) for _, _, dy, dx in pt], parity=(py, px))
-                    wp = torch.empty((cout, 4 * cin), dtype=BF16, device=dev)
-                    ky0, kx0 = pt[0][0], pt[0][1]                          # taps advance by +2 in ky (outer) / kx (inner)
-                    ops.permute4(wsrc.reshape(-1)[ky0 * 4 + kx0:], (16, 8, 2, cout * 16), (cout, 2, 2, cin), wp)
-                    ops.conv_gemm(x, desc, wp, rows, y, bias=convt.bias, colsum=bn.stats[:cout],
-                                  colsumsq=bn.stats[cout:])
+            for cls_i, (py, px) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+                pt = _parity_taps(py, px)
+                desc = ops.conv_desc(grid, grid, cin, [(dy, dx) for _, _, dy, dx in pt], parity=(py, px))
+                ops.conv_gemm(x, desc, wts["wp"][lvl][cls_i], rows, y, bias=convt.bias, colsum=bn.stats[:cout],
+                              colsumsq=bn.stats[cout:])
             grp.finalize()
             ups.append((x, y, grp, grid))
             grid = (2 * grid[0], 2 * grid[1])
@@ -257,56 +307,58 @@ class SegHeadFn(torch.autograd.Function):
     def backward(ctx, d_logits):
         head, images, saved = ctx.head, ctx.images, ctx.saved
         E, mid, out_c, M = ctx.dims
+        wts = saved["w"]
         dev = d_logits.device
         _ensure_grads(head.mlahead)
         for m in (head.unpool1, head.unpool2, head.cls):
             _ensure_grads(m)
         H, W = ctx.grid
+        ups_mods = (head.unpool2, head.unpool1)
+        heads = [head.mlahead.head2, head.mlahead.head3, head.mlahead.head4]
+        # every zero-initialised buffer of the pass from one fill: the levels' reduction sums, then the staged weight gradients
+        stage_sizes = [seq[0].in_channels * 16 * seq[0].out_channels for seq in ups_mods] + [mid * 9 * E] * 3
+        zeros = _Zeros([2 * seq[0].out_channels for seq in ups_mods] + [6 * out_c, 6 * mid] + stage_sizes, dev)
+        reds = [zeros.take(2 * seq[0].out_channels) for seq in ups_mods] + [zeros.take(6 * out_c), zeros.take(6 * mid)]
+        folds = []                                      # (stage, strides, dims, grad): folded back into the parameter layout in ONE launch
         d_logits = d_logits.contiguous().float()
         d = None
         if not ctx.fused_tail:
             d = cls_backward(d_logits, ctx.a_last, head.cls.weight.detach(), head.cls.weight.grad, head.cls.bias.grad, images, H, W)
         ctx.a_last = None
         # ---- transposed convs, last first
-        for seq, (x_in, y, grp, grid) in zip((head.unpool2, head.unpool1), reversed(ctx.ups)):
+        for lvl, (seq, (x_in, y, grp, grid)) in enumerate(zip(ups_mods, reversed(ctx.ups))):
             convt = seq[0]
             cin, cout = convt.in_channels, convt.out_channels
             rows = images * grid[0] * grid[1]
             if d is None:                                                           # classifier + BatchNorm backward, fused
-                dyc = grp.backward_cls_tail(d_logits, y, head.cls, convt.bias.grad, images, H, W)
+                dyc = grp.backward_cls_tail(d_logits, y, head.cls, convt.bias.grad, images, H, W, red=reds[lvl])
             else:
-                dyc = grp.backward([d], [y], [d])[0]                                # in place: d(convT output)
+                dyc = grp.backward([d], [y], [d], red=reds[lvl])[0]                 # in place: d(convT output)
                 ops.colsum_bf16(dyc, convt.bias.grad)
             desc = ops.conv_desc(grid, (2 * grid[0], 2 * grid[1]), cout, TAPS_T_GRAD, s_mul=2)
-            stage = torch.zeros((cin, 16 * cout), dtype=F32, device=dev)
+            stage = zeros.take(cin * 16 * cout).view(cin, 16 * cout)
             ops.conv_wgrad(x_in, dyc, desc, stage)                                  # [ci][tap][co]
-            ops.permute4(stage, (16 * cout, 1, cout), (cin, cout, 16), convt.weight.grad, accumulate=True)
-            wt = torch.empty((cin, 16 * cout), dtype=BF16, device=dev)              # [ci][tap][co] <- W[ci][co][tap]
-            ops.permute4(convt.weight.detach(), (cout * 16, 1, 16), (cin, 16, cout), wt)
-            d = ops.conv_gemm(dyc, desc, wt, rows, torch.empty((rows, cin), dtype=BF16, device=dev))
+            folds.append((stage, (16 * cout, 1, cout), (cin, cout, 16), convt.weight.grad))
+            d = ops.conv_gemm(dyc, desc, wts["wt"][1 - lvl], rows, torch.empty((rows, cin), dtype=BF16, device=dev))
         # ---- the three 3x3 -> 1x1 branches; d = gradient of the concatenated [M, 3*out_c] map
         gh, gw = 8, 32
         d3 = ops.conv_desc((gh, gw), (gh, gw), E, TAPS3)
         d3f = ops.conv_desc((gh, gw), (gh, gw), mid, TAPS3_FLIP)
-        heads = [head.mlahead.head2, head.mlahead.head3, head.mlahead.head4]
         # level 2 of all three branches (one exchange), their 1x1 products, level 1 (one exchange), their 3x3 products
         dy2s = saved["g2"].backward([d[:, i * out_c:(i + 1) * out_c] for i in range(3)], saved["y2"],
-                                    [torch.empty_like(y) for y in saved["y2"]])
+                                    [torch.empty_like(y) for y in saved["y2"]], red=reds[2])
         da1s = []
         for i, seq in enumerate(heads):
             ops.gemm_tn(dy2s[i], saved["a1"][i], seq[3].weight.grad.view(out_c, mid))  # dW2[co][ci]
-            w2t = torch.empty((mid, out_c), dtype=BF16, device=dev)
-            ops.permute4(seq[3].weight.detach(), (1, mid), (mid, out_c), w2t)
-            da1s.append(ops.gemm_nt(dy2s[i], w2t))                                  # [M, mid]
-        dy1s = saved["g1"].backward(da1s, saved["y1"], da1s)
+            da1s.append(ops.gemm_nt(dy2s[i], wts["w2t"][i]))                        # [M, mid]
+        dy1s = saved["g1"].backward(da1s, saved["y1"], da1s, red=reds[3])
         d_taps = []
         for i, seq in enumerate(heads):
-            stage = torch.zeros((mid, 9 * E), dtype=F32, device=dev)
+            stage = zeros.take(mid * 9 * E).view(mid, 9 * E)
             ops.conv_wgrad(dy1s[i], saved["taps"][i], d3, stage)                    # [co][tap][ci]
-            ops.permute4(stage, (9 * E, 1, E), (mid, E, 9), seq[0].weight.grad, accumulate=True)
-            w1d = torch.empty((E, 9 * mid), dtype=BF16, device=dev)                 # [ci][tap][co] <- W[co][ci][tap]
-            ops.permute4(seq[0].weight.detach(), (9, 1, E * 9), (E, 9, mid), w1d)
-            d_taps.append(ops.conv_gemm(dy1s[i], d3f, w1d, M, torch.empty((M, E), dtype=BF16, device=dev)))
+            folds.append((stage, (9 * E, 1, E), (mid, E, 9), seq[0].weight.grad))
+            d_taps.append(ops.conv_gemm(dy1s[i], d3f, wts["w1d"][i], M, torch.empty((M, E), dtype=BF16, device=dev)))
+        ops.permute4_multi(folds, accumulate=True)
         ctx.saved = ctx.ups = None
         return (None, None, *d_taps)
 

@@ -373,6 +373,17 @@ int ccd_cls_tail_bwd_apply(const float* dlogits, const ccd_bf16* y, long ldy, co
 int ccd_permute4(const float* src, const long* src_strides, const long* dst_strides, const int* dims, void* dst,
                  int accumulate, void* stream);
 
+/* Several re-layouts / BatchNorm finalisations in ONE launch (the segmentation head issued 27 + 16 launches of ~5 us per step for
+ * them).  jobs: host array, n <= 24 (permute) / n <= 4 (finalize; the layers of one level, whose statistics arrive together).
+ * ccd_bn_finalize_multi also adds 1 to *batches (nn.BatchNorm2d.num_batches_tracked, int64 on the device) where given. */
+typedef struct { const float* src; void* dst; long src_strides[4]; long dst_strides[4]; int dims[4]; } ccd_permute4_job;
+int ccd_permute4_multi(const ccd_permute4_job* jobs, int n, int accumulate, void* stream);
+typedef struct {
+    const float* stats; float* mean_rstd; float* running_mean; float* running_var; long* batches;
+    float count, eps, momentum; int C;
+} ccd_bn_finalize_job;
+int ccd_bn_finalize_multi(const ccd_bn_finalize_job* jobs, int n, void* stream);
+
 /* ---- finetune path: DINO_Finetune = ViT encoder + Mlp + NRTR decoder + TFLoss ---------------
  * Reference: Dino/model/dino_vision.py:134-246, Dino/decoder/nrtr_decoder.py:92-170, transformer_module.py:8-97,
  * transformer_layers.py:150-163, Dino/loss/ce_loss.py:94-128, train_finetune.py:262-289.  The Linear layers run on

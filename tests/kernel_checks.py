@@ -934,6 +934,48 @@ def check_conv_pieces(dev, seed=20):
     close(dw, wct_q.grad, 1e-2, 0.2, "cls/dw"); close(db, bct.grad, 1e-2, 0.2, "cls/db")
 
 
+def check_multi_launch_helpers(dev, seed=63):
+    """ccd_permute4_multi / ccd_bn_finalize_multi == their one-job-per-launch originals, bit for bit."""
+    g = torch.Generator().manual_seed(seed)
+    srcs = [rnd((5, 7, 3, 4), g), rnd((16, 9, 8), g), rnd((300,), g), rnd((2, 6, 3, 3), g)]
+    specs = [((84, 4, 1, 12), (5, 3, 4, 7)), ((1, 8, 72), (8, 9, 16)), ((1,), (300,)), ((9, 54, 1), (6, 2, 9))]
+    jobs, want = [], []
+    for src, (strides, dims) in zip(srcs, specs):
+        n = 1
+        for d in dims:
+            n *= d
+        sd = src.to(dev)
+        want.append(ops.permute4(sd, strides, dims, torch.empty(n, dtype=BF, device=dev)))
+        jobs.append((sd, strides, dims, torch.full((n,), 9.0, dtype=BF, device=dev)))
+    ops.permute4_multi(jobs)
+    for j, w_ in zip(jobs, want):
+        assert torch.equal(j[3].cpu().view(torch.int16), w_.cpu().view(torch.int16)), "permute4_multi"
+    accs = [torch.full((n_,), 2.0, device=dev) for n_ in (420, 1152)]
+    acc_jobs = [(srcs[0].to(dev), specs[0][0], specs[0][1], accs[0]), (srcs[1].to(dev), specs[1][0], specs[1][1], accs[1])]
+    ops.permute4_multi(acc_jobs, accumulate=True)
+    for (src, strides, dims, got) in acc_jobs:
+        ref = ops.permute4(src, strides, dims, torch.full_like(got, 2.0), accumulate=True)
+        assert torch.equal(got.cpu(), ref.cpu()), "permute4_multi/accumulate"
+    more = [(srcs[2].to(dev), (1,), (300,), torch.empty(300, dtype=BF, device=dev)) for _ in range(30)]      # more jobs than one launch holds
+    ops.permute4_multi(more)
+    assert all(torch.equal(m[3].cpu().view(torch.int16), want[2].cpu().view(torch.int16)) for m in more)
+    # BatchNorm finalisation of three layers of different widths at once
+    single, multi = [], []
+    for C in (128, 64, 40):
+        stats = torch.cat([rnd((C,), g) * 50, torch.rand((C,), generator=g) * 900 + 400]).to(dev)
+        rm, rv = rnd((C,), g).to(dev), (torch.rand((C,), generator=g) + 0.5).to(dev)
+        a = (stats, 1000.0, 1e-5, 0.1, torch.empty(2 * C, device=dev), rm.clone(), rv.clone())
+        ops.bn_finalize(*a)
+        single.append(a)
+        multi.append((stats, 1000.0, 1e-5, 0.1, torch.empty(2 * C, device=dev), rm.clone(), rv.clone(),
+                      torch.full((), 41, dtype=torch.int64, device=dev)))
+    ops.bn_finalize_multi(multi)
+    for a, b in zip(single, multi):
+        for i in (4, 5, 6):
+            assert torch.equal(a[i].cpu(), b[i].cpu()), "bn_finalize_multi"
+        assert int(b[7]) == 42
+
+
 def check_cls_tail(dev, images=2, seed=61, ld_pad=0):
     """The fused tail of the segmentation head (kernels/cls_tail.h: BatchNorm + ReLU + Conv2d(128, 2, 3) forward; the classifier's
     data gradient + BatchNorm's backward sums; dy, the transposed conv's bias gradient, cls.weight's gradient) against torch
@@ -1026,6 +1068,8 @@ def check_seghead(dev, images=1, E=64, seed=21, build_ref=None):
     taps = [rnd((images * 256, E), g).to(BF) for _ in range(3)]
     tin = [t.to(dev).requires_grad_(True) for t in taps]
     logits = sh.seg_head_forward(head, tin, images)
+    assert all(int(m.num_batches_tracked) == 1 for n_, m in head.named_modules()
+               if isinstance(m, torch.nn.BatchNorm2d) and not n_.startswith("conv_mla")), "num_batches_tracked"
     rin = [t.float().view(images, 8, 32, E).permute(0, 3, 1, 2).contiguous().detach().requires_grad_(True) for t in taps]
     x = ref.mlahead(*rin)
     want = ref.cls(ref.unpool2(ref.unpool1(x)))

@@ -333,6 +333,10 @@ def test_kmeans2_mask(hip):
     kc.check_kmeans2_mask(hip.device)
 
 
+def test_multi_launch_helpers(hip):
+    kc.check_multi_launch_helpers(hip.device)
+
+
 def test_cls_tail(hip):
     kc.check_cls_tail(hip.device, images=2)
     kc.check_cls_tail(hip.device, images=67, seed=62, ld_pad=8)             # more bands than the grid takes at once; padded pitch

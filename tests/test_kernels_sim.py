@@ -307,6 +307,10 @@ def test_kmeans2_mask_sim(sim):
     kc.check_kmeans2_mask(sim.device, extra=4)
 
 
+def test_multi_launch_helpers_sim(sim):
+    kc.check_multi_launch_helpers(sim.device)
+
+
 def test_cls_tail_sim(sim):
     kc.check_cls_tail(sim.device, images=1)
 
