@@ -36,9 +36,11 @@ def main():
     marks = [i for i, r in enumerate(rows) if "patch_embed_fwd_kernel" in r[2]]
     assert len(marks) >= 2 * a.steps, "trace too short"
     if a.sequence:
-        last = rows[marks[-2]:]
+        # the iteration BEFORE the last one (the last one's tail runs into the end of the process: readbacks, idle queue), up to and
+        # including the first launch of the next, so that the gap at the iteration boundary shows
+        last = rows[marks[-4]:marks[-2] + 1] if len(marks) >= 4 else rows[marks[-2]:]
         with open(a.sequence, "w") as f:
-            f.write(f"# the last iteration of `{a.trace}`, launch by launch ({len(last)} launches)\n\n")
+            f.write(f"# one steady-state iteration of `{a.trace}`, launch by launch ({len(last)} launches, the last row = the next iteration's first)\n\n")
             f.write("| # | start ms | kernel | workgroups x threads | us | gap before us |\n|---|---|---|---|---|---|\n")
             t0, prev_end = last[0][0], last[0][0]
             for i, (s_, e_, n, v, av, lds, wgs, wg) in enumerate(last):
