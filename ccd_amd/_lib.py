@@ -55,7 +55,7 @@ SIGNATURES = {
     "ccd_mask_to_idmap": [P, P, I, P],
     "ccd_seg_to_mask": [P, P, I, P],
     "ccd_kmeans2_mask": [P, P, P, P, I, P],
-    "ccd_augment_views": [P, P, P, P, P, I, I, I, P, P, P, I, P],
+    "ccd_augment_views": [P, P, P, P, P, I, I, I, P, P, P, I, P, I, P],
     "ccd_warp_idmap": [P, P, I, P, I, P],
     "ccd_region_stats": [P, P, P, P, I, P],
     "ccd_select_scan": [P, I, P, P, P, P, P],

@@ -807,9 +807,10 @@ int ccd_kmeans2_mask(const uint8_t* gray, const long* offsets, const int* hw, ui
 }
 int ccd_augment_views(const uint8_t* img, const float* params, const float* theta, float* out, uint8_t* staged_ws, int batch,
                       int height, int width, const float* mean3, const float* std3, const uint16_t* overlay, int overlay_layers,
-                      void* stream) {
+                      const float* warp_maps, int warp_count, void* stream) {
     CCD_CHECK(img && params && theta && out && staged_ws && mean3 && std3 && batch >= 0, CCD_EINVAL);
     CCD_CHECK(overlay_layers >= 0 && (overlay != nullptr) == (overlay_layers > 0), CCD_EINVAL);
+    CCD_CHECK(warp_count >= 0 && (warp_maps != nullptr) == (warp_count > 0), CCD_EINVAL);
     CCD_CHECK(height >= 2 && width >= 2 && (long)height * width < (1L << 24), CCD_ESHAPE);
     CCD_CHECK(ccd::aug_spatial_smem(height, width) <= 160 * 1024, CCD_ESHAPE);      // the pre-pass keeps a (sample, view) image in LDS
     CCD_CHECK(std3[0] > 0.f && std3[1] > 0.f && std3[2] > 0.f, CCD_EINVAL);
@@ -817,7 +818,8 @@ int ccd_augment_views(const uint8_t* img, const float* params, const float* thet
     CCD_LAUNCH(ccd::augment_spatial_kernel, dim3(2 * batch), dim3(256), (int)ccd::aug_spatial_smem(height, width), stream, img, params,
                staged_ws, height, width, overlay, overlay_layers);
     CCD_LAUNCH(ccd::augment_views_kernel, dim3((height * width + 255) / 256, batch), dim3(256), 0, stream, img, staged_ws, theta,
-               out, batch, height, width, mean3[0], mean3[1], mean3[2], 1.0f / std3[0], 1.0f / std3[1], 1.0f / std3[2]);
+               out, batch, height, width, mean3[0], mean3[1], mean3[2], 1.0f / std3[0], 1.0f / std3[1], 1.0f / std3[2], params, warp_maps,
+               warp_count);
     return ccd_rt_last_error();
 }
 int ccd_warp_idmap(const uint8_t* src, const float* theta, int theta_stride, uint8_t* dst, int images, void* stream) {

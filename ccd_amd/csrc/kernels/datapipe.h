@@ -813,10 +813,14 @@ __global__ __launch_bounds__(256) void augment_spatial_kernel(const unsigned cha
 // img uint8 [B, H, W, 3]; staged uint8 [B, 2, H, W, 3] (augment_spatial_kernel: the augmented images of views 1 / 2);
 // theta fp32 [B, 3, 3]; out fp32 [B, 3 views, 3, H, W]: view 0 plain, view 1 augmented, view 2 augmented and warped (bilinear, zero fill,
 // src = theta (x, y, 1) in normalised coordinates - the inverse of how the dataset derives theta, datasetsupervised_kmeans.py:65-71)
+// warp_maps (optional) fp32 [maps, 2, H, W]: per output pixel the SOURCE position (x, y) in pixels - the piecewise-affine member of the
+// finetuning geometry (imgaug PiecewiseAffine: a jittered 4 x 4 mesh, one affine map per Delaunay triangle, drawn on the host:
+// ccd_amd/dataset/weather.py).  A sample whose view-2 parameter row has params[AUG_P_W + 3] = m > 0 samples map m - 1 instead of theta.
 __global__ __launch_bounds__(256) void augment_views_kernel(const unsigned char* __restrict__ img, const unsigned char* __restrict__ staged,
                                                             const float* __restrict__ theta, float* __restrict__ out,
                                                             int B, int H, int W, float m0, float m1, float m2, float is0,
-                                                            float is1, float is2) {
+                                                            float is1, float is2, const float* __restrict__ params,
+                                                            const float* __restrict__ warp_maps, int warp_count) {
     const int b = blockIdx.y;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= H * W) return;
@@ -834,8 +838,16 @@ __global__ __launch_bounds__(256) void augment_views_kernel(const unsigned char*
     const float* th = theta + (long)b * 9;
     const unsigned char* s2 = staged + (long)(2 * b + 1) * H * W * 3;
     const float xn = 2.0f * (float)x / (float)(W - 1) - 1.0f, yn = 2.0f * (float)y / (float)(H - 1) - 1.0f;
-    const float xs = ((th[0] * xn + th[1] * yn + th[2]) + 1.0f) * 0.5f * (float)(W - 1);
-    const float ys = ((th[3] * xn + th[4] * yn + th[5]) + 1.0f) * 0.5f * (float)(H - 1);
+    float xs = ((th[0] * xn + th[1] * yn + th[2]) + 1.0f) * 0.5f * (float)(W - 1);
+    float ys = ((th[3] * xn + th[4] * yn + th[5]) + 1.0f) * 0.5f * (float)(H - 1);
+    if (warp_maps) {
+        const int m = (int)params[((long)b * 2 + 1) * AUG_NP + AUG_P_W + 3];
+        if (m > 0 && m <= warp_count) {
+            const float* wm = warp_maps + (long)(m - 1) * 2 * plane;
+            xs = wm[pix];
+            ys = wm[plane + pix];
+        }
+    }
     const float xf = floorf(xs), yf = floorf(ys);
     const int x0 = (int)xf, y0 = (int)yf;
     const float ax = xs - xf, ay = ys - yf;

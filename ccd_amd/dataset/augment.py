@@ -7,9 +7,9 @@ to view 2 with probability 0.7 (datasetsupervised_kmeans.py:40-45,60), and `thet
 factors cancel when the augmentation runs at the network resolution, which it does here).  A sample whose 0.7 draw fails
 gets the PLAIN image as view 2 (:72-74): its colour parameters are the identity.
 
-Colour = the reference's imgaug chain: its member LISTS and probabilities, all 50 members of the pretraining chain reproduced (the finetuning geometry's PiecewiseAffine is not - listed
-below - are drawn and leave the image unchanged, so the augmentation distribution is WEAKER than the reference's; README parity
-claims say so) (augmentation_pipelines.py:120-205,
+Colour = the reference's imgaug chain: its member LISTS and probabilities, every member of the pretraining chain (50) and of the
+finetuning list reproduced (the members the image lacks the library for are restated from the published algorithms and say so:
+INTEGRATION.md) (augmentation_pipelines.py:120-205,
 severity 5 - what the shipped pretraining configs select; dataset_pretrain.py:79-158 for finetuning): `Sometimes(0.2, Identity,
 Sequential[arithmetic: OneOf 21, color: Sometimes(0.7, OneOf 9), Blur: Sometimes(0.7, ...), contrast: Sometimes(0.7, OneOf 8),
 weather: Sometimes(0.7, OneOf 4)])`.  A draw picks the member by its POSITION in the reference's list and writes what the kernel
@@ -23,7 +23,8 @@ blended on the device).
 HistogramEqualization / CLAHE (the L channel of 8-bit Lab, float formulas) and AllChannelsCLAHE (round 5: OpenCV's tile algorithm).
 KMeansColorQuantization (round 5: Lloyd's iteration on the Lab triples, cv2.kmeans' rules).
 Snowflakes and Rain (round 5: salt noise on a shrunk canvas, gated, up-sampled, blurred, motion-smeared - on the host like the clouds).
-NOT reproduced - the draw that selects it leaves the image unchanged: PiecewiseAffine (finetuning geometry); severity 2's ElasticTransformation / PerspectiveTransform (no shipped config).
+PiecewiseAffine (finetuning geometry, round 5): a dense source-position map per sample drawn on the host (weather.piecewise_affine_map).
+NOT reproduced - the draw that selects it leaves the image unchanged: severity 2's ElasticTransformation / PerspectiveTransform (no shipped config).
 """
 from __future__ import annotations
 
@@ -391,10 +392,14 @@ def _finetune_colour_params(rs: np.random.RandomState, h: int = 32, w: int = 128
     return p
 
 
-def sample_finetune_params(rs: np.random.RandomState, batch: int, h: int, w: int, overlays=None, resolve: bool = True):
+P_WARP = P_W + 3       # view-2 row: 0 = warp by theta; m > 0 = warp map m - 1 (weather.WarpMaps; a parked task is negative)
+
+
+def sample_finetune_params(rs: np.random.RandomState, batch: int, h: int, w: int, overlays=None, resolve: bool = True, warps=None):
     """(params fp32 [batch, 2, 96] - only row 1 is used, theta fp32 [batch, 3, 3]) for the finetuning augmentation
     (dataset_pretrain.py:79-158): colour as above, geometry = Sometimes(0.6, OneOf[Affine (the pretraining ranges), PiecewiseAffine
-    (not reproduced), Rotate(-45, 45)])."""
+    (scale 0.01 - 0.1: a dense source-position map drawn on the host, `warps` = weather.WarpMaps collects them; without a collector the
+    draw leaves the image unwarped), Rotate(-45, 45)])."""
     params = np.tile(IDENTITY_PARAMS, (batch, 2, 1)).astype(np.float32)
     theta = np.tile(np.eye(3, dtype=np.float32), (batch, 1, 1))
     for b in range(batch):
@@ -403,6 +408,10 @@ def sample_finetune_params(rs: np.random.RandomState, batch: int, h: int, w: int
             g = rs.randint(0, 3)
             if g == 0:
                 theta[b] = theta_from_pixel_matrix(affine_pixel_matrix(rs, h, w), h, w)
+            elif g == 1:
+                seed = rs.randint(0, 1 << 31)
+                if warps is not None:
+                    params[b, 1, P_WARP] = warps.park("PiecewiseAffine", seed)
             elif g == 2:
                 rot = math.radians(rs.uniform(-45.0, 45.0))
                 cx, cy = (w - 1) / 2.0, (h - 1) / 2.0
@@ -410,8 +419,9 @@ def sample_finetune_params(rs: np.random.RandomState, batch: int, h: int, w: int
                 back = np.array([[1, 0, cx], [0, 1, cy], [0, 0, 1]], dtype=np.float64)
                 rotm = np.array([[math.cos(rot), -math.sin(rot), 0], [math.sin(rot), math.cos(rot), 0], [0, 0, 1]])
                 theta[b] = theta_from_pixel_matrix(back @ rotm @ to_o, h, w)
-    if overlays is not None:
-        overlays.start()
-        if resolve:
-            overlays.resolve(params, P_W)
+    for coll, col in ((overlays, P_W), (warps, P_WARP)):
+        if coll is not None:
+            coll.start()
+            if resolve:
+                coll.resolve(params, col)
     return params, theta

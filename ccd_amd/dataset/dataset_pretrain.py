@@ -115,26 +115,27 @@ class DeviceImageAugmenter:
 
     def _draw(self, B):
         from .augment import sample_finetune_params
-        from .weather import LayerFarm, Overlays
+        from .weather import LayerFarm, Overlays, WarpMaps
         if self._farm is None:
             self._farm = LayerFarm(self.workers)
-        overlays = Overlays(self.h, self.w, self._farm)
-        params, theta = sample_finetune_params(self.rs, B, self.h, self.w, overlays=overlays, resolve=False)
-        return B, params, theta, overlays
+        overlays, warps = Overlays(self.h, self.w, self._farm), WarpMaps(self.h, self.w, self._farm)
+        params, theta = sample_finetune_params(self.rs, B, self.h, self.w, overlays=overlays, resolve=False, warps=warps)
+        return B, params, theta, overlays, warps
 
     def __call__(self, images_u8):
         from .. import ops
-        from .augment import P_W
+        from .augment import P_W, P_WARP
         dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
         B = images_u8.shape[0]
         assert tuple(images_u8.shape[1:]) == (self.h, self.w, 3) and images_u8.dtype == torch.uint8
         if self._ahead is None or self._ahead[0] != B:               # drawn one call ahead: the weather layers are computed by the
             self._ahead = self._draw(B)                              # worker pool while the GPU runs the iteration in between
-        _, params, theta, overlays = self._ahead
-        planes = overlays.resolve(params, P_W)
+        _, params, theta, overlays, warps = self._ahead
+        planes, maps = overlays.resolve(params, P_W), warps.resolve(params, P_WARP)
         out = ops.augment_views(images_u8.to(dev, non_blocking=True).contiguous(), torch.from_numpy(params).to(dev),
                                 torch.from_numpy(theta).to(dev), MEAN, STD,
-                                overlay=None if planes is None else torch.from_numpy(planes).to(dev))
+                                overlay=None if planes is None else torch.from_numpy(planes).to(dev),
+                                warp_maps=None if maps is None else torch.from_numpy(maps).to(dev))
         view = out[:, 2].contiguous()
         self._ahead = self._draw(B)                                  # (after the launches: the host draws while the device works)
         return view

@@ -190,14 +190,46 @@ def rain_layers(rs, h, w):
     return out
 
 
-MAKERS = {"Fog": fog_layers, "Clouds": clouds_layers, "Snowflakes": snowflake_layers, "Rain": rain_layers}
+def piecewise_affine_map(rs, h, w, nb_rows=4, nb_cols=4, scale=(0.01, 0.1)):
+    """iaa.PiecewiseAffine(scale=(0.01, 0.1)) (the finetuning geometry's second member, dataset_pretrain.py:156) as a dense map:
+    -> [fp32 [2, h, w]] = the (x, y) SOURCE position of every output pixel.  imgaug: a regular nb_rows x nb_cols mesh over
+    [0, h] x [0, w], every point moved by Normal(0, s) * (h, w) with ONE s ~ U(scale) per image and clipped into the image;
+    skimage.transform.PiecewiseAffineTransform.estimate(mesh, moved) = scipy's Delaunay triangulation of the REGULAR mesh + the affine
+    map of each triangle onto its moved copy, used by skimage.transform.warp as the inverse map (output pixel -> source position;
+    -1 outside the mesh, which covers every pixel here).  The triangulation is scipy's own (what skimage calls): the diagonal
+    qhull picks in each square cell of the degenerate mesh is the library's, not restated."""
+    from scipy.spatial import Delaunay
+    s = rs.uniform(*scale)
+    jitter = rs.normal(0.0, s, size=(nb_rows * nb_cols, 2))
+    xx, yy = np.meshgrid(np.linspace(0, w, nb_cols), np.linspace(0, h, nb_rows))
+    src = np.stack([xx.ravel(), yy.ravel()], 1)                                     # (x, y)
+    dst = src + jitter[:, ::-1] * np.array([w, h], np.float64)                      # (jitter columns are (y, x) in the library)
+    dst[:, 0], dst[:, 1] = np.clip(dst[:, 0], 0, w - 1), np.clip(dst[:, 1], 0, h - 1)
+    tri = Delaunay(src)
+    py, px = np.mgrid[0:h, 0:w]
+    pts = np.stack([px.ravel(), py.ravel()], 1).astype(np.float64)
+    simplex = tri.find_simplex(pts)
+    out = np.full((h * w, 2), -1.0)
+    ones = np.ones((3, 1))
+    for k, verts in enumerate(tri.simplices):
+        sel = simplex == k
+        if sel.any():
+            a = np.linalg.solve(np.hstack([src[verts], ones]), dst[verts])          # [x y 1] a = [x' y']
+            out[sel] = np.hstack([pts[sel], np.ones((int(sel.sum()), 1))]) @ a
+    return [np.ascontiguousarray(out.T.reshape(2, h, w), dtype=np.float32)]
+
+
+# member -> (generator of a list of [2, h, w] planes, the dtype they travel in)
+MAKERS = {"Fog": (fog_layers, np.float16), "Clouds": (clouds_layers, np.float16), "Snowflakes": (snowflake_layers, np.float16),
+          "Rain": (rain_layers, np.float16), "PiecewiseAffine": (piecewise_affine_map, np.float32)}
 
 
 def draw_layers(task):
-    """(member name, seed, h, w) -> the member's layers as fp16 [n, 2, h, w]: a pure function of its arguments (worker processes call it)."""
+    """(member name, seed, h, w) -> the member's planes [n, 2, h, w] (fp16 weather layers, fp32 warp maps): a pure function of its
+    arguments (worker processes call it)."""
     name, seed, h, w = task
-    layers = MAKERS[name](np.random.RandomState(int(seed)), int(h), int(w))
-    return np.stack(layers).astype(np.float16)
+    make, dtype = MAKERS[name]
+    return np.ascontiguousarray(np.stack(make(np.random.RandomState(int(seed)), int(h), int(w))), dtype=dtype)
 
 
 class LayerFarm:
@@ -281,4 +313,28 @@ class Overlays:
         return self._planes
 
     def planes(self):
+        return self._planes
+
+
+class WarpMaps(Overlays):
+    """The piecewise-affine warp maps of one batch (fp32 [maps, 2, H, W], ops.augment_views' `warp_maps`): the same hand-over as the
+    weather layers - a row parks -(task id + 1) in ONE column, `resolve` turns it into map index + 1 (0 = the row warps by theta)."""
+
+    def park(self, name: str, seed: int) -> float:
+        return -float(self.add_task(name, seed) + 1)
+
+    def resolve(self, params: np.ndarray, col: int):
+        self.start()
+        try:
+            results = self.pending.get(timeout=120.0)
+        except Exception as exc:
+            import warnings
+            warnings.warn(f"warp-map workers did not answer ({type(exc).__name__}); drawing {len(self.tasks)} maps in the training process")
+            results = [draw_layers(t) for t in self.tasks]
+        flat = params.reshape(-1, params.shape[-1])
+        maps = []
+        for r in np.nonzero(flat[:, col] < 0)[0]:
+            maps.append(results[int(-flat[r, col]) - 1])
+            flat[r, col] = len(maps)
+        self._planes = np.concatenate(maps) if maps else None
         return self._planes

@@ -498,12 +498,13 @@ def kmeans2_mask(grays, device=None):
     return [host[offs[i]:offs[i + 1]].reshape(arrs[i].shape) for i in range(len(arrs))]
 
 
-def augment_views(img, params, theta, mean, std, overlay=None):
+def augment_views(img, params, theta, mean, std, overlay=None, warp_maps=None):
     """img uint8 [B,H,W,3] (resized samples), params fp32 [B,2,96], theta fp32 [B,3,3] -> image_tensors fp32 [B,3,3,H,W]:
     (plain, colour-augmented, colour-augmented + warped by theta), normalised - the dataset's batch contract
     (datasetsupervised_kmeans.py:48-87).  The neighbourhood members (JPEG, blurs, convolutions) run in a pre-pass that stages
     one uint8 image per (sample, view).  overlay: fp16 [layers, 2, H, W] (alpha, intensity) cloud layers that rows with a `weather`
-    member refer to (ccd_amd/dataset/weather.py), blended at the end of the pre-pass."""
+    member refer to (ccd_amd/dataset/weather.py), blended at the end of the pre-pass.  warp_maps: fp32 [maps, 2, H, W] source
+    positions of the piecewise-affine warps that view-2 rows with params[84] = m > 0 take instead of theta (map m - 1)."""
     import ctypes as C
     assert img.dtype == U8 and img.is_contiguous() and img.dim() == 4 and img.shape[3] == 3
     _chk(params, F32, "params"); _chk(theta, F32, "theta")
@@ -516,8 +517,12 @@ def augment_views(img, params, theta, mean, std, overlay=None):
     if overlay is not None:
         assert overlay.dtype == torch.float16 and overlay.is_contiguous() and tuple(overlay.shape[1:]) == (2, H, W)
         layers = overlay.shape[0]
+    maps = 0
+    if warp_maps is not None:
+        assert warp_maps.dtype == F32 and warp_maps.is_contiguous() and tuple(warp_maps.shape[1:]) == (2, H, W)
+        maps = warp_maps.shape[0]
     _call("ccd_augment_views", _lib.ptr(img), _lib.ptr(params), _lib.ptr(theta), _lib.ptr(out), _lib.ptr(staged), B, H, W,
-          C.cast(m3, C.c_void_p), C.cast(s3, C.c_void_p), _lib.ptr(overlay), int(layers))
+          C.cast(m3, C.c_void_p), C.cast(s3, C.c_void_p), _lib.ptr(overlay), int(layers), _lib.ptr(warp_maps), int(maps))
     return out
 
 

@@ -237,10 +237,13 @@ int ccd_kmeans2_mask(const uint8_t* gray, const long* offsets, const int* hw, ui
  * overlay (optional): fp16 [overlay_layers, 2, H, W] = (alpha, intensity) planes of imgaug's cloud layers (`weather` group: Fog,
  * Clouds - augmentation_pipelines.py:192-193); a parameter row with params[81] = n > 0 blends its layers params[82] .. + n - 1 after
  * the contrast group: out = trunc(clip((1 - alpha) * v + alpha * intensity, 0, 255)).  The planes are drawn on the host
- * (ccd_amd/dataset/weather.py: frequency noise by FFT, a few hundred microseconds per layer). */
+ * (ccd_amd/dataset/weather.py: frequency noise by FFT, a few hundred microseconds per layer).
+ * warp_maps (optional): fp32 [warp_count, 2, H, W] = the SOURCE position (x, y), in pixels, of every output pixel of a
+ * piecewise-affine warp (imgaug PiecewiseAffine, the finetuning geometry's second member, dataset_pretrain.py:156; drawn on the
+ * host); a sample whose view-2 row has params[84] = m > 0 samples map m - 1 (bilinear, zero fill) instead of theta. */
 int ccd_augment_views(const uint8_t* img, const float* params, const float* theta, float* out, uint8_t* staged_ws, int batch,
                       int height, int width, const float* mean3, const float* std3, const uint16_t* overlay, int overlay_layers,
-                      void* stream);
+                      const float* warp_maps, int warp_count, void* stream);
 /* affine_grid(theta[:, :2]) + grid_sample(bilinear) > 0.1, dino_vision.py:72-77 / train.py:234-236; theta row stride in floats */
 int ccd_warp_idmap(const uint8_t* src, const float* theta, int theta_stride, uint8_t* dst, int images, void* stream);
 /* ABIDINOModel.attention, dino_vision.py:38-49, in sparse form: per token up to 4 (plane, normalised weight) pairs -

@@ -475,8 +475,10 @@ def staged_source(p, src_u8, overlay=None):
     return cur
 
 
-def augment_views(img, params, theta, mean, std, overlay=None):
-    """img uint8 [B,H,W,3], params [B,2,96], theta [B,3,3] -> fp32 [B,3,3,H,W]."""
+def augment_views(img, params, theta, mean, std, overlay=None, warp_maps=None):
+    """img uint8 [B,H,W,3], params [B,2,96], theta [B,3,3] -> fp32 [B,3,3,H,W].  warp_maps fp32 [maps,2,H,W]: a sample whose view-2
+    row has params[84] = m > 0 is sampled at map m - 1's (x, y) source positions instead of theta's (imgaug PiecewiseAffine through
+    skimage.transform.warp(order=1, mode="constant", cval=0): bilinear weights, zero beyond the image)."""
     f = np.float32
     img = np.asarray(img)
     B, H, W, _ = img.shape
@@ -495,6 +497,9 @@ def augment_views(img, params, theta, mean, std, overlay=None):
         yn = f(2) * ys.astype(f) / f(H - 1) - f(1)
         sx = ((th[0, 0] * xn + th[0, 1] * yn + th[0, 2]) + f(1)) * f(0.5) * f(W - 1)
         sy = ((th[1, 0] * xn + th[1, 1] * yn + th[1, 2]) + f(1)) * f(0.5) * f(H - 1)
+        m = int(params[b, 1, 84]) if warp_maps is not None else 0
+        if 0 < m <= len(warp_maps):
+            sx, sy = warp_maps[m - 1, 0].astype(f), warp_maps[m - 1, 1].astype(f)
         x0, y0 = np.floor(sx), np.floor(sy)
         ax, ay = (sx - x0).astype(f), (sy - y0).astype(f)
         x0, y0 = x0.astype(np.int64), y0.astype(np.int64)

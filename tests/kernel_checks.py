@@ -448,11 +448,21 @@ def check_augment_views(dev, H=32, W=128, seed=52, max_samples=None):
     theta = A.sample_theta(rs, B, H, W, p_warp=1.0)
     theta[2] = np.eye(3)
     mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    # piecewise-affine warps (the finetuning geometry): samples 3 and 5 take a host-drawn source-position map instead of theta
+    wm = Wt.WarpMaps(H, W)
+    warp_rows = [b for b in (3, 5) if b < B]
+    for b in warp_rows:
+        params[b, 1, A.P_WARP] = wm.park("PiecewiseAffine", int(rs.randint(0, 1 << 31)))
+    maps = wm.resolve(params, A.P_WARP)
+    assert maps is not None and maps.dtype == np.float32 and maps.shape == (len(warp_rows), 2, H, W)
+    assert [int(params[b, 1, A.P_WARP]) for b in warp_rows] == list(range(1, len(warp_rows) + 1))
     got = ops.augment_views(torch.from_numpy(img).to(dev), torch.from_numpy(params).to(dev), torch.from_numpy(theta).to(dev),
-                            mean, std, overlay=torch.from_numpy(planes).to(dev)).cpu().numpy()
+                            mean, std, overlay=torch.from_numpy(planes).to(dev), warp_maps=torch.from_numpy(maps).to(dev)).cpu().numpy()
     assert got.shape == (B, 3, 3, H, W) and np.isfinite(got).all()
     plain = ops.augment_views(torch.from_numpy(img).to(dev), torch.from_numpy(params).to(dev), torch.from_numpy(theta).to(dev),
-                              mean, std).cpu().numpy()           # without the planes the rows' weather entries are ignored
+                              mean, std).cpu().numpy()           # without the planes the rows' weather entries are ignored (and the maps: theta)
+    for b in warp_rows:
+        assert np.abs(got[b, 2] - plain[b, 2]).max() > 0.05, (b, "the warp map changed nothing")
     for r in wrows:
         assert np.abs(got[r // 2, 1 + r % 2] - plain[r // 2, 1 + r % 2]).max() > 0.05, (r, "the cloud layers changed nothing")
     # view 0 is the plain normalised image, exactly
@@ -490,7 +500,7 @@ def check_augment_views(dev, H=32, W=128, seed=52, max_samples=None):
     want2 = (warped_ref * np.float32(1 / 255.0) - np.float32(mean)[:, None, None]) / np.float32(std)[:, None, None]
     np.testing.assert_allclose(got[0, 2], want2, rtol=0, atol=2e-4)
     # every sample: view 2 = the warp of ITS staged image (the restated chain of row [b, 1])
-    want = D.augment_views(img, params, theta, mean, std, overlay=planes)
+    want = D.augment_views(img, params, theta, mean, std, overlay=planes, warp_maps=maps)
     err = np.abs(got[:, 2] - want[:, 2])
     # (a JPEG member FOLLOWED by a histogram equalisation is a tie amplifier: one DCT coefficient that quantises the other way moves a
     # block by a few levels and the equalisation table stretches that by its slope - whether it happens depends on the image; such rows

@@ -454,7 +454,7 @@ def test_snow_rain_layers_and_the_layer_farm():
     for name, lo, hi in (("Snowflakes", 1, 3), ("Rain", 1, 3)):
         counts = set()
         for _ in range(12):
-            layers = Wt.MAKERS[name](rs, 32, 128)
+            layers = Wt.MAKERS[name][0](rs, 32, 128)
             counts.add(len(layers))
             assert lo <= len(layers) <= hi
             for m in layers:
@@ -510,3 +510,51 @@ def test_lab_and_clahe_restatements():
     assert (np.abs(share - 1 / 8) < 0.03).all(), share                    # OneOf 8: every member one eighth of the contrast draws
     cl = p[np.isin(ops_d, (A.D_CLAHE_LAB, A.D_CLAHE_ALL))]
     assert (cl[:, A.P_D + 1] >= 0.1).all() and (cl[:, A.P_D + 1] <= 8.0).all() and set(np.unique(cl[:, A.P_D + 2]).astype(int)) <= set(range(3, 13))
+
+
+def test_piecewise_affine_maps():
+    """weather.piecewise_affine_map (imgaug PiecewiseAffine through skimage's PiecewiseAffineTransform, restated): the per-triangle affine
+    maps against an independent formulation (barycentric interpolation of the moved vertices in scipy's triangulation), the mesh
+    points themselves, zero jitter = the identity, continuity, the clip into the image, and the member's share of the finetuning draw."""
+    from scipy.spatial import Delaunay
+    from ccd_amd.dataset import augment as A, weather as Wt
+    h, w = 32, 128
+    got = Wt.piecewise_affine_map(np.random.RandomState(7), h, w)[0]
+    assert got.shape == (2, h, w) and got.dtype == np.float32
+    # the same draws, interpolated barycentrically
+    rs = np.random.RandomState(7)
+    s = rs.uniform(0.01, 0.1)
+    jitter = rs.normal(0.0, s, size=(16, 2))
+    xx, yy = np.meshgrid(np.linspace(0, w, 4), np.linspace(0, h, 4))
+    src = np.stack([xx.ravel(), yy.ravel()], 1)
+    dst = src + jitter[:, ::-1] * np.array([w, h], np.float64)
+    dst[:, 0], dst[:, 1] = np.clip(dst[:, 0], 0, w - 1), np.clip(dst[:, 1], 0, h - 1)
+    tri = Delaunay(src)
+    py, px = np.mgrid[0:h, 0:w]
+    pts = np.stack([px.ravel(), py.ravel()], 1).astype(np.float64)
+    simp = tri.find_simplex(pts)
+    assert (simp >= 0).all()
+    tr = tri.transform[simp]                                              # barycentric coordinates of every pixel in its triangle
+    lam = np.einsum("nij,nj->ni", tr[:, :2], pts - tr[:, 2])
+    lam = np.hstack([lam, 1.0 - lam.sum(1, keepdims=True)])
+    want = np.einsum("ni,nid->nd", lam, dst[tri.simplices[simp]]).T.reshape(2, h, w)
+    np.testing.assert_allclose(got, want, atol=2e-4)
+    assert got[0].min() >= -1e-4 and got[0].max() <= w - 1 + 1e-4 and got[1].min() >= -1e-4 and got[1].max() <= h - 1 + 1e-4
+    assert abs(got[0, 0, 0] - dst[0, 0]) < 1e-4 and abs(got[1, 0, 0] - dst[0, 1]) < 1e-4      # pixel (0, 0) IS a mesh point
+    assert np.abs(np.diff(got[0], axis=1)).max() < 6.0 and np.abs(np.diff(got[1], axis=0)).max() < 6.0   # continuous across the triangles
+    ident = Wt.piecewise_affine_map(np.random.RandomState(1), h, w, scale=(0.0, 0.0))[0]
+    # (zero jitter: the identity, except in the last mesh column / row, whose points at x = w / y = h are clipped to w - 1 / h - 1 -
+    # the library skips the warp altogether when every jitter is zero)
+    np.testing.assert_allclose(ident[0][:, :2 * w // 3], px[:, :2 * w // 3], atol=1e-4)
+    np.testing.assert_allclose(ident[1][:2 * h // 3], py[:2 * h // 3], atol=1e-4)
+    assert np.abs(ident[0] - px).max() <= 1.0 and np.abs(ident[1] - py).max() <= 1.0
+    # the sampler: Sometimes(0.6) x OneOf 3 = 20 % of the samples carry a map; theta stays the identity for them
+    wm = Wt.WarpMaps(h, w)
+    p, th = A.sample_finetune_params(np.random.RandomState(2), 400, h, w, warps=wm)
+    rows = p[:, 1, A.P_WARP]
+    assert 0.14 < (rows > 0).mean() < 0.26 and (rows >= 0).all()
+    maps = wm.planes()
+    assert maps.shape == (int((rows > 0).sum()), 2, h, w) and sorted(rows[rows > 0].astype(int)) == list(range(1, len(maps) + 1))
+    assert (th[rows > 0] == np.eye(3, dtype=np.float32)).all()
+    p0, _ = A.sample_finetune_params(np.random.RandomState(2), 400, h, w)       # without a collector: unwarped, the same other draws
+    assert (p0[:, 1, A.P_WARP] == 0).all() and (np.delete(p0, A.P_WARP, axis=2) == np.delete(p, A.P_WARP, axis=2)).all()
