@@ -32,6 +32,15 @@ ENVV=(X=1)
 run r05_bench_b256_again2
 ENVV=(CCD_FUSE_PROJ=0)
 run r05_bench_b256_unfused_proj2
+ENVV=(CCD_FUSE_CLS_TAIL=0)
+run r05_bench_b256_unfused_cls_tail
+ENVV=(X=1)
+run r05_bench_b256_again3
+ENVV=(CCD_FUSE_CLS_TAIL=0)
+run r05_bench_b256_unfused_cls_tail2
+python tools/cls_tail_lab.py 2> /dev/null | tail -1 > gpurun_out/r05_cls_tail_lab.jsonl
+python tools/viewmaker_bench.py 2> /dev/null > gpurun_out/r05_viewmaker.jsonl
+cat gpurun_out/r05_cls_tail_lab.jsonl gpurun_out/r05_viewmaker.jsonl
 cat gpurun_out/r05_gputests.log; tail -3 gpurun_out/r05_smoke.log; tail -5 gpurun_out/r05_pmc_traffic.log | cut -c1-400
 head -30 gpurun_out/r05_bench_b256_steady_state.md
 for f in gpurun_out/r05_bench_b256.json gpurun_out/r05_bench_forcedist.json; do python - "$f" <<'PY'
