@@ -238,7 +238,10 @@ class LayerFarm:
 
     def __init__(self, workers=None):
         import os
-        self.workers = int(workers) if workers is not None else max(1, min(32, (os.cpu_count() or 2) // 2))
+        # (default: half the cores, at most 32 - shared between the ranks of the node: 8 ranks x 32 workers beside 8 x the loader's own
+        # workers would oversubscribe a 256-core host)
+        ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+        self.workers = int(workers) if workers is not None else max(1, min(32, (os.cpu_count() or 2) // (2 * ranks)))
         self.pool = None
 
     def submit(self, tasks):
