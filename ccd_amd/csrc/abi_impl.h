@@ -266,7 +266,7 @@ static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, float* ws, long ws_
 extern "C" {
 
 int ccd_abi_version(void) { return 9; }   // 9: ccd_cls_tail_fwd / _bwd_reduce / _bwd_apply (BatchNorm + ReLU + classifier conv of the segmentation head fused); 8: ccd_proj_mlp_fused (proj + residual + LayerNorm-2 in front of the fused MLP), ccd_matvec_bf16; 7: ccd_gemm_tn_pair_ws (split-K workspace instead of fp32 atomics); 6: device-side momentum / DropPath seed (HIP graph of the training step); 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
-const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi8"; }
+const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi9"; }
 int ccd_policy_set(const char* key, int value) {
     CCD_CHECK(key, CCD_EINVAL);
     for (const CcdPolicyKey& k : ccd_policy_keys)
@@ -1162,15 +1162,17 @@ int ccd_cls_tail_fwd(const ccd_bf16* y, long ldy, const float* mean_rstd, const 
     CCD_CHECK(y && mean_rstd && gamma && beta && w && bias && logits && CCD_ALIGNED16(y), CCD_EINVAL);
     if (images == 0) return CCD_OK;
     CCD_CHECK(ccd_cls_tail_shape(images, H, W, C, ldy), CCD_ESHAPE);
-    // a band re-derives the z rows above and below it: 16-row bands (+ 12 % of y read twice) once they fill the chip twice over
-    const int band_rows = (long)images * 2 >= 2L * ccd_rt_num_cus() ? 16 : 8;
+    // a band re-derives the z rows above and below it (8 rows: + 25 % of y read twice, 16: + 12 %): whole images once they fill the chip
+    // twice over
+    const long cus = ccd_grid_cus();
+    const int band_rows = images >= 2 * cus ? 32 : images * 2 >= 2 * cus ? 16 : 8;
     CCD_LAUNCH(ccd::cls_tail_fwd_kernel, dim3((unsigned)(images * (ccd::CT_H / band_rows))), dim3(256), 0, stream, y, ldy,
                mean_rstd, gamma, beta, w, bias, logits, band_rows);
     return ccd_rt_last_error();
 }
 
 static unsigned ccd_cls_tail_grid(int nbands, int per_cu) {
-    const long cap = (long)per_cu * ccd_rt_num_cus();
+    const long cap = (long)per_cu * ccd_grid_cus();          // (persistent grids leave the reserved CUs to an attached gradient reducer)
     return (unsigned)(nbands < cap ? nbands : cap);
 }
 

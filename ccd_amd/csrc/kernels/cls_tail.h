@@ -36,7 +36,7 @@ __device__ __forceinline__ float ct_pre(float v, float mu, float rs, float ga, f
 
 // ---------------------------------------------------------------------------------------------------------- forward
 // grid = images * (32 / band_rows); 256 threads.  A wave owns two of a row's eight 16-pixel tiles and all 128 channels.
-__global__ __launch_bounds__(256) void cls_tail_fwd_kernel(const bf16_t* __restrict__ y, long ldy,
+__global__ __launch_bounds__(256, 2) void cls_tail_fwd_kernel(const bf16_t* __restrict__ y, long ldy,
                                                            const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ logits,
@@ -64,11 +64,14 @@ __global__ __launch_bounds__(256) void cls_tail_fwd_kernel(const bf16_t* __restr
         const int c = 32 * (i >> 3) + 8 * g + (i & 7);
         mu[i] = mean_rstd[c]; rs[i] = mean_rstd[CT_C + c]; ga[i] = gamma[c]; be[i] = beta[c];
     }
-    const bf16_t* yimg = y + (long)n * CT_H * CT_W * ldy + 8 * g;
+    // buffer addressing: the image's descriptor + a 32-bit lane offset (64-bit per-lane addresses of the tiles in flight cost a wave of occupancy)
+    const unsigned ld_b = (unsigned)ldy * 2u;
+    const buf_rsrc yr = make_rsrc(y + (long)n * CT_H * CT_W * ldy, (unsigned)(CT_H * CT_W) * ld_b);
+    const unsigned yo = (unsigned)px * ld_b + 16u * (unsigned)g;
     auto load_tile = [&](int row, int tile, u32x4 (&v)[4]) __attribute__((always_inline)) {
-        const bf16_t* p = yimg + ((long)row * CT_W + tile * 16 + px) * ldy;
+        const unsigned base = (unsigned)(row * CT_W + tile * 16) * ld_b;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) v[ks] = *reinterpret_cast<const u32x4*>(p + 32 * ks);
+        for (int ks = 0; ks < 4; ++ks) v[ks] = buf_load16(yr, yo, base + 64u * (unsigned)ks);
     };
     auto tile_planes = [&](const u32x4 (&v)[4], int slot, int tile) __attribute__((always_inline)) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
