@@ -117,7 +117,7 @@ class ParamArena:
             src = self.flat.data_ptr() + 4 * s.offset
             dst_t = self.mirror_t.data_ptr() + 2 * s.t_offset
             blob += struct.pack("PPPiiii", src, 0, dst_t, rows, cols, tiles, 0)
-            tiles += ((rows + 31) // 32) * ((cols + 31) // 32)
+            tiles += ((rows + 63) // 64) * ((cols + 63) // 64)            # (64 x 64 tiles: include/ccd_hip.h, ccd_mirror_desc)
             n += 1
         if n:
             host = torch.frombuffer(bytearray(blob), dtype=torch.uint8)

@@ -898,9 +898,9 @@ int ccd_l2norm_bwd(const ccd_bf16* x, const float* inv, const ccd_bf16* dy, ccd_
 int ccd_weightnorm_fwd(const float* v, const float* g, ccd_bf16* w, ccd_bf16* w_t, float* inv, int K, int D,
                        void* stream) {
     CCD_CHECK(v && g && w && inv && K > 0 && D > 0, CCD_EINVAL);
-    const size_t smem = (size_t)32 * (D + 1) * 4;
-    CCD_CHECK(smem <= 64 * 1024, CCD_ESHAPE);
-    CCD_LAUNCH(ccd::weightnorm_fwd_kernel, dim3((K + 31) / 32), dim3(256), smem, stream, v, g, w, w_t, inv, K, D);
+    const size_t smem = (size_t)ccd::WN_ROWS * (D + 1) * 4;
+    CCD_CHECK(smem <= 128 * 1024 && D % 4 == 0 && D <= 256 * ccd::WN_MAX_V4 && K % 2 == 0, CCD_ESHAPE);
+    CCD_LAUNCH(ccd::weightnorm_fwd_kernel, dim3((K + ccd::WN_ROWS - 1) / ccd::WN_ROWS), dim3(256), smem, stream, v, g, w, w_t, inv, K, D);
     return ccd_rt_last_error();
 }
 int ccd_weightnorm_bwd(const float* v, const float* g, const float* inv, const float* dw, float* dv, float* dg, int K,
@@ -959,7 +959,8 @@ int ccd_seg_loss(const float* logits, const float* mask_a, const uint8_t* idmap_
                  float* loss_out, float* d_logits, void* stream) {
     CCD_CHECK(logits && mask_a && idmap_b && loss_out && half > 0, CCD_EINVAL);
     const long npix = 2L * half * ccd::CM_PIX;
-    CCD_LAUNCH(ccd::seg_loss_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, logits, mask_a, idmap_b,
+    const long per_block = 256L * ccd::SEG_LOSS_PER_THREAD;
+    CCD_LAUNCH(ccd::seg_loss_kernel, dim3((unsigned)((npix + per_block - 1) / per_block)), dim3(256), 0, stream, logits, mask_a, idmap_b,
                half, grad_scale, loss_out, d_logits);
     return ccd_rt_last_error();
 }

@@ -185,16 +185,19 @@ struct MirrorDesc {
     int rows, cols;
     int tile_begin;    // first 32x32 tile index of this matrix in the launch
 };
+// 64 x 64 tiles (MIRROR_TILE; round 5: 32 x 32 tiles with 2-byte stores = 64-byte segments of the transposed copy ran at 1.6 TB/s):
+// rows of 256 bytes in, 128-byte segments out on both copies - the transposed one as 4-byte pairs of rows
+constexpr int MIRROR_TILE = 64;
 __global__ __launch_bounds__(256) void mirror_bf16_kernel(const MirrorDesc* __restrict__ descs, int ndesc) {
-    __shared__ float tile[32][33];
+    __shared__ float tile[MIRROR_TILE][MIRROR_TILE + 1];
     int d = 0;
     while (d + 1 < ndesc && descs[d + 1].tile_begin <= (int)blockIdx.x) ++d;
     const MirrorDesc m = descs[d];
-    const int tiles_c = (m.cols + 31) / 32;
+    const int tiles_c = (m.cols + MIRROR_TILE - 1) / MIRROR_TILE;
     const int tl = blockIdx.x - m.tile_begin, tr = tl / tiles_c, tc = tl % tiles_c;
-    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    for (int i = ly; i < 32; i += 8) {
-        const int r = tr * 32 + i, c = tc * 32 + lx;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    for (int i = ly; i < MIRROR_TILE; i += 4) {
+        const int r = tr * MIRROR_TILE + i, c = tc * MIRROR_TILE + lx;
         float v = 0.f;
         if (r < m.rows && c < m.cols) {
             v = m.src[(long)r * m.cols + c];
@@ -204,9 +207,18 @@ __global__ __launch_bounds__(256) void mirror_bf16_kernel(const MirrorDesc* __re
     }
     __syncthreads();
     if (m.dst_t) {
-        for (int i = ly; i < 32; i += 8) {
-            const int c = tc * 32 + i, r = tr * 32 + lx;
-            if (r < m.rows && c < m.cols) m.dst_t[(long)c * m.rows + r] = f2bf(tile[lx][i]);
+        const int rp = threadIdx.x & 31, cy = threadIdx.x >> 5;                      // rows 2 rp, 2 rp + 1 of the tile
+        const int r = tr * MIRROR_TILE + 2 * rp;
+        const bool pairs = (m.rows & 1) == 0;                                        // (4-byte alignment of every transposed row)
+        for (int i = cy; i < MIRROR_TILE; i += 8) {
+            const int c = tc * MIRROR_TILE + i;
+            if (c >= m.cols) break;
+            bf16_t* o = m.dst_t + (long)c * m.rows + r;
+            if (pairs && r + 1 < m.rows) *reinterpret_cast<unsigned*>(o) = pack_bf2(tile[2 * rp][i], tile[2 * rp + 1][i]);
+            else {
+                if (r < m.rows) o[0] = f2bf(tile[2 * rp][i]);
+                if (r + 1 < m.rows) o[1] = f2bf(tile[2 * rp + 1][i]);
+            }
         }
     }
 }

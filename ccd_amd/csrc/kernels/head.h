@@ -62,32 +62,51 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const bf16_t* __restric
 }
 
 // effective last-layer weight: w[k,:] = g[k] * v[k,:] / ||v[k,:]||  -> bf16 [K,D] and bf16 transposed [D,K]
-// one workgroup = 32 rows
+// one workgroup = WN_ROWS rows; a wave reads a row ONCE with 16-byte loads (round 5: two passes of 4-byte loads and 64-byte segments
+// of the transposed copy ran at 1.3 TB/s), the transposed copy leaves in 4-byte pairs of rows = 128-byte segments
+constexpr int WN_ROWS = 64, WN_MAX_V4 = 4;                 // D <= 64 lanes * 4 floats * WN_MAX_V4
 __global__ __launch_bounds__(256) void weightnorm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
                                                              bf16_t* __restrict__ w, bf16_t* __restrict__ w_t,
                                                              float* __restrict__ inv_out, int K, int D) {
-    float* tile = reinterpret_cast<float*>(dynamic_smem());      // [32][D + 1]
+    float* tile = reinterpret_cast<float*>(dynamic_smem());      // [WN_ROWS][D + 1]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int k0 = blockIdx.x * 32;
-    for (int r = wv; r < 32; r += 4) {
+    const int k0 = blockIdx.x * WN_ROWS;
+    const int d4 = D >> 2;
+    for (int r = wv; r < WN_ROWS; r += 4) {
         const int k = k0 + r;
         if (k >= K) break;
+        const f32x4v* row = reinterpret_cast<const f32x4v*>(v + (long)k * D);
+        f32x4v x[WN_MAX_V4];
         float s = 0.f;
-        for (int c = lane; c < D; c += 64) { const float a = v[(long)k * D + c]; s += a * a; }
+#pragma unroll
+        for (int j = 0; j < WN_MAX_V4; ++j) {
+            const int c4 = lane + 64 * j;
+            x[j] = c4 < d4 ? row[c4] : f32x4v{0.f, 0.f, 0.f, 0.f};
+            s += x[j].x * x[j].x + x[j].y * x[j].y + x[j].z * x[j].z + x[j].w * x[j].w;
+        }
         const float inv = 1.0f / sqrtf(wave_sum(s));
         const float sc = g[k] * inv;
-        for (int c = lane; c < D; c += 64) {
-            const float a = v[(long)k * D + c] * sc;
-            w[(long)k * D + c] = f2bf(a);
-            tile[r * (D + 1) + c] = a;
+#pragma unroll
+        for (int j = 0; j < WN_MAX_V4; ++j) {
+            const int c4 = lane + 64 * j;
+            if (c4 < d4) {
+                const float a0 = x[j].x * sc, a1 = x[j].y * sc, a2 = x[j].z * sc, a3 = x[j].w * sc;
+                u32x2 o;
+                o.x = pack_bf2(a0, a1); o.y = pack_bf2(a2, a3);
+                *reinterpret_cast<u32x2*>(w + (long)k * D + 4 * c4) = o;
+                float* t = tile + r * (D + 1) + 4 * c4;
+                t[0] = a0; t[1] = a1; t[2] = a2; t[3] = a3;
+            }
         }
         if (lane == 0) inv_out[k] = inv;
     }
     __syncthreads();
     if (w_t) {
-        const int kk = threadIdx.x & 31;
+        const int kp = threadIdx.x & 31;                         // rows 2 kp, 2 kp + 1 of the tile -> one 4-byte store
         for (int c = threadIdx.x >> 5; c < D; c += 8)
-            if (k0 + kk < K) w_t[(long)c * K + k0 + kk] = f2bf(tile[kk * (D + 1) + c]);
+            if (k0 + 2 * kp + 1 < K)
+                *reinterpret_cast<unsigned*>(w_t + (long)c * K + k0 + 2 * kp) =
+                    pack_bf2(tile[(2 * kp) * (D + 1) + c], tile[(2 * kp + 1) * (D + 1) + c]);
     }
 }
 // dv = g*inv * (dw - vhat <dw, vhat>), dg = <dw, vhat>, vhat = v*inv.  Grad slots are overwritten.

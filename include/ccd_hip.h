@@ -202,7 +202,7 @@ typedef struct ccd_mirror_desc {
     ccd_bf16* dst;    /* [rows, cols] or NULL */
     ccd_bf16* dst_t;  /* [cols, rows] or NULL */
     int rows, cols;
-    int tile_begin;   /* first 32x32 tile of this matrix in the launch (prefix sum) */
+    int tile_begin;   /* first 64x64 tile of this matrix in the launch (prefix sum over ceil(rows/64) * ceil(cols/64); ABI 9: was 32x32) */
     int pad_;
 } ccd_mirror_desc;
 int ccd_mirror_bf16(const ccd_mirror_desc* d_descs, int ndesc, int total_tiles, void* stream);

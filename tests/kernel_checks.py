@@ -687,8 +687,8 @@ def check_small_ops(dev, seed=9):
     s1, s2 = m1.to(dev), m2.to(dev)
     d1, t1 = torch.empty(70, 45, dtype=BF).to(dev), torch.empty(45, 70, dtype=BF).to(dev)
     t2 = torch.empty(130, 33, dtype=BF).to(dev)
-    tiles1 = 3 * 2
-    tiles2 = 2 * 5
+    tiles1 = 2 * 1                  # 64 x 64 tiles: ceil(70 / 64) * ceil(45 / 64); the second matrix has an odd row count (2-byte stores)
+    tiles2 = 1 * 3
     blob = struct.pack("PPPiiii", s1.data_ptr(), d1.data_ptr(), t1.data_ptr(), 70, 45, 0, 0)
     blob += struct.pack("PPPiiii", s2.data_ptr(), 0, t2.data_ptr(), 33, 130, tiles1, 0)
     descs = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
