@@ -9,20 +9,17 @@ namespace ccd {
 
 constexpr int PE_PATCH = 4, PE_K = 48, PE_GW = 32, PE_GH = 8;   // 32x128 image -> 8 x 32 tokens
 
-// one workgroup = one row of 32 patches of one view; thread e keeps W[e, 0:48] in registers.  The pixels sit in LDS TAP-major,
-// px4[tap][token]: one 16-byte (broadcast) read serves a tap of FOUR tokens and feeds two packed FMAs - as px[c][r][x] every FMA
-// had its own 4-byte LDS read and the kernel was bound by the LDS instruction rate (121 us for 225 MB).  Same fp32 FMAs in the same
-// order per token: the results are bit-equal to the scalar loop's.
+// one workgroup = one row of 32 patches of one view; thread e keeps W[e, 0:48] in registers
 __global__ __launch_bounds__(128) void patch_embed_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ pos, float* __restrict__ out,
                                                               int E) {
-    __shared__ __attribute__((aligned(16))) float px4[PE_K][PE_GW];
+    __shared__ float px[3][PE_PATCH][PE_GW * PE_PATCH];
     const int view = blockIdx.x / PE_GH, py = blockIdx.x % PE_GH;
     const float* src = img + (long)view * 3 * 32 * 128;
     for (int i = threadIdx.x; i < 3 * 4 * 128; i += blockDim.x) {
-        const int c = i / 512, r = (i / 128) % 4, xx = i % 128;
-        px4[c * 16 + r * 4 + (xx & 3)][xx >> 2] = src[(long)c * 4096 + (py * 4 + r) * 128 + xx];
+        const int c = i / 512, r = (i / 128) % 4, x = i % 128;
+        px[c][r][x] = src[(long)c * 4096 + (py * 4 + r) * 128 + x];
     }
     __syncthreads();
     for (int e = threadIdx.x; e < E; e += blockDim.x) {
@@ -30,19 +27,16 @@ __global__ __launch_bounds__(128) void patch_embed_fwd_kernel(const float* __res
 #pragma unroll
         for (int k = 0; k < PE_K; ++k) wr[k] = w[(long)e * PE_K + k];   // conv weight [E,3,4,4] flattened
         const float b = bias[e];
-        for (int t4 = 0; t4 < PE_GW / 4; ++t4) {
-            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+        for (int tx = 0; tx < PE_GW; ++tx) {
+            float acc = 0.f;
 #pragma unroll
-            for (int k = 0; k < PE_K; ++k) {
-                const f32x4v p = *reinterpret_cast<const f32x4v*>(&px4[k][4 * t4]);
-                const f32x2 wk = {wr[k], wr[k]};
-                a01 += wk * f32x2{p.x, p.y};
-                a23 += wk * f32x2{p.z, p.w};
-            }
-            const int tok = py * PE_GW + 4 * t4;
-            const float acc[4] = {a01[0], a01[1], a23[0], a23[1]};
+            for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) out[((long)view * 256 + tok + u) * E + e] = acc[u] + b + pos[(long)(tok + u) * E + e];
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) acc += wr[c * 16 + r * 4 + x] * px[c][r][tx * 4 + x];
+            const int tok = py * PE_GW + tx;
+            out[((long)view * 256 + tok) * E + e] = acc + b + pos[(long)tok * E + e];
         }
     }
 }
