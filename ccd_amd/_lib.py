@@ -69,6 +69,9 @@ SIGNATURES = {
     "ccd_weightnorm_bwd": [P, P, P, P, P, P, I, I, P],
     "ccd_dino_loss_fwd": [P, P, P, I, P, I, F, F, P, P, P],
     "ccd_dino_loss_bwd": [P, P, P, I, P, I, F, F, P, F, P, P, P],
+    "ccd_head_loss_ws_floats": [I, I],
+    "ccd_head_loss_fwd": [P, L, P, L, P, L, P, L, P, I, I, P, I, F, F, P, P, P, P],
+    "ccd_head_loss_bwd": [P, L, P, L, P, L, P, L, P, I, I, P, I, F, F, P, F, P, P, L, P],
     "ccd_colsum_f32": [P, I, P, I, I, P, P],
     "ccd_matvec_bf16": [P, L, P, I, I, P, P],
     "ccd_center_ema": [P, P, I, P, I, F, P],
@@ -102,7 +105,7 @@ SIGNATURES = {
     "ccd_tf_loss_bwd": [P, L, I, P, I, I, I, P, P, P, P, L, P],
     "ccd_greedy_step": [P, L, I, I, P, I, I, P, I, P],
 }
-_RESTYPES = {"ccd_build_info": C.c_char_p, "ccd_attention_bwd_ws_floats": L, "ccd_gemm_tn_pair_ws_floats": L}
+_RESTYPES = {"ccd_build_info": C.c_char_p, "ccd_attention_bwd_ws_floats": L, "ccd_gemm_tn_pair_ws_floats": L, "ccd_head_loss_ws_floats": L}
 
 
 def bind(lib: C.CDLL) -> C.CDLL:

@@ -21,6 +21,7 @@
 #include "kernels/embed.h"
 #include "kernels/head.h"
 #include "kernels/loss.h"
+#include "kernels/headloss.h"
 #include "kernels/optim.h"
 #include "kernels/conv.h"
 #include "kernels/cls_tail.h"
@@ -265,8 +266,8 @@ static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, float* ws, long ws_
 
 extern "C" {
 
-int ccd_abi_version(void) { return 9; }   // 9: ccd_cls_tail_fwd / _bwd_reduce / _bwd_apply (BatchNorm + ReLU + classifier conv of the segmentation head fused); 8: ccd_proj_mlp_fused (proj + residual + LayerNorm-2 in front of the fused MLP), ccd_matvec_bf16; 7: ccd_gemm_tn_pair_ws (split-K workspace instead of fp32 atomics); 6: device-side momentum / DropPath seed (HIP graph of the training step); 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
-const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi9"; }
+int ccd_abi_version(void) { return 10; }   // 10: ccd_head_loss_fwd / _bwd (last layer + distillation loss, logits never written); 9: ccd_cls_tail_fwd / _bwd_reduce / _bwd_apply (BatchNorm + ReLU + classifier conv of the segmentation head fused); 8: ccd_proj_mlp_fused (proj + residual + LayerNorm-2 in front of the fused MLP), ccd_matvec_bf16; 7: ccd_gemm_tn_pair_ws (split-K workspace instead of fp32 atomics); 6: device-side momentum / DropPath seed (HIP graph of the training step); 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
+const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi10"; }
 int ccd_policy_set(const char* key, int value) {
     CCD_CHECK(key, CCD_EINVAL);
     for (const CcdPolicyKey& k : ccd_policy_keys)
@@ -928,6 +929,73 @@ int ccd_dino_loss_bwd(const float* s_logits, const float* t_logits, const float*
     CCD_LAUNCH(ccd::dino_loss_bwd_kernel, dim3(max_rows), dim3(256), 0, stream, s_logits, t_logits, center, K, d_m,
                max_rows, 1.0f / student_temp, 1.0f / teacher_temp, stats, grad_scale, d_grad_scale, d_logits);
     return ccd_rt_last_error();
+}
+// head's last layer + distillation loss, logits never written (headloss.h).  Column splits: a multiple of 8 (one residue per XCD),
+// 1 024 columns per split where K allows it
+static int ccd_head_loss_splits(int K) {
+    if (K <= 0 || K % 512 != 0) return 0;
+    const int chunks_total = K / 64;
+    for (int cs = 64; cs >= 8; cs -= 8)
+        if (chunks_total % cs == 0) return cs;
+    return 0;
+}
+long ccd_head_loss_ws_floats(int max_rows, int K) {
+    const int cs = ccd_head_loss_splits(K);
+    return cs > 0 && max_rows > 0 ? (long)cs * max_rows * 8 : 0;
+}
+static int ccd_head_loss_launch(ccd::HeadLossParams& q, bool bwd, void* stream) {
+    q.CS = ccd_head_loss_splits(q.K);
+    CCD_CHECK(q.CS > 0, CCD_ESHAPE);
+    q.chunks = q.K / 64 / q.CS;
+    const int smem = ccd::hl_smem_bytes(q.chunks);
+    CCD_CHECK(smem <= 160 * 1024, CCD_ESHAPE);
+    int grid = ccd_grid_cus() & ~7;
+    if (grid < 8) grid = 8;
+    if (bwd) CCD_LAUNCH((ccd::head_loss_kernel<true>), dim3(grid), dim3(ccd::HL_THREADS), smem, stream, q);
+    else CCD_LAUNCH((ccd::head_loss_kernel<false>), dim3(grid), dim3(ccd::HL_THREADS), smem, stream, q);
+    return ccd_rt_last_error();
+}
+static int ccd_head_loss_fill(ccd::HeadLossParams& q, const ccd_bf16* zs, long ld_zs, const ccd_bf16* zt, long ld_zt, const ccd_bf16* ws,
+                              long ld_ws, const ccd_bf16* wt, long ld_wt, const float* center, int K, int D, const int* d_m, int max_rows,
+                              float student_temp, float teacher_temp) {
+    CCD_CHECK(zs && zt && ws && wt && center && d_m, CCD_EINVAL);
+    CCD_CHECK(D == ccd::HL_D && K > 0 && max_rows > 0 && student_temp > 0 && teacher_temp > 0, CCD_ESHAPE);
+    CCD_CHECK(CCD_ALIGNED16(zs) && CCD_ALIGNED16(zt) && CCD_ALIGNED16(ws) && CCD_ALIGNED16(wt) && CCD_ALIGNED16(center), CCD_EINVAL);
+    CCD_CHECK(ld_zs % 8 == 0 && ld_zt % 8 == 0 && ld_ws % 8 == 0 && ld_wt % 8 == 0 && ld_zs >= D && ld_zt >= D && ld_ws >= D && ld_wt >= D, CCD_EINVAL);
+    CCD_CHECK(((long)max_rows + 1) * ld_zs * 2 < CCD_MAX_OPERAND_BYTES && ((long)max_rows + 1) * ld_zt * 2 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
+    // (the weight matrices are walked by 64-bit pointer + a per-lane 32-bit row offset of at most 64 rows)
+    q.zs = reinterpret_cast<const ccd::bf16_t*>(zs); q.ld_zs = ld_zs; q.zt = reinterpret_cast<const ccd::bf16_t*>(zt); q.ld_zt = ld_zt;
+    q.ws = reinterpret_cast<const ccd::bf16_t*>(ws); q.ld_ws = ld_ws; q.wt = reinterpret_cast<const ccd::bf16_t*>(wt); q.ld_wt = ld_wt;
+    q.center = center; q.d_m = d_m; q.max_rows = max_rows; q.K = K;
+    q.ks = 1.4426950408889634f / student_temp; q.kt = 1.4426950408889634f / teacher_temp;
+    q.part = nullptr; q.stats = nullptr; q.grad_scale = 0.f; q.d_grad_scale = nullptr; q.d_logits = nullptr; q.ld_d = 0;
+    return CCD_OK;
+}
+int ccd_head_loss_fwd(const ccd_bf16* zs, long ld_zs, const ccd_bf16* zt, long ld_zt, const ccd_bf16* ws, long ld_ws,
+                      const ccd_bf16* wt, long ld_wt, const float* center, int K, int D, const int* d_m, int max_rows,
+                      float student_temp, float teacher_temp, float* ws_part, float* stats, float* loss_out, void* stream) {
+    ccd::HeadLossParams q;
+    const int rc = ccd_head_loss_fill(q, zs, ld_zs, zt, ld_zt, ws, ld_ws, wt, ld_wt, center, K, D, d_m, max_rows, student_temp, teacher_temp);
+    if (rc != CCD_OK) return rc;
+    CCD_CHECK(ws_part && stats && loss_out && CCD_ALIGNED16(ws_part) && CCD_ALIGNED16(stats), CCD_EINVAL);
+    q.part = ws_part;
+    const int rl = ccd_head_loss_launch(q, false, stream);
+    if (rl != CCD_OK) return rl;
+    CCD_LAUNCH(ccd::head_loss_finish_kernel, dim3((max_rows + 255) / 256), dim3(256), 0, stream, (const float*)ws_part, d_m, max_rows, q.CS, stats, loss_out);
+    return ccd_rt_last_error();
+}
+int ccd_head_loss_bwd(const ccd_bf16* zs, long ld_zs, const ccd_bf16* zt, long ld_zt, const ccd_bf16* ws, long ld_ws,
+                      const ccd_bf16* wt, long ld_wt, const float* center, int K, int D, const int* d_m, int max_rows,
+                      float student_temp, float teacher_temp, const float* stats, float grad_scale, const float* d_grad_scale,
+                      ccd_bf16* d_logits, long ld_d, void* stream) {
+    ccd::HeadLossParams q;
+    const int rc = ccd_head_loss_fill(q, zs, ld_zs, zt, ld_zt, ws, ld_ws, wt, ld_wt, center, K, D, d_m, max_rows, student_temp, teacher_temp);
+    if (rc != CCD_OK) return rc;
+    CCD_CHECK(stats && d_logits && CCD_ALIGNED16(stats) && CCD_ALIGNED16(d_logits) && ld_d % 8 == 0 && ld_d >= K, CCD_EINVAL);
+    CCD_CHECK(33L * ld_d * 2 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
+    q.stats = stats; q.grad_scale = grad_scale; q.d_grad_scale = d_grad_scale;
+    q.d_logits = reinterpret_cast<ccd::bf16_t*>(d_logits); q.ld_d = ld_d;
+    return ccd_head_loss_launch(q, true, stream);
 }
 int ccd_colsum_f32(const float* x, int K, const int* d_rows, int rows_mul, int max_rows, float* out, void* stream) {
     CCD_CHECK(x && out && K > 0 && K % 4 == 0 && max_rows > 0, CCD_EINVAL);

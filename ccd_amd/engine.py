@@ -49,6 +49,9 @@ class Fusion:
     if store_gact is None:                         # a measured tie, 52.9 vs 53.0 ms per step: + 0.47 ms forward, - 0.75 ms gelu'(u)
         store_gact = False                         # product, + 0.2 GB per block of saved activations at B = 256)
     proj_mlp = _env_switch("CCD_FUSE_PROJ")        # proj + residual + LayerNorm-2 in front of the fused MLP, one launch per block half (default: with `mlp`, E <= 384)
+    head_loss = _env_switch("CCD_FUSE_HEAD_LOSS")  # last layer + distillation loss in one pass, logits never written (default: on where ccd_head_loss_* take the shape)
+    if head_loss is None:
+        head_loss = True
     side_stream = bool(_env_switch("CCD_SIDE_STREAM"))
     double_gb = False                       # tests: rotate the two gb buffers of the side-stream mode also without a side stream
 
@@ -163,7 +166,10 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
             c.y1, c.mean1, c.rstd1 = pending
         c.qkv = ops.gemm_nt(c.y1, arena.wb(b + "attn.qkv.weight"), bias=arena.w(b + "attn.qkv.bias"))
         c.att, c.lse = ops.attention_fwd(c.qkv.view(N, 256, 3 * E), spec.heads, scale)
-        if fuse_proj:
+        # (a dropped MLP branch reads x_mid back, so the one-launch block half needs x_mid written: a pass that keeps nothing AND
+        # draws DropPath masks - train() under no_grad - takes the two-launch path for that block)
+        proj_here = fuse_proj and (save or c.ds2 is None)
+        if proj_here:
             # the block's second half in ONE launch: x_mid and y2 stay in registers (a pass that saves nothing writes neither)
             nxt = f"{pre}blocks.{i + 1}.norm1." if i + 1 < spec.depth else pre + "norm."
             # a segmentation tap behind this block is one more LayerNorm of the same rows: the kernel emits it (same statistics)
@@ -187,7 +193,7 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
             c.x_mid = ops.gemm_nt(c.att.view(R, E), arena.wb(b + "attn.proj.weight"), epilogue=ops.EPI_RESID,
                                   bias=arena.w(b + "attn.proj.bias"), resid=x, rowscale=c.ds1, rows_per_sample=256)
             c.y2, c.mean2, c.rstd2 = ops.ln_fwd(c.x_mid, arena.w(b + "norm2.weight"), arena.w(b + "norm2.bias"), spec.eps)
-        if fuse_proj:
+        if proj_here:
             pass
         elif fuse_mlp:
             nxt = f"{pre}blocks.{i + 1}.norm1." if i + 1 < spec.depth else pre + "norm."
@@ -218,7 +224,7 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
         ctxs.append(c if save else None)
         if need_taps and i + 1 in spec.taps:
             j = len(taps)
-            if fuse_proj:
+            if proj_here:
                 t, mu, rs = tap_out[0], mean_n, rstd_n           # (LayerNorm statistics depend on the rows only)
             else:
                 t, mu, rs = ops.ln_fwd(x, arena.w(f"{pre}norm_seg.{j}.weight"), arena.w(f"{pre}norm_seg.{j}.bias"), spec.eps)
@@ -508,8 +514,46 @@ class RegionPoolFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------------- DINO head
-def head_forward(arena, pre, rows, d_total, save, rows_mul=2):
-    """rows bf16 [max_rows, E] -> logits fp32 [max_rows, K] (only the first rows_mul*d_total[0] rows are computed)."""
+class LazyLogits:
+    """logits = zn @ w^T of a DINO head that nobody has asked for yet (round 6).  The distillation loss takes the two factors
+    (ccd_head_loss_fwd / _bwd: a logit lives in a register for as long as it takes to fold it into its row's softmax state); whoever
+    wants the [max_rows, K] fp32 tensor itself calls tensor() and pays for the product then.  `stub` is the 1-element autograd
+    stand-in HeadFn returned: the bf16 logit gradient travels to HeadFn.backward through _BF16_LOGIT_GRADS under its address."""
+
+    def __init__(self, zn, w, d_total, rows_mul):
+        self.zn, self.w, self.d_total, self.rows_mul = zn, w, d_total, rows_mul
+        self.stub = None
+        self._tensor = None
+
+    @property
+    def shape(self):
+        return torch.Size((self.zn.shape[0], self.w.shape[0]))
+
+    @property
+    def device(self):
+        return self.zn.device
+
+    def detach(self):
+        return self
+
+    def tensor(self):
+        """The [max_rows, K] fp32 matrix itself (rows < rows_mul * M computed), outside autograd: for inspection / API parity."""
+        if self._tensor is None:
+            self._tensor = torch.empty(tuple(self.shape), dtype=F32, device=self.zn.device)
+            ops.gemm_nt(self.zn, self.w, epilogue=ops.EPI_F32, out=self._tensor, m_fastest=1, d_rows=self.d_total, rows_mul=self.rows_mul)
+        return self._tensor
+
+
+_LAZY_LOGITS = {}        # stub address -> LazyLogits, between HeadFn.forward and the caller of HeadFn.apply
+
+
+def logits_tensor(x):
+    return x.tensor() if isinstance(x, LazyLogits) else x
+
+
+def head_forward(arena, pre, rows, d_total, save, rows_mul=2, lazy=False):
+    """rows bf16 [max_rows, E] -> logits fp32 [max_rows, K] (only the first rows_mul*d_total[0] rows are computed); with `lazy`,
+    where the fused head + loss kernels take the shape, a LazyLogits instead (the product is left to the loss)."""
     dev = rows.device
     dyn = dict(d_rows=d_total, rows_mul=rows_mul)
     u0, a0 = ops.gemm_nt(rows, arena.wb(pre + "mlp.0.weight"), epilogue=ops.EPI_GELU, bias=arena.w(pre + "mlp.0.bias"), **dyn)
@@ -524,6 +568,9 @@ def head_forward(arena, pre, rows, d_total, save, rows_mul=2):
     w_t = torch.empty((D, K), dtype=BF16, device=dev) if save else None
     winv = torch.empty(K, dtype=F32, device=dev)
     ops.weightnorm_fwd(v, gw, w, w_t, winv)
+    saved = (rows, u0, a0, u1, a1, z, zn, inv, w_t, winv) if save else None
+    if lazy and rows_mul == 2 and Fusion.head_loss and ops.head_loss_supported(K, D, rows.shape[0]):
+        return LazyLogits(zn, w, d_total, rows_mul), saved
     logits = torch.empty((rows.shape[0], K), dtype=F32, device=dev)
     ops.gemm_nt(zn, w, epilogue=ops.EPI_F32, out=logits, m_fastest=1, **dyn)
     if not save:
@@ -532,7 +579,6 @@ def head_forward(arena, pre, rows, d_total, save, rows_mul=2):
         _LOGIT_FACTORS.clear()
         if D % 256 == 0:
             _LOGIT_FACTORS[logits.data_ptr()] = (zn, w)
-    saved = (rows, u0, a0, u1, a1, z, zn, inv, w_t, winv) if save else None
     return logits, saved
 
 
@@ -542,7 +588,12 @@ _LOGIT_FACTORS = {}      # logits buffer address -> (zn bf16 [rows, D], w bf16 [
 def logit_column_sums(logits, d_total, out, rows_mul=2):
     """out[k] += sum over the first rows_mul * d_total[0] rows of logits[:, k] - through the factors head_forward parked for this
     buffer when it has them (colsum of zn, then w . that), by a pass over the logits otherwise."""
-    fac = _LOGIT_FACTORS.pop(logits.data_ptr(), None)
+    if isinstance(logits, LazyLogits):
+        fac = (logits.zn, logits.w) if logits.w.shape[1] % 256 == 0 else None
+        if fac is None:
+            logits = logits.tensor()
+    else:
+        fac = _LOGIT_FACTORS.pop(logits.data_ptr(), None)
     if fac is None or fac[0].shape[0] != logits.shape[0]:
         ops.colsum_f32(logits, out, d_rows=d_total, rows_mul=rows_mul)
         return out
@@ -591,11 +642,17 @@ _BF16_LOGIT_GRADS = {}
 
 class HeadFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rows, module, d_total, rows_mul=2):
+    def forward(ctx, rows, module, d_total, rows_mul=2, lazy=False):
         save = ctx.needs_input_grad[0]
-        logits, saved = head_forward(module.arena, module.arena_prefix, rows, d_total, save, rows_mul)
+        logits, saved = head_forward(module.arena, module.arena_prefix, rows, d_total, save, rows_mul, lazy)
         ctx.module, ctx.saved, ctx.d_total, ctx.rows_mul = module, saved, d_total, rows_mul
+        if isinstance(logits, LazyLogits):
+            # the autograd output is a 1-element stand-in; head_rows() hands the caller the LazyLogits parked under its address
+            stub = torch.zeros(1, dtype=F32, device=rows.device)
+            _LAZY_LOGITS[stub.data_ptr()] = logits
+            logits = stub
         ctx.logits_key = logits.data_ptr()
+        ctx.logits_shape = tuple(logits.shape)
         _BF16_LOGIT_GRADS.pop(ctx.logits_key, None)
         return logits
 
@@ -607,15 +664,65 @@ class HeadFn(torch.autograd.Function):
             if any(st != 0 for st in d_logits.stride()):          # another consumer contributed a real gradient
                 parked = parked + d_logits.to(BF16)
             d_logits = parked
+        elif ctx.logits_shape == (1,):                           # lazy logits: the gradient only ever arrives parked
+            if parked is None:
+                raise RuntimeError("HeadFn.backward: no logit gradient was parked for a head whose logits were left to the fused loss")
+            d_logits = parked
         d_rows = head_backward(m.arena, m.arena_prefix, ctx.saved, d_logits.contiguous().to(BF16), ctx.d_total,
                                m.weight_g_trainable, ctx.rows_mul)
         ctx.saved = None
         if m.grad_ready_hook is not None:
             m.grad_ready_hook(m.arena_prefix)
-        return d_rows, None, None, None
+        return d_rows, None, None, None, None
+
+
+def head_rows(module, rows, d_total, rows_mul=2, lazy=False):
+    """HeadFn.apply; with `lazy` the result may be a LazyLogits (its .stub carries the autograd edge)."""
+    out = HeadFn.apply(rows, module, d_total, rows_mul, lazy)
+    handle = _LAZY_LOGITS.pop(out.data_ptr(), None) if lazy and out.numel() == 1 else None
+    if handle is None:
+        return out
+    handle.stub = out
+    return handle
 
 
 # ---------------------------------------------------------------------------------------------------------- losses
+class FusedDinoLossFn(torch.autograd.Function):
+    """DinoLossFn on the FACTORS of the two logit matrices (LazyLogits): ccd_head_loss_fwd / _bwd, the logits are never written.
+    The student's bf16 logit gradient is parked for HeadFn.backward (see _BF16_LOGIT_GRADS); the stub's own gradient is a zero."""
+
+    @staticmethod
+    def forward(ctx, stub, s, t, center, d_total, student_temp, teacher_temp):
+        dev = stub.device
+        stats = torch.empty((s.zn.shape[0], 4), dtype=F32, device=dev)
+        loss = torch.zeros(1, dtype=F32, device=dev)
+        center = center.clone()     # DINOLoss.update_center rewrites the buffer in place right after this forward
+        ops.head_loss_fwd(s.zn, t.zn, s.w, t.w, center, d_total, student_temp, teacher_temp, stats, loss)
+        ctx.saved = (s.zn, t.zn, s.w, t.w, center, stats)
+        ctx.d_total, ctx.temps, ctx.key = d_total, (student_temp, teacher_temp), stub.data_ptr()
+        return loss
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        zs, zt, ws, wt, center, stats = ctx.saved
+        ctx.saved = None
+        d_logits = torch.empty((zs.shape[0], ws.shape[0]), dtype=BF16, device=zs.device)     # rows past 2M are never read
+        ops.head_loss_bwd(zs, zt, ws, wt, center, ctx.d_total, ctx.temps[0], ctx.temps[1], stats, 1.0, d_logits,
+                          d_grad_scale=d_loss.contiguous().float())
+        _BF16_LOGIT_GRADS[ctx.key] = d_logits
+        return torch.zeros(1, dtype=F32, device=zs.device), None, None, None, None, None, None
+
+
+def dino_loss(s_logits, t_logits, center, d_total, student_temp, teacher_temp, park_grad):
+    """The distillation loss of Dino_loss.py:81-105 on logits tensors or LazyLogits (both lazy: the fused kernels)."""
+    if isinstance(s_logits, LazyLogits) and isinstance(t_logits, LazyLogits) and s_logits.stub is not None and \
+            s_logits.shape == t_logits.shape and s_logits.zn.shape == t_logits.zn.shape:
+        return FusedDinoLossFn.apply(s_logits.stub, s_logits, t_logits, center, d_total, student_temp, teacher_temp)
+    if isinstance(s_logits, LazyLogits):
+        raise RuntimeError("a student head's lazy logits cannot be materialised behind autograd's back: run the head with lazy=False")
+    t = logits_tensor(t_logits)
+    return DinoLossFn.apply(s_logits, t.detach(), center, d_total, student_temp, teacher_temp, park_grad)
+
 class DinoLossFn(torch.autograd.Function):
     """loss (1-element fp32 tensor) of the two cross-view CE terms; d(student logits) in bf16."""
 

@@ -48,8 +48,7 @@ class DINOLoss(nn.Module):
         # --- character-to-character distillation
         temp = float(self.teacher_temp_schedule[epoch])
         center = self.center.view(-1)
-        dino_loss = engine.DinoLossFn.apply(s_logits, t_logits.detach(), center, d_total, self.student_temp, temp,
-                                            direct)[0]
+        dino_loss = engine.dino_loss(s_logits, t_logits.detach(), center, d_total, self.student_temp, temp, direct)[0]
         self.update_center(t_logits.detach(), d_total)
         self.losses["mask_loss"] = mask_loss
         self.losses["Dino_loss"] = dino_loss

@@ -82,7 +82,8 @@ class ABIDINOModel(ArenaModule):
     # ---------------------------------------------------------------------------------------- sub-steps
     def _pooled_logits(self, tokens, sel):
         rows = engine.RegionPoolFn.apply(tokens, sel)
-        return self.head.forward_rows(rows, sel.total)
+        # (lazy: the head may leave its last product to the loss - engine.LazyLogits, ccd_head_loss_fwd / _bwd)
+        return self.head.forward_rows(rows, sel.total, lazy=True)
 
     def attention(self, feature, clusters):
         """Reference-shaped helper (dino_vision.py:38-49): feature [N,E,8,32], clusters [N,26,32,128] -> ([N,26,E], index)."""
@@ -122,12 +123,12 @@ class ABIDINOModel(ArenaModule):
             logits = self._pooled_logits(tokens, sel)
             return ModelOutput(
                 {"mask": seg, "image": x, "zero": ClusterMaps(sel), "logits_buf": logits, "selection": sel},
-                {"instances_view": lambda: logits[: 2 * sel.M], "index": lambda: sel.new_index.bool()})
+                {"instances_view": lambda: engine.logits_tensor(logits)[: 2 * sel.M], "index": lambda: sel.new_index.bool()})
         sel = clusters.selection if isinstance(clusters, ClusterMaps) else \
             engine.Selection(ops.planes_to_idmap(clusters), B)
         logits = self._pooled_logits(tokens, sel)
         return ModelOutput({"logits_buf": logits, "selection": sel},
-                           {"instances_view": lambda: logits[: 2 * sel.M],
+                           {"instances_view": lambda: engine.logits_tensor(logits)[: 2 * sel.M],
                             "feature": lambda: self.backbone.to_2D(tokens).float()})
 
 

@@ -174,10 +174,11 @@ class DINOHead(ArenaModule):
     def _transposed_names(self):
         return ["mlp.0.weight", "mlp.2.weight", "mlp.4.weight"]
 
-    def forward_rows(self, rows, d_total):
-        """rows bf16 [max_rows, in_dim] with the live row count 2*d_total[0] on the device -> logits fp32."""
+    def forward_rows(self, rows, d_total, lazy=False):
+        """rows bf16 [max_rows, in_dim] with the live row count 2*d_total[0] on the device -> logits fp32; `lazy`: an
+        engine.LazyLogits where the fused head + loss kernels take the shape (the [max_rows, out_dim] matrix is never written)."""
         self.ensure_arena()
-        return engine.HeadFn.apply(rows, self, d_total)
+        return engine.head_rows(self, rows, d_total, 2, lazy)
 
     def forward(self, x):
         self.ensure_arena()

@@ -620,6 +620,51 @@ def dino_loss_bwd(s_logits, t_logits, center, d_m, student_temp, teacher_temp, s
               _lib.ptr(d_logits))
 
 
+def head_loss_supported(K, D, max_rows):
+    """True where ccd_head_loss_fwd / _bwd take the shape (D == 256, K % 512 == 0): the logits need not be materialised."""
+    return D == 256 and K % 512 == 0 and max_rows > 0 and _lib.get().ccd_head_loss_ws_floats(int(max_rows), int(K)) > 0
+
+
+_HEAD_LOSS_WS = {}
+
+
+def _head_loss_ws(device, n):
+    """One workspace per (device, stream) for the per-split partials of ccd_head_loss_fwd (grown, never shrunk)."""
+    key = (device.index if device.type == "cuda" else -1, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    ws = _HEAD_LOSS_WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _HEAD_LOSS_WS[key] = torch.empty(int(n), dtype=F32, device=device)
+    return ws
+
+
+def head_loss_fwd(zs, zt, ws, wt, center, d_m, student_temp, teacher_temp, stats, loss_out):
+    """loss_out += DINO distillation loss of logits zs @ ws^T (student) against zt @ wt^T (teacher, centred) - the logits stay in
+    registers (include/ccd_hip.h: ccd_head_loss_fwd).  stats [max_rows, 4] is what head_loss_bwd reads."""
+    for t, n in ((zs, "zs"), (zt, "zt"), (ws, "ws"), (wt, "wt")):
+        _chk(t, BF16, n)
+    _chk(center, F32, "center"); _chk(stats, F32, "stats")
+    max_rows, D = zs.shape
+    K = ws.shape[0]
+    assert zt.shape == zs.shape and wt.shape == ws.shape and ws.shape[1] == D and stats.shape == (max_rows, 4)
+    part = _head_loss_ws(zs.device, _lib.get().ccd_head_loss_ws_floats(max_rows, K))
+    with _Span("head_loss_fwd", 4.0 * max_rows * K * D, 4.0 * K * D):
+        _call("ccd_head_loss_fwd", _lib.ptr(zs), zs.stride(0), _lib.ptr(zt), zt.stride(0), _lib.ptr(ws), ws.stride(0), _lib.ptr(wt),
+              wt.stride(0), _lib.ptr(center), K, D, _lib.ptr(d_m), max_rows, float(student_temp), float(teacher_temp), _lib.ptr(part),
+              _lib.ptr(stats), _lib.ptr(loss_out))
+
+
+def head_loss_bwd(zs, zt, ws, wt, center, d_m, student_temp, teacher_temp, stats, grad_scale, d_logits, d_grad_scale=None):
+    """d_logits (bf16 [max_rows, K], rows < 2M written) = d loss / d (zs @ ws^T), the products recomputed (ccd_head_loss_bwd)."""
+    _chk(d_logits, BF16, "d_logits")
+    max_rows, D = zs.shape
+    K = ws.shape[0]
+    assert d_logits.shape == (max_rows, K)
+    with _Span("head_loss_bwd", 4.0 * max_rows * K * D, 4.0 * K * D + 2.0 * max_rows * K):
+        _call("ccd_head_loss_bwd", _lib.ptr(zs), zs.stride(0), _lib.ptr(zt), zt.stride(0), _lib.ptr(ws), ws.stride(0), _lib.ptr(wt),
+              wt.stride(0), _lib.ptr(center), K, D, _lib.ptr(d_m), max_rows, float(student_temp), float(teacher_temp), _lib.ptr(stats),
+              float(grad_scale), _lib.ptr(d_grad_scale), _lib.ptr(d_logits), d_logits.stride(0))
+
+
 def colsum_f32(x, out, d_rows=None, rows_mul=1):
     max_rows, K = x.shape
     _call("ccd_colsum_f32", _lib.ptr(x), K, _lib.ptr(d_rows), rows_mul, max_rows, _lib.ptr(out))

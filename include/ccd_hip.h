@@ -281,6 +281,23 @@ int ccd_dino_loss_bwd(const float* s_logits, const float* t_logits, const float*
                       int max_rows, float student_temp, float teacher_temp, const float* stats, float grad_scale,
                       const float* d_grad_scale /* optional device scalar, multiplied in */, ccd_bf16* d_logits,
                       void* stream);
+/* The head's last layer AND the distillation loss in one pass, the [2M, K] logits never written (ABI 10; replaces the chain
+ * ccd_gemm_nt(EPI_F32) x 2 -> ccd_dino_loss_fwd / _bwd of vision_transformer.py:326-327 + Dino_loss.py:81-105 where D == 256 and
+ * K % 512 == 0): logits s = zs . ws^T, t = zt . wt^T are formed tile by tile in registers and folded into per-row online-softmax
+ * state; the backward entry recomputes the same tiles and writes the bf16 logit gradient d_logits [>= 2M, K] that the head's
+ * weight / data gradient products read.  zs / zt [max_rows, 256] bf16 (L2-normalised rows), ws / wt [K, 256] bf16 (weight-normed
+ * last layers), center [K] fp32, d_m = device M, ws_part = workspace of ccd_head_loss_ws_floats(max_rows, K) floats,
+ * stats [max_rows, 4] (written by _fwd, read by _bwd; base-2 domain: m_s, 1 / l_s, m_t, 1 / l_t), loss_out accumulates the scalar.
+ * CCD_ESHAPE for other shapes: the caller takes the unfused chain. */
+long ccd_head_loss_ws_floats(int max_rows, int K);
+int ccd_head_loss_fwd(const ccd_bf16* zs, long ld_zs, const ccd_bf16* zt, long ld_zt, const ccd_bf16* ws, long ld_ws,
+                      const ccd_bf16* wt, long ld_wt, const float* center, int K, int D, const int* d_m, int max_rows,
+                      float student_temp, float teacher_temp, float* ws_part, float* stats, float* loss_out, void* stream);
+int ccd_head_loss_bwd(const ccd_bf16* zs, long ld_zs, const ccd_bf16* zt, long ld_zt, const ccd_bf16* ws, long ld_ws,
+                      const ccd_bf16* wt, long ld_wt, const float* center, int K, int D, const int* d_m, int max_rows,
+                      float student_temp, float teacher_temp, const float* stats, float grad_scale,
+                      const float* d_grad_scale /* optional device scalar, multiplied in */, ccd_bf16* d_logits, long ld_d,
+                      void* stream);
 int ccd_colsum_f32(const float* x, int K, const int* d_rows, int rows_mul, int max_rows, float* out, void* stream);
 /* out[k] += sum_d w[k, d] * v[d]  (w [K, D] bf16, D % 256 == 0, v and out fp32).  The teacher centre of Dino_loss.py:133-143 without a
  * pass over the [2M, K] teacher logits: their column sums are (sum of the rows of zn) . W^T - ccd_colsum_bf16 of the l2-normalised

@@ -751,6 +751,50 @@ def check_dino_loss(dev, M=11, K=4096, seed=11, temp=0.04):
     close(cen, O.center_update(center, t[:2 * M]).reshape(-1), 1e-5, 1e-6, "dino/center")
 
 
+def check_head_loss(dev, M=11, K=512, seed=21, temp=0.04, spare=6):
+    """ccd_head_loss_fwd / _bwd (headloss.h): the head's last layer and the distillation loss with the logits in registers, against
+    the oracle's loss on logits formed in fp32 from the same bf16 factors, and against the unfused kernels (dino_loss_fwd / _bwd
+    on materialised logits).  One weight row of either network is scaled up so that the running maxima move late in a row."""
+    gen = torch.Generator().manual_seed(seed)
+    D, max_rows = 256, 2 * M + spare
+    nrm = lambda x: x / x.norm(dim=1, keepdim=True)
+    zs, zt = nrm(rnd((max_rows, D), gen)).to(BF), nrm(rnd((max_rows, D), gen)).to(BF)
+    ws, wt = nrm(rnd((K, D), gen)), nrm(rnd((K, D), gen))
+    ws[K // 2 + 3] *= 4.0; wt[K - 5] *= 3.0
+    ws, wt = ws.to(BF), wt.to(BF)
+    center = rnd((1, K), gen, 0.05)
+    s = (zs.float() @ ws.float().t())[:2 * M]
+    t = (zt.float() @ wt.float().t())[:2 * M]
+    sr = s.clone().requires_grad_(True)
+    ref = O.dino_ce(sr, t, center, temp)
+    ref.backward()
+    d_m = torch.tensor([M], dtype=torch.int32).to(dev)
+    ZS, ZT, WS, WT, C_ = zs.to(dev), zt.to(dev), ws.to(dev), wt.to(dev), center.reshape(-1).to(dev)
+    assert ops.head_loss_supported(K, D, max_rows)
+    stats = torch.zeros(max_rows, 4).to(dev)
+    loss = torch.zeros(1).to(dev)
+    ops.head_loss_fwd(ZS, ZT, WS, WT, C_, d_m, 0.1, temp, stats, loss)
+    close(loss, ref.reshape(1), 2e-5, 2e-5, "head_loss/loss")
+    dl = torch.full((max_rows, K), 7.0, dtype=BF).to(dev)
+    ops.head_loss_bwd(ZS, ZT, WS, WT, C_, d_m, 0.1, temp, stats, 1.0, dl)
+    gmax = float(sr.grad.abs().max())
+    close(dl[:2 * M], sr.grad, 2e-2, 1e-3 * gmax, "head_loss/dlogits")
+    assert bool((dl[2 * M:] == 7.0).all()), "head_loss_bwd wrote behind row 2M"
+    # the unfused chain on the same logits (what the fused pair replaces)
+    S = torch.zeros(max_rows, K); T_ = torch.zeros(max_rows, K)
+    S[:2 * M] = s; T_[:2 * M] = t
+    st2, loss2 = torch.zeros(max_rows, 4).to(dev), torch.zeros(1).to(dev)
+    ops.dino_loss_fwd(S.to(dev), T_.to(dev), C_, d_m, 0.1, temp, st2, loss2)
+    close(loss, loss2, 2e-5, 2e-5, "head_loss/loss vs unfused")
+    dl2 = torch.zeros(max_rows, K, dtype=BF).to(dev)
+    ops.dino_loss_bwd(S.to(dev), T_.to(dev), C_, d_m, 0.1, temp, st2, 1.0, dl2)
+    close(dl[:2 * M], dl2[:2 * M], 2e-2, 1e-3 * gmax, "head_loss/dlogits vs unfused")
+    # a device-side upstream gradient and a second call into the same buffers (the workspace is reused)
+    gscale = torch.tensor([0.5]).to(dev)
+    ops.head_loss_bwd(ZS, ZT, WS, WT, C_, d_m, 0.1, temp, stats, 2.0, dl, d_grad_scale=gscale)
+    close(dl[:2 * M], sr.grad, 2e-2, 1e-3 * gmax, "head_loss/dlogits scaled")
+
+
 def check_seg_loss(dev, half=2, seed=12):
     gen = torch.Generator().manual_seed(seed)
     logits = rnd((2 * half, 2, 32, 128), gen, 2.0)

@@ -383,6 +383,79 @@ def check_small3_steps(device, loss_tol=1e-3):
     return report
 
 
+def check_no_grad_train_droppath(device, E=128, views=4):
+    """A backbone in train() mode with drop_path > 0 run under no_grad (nothing saved, DropPath masks drawn): the one-launch
+    block half cannot serve a dropped MLP branch without x_mid (CCD_EINVAL), so those blocks take the two-launch path - same
+    tokens as with the fusion switched off, same DropPath seeds."""
+    from ccd_amd import engine
+    from ccd_amd.modules import vision_transformer as vits
+    torch.manual_seed(5)
+    net = vits.VisionTransformer(patch_size=4, embed_dim=E, depth=3, num_heads=E // 64, mlp_ratio=4, qkv_bias=True, drop_path_rate=0.5,
+                                 norm_layer=lambda e: torch.nn.LayerNorm(e, eps=1e-6), out_indices=[1, 2, 3]).to(device).train()
+    net.ensure_arena()
+    img = torch.randn((views, 3, 32, 128), generator=torch.Generator().manual_seed(1)).to(device)
+    outs = []
+    saved = engine.Fusion.proj_mlp
+    try:
+        for fused in (True, False):
+            engine.Fusion.proj_mlp = fused
+            engine._DROPPATH_SEED.update(base=1234, calls=0)
+            with torch.no_grad():
+                tokens, *taps = net.tokens_and_taps(img)
+            outs.append([tokens.float().cpu()] + [t.float().cpu() for t in taps])
+    finally:
+        engine.Fusion.proj_mlp = saved
+        engine._DROPPATH_SEED.update(base=None, calls=0)
+    assert engine.Fusion.resolve_proj(E), "the embedding width must be one the fused block half takes"
+    for a, b in zip(*outs):
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) < 0.06, float((a - b).abs().max())      # bf16 LayerNorm outputs of O(1) values
+
+
+def check_head_loss_fusion_matches_unfused(device, batch=4, out_dim=512):
+    """One training iteration with the head's last product left to the loss (engine.LazyLogits -> ccd_head_loss_fwd / _bwd, the
+    default where bottleneck_dim == 256) against the same iteration with the logits materialised (CCD_FUSE_HEAD_LOSS=0's chain):
+    same losses, same centre, same update; the lazy output still hands out `instances_view` on request."""
+    from ccd_amd import engine
+    results = {}
+    saved = engine.Fusion.head_loss
+    try:
+        for fused in (True, False):
+            engine.Fusion.head_loss = fused
+            torch.manual_seed(3)
+            np.random.seed(3)
+            student, teacher = pretrain.build_networks(
+                arch=None, out_dim=out_dim, drop_path_rate=0.0, norm_last_layer=False, seg_channel=192,
+                backbone_kwargs=dict(embed_dim=192, depth=3, num_heads=3, out_indices=[1, 2, 3]),
+                head_kwargs=dict(hidden_dim=256, bottleneck_dim=256), device=device)
+            dino_loss = DINOLoss(out_dim, 2, 0.04, 0.04, 0, 40).to(device)
+            images, masks, metrics = make_batch(batch, seed=11, device=device)
+            if fused:       # the forward pass alone: the student's logits are lazy, and can still be looked at
+                s_out = student(images, metrics.float(), masks, 1, clusters=None)
+                assert isinstance(s_out.raw("logits_buf"), engine.LazyLogits)
+                view = s_out["instances_view"]
+                assert view.shape[1] == out_dim and view.shape[0] == 2 * s_out.raw("selection").M
+                engine._LAZY_LOGITS.clear()
+            opt = pretrain.make_optimizer(student, clip_grad=3.0)
+            w_init = student.arena.flat.clone()
+            loss = pretrain.training_iteration(student, teacher, dino_loss, opt, images, masks, metrics, 1, 2e-4, 0.05, 0.99)
+            if device.type == "cuda":
+                torch.cuda.synchronize()
+            results[fused] = (loss.item(), dino_loss.last_losses["Dino_loss"].item(), student.arena.grad.clone(),
+                              student.arena.flat.clone() - w_init, dino_loss.center.clone())
+            assert not engine._LAZY_LOGITS and not engine._BF16_LOGIT_GRADS, "a parked handle / gradient was left behind"
+    finally:
+        engine.Fusion.head_loss = saved
+    (l1, d1, g1, u1, c1), (l0, d0, g0, u0, c0) = results[True], results[False]
+    assert abs(l1 - l0) < 2e-5 and abs(d1 - d0) < 2e-5, (l1, l0, d1, d0)
+    assert float((c1 - c0).abs().max()) < 1e-6
+    rel_g = ((g1 - g0).double().norm() / g0.double().norm()).item()
+    assert rel_g < 2e-2, rel_g          # bf16 logit gradients, rounded once in either chain
+    rel_u = ((u1 - u0).double().norm() / u0.double().norm()).item()
+    assert rel_u < 0.1, rel_u           # (Adam's first step: +-lr where the gradient's sign is rounding noise)
+    return {"loss": [l1, l0], "dino": [d1, d0], "rel_grad": rel_g, "rel_update": rel_u}
+
+
 def check_dist_world1(device, port=29611):
     """The N > 1 path on the one GPU there is: a 1-rank `nccl` (= RCCL) group, SyncBatchNorm conversion, DataParallel with
     its bucketed asynchronous all-reduces on a dedicated process group and reserved compute units, the centre all-reduce -

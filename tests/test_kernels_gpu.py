@@ -179,6 +179,13 @@ def test_dino_loss(hip, M, K):
     kc.check_dino_loss(hip.device, M=M, K=K)
 
 
+@pytest.mark.parametrize("M,K", [(11, 4096), (48, 65536), (1650, 65536), (300, 1536)])
+def test_head_loss(hip, M, K):
+    """ccd_head_loss_fwd / _bwd: last layer + distillation loss with the logits in registers (Dino_loss.py:81-105 on
+    vision_transformer.py:326-327's product) against the oracle and against the unfused kernels; (1650, 65536) is the benchmark's size."""
+    kc.check_head_loss(hip.device, M=M, K=K, seed=M % 13)
+
+
 def test_seg_loss(hip):
     kc.check_seg_loss(hip.device, half=4)
 

@@ -170,6 +170,16 @@ def test_head_pieces_sim(sim):
     kc.check_head_pieces(sim.device)
 
 
+def test_head_loss_sim(sim, monkeypatch):
+    """headloss.h on the CPU executor: 8 workgroups (one per 'XCD'), each walking several (split, row tile) items with the weight
+    ring running across them; rows that straddle M inside a tile, a ragged last tile; 16 workgroups; one chunk and two per split."""
+    monkeypatch.setenv("CCD_SIM_CUS", "8")
+    kc.check_head_loss(sim.device, M=11, K=512)                 # 1 row tile, 8 splits of one chunk
+    kc.check_head_loss(sim.device, M=75, K=1024, seed=22)       # 2 row tiles (150 rows), 8 splits of two chunks
+    monkeypatch.setenv("CCD_SIM_CUS", "16")
+    kc.check_head_loss(sim.device, M=70, K=1536, seed=23, spare=0)    # 24 chunks: 24 splits of one chunk, 2 row tiles, 16 workgroups
+
+
 def test_dino_loss_sim(sim):
     kc.check_dino_loss(sim.device)
 

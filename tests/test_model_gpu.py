@@ -49,6 +49,19 @@ def test_distributed_path_on_one_rank(hip):
         json.dump(report, f)
 
 
+def test_no_grad_train_droppath(hip):
+    mc.check_no_grad_train_droppath(hip.device, E=384, views=8)
+
+
+def test_head_loss_fusion_matches_unfused(hip):
+    """The head's last product left to the loss (ccd_head_loss_fwd / _bwd, logits never written) against the materialised chain:
+    one iteration each at out_dim = 4096, same losses / centre / gradients."""
+    report = mc.check_head_loss_fusion_matches_unfused(hip.device, batch=8, out_dim=4096)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/head_loss_fusion.json", "w") as f:
+        json.dump(report, f)
+
+
 def test_optimizer_host_runs_ahead(hip):
     mc.check_optimizer_host_runs_ahead(hip.device)
 

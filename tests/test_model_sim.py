@@ -30,6 +30,17 @@ def test_tiny_training_iteration_rotating_gb_buffers_sim(sim, lnbwd):
         engine.Fusion.double_gb, engine.Fusion.lnbwd = saved
 
 
+def test_no_grad_train_droppath_sim(sim):
+    """train() + no_grad + drop_path > 0: blocks with a DropPath mask fall back from ccd_proj_mlp_fused."""
+    mc.check_no_grad_train_droppath(sim.device, E=128, views=2)
+
+
+def test_head_loss_fusion_matches_unfused_sim(sim, monkeypatch):
+    """ccd_head_loss_fwd / _bwd inside the training iteration (LazyLogits) against the chain it replaces, on the CPU executor."""
+    monkeypatch.setenv("CCD_SIM_CUS", "8")
+    mc.check_head_loss_fusion_matches_unfused(sim.device, batch=2)
+
+
 def test_wide_768_model_iteration_sim(sim):
     """E = 768 / 12 heads (BASELINE config #4's shape) on the CPU executor: a 3-block model of that width, one full pretraining
     iteration against the CPU oracle - the unfused GEMM path, LayerNorm kernels beyond 512 columns, 12-head attention."""
