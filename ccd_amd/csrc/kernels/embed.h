@@ -47,6 +47,35 @@ __global__ __launch_bounds__(128) void patch_embed_fwd_kernel(const float* __res
 //   patch_rows_kernel    : patches[tok, c*16 + r*4 + x] = bf16(img[view, c, 4*py + r, 4*px + x])  (im2col, K = 48)
 //   gemm_bf16_kernel<TN> : d_w[E,48] += gb^T . patches
 // thread = (token, 4 consecutive channels), blockIdx.y = slice of the views; 4 loads in flight
+// (round 6) the bf16 gradient stream needs no copy: d_pos only
+__global__ __launch_bounds__(256) void pos_grad_sum16_kernel(const bf16_t* __restrict__ g, float* __restrict__ d_pos, int views, int E,
+                                                             int views_per_slice) {
+    const int e4 = E >> 2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 256 * e4) return;
+    const int tok = i / e4, e = (i % e4) * 4;
+    const int v0 = blockIdx.y * views_per_slice;
+    const int v1 = v0 + views_per_slice < views ? v0 + views_per_slice : views;
+    const long stride = 256L * E;
+    const long base = (long)tok * E + e;
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    int v = v0;
+    for (; v + 3 < v1; v += 4) {
+        u32x2 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const u32x2*>(g + base + (v + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += f32x4v{bf_lo(x[u].x), bf_hi(x[u].x), bf_lo(x[u].y), bf_hi(x[u].y)};
+    }
+    for (; v < v1; ++v) {
+        const u32x2 x = *reinterpret_cast<const u32x2*>(g + base + v * stride);
+        acc += f32x4v{bf_lo(x.x), bf_hi(x.x), bf_lo(x.y), bf_hi(x.y)};
+    }
+    atomicAdd(d_pos + base, acc.x);
+    atomicAdd(d_pos + base + 1, acc.y);
+    atomicAdd(d_pos + base + 2, acc.z);
+    atomicAdd(d_pos + base + 3, acc.w);
+}
 __global__ __launch_bounds__(256) void pos_grad_cast_kernel(const float* __restrict__ g, float* __restrict__ d_pos,
                                                             bf16_t* __restrict__ gb, int views, int E,
                                                             int views_per_slice) {

@@ -64,10 +64,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // Optional fused tail (gb != null): gb[row,:] = bf16(g_new[row,:] * rowscale[row / rows_per_sample]) - the gradient
 // entering the NEXT residual branch with that branch's DropPath scale - and dbias += column sums of gb (the bias
 // gradient of that branch's output projection).  Saves a pass over g and a pass over gb per branch.
-template <bool ACCUM, int LN_STEPS>
+// G16 (round 6): the gradient stream g is bf16 (read, accumulated in fp32, rounded once per writer).
+template <bool ACCUM, int LN_STEPS, bool G16 = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     const float* __restrict__ gamma, float* __restrict__ g,
+                                                     const float* __restrict__ gamma, void* __restrict__ g_,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      bf16_t* __restrict__ gb, const float* __restrict__ rowscale,
                                                      int rows_per_sample, float* __restrict__ dbias, int rows, int E,
@@ -96,7 +97,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         // two wave reductions it used to wait for a second HBM round trip per row) - and has arrived before the first store
         const float* xr = x + (long)row * E;
         const bf16_t* dyr = dy + (long)row * E;
-        float* gr = g + (long)row * E;
+        float* gr = reinterpret_cast<float*>(g_) + (long)row * E;
+        bf16_t* gr16 = reinterpret_cast<bf16_t*>(g_) + (long)row * E;
         f32x4v xv[LN_STEPS], gv[LN_STEPS];
         u32x2 dw[LN_STEPS];
 #pragma unroll
@@ -106,7 +108,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             if (c < E) {
                 xv[i] = *reinterpret_cast<const f32x4v*>(xr + c);
                 dw[i] = *reinterpret_cast<const u32x2*>(dyr + c);
-                if (ACCUM) gv[i] = *reinterpret_cast<const f32x4v*>(gr + c);
+                if (ACCUM) {
+                    if constexpr (G16) {
+                        const u32x2 h = *reinterpret_cast<const u32x2*>(gr16 + c);
+                        gv[i] = f32x4v{bf_lo(h.x), bf_hi(h.x), bf_lo(h.y), bf_hi(h.y)};
+                    } else gv[i] = *reinterpret_cast<const f32x4v*>(gr + c);
+                }
             }
         }
         const float mu = mean[row], rs = rstd[row];
@@ -141,7 +148,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             if (c < E) {
                 f32x4v dx = (d[i] - s1 - xh[i] * s2) * rs;
                 if (ACCUM) dx += gv[i];
-                *reinterpret_cast<f32x4v*>(gr + c) = dx;
+                if constexpr (G16) {
+                    u32x2 h;
+                    h.x = pack_bf2(dx.x, dx.y);
+                    h.y = pack_bf2(dx.z, dx.w);
+                    *reinterpret_cast<u32x2*>(gr16 + c) = h;
+                } else *reinterpret_cast<f32x4v*>(gr + c) = dx;
                 if (gb) {
                     const f32x4v o = dx * sc;
                     u32x2 pk;

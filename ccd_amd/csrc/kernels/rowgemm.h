@@ -37,8 +37,8 @@ struct RowGemmParams {
     const float* mean;      // [M]
     const float* rstd;
     const float* gamma;     // [E]
-    float* g;               // [M, E] fp32 gradient of the residual stream (in / out)
-    long ldg;
+    void* g;                // [M, E] gradient of the residual stream (in / out): fp32, or bf16 in the G16 instantiations (round 6:
+    long ldg;               // half the bytes of the stream that every LayerNorm-backward epilogue reads and rewrites)
     int accumulate;
     float* dgamma;          // [E] +=
     float* dbeta;
@@ -132,8 +132,9 @@ __device__ __forceinline__ void rg_colsum16(const float (&v)[16], float* dst, in
     atomicAdd(dst + 8 * ((lq >> 2) & 3) + 4 * hf + (lq & 3), rg_fold16(v, lq));
 }
 
-template <int E, int R, int EPI, bool ADMA = false>
+template <int E, int R, int EPI, bool ADMA = false, bool G16 = false>
 __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p) {
+    static_assert(!G16 || EPI == RG_LNBWD, "the bf16 stream is the LayerNorm-backward epilogue's");
     constexpr int RG_NSLOT = ADMA ? 4 : rg_slots(E);
     static_assert(!ADMA || (E == 384 && R == 3), "activation DMA: 3 image slots per wave, 160 KiB of LDS at E = 384");
     constexpr int KT = E / 64;             // ring requests (1 KiB wave instructions) per wave and piece
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
     // the row-wise streams of the epilogue: (x, g, gb) for the LayerNorm backward, (resid, out, ln_y) for residual + LayerNorm
     const buf_rsrc rs_x = EPI == RG_LNBWD ? make_rsrc(p.x, (unsigned)((((long)p.M - 1) * p.ldx + E) * 4))
                                           : make_rsrc(p.resid, (unsigned)((((long)p.M - 1) * p.ldr + E) * 4));
-    const buf_rsrc rs_g = EPI == RG_LNBWD ? make_rsrc(p.g, (unsigned)((((long)p.M - 1) * p.ldg + E) * 4))
+    const buf_rsrc rs_g = EPI == RG_LNBWD ? make_rsrc(p.g, (unsigned)((((long)p.M - 1) * p.ldg + E) * (G16 ? 2 : 4)))
                                           : make_rsrc(p.out, (unsigned)((((long)p.M - 1) * p.ldc + E) * 4));
     const buf_rsrc rs_b = EPI == RG_LNBWD ? make_rsrc(p.gb, p.gb ? (unsigned)((((long)p.M - 1) * p.ld_gb + E) * 2) : 0u)
                                           : make_rsrc(p.ln_y, (unsigned)((((long)p.M - 1) * p.ld_y + E) * 2));
@@ -508,22 +509,28 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
         // Pass B: dx, g and gb per 32-column tile, leaving through the wave's scratch image as 128-byte row segments
         {
             const LaneOff lo(t);
-            const unsigned lo_gl = lo.frag(p.ldg, 4, 4), so_g = (unsigned)r0 * (unsigned)(p.ldg * 4);
-            const unsigned lo_o = lo.rows8(p.ldg, 4), lo_n = lo.rows8(p.ld_gb, 2);
+            constexpr int GB = G16 ? 2 : 4;            // bytes per element of the gradient stream
+            const unsigned lo_gl = lo.frag(p.ldg, GB, 4), so_g = (unsigned)r0 * (unsigned)(p.ldg * GB);
+            const unsigned lo_o = lo.rows8(p.ldg, GB), lo_n = lo.rows8(p.ld_gb, 2);
             constexpr int PB = 3;
-            u32x4 gbuf[PB][4];
+            u32x4 gbuf[PB][4];                         // (G16: .x / .y hold the lane's four bf16)
             auto load_xg = [&](int nt) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     gbuf[nt % PB][g] = u32x4{0u, 0u, 0u, 0u};
-                    if (p.accumulate) gbuf[nt % PB][g] = stream_load16<NT_RG_G>(rs_g, lo_gl, so_g + (32 * nt + 8 * g) * 4);
+                    if (p.accumulate) {
+                        if constexpr (G16) {
+                            const buf_u32x2 h = buf_load8(rs_g, lo_gl, so_g + (32 * nt + 8 * g) * 2);
+                            gbuf[nt % PB][g].x = h.x; gbuf[nt % PB][g].y = h.y;
+                        } else gbuf[nt % PB][g] = stream_load16<NT_RG_G>(rs_g, lo_gl, so_g + (32 * nt + 8 * g) * 4);
+                    }
                 }
             };
 #pragma unroll
             for (int nt = 0; nt < PB - 1 && nt < NT; ++nt) load_xg(nt);
 #pragma unroll
             for (int np = 0; np < NT / 2; ++np) {
-                u32x2 ypk[2][4];
+                u32x2 ypk[2][4], gpk[2][4];
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
                     const int nt = 2 * np + tt;
@@ -531,8 +538,14 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
                     float vbi[16];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const f32x4v go = __builtin_bit_cast(f32x4v, gbuf[nt % PB][g]);
-                        const float oo[4] = {go.x, go.y, go.z, go.w};
+                        float oo[4];
+                        if constexpr (G16) {
+                            oo[0] = bf_lo(gbuf[nt % PB][g].x); oo[1] = bf_hi(gbuf[nt % PB][g].x);
+                            oo[2] = bf_lo(gbuf[nt % PB][g].y); oo[3] = bf_hi(gbuf[nt % PB][g].y);
+                        } else {
+                            const f32x4v go = __builtin_bit_cast(f32x4v, gbuf[nt % PB][g]);
+                            oo[0] = go.x; oo[1] = go.y; oo[2] = go.z; oo[3] = go.w;
+                        }
                         float v[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -541,7 +554,10 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
                             const float dx = fmaf(-c2, rg_unpack_xh(pk), fmaf(rg_unpack_dg(pk), rs, -c1));
                             v[e] = oo[e] + dx;
                         }
-                        *reinterpret_cast<f32x4v*>(scratch + lo.scr_wr(2 * g + lo.hf)) = f32x4v{v[0], v[1], v[2], v[3]};
+                        if constexpr (G16) {
+                            gpk[tt][g].x = pack_bf2(v[0], v[1]);
+                            gpk[tt][g].y = pack_bf2(v[2], v[3]);
+                        } else *reinterpret_cast<f32x4v*>(scratch + lo.scr_wr(2 * g + lo.hf)) = f32x4v{v[0], v[1], v[2], v[3]};
                         if (p.gb) {
                             ypk[tt][g].x = pack_bf2(v[0] * sc, v[1] * sc);
                             ypk[tt][g].y = pack_bf2(v[2] * sc, v[3] * sc);
@@ -551,15 +567,31 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
                         }
                     }
                     if (p.gb && p.dbias) rg_colsum16(vbi, cs + 2 * E + 32 * nt, lq, hf);
+                    if constexpr (!G16) {
+                        wave_lds_fence();
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const u32x4 o = *reinterpret_cast<const u32x4*>(scratch + lo.scr_rd(i));
+                            stream_store16<NT_RG_G>(rs_g, lo_o, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldg * 4) + 128 * nt, o);
+                        }
+                        wave_lds_fence();
+                    }
+                    CCD_SCHED_FENCE();
+                    asm volatile("" ::: "memory");
+                }
+                if constexpr (G16) {       // the bf16 stream leaves like gb: two tiles = one 128-byte row segment
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<u32x2*>(scratch + lo.scr_wr(4 * tt + g) + 8 * lo.hf) = gpk[tt][g];
                     wave_lds_fence();
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const u32x4 o = *reinterpret_cast<const u32x4*>(scratch + lo.scr_rd(i));
-                        stream_store16<NT_RG_G>(rs_g, lo_o, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldg * 4) + 128 * nt, o);
+                        stream_store16<NT_RG_G>(rs_g, lo_o, (unsigned)(r0 + 8 * i) * (unsigned)(p.ldg * 2) + 128 * np, o);
                     }
                     wave_lds_fence();
-                    CCD_SCHED_FENCE();
-                    asm volatile("" ::: "memory");
                 }
                 if (p.gb) {
 #pragma unroll
@@ -592,7 +624,7 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
 #ifdef CCD_MLP_LAB
     RG_STAMP(6)
     if (t == 0)
-        for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(EPI == RG_LNBWD ? p.g : p.out)[blockIdx.x * 8 + i] = ph[i];
+        for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(EPI == RG_LNBWD ? p.g : (void*)p.out)[blockIdx.x * 8 + i] = ph[i];
 #endif
 }
 

@@ -54,6 +54,11 @@ __device__ __forceinline__ buf_u32x4 buf_load16(buf_rsrc r, unsigned byte_offset
 __device__ __forceinline__ buf_u32x4 buf_load16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_offset, (int)uniform_offset, 0);
 }
+// 8-byte form (four bf16 of a lane's row: the bf16 gradient stream of the LayerNorm-backward epilogues, round 6)
+typedef __attribute__((ext_vector_type(2))) unsigned buf_u32x2;
+__device__ __forceinline__ buf_u32x2 buf_load8(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane_offset, (int)uniform_offset, 0);
+}
 // STORE-DATA HAZARD (found in round 4 on rowgemm8.h, two waves per SIMD): a 16-byte buffer store reads its data registers a few
 // cycles AFTER it issues.  LLVM's hazard recogniser inserts the wait state only when the store has no SGPR soffset (GCNHazardRecognizer:
 // "this hazard only exists if the instruction is not using a register in the soffset field") - ours always has one, and on gfx950 a

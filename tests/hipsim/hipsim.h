@@ -245,6 +245,14 @@ inline buf_u32x4 buf_load16(buf_rsrc r, unsigned lane_offset, unsigned uniform_o
     if (o + 16ull <= (unsigned long long)r.bytes) std::memcpy(&v, r.base + o, 16);
     return v;
 }
+typedef __attribute__((ext_vector_type(2))) unsigned buf_u32x2;
+inline buf_u32x2 buf_load8(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset) {
+    sim_vmem_slot();
+    const unsigned long long o = (unsigned long long)lane_offset + uniform_offset;
+    buf_u32x2 v = {0u, 0u};
+    if (o + 8ull <= (unsigned long long)r.bytes) std::memcpy(&v, r.base + o, 8);
+    return v;
+}
 inline void bufdma16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset, char* lds_base) {
     const unsigned long long o = (unsigned long long)lane_offset + uniform_offset;
     const bool in_range = o + 16ull <= (unsigned long long)r.bytes;
