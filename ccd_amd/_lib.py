@@ -36,16 +36,19 @@ SIGNATURES = {
     "ccd_gemm_tn_pair_ws": [P, L, P, L, I, I, P, L, P, L, P, L, I, I, P, L, I, P, L, P],
     "ccd_gemm_tn_pair_ws_floats": [I, I, I, I],
     "ccd_gemm_nt_lnbwd": [P, L, P, L, I, I, I, P, L, P, P, P, P, L, I, P, P, P, L, P, I, P, P],
+    "ccd_gemm_nt_lnbwd_g16": [P, L, P, L, I, I, I, P, L, P, P, P, P, L, I, P, P, P, L, P, I, P, P],
     "ccd_proj_mlp_fused": [P, L, P, L, P, P, L, P, P, P, P, L, P, L, P, P, P, L, P, P, L, P, P, I, P, L, P, P, F, P, L, P, P, P, L, P, P, P, L,
                            I, I, I, P],
     "ccd_mlp_fused": [P, L, P, L, P, P, L, P, P, L, P, I, P, L, P, P, F, P, L, P, P, P, L, P, L, I, I, I, P],
     "ccd_ln_fwd": [P, P, P, P, P, P, I, I, F, P],
     "ccd_ln_bwd": [P, P, P, P, P, P, I, P, P, P, P, I, P, I, I, P],
+    "ccd_ln_bwd_g16": [P, P, P, P, P, P, I, P, P, P, P, I, P, I, I, P],
     "ccd_attention_fwd": [P, P, P, I, I, F, P],
     "ccd_attention_bwd": [P, P, P, P, P, P, I, I, F, P, P, P, P, L, P],
     "ccd_attention_bwd_ws_floats": [I, I],
     "ccd_patch_embed_fwd": [P, P, P, P, P, I, I, P],
     "ccd_patch_embed_bwd": [P, P, P, P, P, P, P, I, I, P],
+    "ccd_patch_embed_bwd_g16": [P, P, P, P, P, P, I, I, P],
     "ccd_small_matmul_f32": [P, P, P, I, I, I, I, I, P],
     "ccd_colsum_bf16": [P, L, I, I, P, I, P, P],
     "ccd_mirror_bf16": [P, I, I, P],

@@ -266,7 +266,7 @@ static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, float* ws, long ws_
 
 extern "C" {
 
-int ccd_abi_version(void) { return 10; }   // 10: ccd_head_loss_fwd / _bwd (last layer + distillation loss, logits never written); 9: ccd_cls_tail_fwd / _bwd_reduce / _bwd_apply (BatchNorm + ReLU + classifier conv of the segmentation head fused); 8: ccd_proj_mlp_fused (proj + residual + LayerNorm-2 in front of the fused MLP), ccd_matvec_bf16; 7: ccd_gemm_tn_pair_ws (split-K workspace instead of fp32 atomics); 6: device-side momentum / DropPath seed (HIP graph of the training step); 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
+int ccd_abi_version(void) { return 10; }   // 10: ccd_head_loss_fwd / _bwd (last layer + distillation loss, logits never written), ccd_*_g16 (bf16 residual-gradient stream); 9: ccd_cls_tail_fwd / _bwd_reduce / _bwd_apply (BatchNorm + ReLU + classifier conv of the segmentation head fused); 8: ccd_proj_mlp_fused (proj + residual + LayerNorm-2 in front of the fused MLP), ccd_matvec_bf16; 7: ccd_gemm_tn_pair_ws (split-K workspace instead of fp32 atomics); 6: device-side momentum / DropPath seed (HIP graph of the training step); 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
 const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi10"; }
 int ccd_policy_set(const char* key, int value) {
     CCD_CHECK(key, CCD_EINVAL);
@@ -381,10 +381,10 @@ int ccd_gemm_nt_resid_ln(const ccd_bf16* A, long lda, const ccd_bf16* B, long ld
     return ccd_launch_gemm_row384(p, 7 /* EPI_RESID_LN */, stream, cus);
 }
 
-int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, const float* x, long ldx,
-                      const float* mean, const float* rstd, const float* gamma, float* g, long ldg, int accumulate,
-                      float* dgamma, float* dbeta, ccd_bf16* gb, long ldgb, const float* rowscale, int rows_per_sample,
-                      float* dbias, void* stream) {
+static int ccd_gemm_nt_lnbwd_any(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, const float* x, long ldx,
+                                 const float* mean, const float* rstd, const float* gamma, void* g, int g16, long ldg, int accumulate,
+                                 float* dgamma, float* dbeta, ccd_bf16* gb, long ldgb, const float* rowscale, int rows_per_sample,
+                                 float* dbias, void* stream) {
     CCD_CHECK(A && B && x && mean && rstd && gamma && g && dgamma && dbeta, CCD_EINVAL);
     CCD_CHECK(CCD_ALIGNED16(A) && CCD_ALIGNED16(B) && CCD_ALIGNED16(x) && CCD_ALIGNED16(g) && CCD_ALIGNED16(gb), CCD_EINVAL);
     if (M == 0) return CCD_OK;
@@ -395,7 +395,7 @@ int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, 
     const int cus = ccd_grid_cus();
     if (ccd_policy().rowgemm && (N == 128 || N == 256 || N == 384 || N == 512) && K % (64 * ccd::rg_ring(N)) == 0 && ldg % 4 == 0 &&
         ((long)M + (long)cus * ccd::RG_BM) * lda * 2 < CCD_MAX_OPERAND_BYTES && (long)M * ldx * 4 < CCD_MAX_OPERAND_BYTES &&
-        (long)M * ldg * 4 < CCD_MAX_OPERAND_BYTES) {
+        (long)M * ldg * 4 < CCD_MAX_OPERAND_BYTES && (!g16 || (N <= 384 && ldg % 8 == 0))) {
         ccd::RowGemmParams q;
         q.A = A; q.lda = lda; q.W = B; q.ldw = ldb; q.M = M; q.K = K; q.x = x; q.ldx = ldx; q.mean = mean; q.rstd = rstd;
         q.gamma = gamma; q.g = g; q.ldg = ldg; q.accumulate = accumulate; q.dgamma = dgamma; q.dbeta = dbeta; q.gb = gb;
@@ -405,6 +405,14 @@ int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, 
         q.ldr = q.ldc = q.ld_y = 0; q.ln_eps = 0.f;
         const int tiles = (M + ccd::RG_BM - 1) / ccd::RG_BM, smem = ccd::rg_smem_bytes(N);
         const dim3 grid(tiles < cus ? tiles : cus), block(ccd::RG_THREADS);
+        if (g16) {             // round 6: the residual-gradient stream in bf16
+            if (N == 384 && ccd_policy().rowgemm_adma)
+                CCD_LAUNCH((ccd::rowgemm_kernel<384, 3, ccd::RG_LNBWD, true, true>), grid, block, ccd::rg_smem_bytes_adma(384), stream, q);
+            else if (N == 384) CCD_LAUNCH((ccd::rowgemm_kernel<384, ccd::rg_ring(384), ccd::RG_LNBWD, false, true>), grid, block, smem, stream, q);
+            else if (N == 256) CCD_LAUNCH((ccd::rowgemm_kernel<256, ccd::rg_ring(256), ccd::RG_LNBWD, false, true>), grid, block, smem, stream, q);
+            else CCD_LAUNCH((ccd::rowgemm_kernel<128, ccd::rg_ring(128), ccd::RG_LNBWD, false, true>), grid, block, smem, stream, q);
+            return ccd_rt_last_error();
+        }
         if (N == 512) CCD_LAUNCH((ccd::rowgemm_kernel<512, ccd::rg_ring(512), ccd::RG_LNBWD>), grid, block, smem, stream, q);
         else if (N == 384 && ccd_policy().rowgemm_adma)   // round 4: the activation rows by LDS-DMA too
             CCD_LAUNCH((ccd::rowgemm_kernel<384, 3, ccd::RG_LNBWD, true>), grid, block, ccd::rg_smem_bytes_adma(384), stream, q);
@@ -413,7 +421,7 @@ int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, 
         else CCD_LAUNCH((ccd::rowgemm_kernel<128, ccd::rg_ring(128), ccd::RG_LNBWD>), grid, block, smem, stream, q);
         return ccd_rt_last_error();
     }
-    CCD_CHECK(N <= ccd::GR_BN, CCD_ESHAPE);
+    CCD_CHECK(N <= ccd::GR_BN && !g16, CCD_ESHAPE);       // (the bf16 stream exists in the row-owner kernels only)
     ccd::GemmParams p = ccd::GemmParams();
     p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.C = g; p.ldc = ldg; p.resid = x; p.ldr = ldx;
     p.rowscale = gb ? rowscale : nullptr; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; p.alpha = 1.0f;
@@ -423,6 +431,20 @@ int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, 
     p.ln_gamma = gamma; p.ln_mean = const_cast<float*>(mean); p.ln_rstd = const_cast<float*>(rstd);
     p.lnb_accumulate = accumulate; p.lnb_gb = gb; p.ld_gb = ldgb; p.lnb_dgamma = dgamma; p.lnb_dbeta = dbeta; p.lnb_dbias = dbias;
     return ccd_launch_gemm_row384(p, 8 /* EPI_LNBWD */, stream, cus);
+}
+int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, const float* x, long ldx,
+                      const float* mean, const float* rstd, const float* gamma, float* g, long ldg, int accumulate,
+                      float* dgamma, float* dbeta, ccd_bf16* gb, long ldgb, const float* rowscale, int rows_per_sample,
+                      float* dbias, void* stream) {
+    return ccd_gemm_nt_lnbwd_any(A, lda, B, ldb, M, N, K, x, ldx, mean, rstd, gamma, g, 0, ldg, accumulate, dgamma, dbeta, gb, ldgb, rowscale,
+                                 rows_per_sample, dbias, stream);
+}
+int ccd_gemm_nt_lnbwd_g16(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, const float* x, long ldx,
+                          const float* mean, const float* rstd, const float* gamma, ccd_bf16* g, long ldg, int accumulate,
+                          float* dgamma, float* dbeta, ccd_bf16* gb, long ldgb, const float* rowscale, int rows_per_sample,
+                          float* dbias, void* stream) {
+    return ccd_gemm_nt_lnbwd_any(A, lda, B, ldb, M, N, K, x, ldx, mean, rstd, gamma, g, 1, ldg, accumulate, dgamma, dbeta, gb, ldgb, rowscale,
+                                 rows_per_sample, dbias, stream);
 }
 
 int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, const float* b1, const ccd_bf16* w2, long ld2,
@@ -631,9 +653,9 @@ int ccd_ln_fwd(const float* x, const float* gamma, const float* beta, ccd_bf16* 
     return ccd_rt_last_error();
 }
 
-int ccd_ln_bwd(const ccd_bf16* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* g,
-               int accumulate, float* dgamma, float* dbeta, ccd_bf16* gb, const float* rowscale, int rows_per_sample,
-               float* dbias, int rows, int E, void* stream) {
+static int ccd_ln_bwd_any(const ccd_bf16* dy, const float* x, const float* mean, const float* rstd, const float* gamma, void* g, int g16,
+                          int accumulate, float* dgamma, float* dbeta, ccd_bf16* gb, const float* rowscale, int rows_per_sample,
+                          float* dbias, int rows, int E, void* stream) {
     CCD_CHECK(dy && x && mean && rstd && gamma && g && dgamma && dbeta, CCD_EINVAL);
     if (rows == 0) return CCD_OK;
     CCD_CHECK(rows > 0 && E > 0 && E % 4 == 0 && E <= 1024, CCD_ESHAPE);
@@ -642,12 +664,25 @@ int ccd_ln_bwd(const ccd_bf16* dy, const float* x, const float* mean, const floa
     int rpb = (rows + blocks - 1) / blocks;
     rpb = ((rpb + 3) / 4) * 4;
     blocks = (rows + rpb - 1) / rpb;
-#define CCD_LN_BWD(ACC, ST) CCD_LAUNCH((ccd::ln_bwd_kernel<ACC, ST>), dim3(blocks), dim3(256), 0, stream, dy, x, mean, rstd, gamma, g, \
-                                       dgamma, dbeta, gb, rowscale, rows_per_sample, dbias, rows, E, rpb)
-    if (ccd::ln_steps(E) == 2) { if (accumulate) CCD_LN_BWD(true, 2); else CCD_LN_BWD(false, 2); }
-    else { if (accumulate) CCD_LN_BWD(true, 4); else CCD_LN_BWD(false, 4); }
+#define CCD_LN_BWD(ACC, ST, G16) CCD_LAUNCH((ccd::ln_bwd_kernel<ACC, ST, G16>), dim3(blocks), dim3(256), 0, stream, dy, x, mean, rstd, gamma, g, \
+                                            dgamma, dbeta, gb, rowscale, rows_per_sample, dbias, rows, E, rpb)
+    if (g16) {
+        if (ccd::ln_steps(E) == 2) { if (accumulate) CCD_LN_BWD(true, 2, true); else CCD_LN_BWD(false, 2, true); }
+        else { if (accumulate) CCD_LN_BWD(true, 4, true); else CCD_LN_BWD(false, 4, true); }
+    } else if (ccd::ln_steps(E) == 2) { if (accumulate) CCD_LN_BWD(true, 2, false); else CCD_LN_BWD(false, 2, false); }
+    else { if (accumulate) CCD_LN_BWD(true, 4, false); else CCD_LN_BWD(false, 4, false); }
 #undef CCD_LN_BWD
     return ccd_rt_last_error();
+}
+int ccd_ln_bwd(const ccd_bf16* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* g,
+               int accumulate, float* dgamma, float* dbeta, ccd_bf16* gb, const float* rowscale, int rows_per_sample,
+               float* dbias, int rows, int E, void* stream) {
+    return ccd_ln_bwd_any(dy, x, mean, rstd, gamma, g, 0, accumulate, dgamma, dbeta, gb, rowscale, rows_per_sample, dbias, rows, E, stream);
+}
+int ccd_ln_bwd_g16(const ccd_bf16* dy, const float* x, const float* mean, const float* rstd, const float* gamma, ccd_bf16* g,
+                   int accumulate, float* dgamma, float* dbeta, ccd_bf16* gb, const float* rowscale, int rows_per_sample,
+                   float* dbias, int rows, int E, void* stream) {
+    return ccd_ln_bwd_any(dy, x, mean, rstd, gamma, g, 1, accumulate, dgamma, dbeta, gb, rowscale, rows_per_sample, dbias, rows, E, stream);
 }
 
 // ------------------------------------------------------------------------------------------ attention
@@ -711,8 +746,9 @@ int ccd_patch_embed_fwd(const float* img, const float* w, const float* bias, con
     CCD_LAUNCH(ccd::patch_embed_fwd_kernel, dim3(views * ccd::PE_GH), dim3(128), 0, stream, img, w, bias, pos, out, E);
     return ccd_rt_last_error();
 }
-int ccd_patch_embed_bwd(const float* img, const float* g, float* d_w, float* d_bias, float* d_pos, ccd_bf16* ws_g,
-                        ccd_bf16* ws_patches, int views, int E, void* stream) {
+static int ccd_patch_embed_bwd_any(const float* img, const void* g, int g16, float* d_w, float* d_bias, float* d_pos, ccd_bf16* ws_g,
+                                   ccd_bf16* ws_patches, int views, int E, void* stream) {
+    if (g16) ws_g = const_cast<ccd_bf16*>(reinterpret_cast<const ccd_bf16*>(g));       // the stream IS the bf16 operand: no copy
     CCD_CHECK(img && g && d_w && d_bias && d_pos && ws_g && ws_patches, CCD_EINVAL);
     CCD_CHECK(CCD_ALIGNED16(g) && CCD_ALIGNED16(img) && CCD_ALIGNED16(ws_g) && CCD_ALIGNED16(ws_patches), CCD_EINVAL);
     if (views == 0) return CCD_OK;
@@ -722,8 +758,9 @@ int ccd_patch_embed_bwd(const float* img, const float* g, float* d_w, float* d_b
     if (slices > views) slices = views;
     const int vps = (views + slices - 1) / slices;
     slices = (views + vps - 1) / vps;
-    CCD_LAUNCH(ccd::pos_grad_cast_kernel, dim3((threads + 255) / 256, slices), dim3(256), 0, stream, g, d_pos, ws_g, views,
-               E, vps);
+    if (g16) CCD_LAUNCH(ccd::pos_grad_sum16_kernel, dim3((threads + 255) / 256, slices), dim3(256), 0, stream, (const ccd::bf16_t*)g, d_pos, views, E, vps);
+    else CCD_LAUNCH(ccd::pos_grad_cast_kernel, dim3((threads + 255) / 256, slices), dim3(256), 0, stream, (const float*)g, d_pos, ws_g, views,
+                    E, vps);
     int rc = ccd_rt_last_error();
     if (rc != CCD_OK) return rc;
     const long tokens = 256L * views;
@@ -736,6 +773,14 @@ int ccd_patch_embed_bwd(const float* img, const float* g, float* d_w, float* d_b
     if (rc != CCD_OK) return rc;
     return ccd_gemm_tn(ws_g, E, ws_patches, ccd::PE_K, E, ccd::PE_K, (int)tokens, CCD_EPI_ATOMIC, d_w, ccd::PE_K, 1.0f, 0,
                        nullptr, 1, stream);
+}
+int ccd_patch_embed_bwd(const float* img, const float* g, float* d_w, float* d_bias, float* d_pos, ccd_bf16* ws_g,
+                        ccd_bf16* ws_patches, int views, int E, void* stream) {
+    return ccd_patch_embed_bwd_any(img, g, 0, d_w, d_bias, d_pos, ws_g, ws_patches, views, E, stream);
+}
+int ccd_patch_embed_bwd_g16(const float* img, const ccd_bf16* g, float* d_w, float* d_bias, float* d_pos, ccd_bf16* ws_patches, int views,
+                            int E, void* stream) {
+    return ccd_patch_embed_bwd_any(img, g, 1, d_w, d_bias, d_pos, nullptr, ws_patches, views, E, stream);
 }
 int ccd_small_matmul_f32(const float* A, const float* B, float* C, int M, int N, int K, int trans_a, int accumulate,
                          void* stream) {

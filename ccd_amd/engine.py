@@ -52,6 +52,7 @@ class Fusion:
     head_loss = _env_switch("CCD_FUSE_HEAD_LOSS")  # last layer + distillation loss in one pass, logits never written (default: on where ccd_head_loss_* take the shape)
     if head_loss is None:
         head_loss = True
+    g_bf16 = _env_switch("CCD_G_BF16")             # the backward pass's residual-gradient stream in bf16 (round 6; None = the measured default)
     side_stream = bool(_env_switch("CCD_SIDE_STREAM"))
     double_gb = False                       # tests: rotate the two gb buffers of the side-stream mode also without a side stream
 
@@ -63,10 +64,19 @@ class Fusion:
         return ln, mlp, lnbwd
 
     @classmethod
+    def resolve_g16(cls, E):
+        """The gradient of the residual stream as a bf16 tensor between the LayerNorm-backward epilogues (ccd_*_g16): each of the 24
+        epilogues of a ViT-Small backward pass reads and rewrites it (9.6 GB per step in fp32).  Row-owner widths only."""
+        on = cls.g_bf16 if cls.g_bf16 is not None else G_BF16_DEFAULT
+        return bool(on) and cls.resolve(E)[2] and E in (128, 256, 384)
+
+    @classmethod
     def resolve_proj(cls, E):
         """ccd_proj_mlp_fused (round 5) replaces ccd_gemm_nt_resid_ln + ccd_mlp_fused where both would run (it cannot store gelu(u))."""
         return cls.resolve(E)[1] and E <= 384 and not cls.store_gact and (cls.proj_mlp if cls.proj_mlp is not None else True)
 
+
+G_BF16_DEFAULT = True         # measured: 46.43 against 46.86 ms per step, every 1e-3 parity gate green (profiles/r06_g_bf16_*)
 
 _DROPPATH_SEED = {"base": None, "calls": 0, "device": None}
 DROPPATH_SEED_STRIDE = 0x632BE59BD9B4E019
@@ -300,7 +310,7 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
     E, N = spec.E, img.shape[0]
     R = N * 256
     dev = img.device
-    g = torch.empty((R, E), dtype=F32, device=dev)
+    g = torch.empty((R, E), dtype=BF16 if Fusion.resolve_g16(E) else F32, device=dev)
     tap_at = {i: (j, x, m, r) for j, (i, x, m, r) in enumerate(tap_ctx) if d_taps[j] is not None}
     scale = (E // spec.heads) ** -0.5
     top = spec.depth - 1
@@ -347,7 +357,7 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
             have_gb = True
         if not have_gb:          # only when no gradient reached the final norm: plain cast + column sum
             gbw = gb_write()
-            ops.scale_cast_rows(g, gbw, c.ds2, 256)
+            ops.scale_cast_rows(g if g.dtype == F32 else g.float(), gbw, c.ds2, 256)
             ops.colsum_bf16(gbw, arena.g(b + "mlp.fc2.bias"))
         # ---- MLP branch: x_out = x_mid + ds2 * fc2(gelu(fc1(LN2(x_mid))))
         gact, y2, att, y1 = c.gact, c.y2, c.att, c.y1

@@ -158,15 +158,17 @@ def gemm_nt_lnbwd(a, b, x, mean, rstd, gamma, g, dgamma, dbeta, accumulate=True,
                   dbias=None):
     """dy = a @ b^T is the gradient of a LayerNorm output: g (+)= LN'(dy) with dgamma / dbeta (+ the bf16 tail of ln_bwd) in
     the epilogue of the product - dy never reaches HBM (ccd_gemm_nt + ccd_ln_bwd in one launch; N <= 384 or N = 512)."""
-    _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(x, F32, "x"); _chk(g, F32, "g"); _chk(gb, BF16, "gb")
+    g16 = g.dtype == BF16           # (round 6) the residual-gradient stream in bf16: ccd_gemm_nt_lnbwd_g16
+    _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(x, F32, "x"); _chk(g, BF16 if g16 else F32, "g"); _chk(gb, BF16, "gb")
     M, K = a.shape
     N = b.shape[0]
     assert b.shape[1] == K and tuple(x.shape) == (M, N) and tuple(g.shape) == (M, N) and N <= 512
-    span = TIMER.span("gemm_nt_lnbwd", 2.0 * M * N * K, 2.0 * (M * K + N * K) + M * N * (12.0 if accumulate else 8.0)
+    gbytes = 2.0 if g16 else 4.0
+    span = TIMER.span("gemm_nt_lnbwd", 2.0 * M * N * K, 2.0 * (M * K + N * K) + M * N * (4.0 + (2 * gbytes if accumulate else gbytes))
                       + (2.0 * M * N if gb is not None else 0.0)) if TIMER is not None else None
     if span:
         span[0].record()
-    _call("ccd_gemm_nt_lnbwd", _lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0), M, N, K, _lib.ptr(x), x.stride(0),
+    _call("ccd_gemm_nt_lnbwd_g16" if g16 else "ccd_gemm_nt_lnbwd", _lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0), M, N, K, _lib.ptr(x), x.stride(0),
           _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(g), g.stride(0), 1 if accumulate else 0, _lib.ptr(dgamma),
           _lib.ptr(dbeta), _lib.ptr(gb), 0 if gb is None else gb.stride(0), _lib.ptr(rowscale), int(rows_per_sample),
           _lib.ptr(dbias))
@@ -352,10 +354,13 @@ def ln_fwd(x, gamma, beta, eps=1e-6):
 def ln_bwd(dy, x, mean, rstd, gamma, g, dgamma, dbeta, accumulate=True, gb=None, rowscale=None, rows_per_sample=1,
            dbias=None):
     """g (+)= LN'(dy); dgamma += , dbeta += (in place).  Optional fused tail: gb = bf16(g * rowscale), dbias += colsum(gb)."""
-    _chk(dy, BF16, "dy"); _chk(x, F32, "x"); _chk(g, F32, "g"); _chk(gb, BF16, "gb")
+    g16 = g.dtype == BF16
+    _chk(dy, BF16, "dy"); _chk(x, F32, "x"); _chk(g, BF16 if g16 else F32, "g"); _chk(gb, BF16, "gb")
     rows, E = x.shape
-    with _Span("layernorm_bwd", 16.0 * rows * E, rows * E * ((14.0 if accumulate else 10.0) + (2.0 if gb is not None else 0.0))):
-        _lib.check(_lib.get().ccd_ln_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma),
+    fn = _lib.get().ccd_ln_bwd_g16 if g16 else _lib.get().ccd_ln_bwd
+    gbytes = 2.0 if g16 else 4.0
+    with _Span("layernorm_bwd", 16.0 * rows * E, rows * E * (6.0 + (2 * gbytes if accumulate else gbytes) + (2.0 if gb is not None else 0.0))):
+        _lib.check(fn(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma),
                                          _lib.ptr(g), 1 if accumulate else 0, _lib.ptr(dgamma), _lib.ptr(dbeta),
                                          _lib.ptr(gb), _lib.ptr(rowscale), int(rows_per_sample), _lib.ptr(dbias), rows, E,
                                          _lib.stream()), "ln_bwd")
@@ -420,9 +425,12 @@ def patch_embed_fwd(img, w, bias, pos, out=None):
 
 def patch_embed_bwd(img, g, d_w, d_bias, d_pos):
     views, E = img.shape[0], g.shape[-1]
-    assert img.dtype == F32 and img.is_contiguous() and g.dtype == F32 and g.is_contiguous()
-    ws_g = torch.empty((views * 256, E), dtype=BF16, device=g.device)
+    assert img.dtype == F32 and img.is_contiguous() and g.dtype in (F32, BF16) and g.is_contiguous()
     ws_p = torch.empty((views * 256, 48), dtype=BF16, device=g.device)
+    if g.dtype == BF16:
+        _call("ccd_patch_embed_bwd_g16", _lib.ptr(img), _lib.ptr(g), _lib.ptr(d_w), _lib.ptr(d_bias), _lib.ptr(d_pos), _lib.ptr(ws_p), views, E)
+        return
+    ws_g = torch.empty((views * 256, E), dtype=BF16, device=g.device)
     _call("ccd_patch_embed_bwd", _lib.ptr(img), _lib.ptr(g), _lib.ptr(d_w), _lib.ptr(d_bias), _lib.ptr(d_pos),
           _lib.ptr(ws_g), _lib.ptr(ws_p), views, E)
 
@@ -647,7 +655,7 @@ def head_loss_fwd(zs, zt, ws, wt, center, d_m, student_temp, teacher_temp, stats
     K = ws.shape[0]
     assert zt.shape == zs.shape and wt.shape == ws.shape and ws.shape[1] == D and stats.shape == (max_rows, 4)
     part = _head_loss_ws(zs.device, _lib.get().ccd_head_loss_ws_floats(max_rows, K))
-    with _Span("head_loss_fwd", 4.0 * max_rows * K * D, 4.0 * K * D):
+    with _Span("head_loss_fwd", 0.0, 4.0 * K * D):          # (the live row count 2M is device-side: no flop figure)
         _call("ccd_head_loss_fwd", _lib.ptr(zs), zs.stride(0), _lib.ptr(zt), zt.stride(0), _lib.ptr(ws), ws.stride(0), _lib.ptr(wt),
               wt.stride(0), _lib.ptr(center), K, D, _lib.ptr(d_m), max_rows, float(student_temp), float(teacher_temp), _lib.ptr(part),
               _lib.ptr(stats), _lib.ptr(loss_out))
@@ -659,7 +667,7 @@ def head_loss_bwd(zs, zt, ws, wt, center, d_m, student_temp, teacher_temp, stats
     max_rows, D = zs.shape
     K = ws.shape[0]
     assert d_logits.shape == (max_rows, K)
-    with _Span("head_loss_bwd", 4.0 * max_rows * K * D, 4.0 * K * D + 2.0 * max_rows * K):
+    with _Span("head_loss_bwd", 0.0, 4.0 * K * D):
         _call("ccd_head_loss_bwd", _lib.ptr(zs), zs.stride(0), _lib.ptr(zt), zt.stride(0), _lib.ptr(ws), ws.stride(0), _lib.ptr(wt),
               wt.stride(0), _lib.ptr(center), K, D, _lib.ptr(d_m), max_rows, float(student_temp), float(teacher_temp), _lib.ptr(stats),
               float(grad_scale), _lib.ptr(d_grad_scale), _lib.ptr(d_logits), d_logits.stride(0))

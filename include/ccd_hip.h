@@ -88,6 +88,13 @@ int ccd_gemm_nt_lnbwd(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, 
                       const float* mean, const float* rstd, const float* gamma, float* g, long ldg, int accumulate,
                       float* dgamma, float* dbeta, ccd_bf16* gb, long ldgb, const float* rowscale, int rows_per_sample,
                       float* dbias, void* stream);
+/* The same with the residual-gradient stream g in bf16 (ABI 10; N in {128, 256, 384} - CCD_ESHAPE otherwise): g is read as bf16,
+ * accumulated in fp32 and rounded once per writer - half the bytes of the stream that every LayerNorm backward of a transformer
+ * block reads and rewrites (the reference keeps that gradient in fp32 under autocast; gated by the parity tests). */
+int ccd_gemm_nt_lnbwd_g16(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, const float* x, long ldx,
+                          const float* mean, const float* rstd, const float* gamma, ccd_bf16* g, long ldg, int accumulate,
+                          float* dgamma, float* dbeta, ccd_bf16* gb, long ldgb, const float* rowscale, int rows_per_sample,
+                          float* dbias, void* stream);
 /* The whole MLP branch of a transformer block in one launch (Mlp.forward + the residual of Block.forward,
  * Dino/modules/vision_transformer.py:59-65,107-113, and the LayerNorm that consumes the stream next, :99/:156):
  *   h = gelu(bf16(y . W1^T + b1)) ;  out (f32) = resid + (h . W2^T + b2) * rowscale[row / rows_per_sample]
@@ -162,6 +169,10 @@ int ccd_ln_bwd(const ccd_bf16* dy, const float* x, const float* mean, const floa
                float* g, int accumulate, float* dgamma, float* dbeta, ccd_bf16* gb, const float* rowscale,
                int rows_per_sample, float* dbias, int rows, int E, void* stream);
 
+int ccd_ln_bwd_g16(const ccd_bf16* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                   ccd_bf16* g /* bf16 stream, see ccd_gemm_nt_lnbwd_g16 */, int accumulate, float* dgamma, float* dbeta, ccd_bf16* gb,
+                   const float* rowscale, int rows_per_sample, float* dbias, int rows, int E, void* stream);
+
 /* ---------------------------------------------------------------- attention, vit.py:80-92 (T = 256, head_dim = 64)
  * qkv [views, 256, 3, heads, 64] bf16 (the layout Attention.forward reshapes to), out [views, 256, heads*64]  */
 int ccd_attention_fwd(const ccd_bf16* qkv, ccd_bf16* out, float* lse, int views, int heads, float scale,
@@ -190,6 +201,9 @@ int ccd_patch_embed_fwd(const float* img, const float* w, const float* bias, con
  * d_w = bf16(g)^T . bf16(patches) on the MFMA path (TN GEMM), d_bias = column sums of bf16(g). */
 int ccd_patch_embed_bwd(const float* img, const float* g, float* d_w, float* d_bias, float* d_pos, ccd_bf16* ws_g,
                         ccd_bf16* ws_patches, int views, int E, void* stream);
+/* the same on a bf16 stream g: it is the TN product's operand as it lies (no ws_g) */
+int ccd_patch_embed_bwd_g16(const float* img, const ccd_bf16* g, float* d_w, float* d_bias, float* d_pos, ccd_bf16* ws_patches, int views,
+                            int E, void* stream);
 /* C[M,N] (+)= op(A) . B, fp32, tiny problems (bicubic pos-embed resampling = fixed 256x256 linear map, vit.py:182-201) */
 int ccd_small_matmul_f32(const float* A, const float* B, float* C, int M, int N, int K, int trans_a, int accumulate,
                          void* stream);

@@ -173,7 +173,7 @@ def check_gemm_tn_pair(dev, Mc, shape1, shape2, seed=5):
             assert torch.equal(again[0], outs[0]) and torch.equal(again[1], outs[1]), "tn_pair with a workspace is not deterministic"
 
 
-def check_layernorm(dev, rows, E, seed=2):
+def check_layernorm(dev, rows, E, seed=2, g16=False):
     g = torch.Generator().manual_seed(seed)
     x = rnd((rows, E), g) * 2 + 0.3
     gamma = 1 + 0.1 * rnd((E,), g); beta = 0.1 * rnd((E,), g)
@@ -185,17 +185,19 @@ def check_layernorm(dev, rows, E, seed=2):
     xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
     F.layer_norm(xr, (E,), gr, br, 1e-6).backward(dy.float())
     g0 = rnd((rows, E), g)
+    if g16:                      # the gradient stream as a bf16 tensor (ccd_ln_bwd_g16)
+        g0 = g0.to(BF).float()
     rows_per_sample = 4
     rowscale = (torch.rand((rows + rows_per_sample - 1) // rows_per_sample, generator=g) > 0.3).float() * 1.25
     for acc in (True, False):
         for fused in (False, True):
-            gbuf = g0.clone().to(dev)
+            gbuf = (g0.to(BF) if g16 else g0.clone()).to(dev)
             dgam = torch.zeros(E).to(dev); dbet = torch.zeros(E).to(dev)
             gb = torch.zeros(rows, E, dtype=BF).to(dev); dbias = torch.full((E,), 0.25).to(dev)
             kw = dict(gb=gb, rowscale=rowscale.to(dev), rows_per_sample=rows_per_sample, dbias=dbias) if fused else {}
             ops.ln_bwd(dy.to(dev), x.to(dev), mean, rstd, gamma.to(dev), gbuf, dgam, dbet, accumulate=acc, **kw)
             want_g = xr.grad + (g0 if acc else 0)
-            close(gbuf, want_g, 1e-3, 1e-4, f"ln/dx acc={acc}")
+            close(gbuf, want_g, 1e-2 if g16 else 1e-3, 1e-3 if g16 else 1e-4, f"ln/dx acc={acc}")
             close(dgam, gr.grad, 1e-3, 1e-3, "ln/dgamma")
             close(dbet, br.grad, 1e-3, 1e-3, "ln/dbeta")
             if fused:
@@ -664,6 +666,12 @@ def check_patch_embed(dev, views=3, E=192, seed=8):
     close(dw.reshape(E, 3, 4, 4), w.grad, 1e-2, tol, "pe/dw")
     close(db, b.grad, 1e-2, tol, "pe/db")
     close(dp, pos.grad, 1e-3, 1e-4, "pe/dpos")
+    # the same from a bf16 gradient stream (ccd_patch_embed_bwd_g16: the stream is the product's operand as it lies)
+    dw, db, dp = torch.zeros(E, 48).to(dev), torch.zeros(E).to(dev), torch.zeros(256, E).to(dev)
+    ops.patch_embed_bwd(img.to(dev), gr.reshape(-1, E).to(BF).to(dev), dw, db, dp)
+    close(dw.reshape(E, 3, 4, 4), w.grad, 1e-2, tol, "pe16/dw")
+    close(db, b.grad, 1e-2, tol, "pe16/db")
+    close(dp, gr.to(BF).float().sum(0), 1e-3, 1e-3, "pe16/dpos")
 
 
 def check_small_ops(dev, seed=9):
@@ -1330,8 +1338,9 @@ def check_matvec_bf16(dev, K=1000, D=256, seed=51):
     close(cs, logits.sum(0), 1e-4, 1e-4, "column sums of zn @ w^T through the factors")
 
 
-def check_gemm_lnbwd(dev, M, N, K, seed=33):
-    """Data-gradient product with the LayerNorm backward in its epilogue == gemm_nt followed by ln_bwd, and both == autograd."""
+def check_gemm_lnbwd(dev, M, N, K, seed=33, g16=False):
+    """Data-gradient product with the LayerNorm backward in its epilogue == gemm_nt followed by ln_bwd, and both == autograd.
+    g16: the gradient stream g is a bf16 tensor (ccd_gemm_nt_lnbwd_g16) - read as bf16, accumulated in fp32, rounded once."""
     g = torch.Generator().manual_seed(seed)
     a = rnd((M, K), g).to(BF); b = rnd((N, K), g, 0.2).to(BF)
     x = rnd((M, N), g) * 2 + 0.3
@@ -1339,6 +1348,8 @@ def check_gemm_lnbwd(dev, M, N, K, seed=33):
     mean, var = x.mean(1), x.var(1, unbiased=False)
     rstd = (var + 1e-6).rsqrt()
     g0 = rnd((M, N), g)
+    if g16:
+        g0 = g0.to(BF).float()
     rps = 16
     rowscale = (torch.rand((M + rps - 1) // rps, generator=g) > 0.3).float() * 1.25
     dy = a.float() @ b.float().t()
@@ -1347,7 +1358,7 @@ def check_gemm_lnbwd(dev, M, N, K, seed=33):
     scale_dy = float(dy.pow(2).mean().sqrt())
     for acc in (True, False):
         for tail in (True, False):
-            gbuf = g0.clone().to(dev)
+            gbuf = (g0.to(BF) if g16 else g0.clone()).to(dev)
             dgam = torch.full((N,), 0.5).to(dev); dbet = torch.full((N,), -0.25).to(dev)
             gb = torch.zeros(M, N, dtype=BF).to(dev) if tail else None
             dbias = torch.full((N,), 0.25).to(dev)
@@ -1356,7 +1367,7 @@ def check_gemm_lnbwd(dev, M, N, K, seed=33):
                               dbias=dbias if tail else None)
             want_g = xr.grad + (g0 if acc else 0)
             tag = f"lnbwd acc={acc} tail={tail}"
-            close(gbuf, want_g, 2e-3, 2e-3 * scale_dy, tag + "/g")
+            close(gbuf, want_g, 1e-2 if g16 else 2e-3, 2e-3 * scale_dy, tag + "/g")
             close(dgam, gr.grad + 0.5, 2e-3, 2e-3 * scale_dy * M ** 0.5, tag + "/dgamma")
             close(dbet, br.grad - 0.25, 2e-3, 2e-3 * scale_dy * M ** 0.5, tag + "/dbeta")
             if tail:

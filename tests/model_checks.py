@@ -383,6 +383,47 @@ def check_small3_steps(device, loss_tol=1e-3):
     return report
 
 
+def check_g_bf16_matches_fp32(device, E=128, batch=2, drop_path=0.3):
+    """The backward pass with its residual-gradient stream as a bf16 tensor (engine.Fusion.g_bf16, ccd_*_g16) against the fp32
+    stream: the forward pass and the losses are the same computation, every gradient tensor agrees to bf16 rounding of ONE stream
+    (relative L2 error of the whole gradient arena, and of the tensors at the far end of the stream - the patch embedding)."""
+    from ccd_amd import engine
+    results = {}
+    saved = engine.Fusion.g_bf16
+    try:
+        for g16 in (False, True):
+            engine.Fusion.g_bf16 = g16
+            torch.manual_seed(3)
+            np.random.seed(3)
+            engine._DROPPATH_SEED.update(base=77, calls=0)
+            student, teacher = pretrain.build_networks(
+                arch=None, out_dim=512, drop_path_rate=drop_path, norm_last_layer=False, seg_channel=E,
+                backbone_kwargs=dict(embed_dim=E, depth=3, num_heads=E // 64, out_indices=[1, 2, 3]),
+                head_kwargs=dict(hidden_dim=256, bottleneck_dim=64), device=device)
+            assert engine.Fusion.resolve_g16(E) == g16
+            dino_loss = DINOLoss(512, 2, 0.04, 0.04, 0, 40).to(device)
+            images, masks, metrics = make_batch(batch, seed=11, device=device)
+            opt = pretrain.make_optimizer(student, clip_grad=3.0)
+            loss = pretrain.training_iteration(student, teacher, dino_loss, opt, images, masks, metrics, 1, 2e-4, 0.05, 0.99)
+            if device.type == "cuda":
+                torch.cuda.synchronize()
+            grads = {n: student.arena.g(n).clone() for n in ("backbone.patch_embed.proj.weight", "backbone.pos_embed",
+                                                             "backbone.blocks.0.attn.qkv.weight", "backbone.blocks.2.mlp.fc1.weight")}
+            results[g16] = (loss.item(), student.arena.grad.clone(), grads)
+    finally:
+        engine.Fusion.g_bf16 = saved
+        engine._DROPPATH_SEED.update(base=None, calls=0)
+    (l0, g0, t0), (l1, g1, t1) = results[False], results[True]
+    assert abs(l0 - l1) < 1e-6, (l0, l1)
+    report = {"loss": [l0, l1], "rel_grad_all": ((g1 - g0).double().norm() / g0.double().norm()).item()}
+    assert report["rel_grad_all"] < 1e-2, report
+    for n in t0:
+        rel = ((t1[n] - t0[n]).double().norm() / t0[n].double().norm().clamp_min(1e-30)).item()
+        report["rel_" + n] = rel
+        assert rel < 2e-2, (n, rel)
+    return report
+
+
 def check_no_grad_train_droppath(device, E=128, views=4):
     """A backbone in train() mode with drop_path > 0 run under no_grad (nothing saved, DropPath masks drawn): the one-launch
     block half cannot serve a dropped MLP branch without x_mid (CCD_EINVAL), so those blocks take the two-launch path - same

@@ -113,6 +113,7 @@ def test_rowproj_is_the_default_for_the_vit_projections(hip):
 @pytest.mark.parametrize("rows,E", [(37, 192), (4096, 384), (1001, 512)])
 def test_layernorm(hip, rows, E):
     kc.check_layernorm(hip.device, rows, E)
+    kc.check_layernorm(hip.device, rows, E, g16=True)
 
 
 @pytest.mark.parametrize("views,heads,spike", [(1, 2, False), (16, 6, False), (3, 8, True)])
@@ -242,6 +243,16 @@ def test_gemm_row384(hip, M, N, K):
 def test_gemm_lnbwd(hip, M, N, K):
     from ccd_amd import ops
     kc.check_gemm_lnbwd(hip.device, M=M, N=N, K=K)            # rowgemm.h where K % (64 R) == 0 and N in {128, 256, 384, 512}
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 384, 384), (4096, 384, 1536), (40000, 384, 1152), (5000, 128, 512), (33000, 256, 768)])
+def test_gemm_lnbwd_bf16_stream(hip, M, N, K):
+    """ccd_gemm_nt_lnbwd_g16: the residual-gradient stream as a bf16 tensor (read bf16, accumulated fp32, rounded once per writer)."""
+    from ccd_amd import ops
+    kc.check_gemm_lnbwd(hip.device, M=M, N=N, K=K, g16=True)
+    if N == 384:
+        with ops.policy(rowgemm_adma=0):
+            kc.check_gemm_lnbwd(hip.device, M=M, N=N, K=K, seed=36, g16=True)
 
 
 def test_gemm_lnbwd_row384_kernel(hip):

@@ -109,6 +109,7 @@ def test_rowproj_sim(sim, monkeypatch):
 def test_layernorm_sim(sim):
     kc.check_layernorm(sim.device, rows=37, E=192)
     kc.check_layernorm(sim.device, rows=9, E=384)
+    kc.check_layernorm(sim.device, rows=37, E=192, g16=True)      # (round 6) the gradient stream as a bf16 tensor
 
 
 def test_attention_sim(sim):
@@ -250,6 +251,13 @@ def test_gemm_lnbwd_sim(sim):
     kc.check_gemm_lnbwd(sim.device, M=70, N=384, K=768)
     kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=128)      # gemm_row384.h
     kc.check_gemm_lnbwd(sim.device, M=140, N=192, K=64)
+    # round 6: the gradient stream as a bf16 tensor (row-owner kernels: ADMA and register-loaded activation rows, N = 128 / 256)
+    kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=384, g16=True)
+    kc.check_gemm_lnbwd(sim.device, M=1100, N=384, K=576, seed=34, g16=True)
+    kc.check_gemm_lnbwd(sim.device, M=200, N=128, K=256, g16=True)
+    kc.check_gemm_lnbwd(sim.device, M=260, N=256, K=256, g16=True)
+    with ops.policy(rowgemm_adma=0):
+        kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=384, seed=35, g16=True)
 
 
 def test_gemm_resid_ln_sim(sim):

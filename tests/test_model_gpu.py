@@ -49,6 +49,13 @@ def test_distributed_path_on_one_rank(hip):
         json.dump(report, f)
 
 
+def test_g_bf16_matches_fp32(hip):
+    report = mc.check_g_bf16_matches_fp32(hip.device, E=384, batch=8)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/g_bf16_vs_fp32.json", "w") as f:
+        json.dump(report, f)
+
+
 def test_no_grad_train_droppath(hip):
     mc.check_no_grad_train_droppath(hip.device, E=384, views=8)
 

@@ -30,6 +30,11 @@ def test_tiny_training_iteration_rotating_gb_buffers_sim(sim, lnbwd):
         engine.Fusion.double_gb, engine.Fusion.lnbwd = saved
 
 
+def test_g_bf16_matches_fp32_sim(sim):
+    """The bf16 residual-gradient stream (ccd_*_g16) inside a training iteration against the fp32 stream, on the CPU executor."""
+    mc.check_g_bf16_matches_fp32(sim.device, E=128, batch=2)
+
+
 def test_no_grad_train_droppath_sim(sim):
     """train() + no_grad + drop_path > 0: blocks with a DropPath mask fall back from ccd_proj_mlp_fused."""
     mc.check_no_grad_train_droppath(sim.device, E=128, views=2)
