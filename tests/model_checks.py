@@ -414,7 +414,7 @@ def check_g_bf16_matches_fp32(device, E=128, batch=2, drop_path=0.3):
         engine.Fusion.g_bf16 = saved
         engine._DROPPATH_SEED.update(base=None, calls=0)
     (l0, g0, t0), (l1, g1, t1) = results[False], results[True]
-    assert abs(l0 - l1) < 1e-6, (l0, l1)
+    assert abs(l0 - l1) < 1e-5, (l0, l1)          # (the same forward pass up to the order of its fp32 atomics)
     report = {"loss": [l0, l1], "rel_grad_all": ((g1 - g0).double().norm() / g0.double().norm()).item()}
     assert report["rel_grad_all"] < 1e-2, report
     for n in t0:

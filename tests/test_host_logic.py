@@ -189,3 +189,45 @@ def test_every_16_byte_buffer_store_holds_its_data_registers():
         for h in hits:
             end = code.index("\n}", h)                      # the helper's closing brace
             assert "buf_store_data_hold(" in code[h:end], f"prelude_hip.h: 16-byte buffer store at offset {h} without buf_store_data_hold"
+
+
+def test_row_owner_kernels_stay_within_their_recorded_spill_ceilings():
+    """The 512-register row-owner kernels compile without spills in their product loops only as long as nothing pushes the allocator
+    over the edge (227 spills from one `if`, 122 scalar spills from hoisted descriptors) - and a spill costs milliseconds
+    silently.  The code object's own figures (tools/codeobj_regs.py) are checked against ceilings recorded on the round-6 tree:
+    kernel pattern -> (VGPR spills, SGPR spills, scratch bytes).  A compiler bump or an edit that raises one of them fails HERE, on the
+    CPU, not as a slower step on the GPU.  (The spills that are recorded sit outside the chunk loops: checked in the ISA when recorded.)"""
+    import re
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import codeobj_regs
+    regs = codeobj_regs.load()
+    ceilings = {
+        r"ccd::mlp_fused_kernel<384, false, true>": (72, 8, 292),
+        r"ccd::mlp_fused_kernel<384, true, true>": (78, 101, 304),
+        r"ccd::mlp_fused_kernel<384, false, false>": (0, 0, 0),
+        r"ccd::mlp_fused_kernel<384, true, false>": (0, 24, 0),
+        r"ccd::rowgemm_kernel<384, 3, 0, true, false>": (2, 12, 12),
+        r"ccd::rowgemm_kernel<384, 3, 0, true, true>": (2, 12, 12),
+        r"ccd::rowgemm_kernel<384, 3, 1, true, false>": (0, 0, 0),
+        r"ccd::rowproj_kernel<384, 2>": (0, 0, 0),
+        r"ccd::attention_bwd_onepass_kernel": (0, 10, 0),
+        r"ccd::attention_fwd_kernel": (0, 0, 0),
+        r"ccd::cls_tail_fwd_kernel": (0, 0, 0),
+        r"ccd::cls_tail_bwd_kernel<false, 4>": (0, 0, 0),
+        r"ccd::cls_tail_bwd_kernel<true, 4>": (0, 0, 0),
+        r"ccd::head_loss_kernel<false>": (0, 0, 0),
+        r"ccd::head_loss_kernel<true>": (0, 0, 0),
+        r"ccd::gemm256_kernel<5, 256, false>": (0, 0, 0),
+        r"ccd::gemm_tn384_kernel<4, 2, 4, 3, 3>": (0, 0, 0),
+    }
+    for name, (vs, ss, sb) in ceilings.items():
+        assert name in regs, f"{name}: not in the code object (renamed? update the ceiling table)"
+        r = regs[name]
+        got = (int(r["vgpr_spill"]), int(r["sgpr_spill"]), int(r["scratch"]))
+        assert got[0] <= vs and got[1] <= ss and got[2] <= sb, f"{name}: (VGPR spills, SGPR spills, scratch B) = {got}, recorded ceiling {(vs, ss, sb)}"
+        assert int(r["vgpr"]) <= 512
+    # two workgroups per CU is what these kernels' launch geometry assumes: <= 256 registers
+    for name in (r"ccd::attention_bwd_onepass_kernel", r"ccd::cls_tail_bwd_kernel<false, 4>", r"ccd::cls_tail_bwd_kernel<true, 4>", r"ccd::cls_tail_fwd_kernel"):
+        assert int(regs[name]["vgpr"]) <= 256, (name, regs[name]["vgpr"])
