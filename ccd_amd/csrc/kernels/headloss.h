@@ -86,19 +86,30 @@ __global__ __launch_bounds__(HL_THREADS, 1) void head_loss_kernel(HeadLossParams
     char* req_lds = nullptr;
     long step_a = 0;
     unsigned req_lane = 0;
+    // the issue stream's item: (split j_i, row tile rt_i) of item n_i, kept incrementally (no division per piece), and where the
+    // item's columns start in either weight matrix
+    int j_i = q / RT, rt_i = q - j_i * RT;
+    const unsigned cstride_s = (unsigned)(64 * p.ld_ws * 2), cstride_t = (unsigned)(64 * p.ld_wt * 2);     // bytes per 64-column chunk
+    const char* item_s = reinterpret_cast<const char*>(p.ws) + (unsigned long long)((xcd + 8 * j_i) * p.chunks) * cstride_s;
+    const char* item_t = reinterpret_cast<const char*>(p.wt) + (unsigned long long)((xcd + 8 * j_i) * p.chunks) * cstride_t;
     auto issue_prepare = [&]() __attribute__((always_inline)) {
-        const int n = n_i < items ? n_i : q;             // behind the last item: any valid piece (drained at the end)
-        const int cs = xcd + 8 * (n / RT);
         const int chunk = pos_i >> 2, net = (pos_i >> 1) & 1, half = pos_i & 1;
-        const long col0 = ((long)cs * p.chunks + chunk) * 64;
-        const long ld = net ? p.ld_wt : p.ld_ws;
-        req_base = reinterpret_cast<const char*>(net ? p.wt : p.ws) + (col0 * ld + half * (E / 2)) * 2;
-        step_a = 64 * ld;
+        req_base = (net ? item_t : item_s) + (unsigned)chunk * (net ? cstride_t : cstride_s) + half * E;      // (E / 2 elements = E bytes)
+        step_a = 64 * (net ? p.ld_wt : p.ld_ws);
         req_lane = net ? req_lane_t : req_lane_s;
         req_lds = smem + slot_i * PIECE + w * 1024;
         slot_i = slot_i + 1 == NSLOT ? 0 : slot_i + 1;
         pos_i = pos_i + 1;
-        if (pos_i == NP) { pos_i = 0; n_i += Gx; }
+        if (pos_i == NP) {
+            pos_i = 0;
+            if (n_i + Gx < items) {        // behind the last item: the same pieces again (drained at the end)
+                n_i += Gx;
+                rt_i += Gx;
+                while (rt_i >= RT) { rt_i -= RT; ++j_i; }
+                item_s = reinterpret_cast<const char*>(p.ws) + (unsigned long long)((xcd + 8 * j_i) * p.chunks) * cstride_s;
+                item_t = reinterpret_cast<const char*>(p.wt) + (unsigned long long)((xcd + 8 * j_i) * p.chunks) * cstride_t;
+            }
+        }
     };
     auto issue_one = [&](int i) __attribute__((always_inline)) {
         glds16(req_base + ((i & 1) * step_a + (i >> 1) * 128) + req_lane, req_lds + 4096 * i);
@@ -166,9 +177,8 @@ __global__ __launch_bounds__(HL_THREADS, 1) void head_loss_kernel(HeadLossParams
         const int rows_left = rows - r0 > 32 ? 32 : (rows - r0 > 0 ? rows - r0 : 0);
         const buf_rsrc rs_d = make_rsrc(BWD ? p.d_logits + (long)r0 * p.ld_d : nullptr,
                                         BWD && rows_left > 0 ? (unsigned)((((long)rows_left - 1) * p.ld_d + p.K) * 2) : 0u);
-#pragma unroll 1
-        for (int c = 0; c < p.chunks; ++c) {
-            f32x16 hs[2], ht[2];
+        // one chunk = four pieces: Ws(c, 0), Ws(c, 1) -> hs;  Wt(c, 0), Wt(c, 1) -> ht;  filler(piece index, MFMA step) rides between the MFMAs
+        auto chunk_products = [&](f32x16 (&hs)[2], f32x16 (&ht)[2], auto&& filler) __attribute__((always_inline)) {
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -187,54 +197,70 @@ __global__ __launch_bounds__(HL_THREADS, 1) void head_loss_kernel(HeadLossParams
                     [&](auto Kk) {
                         constexpr int k = decltype(Kk)::value, stride = KJ / KT;
                         if constexpr (k % stride == 1 && k / stride < KT) issue_one(k / stride);
+                        filler(std::integral_constant<int, 2 * net + kh>{}, Kk);
                     });
             };
             piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
             piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
             piece(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
             piece(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
-            // register r of tile tt = column 64 c + 32 tt + 16 (r >> 3) + 8 hf + (r & 7) of the split, this lane's row
-            const float* cc = ct + 64 * c + 8 * hf;
-            if constexpr (!BWD) {
-                // teacher logits, centred and scaled, back into their registers; the chunk's two maxima
-                float cms = -3.0e38f, cmt = -3.0e38f;
+        };
+        // register r of tile tt = column 64 c + 32 tt + 16 (r >> 3) + 8 hf + (r & 7) of the split, this lane's row
+        if constexpr (!BWD) {
+            // (Round 6 also built the software-pipelined form - the online-softmax update of chunk c - 1 riding between the MFMAs of chunk
+            // c, one logit pair per MFMA step - and measured it SLOWER: 396 against 338 us per launch.  With one wave per SIMD a VALU
+            // instruction costs its issue slot wherever it stands (tools/probe/two_wg_probe.hip: 6 fillers per MFMA take the product loop from
+            // 33.5 to 54 cycles per MFMA), and between the MFMAs it also delays the next fragment wait.  The update runs behind its chunk.)
+            f32x16 hA[2], tA[2];
+            float cv[32];
+            float cms = -3.0e38f, cmt = -3.0e38f, ls0 = 0.f, ls1 = 0.f, lt0 = 0.f, lt1 = 0.f, d0 = 0.f, d1 = 0.f;
+            auto load_cv = [&](int c_of) __attribute__((always_inline)) {           // the centre columns of chunk c_of, in accumulator order
+                const float* cc = ct + 64 * c_of + 8 * hf;
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) {
-                        const f32x4v cv = *reinterpret_cast<const f32x4v*>(cc + 32 * tt + 16 * (s4 >> 1) + 4 * (s4 & 1));
-                        const float c4[4] = {cv.x, cv.y, cv.z, cv.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int r = 4 * s4 + e;
-                            const float xt = fmaf(ht[tt][r], p.kt, -c4[e]);
-                            ht[tt][r] = xt;
-                            cmt = fmaxf(cmt, xt);
-                            cms = fmaxf(cms, hs[tt][r]);
-                        }
+                        const f32x4v v = *reinterpret_cast<const f32x4v*>(cc + 32 * tt + 16 * (s4 >> 1) + 4 * (s4 & 1));
+                        cv[16 * tt + 4 * s4] = v.x; cv[16 * tt + 4 * s4 + 1] = v.y; cv[16 * tt + 4 * s4 + 2] = v.z; cv[16 * tt + 4 * s4 + 3] = v.w;
                     }
-                cms *= p.ks;
-                {
-                    const float nms = fmaxf(st.ms, cms), nmt = fmaxf(st.mt, cmt);
-                    const float fs = fast_exp2(st.ms - nms), ft = fast_exp2(st.mt - nmt);
-                    st.ls *= fs; st.lt *= ft; st.dot *= ft;
-                    st.ms = nms; st.mt = nmt;
-                }
-                float ls0 = 0.f, ls1 = 0.f, lt0 = 0.f, lt1 = 0.f, d0 = 0.f, d1 = 0.f;
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const float xs0 = hs[tt][r] * p.ks, xs1 = hs[tt][r + 1] * p.ks;
-                        ls0 += fast_exp2(xs0 - st.ms);
-                        ls1 += fast_exp2(xs1 - st.ms);
-                        const float p0 = fast_exp2(ht[tt][r] - st.mt), p1 = fast_exp2(ht[tt][r + 1] - st.mt);
-                        lt0 += p0; lt1 += p1;
-                        d0 = fmaf(p0, xs0, d0);
-                        d1 = fmaf(p1, xs1, d1);
-                    }
-                st.ls += ls0 + ls1; st.lt += lt0 + lt1; st.dot += d0 + d1;
-            } else {
+                cms = -3.0e38f; cmt = -3.0e38f;
+            };
+            auto stage_a = [&](auto EI, f32x16 (&hP)[2], f32x16 (&tP)[2]) __attribute__((always_inline)) {
+                constexpr int e = decltype(EI)::value, tt = e >> 4, r = e & 15;
+                const float xt = fmaf(tP[tt][r], p.kt, -cv[e]);
+                tP[tt][r] = xt;
+                cmt = fmaxf(cmt, xt);
+                cms = fmaxf(cms, hP[tt][r]);
+            };
+            auto rescale = [&]() __attribute__((always_inline)) {
+                const float nms = fmaxf(st.ms, cms * p.ks), nmt = fmaxf(st.mt, cmt);
+                const float fs = fast_exp2(st.ms - nms), ft = fast_exp2(st.mt - nmt);
+                st.ls *= fs; st.lt *= ft; st.dot *= ft;
+                st.ms = nms; st.mt = nmt;
+                ls0 = ls1 = lt0 = lt1 = d0 = d1 = 0.f;
+            };
+            auto stage_b = [&](auto EI, f32x16 (&hP)[2], f32x16 (&tP)[2]) __attribute__((always_inline)) {
+                constexpr int e = decltype(EI)::value, tt = e >> 4, r = e & 15;
+                const float es = fast_exp2(fmaf(hP[tt][r], p.ks, -st.ms)), pt = fast_exp2(tP[tt][r] - st.mt);
+                if constexpr (e & 1) { ls1 += es; lt1 += pt; d1 = fmaf(pt, hP[tt][r], d1); }       // (dot carries sum p * s: times ks when it is published)
+                else { ls0 += es; lt0 += pt; d0 = fmaf(pt, hP[tt][r], d0); }
+            };
+            auto finish_b = [&]() __attribute__((always_inline)) { st.ls += ls0 + ls1; st.lt += lt0 + lt1; st.dot += d0 + d1; };
+#pragma unroll 1
+            for (int c = 0; c < p.chunks; ++c) {
+                chunk_products(hA, tA, [](auto, auto) {});
+                load_cv(c);
+                mlp_static_for<0, 32>([&](auto EI) { stage_a(EI, hA, tA); });
+                rescale();
+                mlp_static_for<0, 32>([&](auto EI) { stage_b(EI, hA, tA); });
+                finish_b();
+            }
+        } else {
+#pragma unroll 1
+            for (int c = 0; c < p.chunks; ++c) {
+                f32x16 hs[2], ht[2];
+                chunk_products(hs, ht, [](auto, auto) {});
+                const float* cc = ct + 64 * c + 8 * hf;
                 // d s[i, k] = gs * (softmax_s - softmax_t): packed to bf16, out through the wave's scratch image as 128-byte row segments
                 const int ln = opaque_vgpr(t) & 63, lhf = ln >> 5, llq = ln & 31, ldr_ = ln >> 3, ldp = ln & 7;
 #pragma unroll
@@ -270,6 +296,7 @@ __global__ __launch_bounds__(HL_THREADS, 1) void head_loss_kernel(HeadLossParams
         }
         if constexpr (!BWD) {
             // the row's two column halves meet; the lower half-wave publishes the split's partial
+            st.dot *= p.ks;
             hl_merge(st, shfl_xor(st.ms, 32), shfl_xor(st.ls, 32), shfl_xor(st.mt, 32), shfl_xor(st.lt, 32), shfl_xor(st.dot, 32));
             if (live && hf == 0) {
                 float* o = p.part + ((long)cs * p.max_rows + row) * 8;
