@@ -994,7 +994,7 @@ static int ccd_head_loss_launch(ccd::HeadLossParams& q, bool bwd, void* stream) 
     q.chunks = q.K / 64 / q.CS;
     const int smem = ccd::hl_smem_bytes(q.chunks);
     CCD_CHECK(smem <= 160 * 1024, CCD_ESHAPE);
-    int grid = ccd_grid_cus() & ~7;
+    int grid = (2 * ccd_grid_cus()) & ~7;          // two workgroups per CU (<= 256 registers, 72 KiB of LDS): one's softmax update runs under the other's products
     if (grid < 8) grid = 8;
     if (bwd) CCD_LAUNCH((ccd::head_loss_kernel<true>), dim3(grid), dim3(ccd::HL_THREADS), smem, stream, q);
     else CCD_LAUNCH((ccd::head_loss_kernel<false>), dim3(grid), dim3(ccd::HL_THREADS), smem, stream, q);

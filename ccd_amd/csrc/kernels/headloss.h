@@ -43,7 +43,7 @@ struct HeadLossParams {
     long ld_d;
 };
 
-constexpr int HL_THREADS = 256, HL_D = 256, HL_BM = 128, HL_SCRATCH = 4096, HL_NSLOT = 5, HL_PIECE = 32 * HL_D * 2;
+constexpr int HL_THREADS = 256, HL_D = 256, HL_BM = 128, HL_SCRATCH = 4096, HL_NSLOT = 3, HL_PIECE = 32 * HL_D * 2;
 __host__ __device__ inline int hl_smem_bytes(int chunks) { return HL_NSLOT * HL_PIECE + 4 * HL_SCRATCH + 2 * chunks * 64 * 4; }
 
 struct HlState { float ms, ls, mt, lt, dot; };
@@ -59,7 +59,7 @@ __device__ __forceinline__ void hl_merge(HlState& a, float oms, float ols, float
 }
 
 template <bool BWD>
-__global__ __launch_bounds__(HL_THREADS, 1) void head_loss_kernel(HeadLossParams p) {
+__global__ __launch_bounds__(HL_THREADS, 2) void head_loss_kernel(HeadLossParams p) {
     constexpr int E = HL_D, KT = E / 64, KJ = E / 16, PIECE = HL_PIECE, NSLOT = HL_NSLOT, AHEAD = NSLOT - 1, DEPTH = 6;
     static_assert(KJ == 16 && KT == 4, "a piece = 64 weight rows x one K half of 128 = 16 MFMA steps");
     const int M = uniform_i32(p.d_m[0]);
@@ -212,22 +212,15 @@ __global__ __launch_bounds__(HL_THREADS, 1) void head_loss_kernel(HeadLossParams
             // instruction costs its issue slot wherever it stands (tools/probe/two_wg_probe.hip: 6 fillers per MFMA take the product loop from
             // 33.5 to 54 cycles per MFMA), and between the MFMAs it also delays the next fragment wait.  The update runs behind its chunk.)
             f32x16 hA[2], tA[2];
-            float cv[32];
+            const float* cvp = ct;
             float cms = -3.0e38f, cmt = -3.0e38f, ls0 = 0.f, ls1 = 0.f, lt0 = 0.f, lt1 = 0.f, d0 = 0.f, d1 = 0.f;
-            auto load_cv = [&](int c_of) __attribute__((always_inline)) {           // the centre columns of chunk c_of, in accumulator order
-                const float* cc = ct + 64 * c_of + 8 * hf;
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        const f32x4v v = *reinterpret_cast<const f32x4v*>(cc + 32 * tt + 16 * (s4 >> 1) + 4 * (s4 & 1));
-                        cv[16 * tt + 4 * s4] = v.x; cv[16 * tt + 4 * s4 + 1] = v.y; cv[16 * tt + 4 * s4 + 2] = v.z; cv[16 * tt + 4 * s4 + 3] = v.w;
-                    }
+            auto load_cv = [&](int c_of) __attribute__((always_inline)) {           // where the centre columns of chunk c_of start for this half-wave
+                cvp = ct + 64 * c_of + 8 * hf;
                 cms = -3.0e38f; cmt = -3.0e38f;
             };
             auto stage_a = [&](auto EI, f32x16 (&hP)[2], f32x16 (&tP)[2]) __attribute__((always_inline)) {
                 constexpr int e = decltype(EI)::value, tt = e >> 4, r = e & 15;
-                const float xt = fmaf(tP[tt][r], p.kt, -cv[e]);
+                const float xt = fmaf(tP[tt][r], p.kt, -cvp[32 * tt + 16 * (r >> 3) + (r & 7)]);
                 tP[tt][r] = xt;
                 cmt = fmaxf(cmt, xt);
                 cms = fmaxf(cms, hP[tt][r]);
