@@ -35,11 +35,11 @@
 #define CCD_ALIGNED16(p) ((((uintptr_t)(p)) & 15u) == 0)
 #define CCD_MAX_OPERAND_BYTES 0x7ffffff0L
 
-static int ccd_grid_cus();
+static int ccd_grid_cus(long tiles = 0);
 // persistent grid: one workgroup per resident slot (2 per CU), never more than there are work items
 static int ccd_gemm_grid(ccd::GemmParams& p, int tiles, int splits) {
     p.work_items = tiles * splits;
-    const int cap = 2 * ccd_grid_cus();
+    const int cap = 2 * ccd_grid_cus((p.work_items + 1) / 2);      // (split counts are sized for the whole chip: no extra round for 16 left-over items)
     return p.work_items < cap ? p.work_items : cap;
 }
 
@@ -138,14 +138,23 @@ static CcdPolicy& ccd_policy() {
 // Reserving CUs is expensive for the row-owner kernels (131072 rows = 512 tiles of 256 rows: 2 rounds on 256 CUs, 3 on 248 - the
 // fused MLP, the residual + LayerNorm product and the LayerNorm-backward product ran 16-20 % longer), and a bucket's all-reduce is in
 // flight for well under a millisecond: with cu_reserve_window >= 0 only the launches right behind a bucket launch leave CUs free.
-static int ccd_grid_cus() {
+// `tiles` (row-owner launches, one workgroup per CU, a few large tiles each): a launch whose tiles fill the whole chip in r rounds and
+// would need r + 1 on the reduced grid (512 tiles of 256 rows: 2 rounds on 256 CUs, 3 on 248) takes every CU - the collective's
+// workgroups then get in when this launch's first workgroups retire, at most one kernel (< 0.7 ms) late, instead of every such launch
+// paying half its run time for CUs the collective needs for a fraction of it.  The launch still uses up one slot of the window.
+static int ccd_grid_cus(long tiles) {
     CcdPolicy& pol = ccd_policy();
     int reserve = pol.cu_reserve;
     if (reserve > 0 && pol.cu_reserve_window >= 0) {
         if (pol.cu_reserve_left > 0) --pol.cu_reserve_left;
         else reserve = 0;
     }
-    const int cus = ccd_rt_num_cus() - reserve;
+    const int all = ccd_rt_num_cus();
+    if (reserve > 0 && tiles > 0 && 8 * reserve <= all) {        // (a reserve of most of the chip is a test forcing a small grid)
+        const long full = (tiles + all - 1) / all, less = (tiles + (all - reserve) - 1) / (all - reserve);
+        if (less > full && full <= 4) reserve = 0;
+    }
+    const int cus = all - reserve;
     return cus > 1 ? cus : 1;
 }
 // row-owner projection (rowproj.h): out bf16 = A . B^T + bias, K in {384, 512}, N % 64 == 0
@@ -160,7 +169,7 @@ static int ccd_launch_rowproj(const ccd::GemmParams& p, void* stream) {
     ccd::RowProjParams q;
     q.a = reinterpret_cast<const ccd::bf16_t*>(p.A); q.lda = p.lda; q.w = reinterpret_cast<const ccd::bf16_t*>(p.B); q.ldw = p.ldb;
     q.bias = p.bias; q.out = reinterpret_cast<ccd::bf16_t*>(p.C); q.ldc = p.ldc; q.M = p.M; q.N = p.N;
-    const int cus = ccd_grid_cus(), smem = ccd::rp_smem_bytes(p.K, p.N);
+    const int cus = ccd_grid_cus((p.M + ccd::rp_rows(p.K == 384 ? 2 : 1) - 1) / ccd::rp_rows(p.K == 384 ? 2 : 1)), smem = ccd::rp_smem_bytes(p.K, p.N);
     if (p.K == 384) {
         const int tiles = (p.M + ccd::rp_rows(2) - 1) / ccd::rp_rows(2), rb = ccd_policy().rowproj_rb;
         if (rb == 1 || (rb == 0 && tiles < cus)) {       // (round 5) the chip is not full of 256-row tiles: half the rows per workgroup
@@ -196,7 +205,7 @@ static int ccd_launch_gemm256(const ccd::GemmParams& p, int epilogue, void* stre
 // `cus`: the caller's ccd_grid_cus() when it already asked (one launch consumes ONE slot of the cu_reserve window), -1 otherwise
 static int ccd_launch_gemm_row384(const ccd::GemmParams& p, int epilogue, void* stream, int cus = -1) {
     const int tiles = (p.M + ccd::GR_BM - 1) / ccd::GR_BM;
-    if (cus < 0) cus = ccd_grid_cus();
+    if (cus < 0) cus = ccd_grid_cus(tiles);
     const dim3 grid(tiles < cus ? tiles : cus), block(ccd::GR_THREADS);
     const size_t smem = ccd::GR_SMEM_BYTES;
     switch (epilogue) {
@@ -348,7 +357,7 @@ int ccd_gemm_nt_resid_ln(const ccd_bf16* A, long lda, const ccd_bf16* B, long ld
     CCD_CHECK(N <= 512 && N % 8 == 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && ldr % 4 == 0 &&
               ldy % 8 == 0, CCD_ESHAPE);
     CCD_CHECK(((long)M * lda + K) * 2 < CCD_MAX_OPERAND_BYTES && ((long)N * ldb + K) * 2 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
-    const int cus = ccd_grid_cus();
+    const int cus = ccd_grid_cus((M + ccd::RG_BM - 1) / ccd::RG_BM);
     // (measured at N = 384: 0.131 ms with gemm_row384.h's 8-wave tile - whose residual rows stream in under the staging
     // barrier - against 0.198 ms here, where the epilogue starts after the last MFMA: the row-owner kernel is the default
     // only where the other does not exist, N = 512; policy rowgemm = 2 forces it)
@@ -392,7 +401,7 @@ static int ccd_gemm_nt_lnbwd_any(const ccd_bf16* A, long lda, const ccd_bf16* B,
     CCD_CHECK(N <= 512 && N % 8 == 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldx % 4 == 0 && ldg % 4 == 0 &&
               (!gb || ldgb % 4 == 0), CCD_ESHAPE);
     CCD_CHECK(((long)M * lda + K) * 2 < CCD_MAX_OPERAND_BYTES && ((long)N * ldb + K) * 2 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
-    const int cus = ccd_grid_cus();
+    const int cus = ccd_grid_cus((M + ccd::RG_BM - 1) / ccd::RG_BM);
     if (ccd_policy().rowgemm && (N == 128 || N == 256 || N == 384 || N == 512) && K % (64 * ccd::rg_ring(N)) == 0 && ldg % 4 == 0 &&
         ((long)M + (long)cus * ccd::RG_BM) * lda * 2 < CCD_MAX_OPERAND_BYTES && (long)M * ldx * 4 < CCD_MAX_OPERAND_BYTES &&
         (long)M * ldg * 4 < CCD_MAX_OPERAND_BYTES && (!g16 || (N <= 384 && ldg % 8 == 0))) {
@@ -469,7 +478,7 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
     p.a = nullptr; p.lda = 0; p.wp = nullptr; p.ldp = 0; p.bp = nullptr; p.rowscale1 = nullptr; p.ln2_gamma = p.ln2_beta = nullptr;
     p.xmid = nullptr; p.ldxm = 0; p.y2 = nullptr; p.ldy2 = 0; p.mean2 = p.rstd2 = nullptr;
     p.tap_gamma = p.tap_beta = nullptr; p.tap_y = nullptr; p.ld_tap = 0;
-    const int tiles = (M + ccd::MLP_BM - 1) / ccd::MLP_BM, cus = ccd_grid_cus();
+    const int tiles = (M + ccd::MLP_BM - 1) / ccd::MLP_BM, cus = ccd_grid_cus(tiles);
     const dim3 grid(tiles < cus ? tiles : cus), block(ccd::MLP_THREADS);
     if (E == 512) {
         if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<512, true>), grid, block, smem, stream, p);
@@ -520,7 +529,7 @@ int ccd_proj_mlp_fused(const ccd_bf16* a, long lda, const ccd_bf16* wp, long ldp
     p.a = a; p.lda = lda; p.wp = wp; p.ldp = ldp; p.bp = bp; p.rowscale1 = rowscale1; p.ln2_gamma = ln2_gamma; p.ln2_beta = ln2_beta;
     p.xmid = xmid; p.ldxm = ldxm; p.y2 = y2; p.ldy2 = ldy2; p.mean2 = mean2; p.rstd2 = rstd2;
     p.tap_gamma = tap_gamma; p.tap_beta = tap_beta; p.tap_y = tap_y; p.ld_tap = ld_tap;
-    const int tiles = (M + ccd::MLP_BM - 1) / ccd::MLP_BM, cus = ccd_grid_cus();
+    const int tiles = (M + ccd::MLP_BM - 1) / ccd::MLP_BM, cus = ccd_grid_cus(tiles);
     const dim3 grid(tiles < cus ? tiles : cus), block(ccd::MLP_THREADS);
     if (E == 384) {
         if (u) CCD_LAUNCH((ccd::mlp_fused_kernel<384, true, true>), grid, block, smem, stream, p);

@@ -310,12 +310,14 @@ def _weather_member(p, rs, name, h, w, overlays):
     """`weather`: the layers of Fog / Clouds / Snowflakes / Rain are generated HERE (ccd_amd/dataset/weather.py) and blended on the
     device: the row names the first of its layers among the batch's overlay planes, their number and the blend (cloud / rain: alpha
     towards an intensity; snow: add, then raise).  Without a collector (`overlays` None: a caller that does not ship overlay planes)
-    nothing is drawn."""
+    no layer is made - but the layer seed is drawn either way, so the sampler's random stream (every later draw of the batch) does not
+    depend on whether overlay planes are shipped."""
+    layer_seed = rs.randint(0, 1 << 31)
     if overlays is None:
         return
     from . import weather
     # (-1, task id, blend) until Overlays.resolve() has the layers: then (their number, the first one's index, blend)
-    p[P_W], p[P_W + 1] = -1, overlays.add_task(name, rs.randint(0, 1 << 31))
+    p[P_W], p[P_W + 1] = -1, overlays.add_task(name, layer_seed)
     p[P_W + 2] = weather.SNOW_MODE if name == "Snowflakes" else weather.CLOUD_MODE      # how the device blends the planes
 
 

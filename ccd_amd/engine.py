@@ -459,6 +459,11 @@ class BackboneFn(torch.autograd.Function):
             # the Function, so autograd still files the node under the caller's stream and the backward pass gets the whole chip
             main = torch.cuda.current_stream(img.device)
             hop.stream.wait_stream(main)
+            # img (and the module's resample matrix) were allocated on the caller's stream: tell the caching allocator that the hop
+            # stream reads them, or a join=False pass could see its input block handed to the caller's next allocation
+            img.record_stream(hop.stream)
+            if module.resample.is_cuda:
+                module.resample.record_stream(hop.stream)
             with torch.cuda.stream(hop.stream), ops.policy(cu_reserve=hop.reserve, cu_reserve_window=-1):
                 tokens, taps, saved = backbone_forward(module.arena, module.arena_prefix, module.spec, img, module.resample,
                                                        save, module.training, need_taps)

@@ -155,6 +155,11 @@ class DINOHead(ArenaModule):
         super().__init__()
         if use_bn or nlayers != 3:
             raise NotImplementedError("HIP DINOHead covers the shipped configuration: nlayers=3, use_bn=False")
+        # ccd_weightnorm_fwd writes the transposed bf16 copy of the last layer two output units (4 bytes) at a time and reads a row
+        # of v as 16-byte pieces: say so here, at model build time, not as a CCD_ESHAPE from the first forward pass
+        if out_dim % 2 or bottleneck_dim % 4 or bottleneck_dim > 1024:
+            raise ValueError(f"HIP DINOHead: out_dim must be even and bottleneck_dim a multiple of 4 (<= 1024); got out_dim={out_dim}, "
+                             f"bottleneck_dim={bottleneck_dim}")
         self.mlp = nn.Sequential(nn.Linear(in_dim, hidden_dim), nn.GELU(), nn.Linear(hidden_dim, hidden_dim), nn.GELU(),
                                  nn.Linear(hidden_dim, bottleneck_dim))
         for m in self.mlp:

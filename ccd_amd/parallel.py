@@ -68,6 +68,11 @@ class GradReducer:
             if not self._avg and self.world > 1:
                 self.arena.grad[lo:hi].div_(self.world)
         self._works, self._done = [], []
+        if self.reserve_window > 0 and self.arena.device.type == "cuda":
+            # every collective has been waited for: what is left of the last bucket's window must not reach into the optimizer and the
+            # next iteration's forward pass (measured on the N > 1 path of one rank: its first block halves ran 20 % longer)
+            from . import ops
+            ops.policy_set("cu_reserve_left", 0)
 
 
 def _merge(ranges):
@@ -86,12 +91,14 @@ class DataParallel(nn.Module):
     construction, overlapped gradient averaging."""
 
     def __init__(self, module, device_ids=None, find_unused_parameters=False, process_group=None,
-                 bucket_elems=8 * 1024 * 1024, reduce_at_world1=False, cu_reserve=8, reserve_window=8):
+                 bucket_elems=8 * 1024 * 1024, reduce_at_world1=False, cu_reserve=8, reserve_window=3):
         """cu_reserve: compute units the persistent GEMM grids leave free so that the RCCL kernels of a bucket's all-reduce find
         a slot next to them (policy key `cu_reserve`; 0 = take every CU) - for the `reserve_window` kernel launches that follow
-        the bucket's launch (~2 ms of the backward pass; a 32-MB all-reduce over xGMI is in flight for well under 1 ms), not for
-        the whole step: 248 instead of 256 workgroups cost the row-owner kernels a third round of tiles (measured on the N > 1
-        path of one rank: fused MLP + 20 %, LayerNorm-backward product + 18 %).  reserve_window = -1: every launch."""
+        the bucket's launch (3 launches ~ 0.75 ms of the backward pass; a 32-MB ring all-reduce over 8 GPUs moves 56 MB per GPU over
+        xGMI, ~0.3 ms), not for the whole step: 248 instead of 256 workgroups cost the row-owner kernels a whole extra round of tiles
+        (measured on the N > 1 path of one rank: fused MLP + 20 %, LayerNorm-backward product + 18 %), which is why a row-owner launch
+        that the reserve would push into an extra round takes every CU anyway (csrc/abi_impl.h: ccd_grid_cus) and the window is reset
+        once every collective has been waited for.  reserve_window = -1: every launch."""
         super().__init__()
         self.module = module
         self.reducer = None

@@ -197,9 +197,11 @@ def cls_backward(d_logits, x, w, dw, db, images, H, W):
     return dx
 
 
-def _relaid_weights(head, E, mid, out_c, dev):
-    """Every bf16 GEMM operand the head's forward AND backward take from its fp32 master weights, re-laid in ONE launch
-    (ops.permute4_multi; they were 22 launches of ~5 us per step).  -> dict of tensors."""
+def _relaid_weights(head, E, mid, out_c, dev, backward=True):
+    """Every bf16 GEMM operand the head's forward AND (backward=True) backward take from its fp32 master weights, re-laid in ONE
+    launch (ops.permute4_multi; they were 22 launches of ~5 us per step).  -> dict of tensors.  The backward's operands (w2t, w1d,
+    wt) are a snapshot taken at forward time - the weights the forward pass multiplied by, which is what autograd's saved tensors
+    would hold too; a no-grad / eval pass does not build them."""
     heads = [head.mlahead.head2, head.mlahead.head3, head.mlahead.head4]
     w, jobs = {"w1": [], "w2": [], "w2t": [], "w1d": [], "wp": [], "wt": []}, []
 
@@ -212,8 +214,9 @@ def _relaid_weights(head, E, mid, out_c, dev):
         w3, w1x1 = seq[0].weight.detach(), seq[3].weight.detach()
         job("w1", w3, (E * 9, 1, 9), (mid, 9, E), (mid, 9 * E))                    # forward 3x3: [co][tap][ci]
         job("w2", w1x1, (mid, 1), (out_c, mid), (out_c, mid))                      # forward 1x1
-        job("w2t", w1x1, (1, mid), (mid, out_c), (mid, out_c))                     # its data gradient
-        job("w1d", w3, (9, 1, E * 9), (E, 9, mid), (E, 9 * mid))                   # 3x3 data gradient: [ci][tap][co] <- W[co][ci][tap]
+        if backward:
+            job("w2t", w1x1, (1, mid), (mid, out_c), (mid, out_c))                 # its data gradient
+            job("w1d", w3, (9, 1, E * 9), (E, 9, mid), (E, 9 * mid))               # 3x3 data gradient: [ci][tap][co] <- W[co][ci][tap]
     for seq in (head.unpool1, head.unpool2):
         convt = seq[0]
         cin, cout = convt.in_channels, convt.out_channels
@@ -227,7 +230,8 @@ def _relaid_weights(head, E, mid, out_c, dev):
                 jobs.append((wsrc.reshape(-1)[ky0 * 4 + kx0:], (16, 8, 2, cout * 16), (cout, 2, 2, cin), dst))
                 per.append(dst)
         w["wp"].append(per)
-        job("wt", wsrc, (cout * 16, 1, 16), (cin, 16, cout), (cin, 16 * cout))     # data gradient: [ci][tap][co] <- W[ci][co][tap]
+        if backward:
+            job("wt", wsrc, (cout * 16, 1, 16), (cin, 16, cout), (cin, 16 * cout)) # data gradient: [ci][tap][co] <- W[ci][co][tap]
     ops.permute4_multi(jobs)
     return w
 
@@ -250,7 +254,7 @@ class SegHeadFn(torch.autograd.Function):
         d3 = ops.conv_desc((gh, gw), (gh, gw), E, TAPS3)
         d1 = ops.conv_desc((gh, gw), (gh, gw), mid, TAPS1)
         cat = torch.empty((M, 3 * out_c), dtype=BF16, device=dev)
-        wts = _relaid_weights(head, E, mid, out_c, dev)
+        wts = _relaid_weights(head, E, mid, out_c, dev, backward=any(ctx.needs_input_grad))
         zeros = _Zeros([6 * mid, 6 * out_c] + [2 * seq[0].out_channels for seq in ups_mods], dev)     # the four levels' statistics
         saved = {"taps": taps, "y1": [], "a1": [], "y2": [], "w": wts}
         # level 1 of the three independent branches (3x3 conv), ONE statistics exchange, then level 2 (1x1 conv), ONE more

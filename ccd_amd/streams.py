@@ -52,6 +52,16 @@ def partition(device, teacher_per_xcd=16, layout="cu", xcds=8, cus_per_xcd=32):
     device = torch.device(device)
     if device.type != "cuda":
         return None
+    if layout not in ("cu", "xcd"):
+        raise ValueError(f"CU-mask layout {layout!r}: expected 'cu' or 'xcd'")
+    limit = cus_per_xcd if layout == "cu" else xcds
+    if not 0 < int(teacher_per_xcd) < limit:
+        raise ValueError(f"teacher share {teacher_per_xcd} outside 1 .. {limit - 1} for layout {layout!r}")
+    # the mask layout above is the 8-XCD x 32-CU part's (MI355X); another CU count (MI300X's 304, a partitioned mode) would drop or
+    # mis-assign compute units and size cu_reserve from the wrong counts: no split there
+    have = torch.cuda.get_device_properties(device).multi_processor_count
+    if have != xcds * cus_per_xcd:
+        raise RuntimeError(f"CU-masked split is laid out for {xcds} XCDs x {cus_per_xcd} CUs; this device reports {have} compute units")
     key = (device.index if device.index is not None else torch.cuda.current_device(), int(teacher_per_xcd), layout)
     if key not in _CACHE:
         total = xcds * cus_per_xcd
@@ -73,4 +83,6 @@ def env_partition():
     if not v or v == "0":
         return None
     layout, _, n = v.partition(":")
+    if layout not in ("cu", "xcd") or not n.isdigit() or int(n) < 1:
+        raise ValueError(f"CCD_FWD_SPLIT={v!r}: expected 'cu:<CUs per XCD>' or 'xcd:<XCDs>'")
     return layout, int(n)
