@@ -168,8 +168,8 @@ class GraphedTrainingStep:
         same masks as an eager run with the same torch seed;
       * the teacher temperature and the epoch < 30 branch ARE launch-time constants: a change re-captures (once per epoch
         during the temperature warm-up, once at epoch 30).
-    The first `eager_steps` calls run eagerly (they are real iterations): lazily built tables, MIOpen's algorithm search and
-    the allocator's pools settle before anything is captured.  Single process only - the gradient all-reduce of
+    The first `eager_steps` calls run eagerly (they are real iterations): lazily built tables (optimizer table, weight
+    transposes) and the allocator's pools settle before anything is captured.  Single process only - the gradient all-reduce of
     parallel.DataParallel is launched from autograd hooks on a side stream and is not captured.  Bench-only (`bench.py --graph`):
     train.py runs the eager iteration, whose finite-loss check reads the loss every step."""
 

@@ -558,3 +558,58 @@ def test_piecewise_affine_maps():
     assert (th[rows > 0] == np.eye(3, dtype=np.float32)).all()
     p0, _ = A.sample_finetune_params(np.random.RandomState(2), 400, h, w)       # without a collector: unwarped, the same other draws
     assert (p0[:, 1, A.P_WARP] == 0).all() and (np.delete(p0, A.P_WARP, axis=2) == np.delete(p, A.P_WARP, axis=2)).all()
+
+
+def test_host_drawn_layers_against_their_second_restatement():
+    """What draws the weather planes and the PiecewiseAffine maps (ccd_amd/dataset/weather.py) against oracle/weather_np.py - a second
+    restatement of the same published algorithms in other formulations (dense resampling matrices, fftfreq distances and one inverse
+    FFT per axis, explicit mirror padding and window sums, barycentric interpolation) - value by value on shared seeds: the product's
+    generators are not their own checker any more.  Float fields agree to rounding; layers that pass through 8-bit images (the cubic
+    up-sampling, the blurs) may differ by ONE level where the two formulations round a .5 apart - on at most 0.2 % of a layer's pixels.
+    Building blocks that a library of this image does implement are pinned to it (scipy.ndimage.correlate, torch's bicubic kernel)."""
+    from scipy import ndimage
+    from ccd_amd.dataset import weather as Wt
+    from oracle import weather_np as On
+    h, w = 32, 128
+    rs = np.random.RandomState(0)
+    img = (rs.rand(h, w) * 255).astype(np.uint8)
+    for shape in ((5, 5), (4, 6), (3, 7)):
+        k = rs.rand(*shape)
+        assert np.abs(On.correlate_mirror(img, k) - ndimage.correlate(img.astype(np.float64), k, mode="mirror")).max() < 1e-9
+    src = rs.rand(7, 9)
+    assert np.abs(On.resize_cubic(src, h, w) - Wt.resize_cubic(src, h, w)).max() < 1e-12
+    ref = F.interpolate(torch.from_numpy(src)[None, None], size=(h, w), mode="bicubic", align_corners=False)[0, 0].numpy()
+    assert np.abs(On.resize_cubic(src, h, w) - ref).max() < 1e-6        # ATen's bicubic: the same kernel (A = -0.75) and border rule
+
+    def same(a, b, level):
+        """a, b: float fields; `level`: what one 8-bit level is worth in them (0: no 8-bit stage)."""
+        d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+        tol = 2e-5 * max(1.0, float(np.abs(b).max()))
+        off = d > tol
+        assert off.mean() <= 0.002 and (not off.any() or d.max() <= 1.01 * level + tol), (float(off.mean()), float(d.max()), level)
+
+    for seed in range(6):
+        for exponent, px in ((-1.0, 128), (-3.0, 128), (-2.0, 5), (-2.5, 7.3), (-4.0, 2)):
+            same(On.frequency_noise(np.random.RandomState(seed), h, w, exponent, px),
+                 Wt.frequency_noise(np.random.RandomState(seed), h, w, exponent, px), 1.0 / 255.0)
+        for o_make, p_make in ((On.fog_layers, Wt.fog_layers), (On.clouds_layers, Wt.clouds_layers)):
+            got, want = o_make(np.random.RandomState(seed), h, w), p_make(np.random.RandomState(seed), h, w)
+            assert len(got) == len(want)
+            for (alpha, intensity), layer in zip(got, want):
+                same(alpha, layer[0], 1.0 / 255.0)
+                same(intensity, layer[1], 255.0 / 5.0 / 255.0 * 2.0)           # the fine field: +- mean / 5 through an 8-bit image
+        got, want = On.snowflake_layers(np.random.RandomState(seed), h, w), Wt.snowflake_layers(np.random.RandomState(seed), h, w)
+        assert len(got) == len(want)
+        for (add, floor_), layer in zip(got, want):
+            # one level of the noise image, through the gamma table's steepest step and the re-gain (<= 6) and speed (<= 2) factors
+            same(add, layer[0], 12.0)
+            same(floor_, layer[1], 24.0)
+        got, want = On.rain_layers(np.random.RandomState(seed), h, w), Wt.rain_layers(np.random.RandomState(seed), h, w)
+        assert len(got) == len(want)
+        for (alpha, colour), layer in zip(got, want):
+            same(alpha, layer[0], 1.0 / 255.0)
+            if (alpha.reshape(-1)[:1000] == layer[0].reshape(-1)[:1000]).all():      # the drop colour is a function of those values
+                assert np.abs(colour - layer[1]).max() < 1e-3
+        sx, sy = On.piecewise_affine_map(np.random.RandomState(seed), h, w)
+        pm = Wt.piecewise_affine_map(np.random.RandomState(seed), h, w)[0]
+        assert np.abs(sx - pm[0]).max() < 1e-4 and np.abs(sy - pm[1]).max() < 1e-4

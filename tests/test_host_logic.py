@@ -25,7 +25,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert not missing, missing
     assert sorted(_lib.SIGNATURES) == declared, "ccd_amd/_lib.py signature table out of sync with include/ccd_hip.h"
     _lib.bind(lib)
-    assert lib.ccd_abi_version() == 9
+    assert lib.ccd_abi_version() == 10
 
 
 def test_product_has_no_cpu_fallback():
