@@ -37,6 +37,7 @@ SIGNATURES = {
     "ccd_gemm_tn_pair_ws_floats": [I, I, I, I],
     "ccd_gemm_nt_lnbwd": [P, L, P, L, I, I, I, P, L, P, P, P, P, L, I, P, P, P, L, P, I, P, P],
     "ccd_gemm_nt_lnbwd_g16": [P, L, P, L, I, I, I, P, L, P, P, P, P, L, I, P, P, P, L, P, I, P, P],
+    "ccd_gemm_nt_lnbwd_tap_g16": [P, L, P, L, I, I, I, P, L, P, P, P, P, L, I, P, P, P, L, P, I, P, P, L, P, P, P, P],
     "ccd_proj_mlp_fused": [P, L, P, L, P, P, L, P, P, P, P, L, P, L, P, P, P, L, P, P, L, P, P, I, P, L, P, P, F, P, L, P, P, P, L, P, P, P, L,
                            I, I, I, P],
     "ccd_mlp_fused": [P, L, P, L, P, P, L, P, P, L, P, I, P, L, P, P, F, P, L, P, P, P, L, P, L, I, I, I, P],

@@ -275,7 +275,7 @@ static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, float* ws, long ws_
 
 extern "C" {
 
-int ccd_abi_version(void) { return 10; }   // 10: ccd_head_loss_fwd / _bwd (last layer + distillation loss, logits never written), ccd_*_g16 (bf16 residual-gradient stream); 9: ccd_cls_tail_fwd / _bwd_reduce / _bwd_apply (BatchNorm + ReLU + classifier conv of the segmentation head fused); 8: ccd_proj_mlp_fused (proj + residual + LayerNorm-2 in front of the fused MLP), ccd_matvec_bf16; 7: ccd_gemm_tn_pair_ws (split-K workspace instead of fp32 atomics); 6: device-side momentum / DropPath seed (HIP graph of the training step); 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
+int ccd_abi_version(void) { return 11; }   // 11: ccd_gemm_nt_lnbwd_tap_g16 (a segmentation tap's LayerNorm backward inside the qkv data-gradient product's epilogue); 10: ccd_head_loss_fwd / _bwd (last layer + distillation loss, logits never written), ccd_*_g16 (bf16 residual-gradient stream); 9: ccd_cls_tail_fwd / _bwd_reduce / _bwd_apply (BatchNorm + ReLU + classifier conv of the segmentation head fused); 8: ccd_proj_mlp_fused (proj + residual + LayerNorm-2 in front of the fused MLP), ccd_matvec_bf16; 7: ccd_gemm_tn_pair_ws (split-K workspace instead of fp32 atomics); 6: device-side momentum / DropPath seed (HIP graph of the training step); 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
 const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi10"; }
 int ccd_policy_set(const char* key, int value) {
     CCD_CHECK(key, CCD_EINVAL);
@@ -390,10 +390,22 @@ int ccd_gemm_nt_resid_ln(const ccd_bf16* A, long lda, const ccd_bf16* B, long ld
     return ccd_launch_gemm_row384(p, 7 /* EPI_RESID_LN */, stream, cus);
 }
 
+struct CcdLnTap {       // a second LayerNorm backward of the same rows (rowgemm.h: TAP), or tap_dy == nullptr
+    const ccd_bf16* tap_dy = nullptr;
+    long ld_tap = 0;
+    const float* tap_gamma = nullptr;
+    float* tap_dgamma = nullptr;
+    float* tap_dbeta = nullptr;
+};
 static int ccd_gemm_nt_lnbwd_any(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, const float* x, long ldx,
                                  const float* mean, const float* rstd, const float* gamma, void* g, int g16, long ldg, int accumulate,
                                  float* dgamma, float* dbeta, ccd_bf16* gb, long ldgb, const float* rowscale, int rows_per_sample,
-                                 float* dbias, void* stream) {
+                                 float* dbias, void* stream, const CcdLnTap& tap = CcdLnTap()) {
+    if (tap.tap_dy) {       // the tap rides on the row-owner kernel of the bf16 gradient stream at N = 384 (the ViT-Small path) only
+        CCD_CHECK(tap.tap_gamma && tap.tap_dgamma && tap.tap_dbeta && CCD_ALIGNED16(tap.tap_dy) && tap.ld_tap % 8 == 0, CCD_EINVAL);
+        CCD_CHECK(g16 && N == 384 && ccd_policy().rowgemm && K % (64 * ccd::rg_ring(N)) == 0 && (long)M * tap.ld_tap * 2 < CCD_MAX_OPERAND_BYTES,
+                  CCD_ESHAPE);
+    }
     CCD_CHECK(A && B && x && mean && rstd && gamma && g && dgamma && dbeta, CCD_EINVAL);
     CCD_CHECK(CCD_ALIGNED16(A) && CCD_ALIGNED16(B) && CCD_ALIGNED16(x) && CCD_ALIGNED16(g) && CCD_ALIGNED16(gb), CCD_EINVAL);
     if (M == 0) return CCD_OK;
@@ -412,8 +424,15 @@ static int ccd_gemm_nt_lnbwd_any(const ccd_bf16* A, long lda, const ccd_bf16* B,
         q.dbias = gb ? dbias : nullptr; q.lab = ccd_policy().lab;
         q.bias = nullptr; q.resid = nullptr; q.out = nullptr; q.ln_beta = nullptr; q.ln_y = nullptr; q.ln_mean = q.ln_rstd = nullptr;
         q.ldr = q.ldc = q.ld_y = 0; q.ln_eps = 0.f;
+        q.tap_dy = tap.tap_dy; q.ld_tap = tap.ld_tap; q.tap_gamma = tap.tap_gamma; q.tap_dgamma = tap.tap_dgamma; q.tap_dbeta = tap.tap_dbeta;
         const int tiles = (M + ccd::RG_BM - 1) / ccd::RG_BM, smem = ccd::rg_smem_bytes(N);
         const dim3 grid(tiles < cus ? tiles : cus), block(ccd::RG_THREADS);
+        if (g16 && tap.tap_dy) {
+            if (ccd_policy().rowgemm_adma)
+                CCD_LAUNCH((ccd::rowgemm_kernel<384, 3, ccd::RG_LNBWD, true, true, true>), grid, block, ccd::rg_smem_bytes_adma(384, true), stream, q);
+            else CCD_LAUNCH((ccd::rowgemm_kernel<384, ccd::rg_ring(384), ccd::RG_LNBWD, false, true, true>), grid, block, ccd::rg_smem_bytes(384, true), stream, q);
+            return ccd_rt_last_error();
+        }
         if (g16) {             // round 6: the residual-gradient stream in bf16
             if (N == 384 && ccd_policy().rowgemm_adma)
                 CCD_LAUNCH((ccd::rowgemm_kernel<384, 3, ccd::RG_LNBWD, true, true>), grid, block, ccd::rg_smem_bytes_adma(384), stream, q);
@@ -454,6 +473,18 @@ int ccd_gemm_nt_lnbwd_g16(const ccd_bf16* A, long lda, const ccd_bf16* B, long l
                           float* dbias, void* stream) {
     return ccd_gemm_nt_lnbwd_any(A, lda, B, ldb, M, N, K, x, ldx, mean, rstd, gamma, g, 1, ldg, accumulate, dgamma, dbeta, gb, ldgb, rowscale,
                                  rows_per_sample, dbias, stream);
+}
+
+int ccd_gemm_nt_lnbwd_tap_g16(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, const float* x, long ldx,
+                              const float* mean, const float* rstd, const float* gamma, ccd_bf16* g, long ldg, int accumulate,
+                              float* dgamma, float* dbeta, ccd_bf16* gb, long ldgb, const float* rowscale, int rows_per_sample,
+                              float* dbias, const ccd_bf16* tap_dy, long ld_tap, const float* tap_gamma, float* tap_dgamma,
+                              float* tap_dbeta, void* stream) {
+    CCD_CHECK(tap_dy, CCD_EINVAL);
+    CcdLnTap tap;
+    tap.tap_dy = tap_dy; tap.ld_tap = ld_tap; tap.tap_gamma = tap_gamma; tap.tap_dgamma = tap_dgamma; tap.tap_dbeta = tap_dbeta;
+    return ccd_gemm_nt_lnbwd_any(A, lda, B, ldb, M, N, K, x, ldx, mean, rstd, gamma, g, 1, ldg, accumulate, dgamma, dbeta, gb, ldgb, rowscale,
+                                 rows_per_sample, dbias, stream, tap);
 }
 
 int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, const float* b1, const ccd_bf16* w2, long ld2,

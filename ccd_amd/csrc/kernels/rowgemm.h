@@ -60,6 +60,15 @@ struct RowGemmParams {
     float* ln_mean;
     float* ln_rstd;
     int lab;                // experiment switch (policy key "lab"): n > 0 delays odd workgroups by ~n * 8 k cycles
+    // TAP (round 6): a SECOND LayerNorm of the same rows - a segmentation tap (vision_transformer.py:245-249, norm_seg: other gamma /
+    // beta, same statistics) - whose backward pass ran as a launch of its own (ln_bwd: d_tap, x, g read, g and gb written: 0.19 ms,
+    // three taps per step).  LayerNorm's backward is linear in dy * gamma: dx = core(dy1 * gamma1 + d_tap * gamma_tap), so the tap's
+    // gradient joins the product's accumulators in pass A (one more bf16 row stream) and x, g, gb move once.
+    const bf16_t* tap_dy;   // [M, E] bf16: gradient of the tap's output, or unused (TAP instantiations only)
+    long ld_tap;
+    const float* tap_gamma; // [E]
+    float* tap_dgamma;      // [E] +=
+    float* tap_dbeta;
 };
 
 constexpr int RG_SCRATCH = 4096, RG_THREADS = 256, RG_BM = 128;
@@ -76,14 +85,14 @@ constexpr int RG_LNBWD = 0, RG_RESID_LN = 1;
 // consumed last (free until the next tile's first window refills it; one barrier per tile in front of its first use).
 // VMEM per window: hh = 0 issues the 4 activation DMAs (steps 0, 2, 4, 6: block b + 3, slot b % 3) and KT ring requests (steps
 // 1, 5, ...), hh = 1 the KT requests only: any two consecutive windows issue 2 KT + 4, the ring's counted wait.
-__host__ __device__ inline int rg_smem_bytes_adma(int E) { return 4 * mlp_piece_bytes(E) + 4 * 3 * 4096 + 4 * E * 4; }
+__host__ __device__ inline int rg_smem_bytes_adma(int E, bool tap = false) { return 4 * mlp_piece_bytes(E) + 4 * 3 * 4096 + (tap ? 7 : 4) * E * 4; }
 struct RgAdmaExtra {       // window hh = 1: the next block's four fragment reads ride behind MFMA steps 2, 6, 10, 14
     static constexpr int at(int k) { return (k % 4 == 2 && k < 16) ? 1 : 0; }
 };
 // ring slots: 5 (four pieces ahead) where 160 KiB allow it, 4 at E = 512 (32-KiB pieces)
 __host__ __device__ constexpr int rg_slots(int E) { return E <= 384 ? 5 : 4; }
-__host__ __device__ inline int rg_smem_bytes(int E) {
-    return rg_slots(E) * mlp_piece_bytes(E) + 4 * RG_SCRATCH + 4 * E * 4;   // ring, scratch, gamma + 3 vectors (sums | beta, bias)
+__host__ __device__ inline int rg_smem_bytes(int E, bool tap = false) {
+    return rg_slots(E) * mlp_piece_bytes(E) + 4 * RG_SCRATCH + (tap ? 7 : 4) * E * 4;   // ring, scratch, gamma + 3 vectors (sums | beta, bias) [+ the tap's gamma and 2 sums]
 }
 
 // activation k-blocks a lane holds (the newest arrives R - 1 blocks = 2 (R - 1) pieces ahead of its use): 48 registers at
@@ -132,9 +141,10 @@ __device__ __forceinline__ void rg_colsum16(const float (&v)[16], float* dst, in
     atomicAdd(dst + 8 * ((lq >> 2) & 3) + 4 * hf + (lq & 3), rg_fold16(v, lq));
 }
 
-template <int E, int R, int EPI, bool ADMA = false, bool G16 = false>
+template <int E, int R, int EPI, bool ADMA = false, bool G16 = false, bool TAP = false>
 __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p) {
     static_assert(!G16 || EPI == RG_LNBWD, "the bf16 stream is the LayerNorm-backward epilogue's");
+    static_assert(!TAP || EPI == RG_LNBWD, "the tap is a second LayerNorm backward of the same rows");
     constexpr int RG_NSLOT = ADMA ? 4 : rg_slots(E);
     static_assert(!ADMA || (E == 384 && R == 3), "activation DMA: 3 image slots per wave, 160 KiB of LDS at E = 384");
     constexpr int KT = E / 64;             // ring requests (1 KiB wave instructions) per wave and piece
@@ -158,10 +168,13 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
     float* cs = vga + E;                   // RG_LNBWD: [3][E] dgamma, dbeta, dbias of this workgroup
     float* vbe = vga + E;                  // RG_RESID_LN: beta, bias
     float* vbi = vbe + E;
+    float* vgt = cs + 3 * E;               // TAP: the tap's gamma, then [2][E] its dgamma, dbeta of this workgroup
+    float* cst = vgt + E;
     for (int i = t; i < E; i += RG_THREADS) {
         vga[i] = p.gamma[i];
         if (EPI == RG_LNBWD) { cs[i] = 0.f; cs[E + i] = 0.f; cs[2 * E + i] = 0.f; }
         else { vbe[i] = p.ln_beta[i]; vbi[i] = p.bias ? p.bias[i] : 0.f; }
+        if constexpr (TAP) { vgt[i] = p.tap_gamma[i]; cst[i] = 0.f; cst[E + i] = 0.f; }
     }
     __syncthreads();
 
@@ -465,9 +478,16 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
             const unsigned lo_x = LaneOff(t).frag(p.ldx, 4, 4);
             constexpr int PA = 4;          // tiles of x in flight (HBM latency x 14 GB/s per CU and tile in flight)
             u32x4 xb[PA][4];
+            // TAP: the lane's four bf16 of d_tap per column group, the same tiles ahead
+            const buf_rsrc rs_t = make_rsrc(TAP ? p.tap_dy : nullptr, TAP ? (unsigned)((((long)p.M - 1) * p.ld_tap + E) * 2) : 0u);
+            const unsigned lo_t = TAP ? LaneOff(t).frag(p.ld_tap, 2, 4) : 0u, so_t = TAP ? (unsigned)r0 * (unsigned)(p.ld_tap * 2) : 0u;
+            buf_u32x2 tb[TAP ? PA : 1][4];
             auto load_x = [&](int nt) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) xb[nt % PA][g] = stream_load16<NT_RG_X>(rs_x, lo_x, so_x + (32 * nt + 8 * g) * 4);
+                for (int g = 0; g < 4; ++g) {
+                    xb[nt % PA][g] = stream_load16<NT_RG_X>(rs_x, lo_x, so_x + (32 * nt + 8 * g) * 4);
+                    if constexpr (TAP) tb[nt % PA][g] = buf_load8(rs_t, lo_t, so_t + (32 * nt + 8 * g) * 2);
+                }
             };
 #pragma unroll
             for (int nt = 0; nt < PA - 1 && nt < NT; ++nt) load_x(nt);
@@ -482,7 +502,13 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
                     const float xx[4] = {x.x, x.y, x.z, x.w}, gg[4] = {ga.x, ga.y, ga.z, ga.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float dy = acc[nt][4 * g + e], xh = (xx[e] - mu) * rs, dg = dy * gg[e];
+                        const float dy = acc[nt][4 * g + e], xh = (xx[e] - mu) * rs;
+                        float dg = dy * gg[e];
+                        if constexpr (TAP) {       // the tap's share of dy * gamma (its own column sums follow below, on tb again)
+                            const unsigned wd = (e < 2) ? tb[nt % PA][g].x : tb[nt % PA][g].y;
+                            const float dt = (e & 1) ? bf_hi(wd) : bf_lo(wd);
+                            dg = fmaf(dt, vgt[32 * nt + 8 * g + 4 * hf + e], dg);
+                        }
                         // what pass B needs, in the accumulator's own register, so that x is read once: dy * gamma rounded to 12
                         // mantissa bits (the unfused pair rounds dy to 8) above xhat in 12-bit fixed point (|xhat| < 20, steps of 0.01;
                         // it only scales the small second-moment correction)
@@ -496,6 +522,21 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
                 }
                 rg_colsum16(vg, cs + 32 * nt, lq, hf);
                 rg_colsum16(vb, cs + E + 32 * nt, lq, hf);
+                if constexpr (TAP) {           // dgamma_tap += colsum(d_tap * xhat), dbeta_tap += colsum(d_tap): xhat back out of the packed word
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned wd = (e < 2) ? tb[nt % PA][g].x : tb[nt % PA][g].y;
+                            const float dt = (e & 1) ? bf_hi(wd) : bf_lo(wd);
+                            const f32x4v xv = __builtin_bit_cast(f32x4v, xb[nt % PA][g]);
+                            const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+                            vg[4 * g + e] = dt * ((xx[e] - mu) * rs);
+                            vb[4 * g + e] = dt;
+                        }
+                    rg_colsum16(vg, cst + 32 * nt, lq, hf);
+                    rg_colsum16(vb, cst + E + 32 * nt, lq, hf);
+                }
                 CCD_SCHED_FENCE();             // one tile at a time: interleaved tiles (and every load of the pass hoisted to
                 asm volatile("" ::: "memory");   // its top) cost more registers than there are
             }
@@ -619,6 +660,10 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rowgemm_kernel(RowGemmParams p)
             atomicAdd(p.dgamma + i, cs[i]);
             atomicAdd(p.dbeta + i, cs[E + i]);
             if (p.dbias) atomicAdd(p.dbias + i, cs[2 * E + i]);
+            if constexpr (TAP) {
+                atomicAdd(p.tap_dgamma + i, cst[i]);
+                atomicAdd(p.tap_dbeta + i, cst[E + i]);
+            }
         }
     }
 #ifdef CCD_MLP_LAB

@@ -45,6 +45,9 @@ class Fusion:
     ln = _env_switch("CCD_FUSE_LN")                # LayerNorm in the epilogue of proj / fc2   (default: E <= 384)
     mlp = _env_switch("CCD_FUSE_MLP")              # fc1 -> GELU -> fc2 -> residual -> LayerNorm in one launch (default: with `ln`)
     lnbwd = _env_switch("CCD_FUSE_LNBWD")          # LayerNorm backward in the epilogue of the data-gradient product (default: on)
+    fold_tap = _env_switch("CCD_FOLD_TAP")         # a tap's LayerNorm backward inside the qkv data-gradient product of the block above
+    if fold_tap is None:                           # (round 6; CCD_FOLD_TAP=0: the separate ccd_ln_bwd launch per tap)
+        fold_tap = True
     store_gact = _env_switch("CCD_STORE_GACT")     # the fused MLP forward also stores gelu(u) for the backward pass (default: off -
     if store_gact is None:                         # a measured tie, 52.9 vs 53.0 ms per step: + 0.47 ms forward, - 0.75 ms gelu'(u)
         store_gact = False                         # product, + 0.2 GB per block of saved activations at B = 256)
@@ -346,10 +349,13 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
         have_gb = bool(tail)
     else:
         g.zero_()
+    # A tap behind block i is a second LayerNorm of the rows that norm1 of block i + 1 normalises (same statistics): its backward pass
+    # rides in the epilogue of block i + 1's qkv data-gradient product (ccd_gemm_nt_lnbwd_tap_g16) instead of a launch of its own
+    fold_taps = fuse_lnbwd and Fusion.fold_tap and ops.lnbwd_tap_supported(g, E)
     for i in reversed(range(spec.depth)):
         b = f"{pre}blocks.{i}."
         c = ctxs[i]
-        if i in tap_at:
+        if i in tap_at and not (fold_taps and i + 1 < spec.depth):
             j, xt, m, r = tap_at[i]
             ops.ln_bwd(d_taps[j].reshape(R, E), xt, m, r, arena.w(f"{pre}norm_seg.{j}.weight"), g,
                        arena.g(f"{pre}norm_seg.{j}.weight"), arena.g(f"{pre}norm_seg.{j}.bias"), accumulate=True,
@@ -410,10 +416,15 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
         def qkv_grads(gb=gb, d_qkv=d_qkv):
             # proj.weight's gradient waits for qkv.weight's: one launch for both
             ops.gemm_tn_pair(gb, att.view(R, E), arena.g(b + "attn.proj.weight"), d_qkv, y1, arena.g(b + "attn.qkv.weight"))
-        want_tail = i > 0 and (i - 1) not in tap_at
+        fold_here = fold_taps and (i - 1) in tap_at
+        want_tail = i > 0 and ((i - 1) not in tap_at or fold_here)
         if fuse_lnbwd:
             readers[cur[0]] = side.run(qkv_grads, gb, att, d_qkv, y1)
             tail = mlp_tail(i - 1) if want_tail else {}
+            if fold_here:      # the tap behind block i - 1: x_in of this block IS the tap's input, mean1 / rstd1 its statistics
+                j = tap_at[i - 1][0]
+                tail["tap"] = (d_taps[j].reshape(R, E), arena.w(f"{pre}norm_seg.{j}.weight"), arena.g(f"{pre}norm_seg.{j}.weight"),
+                               arena.g(f"{pre}norm_seg.{j}.bias"))
             ops.gemm_nt_lnbwd(d_qkv, arena.wbt(b + "attn.qkv.weight"), c.x_in, c.mean1, c.rstd1, arena.w(b + "norm1.weight"), g,
                               arena.g(b + "norm1.weight"), arena.g(b + "norm1.bias"), accumulate=True, **tail)
         else:

@@ -154,10 +154,17 @@ def gemm_nt_resid_ln(a, b, *, bias, resid, rowscale, rows_per_sample, gamma, bet
     return out, y, mean, rstd
 
 
+def lnbwd_tap_supported(g, N):
+    """ccd_gemm_nt_lnbwd_tap_g16 takes the bf16 gradient stream at N = 384 (the ViT-Small path)."""
+    return g.dtype == BF16 and N == 384 and policy_get("rowgemm") != 0
+
+
 def gemm_nt_lnbwd(a, b, x, mean, rstd, gamma, g, dgamma, dbeta, accumulate=True, gb=None, rowscale=None, rows_per_sample=1,
-                  dbias=None):
+                  dbias=None, tap=None):
     """dy = a @ b^T is the gradient of a LayerNorm output: g (+)= LN'(dy) with dgamma / dbeta (+ the bf16 tail of ln_bwd) in
-    the epilogue of the product - dy never reaches HBM (ccd_gemm_nt + ccd_ln_bwd in one launch; N <= 384 or N = 512)."""
+    the epilogue of the product - dy never reaches HBM (ccd_gemm_nt + ccd_ln_bwd in one launch; N <= 384 or N = 512).
+    tap = (d_tap bf16 [M, N], tap_gamma, tap_dgamma, tap_dbeta): a second LayerNorm of the same rows (a segmentation tap: same
+    statistics, other gamma) whose backward pass joins the epilogue (lnbwd_tap_supported)."""
     g16 = g.dtype == BF16           # (round 6) the residual-gradient stream in bf16: ccd_gemm_nt_lnbwd_g16
     _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(x, F32, "x"); _chk(g, BF16 if g16 else F32, "g"); _chk(gb, BF16, "gb")
     M, K = a.shape
@@ -168,10 +175,18 @@ def gemm_nt_lnbwd(a, b, x, mean, rstd, gamma, g, dgamma, dbeta, accumulate=True,
                       + (2.0 * M * N if gb is not None else 0.0)) if TIMER is not None else None
     if span:
         span[0].record()
-    _call("ccd_gemm_nt_lnbwd_g16" if g16 else "ccd_gemm_nt_lnbwd", _lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0), M, N, K, _lib.ptr(x), x.stride(0),
-          _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(g), g.stride(0), 1 if accumulate else 0, _lib.ptr(dgamma),
-          _lib.ptr(dbeta), _lib.ptr(gb), 0 if gb is None else gb.stride(0), _lib.ptr(rowscale), int(rows_per_sample),
-          _lib.ptr(dbias))
+    common = (_lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0), M, N, K, _lib.ptr(x), x.stride(0),
+              _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(g), g.stride(0), 1 if accumulate else 0, _lib.ptr(dgamma),
+              _lib.ptr(dbeta), _lib.ptr(gb), 0 if gb is None else gb.stride(0), _lib.ptr(rowscale), int(rows_per_sample),
+              _lib.ptr(dbias))
+    if tap is not None:
+        d_tap, tap_gamma, tap_dgamma, tap_dbeta = tap
+        _chk(d_tap, BF16, "d_tap")
+        assert g16 and tuple(d_tap.shape) == (M, N)
+        _call("ccd_gemm_nt_lnbwd_tap_g16", *common, _lib.ptr(d_tap), d_tap.stride(0), _lib.ptr(tap_gamma), _lib.ptr(tap_dgamma),
+              _lib.ptr(tap_dbeta))
+    else:
+        _call("ccd_gemm_nt_lnbwd_g16" if g16 else "ccd_gemm_nt_lnbwd", *common)
     if span:
         span[1].record()
     return g

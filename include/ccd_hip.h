@@ -95,6 +95,16 @@ int ccd_gemm_nt_lnbwd_g16(const ccd_bf16* A, long lda, const ccd_bf16* B, long l
                           const float* mean, const float* rstd, const float* gamma, ccd_bf16* g, long ldg, int accumulate,
                           float* dgamma, float* dbeta, ccd_bf16* gb, long ldgb, const float* rowscale, int rows_per_sample,
                           float* dbias, void* stream);
+/* The same with a SECOND LayerNorm of the same rows folded into the epilogue (ABI 11; N == 384 only - CCD_ESHAPE otherwise): a
+ * segmentation tap (Dino/modules/vision_transformer.py:245-249: norm_seg[j](x) of the rows that norm1 of the next block also
+ * normalises - same mean / rstd, other gamma).  LayerNorm's backward is linear in dy * gamma, so
+ *   dx = core(dy * gamma + tap_dy * tap_gamma);  tap_dgamma += colsum(tap_dy * xhat);  tap_dbeta += colsum(tap_dy)
+ * and x, g, gb move once instead of twice.  Replaces ccd_gemm_nt_lnbwd_g16 + ccd_ln_bwd of the tap (tap_dy: [M, N] bf16). */
+int ccd_gemm_nt_lnbwd_tap_g16(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int M, int N, int K, const float* x, long ldx,
+                              const float* mean, const float* rstd, const float* gamma, ccd_bf16* g, long ldg, int accumulate,
+                              float* dgamma, float* dbeta, ccd_bf16* gb, long ldgb, const float* rowscale, int rows_per_sample,
+                              float* dbias, const ccd_bf16* tap_dy, long ld_tap, const float* tap_gamma, float* tap_dgamma,
+                              float* tap_dbeta, void* stream);
 /* The whole MLP branch of a transformer block in one launch (Mlp.forward + the residual of Block.forward,
  * Dino/modules/vision_transformer.py:59-65,107-113, and the LayerNorm that consumes the stream next, :99/:156):
  *   h = gelu(bf16(y . W1^T + b1)) ;  out (f32) = resid + (h . W2^T + b2) * rowscale[row / rows_per_sample]

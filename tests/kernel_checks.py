@@ -1338,9 +1338,11 @@ def check_matvec_bf16(dev, K=1000, D=256, seed=51):
     close(cs, logits.sum(0), 1e-4, 1e-4, "column sums of zn @ w^T through the factors")
 
 
-def check_gemm_lnbwd(dev, M, N, K, seed=33, g16=False):
+def check_gemm_lnbwd(dev, M, N, K, seed=33, g16=False, tap=False):
     """Data-gradient product with the LayerNorm backward in its epilogue == gemm_nt followed by ln_bwd, and both == autograd.
-    g16: the gradient stream g is a bf16 tensor (ccd_gemm_nt_lnbwd_g16) - read as bf16, accumulated in fp32, rounded once."""
+    g16: the gradient stream g is a bf16 tensor (ccd_gemm_nt_lnbwd_g16) - read as bf16, accumulated in fp32, rounded once.
+    tap: a second LayerNorm of the same rows (other gamma / beta) whose output gradient arrives as a bf16 tensor and whose backward
+    pass joins the epilogue (ccd_gemm_nt_lnbwd_tap_g16) == autograd of the SUM of the two LayerNorms (vision_transformer.py:245-249)."""
     g = torch.Generator().manual_seed(seed)
     a = rnd((M, K), g).to(BF); b = rnd((N, K), g, 0.2).to(BF)
     x = rnd((M, N), g) * 2 + 0.3
@@ -1355,6 +1357,11 @@ def check_gemm_lnbwd(dev, M, N, K, seed=33, g16=False):
     dy = a.float() @ b.float().t()
     xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = torch.zeros(N, requires_grad=True)
     F.layer_norm(xr, (N,), gr, br, 1e-6).backward(dy)
+    if tap:
+        gamma_t = 1 + 0.2 * rnd((N,), g)
+        d_tap = (rnd((M, N), g) * float(dy.std())).to(BF)
+        gtr = gamma_t.clone().requires_grad_(True); btr = torch.zeros(N, requires_grad=True)
+        F.layer_norm(xr, (N,), gtr, btr, 1e-6).backward(d_tap.float())          # accumulates onto xr.grad
     scale_dy = float(dy.pow(2).mean().sqrt())
     for acc in (True, False):
         for tail in (True, False):
@@ -1362,14 +1369,21 @@ def check_gemm_lnbwd(dev, M, N, K, seed=33, g16=False):
             dgam = torch.full((N,), 0.5).to(dev); dbet = torch.full((N,), -0.25).to(dev)
             gb = torch.zeros(M, N, dtype=BF).to(dev) if tail else None
             dbias = torch.full((N,), 0.25).to(dev)
+            tap_kw = {}
+            if tap:
+                dgam_t = torch.full((N,), 0.125).to(dev); dbet_t = torch.full((N,), -0.5).to(dev)
+                tap_kw["tap"] = (d_tap.to(dev), gamma_t.to(dev), dgam_t, dbet_t)
             ops.gemm_nt_lnbwd(a.to(dev), b.to(dev), x.to(dev), mean.to(dev), rstd.to(dev), gamma.to(dev), gbuf, dgam, dbet,
                               accumulate=acc, gb=gb, rowscale=rowscale.to(dev) if tail else None, rows_per_sample=rps,
-                              dbias=dbias if tail else None)
+                              dbias=dbias if tail else None, **tap_kw)
             want_g = xr.grad + (g0 if acc else 0)
             tag = f"lnbwd acc={acc} tail={tail}"
             close(gbuf, want_g, 1e-2 if g16 else 2e-3, 2e-3 * scale_dy, tag + "/g")
             close(dgam, gr.grad + 0.5, 2e-3, 2e-3 * scale_dy * M ** 0.5, tag + "/dgamma")
             close(dbet, br.grad - 0.25, 2e-3, 2e-3 * scale_dy * M ** 0.5, tag + "/dbeta")
+            if tap:
+                close(dgam_t, gtr.grad + 0.125, 2e-3, 2e-3 * scale_dy * M ** 0.5, tag + "/tap dgamma")
+                close(dbet_t, btr.grad - 0.5, 2e-3, 2e-3 * scale_dy * M ** 0.5, tag + "/tap dbeta")
             if tail:
                 want_gb = (want_g * rowscale.repeat_interleave(rps)[:M, None])
                 close(gb, want_gb, 1e-2, 1e-2 * scale_dy, tag + "/gb")

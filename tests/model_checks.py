@@ -383,6 +383,47 @@ def check_small3_steps(device, loss_tol=1e-3):
     return report
 
 
+def check_fold_tap_matches_separate(device, E=384, batch=4, drop_path=0.3):
+    """A tap's LayerNorm backward inside the qkv data-gradient product of the block above (engine.Fusion.fold_tap,
+    ccd_gemm_nt_lnbwd_tap_g16) against the separate ccd_ln_bwd launch per tap: the same sums in another order - every gradient
+    tensor agrees to the rounding of the bf16 stream, the norm_seg gradients (what the fold computes itself) tensor by tensor."""
+    from ccd_amd import engine
+    results = {}
+    saved = engine.Fusion.fold_tap
+    names = ["backbone.norm_seg.0.weight", "backbone.norm_seg.0.bias", "backbone.norm_seg.1.weight", "backbone.norm_seg.1.bias",
+             "backbone.blocks.2.norm1.weight", "backbone.blocks.0.mlp.fc2.bias", "backbone.patch_embed.proj.weight"]
+    try:
+        for fold in (False, True):
+            engine.Fusion.fold_tap = fold
+            torch.manual_seed(5)
+            np.random.seed(5)
+            engine._DROPPATH_SEED.update(base=91, calls=0)
+            student, teacher = pretrain.build_networks(
+                arch=None, out_dim=512, drop_path_rate=drop_path, norm_last_layer=False, seg_channel=E,
+                backbone_kwargs=dict(embed_dim=E, depth=4, num_heads=E // 64, out_indices=[1, 2, 4]),
+                head_kwargs=dict(hidden_dim=256, bottleneck_dim=64), device=device)
+            assert engine.Fusion.resolve_g16(E), "the fold rides on the bf16 gradient stream"
+            dino_loss = DINOLoss(512, 2, 0.04, 0.04, 0, 40).to(device)
+            images, masks, metrics = make_batch(batch, seed=13, device=device)
+            opt = pretrain.make_optimizer(student, clip_grad=3.0)
+            loss = pretrain.training_iteration(student, teacher, dino_loss, opt, images, masks, metrics, 1, 2e-4, 0.05, 0.99)
+            if device.type == "cuda":
+                torch.cuda.synchronize()
+            results[fold] = (loss.item(), student.arena.grad.clone(), {n: student.arena.g(n).clone() for n in names})
+    finally:
+        engine.Fusion.fold_tap = saved
+        engine._DROPPATH_SEED.update(base=None, calls=0)
+    (l0, g0, t0), (l1, g1, t1) = results[False], results[True]
+    assert abs(l0 - l1) < 1e-5, (l0, l1)
+    report = {"loss": [l0, l1], "rel_grad_all": ((g1 - g0).double().norm() / g0.double().norm()).item()}
+    assert report["rel_grad_all"] < 1e-2, report
+    for n in names:
+        rel = ((t1[n] - t0[n]).double().norm() / t0[n].double().norm().clamp_min(1e-30)).item()
+        report["rel_" + n] = rel
+        assert rel < 1e-2, (n, rel)
+    return report
+
+
 def check_g_bf16_matches_fp32(device, E=128, batch=2, drop_path=0.3):
     """The backward pass with its residual-gradient stream as a bf16 tensor (engine.Fusion.g_bf16, ccd_*_g16) against the fp32
     stream: the forward pass and the losses are the same computation, every gradient tensor agrees to bf16 rounding of ONE stream

@@ -208,9 +208,10 @@ def test_row_owner_kernels_stay_within_their_recorded_spill_ceilings():
         r"ccd::mlp_fused_kernel<384, true, true>": (78, 101, 304),
         r"ccd::mlp_fused_kernel<384, false, false>": (0, 0, 0),
         r"ccd::mlp_fused_kernel<384, true, false>": (0, 24, 0),
-        r"ccd::rowgemm_kernel<384, 3, 0, true, false>": (2, 12, 12),
-        r"ccd::rowgemm_kernel<384, 3, 0, true, true>": (2, 12, 12),
-        r"ccd::rowgemm_kernel<384, 3, 1, true, false>": (0, 0, 0),
+        r"ccd::rowgemm_kernel<384, 3, 0, true, false, false>": (2, 12, 12),
+        r"ccd::rowgemm_kernel<384, 3, 0, true, true, false>": (2, 12, 12),
+        r"ccd::rowgemm_kernel<384, 3, 0, true, true, true>": (2, 24, 12),          # + a tap's LayerNorm backward in the epilogue
+        r"ccd::rowgemm_kernel<384, 3, 1, true, false, false>": (0, 0, 0),
         r"ccd::rowproj_kernel<384, 2>": (0, 0, 0),
         r"ccd::attention_bwd_onepass_kernel": (0, 10, 0),
         r"ccd::attention_fwd_kernel": (0, 0, 0),

@@ -255,6 +255,16 @@ def test_gemm_lnbwd_bf16_stream(hip, M, N, K):
             kc.check_gemm_lnbwd(hip.device, M=M, N=N, K=K, seed=36, g16=True)
 
 
+@pytest.mark.parametrize("M,K", [(300, 384), (4096, 1536), (40000, 1152), (131072 + 40, 1152)])
+def test_gemm_lnbwd_with_tap(hip, M, K):
+    """ccd_gemm_nt_lnbwd_tap_g16: a segmentation tap's LayerNorm backward inside the epilogue of the qkv data-gradient product."""
+    from ccd_amd import ops
+    kc.check_gemm_lnbwd(hip.device, M=M, N=384, K=K, seed=41, g16=True, tap=True)
+    if M <= 4096:
+        with ops.policy(rowgemm_adma=0):
+            kc.check_gemm_lnbwd(hip.device, M=M, N=384, K=K, seed=42, g16=True, tap=True)
+
+
 def test_gemm_lnbwd_row384_kernel(hip):
     from ccd_amd import ops
     with ops.policy(rowgemm=0):

@@ -258,6 +258,11 @@ def test_gemm_lnbwd_sim(sim):
     kc.check_gemm_lnbwd(sim.device, M=260, N=256, K=256, g16=True)
     with ops.policy(rowgemm_adma=0):
         kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=384, seed=35, g16=True)
+    # round 6: a tap's LayerNorm backward in the same epilogue (both row loaders)
+    kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=384, seed=37, g16=True, tap=True)
+    kc.check_gemm_lnbwd(sim.device, M=1100, N=384, K=576, seed=38, g16=True, tap=True)
+    with ops.policy(rowgemm_adma=0):
+        kc.check_gemm_lnbwd(sim.device, M=300, N=384, K=384, seed=39, g16=True, tap=True)
 
 
 def test_gemm_resid_ln_sim(sim):

@@ -49,6 +49,14 @@ def test_distributed_path_on_one_rank(hip):
         json.dump(report, f)
 
 
+def test_fold_tap_matches_separate_launch(hip):
+    """Taps behind blocks 1 and 2 fold into the qkv products of blocks 2 and 3; the tap behind the last block keeps its own launch."""
+    report = mc.check_fold_tap_matches_separate(hip.device, E=384, batch=4)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/fold_tap_vs_separate.json", "w") as f:
+        json.dump(report, f)
+
+
 def test_g_bf16_matches_fp32(hip):
     report = mc.check_g_bf16_matches_fp32(hip.device, E=384, batch=8)
     os.makedirs("gpurun_out", exist_ok=True)
