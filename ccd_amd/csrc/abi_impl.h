@@ -111,8 +111,6 @@ struct CcdPolicy {
     int cu_reserve_left = 0;    // re-arms it with N whenever it starts a bucket's all-reduce: the kernels that run beside the collective)
     int rowgemm_adma = 1;       // row-owner products at N = 384: the activation rows by LDS-DMA into per-wave images (rowgemm.h, ADMA); 0 = row-per-lane register loads
     int tn_ws = 1;              // paired weight gradients: per-slice partial stores + a reduction pass when the caller lends a workspace (0 = fp32 atomics)
-    int conv_256 = 1;           // implicit-GEMM convolutions with >= conv_256_min_m output pixels and N >= 128 on the 256-row LDS-DMA tile (gemm256.h, CONV); 0 = the 128-square kernel
-    int conv_256_min_m = 16384; // 2: 256-wide column tiles where N >= 256
     int lab = 0;                // scratch switch for kernel experiments (tools/*_lab.py); 0 in production
 };
 struct CcdPolicyKey { const char* name; int CcdPolicy::*field; };
@@ -121,7 +119,7 @@ static const CcdPolicyKey ccd_policy_keys[] = {
     {"gemm_256_min_n", &CcdPolicy::gemm_256_min_n}, {"gemm_256_f32", &CcdPolicy::gemm_256_f32},
     {"gemm_256_deep", &CcdPolicy::gemm_256_deep}, {"gemm_row384", &CcdPolicy::gemm_row384},
     {"rowproj", &CcdPolicy::rowproj}, {"rowproj_min_m", &CcdPolicy::rowproj_min_m}, {"rowproj_rb", &CcdPolicy::rowproj_rb},
-    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_onepass", &CcdPolicy::attn_onepass}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"rowgemm_adma", &CcdPolicy::rowgemm_adma}, {"tn_ws", &CcdPolicy::tn_ws}, {"conv_256", &CcdPolicy::conv_256}, {"conv_256_min_m", &CcdPolicy::conv_256_min_m}, {"lab", &CcdPolicy::lab}};
+    {"rowgemm", &CcdPolicy::rowgemm}, {"ln_bwd_bpc", &CcdPolicy::ln_bwd_bpc}, {"dec_attn_simt", &CcdPolicy::dec_attn_simt}, {"attn_onepass", &CcdPolicy::attn_onepass}, {"attn_skew", &CcdPolicy::attn_skew}, {"attn_tr", &CcdPolicy::attn_tr}, {"gemm_tn384", &CcdPolicy::gemm_tn384}, {"gemm_tn384_min_tiles", &CcdPolicy::gemm_tn384_min_tiles}, {"gemm_tn384_geom", &CcdPolicy::gemm_tn384_geom}, {"cu_reserve", &CcdPolicy::cu_reserve}, {"cu_reserve_window", &CcdPolicy::cu_reserve_window}, {"cu_reserve_left", &CcdPolicy::cu_reserve_left}, {"rowgemm_adma", &CcdPolicy::rowgemm_adma}, {"tn_ws", &CcdPolicy::tn_ws}, {"lab", &CcdPolicy::lab}};
 static CcdPolicy& ccd_policy() {
     static CcdPolicy pol = [] {
         CcdPolicy q;
@@ -1197,20 +1195,6 @@ int ccd_conv_gemm(const ccd_bf16* src, long src_ld, const ccd_conv_desc* desc, c
     p.colsum = colsum; p.colsumsq = colsumsq;
     ccd_fill_gather(p, desc);
     p.c_map = desc->c_map; p.c_py = desc->c_py; p.c_px = desc->c_px;
-    const CcdPolicy& pol = ccd_policy();
-    if (pol.conv_256 && M >= pol.conv_256_min_m && N >= 128 && N <= ccd::G256_MAX_COLSUM_N / 2 && (colsum || !colsumsq)) {
-        // the 256-row LDS-DMA tile (gemm256.h, CONV): the tap gather by the buffer form of the DMA
-        const size_t smem = (size_t)ccd::G256_SMEM_BYTES + (colsum ? (size_t)N * 4 : 0) + (colsumsq ? (size_t)N * 4 : 0);
-        const int cus = ccd_grid_cus();
-        if (pol.conv_256 >= 2 && N >= 256) {
-            const int tiles256 = ((M + ccd::G256_BM - 1) / ccd::G256_BM) * ((N + 255) / 256);
-            CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_BF16, 256, false, true>), dim3(tiles256 < cus ? tiles256 : cus), dim3(ccd::G256_THREADS), smem, stream, p);
-        } else {
-            const int tiles256 = ((M + ccd::G256_BM - 1) / ccd::G256_BM) * ((N + 127) / 128);
-            CCD_LAUNCH((ccd::gemm256_kernel<ccd::EPI_BF16, 128, false, true>), dim3(tiles256 < cus ? tiles256 : cus), dim3(ccd::G256_THREADS), smem, stream, p);
-        }
-        return ccd_rt_last_error();
-    }
     const int tiles = ((M + ccd::GEMM_BM - 1) / ccd::GEMM_BM) * ((N + ccd::GEMM_BN - 1) / ccd::GEMM_BN);
     CCD_LAUNCH((ccd::gemm_bf16_kernel<false, ccd::EPI_BF16, true>), dim3(ccd_gemm_grid(p, tiles, 1)), dim3(256),
                (size_t)ccd::GEMM_SMEM_BYTES, stream, p);

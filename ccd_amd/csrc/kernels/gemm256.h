@@ -31,14 +31,8 @@ __host__ __device__ inline int g256_smem_bytes(int N, bool colsum) { return G256
 // DEEP = true: BK = 32 and FOUR 32-KiB buffers instead of BK = 64 and two 64-KiB ones - three k-steps of DMA in flight
 // (counted vmcnt, LDS-only barriers) instead of one.  Measured on the plain variant: of ~4.0 k cycles per 64-deep k-tile
 // only ~2.2 k are MFMA issue, ~1.8 k are spent waiting for the single in-flight DMA (own vmcnt + the other waves').
-// CONV = true (round 6): the implicit-GEMM convolutions of the segmentation head (GemmParams: g_h_log2 .. c_px; gemm.h's GatherLoader
-// restated for the DMA): k-tile kt is (tap, 64 channels) - wave-uniform -, row r of the A image is the tap's source pixel of output
-// pixel r, fetched by the BUFFER form of the LDS-DMA: a lane whose pixel falls outside the source image asks for an offset behind
-// the descriptor and its 16 bytes of LDS receive zeros (the padding).  The epilogue adds the column sums of squares (BatchNorm batch
-// statistics) beside the column sums and the transposed conv's parity scatter of the output rows (c_map).  EPI_BF16, BK = 64 only.
-template <int EPI, int BN = 256, bool DEEP = false, bool CONV = false>
+template <int EPI, int BN = 256, bool DEEP = false>
 __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) {
-    static_assert(!CONV || (EPI == EPI_BF16 && !DEEP), "the convolution variant: bf16 output, 64-deep k-tiles");
     constexpr int WM = BN == 256 ? 2 : 4, WN = 8 / WM;     // wave grid
     constexpr int WROWS = G256_BM / WM, WCOLS = BN / WN;    // per-wave output
     constexpr int TI = WROWS / 32, TJ = WCOLS / 32;         // 32x32 accumulator tiles per wave
@@ -93,14 +87,9 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
     // one pass of global atomics when the workgroup is done (was: per tile a transpose through the staging image, three
     // barriers and 256 global atomics - 40 us of a 360-us launch).  The launcher sizes the LDS (g256_smem_bytes).
     float* cs_lds = reinterpret_cast<float*>(smem + G256_SMEM_BYTES);
-    float* css_lds = cs_lds + p.N;                              // CONV: column sums of squares
     const bool cs_on = (EPI == EPI_DGELU || EPI == EPI_BF16) && p.colsum != nullptr;
-    const bool css_on = CONV && cs_on && p.colsumsq != nullptr;
     if (cs_on) {
-        for (int i = t; i < p.N; i += G256_THREADS) {
-            cs_lds[i] = 0.f;
-            if (css_on) css_lds[i] = 0.f;
-        }
+        for (int i = t; i < p.N; i += G256_THREADS) cs_lds[i] = 0.f;
         __syncthreads();                                        // (nothing in flight yet)
     }
     // DMA source pointers of the current item: wave w moves chunks 4w .. 4w+3 (8 rows each) of both operands
@@ -109,11 +98,6 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
     constexpr int ACH = G256_BM / RPC / 8, BCHK = BN / RPC / 8;
     const bf16_t* ga[ACH];
     const bf16_t* gb[BCHK];
-    // CONV: per chunk row the image's first pixel (element offset / lda) and (oy * s_mul) << 16 | (ox * s_mul) - rows behind the matrix: a y
-    // no image reaches -, and the lane's 16-byte slot (elements)
-    unsigned cv_pix[CONV ? ACH : 1], cv_slot[CONV ? ACH : 1];
-    int cv_pos[CONV ? ACH : 1];
-    const buf_rsrc rs_cv = make_rsrc(CONV ? p.A : nullptr, CONV ? (unsigned)(((long)(p.M >> (p.g_h_log2 + p.g_w_log2)) * p.s_h * p.s_w * p.lda) * 2) : 0u);
     int m0, n0;
     bool live;
     auto setup = [&](unsigned item) {
@@ -127,14 +111,6 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
         for (int i = 0; i < ACH; ++i) {
             const int row = RPC * (ACH * w + i) + rin;
             const int src_slot = pos ^ (DEEP ? ((row >> 2) & 3) : (((row >> 1) ^ (row >> 4)) & 7));
-            if constexpr (CONV) {
-                const int gm = m0 + row, hw = p.g_h_log2 + p.g_w_log2;
-                const int n = gm >> hw, oy = (gm >> p.g_w_log2) & ((1 << p.g_h_log2) - 1), ox = gm & ((1 << p.g_w_log2) - 1);
-                cv_pix[i] = (unsigned)(n * p.s_h * p.s_w);
-                cv_pos[i] = gm < p.M ? ((oy * p.s_mul) << 16) | (ox * p.s_mul) : (0x4000 << 16);
-                cv_slot[i] = (unsigned)(src_slot * 8);
-                continue;
-            }
             int ra = m0 + row;
             ra = ra < p.M ? ra : p.M - 1;
             ga[i] = p.A + (long)ra * p.lda + src_slot * 8;
@@ -151,20 +127,8 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
     auto dma = [&](int kt, int buf) {
         char* abuf = smem + (buf << BUF_SHIFT) + ACH * w * 1024;
         char* bbuf = smem + (buf << BUF_SHIFT) + A_IMG + BCHK * w * 1024;
-        if constexpr (CONV) {
-            const int k0 = kt * BK, tap = (k0 / p.cin) & 15, c0 = k0 % p.cin;          // scalar: kt is uniform
-            const int dy = (int)((p.dy_pack >> (4 * tap)) & 15ull) - 8, dx = (int)((p.dx_pack >> (4 * tap)) & 15ull) - 8;
-#pragma unroll
-            for (int i = 0; i < ACH; ++i) {
-                const int sy = (cv_pos[i] >> 16) + dy, sx = (cv_pos[i] & 0xffff) + dx;
-                const bool ok = (unsigned)sy < (unsigned)p.s_h && (unsigned)sx < (unsigned)p.s_w;
-                const unsigned o = ((cv_pix[i] + (unsigned)(sy * p.s_w + sx)) * (unsigned)p.lda + (unsigned)c0 + cv_slot[i]) * 2u;
-                bufdma16(rs_cv, ok ? o : BUF_OOB, 0u, abuf + i * 1024);
-            }
-        } else {
 #pragma unroll
         for (int i = 0; i < ACH; ++i) glds16(ga[i] + kt * BK, abuf + i * 1024);
-        }
 #pragma unroll
         for (int i = 0; i < BCHK; ++i) glds16(gb[i] + kt * BK, bbuf + i * 1024);
     };
@@ -395,9 +359,6 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
         const bool want_stats = (EPI == EPI_DGELU || EPI == EPI_BF16) && p.colsum != nullptr;
 #endif
         float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float csq[CONV ? 8 : 1];
-#pragma unroll
-        for (int e = 0; e < (CONV ? 8 : 1); ++e) csq[e] = 0.f;
         const int ct = t % CT, rr = t / CT;                   // row pass: 8 columns per thread, RSTEP rows per step
         const int gn = en0 + 8 * ct;
         // gelu'(u) epilogue: the pre-activations of a pass's rows are requested ONE PASS AHEAD - after the previous pass's rows have
@@ -504,24 +465,12 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                         const char* src = stg + s2 * ROWB + ((ct ^ (s2 & 15)) * 16);
                         if (EPI == EPI_BF16 || p.C) {
                             const u32x4 wv = *reinterpret_cast<const u32x4*>(src);
-                            long gm_out = gm;
-                            if constexpr (CONV) {
-                                if (p.c_map) {          // transposed-conv parity class: scatter to the 2x upsampled grid
-                                    const int hw = p.g_h_log2 + p.g_w_log2;
-                                    const int n = gm >> hw, oy = (gm >> p.g_w_log2) & ((1 << p.g_h_log2) - 1), ox = gm & ((1 << p.g_w_log2) - 1);
-                                    gm_out = (((long)(n << (p.g_h_log2 + 1)) + 2 * oy + p.c_py) << (p.g_w_log2 + 1)) + 2 * ox + p.c_px;
-                                }
-                            }
-                            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + gm_out * p.ldc + gn) = wv;
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = wv;
                             if (want_stats) {
                                 float v[8];
                                 unpack8(wv, v);
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) csum[e] += v[e];
-                                if constexpr (CONV) {
-#pragma unroll
-                                    for (int e = 0; e < 8; ++e) csq[e] = fmaf(v[e], v[e], csq[e]);
-                                }
                             }
                         }
                         if (EPI == EPI_GELU) {                // gelu(u) of the bf16 pre-activation that backward will see
@@ -564,16 +513,6 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
                 if (CT == 16) v += shfl_xor(v, 16);
                 if (lane < CT && gn + e < p.N) atomicAdd(cs_lds + gn + e, v);
             }
-            if constexpr (CONV) {
-                if (css_on) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float v = csq[e] + shfl_xor(csq[e], 32);
-                        if (CT == 16) v += shfl_xor(v, 16);
-                        if (lane < CT && gn + e < p.N) atomicAdd(css_lds + gn + e, v);
-                    }
-                }
-            }
         }
         }
         if (!has_next) break;
@@ -589,9 +528,6 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
             c = c >= p.N ? c - p.N : c;
             const float v = cs_lds[c];
             if (v != 0.f) atomicAdd(p.colsum + c, v);
-            if constexpr (CONV) {
-                if (css_on && css_lds[c] != 0.f) atomicAdd(p.colsumsq + c, css_lds[c]);
-            }
         }
     }
 #ifdef CCD_GEMM_LAB

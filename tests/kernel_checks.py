@@ -1113,63 +1113,6 @@ def check_cls_tail(dev, images=2, seed=61, ld_pad=0):
     close(red, red_u, 2e-2, 2e-2 * scale, "cls_tail/red vs conv.h")            # (conv.h rounds d(a) to bf16 on the way)
 
 
-def check_conv256(dev, n=3, gh=4, gw=8, cin=64, cout=128, seed=23):
-    """The implicit-GEMM convolutions on the 256-row LDS-DMA tile (gemm256.h, CONV: policy conv_256, from conv_256_min_m output pixels
-    and N >= 128 on) vs torch.nn.functional: 3x3 forward with the BatchNorm statistics, its data gradient, the four parity classes of
-    the 4x4 / stride-2 transposed conv with bias and that layer's data gradient (segmentor.py:41-64,82-95)."""
-    from ccd_amd import seghead as sh
-    g = torch.Generator().manual_seed(seed)
-    rows = n * gh * gw
-    x = rnd((n, cin, gh, gw), g).to(BF)
-    xr = x.permute(0, 2, 3, 1).reshape(rows, cin).contiguous().to(dev)
-    # --- 3x3 forward with statistics (N = cout)
-    w = rnd((cout, cin, 3, 3), g, 0.1)
-    wb = ops.permute4(w.to(dev), (cin * 9, 1, 9), (cout, 9, cin), torch.empty((cout, 9 * cin), dtype=BF, device=dev))
-    d3 = ops.conv_desc((gh, gw), (gh, gw), cin, sh.TAPS3)
-    stats = torch.zeros(2 * cout, device=dev)
-    y = ops.conv_gemm(xr, d3, wb, rows, torch.empty((rows, cout), dtype=BF, device=dev), colsum=stats[:cout], colsumsq=stats[cout:])
-    ref = F.conv2d(x.float(), w.to(BF).float(), padding=1).permute(0, 2, 3, 1).reshape(rows, cout)
-    close(y, ref, 1e-2, 2e-2, "conv256 3x3")
-    yq = y.float().cpu()                               # the statistics are those of the STORED (bf16) values
-    close(stats[:cout], yq.sum(0), 1e-3, 1e-3 * rows ** 0.5, "conv256 3x3/colsum")
-    close(stats[cout:], (yq * yq).sum(0), 1e-3, 1e-3 * rows ** 0.5, "conv256 3x3/colsumsq")
-    # --- 3x3 data gradient (N = cout2 >= 128 input channels of the forward conv, K = 9 * cin)
-    cout2 = 320
-    w2 = rnd((cin, cout2, 3, 3), g, 0.1)              # forward conv cout2 -> cin; its data gradient maps [rows, cin] -> [rows, cout2]
-    wd = ops.permute4(w2.to(dev), (9, 1, cout2 * 9), (cout2, 9, cin), torch.empty((cout2, 9 * cin), dtype=BF, device=dev))
-    d3f = ops.conv_desc((gh, gw), (gh, gw), cin, sh.TAPS3_FLIP)
-    dx = ops.conv_gemm(xr, d3f, wd, rows, torch.empty((rows, cout2), dtype=BF, device=dev))
-    ref = F.conv_transpose2d(x.float(), w2.to(BF).float(), padding=1).permute(0, 2, 3, 1).reshape(rows, cout2)
-    close(dx, ref, 1e-2, 3e-2, "conv256 3x3/dgrad")
-    # --- transposed conv 4x4 stride 2: four parity classes + bias + statistics
-    wt = rnd((cin, cout, 4, 4), g, 0.1)
-    bias = rnd((cout,), g)
-    up = torch.zeros((4 * rows, cout), dtype=BF, device=dev)
-    st2 = torch.zeros(2 * cout, device=dev)
-    for py in (0, 1):
-        for px in (0, 1):
-            pt = sh._parity_taps(py, px)
-            desc = ops.conv_desc((gh, gw), (gh, gw), cin, [(a, b) for _, _, a, b in pt], parity=(py, px))
-            wp = torch.empty((cout, 4 * cin), dtype=BF, device=dev)
-            ops.permute4(wt.to(dev).reshape(-1)[pt[0][0] * 4 + pt[0][1]:], (16, 8, 2, cout * 16), (cout, 2, 2, cin), wp)
-            ops.conv_gemm(xr, desc, wp, rows, up, bias=bias.to(dev), colsum=st2[:cout], colsumsq=st2[cout:])
-    ref = F.conv_transpose2d(x.float(), wt.to(BF).float(), bias, stride=2, padding=1)
-    close(up, ref.permute(0, 2, 3, 1).reshape(4 * rows, cout), 1e-2, 3e-2, "conv256 convT")
-    uq = up.float().cpu()
-    close(st2[:cout], uq.sum(0), 1e-3, 2e-3 * rows ** 0.5, "conv256 convT/colsum")
-    close(st2[cout:], (uq * uq).sum(0), 1e-3, 2e-3 * rows ** 0.5, "conv256 convT/colsumsq")
-    # --- transposed conv data gradient: dIn = conv2d(dOut, W, stride 2), N = cin2 >= 128
-    cin2 = 128
-    dout = rnd((n, 64, 2 * gh, 2 * gw), g).to(BF)
-    wt2 = rnd((cin2, 64, 4, 4), g, 0.1)
-    dor = dout.permute(0, 2, 3, 1).reshape(4 * rows, 64).contiguous().to(dev)
-    descg = ops.conv_desc((gh, gw), (2 * gh, 2 * gw), 64, sh.TAPS_T_GRAD, s_mul=2)
-    wg = ops.permute4(wt2.to(dev), (64 * 16, 1, 16), (cin2, 16, 64), torch.empty((cin2, 16 * 64), dtype=BF, device=dev))
-    din = ops.conv_gemm(dor, descg, wg, rows, torch.empty((rows, cin2), dtype=BF, device=dev))
-    ref = F.conv2d(dout.float(), wt2.to(BF).float(), stride=2, padding=1).permute(0, 2, 3, 1).reshape(rows, cin2)
-    close(din, ref, 1e-2, 5e-2, "conv256 convT/dgrad")
-
-
 def check_seghead(dev, images=1, E=64, seed=21, build_ref=None):
     """SegHeadFn (HIP) vs the reference-shaped nn.Module stack in fp32 (torch library convs) on the same weights."""
     import copy

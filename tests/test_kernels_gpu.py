@@ -199,16 +199,6 @@ def test_conv_pieces(hip):
     kc.check_conv_pieces(hip.device)
 
 
-@pytest.mark.parametrize("n,gh,gw,cin", [(3, 4, 8, 64), (70, 8, 32, 128), (64, 16, 64, 64)])
-def test_conv_on_the_256_row_tile(hip, n, gh, gw, cin):
-    """gemm256.h CONV: partial tiles (96 rows), the head's own grids (8 x 32: 17 920 pixels; 16 x 64: 65 536), both column-tile widths."""
-    from ccd_amd import ops
-    with ops.policy(conv_256_min_m=1):
-        kc.check_conv256(hip.device, n=n, gh=gh, gw=gw, cin=cin)
-    with ops.policy(conv_256_min_m=1, conv_256=2):
-        kc.check_conv256(hip.device, n=n, gh=gh, gw=gw, cin=cin, seed=24)
-
-
 def test_decoder_pieces(hip):
     """finetune path: dropout, target embedding, short-query attention (masks, dropout), TFLoss, greedy step."""
     kc.check_decoder_pieces(hip.device)

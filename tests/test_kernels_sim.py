@@ -197,15 +197,6 @@ def test_conv_pieces_sim(sim):
     kc.check_conv_pieces(sim.device)
 
 
-def test_conv_on_the_256_row_tile_sim(sim):
-    from ccd_amd import ops
-    with ops.policy(conv_256_min_m=1):
-        kc.check_conv256(sim.device, n=3, gh=4, gw=8, cin=64)           # 96 output pixels: one partial tile
-        kc.check_conv256(sim.device, n=5, gh=8, gw=8, cin=64, seed=25)  # 320: two row tiles per column tile
-    with ops.policy(conv_256_min_m=1, conv_256=2):
-        kc.check_conv256(sim.device, n=3, gh=4, gw=8, cin=64, seed=26)  # 256-wide column tiles where N >= 256 (the 192-column product: one partial)
-
-
 def test_seghead_sim(sim):
     kc.check_seghead(sim.device, images=1, E=64)
 
