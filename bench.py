@@ -509,7 +509,7 @@ def main():
                                 "unit": "GB/s" if hbm_bound else "TFLOP/s",
                                 "frac": round(gbs / PEAK_HBM_GBS if hbm_bound else tflops / PEAK_BF16_TF, 4),
                                 "traffic": pmc_traffic(key, a),
-                                # HBM bytes of ONE WHOLE STEP from the same PMC passes (every dispatch, fetch + write; DESIGN section 4d has
+                                # HBM bytes of ONE WHOLE STEP from the same PMC passes (every dispatch, fetch + write; docs/LAB_NOTEBOOK.md section 4d has
                                 # the budget by tensor) - null unless the shipped kernel sources are the ones the passes ran on
                                 "step_bytes": pmc_traffic("_step_bytes", a),
                                 "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),

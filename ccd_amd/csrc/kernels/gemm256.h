@@ -82,7 +82,7 @@ __global__ __launch_bounds__(G256_THREADS, 1) void gemm256_kernel(GemmParams p) 
     if (slot >= cnt_x) return;
     // (Round 4 measured a phase skew here - workgroup slot s starting (s % phases) * delay late, 2 / 4 / 8 phases, 8 - 32 k cycles -
     // on the theory that 256 CUs storing their epilogues at once saturate HBM while the main loops leave it idle: 0.349 - 0.352
-    // against 0.355 ms for the gelu' product, nothing.  The workgroups are not phase-locked)
+    // against 0.355 ms for the gelu' product, nothing.  The workgroups are not phase-locked; see docs/LAB_NOTEBOOK.md section 4e.)
     // column sums (bias gradients): LDS accumulators behind the operand buffers for every column of the product, flushed by
     // one pass of global atomics when the workgroup is done (was: per tile a transpose through the staging image, three
     // barriers and 256 global atomics - 40 us of a 360-us launch).  The launcher sizes the LDS (g256_smem_bytes).

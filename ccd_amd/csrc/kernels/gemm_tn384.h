@@ -2,7 +2,7 @@
 // for P % 384 == 0, Q % 192 == 0, contraction length % 32 == 0 - dW = dY^T X of qkv (1152 x 384), proj (384 x 384),
 // fc1 (1536 x 384) and fc2 (384 x 1536) at embed_dim 384 (Dino/modules/svtr.py:92-145 run backwards by autograd).
 //
-// Why a second TN kernel next to gemm.h's 128-square one: the kind is bound by HBM - PQ / (P + Q)
+// Why a second TN kernel next to gemm.h's 128-square one (docs/LAB_NOTEBOOK.md section 8 item 2): the kind is bound by HBM - PQ / (P + Q)
 // = 192 ... 307 flop per byte, the machine balance is ~310 - and the 128-square kernel fetched 1.7 - 1.9 x its algorithmic bytes
 // (27 - 36 tiles per contraction slice sharing rows through an L2 that most slices straddled) with two k-tiles in flight per
 // workgroup.  Here
@@ -20,7 +20,7 @@
 // 256) resp. 384 B (= 128 mod 256) apart, i.e. on the same / on two alternating halves of the 64 banks: the 16-byte chunk index is
 // XORed with (row & 3) << 2 (A) resp. ((row >> 1) & 1) << 2 (B) - applied to the DMA's SOURCE address, the DMA itself writes
 // lane-linearly - which puts the 4 rows x 64 B of a half-wave on 4 different 64-byte bank groups.
-// Measured on MI355X (131072 rows, tools/tn384_lab.py, tools/tn384_pmc.sh): FETCH_SIZE = 503.6 MB for fc1 =
+// Measured on MI355X (131072 rows, tools/tn384_lab.py, tools/tn384_pmc.sh; docs/LAB_NOTEBOOK.md section 4b): FETCH_SIZE = 503.6 MB for fc1 =
 // 1.00 x its algorithmic bytes, 0 LDS bank-conflict cycles; main loop 1.0 PFLOP/s (1.4 with the DMA removed - the practical
 // bf16 ceiling of this power-limited board is ~1.25), the same for L2-, MALL- and HBM-resident operands; the atomic epilogue of
 // 288 KiB per workgroup costs 40-55 us per launch, which is why the engine launches the products in PAIRS (ccd_gemm_tn_pair).

@@ -64,7 +64,7 @@ __device__ __forceinline__ buf_u32x2 buf_load8(buf_rsrc r, unsigned lane_offset,
 // "this hazard only exists if the instruction is not using a register in the soffset field") - ours always has one, and on gfx950 a
 // VALU write to the first data register right behind the store (`v_mov_b32 v18, 0`, an address computation) reached memory instead
 // of the data in the last lanes of each half wave: run-to-run different values in rows 25 / 27 / 29 / 31 of a tile, lab_r04 notes in
-// DESIGN section 4d.  The empty-bodied `s_nop` below takes the data as an INPUT: the registers stay allocated until two wait
+// docs/LAB_NOTEBOOK.md section 4d.  The empty-bodied `s_nop` below takes the data as an INPUT: the registers stay allocated until two wait
 // states have passed.
 __device__ __forceinline__ void buf_store_data_hold(buf_u32x4 v) { asm volatile("s_nop 1" : : "v"(v)); }
 __device__ __forceinline__ void buf_store16(buf_rsrc r, unsigned lane_offset, unsigned uniform_offset, buf_u32x4 v) {

@@ -1,7 +1,7 @@
 """CU-masked HIP streams: student and teacher forward passes side by side on disjoint sets of compute units.
 
 The two backbone forward passes of an iteration (train.py:232-233) are independent until the loss.  Run one after the other,
-every CU of the chip is in the same phase of the same kernel at the same time (an MFMA phase, then an HBM phase: DESIGN.md
+every CU of the chip is in the same phase of the same kernel at the same time (an MFMA phase, then an HBM phase: docs/LAB_NOTEBOOK.md
 section 4d); run on two streams whose queues are restricted to disjoint CU sets (hipExtStreamCreateWithCUMask), the two
 partitions execute different kernels, so the phases of one fall into the other's gaps.
 

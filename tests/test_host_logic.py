@@ -25,7 +25,10 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert not missing, missing
     assert sorted(_lib.SIGNATURES) == declared, "ccd_amd/_lib.py signature table out of sync with include/ccd_hip.h"
     _lib.bind(lib)
-    assert lib.ccd_abi_version() == 10
+    # the library on disk was built from THESE sources (a stale in-tree .so would carry the previous number)
+    src = open(os.path.join(ROOT, "ccd_amd", "csrc", "abi_impl.h")).read()
+    want = int(re.search(r"int ccd_abi_version\(void\) \{ return (\d+); \}", src).group(1))
+    assert want >= 11 and lib.ccd_abi_version() == want
 
 
 def test_product_has_no_cpu_fallback():
@@ -171,7 +174,7 @@ def test_reference_checkpoint_layout_round_trip(golden_dir, tmp_path):
 
 def test_every_16_byte_buffer_store_holds_its_data_registers():
     """gfx950 reads the data registers of `buffer_store_dwordx4 ... soffset` a few cycles AFTER the instruction issues and LLVM's hazard
-    recogniser exempts exactly that form (a VALU write right behind the store reached memory instead of the data).
+    recogniser exempts exactly that form (docs/LAB_NOTEBOOK.md section 4d: a VALU write right behind the store reached memory instead of the data).
     The fix is a convention - every 16-byte buffer store is followed by buf_store_data_hold - so it is enforced here: the raw builtin /
     instruction may only appear inside prelude_hip.h helpers, and each occurrence must be followed by the hold before the helper ends."""
     import glob
@@ -193,7 +196,7 @@ def test_every_16_byte_buffer_store_holds_its_data_registers():
 
 def test_row_owner_kernels_stay_within_their_recorded_spill_ceilings():
     """The 512-register row-owner kernels compile without spills in their product loops only as long as nothing pushes the allocator
-    over the edge (227 spills from one `if`, 122 scalar spills from hoisted descriptors) - and a spill costs milliseconds
+    over the edge (docs/LAB_NOTEBOOK.md section 4e: 227 spills from one `if`, 122 scalar spills from hoisted descriptors) - and a spill costs milliseconds
     silently.  The code object's own figures (tools/codeobj_regs.py) are checked against ceilings recorded on the round-6 tree:
     kernel pattern -> (VGPR spills, SGPR spills, scratch bytes).  A compiler bump or an edit that raises one of them fails HERE, on the
     CPU, not as a slower step on the GPU.  (The spills that are recorded sit outside the chunk loops: checked in the ISA when recorded.)"""
