@@ -40,6 +40,9 @@ SIGNATURES = {
     "ccd_gemm_nt_lnbwd_tap_g16": [P, L, P, L, I, I, I, P, L, P, P, P, P, L, I, P, P, P, L, P, I, P, P, L, P, P, P, P],
     "ccd_proj_mlp_fused": [P, L, P, L, P, P, L, P, P, P, P, L, P, L, P, P, P, L, P, P, L, P, P, I, P, L, P, P, F, P, L, P, P, P, L, P, P, P, L,
                            I, I, I, P],
+    "ccd_proj_mlp_fused_gact": [P, L, P, L, P, P, L, P, P, P, P, L, P, L, P, P, P, L, P, P, L, P, P, I, P, L, P, P, F, P, L, P, P, P, L, P, L,
+                                P, P, P, L, I, I, I, P],
+    "ccd_mlp_bwd_fused": [P, L, P, L, P, L, P, L, P, L, P, P, L, P, P, P, P, L, I, P, P, P, L, P, I, P, I, I, I, P],
     "ccd_mlp_fused": [P, L, P, L, P, P, L, P, P, L, P, I, P, L, P, P, F, P, L, P, P, P, L, P, L, I, I, I, P],
     "ccd_ln_fwd": [P, P, P, P, P, P, I, I, F, P],
     "ccd_ln_bwd": [P, P, P, P, P, P, I, P, P, P, P, I, P, I, I, P],

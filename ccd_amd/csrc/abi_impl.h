@@ -10,6 +10,7 @@
 #include "kernels/gemm_row384.h"
 #include "kernels/mlp_fused.h"
 #include "kernels/rowgemm.h"
+#include "kernels/mlp_bwd.h"
 #include "kernels/rowproj.h"
 #include "kernels/attention_fwd.h"
 #include "kernels/attention_bwd.h"
@@ -275,8 +276,8 @@ static int ccd_launch_tn384_geom(ccd::GemmParams& p, int Mc, float* ws, long ws_
 
 extern "C" {
 
-int ccd_abi_version(void) { return 11; }   // 11: ccd_gemm_nt_lnbwd_tap_g16 (a segmentation tap's LayerNorm backward inside the qkv data-gradient product's epilogue); 10: ccd_head_loss_fwd / _bwd (last layer + distillation loss, logits never written), ccd_*_g16 (bf16 residual-gradient stream); 9: ccd_cls_tail_fwd / _bwd_reduce / _bwd_apply (BatchNorm + ReLU + classifier conv of the segmentation head fused); 8: ccd_proj_mlp_fused (proj + residual + LayerNorm-2 in front of the fused MLP), ccd_matvec_bf16; 7: ccd_gemm_tn_pair_ws (split-K workspace instead of fp32 atomics); 6: device-side momentum / DropPath seed (HIP graph of the training step); 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
-const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi10"; }
+int ccd_abi_version(void) { return 12; }   // 12: ccd_mlp_bwd_fused (gelu'(u) product + fc1 data gradient + LayerNorm-2 backward in one launch), ccd_proj_mlp_fused_gact (the forward block half also stores gelu(u)); 11: ccd_gemm_nt_lnbwd_tap_g16 (a segmentation tap's LayerNorm backward inside the qkv data-gradient product's epilogue); 10: ccd_head_loss_fwd / _bwd (last layer + distillation loss, logits never written), ccd_*_g16 (bf16 residual-gradient stream); 9: ccd_cls_tail_fwd / _bwd_reduce / _bwd_apply (BatchNorm + ReLU + classifier conv of the segmentation head fused); 8: ccd_proj_mlp_fused (proj + residual + LayerNorm-2 in front of the fused MLP), ccd_matvec_bf16; 7: ccd_gemm_tn_pair_ws (split-K workspace instead of fp32 atomics); 6: device-side momentum / DropPath seed (HIP graph of the training step); 5: ccd_mlp_fused can store gelu(u); 4: ccd_attention_bwd emits the qkv-bias gradient; 3: ccd_policy_set / _get, ccd_mlp_fused; 2: finetune-path entry points
+const char* ccd_build_info(void) { return "ccd_hip gfx950 bf16-mfma abi12"; }
 int ccd_policy_set(const char* key, int value) {
     CCD_CHECK(key, CCD_EINVAL);
     for (const CcdPolicyKey& k : ccd_policy_keys)
@@ -527,13 +528,14 @@ int ccd_mlp_fused(const ccd_bf16* y, long ldy, const ccd_bf16* w1, long ld1, con
     return ccd_rt_last_error();
 }
 
-int ccd_proj_mlp_fused(const ccd_bf16* a, long lda, const ccd_bf16* wp, long ldp, const float* bp, const float* resid, long ldr,
+static int ccd_proj_mlp_fused_impl(const ccd_bf16* a, long lda, const ccd_bf16* wp, long ldp, const float* bp, const float* resid, long ldr,
                        const float* rowscale1, const float* ln2_gamma, const float* ln2_beta, float* xmid, long ldxm, ccd_bf16* y2,
                        long ldy2, float* mean2, float* rstd2, const ccd_bf16* w1, long ld1, const float* b1, const ccd_bf16* w2,
                        long ld2, const float* b2, const float* rowscale2, int rows_per_sample, float* out, long ldc,
                        const float* ln_gamma, const float* ln_beta, float ln_eps, ccd_bf16* ln_y, long ld_y, float* ln_mean,
-                       float* ln_rstd, ccd_bf16* u, long ldu, const float* tap_gamma, const float* tap_beta, ccd_bf16* tap_y, long ld_tap,
-                       int M, int E, int H, void* stream) {
+                       float* ln_rstd, ccd_bf16* u, long ldu, ccd_bf16* gact, long ldga, const float* tap_gamma, const float* tap_beta,
+                       ccd_bf16* tap_y, long ld_tap, int M, int E, int H, void* stream) {
+    CCD_CHECK(!gact || (u && ldga % 8 == 0 && CCD_ALIGNED16(gact)), CCD_EINVAL);
     CCD_CHECK((tap_y != nullptr) == (tap_gamma != nullptr) && (tap_y != nullptr) == (tap_beta != nullptr) && CCD_ALIGNED16(tap_y) &&
               (!tap_y || ld_tap % 8 == 0), CCD_EINVAL);
     CCD_CHECK(a && wp && bp && resid && ln2_gamma && ln2_beta && w1 && b1 && w2 && b2 && out && ln_gamma && ln_beta && ln_y && ln_mean &&
@@ -556,7 +558,7 @@ int ccd_proj_mlp_fused(const ccd_bf16* a, long lda, const ccd_bf16* wp, long ldp
     p.y = nullptr; p.ldy_in = 0; p.w1 = w1; p.ld1 = ld1; p.b1 = b1; p.w2 = w2; p.ld2 = ld2; p.b2 = b2; p.resid = resid; p.ldr = ldr;
     p.rowscale = rowscale2; p.rows_per_sample = (rowscale1 || rowscale2) ? rows_per_sample : ccd::MLP_BM; p.out = out; p.ldc = ldc;
     p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_eps = ln_eps; p.ln_y = ln_y; p.ld_y = ld_y; p.ln_mean = ln_mean;
-    p.ln_rstd = ln_rstd; p.u = u; p.ldu = ldu; p.gact = nullptr; p.ldga = 0; p.M = M; p.H = H; p.lab = ccd_policy().lab;
+    p.ln_rstd = ln_rstd; p.u = u; p.ldu = ldu; p.gact = gact; p.ldga = ldga; p.M = M; p.H = H; p.lab = ccd_policy().lab;
     p.a = a; p.lda = lda; p.wp = wp; p.ldp = ldp; p.bp = bp; p.rowscale1 = rowscale1; p.ln2_gamma = ln2_gamma; p.ln2_beta = ln2_beta;
     p.xmid = xmid; p.ldxm = ldxm; p.y2 = y2; p.ldy2 = ldy2; p.mean2 = mean2; p.rstd2 = rstd2;
     p.tap_gamma = tap_gamma; p.tap_beta = tap_beta; p.tap_y = tap_y; p.ld_tap = ld_tap;
@@ -574,6 +576,59 @@ int ccd_proj_mlp_fused(const ccd_bf16* a, long lda, const ccd_bf16* wp, long ldp
     }
     return ccd_rt_last_error();
 }
+int ccd_proj_mlp_fused(const ccd_bf16* a, long lda, const ccd_bf16* wp, long ldp, const float* bp, const float* resid, long ldr,
+                       const float* rowscale1, const float* ln2_gamma, const float* ln2_beta, float* xmid, long ldxm, ccd_bf16* y2,
+                       long ldy2, float* mean2, float* rstd2, const ccd_bf16* w1, long ld1, const float* b1, const ccd_bf16* w2,
+                       long ld2, const float* b2, const float* rowscale2, int rows_per_sample, float* out, long ldc,
+                       const float* ln_gamma, const float* ln_beta, float ln_eps, ccd_bf16* ln_y, long ld_y, float* ln_mean,
+                       float* ln_rstd, ccd_bf16* u, long ldu, const float* tap_gamma, const float* tap_beta, ccd_bf16* tap_y, long ld_tap,
+                       int M, int E, int H, void* stream) {
+    return ccd_proj_mlp_fused_impl(a, lda, wp, ldp, bp, resid, ldr, rowscale1, ln2_gamma, ln2_beta, xmid, ldxm, y2, ldy2, mean2, rstd2, w1, ld1,
+                                   b1, w2, ld2, b2, rowscale2, rows_per_sample, out, ldc, ln_gamma, ln_beta, ln_eps, ln_y, ld_y, ln_mean, ln_rstd,
+                                   u, ldu, nullptr, 0, tap_gamma, tap_beta, tap_y, ld_tap, M, E, H, stream);
+}
+int ccd_proj_mlp_fused_gact(const ccd_bf16* a, long lda, const ccd_bf16* wp, long ldp, const float* bp, const float* resid, long ldr,
+                            const float* rowscale1, const float* ln2_gamma, const float* ln2_beta, float* xmid, long ldxm, ccd_bf16* y2,
+                            long ldy2, float* mean2, float* rstd2, const ccd_bf16* w1, long ld1, const float* b1, const ccd_bf16* w2,
+                            long ld2, const float* b2, const float* rowscale2, int rows_per_sample, float* out, long ldc,
+                            const float* ln_gamma, const float* ln_beta, float ln_eps, ccd_bf16* ln_y, long ld_y, float* ln_mean,
+                            float* ln_rstd, ccd_bf16* u, long ldu, ccd_bf16* gact, long ldga, const float* tap_gamma, const float* tap_beta,
+                            ccd_bf16* tap_y, long ld_tap, int M, int E, int H, void* stream) {
+    CCD_CHECK(gact, CCD_EINVAL);
+    return ccd_proj_mlp_fused_impl(a, lda, wp, ldp, bp, resid, ldr, rowscale1, ln2_gamma, ln2_beta, xmid, ldxm, y2, ldy2, mean2, rstd2, w1, ld1,
+                                   b1, w2, ld2, b2, rowscale2, rows_per_sample, out, ldc, ln_gamma, ln_beta, ln_eps, ln_y, ld_y, ln_mean, ln_rstd,
+                                   u, ldu, gact, ldga, tap_gamma, tap_beta, tap_y, ld_tap, M, E, H, stream);
+}
+
+int ccd_mlp_bwd_fused(const ccd_bf16* gb, long ldgb, const ccd_bf16* w2t, long ld2, const ccd_bf16* w1t, long ld1, const ccd_bf16* u,
+                      long ldu, ccd_bf16* du, long lddu, float* db1, const float* x, long ldx, const float* mean, const float* rstd,
+                      const float* gamma, ccd_bf16* g, long ldg, int accumulate, float* dgamma, float* dbeta, ccd_bf16* gb_out, long ld_gbo,
+                      const float* rowscale, int rows_per_sample, float* dbias, int M, int E, int H, void* stream) {
+    CCD_CHECK(gb && w2t && w1t && u && du && db1 && x && mean && rstd && gamma && g && dgamma && dbeta, CCD_EINVAL);
+    CCD_CHECK(CCD_ALIGNED16(gb) && CCD_ALIGNED16(w2t) && CCD_ALIGNED16(w1t) && CCD_ALIGNED16(u) && CCD_ALIGNED16(du) && CCD_ALIGNED16(x) &&
+              CCD_ALIGNED16(g) && CCD_ALIGNED16(gb_out), CCD_EINVAL);
+    CCD_CHECK(gb_out != gb, CCD_EINVAL);                    // the weight-gradient launch that follows still reads gb
+    if (M == 0) return CCD_OK;
+    CCD_CHECK(M > 0 && H > 0 && (!rowscale || rows_per_sample > 0), CCD_EINVAL);
+    // (H % 128: the two u images of a wave are used in turn by the chunks of 64 hidden units, across tiles)
+    CCD_CHECK((E == 256 || E == 384) && H % 128 == 0 && ldgb % 8 == 0 && ld2 % 8 == 0 && ld1 % 8 == 0 && ldu % 8 == 0 &&
+              lddu % 8 == 0 && ldx % 4 == 0 && ldg % 8 == 0 && (!gb_out || ld_gbo % 8 == 0), CCD_ESHAPE);
+    CCD_CHECK((long)H * ld2 * 2 < CCD_MAX_OPERAND_BYTES && (long)E * ld1 * 2 < CCD_MAX_OPERAND_BYTES &&
+              ((long)M + 128) * lddu * 2 < CCD_MAX_OPERAND_BYTES && ((long)M + 128) * ldx * 4 < CCD_MAX_OPERAND_BYTES, CCD_ESHAPE);
+    const int smem = ccd::mb_smem_bytes(E, H);
+    CCD_CHECK(smem <= 160 * 1024, CCD_ESHAPE);
+    ccd::MlpBwdParams p;
+    p.gb = gb; p.ld_gb_in = ldgb; p.w2t = w2t; p.ld2 = ld2; p.w1t = w1t; p.ld1 = ld1; p.u = u; p.ldu = ldu; p.du = du; p.lddu = lddu;
+    p.db1 = db1; p.x = x; p.ldx = ldx; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.g = g; p.ldg = ldg; p.accumulate = accumulate;
+    p.dgamma = dgamma; p.dbeta = dbeta; p.gb_out = gb_out; p.ld_gbo = ld_gbo; p.rowscale = gb_out ? rowscale : nullptr;
+    p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; p.dbias = gb_out ? dbias : nullptr; p.M = M; p.H = H;
+    const int tiles = (M + ccd::MB_BM - 1) / ccd::MB_BM, cus = ccd_grid_cus(tiles);
+    const dim3 grid(tiles < cus ? tiles : cus), block(ccd::MB_THREADS);
+    if (E == 384) CCD_LAUNCH((ccd::mlp_bwd_fused_kernel<384>), grid, block, smem, stream, p);
+    else CCD_LAUNCH((ccd::mlp_bwd_fused_kernel<256>), grid, block, smem, stream, p);
+    return ccd_rt_last_error();
+}
+
 
 static int ccd_gemm_tn_impl(const ccd_bf16* A, long lda, const ccd_bf16* B, long ldb, int P, int Q, int Mc, int epilogue, float* C,
                             long ldc, float alpha, int splits, const int* d_rows, int rows_mul, float* colsum_a, void* stream);

@@ -56,6 +56,8 @@ class Fusion:
     if head_loss is None:
         head_loss = True
     g_bf16 = _env_switch("CCD_G_BF16")             # the backward pass's residual-gradient stream in bf16 (round 6; None = the measured default)
+    mlp_bwd = _env_switch("CCD_FUSE_MLP_BWD")      # gelu'(u) product + fc1 data gradient + LayerNorm-2 backward in one launch (ccd_mlp_bwd_fused, round 6;
+                                                   # the forward block half then stores gelu(u) too); None = the measured default
     side_stream = bool(_env_switch("CCD_SIDE_STREAM"))
     double_gb = False                       # tests: rotate the two gb buffers of the side-stream mode also without a side stream
 
@@ -74,11 +76,19 @@ class Fusion:
         return bool(on) and cls.resolve(E)[2] and E in (128, 256, 384)
 
     @classmethod
+    def resolve_mlp_bwd(cls, E, H):
+        """ccd_mlp_bwd_fused replaces the gelu'(u) product and the LayerNorm-backward product of the MLP branch where the one-launch
+        forward block half runs (it hands over gelu(u)) and the gradient stream is bf16."""
+        on = cls.mlp_bwd if cls.mlp_bwd is not None else MLP_BWD_DEFAULT
+        return bool(on) and cls.resolve_proj(E) and cls.resolve_g16(E) and cls.resolve(E)[2] and E in (256, 384) and H % 128 == 0
+
+    @classmethod
     def resolve_proj(cls, E):
         """ccd_proj_mlp_fused (round 5) replaces ccd_gemm_nt_resid_ln + ccd_mlp_fused where both would run (it cannot store gelu(u))."""
         return cls.resolve(E)[1] and E <= 384 and not cls.store_gact and (cls.proj_mlp if cls.proj_mlp is not None else True)
 
 
+MLP_BWD_DEFAULT = False       # measured: 46.96 / 47.01 against 46.05 / 46.09 ms per step with it (profiles/r06_mlp_bwd_step_ab.jsonl)
 G_BF16_DEFAULT = True         # measured: 46.43 against 46.86 ms per step, every 1e-3 parity gate green (profiles/r06_g_bf16_*)
 
 _DROPPATH_SEED = {"base": None, "calls": 0, "device": None}
@@ -160,6 +170,8 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
     # fused, 47.3 unfused; B = 128, one MI355X)
     fuse_ln, fuse_mlp, _ = Fusion.resolve(E)
     fuse_proj = Fusion.resolve_proj(E)
+    # (the one-launch MLP backward wants gelu(u) from the forward kernel: ccd_proj_mlp_fused_gact)
+    bwd_fused = fuse_proj and Fusion.resolve_mlp_bwd(E, arena.w(f"{pre}blocks.0.mlp.fc1.weight").shape[0])
     # the whole MLP branch in one kernel (csrc/kernels/mlp_fused.h): the hidden activation never reaches HBM; when
     # activations are saved only the bf16 pre-activation u is stored and backward re-derives gelu(u) in the epilogue
     # that already reads u (ccd_gemm_nt, EPI_DGELU with a second output)
@@ -192,10 +204,12 @@ def backbone_forward(arena, pre, spec: VitSpec, img, resample, save, training, n
                 c.att.view(R, E), arena.wb(b + "attn.proj.weight"), arena.w(b + "attn.proj.bias"), resid=x, rowscale1=c.ds1,
                 gamma2=arena.w(b + "norm2.weight"), beta2=arena.w(b + "norm2.bias"), w1=arena.wb(b + "mlp.fc1.weight"),
                 b1=arena.w(b + "mlp.fc1.bias"), w2=arena.wb(b + "mlp.fc2.weight"), b2=arena.w(b + "mlp.fc2.bias"), rowscale2=c.ds2,
-                rows_per_sample=256, gamma=arena.w(nxt + "weight"), beta=arena.w(nxt + "bias"), eps=spec.eps, save=save, **tap_kw)
-            if save:
-                c.x_mid, c.y2, c.mean2, c.rstd2, c.u = kept
+                rows_per_sample=256, gamma=arena.w(nxt + "weight"), beta=arena.w(nxt + "bias"), eps=spec.eps, save=save,
+                store_gact=bool(save and bwd_fused), **tap_kw)
             c.gact = None
+            if save:
+                c.x_mid, c.y2, c.mean2, c.rstd2, c.u, *g_kept = kept
+                c.gact = g_kept[0] if g_kept else None
             pending = [y_n, mean_n, rstd_n]
         elif fuse_ln:
             c.x_mid, c.y2, c.mean2, c.rstd2 = ops.gemm_nt_resid_ln(
@@ -325,7 +339,10 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
     # gb = bf16(g * DropPath scale), the gradient that enters a residual branch.  With the side stream on it lives in TWO
     # buffers used in turn: a LayerNorm backward writes the next branch's gb while the weight-gradient launch of the
     # previous branch (side stream) still reads the old one.
-    gbuf = [torch.empty((R, E), dtype=BF16, device=dev) for _ in range(2 if (side.on or Fusion.double_gb) else 1)]
+    # (the one-launch MLP backward reads the branch's gb and writes the next branch's: two buffers as well)
+    bwd_fused = fuse_lnbwd and ctxs[top] is not None and ctxs[top].gact is not None and ctxs[top].u is not None and \
+        Fusion.resolve_mlp_bwd(E, ctxs[top].u.shape[1]) and ops.mlp_bwd_fused_supported(g, E, ctxs[top].u.shape[1])
+    gbuf = [torch.empty((R, E), dtype=BF16, device=dev) for _ in range(2 if (side.on or Fusion.double_gb or bwd_fused) else 1)]
     readers = [None] * len(gbuf)      # event of the last side-stream launch that reads each buffer
     cur = [0]
 
@@ -368,11 +385,22 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
         # ---- MLP branch: x_out = x_mid + ds2 * fc2(gelu(fc1(LN2(x_mid))))
         gact, y2, att, y1 = c.gact, c.y2, c.att, c.y1
         gb = gb_read()
-        # (Round 3 built the whole chain - gelu'(u) product, fc1 data gradient, LayerNorm-2 backward - as ONE row-owner kernel, the
-        # mirror of mlp_fused.h: correct (sim + GPU tests) and SLOWER, 836 us per block against 717 for the two launches below.  u has
-        # to stream in from HBM between the weight pieces of the LDS-DMA ring, and gfx950 counts loads, stores and DMA on one vmcnt:
-        # every ring wait behind a u request also waits for that request's HBM latency.  profiles/r03_mlp_bwd_fused_ab.jsonl.)
-        if gact is None:        # fused-MLP forward kept only u: gelu(u) comes out of the gelu'(u) epilogue below
+        # (The whole chain - gelu'(u) product, fc1 data gradient, LayerNorm-2 backward - as ONE row-owner kernel, the mirror of mlp_fused.h,
+        # was built twice.  Round 3: 836 us per block against 717 for the two launches (u streamed in row-per-lane through the weight
+        # ring's vmcnt queue).  Round 6 (mlp_bwd.h: u by LDS-DMA two chunks ahead, gelu(u) handed over by the forward kernel): 0.558
+        # against 0.598 ms in the lab, 0.607 against 0.605 in the step - and the forward block half pays 0.088 ms per block for storing
+        # gelu(u): 46.96 / 47.01 against 46.05 / 46.09 ms per step.  Kept behind CCD_FUSE_MLP_BWD=1, off by default.
+        # profiles/r03_mlp_bwd_fused_ab.jsonl, profiles/r06_mlp_bwd_lab.jsonl, profiles/r06_mlp_bwd_step_ab.jsonl.)
+        fused_here = bwd_fused and gact is not None
+        if fused_here:
+            # gelu'(u) product, fc1 data gradient and LayerNorm-2 backward in ONE launch (mlp_bwd.h): du is written once, for the weight
+            # gradients, and never read back; the next branch's gb goes to the other buffer (the weight gradients still read this one)
+            old = cur[0]
+            du = ops.mlp_bwd_fused(gb, arena.wbt(b + "mlp.fc2.weight"), arena.wbt(b + "mlp.fc1.weight"), c.u,
+                                   db1=arena.g(b + "mlp.fc1.bias"), x=c.x_mid, mean=c.mean2, rstd=c.rstd2, gamma=arena.w(b + "norm2.weight"),
+                                   g=g, dgamma=arena.g(b + "norm2.weight"), dbeta=arena.g(b + "norm2.bias"), gb_out=gb_write(),
+                                   rowscale=c.ds1, rows_per_sample=256, dbias=arena.g(b + "attn.proj.bias"), accumulate=True)
+        elif gact is None:        # fused-MLP forward kept only u: gelu(u) comes out of the gelu'(u) epilogue below
             gact = torch.empty_like(c.u)
             du = ops.gemm_nt(gb, arena.wbt(b + "mlp.fc2.weight"), epilogue=ops.EPI_DGELU, aux=c.u, out2=gact,
                              colsum=arena.g(b + "mlp.fc1.bias"))
@@ -383,7 +411,9 @@ def backbone_backward(arena, pre, spec: VitSpec, ctx, d_tokens, d_taps, resample
         # both weight gradients of the MLP in ONE launch (ccd_gemm_tn_pair: the same rows, one atomic epilogue per workgroup)
         def mlp_grads(gb=gb, du=du, gact=gact):
             ops.gemm_tn_pair(gb, gact, arena.g(b + "mlp.fc2.weight"), du, y2, arena.g(b + "mlp.fc1.weight"))
-        if fuse_lnbwd:       # dy2 = du . W1 never leaves the chip: LayerNorm-2's backward is the product's epilogue
+        if fused_here:
+            readers[old] = side.run(mlp_grads, gb, gact, du, y2)
+        elif fuse_lnbwd:       # dy2 = du . W1 never leaves the chip: LayerNorm-2's backward is the product's epilogue
             readers[cur[0]] = side.run(mlp_grads, gb, gact, du, y2)
             ops.gemm_nt_lnbwd(du, arena.wbt(b + "mlp.fc1.weight"), c.x_mid, c.mean2, c.rstd2, arena.w(b + "norm2.weight"), g,
                               arena.g(b + "norm2.weight"), arena.g(b + "norm2.bias"), accumulate=True, gb=gb_write(),

@@ -192,6 +192,38 @@ def gemm_nt_lnbwd(a, b, x, mean, rstd, gamma, g, dgamma, dbeta, accumulate=True,
     return g
 
 
+def mlp_bwd_fused_supported(g, E, H):
+    """ccd_mlp_bwd_fused takes the bf16 gradient stream at E in {256, 384} with H a multiple of 128."""
+    return g.dtype == BF16 and E in (256, 384) and H % 128 == 0
+
+
+def mlp_bwd_fused(gb, w2t, w1t, u, *, db1, x, mean, rstd, gamma, g, dgamma, dbeta, gb_out, rowscale=None, rows_per_sample=1,
+                  dbias=None, accumulate=True):
+    """The data-gradient chain of the MLP branch in one launch (include/ccd_hip.h: ccd_mlp_bwd_fused):
+    du = (gb @ w2t^T) * gelu'(u), dy2 = du @ w1t^T, then LayerNorm-2's backward of dy2 as in gemm_nt_lnbwd (bf16 stream g).
+    w2t = fc2.weight^T [H, E], w1t = fc1.weight^T [E, H].  -> du bf16 [M, H]; db1 += colsum(du)."""
+    _chk(gb, BF16, "gb"); _chk(w2t, BF16, "w2t"); _chk(w1t, BF16, "w1t"); _chk(u, BF16, "u"); _chk(x, F32, "x"); _chk(g, BF16, "g")
+    _chk(gb_out, BF16, "gb_out"); _chk(db1, F32, "db1"); _chk(rowscale, F32, "rowscale")
+    M, E = gb.shape
+    H = w2t.shape[0]
+    assert tuple(w2t.shape) == (H, E) and tuple(w1t.shape) == (E, H) and tuple(u.shape) == (M, H) and tuple(x.shape) == (M, E)
+    assert gb_out is None or gb_out.data_ptr() != gb.data_ptr()
+    du = torch.empty((M, H), dtype=BF16, device=gb.device)
+    # algorithmic bytes: gb, u in; du out; x in; g in + out; gb_out out; the weights once
+    nbytes = M * (2.0 * E + 4.0 * H + 4.0 * E + (4.0 if accumulate else 2.0) * E + (2.0 * E if gb_out is not None else 0.0)) + 4.0 * E * H
+    span = TIMER.span("mlp_bwd_fused", 4.0 * M * E * H, nbytes) if TIMER is not None else None
+    if span:
+        span[0].record()
+    _call("ccd_mlp_bwd_fused", _lib.ptr(gb), gb.stride(0), _lib.ptr(w2t), w2t.stride(0), _lib.ptr(w1t), w1t.stride(0),
+          _lib.ptr(u), u.stride(0), _lib.ptr(du), du.stride(0), _lib.ptr(db1),
+          _lib.ptr(x), x.stride(0), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(g), g.stride(0),
+          1 if accumulate else 0, _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(gb_out), 0 if gb_out is None else gb_out.stride(0),
+          _lib.ptr(rowscale), int(rows_per_sample), _lib.ptr(dbias), M, E, H)
+    if span:
+        span[1].record()
+    return du
+
+
 def mlp_fused(y, w1, b1, w2, b2, *, resid, rowscale, rows_per_sample, gamma, beta, eps, store_u=False, store_gact=False, out=None):
     """out (fp32) = resid + (gelu(y @ w1^T + b1) @ w2^T + b2) * rowscale[row // rows_per_sample];
     y_next = LayerNorm(out) * gamma + beta  ->  (out, y_next bf16, mean, rstd, u bf16 | None[, gelu(u) bf16 with store_gact]).
@@ -226,13 +258,14 @@ def mlp_fused(y, w1, b1, w2, b2, *, resid, rowscale, rows_per_sample, gamma, bet
 
 
 def proj_mlp_fused(a, wp, bp, *, resid, rowscale1, gamma2, beta2, w1, b1, w2, b2, rowscale2, rows_per_sample, gamma, beta, eps,
-                   save=False, out=None, tap_gamma=None, tap_beta=None):
+                   save=False, out=None, tap_gamma=None, tap_beta=None, store_gact=False):
     """The second half of a transformer block in one launch (include/ccd_hip.h: ccd_proj_mlp_fused):
         x_mid = resid + (a @ wp^T + bp) * rowscale1;   y2 = LayerNorm(x_mid) * gamma2 + beta2
         out   = x_mid + (gelu(y2 @ w1^T + b1) @ w2^T + b2) * rowscale2;   y_next = LayerNorm(out) * gamma + beta
     -> (out, y_next, mean, rstd, saved) with saved = (x_mid, y2, mean2, rstd2, u) when `save` (what the backward pass reads), else None:
     then x_mid and y2 never reach HBM.  With tap_gamma / tap_beta a sixth result: LayerNorm(out) * tap_gamma + tap_beta (bf16).
-    Raises RuntimeError('unsupported shape') where the kernel does not apply."""
+    store_gact (with save): saved gains a sixth member, gelu(u) bf16 [M, H] (ccd_proj_mlp_fused_gact: what ccd_mlp_bwd_fused's caller
+    hands to the weight-gradient pair).  Raises RuntimeError('unsupported shape') where the kernel does not apply."""
     _chk(a, BF16, "a"); _chk(wp, BF16, "wp"); _chk(w1, BF16, "w1"); _chk(w2, BF16, "w2"); _chk(resid, F32, "resid")
     _chk(rowscale1, F32, "rowscale1"); _chk(rowscale2, F32, "rowscale2")
     M, E = a.shape
@@ -251,23 +284,29 @@ def proj_mlp_fused(a, wp, bp, *, resid, rowscale1, gamma2, beta2, w1, b1, w2, b2
         mean2 = torch.empty(M, dtype=F32, device=dev)
         rstd2 = torch.empty(M, dtype=F32, device=dev)
         u = torch.empty((M, H), dtype=BF16, device=dev)
+    gact = torch.empty((M, H), dtype=BF16, device=dev) if (save and store_gact) else None
     tap = torch.empty((M, E), dtype=BF16, device=dev) if tap_gamma is not None else None
-    # algorithmic bytes: a and resid read, out + y_next written (+ x_mid, y2, u when saved), the three weight matrices once
+    # algorithmic bytes: a and resid read, out + y_next written (+ x_mid, y2, u [, gelu(u)] when saved), the three weight matrices once
     nbytes = M * E * (2.0 + 4.0 + 4.0 + 2.0) + (M * E * 6.0 + 2.0 * M * H if save else 0.0) + 4.0 * E * H + 2.0 * E * E + \
-        (2.0 * M * E if tap is not None else 0.0)
+        (2.0 * M * E if tap is not None else 0.0) + (2.0 * M * H if gact is not None else 0.0)
     span = TIMER.span("proj_mlp_fused", 4.0 * M * E * H + 2.0 * M * E * E, nbytes) if TIMER is not None else None
     if span:
         span[0].record()
-    _call("ccd_proj_mlp_fused", _lib.ptr(a), a.stride(0), _lib.ptr(wp), wp.stride(0), _lib.ptr(bp), _lib.ptr(resid), resid.stride(0),
-          _lib.ptr(rowscale1), _lib.ptr(gamma2), _lib.ptr(beta2), _lib.ptr(xmid), 0 if xmid is None else xmid.stride(0), _lib.ptr(y2),
-          0 if y2 is None else y2.stride(0), _lib.ptr(mean2), _lib.ptr(rstd2), _lib.ptr(w1), w1.stride(0), _lib.ptr(b1), _lib.ptr(w2),
-          w2.stride(0), _lib.ptr(b2), _lib.ptr(rowscale2), int(rows_per_sample), _lib.ptr(out), out.stride(0), _lib.ptr(gamma),
-          _lib.ptr(beta), float(eps), _lib.ptr(yn), yn.stride(0), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(u),
-          0 if u is None else u.stride(0), _lib.ptr(tap_gamma), _lib.ptr(tap_beta), _lib.ptr(tap), 0 if tap is None else tap.stride(0),
-          M, E, H)
+    head = (_lib.ptr(a), a.stride(0), _lib.ptr(wp), wp.stride(0), _lib.ptr(bp), _lib.ptr(resid), resid.stride(0),
+            _lib.ptr(rowscale1), _lib.ptr(gamma2), _lib.ptr(beta2), _lib.ptr(xmid), 0 if xmid is None else xmid.stride(0), _lib.ptr(y2),
+            0 if y2 is None else y2.stride(0), _lib.ptr(mean2), _lib.ptr(rstd2), _lib.ptr(w1), w1.stride(0), _lib.ptr(b1), _lib.ptr(w2),
+            w2.stride(0), _lib.ptr(b2), _lib.ptr(rowscale2), int(rows_per_sample), _lib.ptr(out), out.stride(0), _lib.ptr(gamma),
+            _lib.ptr(beta), float(eps), _lib.ptr(yn), yn.stride(0), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(u),
+            0 if u is None else u.stride(0))
+    tail = (_lib.ptr(tap_gamma), _lib.ptr(tap_beta), _lib.ptr(tap), 0 if tap is None else tap.stride(0), M, E, H)
+    if gact is not None:
+        _call("ccd_proj_mlp_fused_gact", *head, _lib.ptr(gact), gact.stride(0), *tail)
+    else:
+        _call("ccd_proj_mlp_fused", *head, *tail)
     if span:
         span[1].record()
-    res = (out, yn, mean, rstd, ((xmid, y2, mean2, rstd2, u) if save else None))
+    kept = None if not save else ((xmid, y2, mean2, rstd2, u, gact) if gact is not None else (xmid, y2, mean2, rstd2, u))
+    res = (out, yn, mean, rstd, kept)
     return res + (tap,) if tap is not None else res
 
 

@@ -138,6 +138,28 @@ int ccd_proj_mlp_fused(const ccd_bf16* a, long lda, const ccd_bf16* wp, long ldp
                        const float* ln_gamma, const float* ln_beta, float ln_eps, ccd_bf16* ln_y, long ld_y, float* ln_mean,
                        float* ln_rstd, ccd_bf16* u, long ldu, const float* tap_gamma, const float* tap_beta, ccd_bf16* tap_y, long ld_tap,
                        int M, int E, int H, void* stream);
+/* The same, and gelu(u) [M, H] bf16 is stored too (ABI 12; u required): the packed second-product operands of the forward kernel ARE that
+ * tensor, so the backward pass neither gathers Phi a second time nor writes gelu(u) - what ccd_mlp_bwd_fused expects of its caller. */
+int ccd_proj_mlp_fused_gact(const ccd_bf16* a, long lda, const ccd_bf16* wp, long ldp, const float* bp, const float* resid, long ldr,
+                       const float* rowscale1, const float* ln2_gamma, const float* ln2_beta, float* xmid, long ldxm, ccd_bf16* y2,
+                       long ldy2, float* mean2, float* rstd2, const ccd_bf16* w1, long ld1, const float* b1, const ccd_bf16* w2,
+                       long ld2, const float* b2, const float* rowscale2, int rows_per_sample, float* out, long ldc,
+                       const float* ln_gamma, const float* ln_beta, float ln_eps, ccd_bf16* ln_y, long ld_y, float* ln_mean,
+                       float* ln_rstd, ccd_bf16* u, long ldu, ccd_bf16* gact, long ldga, const float* tap_gamma, const float* tap_beta, ccd_bf16* tap_y, long ld_tap,
+                       int M, int E, int H, void* stream);
+/* The data-gradient chain of the MLP branch in one launch - the backward of the block half above (Mlp.forward + LayerNorm-2,
+ * Dino/modules/vision_transformer.py:59-65,110 in autograd order; ABI 12):
+ *   dh = gb . W2 ;  du = dh * gelu'(u) ;  dy2 = du . W1 ;  LayerNorm-2 backward of dy2 as in ccd_gemm_nt_lnbwd_g16
+ *   (g (+)= dx on the bf16 stream, dgamma / dbeta +=, gb_out = bf16(g * rowscale[row / rows_per_sample]), dbias += colsum(gb_out))
+ * w2t = fc2.weight^T [H, E], w1t = fc1.weight^T [E, H] (the transposed bf16 mirrors), u [M, H] the stored pre-activation.  du [M, H] is
+ * written ONCE, for the weight-gradient pair that follows (ccd_gemm_tn_pair: {gb, gelu(u)}, {du, y2}), and never read back; db1 +=
+ * column sums of du (fc1.bias gradient).  gb_out must not alias gb.  E in {256, 384}, H % 128 == 0; CCD_ESHAPE otherwise: the caller
+ * takes ccd_gemm_nt(EPI_DGELU) + ccd_gemm_nt_lnbwd_g16.  Replaces those two. */
+int ccd_mlp_bwd_fused(const ccd_bf16* gb, long ldgb, const ccd_bf16* w2t, long ld2, const ccd_bf16* w1t, long ld1, const ccd_bf16* u,
+                      long ldu, ccd_bf16* du, long lddu, float* db1, const float* x, long ldx, const float* mean, const float* rstd,
+                      const float* gamma, ccd_bf16* g, long ldg, int accumulate, float* dgamma, float* dbeta, ccd_bf16* gb_out, long ld_gbo,
+                      const float* rowscale, int rows_per_sample, float* dbias, int M, int E, int H, void* stream);
+
 /* colsum (optional, epilogues BF16 / DGELU): [N] fp32, += column sums of the output (bias gradient of the producer).
  * CCD_EPI_GELU accepts C == NULL (only gelu(u) is stored: forward passes that keep no activations). */
 /* C[P,Q] (+)= sum_m A[m,P] * B[m,Q]   (weight gradients dW = dY^T X of every Linear; autograd of the above)

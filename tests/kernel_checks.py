@@ -1338,6 +1338,63 @@ def check_matvec_bf16(dev, K=1000, D=256, seed=51):
     close(cs, logits.sum(0), 1e-4, 1e-4, "column sums of zn @ w^T through the factors")
 
 
+def check_mlp_bwd_fused(dev, M, E, H, rps=128, seed=41):
+    """ccd_mlp_bwd_fused against autograd of the same chain in fp32 (on the bf16-rounded operands): du, the LayerNorm-2 backward on the
+    bf16 gradient stream (g, gb_out, dgamma, dbeta, dbias) and the fc1.bias gradient - and against the two launches it replaces
+    (gelu'(u) product + LayerNorm-backward product).  vision_transformer.py:59-65,110 in autograd order."""
+    g_ = torch.Generator().manual_seed(seed)
+    gb = rnd((M, E), g_, 0.5).to(BF)
+    w2 = rnd((E, H), g_, 0.06).to(BF)                 # fc2.weight [E, H]
+    w1 = rnd((H, E), g_, 0.08).to(BF)                 # fc1.weight [H, E]
+    u = rnd((M, H), g_, 1.5).to(BF)
+    u[0, :8] = torch.tensor([0.0, -0.0, 1e-3, -1e-3, 20.0, -20.0, 5.0, -5.0]).to(BF)      # table edges
+    x = rnd((M, E), g_); gamma = 1.0 + 0.2 * rnd((E,), g_)
+    g0 = rnd((M, E), g_).to(BF).float()
+    nsamp = (M + rps - 1) // rps
+    rowscale = (torch.rand(nsamp, generator=g_) > 0.3).float() * 1.25
+    mean = x.mean(1); rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-6)
+    # reference chain
+    dh = gb.float() @ w2.float()
+    uf = u.float().double().requires_grad_(True)
+    F.gelu(uf).sum().backward()
+    du_ref = (dh * uf.grad.float())
+    dy2 = du_ref.to(BF).float() @ w1.float()          # (the kernel feeds the bf16-rounded du to the second product)
+    xh = (x - mean[:, None]) * rstd[:, None]
+    dg = dy2 * gamma
+    dx = (dg - dg.mean(1, keepdim=True) - xh * (dg * xh).mean(1, keepdim=True)) * rstd[:, None]
+    g_ref = g0 + dx
+    rs_rows = rowscale.repeat_interleave(rps)[:M, None]
+    wt2 = w2.t().contiguous().to(dev)                 # fc2.weight^T [H, E]
+    wt1 = w1.t().contiguous().to(dev)                 # fc1.weight^T [E, H]
+    gdev = g0.to(BF).to(dev)
+    dgam, dbet = torch.zeros(E, device=dev), torch.zeros(E, device=dev)
+    dbias, db1 = torch.zeros(E, device=dev), torch.full((H,), 0.25, device=dev)
+    gb_out = torch.empty((M, E), dtype=BF, device=dev)
+    du = ops.mlp_bwd_fused(gb.to(dev), wt2, wt1, u.to(dev), db1=db1, x=x.to(dev), mean=mean.to(dev), rstd=rstd.to(dev),
+                           gamma=gamma.to(dev), g=gdev, dgamma=dgam, dbeta=dbet, gb_out=gb_out, rowscale=rowscale.to(dev),
+                           rows_per_sample=rps, dbias=dbias)
+    close(du, du_ref, 2e-2, 2e-2 * du_ref.abs().max().item(), "mlp_bwd/du")
+    close(gdev, g_ref, 2e-2, 2e-2 * dx.abs().max().item() + 2e-2, "mlp_bwd/g")
+    close(gb_out, g_ref * rs_rows, 2e-2, 2e-2 * g_ref.abs().max().item(), "mlp_bwd/gb_out")
+    tol = 4e-3 * M ** 0.5
+    close(dgam, (dy2 * xh).sum(0), 2e-2, tol * (dy2 * xh).abs().max().item(), "mlp_bwd/dgamma")
+    close(dbet, dy2.sum(0), 2e-2, tol * dy2.abs().max().item(), "mlp_bwd/dbeta")
+    close(dbias, gb_out.float().cpu().sum(0), 1e-3, 1e-3 * M ** 0.5 * gb_out.float().abs().max().item(), "mlp_bwd/dbias(proj)")
+    close(db1 - 0.25, du_ref.sum(0), 2e-2, tol * du_ref.abs().max().item(), "mlp_bwd/db1")
+    if H % (64 * (3 if E == 384 else 2)) != 0:         # (the row-owner LayerNorm-backward product takes K in whole rings of k-blocks)
+        return
+    # the two launches it replaces
+    g2 = g0.to(BF).to(dev)
+    dg2, db2, dbi2, db12 = torch.zeros(E, device=dev), torch.zeros(E, device=dev), torch.zeros(E, device=dev), torch.zeros(H, device=dev)
+    gact2 = torch.empty((M, H), dtype=BF, device=dev)
+    du2 = ops.gemm_nt(gb.to(dev), wt2, epilogue=ops.EPI_DGELU, aux=u.to(dev), out2=gact2, colsum=db12)
+    gb2 = torch.empty((M, E), dtype=BF, device=dev)
+    ops.gemm_nt_lnbwd(du2, wt1, x.to(dev), mean.to(dev), rstd.to(dev), gamma.to(dev), g2, dg2, db2, accumulate=True, gb=gb2,
+                      rowscale=rowscale.to(dev), rows_per_sample=rps, dbias=dbi2)
+    close(du, du2.float(), 2e-2, 1e-2 * du_ref.abs().max().item(), "mlp_bwd/du vs two-launch")
+    close(gdev, g2.float(), 2e-2, 1e-2 * dx.abs().max().item() + 2e-2, "mlp_bwd/g vs two-launch")
+
+
 def check_gemm_lnbwd(dev, M, N, K, seed=33, g16=False, tap=False):
     """Data-gradient product with the LayerNorm backward in its epilogue == gemm_nt followed by ln_bwd, and both == autograd.
     g16: the gradient stream g is a bf16 tensor (ccd_gemm_nt_lnbwd_g16) - read as bf16, accumulated in fp32, rounded once.

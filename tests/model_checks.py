@@ -424,6 +424,54 @@ def check_fold_tap_matches_separate(device, E=384, batch=4, drop_path=0.3):
     return report
 
 
+def check_mlp_bwd_fused_matches_two_launches(device, E=384, batch=4, depth=4, drop_path=0.3):
+    """The MLP branch's data-gradient chain in one launch (engine.Fusion.mlp_bwd: ccd_proj_mlp_fused_gact in the forward pass,
+    ccd_mlp_bwd_fused in the backward pass) against the gelu'(u) product + LayerNorm-backward product it replaces: the same losses
+    (the forward pass only stores one more tensor), every gradient tensor to the rounding of the bf16 operands."""
+    from ccd_amd import engine, ops
+    results = {}
+    saved = engine.Fusion.mlp_bwd
+    names = ["backbone.blocks.0.mlp.fc1.weight", "backbone.blocks.0.mlp.fc1.bias", "backbone.blocks.1.mlp.fc2.weight",
+             "backbone.blocks.1.norm2.weight", "backbone.blocks.1.norm2.bias", "backbone.blocks.0.attn.proj.bias",
+             "backbone.blocks.0.attn.qkv.weight", "backbone.patch_embed.proj.weight"]
+    launched = []
+    real = ops.mlp_bwd_fused
+    try:
+        ops.mlp_bwd_fused = lambda *a, **k: (launched.append(1), real(*a, **k))[1]
+        for fused in (False, True):
+            engine.Fusion.mlp_bwd = fused
+            torch.manual_seed(5)
+            np.random.seed(5)
+            engine._DROPPATH_SEED.update(base=91, calls=0)
+            student, teacher = pretrain.build_networks(
+                arch=None, out_dim=512, drop_path_rate=drop_path, norm_last_layer=False, seg_channel=E,
+                backbone_kwargs=dict(embed_dim=E, depth=depth, num_heads=E // 64, out_indices=[1, 2, depth]),
+                head_kwargs=dict(hidden_dim=256, bottleneck_dim=64), device=device)
+            assert engine.Fusion.resolve_mlp_bwd(E, 4 * E) == fused
+            dino_loss = DINOLoss(512, 2, 0.04, 0.04, 0, 40).to(device)
+            images, masks, metrics = make_batch(batch, seed=13, device=device)
+            opt = pretrain.make_optimizer(student, clip_grad=3.0)
+            n0 = len(launched)
+            loss = pretrain.training_iteration(student, teacher, dino_loss, opt, images, masks, metrics, 1, 2e-4, 0.05, 0.99)
+            if device.type == "cuda":
+                torch.cuda.synchronize()
+            assert len(launched) - n0 == (depth if fused else 0), "one ccd_mlp_bwd_fused launch per block"
+            results[fused] = (loss.item(), student.arena.grad.clone(), {n: student.arena.g(n).clone() for n in names})
+    finally:
+        ops.mlp_bwd_fused = real
+        engine.Fusion.mlp_bwd = saved
+        engine._DROPPATH_SEED.update(base=None, calls=0)
+    (l0, g0, t0), (l1, g1, t1) = results[False], results[True]
+    assert abs(l0 - l1) < 1e-5, (l0, l1)
+    report = {"loss": [l0, l1], "rel_grad_all": ((g1 - g0).double().norm() / g0.double().norm()).item()}
+    assert report["rel_grad_all"] < 1e-2, report
+    for n in names:
+        rel = ((t1[n] - t0[n]).double().norm() / t0[n].double().norm().clamp_min(1e-30)).item()
+        report["rel_" + n] = rel
+        assert rel < 1e-2, (n, rel)
+    return report
+
+
 def check_g_bf16_matches_fp32(device, E=128, batch=2, drop_path=0.3):
     """The backward pass with its residual-gradient stream as a bf16 tensor (engine.Fusion.g_bf16, ccd_*_g16) against the fp32
     stream: the forward pass and the losses are the same computation, every gradient tensor agrees to bf16 rounding of ONE stream

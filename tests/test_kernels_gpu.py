@@ -265,6 +265,41 @@ def test_gemm_lnbwd_with_tap(hip, M, K):
             kc.check_gemm_lnbwd(hip.device, M=M, N=384, K=K, seed=42, g16=True, tap=True)
 
 
+@pytest.mark.parametrize("M,E,H,rps", [(300, 384, 128, 8), (4096 + 72, 384, 1536, 256), (131072, 384, 1536, 256), (33000, 256, 1024, 256)])
+def test_mlp_bwd_fused(hip, M, E, H, rps):
+    """The MLP branch's data-gradient chain in one launch (mlp_bwd.h): gelu'(u) product, fc1 data gradient, LayerNorm-2 backward, du for
+    the weight gradients, fc1.bias column sums - ragged tiles, many tiles per workgroup, the benchmark shape."""
+    kc.check_mlp_bwd_fused(hip.device, M=M, E=E, H=H, rps=rps, seed=M % 11)
+
+
+def test_mlp_bwd_fused_repeatable(hip):
+    """Counted vmcnt + barriers order the weight ring; the u rows arrive through the same queue: 10 launches must agree bit for bit in
+    everything that is not an atomic sum (du, g, gb_out)."""
+    import torch
+    from ccd_amd import ops
+    g = torch.Generator().manual_seed(9)
+    M, E, H = 131072, 384, 1536
+    dev = hip.device
+    gb = kc.rnd((M, E), g, 0.5).to(kc.BF).to(dev); u = kc.rnd((M, H), g, 1.5).to(kc.BF).to(dev)
+    w2t = kc.rnd((H, E), g, 0.06).to(kc.BF).to(dev); w1t = kc.rnd((E, H), g, 0.08).to(kc.BF).to(dev)
+    x = kc.rnd((M, E), g).to(dev); gamma = torch.ones(E, device=dev)
+    mean = x.mean(1); rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-6)
+    g0 = kc.rnd((M, E), g).to(kc.BF).to(dev)
+    ref = None
+    for _ in range(10):
+        gg = g0.clone()
+        gbo = torch.empty((M, E), dtype=kc.BF, device=dev)
+        du = ops.mlp_bwd_fused(gb, w2t, w1t, u, db1=torch.zeros(H, device=dev), x=x, mean=mean, rstd=rstd, gamma=gamma, g=gg,
+                               dgamma=torch.zeros(E, device=dev), dbeta=torch.zeros(E, device=dev), gb_out=gbo, rowscale=None,
+                               rows_per_sample=256, dbias=torch.zeros(E, device=dev))
+        cur = (du.clone(), gg, gbo)
+        if ref is None:
+            ref = cur
+        else:
+            for a, b in zip(ref, cur):
+                assert torch.equal(a, b)
+
+
 def test_gemm_lnbwd_row384_kernel(hip):
     from ccd_amd import ops
     with ops.policy(rowgemm=0):

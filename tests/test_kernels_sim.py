@@ -193,6 +193,14 @@ def test_optimizer_sim(sim):
     kc.check_optimizer(sim.device)
 
 
+def test_mlp_bwd_fused_sim(sim, monkeypatch):
+    """mlp_bwd.h on the CPU executor: ragged tiles, several tiles per workgroup (the ring and the u images run across them), both widths."""
+    monkeypatch.setenv("CCD_SIM_CUS", "2")
+    kc.check_mlp_bwd_fused(sim.device, M=200, E=384, H=128, rps=8)
+    kc.check_mlp_bwd_fused(sim.device, M=128 * 4 + 40, E=256, H=256, rps=128, seed=5)      # 5 tiles on 2 workgroups
+    kc.check_mlp_bwd_fused(sim.device, M=128 * 3, E=384, H=384, rps=64, seed=6)            # 3 tiles: one workgroup walks two
+
+
 def test_conv_pieces_sim(sim):
     kc.check_conv_pieces(sim.device)
 

@@ -57,6 +57,14 @@ def test_fold_tap_matches_separate_launch(hip):
         json.dump(report, f)
 
 
+def test_mlp_bwd_fused_matches_two_launches(hip):
+    """ccd_proj_mlp_fused_gact + ccd_mlp_bwd_fused inside a training iteration against the gelu'(u) product + LayerNorm-backward product."""
+    report = mc.check_mlp_bwd_fused_matches_two_launches(hip.device, E=384, batch=4)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/mlp_bwd_fused_vs_two_launches.json", "w") as f:
+        json.dump(report, f)
+
+
 def test_g_bf16_matches_fp32(hip):
     report = mc.check_g_bf16_matches_fp32(hip.device, E=384, batch=8)
     os.makedirs("gpurun_out", exist_ok=True)

@@ -35,6 +35,12 @@ def test_g_bf16_matches_fp32_sim(sim):
     mc.check_g_bf16_matches_fp32(sim.device, E=128, batch=2)
 
 
+def test_mlp_bwd_fused_matches_two_launches_sim(sim, monkeypatch):
+    """The one-launch MLP backward (mlp_bwd.h) and the gelu(u)-storing forward block half inside a training iteration, CPU executor."""
+    monkeypatch.setenv("CCD_SIM_CUS", "4")
+    mc.check_mlp_bwd_fused_matches_two_launches(sim.device, E=256, batch=2, depth=3)
+
+
 def test_no_grad_train_droppath_sim(sim):
     """train() + no_grad + drop_path > 0: blocks with a DropPath mask fall back from ccd_proj_mlp_fused."""
     mc.check_no_grad_train_droppath(sim.device, E=128, views=2)
