@@ -10,6 +10,8 @@ namespace ccd {
 constexpr int PE_PATCH = 4, PE_K = 48, PE_GW = 32, PE_GH = 8;   // 32x128 image -> 8 x 32 tokens
 
 // one workgroup = one row of 32 patches of one view; thread e keeps W[e, 0:48] in registers
+// (round 6, measured and not kept - profiles/r06_patch_embed_lab.jsonl: the pixels by scalar loads, s_load_dwordx16 per four tokens and no
+// LDS: 136 us against 113; three columns per thread, so that a token's 12 broadcast LDS reads feed 144 fused multiply-adds: 122 against 123)
 __global__ __launch_bounds__(128) void patch_embed_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ pos, float* __restrict__ out,
@@ -137,8 +139,24 @@ __global__ void small_matmul_f32_kernel(const float* __restrict__ a, const float
                                         int M, int N, int K, int trans_a, int accumulate) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
     if (n >= N) return;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;   // four independent chains: the loop is latency-bound
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;   // four independent chains (k mod 4), each in increasing k
     int k = 0;
+    // 32 k-steps of loads in flight per thread: with 4 the loop waited ~0.6 us of L2 latency 64 times (39 us for the 256 x 256 x 384
+    // positional resample, three launches per step); same chains, same order, same bits
+    for (; k + 31 < K; k += 32) {
+        float av[32], bv[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) av[u] = trans_a ? a[(long)(k + u) * M + m] : a[(long)m * K + k + u];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) bv[u] = b[(long)(k + u) * N + n];
+#pragma unroll
+        for (int u = 0; u < 32; u += 4) {
+            acc0 += av[u] * bv[u];
+            acc1 += av[u + 1] * bv[u + 1];
+            acc2 += av[u + 2] * bv[u + 2];
+            acc3 += av[u + 3] * bv[u + 3];
+        }
+    }
     for (; k + 3 < K; k += 4) {
         const float a0 = trans_a ? a[(long)k * M + m] : a[(long)m * K + k];
         const float a1 = trans_a ? a[(long)(k + 1) * M + m] : a[(long)m * K + k + 1];
