@@ -33,21 +33,22 @@ __device__ __forceinline__ void att_stage_rows(const bf16_t* __restrict__ src, l
     }
 }
 // transposed image: [64 d][256 keys] with keys permuted inside 16-groups, 512-B rows, slot XOR (d & 15)
-__device__ __forceinline__ void att_stage_transposed(const bf16_t* __restrict__ src, long row_stride, char* img) {
+// a thread's source rows: keys 4 kb .. 4 kb + 3 (kb = 16 w + (lane & 15)), d blocks (lane >> 4) and (lane >> 4) + 4
+__device__ __forceinline__ const bf16_t* att_transposed_src(const bf16_t* __restrict__ src, long row_stride, int i, int kq) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    return src + (long)(4 * (16 * w + (lane & 15)) + kq) * row_stride + ((lane >> 4) + 4 * i) * 8;
+}
+__device__ __forceinline__ void att_write_transposed(const u32x4 (&r)[2][4], char* img) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int kb = 16 * w + (lane & 15);                  // 4-key block, keys 4*kb .. 4*kb+3
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int db = (lane >> 4) + 4 * i;               // 8-wide d block
-        u32x4 r[4];
-#pragma unroll
-        for (int kq = 0; kq < 4; ++kq)
-            r[kq] = *reinterpret_cast<const u32x4*>(src + (long)(4 * kb + kq) * row_stride + db * 8);
         const int chunk = 4 * (kb >> 2) + att_chunk_pos(kb & 3);   // 8-byte chunk index inside the 512-B row
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int d = 8 * db + j;
-            const unsigned w0 = r[0][j >> 1], w1 = r[1][j >> 1], w2 = r[2][j >> 1], w3 = r[3][j >> 1];
+            const unsigned w0 = r[i][0][j >> 1], w1 = r[i][1][j >> 1], w2 = r[i][2][j >> 1], w3 = r[i][3][j >> 1];
             u32x2 o;
             o.x = perm_b32(w1, w0, (j & 1) ? 0x07060302u : 0x05040100u);
             o.y = perm_b32(w3, w2, (j & 1) ? 0x07060302u : 0x05040100u);
@@ -55,6 +56,14 @@ __device__ __forceinline__ void att_stage_transposed(const bf16_t* __restrict__ 
             *reinterpret_cast<u32x2*>(img + d * 512 + slot * 16 + (chunk & 1) * 8) = o;
         }
     }
+}
+__device__ __forceinline__ void att_stage_transposed(const bf16_t* __restrict__ src, long row_stride, char* img) {
+    u32x4 r[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) r[i][kq] = *reinterpret_cast<const u32x4*>(att_transposed_src(src, row_stride, i, kq));
+    att_write_transposed(r, img);
 }
 
 // A lane's 16 + 16 values of its output row (columns 8 g + 4 hf .. + 3 of each 32-column tile of the transposed product) as
@@ -102,8 +111,34 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const bf16_t* __r
     const bf16_t* k_base = q_base + E;
     const bf16_t* v_base = q_base + 2 * E;
 
+    // the wave's two query tiles are requested FIRST, in front of the 16 staging loads: a workgroup is a chain of HBM round trips
+    // (K / V, then q, then q again) with ~2 us of products behind each, and two workgroups per CU is all the overlap there is - loaded
+    // where they were used, each query tile's round trip stood in the open
+    // (hand-issued - global_load16_late: left to the compiler the eight loads sink behind the staging writes, next to their first use)
+    buf_u32x4 qf2[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            qf2[qt][kk] = buf_u32x4{0u, 0u, 0u, 0u};
+            global_load16_late(qf2[qt][kk], q_base + (long)(64 * w + 32 * qt + lq) * row_stride + 16 * kk + 8 * hf);
+        }
+    // ... and the V rows too: all 24 requests of a thread are out before its first wait (the K rows' writes)
+    u32x4 vr[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            vr[i][kq] = u32x4{0u, 0u, 0u, 0u};
+            global_load16_late(vr[i][kq], att_transposed_src(v_base, row_stride, i, kq));
+        }
     att_stage_rows(k_base, row_stride, k_img);
-    att_stage_transposed(v_base, row_stride, vt_img);
+    glds_wait_all();                       // (the hand-issued requests are older than the K rows': long there)
+    vm_landed4(qf2[0]);
+    vm_landed4(qf2[1]);
+    vm_landed4(vr[0]);
+    vm_landed4(vr[1]);
+    att_write_transposed(vr, vt_img);
     __syncthreads();
     const unsigned k_addr = lds_addr_of(k_img), vt_addr = lds_addr_of(vt_img);
 
@@ -112,8 +147,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const bf16_t* __r
         const int q = 64 * w + 32 * qt + lq;
         bf16x8 qf[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-            qf[kk] = *reinterpret_cast<const bf16x8*>(q_base + (long)q * row_stride + 16 * kk + 8 * hf);
+        for (int kk = 0; kk < 4; ++kk) qf[kk] = __builtin_bit_cast(bf16x8, qt ? qf2[1][kk] : qf2[0][kk]);
 
         // Two key chunks of 128 with a running (max, sum): half the score registers of a single pass - the one-pass
         // version needed all 512 registers (and spilled), i.e. ONE workgroup per CU.
