@@ -314,7 +314,20 @@ __global__ __launch_bounds__(256) void head_loss_finish_kernel(const float* __re
         const float* o = part + (long)row * 8;
         const f32x4v v0 = *reinterpret_cast<const f32x4v*>(o);
         st.ms = v0.x; st.ls = v0.y; st.mt = v0.z; st.lt = v0.w; st.dot = o[4];
-        for (int cs = 1; cs < CS; ++cs) {
+        int cs = 1;
+        for (; cs + 7 < CS; cs += 8) {         // (eight splits' partials in flight: one per trip was a chain of CS L2 round trips, 28 us)
+            f32x4v v[8];
+            float d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float* oc = part + ((long)(cs + u) * max_rows + row) * 8;
+                v[u] = *reinterpret_cast<const f32x4v*>(oc);
+                d[u] = oc[4];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) hl_merge(st, v[u].x, v[u].y, v[u].z, v[u].w, d[u]);
+        }
+        for (; cs < CS; ++cs) {
             const float* oc = part + ((long)cs * max_rows + row) * 8;
             const f32x4v v = *reinterpret_cast<const f32x4v*>(oc);
             hl_merge(st, v.x, v.y, v.z, v.w, oc[4]);
