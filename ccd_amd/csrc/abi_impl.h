@@ -789,15 +789,8 @@ int ccd_attention_fwd(const ccd_bf16* qkv, ccd_bf16* out, float* lse, int views,
     // (Round 4 measured the forward with its K / V images written by LDS-DMA and the V^T fragments read by ds_read_b64_tr_b16 - no
     // register transposition, 158 instead of 225 registers: 0.1039 against 0.1027 ms per layer.  With two workgroups per CU one's
     // staging already hides under the other's products; removed again, profiles/r04_attn_onepass_lab.jsonl.)
-#ifdef CCD_ATT_PERSIST
-    {
-        const int nb = views * heads, slots = 2 * ccd_grid_cus();
-        CCD_LAUNCH((ccd::attention_fwd_kernel<true>), dim3(nb < slots ? nb : slots), dim3(256), ccd::ATT_SMEM_BYTES, stream, qkv, out, lse, heads, scale, nb);
-        return ccd_rt_last_error();
-    }
-#endif
-    CCD_LAUNCH((ccd::attention_fwd_kernel<false>), dim3(views * heads), dim3(256), ccd::ATT_SMEM_BYTES, stream, qkv, out, lse,
-               heads, scale, views * heads);
+    CCD_LAUNCH(ccd::attention_fwd_kernel, dim3(views * heads), dim3(256), ccd::ATT_SMEM_BYTES, stream, qkv, out, lse,
+               heads, scale);
     return ccd_rt_last_error();
 }
 

@@ -98,84 +98,56 @@ struct AttMapPV {          // step k = 4 kt + 2 s2 + dt: address register 2 kt +
     static constexpr int off(int k) { return (k & 1) * 16384; }
 };
 
-// PERSIST (lab): the workgroup walks blocks b, b + gridDim.x, ...; the NEXT block's K and V rows are requested (by hand, into registers that
-// stay live) right behind the barrier that publishes this block's images, its query tiles behind this block's last score product - a
-// block's round trip runs under the previous block's products of the SAME workgroup, not only under the other workgroup's.
-template <bool PERSIST>
 __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                            float* __restrict__ lse, int heads, float scale, int nblocks) {
+                                                            float* __restrict__ lse, int heads, float scale) {
     char* smem = dynamic_smem();
     char* k_img = smem;
     char* vt_img = smem + ATT_T * ATT_D * 2;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hf = lane >> 5, lq = lane & 31;
+    const int view = blockIdx.x / heads, head = blockIdx.x % heads;
     const int E = heads * ATT_D;
     const long row_stride = 3L * E;
+    const bf16_t* q_base = qkv + (long)view * ATT_T * row_stride + head * ATT_D;
+    const bf16_t* k_base = q_base + E;
+    const bf16_t* v_base = q_base + 2 * E;
+
+    // the wave's two query tiles are requested FIRST, in front of the 16 staging loads: a workgroup is a chain of HBM round trips
+    // (K / V, then q, then q again) with ~2 us of products behind each, and two workgroups per CU is all the overlap there is - loaded
+    // where they were used, each query tile's round trip stood in the open
+    // (hand-issued - global_load16_late: left to the compiler the eight loads sink behind the staging writes, next to their first use)
     buf_u32x4 qf2[2][4];
-    u32x4 vr[2][4], kr[8];
-    auto q_of = [&](int b) { return qkv + (long)(b / heads) * ATT_T * row_stride + (b % heads) * ATT_D; };
-    auto request_q = [&](int b) __attribute__((always_inline)) {
-        const bf16_t* q_base = q_of(b);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                global_load16_late(qf2[qt][kk], q_base + (long)(64 * w + 32 * qt + lq) * row_stride + 16 * kk + 8 * hf);
-    };
-    auto request_kv = [&](int b) __attribute__((always_inline)) {
-        const bf16_t* k_base = q_of(b) + E;
-        const bf16_t* v_base = k_base + E;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq) global_load16_late(vr[i][kq], att_transposed_src(v_base, row_stride, i, kq));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int id = threadIdx.x + 256 * i, row = id >> 3, slot = id & 7;
-            global_load16_late(kr[i], k_base + (long)row * row_stride + slot * 8);
+        for (int kk = 0; kk < 4; ++kk) {
+            qf2[qt][kk] = buf_u32x4{0u, 0u, 0u, 0u};
+            global_load16_late(qf2[qt][kk], q_base + (long)(64 * w + 32 * qt + lq) * row_stride + 16 * kk + 8 * hf);
         }
-    };
+    // ... and the V rows too: all 24 requests of a thread are out before its first wait (the K rows' writes)
+    u32x4 vr[2][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        kr[i] = u32x4{0u, 0u, 0u, 0u};
-        vr[i >> 2][i & 3] = u32x4{0u, 0u, 0u, 0u};
-        qf2[i >> 2][i & 3] = buf_u32x4{0u, 0u, 0u, 0u};
-    }
-    int blk = blockIdx.x;
-    // every request of the first block in front of the first wait (the query tiles first: they are consumed last)
-    request_q(blk);
-    request_kv(blk);
-    const unsigned k_addr = lds_addr_of(k_img), vt_addr = lds_addr_of(vt_img);
-#pragma unroll 1
-    for (; blk < nblocks; blk += PERSIST ? (int)gridDim.x : nblocks) {
-    const int view = blk / heads, head = blk % heads;
-    glds_wait_all();
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            vr[i][kq] = u32x4{0u, 0u, 0u, 0u};
+            global_load16_late(vr[i][kq], att_transposed_src(v_base, row_stride, i, kq));
+        }
+    att_stage_rows(k_base, row_stride, k_img);
+    glds_wait_all();                       // (the hand-issued requests are older than the K rows': long there)
     vm_landed4(qf2[0]);
     vm_landed4(qf2[1]);
     vm_landed4(vr[0]);
     vm_landed4(vr[1]);
-    {
-        u32x4 (&k0)[4] = *reinterpret_cast<u32x4 (*)[4]>(&kr[0]);
-        u32x4 (&k1)[4] = *reinterpret_cast<u32x4 (*)[4]>(&kr[4]);
-        vm_landed4(k0);
-        vm_landed4(k1);
-    }
-    if (PERSIST) __syncthreads();          // the previous block's readers are done with the images
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int id = threadIdx.x + 256 * i, row = id >> 3, slot = id & 7;
-        *reinterpret_cast<u32x4*>(k_img + row * 128 + ((slot ^ ((row >> 1) & 7)) * 16)) = kr[i];
-    }
     att_write_transposed(vr, vt_img);
     __syncthreads();
-    const int nxt = blk + (int)gridDim.x;
-    if (PERSIST && nxt < nblocks) request_kv(nxt);
+    const unsigned k_addr = lds_addr_of(k_img), vt_addr = lds_addr_of(vt_img);
 
-    auto query_tile = [&](auto QT) __attribute__((always_inline)) {
-        constexpr int qt = decltype(QT)::value;
+#pragma unroll 1
+    for (int qt = 0; qt < 2; ++qt) {
         const int q = 64 * w + 32 * qt + lq;
         bf16x8 qf[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) qf[kk] = __builtin_bit_cast(bf16x8, qf2[qt][kk]);
+        for (int kk = 0; kk < 4; ++kk) qf[kk] = __builtin_bit_cast(bf16x8, qt ? qf2[1][kk] : qf2[0][kk]);
 
         // Two key chunks of 128 with a running (max, sum): half the score registers of a single pass - the one-pass
         // version needed all 512 registers (and spilled), i.e. ONE workgroup per CU.
@@ -258,10 +230,6 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const bf16_t* __r
         bf16_t* orow = out + ((long)view * ATT_T + q) * E + head * ATT_D;
         att_store_row16(orow, o, hf, inv);
         if (hf == 0) lse[((long)view * heads + head) * ATT_T + q] = mx * scale + logf(sum);
-    };
-    query_tile(std::integral_constant<int, 0>{});
-    query_tile(std::integral_constant<int, 1>{});
-    if (PERSIST && nxt < nblocks) request_q(nxt);          // (behind the last use of this block's query tiles)
     }
 }
 
